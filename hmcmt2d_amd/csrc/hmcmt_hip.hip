@@ -1,0 +1,975 @@
+// libhmcmt_hip.so -- gfx950 (MI355X) implementation of the HMCMT2D hot path behind include/hmcmt.h.
+//
+// Structure:
+//   * "item" kernels: one thread per node / cell / receiver / boundary column, bodies in
+//     hmcmt_items.h (assembly from sigma, 1-D boundary fields, receiver functionals, adjoint
+//     sources, J^T accumulation).
+//   * batched COCG over all S = 2*nFreq complex-symmetric 5-point systems at once, with
+//       - stencil SpMV on the padded nodal grid (real K shared by all frequencies of a mode,
+//         i*omega*D formed on the fly),
+//       - fast-diagonalisation preconditioner: two FP64-MFMA transforms with the mesh's y-eigenbasis
+//         (v_mfma_f64_16x16x4_f64) around a batched tridiagonal solve in z,
+//       - deterministic two-stage reductions (wave shuffles + fixed partial arrays).
+//   * no host compute path: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/hmcmt.h"
+#include "hmcmt_host.h"
+#include "hmcmt_items.h"
+
+using namespace hmcmt;
+
+namespace {
+
+constexpr int MAXNB = 32;          // max partial-sum blocks per system
+constexpr int VBLOCK = 256;        // threads of the vector kernels
+
+// ----------------------------------------------------------------------------------------------
+// solver state shared by the COCG kernels
+// ----------------------------------------------------------------------------------------------
+struct Solver {
+    int S, NB, NYP, NZP, ny, nz, nFreq;
+    long vstride, chunk;
+    const double* omega;
+    const double *cY, *cZ, *dK, *dM;      // [2][vstride]
+    const double* ofz;                    // [2][NZP]
+    const cplx* invp;                     // [S][vstride]
+    cplx *x, *r, *p, *q, *z, *y;          // [S][vstride]
+    cplx *partA;                          // [S][MAXNB]  p'q   | r'z
+    double *partB;                        // [S][MAXNB]  |x|^2 | |z|^2
+    cplx *rho, *alphaBeta;                // [S]
+    int *active, *iters, *status, *nactive;
+    double *errEst;                       // [S] (zz/xx)
+    double tol2;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// block-wide deterministic sum of up to 2 doubles; result valid in thread 0
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh /* [2*4] */) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) { sh[w] = a; sh[4 + w] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        double sa = 0, sb = 0;
+        for (int i = 0; i < nw; ++i) { sa += sh[i]; sb += sh[4 + i]; }
+        a = sa; b = sb;
+    }
+}
+
+__device__ __forceinline__ cplx sum_partA(const Solver& k, int s) {
+    cplx t = cplx{0, 0};
+    for (int b = 0; b < k.NB; ++b) t += k.partA[(long)s * MAXNB + b];
+    return t;
+}
+
+// q = A p (interior nodes), partA = p'q (unconjugated)
+__global__ __launch_bounds__(VBLOCK) void k_spmv(Solver k) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    __shared__ double sh[8];
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx* p = k.p + so;
+    cplx* q = k.q + so;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    double ar = 0, ai = 0;
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+            const cplx c = p[e];
+            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+            acc += k.cY[mo + e] * p[e + 1];
+            acc += k.cY[mo + e - 1] * p[e - 1];
+            acc += k.cZ[mo + e] * p[e + k.NYP];
+            acc += k.cZ[mo + e - k.NYP] * p[e - k.NYP];
+            q[e] = acc;
+            ar += c.re * acc.re - c.im * acc.im;
+            ai += c.re * acc.im + c.im * acc.re;
+        }
+    }
+    block_sum2(ar, ai, sh);
+    if (threadIdx.x == 0) k.partA[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
+}
+
+// alpha = rho / p'q ; x += alpha p ; r -= alpha q ; partB = |x|^2 over interior nodes
+__global__ __launch_bounds__(VBLOCK) void k_update(Solver k) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    __shared__ double sh[8];
+    const long so = (long)s * k.vstride;
+    const cplx al = k.rho[s] / sum_partA(k, s);
+    const cplx *p = k.p + so, *q = k.q + so;
+    cplx *x = k.x + so, *r = k.r + so;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    double xx = 0, dummy = 0;
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+            cplx xv = x[e] + al * p[e];
+            x[e] = xv;
+            r[e] -= al * q[e];
+            xx += cabs2(xv);
+        }
+    }
+    block_sum2(xx, dummy, sh);
+    if (threadIdx.x == 0) {
+        k.partB[(long)s * MAXNB + blockIdx.x] = xx;
+        if (blockIdx.x == 0) k.alphaBeta[s] = al;
+    }
+}
+
+// partA = r'z (unconjugated), partB2 = |z|^2
+__global__ __launch_bounds__(VBLOCK) void k_dots(Solver k, double* partZZ) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    __shared__ double sh[8];
+    __shared__ double sh2[8];
+    const long so = (long)s * k.vstride;
+    const cplx *r = k.r + so, *z = k.z + so;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    double ar = 0, ai = 0, zz = 0, dummy = 0;
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const cplx a = r[e], b = z[e];
+        ar += a.re * b.re - a.im * b.im;
+        ai += a.re * b.im + a.im * b.re;
+        zz += cabs2(b);
+    }
+    block_sum2(ar, ai, sh);
+    block_sum2(zz, dummy, sh2);
+    if (threadIdx.x == 0) {
+        k.partA[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
+        partZZ[(long)s * MAXNB + blockIdx.x] = zz;
+    }
+}
+
+// per-system scalar bookkeeping: convergence test on the error estimate ||z|| <= tol ||x||,
+// beta = rho_new / rho_old.  first != 0: initialise (rho = r'z, beta = 0).
+__global__ void k_check(Solver k, const double* partZZ, int first, int maxit) {
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (int s = threadIdx.x; s < k.S; s += blockDim.x) {
+        if (!k.active[s]) continue;
+        cplx rz = cplx{0, 0};
+        double zz = 0, xx = 0;
+        for (int b = 0; b < k.NB; ++b) {
+            rz += k.partA[(long)s * MAXNB + b];
+            zz += partZZ[(long)s * MAXNB + b];
+            if (!first) xx += k.partB[(long)s * MAXNB + b];
+        }
+        bool on = true;
+        if (first) {
+            k.rho[s] = rz;
+            k.alphaBeta[s] = cplx{0, 0};
+            k.errEst[s] = 1.0;
+            if (zz == 0.0) { on = false; k.errEst[s] = 0.0; }          // zero right-hand side
+        } else {
+            k.iters[s] += 1;
+            k.errEst[s] = sqrt(zz / xx);
+            if (zz <= k.tol2 * xx) on = false;
+            else {
+                k.alphaBeta[s] = rz / k.rho[s];
+                k.rho[s] = rz;
+                if (k.iters[s] >= maxit) { on = false; k.status[s] = HMCMT_ENOCONV; }
+            }
+        }
+        if (!(isfinite(rz.re) && isfinite(rz.im) && isfinite(zz) && isfinite(xx))) {
+            on = false; k.status[s] = HMCMT_EBREAKDOWN;
+        }
+        if (!on) k.active[s] = 0;
+        else atomicAdd(&cnt, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *k.nactive = cnt;
+}
+
+// p = z + beta p   (first: p = z)
+__global__ __launch_bounds__(VBLOCK) void k_pupdate(Solver k, int first) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    const long so = (long)s * k.vstride;
+    const cplx be = k.alphaBeta[s];
+    const cplx* z = k.z + so;
+    cplx* p = k.p + so;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) p[e] = first ? z[e] : z[e] + be * p[e];
+}
+
+// z = r / diag(A)  (Jacobi)
+__global__ __launch_bounds__(VBLOCK) void k_jacobi(Solver k) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        cplx zv = cplx{0, 0};
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1)
+            zv = k.r[so + e] / cplx{k.dK[mo + e], w * k.dM[mo + e]};
+        k.z[so + e] = zv;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// FDM transform: C[m][n] = sum_k A[m][k] * B[k][n],  A, C complex [M][NYP], B real [NYP][NYP].
+// One workgroup = 8 complex rows; the 16-row MFMA tile stacks their real parts (rows 0-7) and
+// imaginary parts (rows 8-15).  Wave w owns n-tiles [w*NTW, (w+1)*NTW).
+// v_mfma_f64_16x16x4_f64 operand layout: A[i = lane%16][k = lane/16], B[k = lane/16][j = lane%16],
+// D[i = 4*r + lane/16][j = lane%16], r = 0..3 (f64 differs from the f32 MFMA layout).
+// ----------------------------------------------------------------------------------------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <int NTW>
+__global__ __launch_bounds__(256) void k_transform(const cplx* __restrict__ A, const double* __restrict__ B,
+                                                    cplx* __restrict__ C, int M, int NYP, int rowsPerSys,
+                                                    const int* __restrict__ active) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 8;
+    if (active) {
+        const int s0 = m0 / rowsPerSys, s1 = min(m0 + 7, M - 1) / rowsPerSys;
+        if (!active[s0] && !active[s1]) return;
+    }
+    const int NT = NYP >> 4;
+    const int t0 = wave * NTW;
+    if (t0 >= NT) return;
+    const int ntl = min(NTW, NT - t0);
+    const int li = lane & 15, lk = lane >> 4;
+    const int arow = m0 + (li & 7);
+    const bool rowok = arow < M;
+    const double* Ap = reinterpret_cast<const double*>(A + (long)(rowok ? arow : 0) * NYP + lk) + (li >> 3);
+    const double* Bp = B + (long)lk * NYP + t0 * 16 + li;
+    d4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = d4{0, 0, 0, 0};
+    const int KS = NYP >> 2;
+#pragma unroll 2
+    for (int ks = 0; ks < KS; ++ks) {
+        double a = rowok ? Ap[(long)ks * 8] : 0.0;      // 4 complex = 8 doubles per k-step
+        const double* bp = Bp + (long)ks * 4 * NYP;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            if (t < ntl) {
+                double b = bp[t * 16];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // D[i = 4*r + lk][j = li] (measured, scripts/probe/mfma_f64_layout.hip): with the stacked tile
+    // r = 0,1 are the real parts of complex rows lk, 4+lk and r = 2,3 their imaginary parts, so every
+    // lane owns two complete complex results and 16 lanes write 256 contiguous bytes.
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        if (t < ntl) {
+            const long col = (long)(t0 + t) * 16 + li;
+            if (m0 + lk < M) C[(long)(m0 + lk) * NYP + col] = cplx{acc[t][0], acc[t][2]};
+            if (m0 + 4 + lk < M) C[(long)(m0 + 4 + lk) * NYP + col] = cplx{acc[t][1], acc[t][3]};
+        }
+    }
+}
+
+// batched tridiagonal solve in z for every (system, eigenmode j): Thomas with precomputed
+// inverse pivots; in place on y[s][iz][j].
+__global__ __launch_bounds__(64) void k_thomas(Solver k) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= k.ny - 1) return;
+    const int mode = s >= k.nFreq;
+    const double* of = k.ofz + (long)mode * k.NZP;
+    const cplx* ip = k.invp + (long)s * k.vstride + j;
+    cplx* y = k.y + (long)s * k.vstride + j;
+    const int nz = k.nz, NYP = k.NYP;
+    cplx prev = cplx{0, 0};
+    for (int iz = 1; iz <= nz - 1; ++iz) {
+        cplx v = y[(long)iz * NYP];
+        if (iz > 1) v -= of[iz - 1] * prev;
+        prev = v * ip[(long)iz * NYP];
+        y[(long)iz * NYP] = prev;
+    }
+    for (int iz = nz - 2; iz >= 1; --iz) {
+        cplx v = y[(long)iz * NYP] - (of[iz] * ip[(long)iz * NYP]) * prev;
+        y[(long)iz * NYP] = v;
+        prev = v;
+    }
+}
+
+// true residual norm check: partB = |b - A x|^2 with b passed separately (verify option)
+__global__ __launch_bounds__(VBLOCK) void k_trueres(Solver k, const cplx* b, const cplx* x, double* partRes, double* partBn) {
+    const int s = blockIdx.y;
+    __shared__ double sh[8];
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx* p = x + so;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    double rr = 0, bb = 0;
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+            const cplx c = p[e];
+            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+            acc += k.cY[mo + e] * p[e + 1];
+            acc += k.cY[mo + e - 1] * p[e - 1];
+            acc += k.cZ[mo + e] * p[e + k.NYP];
+            acc += k.cZ[mo + e - k.NYP] * p[e - k.NYP];
+            // boundary entries of x hold Dirichlet values: they belong to the right-hand side
+            rr += cabs2(b[so + e] - acc);
+            bb += cabs2(b[so + e]);
+        }
+    }
+    block_sum2(rr, bb, sh);
+    if (threadIdx.x == 0) { partRes[(long)s * MAXNB + blockIdx.x] = rr; partBn[(long)s * MAXNB + blockIdx.x] = bb; }
+}
+
+// ----------------------------------------------------------------------------------------------
+// item kernels
+// ----------------------------------------------------------------------------------------------
+#define TID1 (blockIdx.x * blockDim.x + threadIdx.x)
+
+__global__ void k_sigma(View v) { int c = TID1; if (c < v.nCell) item_sigma(v, c); }
+__global__ void k_rowmean(View v) { int kz = TID1; if (kz < v.nz) item_rowmean(v, kz); }
+__global__ void k_coef(View v, int te_doK, int te_doM, int tm_doK, int tm_doM) {
+    int e = TID1;
+    if (e >= v.NZP * (v.ny + 1)) return;
+    int iz = e / (v.ny + 1), iy = e % (v.ny + 1);
+    if (te_doK || te_doM) item_coef(v, 0, iy, iz, te_doK, te_doM);
+    if (tm_doK || tm_doM) item_coef(v, 1, iy, iz, tm_doK, tm_doM);
+}
+__global__ void k_fdm_z(View v) { int e = TID1; if (e < 2 * v.NZP) item_fdm_z(v, e / v.NZP, e % v.NZP); }
+__global__ void k_pivot(View v) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (j < v.ny - 1) item_pivot(v, s, j);
+}
+__global__ void k_bc_forward(View v) {
+    int col = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (col <= v.ny) item_bc_forward(v, s, col);
+}
+__global__ void k_rhs(View v) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (e >= v.NZP * (v.ny + 1)) return;
+    item_rhs(v, s, e % (v.ny + 1), e / (v.ny + 1));
+}
+__global__ void k_rx(View v, int wantDeriv) {
+    int e = TID1;
+    if (e < v.S * v.nRx) item_rx(v, e / v.nRx, e % v.nRx, wantDeriv != 0);
+}
+__global__ void k_resid(View v) { int p = TID1; if (p < v.nData) item_resid(v, p); }
+__global__ void k_misfit(View v, double* out) {
+    __shared__ double sh[8];
+    double a = 0, b = 0;
+    for (int p = threadIdx.x; p < v.nData; p += blockDim.x) a += v.misfitPart[p];
+    block_sum2(a, b, sh);
+    if (threadIdx.x == 0) *out = a;
+}
+__global__ void k_rxcoef(View v) { int e = TID1; if (e < v.S * v.nRx) item_rxcoef(v, e / v.nRx, e % v.nRx); }
+__global__ void k_src(View v) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (e >= 2 * (v.ny + 1)) return;
+    item_src(v, s, e / (v.ny + 1), e % (v.ny + 1));
+}
+__global__ void k_wb(View v) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (e < v.nz) item_wside(v, s, e + 1);
+    else if (e < v.nz + v.ny) item_colw(v, s, e - v.nz);
+}
+__global__ void k_bcsens(View v) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
+    if (c < v.nz) item_bcsens(v, s, prof, c);
+}
+__global__ void k_gradcell(View v) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x, mode = blockIdx.y;
+    if (c < v.nCell) item_gradcell(v, mode, c);
+}
+__global__ void k_gradfinal(View v) { int a = TID1; if (a < v.nAC) item_gradfinal(v, a); }
+
+// copy padded nodal layout -> reference layout [(ny+1)*(nz+1)] per frequency
+__global__ void k_unpad(View v, const cplx* src, cplx* dst, int s0) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    const int nn = (v.ny + 1) * (v.nz + 1);
+    if (e >= nn) return;
+    int iz = e / (v.ny + 1), iy = e % (v.ny + 1);
+    dst[(long)f * nn + e] = src[(long)(s0 + f) * v.vstride + nidx(v, iy, iz)];
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------
+// context
+// ----------------------------------------------------------------------------------------------
+struct hmcmt_ctx {
+    HostProblem hp;
+    View v{};
+    Solver sv{};
+    hmcmt_options opt{};
+    hmcmt_stats stats{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+    std::string err;
+    // device scalars / buffers not in View
+    double *d_m = nullptr, *d_V = nullptr, *d_Vt = nullptr, *d_partZZ = nullptr, *d_misfit = nullptr;
+    double *d_partRes = nullptr, *d_partBn = nullptr;
+    cplx* d_b = nullptr;                  // copy of the right-hand side (verify)
+    cplx* d_fieldsOut = nullptr;
+    // pinned host staging
+    int* h_nactive = nullptr;
+    int* h_iters = nullptr;
+    int* h_status = nullptr;
+    double* h_err = nullptr;
+    double* h_stage = nullptr;            // m / grad / pred / misfit staging
+    size_t stageDoubles = 0;
+    std::vector<int> itersLast;           // [2*S]
+    int lastItFwd = 0, lastItAdj = 0;
+    bool haveModel = false;
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> evPool;
+    std::vector<int> evCat;
+    size_t evUsed = 0;
+    double profMs[HMCMT_NCAT] = {0};
+    long long profN[HMCMT_NCAT] = {0};
+    // leapfrog / prior
+    double *d_mref = nullptr, *d_invM = nullptr, *d_wmVal = nullptr, *d_p = nullptr, *d_mcur = nullptr, *d_g = nullptr;
+    long long *d_wmRow = nullptr, *d_wmCol = nullptr;
+    double *d_lfPart = nullptr, *d_lfScal = nullptr;
+    int* d_lfFlag = nullptr;
+    bool havePrior = false;
+};
+
+static std::string g_createError;
+
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+            return (e_ == hipErrorOutOfMemory) ? HMCMT_ENOMEM : HMCMT_EHIP;                            \
+        }                                                                                              \
+    } while (0)
+
+namespace {
+
+template <class T>
+int dalloc(hmcmt_ctx* ctx, T** p, size_t n, bool zero = true) {
+    void* q = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIPCHK(hipMalloc(&q, bytes));
+    ctx->allocs.push_back(q);
+    if (zero) HIPCHK(hipMemsetAsync(q, 0, bytes, ctx->stream));
+    *p = (T*)q;
+    return 0;
+}
+template <class T>
+int dupload(hmcmt_ctx* ctx, T** p, const std::vector<T>& h) {
+    int rc = dalloc(ctx, p, h.size(), false);
+    if (rc) return rc;
+    if (!h.empty()) HIPCHK(hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+struct ProfScope {
+    hmcmt_ctx* c; int cat; size_t idx;
+    ProfScope(hmcmt_ctx* ctx, int cat_) : c(ctx), cat(cat_), idx((size_t)-1) {
+        if (!c->prof) return;
+        if (c->evUsed + 2 > c->evPool.size()) {
+            for (int i = 0; i < 512; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c->evPool.push_back(e); c->evCat.push_back(0); }
+        }
+        idx = c->evUsed; c->evUsed += 2;
+        c->evCat[idx] = cat;
+        hipEventRecord(c->evPool[idx], c->stream);
+    }
+    ~ProfScope() { if (idx != (size_t)-1) hipEventRecord(c->evPool[idx + 1], c->stream); }
+};
+
+void prof_collect(hmcmt_ctx* c) {
+    if (!c->prof || c->evUsed == 0) return;
+    hipStreamSynchronize(c->stream);
+    for (size_t i = 0; i + 1 < c->evUsed; i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->evPool[i], c->evPool[i + 1]) == hipSuccess) {
+            c->profMs[c->evCat[i]] += ms;
+            c->profN[c->evCat[i]] += 1;
+        }
+    }
+    c->evUsed = 0;
+}
+
+inline dim3 grid1(int n, int b) { return dim3((n + b - 1) / b); }
+
+int launch_transform(hmcmt_ctx* ctx, const cplx* A, const double* B, cplx* C, const int* active) {
+    const View& v = ctx->v;
+    const int M = v.S * v.NZP, NT = v.NYP / 16;
+    const int tiles = (M + 7) / 8;
+    ProfScope ps(ctx, 0);
+    if (NT > 4) {
+        const int NW = (NT + 6) / 7;
+        hipLaunchKernelGGL(k_transform<7>, dim3(tiles), dim3(64 * NW), 0, ctx->stream, A, B, C, M, v.NYP, v.NZP, active);
+    } else {
+        hipLaunchKernelGGL(k_transform<4>, dim3(tiles), dim3(64), 0, ctx->stream, A, B, C, M, v.NYP, v.NZP, active);
+    }
+    return 0;
+}
+
+int apply_precond(hmcmt_ctx* ctx) {
+    Solver& k = ctx->sv;
+    dim3 vg(k.NB, k.S);
+    if (ctx->opt.precond == HMCMT_PRECOND_JACOBI) {
+        ProfScope ps(ctx, 3);
+        hipLaunchKernelGGL(k_jacobi, vg, dim3(VBLOCK), 0, ctx->stream, k);
+        return 0;
+    }
+    launch_transform(ctx, k.r, ctx->d_V, k.y, k.active);
+    {
+        ProfScope ps(ctx, 1);
+        hipLaunchKernelGGL(k_thomas, dim3((k.ny - 1 + 63) / 64, k.S), dim3(64), 0, ctx->stream, k);
+    }
+    launch_transform(ctx, k.y, ctx->d_Vt, k.z, k.active);
+    return 0;
+}
+
+// Solves A x = r for all systems (x zero on interior on entry; r destroyed).  kind 0 forward, 1 adjoint.
+int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
+    Solver& k = ctx->sv;
+    const View& v = ctx->v;
+    k.x = x;
+    k.tol2 = ctx->opt.tol * ctx->opt.tol;
+    const int S = k.S;
+    dim3 vg(k.NB, S), vb(VBLOCK);
+    const size_t vecBytes = (size_t)S * k.vstride * sizeof(cplx);
+    if (ctx->opt.verify) HIPCHK(hipMemcpyAsync(ctx->d_b, k.r, vecBytes, hipMemcpyDeviceToDevice, ctx->stream));
+    // all systems of the requested modes start active
+    {
+        std::vector<int> act(S, 0);
+        for (int s = 0; s < S; ++s) act[s] = (s < k.nFreq) ? (ctx->hp.compTE ? 1 : 0) : (ctx->hp.compTM ? 1 : 0);
+        std::memcpy(ctx->h_iters, act.data(), sizeof(int) * S);     // reuse pinned buffer as staging
+        HIPCHK(hipMemcpyAsync(k.active, ctx->h_iters, sizeof(int) * S, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    HIPCHK(hipMemsetAsync(k.iters, 0, sizeof(int) * S, ctx->stream));
+    HIPCHK(hipMemsetAsync(k.status, 0, sizeof(int) * S, ctx->stream));
+    // z = P^-1 r ; rho = r'z ; p = z
+    apply_precond(ctx);
+    { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_dots, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+    { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_check, dim3(1), dim3(128), 0, ctx->stream, k, ctx->d_partZZ, 1, ctx->opt.maxit); }
+    { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_pupdate, vg, vb, 0, ctx->stream, k, 1); }
+    int& guess = kind == 0 ? ctx->lastItFwd : ctx->lastItAdj;
+    int nextCheck = guess > 2 ? guess : 4;
+    const int every = ctx->opt.check_every > 0 ? ctx->opt.check_every : 2;
+    int it = 0;
+    bool done = false;
+    while (!done && it < ctx->opt.maxit) {
+        ++it;
+        { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv, vg, vb, 0, ctx->stream, k); }
+        { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update, vg, vb, 0, ctx->stream, k); }
+        apply_precond(ctx);
+        { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_dots, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+        { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_check, dim3(1), dim3(128), 0, ctx->stream, k, ctx->d_partZZ, 0, ctx->opt.maxit); }
+        { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_pupdate, vg, vb, 0, ctx->stream, k, 0); }
+        if (it >= nextCheck || it == ctx->opt.maxit) {
+            HIPCHK(hipMemcpyAsync(ctx->h_nactive, k.nactive, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (*ctx->h_nactive == 0) done = true;
+            nextCheck = it + every;
+        }
+    }
+    guess = it;
+    HIPCHK(hipMemcpyAsync(ctx->h_iters, k.iters, sizeof(int) * S, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_status, k.status, sizeof(int) * S, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_err, k.errEst, sizeof(double) * S, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    int mx = 0, sum = 0;
+    for (int s = 0; s < S; ++s) {
+        ctx->itersLast[kind * S + s] = ctx->h_iters[s];
+        mx = std::max(mx, ctx->h_iters[s]); sum += ctx->h_iters[s];
+        if (ctx->h_status[s] != 0 && ctx->stats.status == 0) ctx->stats.status = ctx->h_status[s];
+        if (ctx->h_err[s] > ctx->stats.err_est_max) ctx->stats.err_est_max = ctx->h_err[s];
+    }
+    if (kind == 0) { ctx->stats.iters_fwd_max = mx; ctx->stats.iters_fwd_sum = sum; }
+    else { ctx->stats.iters_adj_max = mx; ctx->stats.iters_adj_sum = sum; }
+    if (!done && ctx->stats.status == 0) ctx->stats.status = HMCMT_ENOCONV;
+    if (ctx->opt.verify) {
+        hipLaunchKernelGGL(k_trueres, vg, vb, 0, ctx->stream, k, ctx->d_b, x, ctx->d_partRes, ctx->d_partBn);
+        std::vector<double> pr((size_t)S * MAXNB), pb((size_t)S * MAXNB);
+        HIPCHK(hipMemcpyAsync(pr.data(), ctx->d_partRes, pr.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(pb.data(), ctx->d_partBn, pb.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (int s = 0; s < S; ++s) {
+            double rr = 0, bb = 0;
+            for (int b = 0; b < k.NB; ++b) { rr += pr[(size_t)s * MAXNB + b]; bb += pb[(size_t)s * MAXNB + b]; }
+            if (bb > 0) ctx->stats.true_res_max = std::max(ctx->stats.true_res_max, std::sqrt(rr / bb));
+        }
+    }
+    (void)v;
+    return 0;
+}
+
+// the whole hot path on device buffers
+int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, double* d_misfit, double* d_grad) {
+    View v = ctx->v;
+    v.m = d_m;
+    if (d_pred) v.pred = reinterpret_cast<cplx*>(d_pred);
+    if (d_grad) v.grad = d_grad;
+    hipStream_t st = ctx->stream;
+    const int S = v.S;
+    ctx->stats = hmcmt_stats{};
+    ctx->stats.nsystems = S;
+    const int nodes = v.NZP * (v.ny + 1);
+    const size_t vecBytes = (size_t)S * v.vstride * sizeof(cplx);
+    {
+        ProfScope ps(ctx, 4);
+        hipLaunchKernelGGL(k_sigma, grid1(v.nCell, 256), dim3(256), 0, st, v);
+        hipLaunchKernelGGL(k_rowmean, grid1(v.nz, 64), dim3(64), 0, st, v);
+        hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, st, v, 0, 1, 1, 0);
+        hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, st, v);
+        if (ctx->opt.precond == HMCMT_PRECOND_FDM)
+            hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 0, st, v);
+        HIPCHK(hipMemsetAsync(v.X, 0, vecBytes, st));
+        hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, S), dim3(64), 0, st, v);
+        hipLaunchKernelGGL(k_rhs, dim3((nodes + 255) / 256, S), dim3(256), 0, st, v);
+    }
+    int rc = solve(ctx, v.X, 0);
+    if (rc) return rc;
+    {
+        ProfScope ps(ctx, 5);
+        hipLaunchKernelGGL(k_rx, grid1(S * v.nRx, 64), dim3(64), 0, st, v, wantGrad ? 1 : 0);
+        hipLaunchKernelGGL(k_resid, grid1(v.nData, 128), dim3(128), 0, st, v);
+        hipLaunchKernelGGL(k_misfit, dim3(1), dim3(256), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit);
+    }
+    if (wantGrad) {
+        {
+            ProfScope ps(ctx, 5);
+            hipLaunchKernelGGL(k_rxcoef, grid1(S * v.nRx, 64), dim3(64), 0, st, v);
+            HIPCHK(hipMemsetAsync(v.R, 0, vecBytes, st));
+            HIPCHK(hipMemsetAsync(v.srcB, 0, sizeof(cplx) * 4 * S, st));
+            hipLaunchKernelGGL(k_src, dim3((2 * (v.ny + 1) + 127) / 128, S), dim3(128), 0, st, v);
+            HIPCHK(hipMemsetAsync(v.Lam, 0, vecBytes, st));
+        }
+        rc = solve(ctx, v.Lam, 1);
+        if (rc) return rc;
+        ProfScope ps(ctx, 6);
+        hipLaunchKernelGGL(k_wb, dim3((v.nz + v.ny + 127) / 128, S), dim3(128), 0, st, v);
+        hipLaunchKernelGGL(k_bcsens, dim3((v.nz + 63) / 64, 3, S), dim3(64), 0, st, v);
+        hipLaunchKernelGGL(k_gradcell, dim3((v.nCell + 127) / 128, 2), dim3(128), 0, st, v);
+        hipLaunchKernelGGL(k_gradfinal, grid1(v.nAC, 128), dim3(128), 0, st, v);
+    }
+    HIPCHK(hipGetLastError());
+    ctx->haveModel = true;
+    return 0;
+}
+
+int finish_status(hmcmt_ctx* ctx) {
+    if (ctx->stats.status == HMCMT_ENOCONV) { ctx->err = "iterative solve did not converge within maxit"; return HMCMT_ENOCONV; }
+    if (ctx->stats.status == HMCMT_EBREAKDOWN) { ctx->err = "Krylov breakdown or non-finite values (NaN/Inf model?)"; return HMCMT_EBREAKDOWN; }
+    return 0;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------------------
+extern "C" {
+
+void hmcmt_default_options(hmcmt_options* o) {
+    if (!o) return;
+    o->precond = HMCMT_PRECOND_FDM;
+    o->maxit = 2000;
+    o->tol = 1e-11;
+    o->check_every = 2;
+    o->verify = 0;
+}
+
+const char* hmcmt_last_error(const hmcmt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
+
+int hmcmt_destroy(hmcmt_ctx* ctx) {
+    if (!ctx) return HMCMT_EINVAL;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (void* p : ctx->allocs) hipFree(p);
+    for (hipEvent_t e : ctx->evPool) hipEventDestroy(e);
+    if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
+    if (ctx->h_iters) hipHostFree(ctx->h_iters);
+    if (ctx->h_status) hipHostFree(ctx->h_status);
+    if (ctx->h_err) hipHostFree(ctx->h_err);
+    if (ctx->h_stage) hipHostFree(ctx->h_stage);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { ctx->err = "no HIP device available (this library has no host compute path)"; return HMCMT_ENODEV; }
+    if (device_id < 0 || device_id >= ndev) { ctx->err = "device_id out of range"; return HMCMT_ENODEV; }
+    ctx->device = device_id;
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    const HostProblem& h = ctx->hp;
+    View& v = ctx->v;
+    v.ny = h.ny; v.nz = h.nz; v.NYP = h.NYP; v.NZP = h.NZP; v.nFreq = h.nFreq; v.S = h.S; v.nRx = h.nRx;
+    v.nData = h.nData; v.nAC = h.nAC; v.nCell = h.nCell; v.zid = h.zid; v.vstride = (long)h.NZP * h.NYP;
+    const size_t VS = (size_t)v.vstride, S = (size_t)h.S;
+    int rc;
+#define UP(field, vec) { decltype(vec)::value_type* p_ = nullptr; if ((rc = dupload(ctx, &p_, vec))) return rc; v.field = p_; }
+    UP(yLen, h.yLen) UP(zLen, h.zLen) UP(omega, h.omega) UP(lam, h.lam)
+    UP(cell2act, h.cell2act) UP(bg, h.bg) UP(act, h.act)
+    UP(rxIdn, h.rxIdn) UP(rxDy1, h.rxDy1) UP(rxDy2, h.rxDy2) UP(rxKL, h.rxKL) UP(rxKR, h.rxKR) UP(rxWL, h.rxWL) UP(rxWR, h.rxWR)
+    UP(predSys, h.predSys) UP(predRx, h.predRx) UP(datSys, h.datSys) UP(datRx, h.datRx)
+    UP(obs, h.obs) UP(dataW, h.dataW) UP(srStart, h.srStart) UP(srList, h.srList)
+#undef UP
+    if ((rc = dupload(ctx, &ctx->d_V, h.Vpad))) return rc;
+    if ((rc = dupload(ctx, &ctx->d_Vt, h.Vtpad))) return rc;
+#define DA(ptr, n) if ((rc = dalloc(ctx, &(ptr), (n)))) return rc;
+    DA(v.sigma, h.nCell) DA(v.sigMeanA, h.nz) DA(v.sigMeanG, h.nz)
+    DA(v.cY, 2 * VS) DA(v.cZ, 2 * VS) DA(v.dK, 2 * VS) DA(v.dM, 2 * VS)
+    DA(v.mzq, 2 * h.NZP) DA(v.dgz, 2 * h.NZP) DA(v.ofz, 2 * h.NZP) DA(v.mzs, 2 * h.NZP)
+    DA(v.invp, S * VS) DA(v.X, S * VS) DA(v.Lam, S * VS) DA(v.R, S * VS)
+    DA(v.Zrx, S * h.nRx) DA(v.rxN0, S * h.nRx) DA(v.rxD, S * h.nRx * 11) DA(v.rxCoef, S * h.nRx)
+    DA(v.pred, h.nData) DA(v.vbar, h.nData) DA(v.misfitPart, h.nData)
+    DA(v.srcB, S * 4) DA(v.wL, S * h.nz) DA(v.wR, S * h.nz) DA(v.colw, S * h.ny)
+    DA(v.gL, S * h.nz) DA(v.gR, S * h.nz) DA(v.gMn, S * h.nz) DA(v.bcsL, S * h.nz) DA(v.bcsR, S * h.nz) DA(v.bcsB, S)
+    DA(v.gPart, 2 * (size_t)h.nCell) DA(v.grad, h.nAC)
+    DA(ctx->d_m, h.nAC) DA(ctx->d_misfit, 1)
+    Solver& k = ctx->sv;
+    k.S = h.S; k.NYP = h.NYP; k.NZP = h.NZP; k.ny = h.ny; k.nz = h.nz; k.nFreq = h.nFreq; k.vstride = v.vstride;
+    k.NB = std::max(1, std::min(MAXNB, (1024 + h.S - 1) / h.S));
+    k.chunk = (v.vstride + k.NB - 1) / k.NB;
+    k.omega = v.omega; k.cY = v.cY; k.cZ = v.cZ; k.dK = v.dK; k.dM = v.dM; k.ofz = v.ofz; k.invp = v.invp;
+    k.r = v.R;
+    DA(k.p, S * VS) DA(k.q, S * VS) DA(k.z, S * VS) DA(k.y, S * VS)
+    DA(k.partA, S * MAXNB) DA(k.partB, S * MAXNB) DA(ctx->d_partZZ, S * MAXNB)
+    DA(ctx->d_partRes, S * MAXNB) DA(ctx->d_partBn, S * MAXNB)
+    DA(k.rho, S) DA(k.alphaBeta, S) DA(k.active, S) DA(k.iters, S) DA(k.status, S) DA(k.nactive, 1) DA(k.errEst, S)
+    DA(ctx->d_b, S * VS)
+    DA(ctx->d_fieldsOut, (size_t)h.nFreq * (h.ny + 1) * (h.nz + 1))
+#undef DA
+    HIPCHK(hipHostMalloc((void**)&ctx->h_nactive, sizeof(int)));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_iters, sizeof(int) * h.S));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_status, sizeof(int) * h.S));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_err, sizeof(double) * h.S));
+    ctx->stageDoubles = (size_t)h.nAC * 4 + (size_t)h.nData * 2 + 16;
+    HIPCHK(hipHostMalloc((void**)&ctx->h_stage, sizeof(double) * ctx->stageDoubles));
+    ctx->itersLast.assign(2 * h.S, 0);
+    // constant halves of the stencils: TE stiffness (mesh only), TM mass (mesh only)
+    const int nodes = v.NZP * (v.ny + 1);
+    hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, ctx->stream, v, 1, 0, 0, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, const double* yLen,
+                 const double* zLen, const double* origin, int64_t nFreq, const double* freqs, int64_t nRx,
+                 const double* rxY, const double* rxZ, int64_t nComp, const int64_t* compMode, int64_t nData,
+                 const int64_t* freqID, const int64_t* rxID, const int64_t* dtID, const uint8_t* dataID,
+                 const double* obs, const double* dataW, int64_t nAC, const int64_t* activeIdx,
+                 const double* bgModel, const hmcmt_options* opts) {
+    if (!out) { g_createError = "null ctx pointer"; return HMCMT_EINVAL; }
+    *out = nullptr;
+    if (!yLen || !zLen || !origin || !freqs || !rxY || !rxZ || !compMode || !dataID || !activeIdx || !bgModel ||
+        (nData > 0 && (!freqID || !rxID || !dtID || !obs || !dataW))) {
+        g_createError = "null input array"; return HMCMT_EINVAL;
+    }
+    hmcmt_ctx* ctx = new hmcmt_ctx();
+    hmcmt_default_options(&ctx->opt);
+    if (opts) ctx->opt = *opts;
+    if (!ctx->hp.build(ny, nz, yLen, zLen, origin, nFreq, freqs, nRx, rxY, rxZ, nComp, compMode, nData, freqID,
+                       rxID, dtID, dataID, obs, dataW, nAC, activeIdx, bgModel)) {
+        g_createError = ctx->hp.error;
+        delete ctx;
+        return HMCMT_EINVAL;
+    }
+    int rc = create_impl(ctx, device_id);
+    if (rc) {
+        g_createError = ctx->err;
+        hmcmt_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return 0;
+}
+
+int hmcmt_set_options(hmcmt_ctx* ctx, const hmcmt_options* o) {
+    if (!ctx || !o) return HMCMT_EINVAL;
+    if (o->precond != HMCMT_PRECOND_JACOBI && o->precond != HMCMT_PRECOND_FDM) { ctx->err = "unknown preconditioner"; return HMCMT_EINVAL; }
+    if (!(o->tol > 0) || o->maxit < 1) { ctx->err = "tol must be > 0 and maxit >= 1"; return HMCMT_EINVAL; }
+    ctx->opt = *o;
+    ctx->lastItFwd = ctx->lastItAdj = 0;
+    return 0;
+}
+
+int hmcmt_get_stats(const hmcmt_ctx* ctx, hmcmt_stats* out) {
+    if (!ctx || !out) return HMCMT_EINVAL;
+    *out = ctx->stats;
+    return 0;
+}
+
+int hmcmt_get_iters(const hmcmt_ctx* ctx, int32_t* iters) {
+    if (!ctx || !iters) return HMCMT_EINVAL;
+    for (size_t i = 0; i < ctx->itersLast.size(); ++i) iters[i] = ctx->itersLast[i];
+    return 0;
+}
+
+int hmcmt_dims(const hmcmt_ctx* ctx, int32_t* o) {
+    if (!ctx || !o) return HMCMT_EINVAL;
+    o[0] = ctx->v.NYP; o[1] = ctx->v.NZP; o[2] = ctx->v.S; o[3] = ctx->v.ny; o[4] = ctx->v.nz; o[5] = ctx->v.zid; o[6] = ctx->sv.NB;
+    return 0;
+}
+
+int hmcmt_grad_device(hmcmt_ctx* ctx, const double* d_m, double* d_pred, double* d_misfit, double* d_grad) {
+    if (!ctx || !d_m || !d_grad) return HMCMT_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = evaluate(ctx, d_m, true, d_pred, d_misfit, d_grad);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    return finish_status(ctx);
+}
+
+int hmcmt_forward_device(hmcmt_ctx* ctx, const double* d_m, double* d_pred, double* d_misfit) {
+    if (!ctx || !d_m) return HMCMT_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = evaluate(ctx, d_m, false, d_pred, d_misfit, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    return finish_status(ctx);
+}
+
+static int host_eval(hmcmt_ctx* ctx, const double* m, double* pred, double* misfit, double* grad, bool wantGrad) {
+    if (!ctx || !m || (wantGrad && !grad)) return HMCMT_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int nAC = ctx->v.nAC, nData = ctx->v.nData;
+    for (int i = 0; i < nAC; ++i)
+        if (!std::isfinite(m[i])) { ctx->err = "non-finite model value"; return HMCMT_EBREAKDOWN; }
+    std::memcpy(ctx->h_stage, m, sizeof(double) * nAC);
+    HIPCHK(hipMemcpyAsync(ctx->d_m, ctx->h_stage, sizeof(double) * nAC, hipMemcpyHostToDevice, ctx->stream));
+    int rc = evaluate(ctx, ctx->d_m, wantGrad, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    double* hs = ctx->h_stage + nAC;
+    HIPCHK(hipMemcpyAsync(hs, ctx->v.pred, sizeof(cplx) * nData, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hs + 2 * nData, ctx->d_misfit, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (wantGrad) HIPCHK(hipMemcpyAsync(hs + 2 * nData + 1, ctx->v.grad, sizeof(double) * nAC, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    if (pred) std::memcpy(pred, hs, sizeof(cplx) * nData);
+    if (misfit) *misfit = hs[2 * nData];
+    if (wantGrad) std::memcpy(grad, hs + 2 * nData + 1, sizeof(double) * nAC);
+    return finish_status(ctx);
+}
+
+int hmcmt_grad(hmcmt_ctx* ctx, const double* m, double* pred, double* misfit, double* grad) {
+    return host_eval(ctx, m, pred, misfit, grad, true);
+}
+int hmcmt_forward(hmcmt_ctx* ctx, const double* m, double* pred, double* misfit) {
+    return host_eval(ctx, m, pred, misfit, nullptr, false);
+}
+
+int hmcmt_get_fields(hmcmt_ctx* ctx, int32_t adjoint, double* exTE, double* hxTM) {
+    if (!ctx) return HMCMT_EINVAL;
+    if (!ctx->haveModel) { ctx->err = "no evaluation has been run yet"; return HMCMT_EINVAL; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const View& v = ctx->v;
+    const int nn = (v.ny + 1) * (v.nz + 1);
+    const cplx* src = adjoint ? v.Lam : v.X;
+    for (int mode = 0; mode < 2; ++mode) {
+        double* dst = mode == 0 ? exTE : hxTM;
+        if (!dst) continue;
+        hipLaunchKernelGGL(k_unpad, dim3((nn + 255) / 256, v.nFreq), dim3(256), 0, ctx->stream, v, src, ctx->d_fieldsOut, mode * v.nFreq);
+        HIPCHK(hipMemcpyAsync(dst, ctx->d_fieldsOut, sizeof(cplx) * (size_t)nn * v.nFreq, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+int hmcmt_profile(hmcmt_ctx* ctx, int32_t enable) {
+    if (!ctx) return HMCMT_EINVAL;
+    ctx->prof = enable != 0;
+    ctx->evUsed = 0;
+    for (int i = 0; i < HMCMT_NCAT; ++i) { ctx->profMs[i] = 0; ctx->profN[i] = 0; }
+    return 0;
+}
+
+int hmcmt_profile_read(hmcmt_ctx* ctx, double* ms, int64_t* launches) {
+    if (!ctx || !ms || !launches) return HMCMT_EINVAL;
+    prof_collect(ctx);
+    for (int i = 0; i < HMCMT_NCAT; ++i) { ms[i] = ctx->profMs[i]; launches[i] = ctx->profN[i]; }
+    return 0;
+}
+
+int hmcmt_debug_transform(hmcmt_ctx* ctx, int32_t which, const double* A, double* C) {
+    if (!ctx || !A || !C) return HMCMT_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)ctx->v.S * ctx->v.vstride * sizeof(cplx);
+    HIPCHK(hipMemcpy(ctx->sv.p, A, bytes, hipMemcpyHostToDevice));
+    launch_transform(ctx, ctx->sv.p, which ? ctx->d_Vt : ctx->d_V, ctx->sv.q, nullptr);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(C, ctx->sv.q, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int set_all_active(hmcmt_ctx* ctx) {
+    std::vector<int> one(ctx->v.S, 1);
+    HIPCHK(hipMemcpy(ctx->sv.active, one.data(), sizeof(int) * one.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int hmcmt_debug_spmv(hmcmt_ctx* ctx, const double* p, double* q) {
+    if (!ctx || !p || !q) return HMCMT_EINVAL;
+    if (!ctx->haveModel) { ctx->err = "no evaluation has been run yet"; return HMCMT_EINVAL; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)ctx->v.S * ctx->v.vstride * sizeof(cplx);
+    HIPCHK(hipMemcpy(ctx->sv.p, p, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(ctx->sv.q, 0, bytes));
+    int rc = set_all_active(ctx);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_spmv, dim3(ctx->sv.NB, ctx->v.S), dim3(VBLOCK), 0, ctx->stream, ctx->sv);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(q, ctx->sv.q, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z) {
+    if (!ctx || !r || !z) return HMCMT_EINVAL;
+    if (!ctx->haveModel) { ctx->err = "no evaluation has been run yet"; return HMCMT_EINVAL; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)ctx->v.S * ctx->v.vstride * sizeof(cplx);
+    HIPCHK(hipMemcpy(ctx->sv.r, r, bytes, hipMemcpyHostToDevice));
+    int rc = set_all_active(ctx);
+    if (rc) return rc;
+    apply_precond(ctx);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(z, ctx->sv.z, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int hmcmt_set_prior(hmcmt_ctx* ctx, const double*, const int64_t*, const int64_t*, const double*, const double*) {
+    if (!ctx) return HMCMT_EINVAL;
+    ctx->err = "hmcmt_set_prior: not built yet";
+    return HMCMT_EINVAL;
+}
+int hmcmt_leapfrog(hmcmt_ctx* ctx, const double*, const double*, double, int32_t, double, double, double,
+                   double*, double*, double*, double*, double*, int32_t*) {
+    if (!ctx) return HMCMT_EINVAL;
+    ctx->err = "hmcmt_leapfrog: not built yet";
+    return HMCMT_EINVAL;
+}
+
+}  // extern "C"

@@ -1,0 +1,398 @@
+// Per-item bodies of the "one thread = one item" kernels of the hot path, written against a
+// plain-pointer view of the context's HBM arrays (struct View).  hmcmt_kernels.hip wraps each in
+// a __global__ launcher; tests/emul/ instantiates the same bodies on the host for CPU unit tests.
+//
+// Data layout.  S = 2*nFreq systems, s < nFreq: TE at frequency s, else TM at
+// frequency s-nFreq.  Every field-like vector lives on the PADDED NODAL GRID
+//     v[s][iz][iy],  iz = 0..nz (NZP = nz+1 rows),  iy = 0..NYP-1,  NYP = roundup(ny+1, 16)
+// with iy fastest; columns iy > ny are always zero, boundary nodes (iy=0, iy=ny, iz=0, iz=nz)
+// hold Dirichlet values for a forward field and zero for residuals / search directions / adjoint
+// fields.  This is the reference's nodal ordering `(iz-1)(ny+1)+iy` (MT2DFwdSolver.jl:232) with a
+// padded row stride, so the interior/boundary split of getBoundaryIndex (:227-248) is implicit.
+#pragma once
+#include "hmcmt_math.h"
+
+namespace hmcmt {
+
+struct View {
+    // sizes
+    int ny, nz, NYP, NZP, nFreq, S, nRx, nData, nAC, nCell;
+    int zid;                       // node row of the receivers (mt2DTE.jl:66-67), 0-based
+    long vstride;                  // NZP*NYP elements per system
+    // mesh (constant)
+    const double* yLen;            // [ny]
+    const double* zLen;            // [nz]
+    const double* omega;           // [S]
+    const double* lam;             // [NYP] generalised eigenvalues of the y-operator (0 in the pad)
+    // model-dependent
+    const double* m;               // [nAC] ln(sigma) on active cells
+    double* sigma;                 // [nCell]
+    const int* cell2act;           // [nCell] active index or -1
+    const double* bg;              // [nCell]
+    const int* act;                // [nAC] cell id of each active cell
+    double* sigMeanA;              // [nz] arithmetic lateral mean (MT1DSensitivity.jl:313)
+    double* sigMeanG;              // [nz] geometric lateral mean (FDM background)
+    // stencil coefficients on the padded nodal grid, per mode: [2][NZP*NYP]
+    double* cY;                    // coupling node (iy,iz) <-> (iy+1,iz)
+    double* cZ;                    // coupling node (iy,iz) <-> (iy,iz+1)
+    double* dK;                    // diagonal of K
+    double* dM;                    // node mass D (A = K + i*omega*D)
+    // FDM background tridiagonals per mode: [2][NZP]
+    double* mzq;                   // multiplies lambda_j
+    double* dgz;                   // z-stiffness diagonal
+    double* ofz;                   // z-stiffness coupling iz <-> iz+1
+    double* mzs;                   // multiplies i*omega
+    cplx* invp;                    // [S][NZP][NYP] inverse pivots of the per-(s,j) tridiagonal LDL^T
+    // fields
+    cplx* X;                       // forward fields (exTE | hxTM), padded nodal layout
+    cplx* Lam;                     // adjoint fields
+    cplx* R;                       // residual / right-hand side
+    // receivers
+    const int* rxIdn;              // [nRx] forward interpolation node `id` (0-based upper node)
+    const double* rxDy1;           // [nRx]
+    const double* rxDy2;           // [nRx]
+    const int* rxKL;               // [nRx] linearInterp (sensUtils.jl:133-161)
+    const int* rxKR;
+    const double* rxWL;
+    const double* rxWR;
+    cplx* Zrx;                     // [S][nRx]
+    int* rxN0;                     // [S][nRx] derivative window start
+    cplx* rxD;                     // [S][nRx][11]: d0[4], d1[4], dq[3]
+    cplx* rxCoef;                  // [S][nRx] sum of conj(W^T W r) over the data of (s, rx)
+    // data
+    const int* predSys;            // [nData] system of the p-th masked entry of the full table
+    const int* predRx;             // [nData] receiver of it
+    const int* datSys;             // [nData] system addressed by (freqID, dtID) of datum p
+    const int* datRx;              // [nData] rxID-1
+    const cplx* obs;               // [nData]
+    const double* dataW;           // [nData]
+    cplx* pred;                    // [nData]
+    cplx* vbar;                    // [nData] conj(W^T W (pred-obs))
+    double* misfitPart;            // [nData] 0.5*|W(pred-obs)|^2
+    const int* srStart;            // [S*nRx+1] CSR of data per (s, rx)
+    const int* srList;             // [nData]
+    // boundary / gradient work arrays
+    cplx* srcB;                    // [S][4]: source on (0,zid), (ny,zid), (0,zid+1), (ny,zid+1)
+    cplx* wL;                      // [S][nz]  weights on left-boundary nodes iz = 1..nz
+    cplx* wR;                      // [S][nz]
+    cplx* colw;                    // [S][ny]
+    cplx* gL;                      // [S][nz]  dBC^T w, left column cells
+    cplx* gR;                      // [S][nz]
+    cplx* gMn;                     // [S][nz]  last row of the mean-profile sensitivity
+    cplx* bcsL;                    // [S][nz]  sensitivity-version boundary fields (TM term)
+    cplx* bcsR;                    // [S][nz]
+    cplx* bcsB;                    // [S]      mean-profile bottom value
+    double* gPart;                 // [2][nCell] P-term partial sums per mode
+    double* grad;                  // [nAC]
+};
+
+HD long nidx(const View& v, int iy, int iz) { return (long)iz * v.NYP + iy; }
+
+// --- sigma = A*exp(m) + bg  (HMCSampler.jl:292-293, HMCUtility.jl:69-77)
+HD void item_sigma(const View& v, int cell) {
+    int a = v.cell2act[cell];
+    v.sigma[cell] = v.bg[cell] + (a >= 0 ? exp(v.m[a]) : 0.0);
+}
+
+// --- lateral means of one cell row (arithmetic: MT1DSensitivity.jl:313; geometric: FDM background)
+HD void item_rowmean(const View& v, int kz) {
+    double sa = 0.0, sl = 0.0;
+    for (int ky = 0; ky < v.ny; ++ky) {
+        double s = v.sigma[(long)kz * v.ny + ky];
+        sa += s;
+        sl += log(s);
+    }
+    v.sigMeanA[kz] = sa / v.ny;
+    v.sigMeanG[kz] = exp(sl / v.ny);
+}
+
+// --- 5-point stencil of  Grad' diag(AveCF*F*q) Grad  and node mass AveCN*F*s at one node
+//     (MT2DFwdSolver.jl:124-135,150-161; MT2DOperators.jl:35-48,118-130).
+//     mode 0 (TE): q = 1/mu0, s = sigma ; mode 1 (TM): q = 1/sigma, s = mu0.
+HD double cellq(const View& v, int mode, int ky, int kz) {
+    return mode == 0 ? 1.0 / MU0 : 1.0 / v.sigma[(long)kz * v.ny + ky];
+}
+HD double cells(const View& v, int mode, int ky, int kz) {
+    return mode == 0 ? v.sigma[(long)kz * v.ny + ky] : MU0;
+}
+HD double coupY(const View& v, int mode, int iy, int iz) {   // edge (iy,iz)-(iy+1,iz), 1<=iz<=nz-1
+    return -(0.5 / v.yLen[iy]) * (v.zLen[iz - 1] * cellq(v, mode, iy, iz - 1) + v.zLen[iz] * cellq(v, mode, iy, iz));
+}
+HD double coupZ(const View& v, int mode, int iy, int iz) {   // edge (iy,iz)-(iy,iz+1), 1<=iy<=ny-1
+    return -(0.5 / v.zLen[iz]) * (v.yLen[iy - 1] * cellq(v, mode, iy - 1, iz) + v.yLen[iy] * cellq(v, mode, iy, iz));
+}
+HD void item_coef(const View& v, int mode, int iy, int iz, bool doK, bool doM) {
+    const long o = (long)mode * v.vstride + nidx(v, iy, iz);
+    const bool rowI = iz >= 1 && iz <= v.nz - 1, colI = iy >= 1 && iy <= v.ny - 1;
+    if (doK) {
+        double cy = 0.0, cz = 0.0, dk = 0.0;
+        if (rowI && iy <= v.ny - 1) cy = coupY(v, mode, iy, iz);
+        if (colI && iz <= v.nz - 1) cz = coupZ(v, mode, iy, iz);
+        if (rowI && colI)
+            dk = -(coupY(v, mode, iy, iz) + coupY(v, mode, iy - 1, iz) + coupZ(v, mode, iy, iz) + coupZ(v, mode, iy, iz - 1));
+        v.cY[o] = cy; v.cZ[o] = cz; v.dK[o] = dk;
+    }
+    if (doM) {
+        double d = 0.0;
+        if (rowI && colI) {
+            double ya = v.yLen[iy - 1], yb = v.yLen[iy], za = v.zLen[iz - 1], zb = v.zLen[iz];
+            d = 0.25 * (ya * za * cells(v, mode, iy - 1, iz - 1) + yb * za * cells(v, mode, iy, iz - 1) +
+                        ya * zb * cells(v, mode, iy - 1, iz) + yb * zb * cells(v, mode, iy, iz));
+        }
+        v.dM[o] = d;
+    }
+}
+
+// --- background (laterally averaged) tridiagonal in z for the fast-diagonalisation
+//     preconditioner: P = Ty (x) Mz_q + My (x) (Tz_q + i w Mz_s)   
+HD void item_fdm_z(const View& v, int mode, int iz) {
+    const long o = (long)mode * v.NZP + iz;
+    if (iz < 1 || iz > v.nz - 1) { v.mzq[o] = 0; v.dgz[o] = 0; v.ofz[o] = 0; v.mzs[o] = 0; return; }
+    double qa, qb, sa, sb;
+    if (mode == 0) { qa = qb = 1.0 / MU0; sa = v.sigMeanG[iz - 1]; sb = v.sigMeanG[iz]; }
+    else { qa = 1.0 / v.sigMeanG[iz - 1]; qb = 1.0 / v.sigMeanG[iz]; sa = sb = MU0; }
+    double za = v.zLen[iz - 1], zb = v.zLen[iz];
+    v.mzq[o] = 0.5 * (za * qa + zb * qb);
+    v.mzs[o] = 0.5 * (za * sa + zb * sb);
+    v.dgz[o] = qa / za + qb / zb;
+    v.ofz[o] = (iz <= v.nz - 2) ? -(qb / zb) : 0.0;
+}
+
+// --- inverse pivots of the (s, j) tridiagonal:  d_iz = lam_j*mzq + dgz + i w mzs
+HD void item_pivot(const View& v, int s, int j) {
+    const int mode = s >= v.nFreq;
+    const double w = v.omega[s], lam = v.lam[j];
+    const double *mzq = v.mzq + (long)mode * v.NZP, *dgz = v.dgz + (long)mode * v.NZP,
+                 *ofz = v.ofz + (long)mode * v.NZP, *mzs = v.mzs + (long)mode * v.NZP;
+    cplx* ip = v.invp + (long)s * v.vstride + j;
+    cplx prev = cplx{0, 0};
+    for (int iz = 1; iz <= v.nz - 1; ++iz) {
+        cplx d = cplx{lam * mzq[iz] + dgz[iz], w * mzs[iz]};
+        if (iz > 1) d -= (ofz[iz - 1] * ofz[iz - 1]) * prev;
+        prev = crecip(d);
+        ip[(long)iz * v.NYP] = prev;
+    }
+}
+
+// --- Dirichlet values of the forward problem written into X's boundary nodes
+//     (getBoundaryMT2DTE/TM, mt2DTE.jl:100-134, mt2DTM.jl:100-134).  col = 0..ny.
+HD void item_bc_forward(const View& v, int s, int col) {
+    const bool tm = s >= v.nFreq;
+    const double w = v.omega[s];
+    cplx* X = v.X + (long)s * v.vstride;
+    X[nidx(v, col, 0)] = cplx{1.0, 0.0};                  // top row incl. corners
+    if (col == 0 || col == v.ny) {
+        const int ky = col == 0 ? 0 : v.ny - 1;
+        bc1d_forward(w, v.nz, v.zLen, v.sigma + ky, v.sigma + ky, v.ny, 1.0, 0.0, tm,
+                     X + nidx(v, col, 1), v.NYP);
+    } else {
+        const double ya = v.yLen[col - 1], yb = v.yLen[col];
+        // (sig[i-1]*yLen[i-1] + sig[i]*yLen[i]) / (yLen[i-1]+yLen[i])  -- weights applied first
+        cplx b = bc1d_forward(w, v.nz, v.zLen, v.sigma + (col - 1), v.sigma + col, v.ny,
+                              ya / (ya + yb), yb / (ya + yb), tm, nullptr, 0);
+        X[nidx(v, col, v.nz)] = b;
+    }
+}
+
+// --- y = K u + i w D u at one interior node (u on the padded nodal grid incl. boundary values)
+HD cplx stencil_apply(const View& v, int s, const cplx* u, int iy, int iz) {
+    const int mode = s >= v.nFreq;
+    const long mo = (long)mode * v.vstride, o = nidx(v, iy, iz);
+    const double *cY = v.cY + mo, *cZ = v.cZ + mo;
+    cplx c = u[o];
+    cplx acc = cplx{v.dK[mo + o] * c.re - v.omega[s] * v.dM[mo + o] * c.im,
+                    v.dK[mo + o] * c.im + v.omega[s] * v.dM[mo + o] * c.re};
+    acc += cY[o] * u[o + 1];
+    acc += cY[o - 1] * u[o - 1];
+    acc += cZ[o] * u[o + v.NYP];
+    acc += cZ[o - v.NYP] * u[o - v.NYP];
+    return acc;
+}
+
+// --- rhs = -Aio*bc (mt2DTE.jl:44): u = X with zero interior, so K u picks the boundary terms
+HD void item_rhs(const View& v, int s, int iy, int iz) {
+    const long o = (long)s * v.vstride + nidx(v, iy, iz);
+    const bool interior = iz >= 1 && iz <= v.nz - 1 && iy >= 1 && iy <= v.ny - 1;
+    if (!interior) { v.R[o] = cplx{0, 0}; return; }
+    const int mode = s >= v.nFreq;
+    const long mo = (long)mode * v.vstride, n = nidx(v, iy, iz);
+    const cplx* X = v.X + (long)s * v.vstride;
+    cplx acc = cplx{0, 0};
+    if (iy == v.ny - 1) acc += v.cY[mo + n] * X[n + 1];
+    if (iy == 1) acc += v.cY[mo + n - 1] * X[n - 1];
+    if (iz == v.nz - 1) acc += v.cZ[mo + n] * X[n + v.NYP];
+    if (iz == 1) acc += v.cZ[mo + n - v.NYP] * X[n - v.NYP];
+    v.R[o] = -acc;
+}
+
+// --- impedance and its derivative at one receiver of one system
+HD void item_rx(const View& v, int s, int r, bool wantDeriv) {
+    const bool tm = s >= v.nFreq;
+    const cplx* F0 = v.X + (long)s * v.vstride + nidx(v, 0, v.zid);
+    const cplx* F1 = F0 + v.NYP;
+    const double* sig1 = v.sigma + (long)v.zid * v.ny;
+    const double dz1 = v.zLen[v.zid];
+    v.Zrx[(long)s * v.nRx + r] = rx_impedance(tm, v.omega[s], v.ny, F0, F1, v.yLen, sig1, dz1,
+                                               v.rxIdn[r], v.rxDy1[r], v.rxDy2[r]);
+    if (wantDeriv) {
+        cplx* D = v.rxD + ((long)s * v.nRx + r) * 11;
+        rx_impedance_deriv(tm, v.omega[s], v.ny, F0, F1, v.yLen, sig1, dz1, v.rxKL[r], v.rxKR[r],
+                           v.rxWL[r], v.rxWR[r], &v.rxN0[(long)s * v.nRx + r], D, D + 4, D + 8);
+    }
+}
+
+// --- residual, misfit terms and conj(W'W r) per datum (HMCSampler.jl:298-304, compJacTMatVec.jl:160)
+HD void item_resid(const View& v, int p) {
+    cplx z = v.Zrx[(long)v.predSys[p] * v.nRx + v.predRx[p]];
+    v.pred[p] = z;
+    cplx res = v.dataW[p] * (z - v.obs[p]);
+    v.misfitPart[p] = 0.5 * cabs2(res);
+    v.vbar[p] = conj(v.dataW[p] * res);
+}
+
+// --- per (s, rx): sum of vbar over the data addressing that receiver of that system
+HD void item_rxcoef(const View& v, int s, int r) {
+    const long k = (long)s * v.nRx + r;
+    cplx c = cplx{0, 0};
+    for (int t = v.srStart[k]; t < v.srStart[k + 1]; ++t) c += v.vbar[v.srList[t]];
+    v.rxCoef[k] = c;
+}
+
+// --- adjoint source sVec = L^T conj(v) on node rows zid, zid+1 (compJacTMatVec.jl:208, :279):
+//     interior part -> R, boundary part (iy = 0 / ny) -> srcB
+HD void item_src(const View& v, int s, int row, int iy) {
+    const int iz = v.zid + row;
+    cplx acc = cplx{0, 0};
+    for (int r = 0; r < v.nRx; ++r) {
+        const long k = (long)s * v.nRx + r;
+        const int o = iy - v.rxN0[k];
+        if (o >= 0 && o < 4) acc += v.rxCoef[k] * v.rxD[k * 11 + row * 4 + o];
+    }
+    const bool interior = iz >= 1 && iz <= v.nz - 1 && iy >= 1 && iy <= v.ny - 1;
+    if (interior) v.R[(long)s * v.vstride + nidx(v, iy, iz)] = acc;
+    else if (iy == 0) v.srcB[(long)s * 4 + row * 2 + 0] = acc;
+    else if (iy == v.ny) v.srcB[(long)s * 4 + row * 2 + 1] = acc;
+}
+
+// --- boundary weights w_b = s_b - (K lambda)_b  (compJacTMatVec.jl:240-242, :312-316)
+HD cplx srcB_at(const View& v, int s, int side, int iz) {
+    if (iz == v.zid) return v.srcB[(long)s * 4 + side];
+    if (iz == v.zid + 1) return v.srcB[(long)s * 4 + 2 + side];
+    return cplx{0, 0};
+}
+HD void item_wside(const View& v, int s, int iz) {          // iz = 1..nz
+    const int mode = s >= v.nFreq;
+    const long mo = (long)mode * v.vstride;
+    const cplx* L = v.Lam + (long)s * v.vstride;
+    cplx wl = srcB_at(v, s, 0, iz), wr = srcB_at(v, s, 1, iz);
+    if (iz <= v.nz - 1) {
+        wl -= v.cY[mo + nidx(v, 0, iz)] * L[nidx(v, 1, iz)];
+        wr -= v.cY[mo + nidx(v, v.ny - 1, iz)] * L[nidx(v, v.ny - 1, iz)];
+    }
+    v.wL[(long)s * v.nz + iz - 1] = wl;
+    v.wR[(long)s * v.nz + iz - 1] = wr;
+}
+HD cplx wbottom(const View& v, int s, int iy) {             // iy = 1..ny-1
+    const int mode = s >= v.nFreq;
+    const long mo = (long)mode * v.vstride;
+    const cplx* L = v.Lam + (long)s * v.vstride;
+    return -(v.cZ[mo + nidx(v, iy, v.nz - 1)] * L[nidx(v, iy, v.nz - 1)]);
+}
+HD void item_colw(const View& v, int s, int ky) {           // MT1DSensitivity.jl:315-328
+    cplx c = cplx{0, 0};
+    if (ky >= 1) c += wbottom(v, s, ky) * (v.yLen[ky] / (v.yLen[ky - 1] + v.yLen[ky]));
+    if (ky + 1 <= v.ny - 1) c += wbottom(v, s, ky + 1) * (v.yLen[ky] / (v.yLen[ky] + v.yLen[ky + 1]));
+    v.colw[(long)s * v.ny + ky] = c;
+}
+
+// --- dBC^T w by columns of the 1-D sensitivities (getBCDerivMatrix, MT1DSensitivity.jl:253-333)
+//     prof 0: left edge column, 1: right edge column, 2: lateral-mean profile
+HD void item_bcsens(const View& v, int s, int prof, int c) {
+    const bool tm = s >= v.nFreq;
+    const double w = v.omega[s];
+    const long o = (long)s * v.nz;
+    if (prof == 0)
+        v.gL[o + c] = bc1d_sens_column(w, v.nz, v.zLen, v.sigma, v.ny, tm, c, v.wL + o, 1,
+                                       (tm && c == 0) ? v.bcsL + o : nullptr, 1);
+    else if (prof == 1)
+        v.gR[o + c] = bc1d_sens_column(w, v.nz, v.zLen, v.sigma + (v.ny - 1), v.ny, tm, c, v.wR + o, 1,
+                                       (tm && c == 0) ? v.bcsR + o : nullptr, 1);
+    else {
+        // mean profile: only its bottom field value is a boundary value (fstride 0: last write wins)
+        v.gMn[o + c] = bc1d_sens_column(w, v.nz, v.zLen, v.sigMeanA, 1, tm, c, nullptr, 0,
+                                        (tm && c == 0) ? v.bcsB + s : nullptr, 0);
+    }
+}
+
+// --- TM field with the sensitivity-version boundary values (compJacTMatVec.jl:307,315):
+//     h~ = forward solution on interior nodes, getBCderivTM's bc on boundary nodes
+HD cplx tm_field_sens(const View& v, int s, int iy, int iz) {
+    if (iz == 0) return cplx{1.0, 0.0};
+    if (iy == 0) return v.bcsL[(long)s * v.nz + iz - 1];
+    if (iy == v.ny) return v.bcsR[(long)s * v.nz + iz - 1];
+    if (iz == v.nz) return v.bcsB[s];
+    return v.X[(long)s * v.vstride + nidx(v, iy, iz)];
+}
+
+// --- P-terms of J^T v for one cell, summed over the frequencies of one mode
+HD void item_gradcell(const View& v, int mode, int cell) {
+    const int ky = cell % v.ny, kz = cell / v.ny;
+    const double area = v.yLen[ky] * v.zLen[kz];
+    double acc = 0.0;
+    for (int f = 0; f < v.nFreq; ++f) {
+        const int s = mode * v.nFreq + f;
+        const cplx* L = v.Lam + (long)s * v.vstride;
+        if (mode == 0) {
+            // -i w (1/4 area) sum over the 4 corner nodes e*lambda (compJacTMatVec.jl:83,235)
+            const cplx* E = v.X + (long)s * v.vstride;
+            cplx sum = cplx{0, 0};
+            for (int dz = 0; dz < 2; ++dz)
+                for (int dy = 0; dy < 2; ++dy) {
+                    long n = nidx(v, ky + dy, kz + dz);
+                    sum += E[n] * L[n];
+                }
+            // Re[-i w a sum] = w a Im(sum)
+            acc += v.omega[s] * 0.25 * area * sum.im;
+        } else {
+            // (area/sig^2) * 1/2 * sum over the 4 edges (grad h~)(grad lambda)
+            // (compJacTMatVec.jl:97-99,306-307,314-315); mesh-boundary edges have grad lambda = 0
+            cplx h00 = tm_field_sens(v, s, ky, kz), h10 = tm_field_sens(v, s, ky + 1, kz);
+            cplx h01 = tm_field_sens(v, s, ky, kz + 1), h11 = tm_field_sens(v, s, ky + 1, kz + 1);
+            cplx l00 = L[nidx(v, ky, kz)], l10 = L[nidx(v, ky + 1, kz)];
+            cplx l01 = L[nidx(v, ky, kz + 1)], l11 = L[nidx(v, ky + 1, kz + 1)];
+            const double iy2 = 1.0 / (v.yLen[ky] * v.yLen[ky]), iz2 = 1.0 / (v.zLen[kz] * v.zLen[kz]);
+            cplx sum = ((h10 - h00) * (l10 - l00) + (h11 - h01) * (l11 - l01)) * iy2 +
+                       ((h01 - h00) * (l01 - l00) + (h11 - h10) * (l11 - l10)) * iz2;
+            const double sg = v.sigma[cell];
+            acc += 0.5 * area / (sg * sg) * sum.re;
+        }
+    }
+    v.gPart[(long)mode * v.nCell + cell] = acc;
+}
+
+// --- final assembly of the gradient w.r.t. m = ln(sigma) for one active cell:
+//     P-terms + boundary terms + Q-terms, real part, chain rule (compJacTMatVec.jl:244,318,325-327;
+//     HMCSampler.jl:306)
+HD void item_gradfinal(const View& v, int a) {
+    const int cell = v.act[a];
+    const int ky = cell % v.ny, kz = cell / v.ny;
+    double g = v.gPart[cell] + v.gPart[(long)v.nCell + cell];
+    for (int s = 0; s < v.S; ++s) {
+        const long o = (long)s * v.nz + kz;
+        cplx b = v.gMn[o] * v.colw[(long)s * v.ny + ky];
+        if (ky == 0) b += v.gL[o];
+        if (ky == v.ny - 1) b += v.gR[o];
+        g += b.re;
+    }
+    if (kz == v.zid) {
+        for (int s = 0; s < v.S; ++s)
+            for (int r = 0; r < v.nRx; ++r) {
+                const long k = (long)s * v.nRx + r;
+                const int o = ky - v.rxN0[k];
+                if (o >= 0 && o < 3) g += (v.rxCoef[k] * v.rxD[k * 11 + 8 + o]).re;
+            }
+    }
+    v.grad[a] = exp(v.m[a]) * g;
+}
+
+}  // namespace hmcmt

@@ -1,0 +1,268 @@
+"""ctypes binding of libhmcmt_hip.so (include/hmcmt.h).
+
+There is no fallback: if the shared library is missing, cannot be loaded, or no HIP device is
+present, the calls raise.  `build_library()` compiles the in-tree source for gfx950 with hipcc.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+from .marshal import CreateArgs, CREATE_ARGTYPES, c_double_p, c_int64_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libhmcmt_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = [os.path.join(CSRC, "hmcmt_hip.hip")]
+HEADERS = [os.path.join(CSRC, h) for h in ("hmcmt_math.h", "hmcmt_items.h", "hmcmt_host.h")] + \
+          [os.path.join(HERE, "..", "include", "hmcmt.h")]
+
+HMCMT_NCAT = 7
+CATEGORIES = ["fdm_transform", "tridiagonal", "spmv", "vector_ops", "assembly_bc", "receivers", "gradient"]
+ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "EHIP", -10: "ENOCONV", -11: "EBREAKDOWN", -13: "ENOMEM"}
+
+
+class HmcmtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libhmcmt_hip: {ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class Options(C.Structure):
+    _fields_ = [("precond", C.c_int32), ("maxit", C.c_int32), ("tol", C.c_double),
+                ("check_every", C.c_int32), ("verify", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iters_fwd_max", C.c_int32), ("iters_adj_max", C.c_int32),
+                ("iters_fwd_sum", C.c_int32), ("iters_adj_sum", C.c_int32),
+                ("err_est_max", C.c_double), ("true_res_max", C.c_double),
+                ("status", C.c_int32), ("nsystems", C.c_int32)]
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -shared: cross-compiles without a GPU."""
+    newest = max(os.path.getmtime(f) for f in SOURCES + HEADERS)
+    if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= newest:
+        return SO_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-Wno-unused-value", "-Wno-pass-failed", "-o", SO_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise HmcmtError(-2, f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(there is no CPU fallback)")
+    lib = C.CDLL(SO_PATH)
+    vp = C.c_void_p
+    lib.hmcmt_default_options.argtypes = [C.POINTER(Options)]
+    lib.hmcmt_default_options.restype = None
+    lib.hmcmt_create.argtypes = [C.POINTER(vp), C.c_int32] + CREATE_ARGTYPES + [C.POINTER(Options)]
+    lib.hmcmt_destroy.argtypes = [vp]
+    lib.hmcmt_last_error.argtypes = [vp]
+    lib.hmcmt_last_error.restype = C.c_char_p
+    lib.hmcmt_set_options.argtypes = [vp, C.POINTER(Options)]
+    lib.hmcmt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.hmcmt_get_iters.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.hmcmt_grad.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_double_p]
+    lib.hmcmt_forward.argtypes = [vp, c_double_p, c_double_p, c_double_p]
+    lib.hmcmt_grad_device.argtypes = [vp, vp, vp, vp, vp]
+    lib.hmcmt_forward_device.argtypes = [vp, vp, vp, vp]
+    lib.hmcmt_set_prior.argtypes = [vp, c_double_p, c_int64_p, c_int64_p, c_double_p, c_double_p]
+    lib.hmcmt_leapfrog.argtypes = [vp, c_double_p, c_double_p, C.c_double, C.c_int32, C.c_double, C.c_double,
+                                   C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                   C.POINTER(C.c_int32)]
+    lib.hmcmt_get_fields.argtypes = [vp, C.c_int32, c_double_p, c_double_p]
+    lib.hmcmt_profile.argtypes = [vp, C.c_int32]
+    lib.hmcmt_profile_read.argtypes = [vp, c_double_p, c_int64_p]
+    lib.hmcmt_dims.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.hmcmt_debug_transform.argtypes = [vp, C.c_int32, c_double_p, c_double_p]
+    lib.hmcmt_debug_spmv.argtypes = [vp, c_double_p, c_double_p]
+    lib.hmcmt_debug_precond.argtypes = [vp, c_double_p, c_double_p]
+    for name in ("hmcmt_create", "hmcmt_destroy", "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters",
+                 "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_set_prior",
+                 "hmcmt_leapfrog", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_read", "hmcmt_dims",
+                 "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond"):
+        getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "hmcmt_last_error",
+                    "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters", "hmcmt_grad", "hmcmt_forward",
+                    "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_set_prior", "hmcmt_leapfrog",
+                    "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_read", "hmcmt_dims",
+                    "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond"]
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+class HipContext:
+    """One GPU context: the drop-in for the reference's per-call solver state."""
+
+    def __init__(self, mtMesh, mtData, invParam, device_id=0, precond="fdm", tol=None, maxit=None,
+                 verify=False, check_every=None):
+        self.lib = load_library()
+        self.args = CreateArgs(mtMesh, mtData, invParam)
+        opts = Options()
+        self.lib.hmcmt_default_options(C.byref(opts))
+        opts.precond = {"jacobi": 0, "fdm": 1}[precond]
+        if precond == "jacobi" and maxit is None:
+            maxit = 20000
+        if tol is not None:
+            opts.tol = tol
+        if maxit is not None:
+            opts.maxit = maxit
+        if check_every is not None:
+            opts.check_every = check_every
+        opts.verify = int(verify)
+        self.opts = opts
+        h = C.c_void_p()
+        rc = self.lib.hmcmt_create(C.byref(h), device_id, *self.args.as_tuple(), C.byref(opts))
+        if rc != 0:
+            raise HmcmtError(rc, (self.lib.hmcmt_last_error(None) or b"").decode())
+        self.h = h
+        d = (C.c_int32 * 7)()
+        self.lib.hmcmt_dims(self.h, d)
+        self.NYP, self.NZP, self.S, self.ny, self.nz, self.zid, self.nblk = list(d)
+        self.nAC, self.nData, self.nFreq = self.args.nAC, self.args.nData, self.args.nFreq
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise HmcmtError(rc, (self.lib.hmcmt_last_error(self.h) or b"").decode())
+
+    def set_options(self, **kw):
+        for k, v in kw.items():
+            if k == "precond":
+                v = {"jacobi": 0, "fdm": 1}[v]
+            setattr(self.opts, k, v)
+        self._check(self.lib.hmcmt_set_options(self.h, C.byref(self.opts)))
+
+    def stats(self):
+        s = Stats()
+        self._check(self.lib.hmcmt_get_stats(self.h, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in Stats._fields_}
+
+    def iters(self):
+        it = (C.c_int32 * (2 * self.S))()
+        self._check(self.lib.hmcmt_get_iters(self.h, it))
+        return np.array(list(it)).reshape(2, self.S)
+
+    # -- hot path -----------------------------------------------------------------------------
+    def grad(self, m):
+        """compDataGradient: m -> (predData, dataMisfit, dataGrad)."""
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        if m.shape != (self.nAC,):
+            raise ValueError("model vector has the wrong length")
+        pred = np.empty(self.nData, dtype=np.complex128)
+        grad = np.empty(self.nAC)
+        mis = C.c_double()
+        self._check(self.lib.hmcmt_grad(self.h, _dp(m), _dp(pred), C.byref(mis), _dp(grad)))
+        return pred, mis.value, grad
+
+    def forward(self, m):
+        """MT2DFwdSolver + compDataMisfit: m -> (predData, dataMisfit)."""
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        if m.shape != (self.nAC,):
+            raise ValueError("model vector has the wrong length")
+        pred = np.empty(self.nData, dtype=np.complex128)
+        mis = C.c_double()
+        self._check(self.lib.hmcmt_forward(self.h, _dp(m), _dp(pred), C.byref(mis)))
+        return pred, mis.value
+
+    def grad_device(self, d_m, d_pred, d_misfit, d_grad):
+        """Raw device pointers (ints), e.g. torch tensors' data_ptr()."""
+        self._check(self.lib.hmcmt_grad_device(self.h, d_m, d_pred, d_misfit, d_grad))
+
+    def forward_device(self, d_m, d_pred, d_misfit):
+        self._check(self.lib.hmcmt_forward_device(self.h, d_m, d_pred, d_misfit))
+
+    def fields(self, adjoint=False):
+        nn = (self.ny + 1) * (self.nz + 1)
+        e = np.empty(nn * self.nFreq, dtype=np.complex128)
+        h = np.empty(nn * self.nFreq, dtype=np.complex128)
+        self._check(self.lib.hmcmt_get_fields(self.h, int(adjoint), _dp(e), _dp(h)))
+        return e.reshape(self.nFreq, nn).T.copy(), h.reshape(self.nFreq, nn).T.copy()
+
+    # -- prior / leapfrog ---------------------------------------------------------------------
+    def set_prior(self, mref, Wm, invM):
+        Wm = Wm.tocsr()
+        self._prior = (np.ascontiguousarray(mref, dtype=np.float64),
+                       np.ascontiguousarray(Wm.indptr, dtype=np.int64),
+                       np.ascontiguousarray(Wm.indices, dtype=np.int64),
+                       np.ascontiguousarray(Wm.data, dtype=np.float64),
+                       np.ascontiguousarray(invM, dtype=np.float64))
+        a = self._prior
+        self._check(self.lib.hmcmt_set_prior(self.h, _dp(a[0]), a[1].ctypes.data_as(c_int64_p),
+                                             a[2].ctypes.data_as(c_int64_p), _dp(a[3]), _dp(a[4])))
+
+    def leapfrog(self, m0, p0, dt, L, regParam, lnSigMin, lnSigMax):
+        m0 = np.ascontiguousarray(m0, dtype=np.float64)
+        p0 = np.ascontiguousarray(p0, dtype=np.float64)
+        m1 = np.empty(self.nAC); p1 = np.empty(self.nAC)
+        pred = np.empty(self.nData, dtype=np.complex128)
+        mis = C.c_double(); mnorm = C.c_double(); nf = C.c_int32()
+        self._check(self.lib.hmcmt_leapfrog(self.h, _dp(m0), _dp(p0), dt, L, regParam, lnSigMin, lnSigMax,
+                                            _dp(m1), _dp(p1), _dp(pred), C.byref(mis), C.byref(mnorm),
+                                            C.byref(nf)))
+        return m1, p1, pred, mis.value, mnorm.value, nf.value
+
+    # -- instrumentation ----------------------------------------------------------------------
+    def profile(self, enable=True):
+        self._check(self.lib.hmcmt_profile(self.h, int(enable)))
+
+    def profile_read(self):
+        ms = np.zeros(HMCMT_NCAT)
+        n = np.zeros(HMCMT_NCAT, dtype=np.int64)
+        self._check(self.lib.hmcmt_profile_read(self.h, _dp(ms), n.ctypes.data_as(c_int64_p)))
+        return {c: (float(ms[i]), int(n[i])) for i, c in enumerate(CATEGORIES)}
+
+    def _vec(self, a):
+        a = np.ascontiguousarray(a, dtype=np.complex128)
+        if a.size != self.S * self.NZP * self.NYP:
+            raise ValueError("vector must be in the padded nodal layout [S][NZP][NYP]")
+        return a
+
+    def debug_transform(self, which, A):
+        A = self._vec(A)
+        Cc = np.empty_like(A)
+        self._check(self.lib.hmcmt_debug_transform(self.h, which, _dp(A), _dp(Cc)))
+        return Cc
+
+    def debug_spmv(self, p):
+        p = self._vec(p)
+        q = np.empty_like(p)
+        self._check(self.lib.hmcmt_debug_spmv(self.h, _dp(p), _dp(q)))
+        return q
+
+    def debug_precond(self, r):
+        r = self._vec(r)
+        z = np.empty_like(r)
+        self._check(self.lib.hmcmt_debug_precond(self.h, _dp(r), _dp(z)))
+        return z
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hmcmt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,149 @@
+/* hmcmt.h -- C ABI of libhmcmt_hip.so: the MI355X-native hot path of CUG-EMI/HMCMT2D.
+ *
+ * One context = one GPU = one HMC chain's worth of state.  A context is NOT thread-safe;
+ * distinct contexts are independent.  All pointers are caller-owned; the library copies what it
+ * needs during hmcmt_create and never retains host pointers.  Complex arrays are interleaved
+ * (re, im) doubles: the memory layout of Julia's ComplexF64, numpy complex128 and C's
+ * `double _Complex`.  Index arrays are 1-based int64, exactly as the reference stores them.
+ *
+ * Every function returns 0 on success or a negative HMCMT_E* code; it never throws or aborts.
+ * hmcmt_last_error() gives the message of the last failure.  There is NO host compute path:
+ * without a HIP device hmcmt_create fails with HMCMT_ENODEV.
+ *
+ * What each entry point replaces in the reference (/root/reference, all under HMCMT/src/):
+ *
+ *   hmcmt_create / hmcmt_destroy
+ *       the per-run set-up the reference redoes inside every call: setupTensorMesh2D!
+ *       (MTFwdSolver/MT2DOperators.jl:16-27), getBoundaryIndex (MT2DFwdSolver.jl:227-248),
+ *       preSetRxFieldSens (MTSensitivity/sensUtils.jl:17-52), compDataWeightMat / activeCell
+ *       plumbing (HMCStruct/HMCStruct.jl:99-125).
+ *   hmcmt_grad   == compDataGradient(mtMesh, mtData, invParam, hmcprior)
+ *       (HMCSampler/HMCSampler.jl:277-330): m = ln(sigma) on active cells ->
+ *       (predData, dataMisfit, dataGrad); internally MT2DFwdSolver (MT2DFwdSolver.jl:74-216),
+ *       compMT2DTE/TM (mt2DTE.jl:19-83, mt2DTM.jl:18-83), compJacTMatVec
+ *       (MTSensitivity/compJacTMatVec.jl:8-327) and the MUMPS/UMFPACK factor+solve they call
+ *       (MUMPS/src/MUMPSfuncs.jl:32,128; mt2DTE.jl:47-55).
+ *   hmcmt_forward == MT2DFwdSolver + compDataMisfit as used by getHamiltonian
+ *       (HMCSampler.jl:358-397, :498-507).
+ *   hmcmt_leapfrog == proposeLeapfrog (HMCSampler.jl:206-269) with the trajectory kept on the
+ *       device, plus the Hamiltonian terms getHamiltonian needs at the proposal.
+ *   hmcmt_get_fields: exTE / hxTM of MT2DFwdData (MT2DFwdSolver.jl:44-53), reference node order.
+ */
+#ifndef HMCMT_H
+#define HMCMT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMCMT_OK          0
+#define HMCMT_EINVAL     -1   /* bad argument (message says which) */
+#define HMCMT_ENODEV     -2   /* no usable HIP device */
+#define HMCMT_EHIP       -3   /* HIP runtime error */
+#define HMCMT_ENOCONV   -10   /* an iterative solve hit maxit (cf. MUMPS -10 "singular", MUMPSfuncs.jl:59-73) */
+#define HMCMT_EBREAKDOWN -11  /* Krylov breakdown / non-finite values (a NaN model would hang the reference, HMCSampler.jl:546-548) */
+#define HMCMT_ENOMEM    -13   /* device allocation failed (cf. MUMPS -13) */
+
+#define HMCMT_PRECOND_JACOBI 0
+#define HMCMT_PRECOND_FDM    1   /* fast diagonalisation with a laterally averaged background (default) */
+
+typedef struct hmcmt_ctx hmcmt_ctx;
+
+typedef struct hmcmt_options {
+    int32_t precond;      /* HMCMT_PRECOND_* ; default FDM */
+    int32_t maxit;        /* iteration cap per solve; default 2000 (FDM) */
+    double  tol;          /* stop when ||P^-1 r|| <= tol*||x|| (error estimate); default 1e-11 */
+    int32_t check_every;  /* host convergence poll interval in iterations; default 2 */
+    int32_t verify;       /* 1: also compute true relative residuals ||b-Ax||/||b|| after each solve */
+} hmcmt_options;
+
+typedef struct hmcmt_stats {
+    int32_t iters_fwd_max, iters_adj_max;   /* max over systems of the last call */
+    int32_t iters_fwd_sum, iters_adj_sum;   /* sum over systems */
+    double  err_est_max;                    /* max over systems of ||P^-1 r||/||x|| at exit */
+    double  true_res_max;                   /* max ||b-Ax||/||b|| (only with options.verify) */
+    int32_t status;                         /* 0 or HMCMT_ENOCONV / HMCMT_EBREAKDOWN */
+    int32_t nsystems;                       /* 2*nFreq */
+} hmcmt_stats;
+
+void hmcmt_default_options(hmcmt_options* opts);
+
+/* Builds a context on HIP device `device_id`.
+ *   ny, nz            cells in y / z (nz INCLUDES the air layers, TensorMesh2D.gridSize)
+ *   yLen[ny], zLen[nz], origin[2]      TensorMesh2D fields (HMCFileIO.jl:45-60)
+ *   freqs[nFreq]; rxY[nRx], rxZ[nRx]   MTData.freqs, columns of MTData.rxLoc
+ *   compMode[nComp]   1 for a data component containing "XY" (TE), 2 for "YX" (TM)
+ *   freqID/rxID/dtID[nData]  1-based, MTData fields; dataID[nComp*nRx*nFreq] mask, dt fastest
+ *   obs[nData] complex, dataW[nData] = diag of InvDataModel.dataW
+ *   activeIdx[nAC]    1-based cell id of each active cell (= activeCell.rowval), bgModel[ny*nz]
+ *   opts              NULL for defaults */
+int hmcmt_create(hmcmt_ctx** ctx, int32_t device_id,
+                 int64_t ny, int64_t nz, const double* yLen, const double* zLen, const double* origin,
+                 int64_t nFreq, const double* freqs,
+                 int64_t nRx, const double* rxY, const double* rxZ,
+                 int64_t nComp, const int64_t* compMode,
+                 int64_t nData, const int64_t* freqID, const int64_t* rxID, const int64_t* dtID,
+                 const uint8_t* dataID, const double* obs, const double* dataW,
+                 int64_t nAC, const int64_t* activeIdx, const double* bgModel,
+                 const hmcmt_options* opts);
+int hmcmt_destroy(hmcmt_ctx* ctx);
+const char* hmcmt_last_error(const hmcmt_ctx* ctx);   /* ctx may be NULL: create-time error */
+
+int hmcmt_set_options(hmcmt_ctx* ctx, const hmcmt_options* opts);
+int hmcmt_get_stats(const hmcmt_ctx* ctx, hmcmt_stats* out);
+/* per-system iteration counts of the last call: iters[2*S] (forward, then adjoint) */
+int hmcmt_get_iters(const hmcmt_ctx* ctx, int32_t* iters);
+
+/* Host-buffer entry points (synchronous). pred: complex[nData]; grad: [nAC]. */
+int hmcmt_grad(hmcmt_ctx* ctx, const double* m, double* pred, double* misfit, double* grad);
+int hmcmt_forward(hmcmt_ctx* ctx, const double* m, double* pred, double* misfit);
+
+/* Device-buffer entry points: all pointers are DEVICE pointers on the context's GPU; work is
+ * enqueued on the context's stream and complete when the call returns. */
+int hmcmt_grad_device(hmcmt_ctx* ctx, const double* d_m, double* d_pred, double* d_misfit, double* d_grad);
+int hmcmt_forward_device(hmcmt_ctx* ctx, const double* d_m, double* d_pred, double* d_misfit);
+
+/* One leapfrog trajectory on the device (proposeLeapfrog, HMCSampler.jl:206-269; diagonal mass).
+ *   m0, p0 [nAC]      current model / momentum (host)
+ *   invM [nAC]        diagonal of M^-1
+ *   mref [nAC]        prior reference model; Wm in CSR (rowptr[nAC+1], colind, val; 0-based int64)
+ *   dt, L, regParam, lnSigMin, lnSigMax     as in HMCPrior
+ * Outputs (host): m1, p1 [nAC]; pred complex[nData] and misfit at the proposal (what the next
+ * getHamiltonian call would recompute, HMCSampler.jl:364); mnorm = 0.5*lambda*(m-mref)'Wm(m-mref);
+ * nfevals = number of gradient evaluations performed (L+1). */
+int hmcmt_set_prior(hmcmt_ctx* ctx, const double* mref, const int64_t* wm_rowptr,
+                    const int64_t* wm_colind, const double* wm_val, const double* invM);
+int hmcmt_leapfrog(hmcmt_ctx* ctx, const double* m0, const double* p0, double dt, int32_t L,
+                   double regParam, double lnSigMin, double lnSigMax,
+                   double* m1, double* p1, double* pred, double* misfit, double* mnorm,
+                   int32_t* nfevals);
+
+/* Solution fields of the last evaluation in the reference's layout: complex[(ny+1)*(nz+1)*nFreq],
+ * node index (iz*(ny+1)+iy) fastest, then frequency (MT2DFwdSolver.jl:111-112).  adjoint=1 returns
+ * the adjoint fields instead (interior = eVal of compJacTMatVec.jl:221, boundary 0). */
+int hmcmt_get_fields(hmcmt_ctx* ctx, int32_t adjoint, double* exTE, double* hxTM);
+
+/* Kernel-time accounting with HIP events on the context's stream.
+ * categories: 0 fdm-transform (MFMA), 1 tridiagonal, 2 stencil SpMV, 3 vector ops,
+ *             4 assembly+boundary, 5 receivers+sources, 6 gradient accumulation */
+#define HMCMT_NCAT 7
+int hmcmt_profile(hmcmt_ctx* ctx, int32_t enable);            /* resets the counters */
+int hmcmt_profile_read(hmcmt_ctx* ctx, double* ms /*[HMCMT_NCAT]*/, int64_t* launches /*[HMCMT_NCAT]*/);
+
+/* sizes the roofline accounting needs: out = {NYP, NZP, S, ny, nz, zid, nblk} */
+int hmcmt_dims(const hmcmt_ctx* ctx, int32_t* out);
+
+/* Test hooks (exercise single kernels through the ABI).
+ * hmcmt_debug_transform: C = A*V (which=0) or A*V' (which=1) with the context's FDM matrices;
+ *   A, C: host complex[S*NZP*NYP] in the padded nodal layout.
+ * hmcmt_debug_spmv: q = A_s p for all systems at the model of the last evaluation. */
+int hmcmt_debug_transform(hmcmt_ctx* ctx, int32_t which, const double* A, double* C);
+int hmcmt_debug_spmv(hmcmt_ctx* ctx, const double* p, double* q);
+int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMCMT_H */
