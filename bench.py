@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: leapfrog steps/s (= forward + gradient evaluations/s) on the 200x100-cell,
+16-frequency synthetic of BASELINE.json, one independent chain per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3]
+
+A step is one pass of the hot path -- compDataGradient (HMCSampler.jl:277-330) -- at the next model
+of a synthetic leapfrog trajectory m_k = m_0 + k*dt*p; all K models are resident in HBM before the
+timed region and predData / misfit / gradient stay in HBM.  For N > 1 the driver launches this file
+with torch.distributed.run (one rank per GPU, RCCL); ranks are independent chains (weak scaling) and
+the only collective in the timed region is the barrier.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X dense FP64 matrix peak (datasheet; = 1/2 of the 157.3 TF FP32
+                                  # matrix rate listed in MI355X_MICROARCH.md); pure-MFMA loop measures ~70
+
+
+def build_problem(name, seed):
+    """Synthetic workload of SURVEY §8(d): observed data = GPU forward of the true model + 3 % noise."""
+    from hmcmt2d_amd import synthetic as S, invsetup as I
+    from hmcmt2d_amd.lib import HipContext
+    mesh, data, sig_true = S.make_config(name)
+    ny, nz = mesh.gridSize
+    nair = len(mesh.airLayer)
+    mesh.sigma = np.concatenate([np.full(ny * nair, S.SIG_AIR), np.full(ny * (nz - nair), 0.01)])
+    n = len(data.rxID)
+    inv0 = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, np.zeros(n, complex), np.ones(n))
+    return mesh, data, inv0, sig_true
+
+
+def cpu_baseline(name):
+    """Oracle (numpy/scipy restatement, direct solver) on a bounded sample: THREE of the config's
+    frequencies (TE + TM), single thread; value extrapolates linearly in the number of frequencies
+    (the reference's frequency loop is serial, MT2DFwdSolver.jl:140-146)."""
+    from threadpoolctl import threadpool_limits
+    from oracle import hmcmt_oracle as O
+    from hmcmt2d_amd import synthetic as S, invsetup as I
+    from hmcmt2d_amd.structs import HMCPrior
+    mesh, data, _ = S.make_config(name)
+    nF = len(data.freqs)
+    fs = [data.freqs[0], data.freqs[nF // 2], data.freqs[-1]]
+    d1 = S.make_data_layout(fs, data.rxLoc[:, 0])
+    ny, nz = mesh.gridSize
+    nair = len(mesh.airLayer)
+    mesh.sigma = np.concatenate([np.full(ny * nair, S.SIG_AIR), np.full(ny * (nz - nair), 0.01)])
+    n = len(d1.rxID)
+    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, np.full(n, 0.02 + 0.02j), np.full(n, 1e-3))
+    inv.strModel = S.rough_state(len(inv.strModel))
+    with threadpool_limits(limits=1):
+        O.setupTensorMesh2D(mesh)
+        t0 = time.time()
+        O.compDataGradient(mesh, d1, inv, HMCPrior(), True)      # dense dBC, as the reference forms it
+        dt = time.time() - t0
+    return {"value": len(fs) / (dt * nF), "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": f"oracle compDataGradient (numpy/scipy, SuperLU direct solves, dense dBC as the reference) "
+                      f"at {len(fs)} of {nF} frequencies ({fs[0]:.3g}, {fs[1]:.3g}, {fs[2]:.3g} Hz; TE+TM) of {name}: "
+                      f"{dt:.2f} s, scaled x{nF}/{len(fs)} to a full step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from hmcmt2d_amd import synthetic as S, invsetup as I
+    from hmcmt2d_amd.lib import HipContext
+    name = args.config
+    mesh, data, inv0, sig_true = build_problem(name, rank)
+    # observed data from the GPU forward of the true model (+ seeded noise), then the real context
+    ctx0 = HipContext(mesh, data, inv0, device_id=local)
+    m_true = np.log(sig_true[inv0.activeIdx])
+    pred_true, _ = ctx0.forward(m_true)
+    ctx0.close()
+    obs, err = S.noisy_observations(pred_true)
+    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, obs, err)
+    ctx = HipContext(mesh, data, inv, device_id=local)
+    nAC, nData = ctx.nAC, ctx.nData
+
+    K, W = args.steps, args.warmup
+    rng = np.random.default_rng([1, rank])
+    m0 = S.rough_state(nAC, seed=1 + rank)
+    p = np.clip(rng.standard_normal(nAC), -2.5, 2.5)
+    traj = np.stack([m0 + 0.03 * k * p / max(1, K + W) * 8 for k in range(K + W)])   # |dm| <= 0.6 over the run
+    dev = torch.device("cuda", local)
+    d_m = torch.from_numpy(traj).to(dev)
+    d_pred = torch.zeros(2 * nData, dtype=torch.float64, device=dev)
+    d_mis = torch.zeros(1, dtype=torch.float64, device=dev)
+    d_grad = torch.zeros(nAC, dtype=torch.float64, device=dev)
+
+    def step(k):
+        ctx.grad_device(d_m[k].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr(), d_grad.data_ptr())
+
+    for k in range(W):
+        step(k)
+    ctx.profile(["fdm_transform"])                         # HIP events around the dominant kernel only
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        step(k)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    st = ctx.stats()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    misfit = float(d_mis.item())
+    gnorm = float(torch.linalg.vector_norm(d_grad).item())
+
+    if rank == 0:
+        ms_tr, n_tr = prof["fdm_transform"]
+        avg_us = 1e3 * ms_tr / max(n_tr, 1)
+        # algorithmic flops of one transform launch: real V (nyi x nyi) applied to the real and imaginary
+        # parts of S*(nz-1) interior rows of length nyi: 2 * 2 * S*nzi*nyi^2   
+        nyi, nzi = ctx.ny - 1, ctx.nz - 1
+        flops = 4.0 * ctx.S * nzi * nyi * nyi
+        achieved = flops / (avg_us * 1e-6) / 1e12 if n_tr else 0.0
+        out = {
+            "metric": "leapfrog steps/sec (= fwd+grad evals/sec), 200x100 mesh x 16 freq",
+            "value": world * K / elapsed, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{name}: {mesh.gridSize[0]}x{mesh.gridSize[1] - len(mesh.airLayer)}-cell mesh "
+                                   f"(+{len(mesh.airLayer)} air rows), {len(data.freqs)} freq, TE+TM, "
+                                   f"{data.rxLoc.shape[0]} receivers, 1 independent chain per GPU",
+                       "systems_per_step": ctx.S, "unknowns_per_system": nyi * nzi, "nparam": nAC,
+                       "solver": "batched COCG + fast-diagonalisation preconditioner, tol 1e-11 (error estimate)",
+                       "iters_fwd_max": st["iters_fwd_max"], "iters_adj_max": st["iters_adj_max"],
+                       "parallelism": f"chains x{world}" if world > 1 else "1 chain"},
+            "roofline": {"bound": "mfma", "kernel": "k_transform (FP64 MFMA 16x16x4)", "achieved": achieved,
+                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "avg_launch_us": avg_us, "launches_per_step": n_tr / K,
+                         "flops_per_launch": flops},
+            "check": {"misfit_last": misfit, "grad_l2_last": gnorm, "solver_status": st["status"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(name)
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -228,83 +228,186 @@ __global__ __launch_bounds__(VBLOCK) void k_jacobi(Solver k) {
 
 // ----------------------------------------------------------------------------------------------
 // FDM transform: C[m][n] = sum_k A[m][k] * B[k][n],  A, C complex [M][NYP], B real [NYP][NYP].
-// One workgroup = 8 complex rows; the 16-row MFMA tile stacks their real parts (rows 0-7) and
-// imaginary parts (rows 8-15).  Wave w owns n-tiles [w*NTW, (w+1)*NTW).
-// v_mfma_f64_16x16x4_f64 operand layout: A[i = lane%16][k = lane/16], B[k = lane/16][j = lane%16],
-// D[i = 4*r + lane/16][j = lane%16], r = 0..3 (f64 differs from the f32 MFMA layout).
+//
+// One wave = 8 complex rows x NTW column tiles of 16.  The 16-row MFMA tile stacks the rows' real
+// parts (tile rows 0-7) and imaginary parts (8-15), so one B fragment feeds both.
+// v_mfma_f64_16x16x4_f64 layout (measured, scripts/probe/mfma_f64_layout.hip):
+//   A[i = lane%16][k = lane/16], B[k = lane/16][j = lane%16], D[i = 4*r + lane/16][j = lane%16].
+// The reduction index is processed 16 at a time with the permutation k = 16*kg + 4*(lane/16) + i
+// for MFMA step i = 0..3, so each lane reads 4 consecutive complex of its A row (64 B) and the
+// constant B operand is pre-swizzled on the host into fragment order
+//   Bsw[((kg*NT + t)*64 + lane)*4 + i] = B[16*kg + 4*(lane/16) + i][16*t + lane%16]
+// (two 16-byte loads per tile per 4 MFMAs).  Operands of group kg+1 are fetched into registers
+// while group kg is multiplied; there is no LDS and no barrier.
 // ----------------------------------------------------------------------------------------------
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 template <int NTW>
-__global__ __launch_bounds__(256) void k_transform(const cplx* __restrict__ A, const double* __restrict__ B,
+__device__ __forceinline__ void transform_body(const cplx* __restrict__ A, const double* __restrict__ Bsw,
+                                               cplx* __restrict__ C, int M, int NYP, int m0, int t0, int lane) {
+    const int NT = NYP >> 4, KG = NYP >> 4;
+    // Every workgroup streams the same B; starting each at a different k-group keeps the CUs of an
+    // XCD on different L2 channels instead of all requesting the same lines at once.
+    const int kg0 = (m0 >> 3) % KG;
+    const int li = lane & 15, lk = lane >> 4;
+    const bool im = (li >> 3) != 0;
+    const int arow = min(m0 + (li & 7), M - 1);
+    const d4* Ap = reinterpret_cast<const d4*>(A + (long)arow * NYP + 4 * lk);
+    const d4* Bp = reinterpret_cast<const d4*>(Bsw) + (long)t0 * 64 + lane;
+    const long bstride = (long)NT * 64;                // d4 per k-group
+    d4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = d4{0, 0, 0, 0};
+    d4 a0 = Ap[kg0 * 8], a1 = Ap[kg0 * 8 + 1];
+    d4 b[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) b[t] = Bp[kg0 * bstride + t * 64];
+    for (int it = 0; it < KG; ++it) {
+        int kn = kg0 + it + 1;                          // next k-group (wraps; last one re-reads, harmless)
+        if (kn >= KG) kn -= KG;
+        const d4 na0 = Ap[kn * 8], na1 = Ap[kn * 8 + 1];
+        d4 nb[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) nb[t] = Bp[kn * bstride + t * 64];
+        // Pin the software pipeline.  Left alone, LLVM folds the phi of loads back into a load at the
+        // top of the iteration and the scheduler emits load -> wait -> MFMA with no overlap.  The two
+        // scheduling barriers keep "issue next loads | multiply current | wait for next" in this order.
+        __builtin_amdgcn_sched_barrier(0);
+        const double av[4] = {im ? a0[1] : a0[0], im ? a0[3] : a0[2], im ? a1[1] : a1[0], im ? a1[3] : a1[2]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], b[t][i], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = na0; a1 = na1;
+        asm volatile("" : "+v"(a0), "+v"(a1));
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) { b[t] = nb[t]; asm volatile("" : "+v"(b[t])); }
+    }
+    // r = 0,1: real parts of complex rows lk, 4+lk; r = 2,3: their imaginary parts -> every lane owns two
+    // complete complex results; 16 lanes write 256 contiguous bytes.
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const long col = (long)(t0 + t) * 16 + li;
+        if (m0 + lk < M) C[(long)(m0 + lk) * NYP + col] = cplx{acc[t][0], acc[t][2]};
+        if (m0 + 4 + lk < M) C[(long)(m0 + 4 + lk) * NYP + col] = cplx{acc[t][1], acc[t][3]};
+    }
+}
+
+// Workgroup = RG row groups (8 complex rows each) x NW column splits, RG*NW <= 4 waves, so that a
+// CU holding one workgroup runs one wave per SIMD (two 2-wave workgroups on a CU land on the same
+// SIMD pair and halve the MFMA rate -- measured, scripts/probe/transform_bench.hip).  Column tiles
+// are dealt to the NW waves as evenly as possible (first `extra` waves get one more).
+__global__ __launch_bounds__(256) void k_transform(const cplx* __restrict__ A, const double* __restrict__ Bsw,
                                                     cplx* __restrict__ C, int M, int NYP, int rowsPerSys,
-                                                    const int* __restrict__ active) {
+                                                    const int* __restrict__ active, int NW, int RG) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.x * 8;
+    const int rg = wave / NW, nw = wave - rg * NW;
+    const int m0 = (blockIdx.x * RG + rg) * 8;
+    if (m0 >= M) return;
     if (active) {
         const int s0 = m0 / rowsPerSys, s1 = min(m0 + 7, M - 1) / rowsPerSys;
         if (!active[s0] && !active[s1]) return;
     }
     const int NT = NYP >> 4;
-    const int t0 = wave * NTW;
-    if (t0 >= NT) return;
-    const int ntl = min(NTW, NT - t0);
-    const int li = lane & 15, lk = lane >> 4;
-    const int arow = m0 + (li & 7);
-    const bool rowok = arow < M;
-    const double* Ap = reinterpret_cast<const double*>(A + (long)(rowok ? arow : 0) * NYP + lk) + (li >> 3);
-    const double* Bp = B + (long)lk * NYP + t0 * 16 + li;
-    d4 acc[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) acc[t] = d4{0, 0, 0, 0};
-    const int KS = NYP >> 2;
-#pragma unroll 2
-    for (int ks = 0; ks < KS; ++ks) {
-        double a = rowok ? Ap[(long)ks * 8] : 0.0;      // 4 complex = 8 doubles per k-step
-        const double* bp = Bp + (long)ks * 4 * NYP;
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            if (t < ntl) {
-                double b = bp[t * 16];
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-            }
-        }
-    }
-    // D[i = 4*r + lk][j = li] (measured, scripts/probe/mfma_f64_layout.hip): with the stacked tile
-    // r = 0,1 are the real parts of complex rows lk, 4+lk and r = 2,3 their imaginary parts, so every
-    // lane owns two complete complex results and 16 lanes write 256 contiguous bytes.
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-        if (t < ntl) {
-            const long col = (long)(t0 + t) * 16 + li;
-            if (m0 + lk < M) C[(long)(m0 + lk) * NYP + col] = cplx{acc[t][0], acc[t][2]};
-            if (m0 + 4 + lk < M) C[(long)(m0 + 4 + lk) * NYP + col] = cplx{acc[t][1], acc[t][3]};
-        }
+    const int base = NT / NW, extra = NT % NW;
+    const int ntl = base + (nw < extra ? 1 : 0);
+    const int t0 = nw * base + min(nw, extra);
+    switch (ntl) {
+        case 1: transform_body<1>(A, Bsw, C, M, NYP, m0, t0, lane); break;
+        case 2: transform_body<2>(A, Bsw, C, M, NYP, m0, t0, lane); break;
+        case 3: transform_body<3>(A, Bsw, C, M, NYP, m0, t0, lane); break;
+        case 4: transform_body<4>(A, Bsw, C, M, NYP, m0, t0, lane); break;
+        case 5: transform_body<5>(A, Bsw, C, M, NYP, m0, t0, lane); break;
+        case 6: transform_body<6>(A, Bsw, C, M, NYP, m0, t0, lane); break;
+        case 7: transform_body<7>(A, Bsw, C, M, NYP, m0, t0, lane); break;
+        default: break;
     }
 }
 
-// batched tridiagonal solve in z for every (system, eigenmode j): Thomas with precomputed
-// inverse pivots; in place on y[s][iz][j].
+// batched tridiagonal solve in z for every (system, eigenmode j): Thomas with precomputed inverse
+// pivots, in place on y[s][iz][j]; lanes = consecutive j (coalesced 1 KiB rows).  The recurrence is
+// serial in iz, so the kernel is latency-bound: coupling coefficients sit in LDS, rows are processed
+// in branch-free blocks of TB with the next block's operands already in flight, and the (< TB) tail
+// rows use a plain loop.
+constexpr int TB = 8;
+constexpr int MAXNZP = 1024;
 __global__ __launch_bounds__(64) void k_thomas(Solver k) {
     const int s = blockIdx.y;
     if (!k.active[s]) return;
+    __shared__ double sof[MAXNZP];
+    const int mode = s >= k.nFreq;
+    for (int i = threadIdx.x; i < k.NZP; i += 64) sof[i] = k.ofz[(long)mode * k.NZP + i];
+    __syncthreads();
     const int j = blockIdx.x * 64 + threadIdx.x;
     if (j >= k.ny - 1) return;
-    const int mode = s >= k.nFreq;
-    const double* of = k.ofz + (long)mode * k.NZP;
-    const cplx* ip = k.invp + (long)s * k.vstride + j;
-    cplx* y = k.y + (long)s * k.vstride + j;
-    const int nz = k.nz, NYP = k.NYP;
+    const cplx* __restrict__ ip = k.invp + (long)s * k.vstride + j;
+    cplx* __restrict__ y = k.y + (long)s * k.vstride + j;
+    const long NYP = k.NYP;
+    const int n = k.nz - 1;                             // rows 1..n
     cplx prev = cplx{0, 0};
-    for (int iz = 1; iz <= nz - 1; ++iz) {
-        cplx v = y[(long)iz * NYP];
-        if (iz > 1) v -= of[iz - 1] * prev;
-        prev = v * ip[(long)iz * NYP];
-        y[(long)iz * NYP] = prev;
+    cplx yv[TB], pv[TB];
+    // ---- forward: y'_iz = (y_iz - of_{iz-1} y'_{iz-1}) * invp_iz   (sof[0] = 0)
+    const int nfull = n / TB;
+    if (nfull > 0) {
+#pragma unroll
+        for (int t = 0; t < TB; ++t) { yv[t] = y[(1 + t) * NYP]; pv[t] = ip[(1 + t) * NYP]; }
+        for (int b = 0; b < nfull; ++b) {
+            const int nb = (b + 1 < nfull) ? b + 1 : b;  // last block re-reads itself (harmless)
+            cplx ny_[TB], np_[TB];
+#pragma unroll
+            for (int t = 0; t < TB; ++t) { ny_[t] = y[(1 + nb * TB + t) * NYP]; np_[t] = ip[(1 + nb * TB + t) * NYP]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                const int iz = 1 + b * TB + t;
+                cplx v = yv[t] - sof[iz - 1] * prev;
+                prev = v * pv[t];
+                y[iz * NYP] = prev;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                yv[t] = ny_[t]; pv[t] = np_[t];
+                asm volatile("" : "+v"(yv[t].re), "+v"(yv[t].im), "+v"(pv[t].re), "+v"(pv[t].im));
+            }
+        }
     }
-    for (int iz = nz - 2; iz >= 1; --iz) {
-        cplx v = y[(long)iz * NYP] - (of[iz] * ip[(long)iz * NYP]) * prev;
-        y[(long)iz * NYP] = v;
+    for (int iz = 1 + nfull * TB; iz <= n; ++iz) {
+        cplx v = y[iz * NYP] - sof[iz - 1] * prev;
+        prev = v * ip[iz * NYP];
+        y[iz * NYP] = prev;
+    }
+    // ---- backward: x_iz = y'_iz - (of_iz invp_iz) x_{iz+1}, iz = n-1 .. 1 ; prev = x_n
+    const int nb_ = n - 1, nfullb = nb_ / TB;           // rows n-1 .. 1
+    if (nfullb > 0) {
+#pragma unroll
+        for (int t = 0; t < TB; ++t) { yv[t] = y[(n - 1 - t) * NYP]; pv[t] = ip[(n - 1 - t) * NYP]; }
+        for (int b = 0; b < nfullb; ++b) {
+            const int nb = (b + 1 < nfullb) ? b + 1 : b;
+            cplx ny_[TB], np_[TB];
+#pragma unroll
+            for (int t = 0; t < TB; ++t) { ny_[t] = y[(n - 1 - nb * TB - t) * NYP]; np_[t] = ip[(n - 1 - nb * TB - t) * NYP]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                const int iz = n - 1 - b * TB - t;
+                cplx v = yv[t] - (sof[iz] * pv[t]) * prev;
+                y[iz * NYP] = v;
+                prev = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                yv[t] = ny_[t]; pv[t] = np_[t];
+                asm volatile("" : "+v"(yv[t].re), "+v"(yv[t].im), "+v"(pv[t].re), "+v"(pv[t].im));
+            }
+        }
+    }
+    for (int iz = n - 1 - nfullb * TB; iz >= 1; --iz) {
+        cplx v = y[iz * NYP] - (sof[iz] * ip[iz * NYP]) * prev;
+        y[iz * NYP] = v;
         prev = v;
     }
 }
@@ -325,11 +428,11 @@ __global__ __launch_bounds__(VBLOCK) void k_trueres(Solver k, const cplx* b, con
             const cplx c = p[e];
             const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
             cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
-            acc += k.cY[mo + e] * p[e + 1];
-            acc += k.cY[mo + e - 1] * p[e - 1];
-            acc += k.cZ[mo + e] * p[e + k.NYP];
-            acc += k.cZ[mo + e - k.NYP] * p[e - k.NYP];
             // boundary entries of x hold Dirichlet values: they belong to the right-hand side
+            if (iy + 1 <= k.ny - 1) acc += k.cY[mo + e] * p[e + 1];
+            if (iy - 1 >= 1) acc += k.cY[mo + e - 1] * p[e - 1];
+            if (iz + 1 <= k.nz - 1) acc += k.cZ[mo + e] * p[e + k.NYP];
+            if (iz - 1 >= 1) acc += k.cZ[mo + e - k.NYP] * p[e - k.NYP];
             rr += cabs2(b[so + e] - acc);
             bb += cabs2(b[so + e]);
         }
@@ -439,7 +542,7 @@ struct hmcmt_ctx {
     int lastItFwd = 0, lastItAdj = 0;
     bool haveModel = false;
     // profiling
-    bool prof = false;
+    unsigned profMask = 0;            // bit c: time category c with HIP events
     std::vector<hipEvent_t> evPool;
     std::vector<int> evCat;
     size_t evUsed = 0;
@@ -487,7 +590,7 @@ int dupload(hmcmt_ctx* ctx, T** p, const std::vector<T>& h) {
 struct ProfScope {
     hmcmt_ctx* c; int cat; size_t idx;
     ProfScope(hmcmt_ctx* ctx, int cat_) : c(ctx), cat(cat_), idx((size_t)-1) {
-        if (!c->prof) return;
+        if (!((c->profMask >> cat) & 1u)) return;
         if (c->evUsed + 2 > c->evPool.size()) {
             for (int i = 0; i < 512; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c->evPool.push_back(e); c->evCat.push_back(0); }
         }
@@ -499,7 +602,7 @@ struct ProfScope {
 };
 
 void prof_collect(hmcmt_ctx* c) {
-    if (!c->prof || c->evUsed == 0) return;
+    if (c->evUsed == 0) return;
     hipStreamSynchronize(c->stream);
     for (size_t i = 0; i + 1 < c->evUsed; i += 2) {
         float ms = 0;
@@ -513,17 +616,16 @@ void prof_collect(hmcmt_ctx* c) {
 
 inline dim3 grid1(int n, int b) { return dim3((n + b - 1) / b); }
 
-int launch_transform(hmcmt_ctx* ctx, const cplx* A, const double* B, cplx* C, const int* active) {
+int launch_transform(hmcmt_ctx* ctx, const cplx* A, const double* Bsw, cplx* C, const int* active) {
     const View& v = ctx->v;
     const int M = v.S * v.NZP, NT = v.NYP / 16;
-    const int tiles = (M + 7) / 8;
+    const int groups = (M + 7) / 8;
+    const int NW = std::min(4, (NT + 6) / 7);
+    if ((NT + NW - 1) / NW > 7) { ctx->err = "mesh too wide for the transform kernel (ny+1 > 448)"; return HMCMT_EINVAL; }
+    const int RG = std::max(1, 4 / NW);
     ProfScope ps(ctx, 0);
-    if (NT > 4) {
-        const int NW = (NT + 6) / 7;
-        hipLaunchKernelGGL(k_transform<7>, dim3(tiles), dim3(64 * NW), 0, ctx->stream, A, B, C, M, v.NYP, v.NZP, active);
-    } else {
-        hipLaunchKernelGGL(k_transform<4>, dim3(tiles), dim3(64), 0, ctx->stream, A, B, C, M, v.NYP, v.NZP, active);
-    }
+    hipLaunchKernelGGL(k_transform, dim3((groups + RG - 1) / RG), dim3(64 * NW * RG), 0, ctx->stream, A, Bsw, C, M,
+                       v.NYP, v.NZP, active, NW, RG);
     return 0;
 }
 
@@ -719,6 +821,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { ctx->err = "no HIP device available (this library has no host compute path)"; return HMCMT_ENODEV; }
     if (device_id < 0 || device_id >= ndev) { ctx->err = "device_id out of range"; return HMCMT_ENODEV; }
     ctx->device = device_id;
+    if (ctx->hp.NZP > MAXNZP) { ctx->err = "nz too large for the tridiagonal kernel (nz+1 > 1024)"; return HMCMT_EINVAL; }
     HIPCHK(hipSetDevice(device_id));
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     const HostProblem& h = ctx->hp;
@@ -734,8 +837,22 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     UP(predSys, h.predSys) UP(predRx, h.predRx) UP(datSys, h.datSys) UP(datRx, h.datRx)
     UP(obs, h.obs) UP(dataW, h.dataW) UP(srStart, h.srStart) UP(srList, h.srList)
 #undef UP
-    if ((rc = dupload(ctx, &ctx->d_V, h.Vpad))) return rc;
-    if ((rc = dupload(ctx, &ctx->d_Vt, h.Vtpad))) return rc;
+    {
+        // fragment-order copies of V and V' (see k_transform)
+        const int NT = h.NYP / 16, KG = h.NYP / 16;
+        auto swz = [&](const std::vector<double>& B) {
+            std::vector<double> o((size_t)h.NYP * h.NYP);
+            for (int kg = 0; kg < KG; ++kg)
+                for (int t = 0; t < NT; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int i = 0; i < 4; ++i)
+                            o[(((size_t)kg * NT + t) * 64 + lane) * 4 + i] =
+                                B[(size_t)(16 * kg + 4 * (lane / 16) + i) * h.NYP + 16 * t + lane % 16];
+            return o;
+        };
+        if ((rc = dupload(ctx, &ctx->d_V, swz(h.Vpad)))) return rc;
+        if ((rc = dupload(ctx, &ctx->d_Vt, swz(h.Vtpad)))) return rc;
+    }
 #define DA(ptr, n) if ((rc = dalloc(ctx, &(ptr), (n)))) return rc;
     DA(v.sigma, h.nCell) DA(v.sigMeanA, h.nz) DA(v.sigMeanG, h.nz)
     DA(v.cY, 2 * VS) DA(v.cZ, 2 * VS) DA(v.dK, 2 * VS) DA(v.dM, 2 * VS)
@@ -901,7 +1018,7 @@ int hmcmt_get_fields(hmcmt_ctx* ctx, int32_t adjoint, double* exTE, double* hxTM
 
 int hmcmt_profile(hmcmt_ctx* ctx, int32_t enable) {
     if (!ctx) return HMCMT_EINVAL;
-    ctx->prof = enable != 0;
+    ctx->profMask = (unsigned)enable;
     ctx->evUsed = 0;
     for (int i = 0; i < HMCMT_NCAT; ++i) { ctx->profMs[i] = 0; ctx->profN[i] = 0; }
     return 0;

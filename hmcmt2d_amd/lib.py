@@ -224,7 +224,14 @@ class HipContext:
 
     # -- instrumentation ----------------------------------------------------------------------
     def profile(self, enable=True):
-        self._check(self.lib.hmcmt_profile(self.h, int(enable)))
+        """enable: True (all categories), False, or an iterable of category names to time."""
+        if enable is True:
+            mask = (1 << HMCMT_NCAT) - 1
+        elif not enable:
+            mask = 0
+        else:
+            mask = sum(1 << CATEGORIES.index(c) for c in enable)
+        self._check(self.lib.hmcmt_profile(self.h, mask))
 
     def profile_read(self):
         ms = np.zeros(HMCMT_NCAT)

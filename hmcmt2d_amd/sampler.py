@@ -1,0 +1,303 @@
+"""Host-side mirror of the reference sampler API on top of the HIP library.
+
+Same function names, argument order and return values as HMCMT/src/HMCSampler/HMCSampler.jl:
+`compDataGradient` (:277-330), `getHamiltonian` (:358-397), `proposeLeapfrog` (:206-269),
+`getKineticEnergy` / `getKineticGradient` (:407-431), `getMomentumVector` (:441-453),
+`setMassMatrix` (:463-474), `checkParameterBound` (:515-559), `runHMCSampler` (:72-196) and
+`parallelHMCSampler` (parallelHMC.jl:10-49).  The only compute they do themselves is O(nparam)
+vector arithmetic; the forward / adjoint solves go through `HipContext` (include/hmcmt.h).
+
+Differences that are deliberate and documented:
+  * random numbers come from an explicit `numpy.random.Generator` (the reference uses Julia's
+    unseeded global RNG, so sample-level parity with it is impossible by construction);
+  * `getHamiltonian` reuses the forward response of the last gradient evaluation when it was
+    computed at the same model (the reference repeats an identical forward solve,
+    HMCSampler.jl:251 vs :364); `reuse_forward=False` restores the reference's cost structure;
+  * a non-finite model raises instead of spinning forever in the bound reflection (:546-548).
+"""
+from __future__ import annotations
+
+import time
+import numpy as np
+
+from .lib import HipContext
+from .structs import HMCParameter, HMCStatus, initHMCParameter, initHMCStatus
+
+_contexts: dict = {}
+
+
+def get_context(mtMesh, mtData, invParam, device_id=0, **opts) -> HipContext:
+    """One HIP context per InvDataModel (created lazily, cached)."""
+    key = id(invParam)
+    ctx = _contexts.get(key)
+    if ctx is None:
+        ctx = HipContext(mtMesh, mtData, invParam, device_id=device_id, **opts)
+        ctx._cache = None
+        _contexts[key] = ctx
+    return ctx
+
+
+def release_context(invParam):
+    ctx = _contexts.pop(id(invParam), None)
+    if ctx is not None:
+        ctx.close()
+
+
+def _check_solver(hmcprior):
+    if hmcprior.linearSolver.lower() not in ("", "hip"):
+        raise ValueError(f"linearsolver {hmcprior.linearSolver!r}: this package only has the HIP path "
+                         "(use `linearsolver: hip`)")
+
+
+# --------------------------------------------------------------------------------------------
+def compDataGradient(mtMesh, mtData, invParam, hmcprior, ctx: HipContext | None = None):
+    """m = invParam.strModel -> (predData, dataMisfit, dataGrad)."""
+    _check_solver(hmcprior)
+    ctx = ctx or get_context(mtMesh, mtData, invParam)
+    m = np.asarray(invParam.strModel, dtype=np.float64)
+    pred, misfit, grad = ctx.grad(m)
+    sigma = invParam.bgModel.copy()
+    sigma[invParam.activeIdx] += np.exp(m)
+    mtMesh.sigma = sigma                                   # HMCSampler.jl:294
+    ctx._cache = (m.copy(), pred, misfit)
+    return pred, misfit, grad
+
+
+def compDataMisfit(predData, invParam):
+    res = invParam.dataW * (predData - invParam.obsData)
+    return 0.5 * float(np.real(np.vdot(res, res)))
+
+
+def getKineticEnergy(momentum, hmcParam: HMCParameter):
+    return 0.5 * float(np.dot(momentum, hmcParam.invM * momentum))
+
+
+def getKineticGradient(momentum, hmcParam: HMCParameter):
+    return hmcParam.invM * momentum
+
+
+def getMomentumVector(nparam, hmcParam: HMCParameter, rng):
+    mp = np.clip(rng.standard_normal(nparam), -2.5, 2.5)   # clipped N(0,1), HMCSampler.jl:444-447
+    return hmcParam.sqrtM * mp
+
+
+def setMassMatrix(nparam, scaling=1.0):
+    mass = scaling * np.ones(nparam)
+    return 1.0 / mass, np.sqrt(mass)
+
+
+def checkParameterBound(model, momentum, hmcprior):
+    """Reflect at the ln(sigma) bounds and flip the momentum (vectorised; same fixed point as the
+    reference's per-element while loop)."""
+    lo, hi = np.log(hmcprior.sigBounds[0]), np.log(hmcprior.sigBounds[1])
+    if not (np.all(np.isfinite(model)) and hi > lo):
+        raise FloatingPointError("non-finite model value in checkParameterBound")
+    for _ in range(500):
+        below, above = model < lo, model > hi
+        if not (below.any() or above.any()):
+            return model, momentum
+        model = np.where(below, 2.0 * lo - model, model)
+        momentum = np.where(below, -momentum, momentum)
+        above = model > hi
+        model = np.where(above, 2.0 * hi - model, model)
+        momentum = np.where(above, -momentum, momentum)
+    raise FloatingPointError("bound reflection did not terminate")
+
+
+def getHamiltonian(mtData, mtMesh, invParam, hmcprior, hmcParam: HMCParameter,
+                   ctx: HipContext | None = None, reuse_forward=True):
+    """(dataMisfit, kinetic, hamiltonian, mnorm, predData) at invParam.strModel."""
+    _check_solver(hmcprior)
+    ctx = ctx or get_context(mtMesh, mtData, invParam)
+    m = np.asarray(invParam.strModel, dtype=np.float64)
+    cache = getattr(ctx, "_cache", None)
+    if reuse_forward and cache is not None and np.array_equal(cache[0], m):
+        pred, misfit = cache[1], cache[2]
+    else:
+        pred, misfit = ctx.forward(m)
+        ctx._cache = (m.copy(), pred, misfit)
+    kp = getKineticEnergy(hmcParam.momentum, hmcParam)
+    mprior = m - invParam.refModel
+    mnorm = 0.5 * float(mprior @ (invParam.Wm @ mprior)) * hmcprior.regParam
+    return misfit, kp, misfit + kp + mnorm, mnorm, pred
+
+
+def proposeLeapfrog(hmcParamCurrent: HMCParameter, mtMesh, mtData, invParam, hmcprior, rng=None,
+                    intstep=None, ctx: HipContext | None = None):
+    """Leapfrog trajectory; L ~ U{timestep[0]..timestep[1]} unless `intstep` is given."""
+    ctx = ctx or get_context(mtMesh, mtData, invParam)
+    currModel = hmcParamCurrent.rhomodel
+    currMomentum = hmcParamCurrent.momentum
+    invParam.strModel = currModel.copy()
+    _, _, dataGrad = compDataGradient(mtMesh, mtData, invParam, hmcprior, ctx)
+    hmcprior.nfevals += 1
+    refModel, Wm = invParam.refModel, invParam.Wm
+    dataGrad = dataGrad + (Wm @ (currModel - refModel)) * hmcprior.regParam
+    dt = hmcprior.dt
+    propMomentum = currMomentum - 0.5 * dt * dataGrad
+    propModel = currModel.copy()
+    if intstep is None:
+        intstep = int(rng.integers(hmcprior.timestep[0], hmcprior.timestep[1] + 1))
+    maxStepSize = 3.0
+    for k in range(1, intstep + 1):
+        dm = dt * getKineticGradient(propMomentum, hmcParamCurrent)
+        dmMax = np.max(np.abs(dm))
+        if dmMax > maxStepSize:
+            dm = dm / dmMax * maxStepSize
+        propModel = propModel + dm
+        propModel, propMomentum = checkParameterBound(propModel, propMomentum, hmcprior)
+        invParam.strModel = propModel.copy()
+        _, _, dataGrad = compDataGradient(mtMesh, mtData, invParam, hmcprior, ctx)
+        hmcprior.nfevals += 1
+        dataGrad = dataGrad + (Wm @ (propModel - refModel)) * hmcprior.regParam
+        delta = dt * dataGrad
+        propMomentum = propMomentum - (delta if k < intstep else 0.5 * delta)
+    return propModel, propMomentum
+
+
+def runHMCSampler(mtMesh, mtData, invParam, hmcprior, rng=None, rhoref=None, ctx: HipContext | None = None,
+                  verbose=False, reuse_forward=True):
+    """Returns (hmcmodel[nparam, nsamples], hmcstats, hmcdata[ndata, nsamples+1])."""
+    _check_solver(hmcprior)
+    rng = rng or np.random.default_rng()
+    ctx = ctx or get_context(mtMesh, mtData, invParam)
+    nparam, ndata = len(invParam.strModel), len(invParam.obsData)
+    if hmcprior.massType != "diagonal":
+        raise NotImplementedError("only the reference's default diagonal mass matrix is supported "
+                                  "(the dense variant needs nparam^2 memory, SURVEY App. B.14)")
+    cur = initHMCParameter(nparam)
+    cur.invM, cur.sqrtM = setMassMatrix(nparam, 1.0)
+    cur.rhomodel = invParam.strModel.copy()               # file start model stays the chain state (:88)
+    cur.momentum = getMomentumVector(nparam, cur, rng)
+    prop = HMCParameter(nparam, cur.rhomodel.copy(), cur.momentum.copy(), cur.invM, cur.sqrtM)
+    # random homogeneous start / reference model (:100-109)
+    rho0 = 1.0 / np.exp(invParam.strModel[0])
+    if rhoref is None:
+        rhoref = np.round(rho0 * 0.5 + (rho0 * 1.5 - rho0 * 0.5) * rng.random())
+    if verbose:
+        print(f"Homogeneous starting model with a resistivity of {rhoref} Ωm is used.")
+    strModel = np.log(np.ones(nparam) / rhoref)
+    invParam.strModel = strModel.copy()
+    invParam.refModel = strModel.copy()
+    startD, startK, startH, startM, predData = getHamiltonian(mtData, mtMesh, invParam, hmcprior, cur, ctx,
+                                                              reuse_forward)
+    nsamples = hmcprior.totalsamples
+    hmcmodel = np.zeros((nparam, nsamples))
+    hmcdata = np.zeros((ndata, nsamples + 1), dtype=np.complex128)
+    stats: HMCStatus = initHMCStatus(nsamples)
+    stats.hmstats[:, 0] = [startD, startM, startK, startH]
+    hmcdata[:, 0] = predData
+    for it in range(1, nsamples + 1):
+        propModel, propMomentum = proposeLeapfrog(cur, mtMesh, mtData, invParam, hmcprior, rng, None, ctx)
+        prop.rhomodel, prop.momentum = propModel.copy(), propMomentum.copy()
+        finishD, finishK, finishH, finishM, predData = getHamiltonian(mtData, mtMesh, invParam, hmcprior, prop,
+                                                                      ctx, reuse_forward)
+        hdif = startH - finishH
+        aratio = rng.random()
+        if hdif > 0 or aratio < np.exp(hdif):
+            cur.rhomodel, cur.momentum = propModel.copy(), propMomentum.copy()
+            startD, startM = finishD, finishM
+            stats.nAccept += 1
+            stats.acceptstats[it - 1] = True
+            hmcdata[:, it] = predData
+        else:
+            stats.nReject += 1
+            hmcdata[:, it] = hmcdata[:, it - 1]
+        if verbose:
+            print(f"iterNo={it:6d} dtMisfit={finishD:8.3e} mNorm={finishM:8.3e} KEnergy={finishK:8.3e} "
+                  f"HEnergy={finishH:8.3e} {'accepted' if stats.acceptstats[it - 1] else 'rejected'} "
+                  f"p={min(1.0, float(np.exp(min(hdif, 0.0)))):.3f}")
+        cur.momentum = getMomentumVector(nparam, cur, rng)
+        startK = getKineticEnergy(cur.momentum, cur)
+        startH = startD + startM + startK
+        stats.hmstats[:, it] = [startD, startM, startK, startH]
+        hmcmodel[:, it - 1] = cur.rhomodel
+    return hmcmodel, stats, hmcdata
+
+
+# --------------------------------------------------------------------------------------------
+def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, outdir=None, nchains=None,
+                       run_chain=None):
+    """Independent chains, one process per GPU (parallelHMC.jl:10-49).
+
+    With `torch.distributed` initialised (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
+    CPU tests) rank r runs chains r, r+W, ... on its own GPU with RNG stream (seed, chain) and the
+    sample blocks are ALL-GATHERED so every rank holds every chain; rank 0 writes the per-chain
+    files the reference writes.  Without a process group the chains run one after another.
+    `pids` is kept for signature parity: its length is the number of chains (default: world size).
+    `run_chain(chain_index, rng)` can replace the sampler (used by the CPU tests).
+    Returns (hmcmodel[list], hmcstats[list], hmcdata[list]) indexed by chain.
+    """
+    import copy
+    try:
+        import torch
+        import torch.distributed as dist
+        have_pg = dist.is_available() and dist.is_initialized()
+    except Exception:                                       # pragma: no cover
+        have_pg = False
+    world, rank = (dist.get_world_size(), dist.get_rank()) if have_pg else (1, 0)
+    if nchains is None:
+        nchains = len(pids) if pids is not None else world
+    mine = list(range(rank, nchains, world))
+    results = {}
+    for c in mine:
+        rng = np.random.default_rng([seed, c])
+        t0 = time.time()
+        if run_chain is not None:
+            model, stats, data = run_chain(c, rng)
+        else:
+            inv_c, prior_c, mesh_c = copy.deepcopy(invParam), copy.deepcopy(hmcprior), copy.deepcopy(mtMesh)
+            model, stats, data = runHMCSampler(mesh_c, mtData, inv_c, prior_c, rng)
+            release_context(inv_c)
+        results[c] = (model, stats, data, time.time() - t0)
+
+    nparam, nsamples = next(iter(results.values()))[0].shape if results else (len(invParam.strModel), hmcprior.totalsamples)
+    ndata = len(invParam.obsData)
+    per = (nchains + world - 1) // world                   # chain slots per rank (padded)
+    blk = nparam * nsamples + 4 * (nsamples + 1) + nsamples + 2 * ndata * (nsamples + 1) + 2
+
+    def pack(slot):
+        c = rank + slot * world
+        buf = np.zeros(blk)
+        if c in results:
+            model, stats, data, secs = results[c]
+            o = 0
+            buf[o:o + model.size] = model.reshape(-1); o += model.size
+            buf[o:o + stats.hmstats.size] = stats.hmstats.reshape(-1); o += stats.hmstats.size
+            buf[o:o + nsamples] = stats.acceptstats.astype(float); o += nsamples
+            buf[o:o + 2 * data.size] = data.reshape(-1).view(np.float64); o += 2 * data.size
+            buf[o] = secs; buf[o + 1] = 1.0
+        return buf
+
+    local = np.concatenate([pack(s) for s in range(per)]) if per else np.zeros(0)
+    if have_pg and world > 1:
+        use_cuda = dist.get_backend() == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+        send = torch.from_numpy(local).to(dev)
+        recv = torch.empty(world * local.size, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(recv, send)             # RCCL ring over xGMI on the GPU box
+        allbuf = recv.cpu().numpy().reshape(world, per, blk)
+    else:
+        allbuf = local.reshape(1, per, blk)
+
+    hmcmodel, hmcstats, hmcdata, secs = [None] * nchains, [None] * nchains, [None] * nchains, [0.0] * nchains
+    for r in range(world):
+        for s in range(per):
+            c = r + s * world
+            if c >= nchains:
+                continue
+            buf = allbuf[r, s]
+            o = 0
+            model = buf[o:o + nparam * nsamples].reshape(nparam, nsamples).copy(); o += nparam * nsamples
+            hm = buf[o:o + 4 * (nsamples + 1)].reshape(4, nsamples + 1).copy(); o += 4 * (nsamples + 1)
+            acc = buf[o:o + nsamples] > 0.5; o += nsamples
+            data = buf[o:o + 2 * ndata * (nsamples + 1)].copy().view(np.complex128).reshape(ndata, nsamples + 1)
+            o += 2 * ndata * (nsamples + 1)
+            secs[c] = float(buf[o])
+            hmcmodel[c], hmcdata[c] = model, data
+            hmcstats[c] = HMCStatus(int(acc.sum()), int((~acc).sum()), acc, hm)
+    if outdir is not None and rank == 0:
+        from .fileio import outputHMCSamples
+        for c in range(nchains):
+            outputHMCSamples(hmcmodel[c], hmcstats[c], hmcdata[c], ichain=c + 1, cputime=secs[c], outdir=outdir)
+    return hmcmodel, hmcstats, hmcdata

@@ -1,0 +1,58 @@
+"""The C-ABI shared library: builds for gfx950, loads, exports every symbol include/hmcmt.h declares,
+and refuses to run without a HIP device (no CPU fallback).  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from hmcmt2d_amd import lib as L
+from tests.conftest import HAVE_GPU, ROOT
+
+
+@pytest.fixture(scope="module")
+def so():
+    return ctypes.CDLL(L.build_library())
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "hmcmt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hmcmt_[a-z_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(so):
+    names = declared_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(so, n), f"{n} declared in include/hmcmt.h but not exported"
+    assert set(names) == set(L.EXPORTED_SYMBOLS)
+
+
+def test_default_options(so):
+    o = L.Options()
+    L.load_library().hmcmt_default_options(ctypes.byref(o))
+    assert o.precond == 1 and o.maxit >= 100 and 0 < o.tol < 1e-8 and o.check_every >= 1
+
+
+@pytest.mark.skipif(HAVE_GPU, reason="checks the no-device error path")
+def test_create_fails_loudly_without_a_device():
+    from tests.helpers import make_problem
+    mesh, data, inv, m = make_problem("tiny")
+    with pytest.raises(L.HmcmtError) as e:
+        L.HipContext(mesh, data, inv)
+    assert e.value.code == -2 and "no host compute path" in str(e.value)
+
+
+def test_create_rejects_bad_arguments_before_touching_the_device():
+    from tests.helpers import make_problem
+    import numpy as np
+    mesh, data, inv, m = make_problem("tiny")
+    data.rxLoc = data.rxLoc.copy(); data.rxLoc[:, 1] = 37.0      # no grid node at that depth
+    with pytest.raises(L.HmcmtError) as e:
+        L.HipContext(mesh, data, inv)
+    assert e.value.code == -1 and "receiver depth" in str(e.value)
+    mesh, data, inv, m = make_problem("tiny")
+    data.dataType = "Rho_Pha"
+    with pytest.raises(ValueError):
+        L.HipContext(mesh, data, inv)

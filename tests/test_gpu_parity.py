@@ -1,0 +1,192 @@
+"""Parity of the HIP path (called through the C ABI, include/hmcmt.h) with the oracle.
+
+Tolerances (fp64 / complex128 arithmetic throughout):
+  predData, misfit : 1e-9 relative  -- iterative solves stop at an error estimate of 1e-11
+  gradient         : 1e-7 relative to max|g| -- the floor is the reference's own numerically unstable
+                     bottom-boundary sensitivity row (rounding noise), not the solver
+  fields           : 1e-8 absolute on receiver rows; deep boundary values differ by the rounding-
+                     dependent layer of the reference's overflow cut-off (mt1DField.jl:76-82)
+"""
+import os
+import numpy as np
+import pytest
+
+from hmcmt2d_amd.lib import HipContext, HmcmtError
+from hmcmt2d_amd.structs import HMCPrior
+from tests.helpers import GOLDEN, make_problem, oracle_eval, relmax
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny_ctx():
+    mesh, data, inv, m = make_problem("tiny")
+    ctx = HipContext(mesh, data, inv, verify=True)
+    yield mesh, data, inv, m, ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg2"])
+def test_gradient_parity_with_oracle_and_golden(name):
+    mesh, data, inv, m = make_problem(name)
+    ctx = HipContext(mesh, data, inv, verify=True)
+    pred, misfit, grad = ctx.grad(m)
+    st = ctx.stats()
+    po, mo, go = oracle_eval(mesh, data, inv, m)
+    assert relmax(pred, po) < 1e-9
+    assert abs(misfit - mo) / mo < 1e-9
+    assert relmax(grad, go) < 1e-7
+    g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    assert relmax(pred, g["pred"]) < 1e-9 and relmax(grad, g["grad"]) < 1e-7
+    assert st["status"] == 0 and st["true_res_max"] < 1e-8 and st["err_est_max"] < 1e-10
+    assert st["iters_fwd_max"] < 40 and st["iters_adj_max"] < 40
+    # receiver-row fields in the reference layout
+    ex, hx = ctx.fields()
+    ny = mesh.gridSize[0]; zid = len(mesh.airLayer)
+    rows = slice(zid * (ny + 1), (zid + 2) * (ny + 1))
+    assert np.abs(ex[rows] - g["exTE_rx"]).max() < 1e-8 and np.abs(hx[rows] - g["hxTM_rx"]).max() < 1e-8
+    ctx.close()
+
+
+def test_forward_only_equals_gradient_forward(tiny_ctx):
+    mesh, data, inv, m, ctx = tiny_ctx
+    p1, f1, _ = ctx.grad(m)
+    p2, f2 = ctx.forward(m)
+    assert np.array_equal(p1, p2) and f1 == f2            # same kernels, deterministic reductions
+
+
+def test_repeatability_bitwise(tiny_ctx):
+    mesh, data, inv, m, ctx = tiny_ctx
+    a = ctx.grad(m)
+    b = ctx.grad(m)
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
+
+
+def test_jacobi_and_fdm_preconditioners_agree(tiny_ctx):
+    mesh, data, inv, m, ctx = tiny_ctx
+    p1, f1, g1 = ctx.grad(m)
+    it_fdm = ctx.iters().max()
+    ctx.set_options(precond="jacobi", maxit=20000)
+    p0, f0, g0 = ctx.grad(m)
+    it_jac = ctx.iters().max()
+    ctx.set_options(precond="fdm", maxit=2000)
+    assert relmax(p0, p1) < 1e-9 and relmax(g0, g1) < 1e-7 and it_jac > 3 * it_fdm
+
+
+def test_kernels_against_host_instantiation(tiny_ctx):
+    """transform / SpMV / preconditioner kernels vs the same arithmetic on the host."""
+    from tests.emul.emul_py import Emul
+    mesh, data, inv, m, ctx = tiny_ctx
+    ctx.grad(m)
+    E = Emul(mesh, data, inv); E.grad(m, False)
+    shape = (ctx.S, ctx.NZP, ctx.NYP)
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    V = E.get("Vpad").reshape(ctx.NYP, ctx.NYP)
+    assert relmax(ctx.debug_transform(0, A).reshape(shape), A @ V) < 1e-13
+    assert relmax(ctx.debug_transform(1, A).reshape(shape), A @ V.T) < 1e-13
+    P = np.zeros(shape, complex); P[:, 1:ctx.nz, 1:ctx.ny] = A[:, 1:ctx.nz, 1:ctx.ny]
+    assert relmax(ctx.debug_spmv(P), E.apply("spmv", P)) < 1e-13
+    assert relmax(ctx.debug_precond(P), E.apply("fdm", P)) < 1e-11
+
+
+def test_operator_symmetry_properties():
+    """Size-independent properties at the headline size (cfg3): A and P^-1 are complex symmetric
+    (x'Ay = y'Ax unconjugated) and linear -- what COCG relies on."""
+    mesh, data, inv, m = make_problem("cfg3")
+    ctx = HipContext(mesh, data, inv)
+    ctx.forward(m)
+    shape = (ctx.S, ctx.NZP, ctx.NYP)
+    rng = np.random.default_rng(1)
+
+    def rand():
+        v = np.zeros(shape, complex)
+        v[:, 1:ctx.nz, 1:ctx.ny] = rng.standard_normal((ctx.S, ctx.nz - 1, ctx.ny - 1)) + 1j * rng.standard_normal((ctx.S, ctx.nz - 1, ctx.ny - 1))
+        return v
+
+    x, y = rand(), rand()
+    for op in (ctx.debug_spmv, ctx.debug_precond):
+        Ax, Ay = op(x).reshape(shape), op(y).reshape(shape)
+        a = np.sum(y * Ax, axis=(1, 2)); b = np.sum(x * Ay, axis=(1, 2))
+        assert np.max(np.abs(a - b) / np.abs(a)) < 1e-9
+        lin = op(2.0 * x + (0.5 - 1j) * y).reshape(shape)
+        assert relmax(lin, 2.0 * Ax + (0.5 - 1j) * Ay) < 1e-10
+    ctx.close()
+
+
+def test_headline_size_gradient_checks():
+    """cfg3 (200x100 cells, 16 freq): FDM vs looser tolerance consistency, directional finite
+    difference of the GPU misfit along an interior-cell direction, and convergence statistics."""
+    mesh, data, inv, m = make_problem("cfg3")
+    ctx = HipContext(mesh, data, inv, verify=True)
+    pred, f0, g = ctx.grad(m)
+    st = ctx.stats()
+    assert st["status"] == 0 and st["true_res_max"] < 1e-8 and st["iters_fwd_max"] < 60
+    ny = mesh.gridSize[0]
+    d = np.zeros(len(m))
+    core = [(kz, ky) for kz in range(3, 12) for ky in range(90, 110)]          # shallow core cells
+    rng = np.random.default_rng(3)
+    for kz, ky in core:
+        d[kz * ny + ky] = rng.standard_normal()
+    h = 1e-4
+    fp = ctx.forward(m + h * d)[1]; fm = ctx.forward(m - h * d)[1]
+    fd = (fp - fm) / (2 * h)
+    assert abs(fd - g @ d) / abs(fd) < 5e-3
+    ctx.set_options(tol=1e-8)
+    _, f1, g1 = ctx.grad(m)
+    assert abs(f1 - f0) / f0 < 1e-6 and relmax(g1, g) < 1e-5
+    ctx.close()
+
+
+def test_error_paths(tiny_ctx):
+    mesh, data, inv, m, ctx = tiny_ctx
+    bad = m.copy(); bad[3] = np.nan
+    with pytest.raises(HmcmtError) as e:
+        ctx.grad(bad)
+    assert e.value.code == -11
+    ctx.set_options(maxit=2)
+    with pytest.raises(HmcmtError) as e:
+        ctx.grad(m)
+    assert e.value.code == -10
+    ctx.set_options(maxit=2000)
+    with pytest.raises(ValueError):
+        ctx.grad(m[:-1])
+    p, f, g = ctx.grad(m)                                  # context still usable afterwards
+    assert np.isfinite(f)
+
+
+def test_te_only_data_subset():
+    """Only ZXY data at a subset of frequencies/receivers: TM systems are skipped, masks honoured."""
+    from hmcmt2d_amd import synthetic as S, invsetup as I
+    from hmcmt2d_amd.structs import MTData
+    mesh, data, inv, m = make_problem("tiny")
+    keepm = (data.dtID == 1) & ~((data.freqID == 2) & (data.rxID == 3))
+    nF, nR = len(data.freqs), data.rxLoc.shape[0]
+    dataID = np.zeros((nF, nR, 1), bool)
+    dataID[data.freqID[keepm] - 1, data.rxID[keepm] - 1, 0] = True
+    d2 = MTData(data.rxLoc, data.freqs, "Impedance", ["ZXY"], data.rxID[keepm], data.freqID[keepm],
+                np.ones(keepm.sum(), np.int64), dataID.reshape(-1), True, False)
+    inv2 = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0, 0, inv.obsData[keepm], (1.0 / inv.dataW)[keepm])
+    ctx = HipContext(mesh, d2, inv2)
+    pred, f, g = ctx.grad(m)
+    po, fo, go = oracle_eval(mesh, d2, inv2, m)
+    assert relmax(pred, po) < 1e-9 and abs(f - fo) / fo < 1e-9 and relmax(g, go) < 1e-7
+    assert ctx.iters()[:, nF:].max() == 0                  # no TM iterations at all
+    ctx.close()
+
+
+def test_sampler_short_chain_on_gpu_matches_oracle_chain():
+    """Identical short chains: oracle (direct solver) vs HIP (iterative) under the same Generator."""
+    import copy
+    from oracle import hmcmt_oracle as O
+    from hmcmt2d_amd import sampler
+    mesh, data, inv, m = make_problem("tiny")
+    prior = HMCPrior(totalsamples=3, burninsamples=1, dt=0.02, timestep=[2, 3], sigBounds=[1e-4, 1.0])
+    mesh_o, inv_o, prior_o = copy.deepcopy(mesh), copy.deepcopy(inv), copy.deepcopy(prior)
+    O.setupTensorMesh2D(mesh_o)
+    mo, so, do = O.runHMCSampler(mesh_o, data, inv_o, prior_o, np.random.default_rng(5), dense_dbc=False)
+    inv_p, prior_p = copy.deepcopy(inv), copy.deepcopy(prior)
+    mp, sp_, dp = sampler.runHMCSampler(copy.deepcopy(mesh), data, inv_p, prior_p, np.random.default_rng(5))
+    sampler.release_context(inv_p)
+    assert np.array_equal(sp_.acceptstats, so["acceptstats"])
+    assert relmax(mp, mo) < 1e-7 and relmax(dp, do) < 1e-7 and relmax(sp_.hmstats, so["hmstats"]) < 1e-7

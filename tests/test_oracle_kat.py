@@ -1,0 +1,125 @@
+"""Known-answer tests that pin the oracle (the reference ships no tests for this path)."""
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+import pytest
+
+from oracle import hmcmt_oracle as O
+from hmcmt2d_amd import synthetic as S, invsetup as I
+from hmcmt2d_amd.structs import HMCPrior
+from tests.helpers import make_problem, oracle_eval
+
+
+def divgrad(n1, n2, n3):
+    """Div*Div' of MUMPS/test/getDivGrad.jl:3-13."""
+    e = sp.identity
+    D1 = sp.kron(e(n3), sp.kron(e(n2), O.ddx(n1)))
+    D2 = sp.kron(e(n3), sp.kron(O.ddx(n2), e(n1)))
+    D3 = sp.kron(O.ddx(n3), sp.kron(e(n2), e(n1)))
+    Div = sp.hstack([D1, D2, D3])
+    return (Div @ Div.T).tocsc()
+
+
+def test_direct_solver_meets_mumps_residual_bar():
+    """MUMPS/test/testDivGrad.jl:16-59: relative residual < 1e-14 (real SPD and complex symmetric,
+    single and 10 right-hand sides) for the direct solve the oracle uses."""
+    rng = np.random.default_rng(0)
+    A = divgrad(16, 16, 8)
+    n = A.shape[0]
+    lu = spla.splu(A)
+    for nrhs in (1, 10):
+        b = rng.standard_normal((n, nrhs))
+        x = lu.solve(b)
+        assert np.max(np.linalg.norm(A @ x - b, axis=0) / np.linalg.norm(b, axis=0)) < 1e-14
+    Ac = (A + 1j * sp.diags(rng.random(n))).tocsc()
+    luc = spla.splu(Ac)
+    b = rng.standard_normal((n, 10)) + 1j * rng.standard_normal((n, 10))
+    x = luc.solve(b)
+    assert x.dtype == np.complex128
+    assert np.max(np.linalg.norm(Ac @ x - b, axis=0) / np.linalg.norm(b, axis=0)) < 1e-14
+
+
+def test_halfspace_impedance_matches_example_data_scale():
+    """|Z| over a 100 Ohm-m half-space at 100 Hz is 0.1987(1+i) (cf. the first rows of
+    HMCMT/examples/dprism3d/dprism2dobs.dat: 0.2005+0.1987i, -0.1815-0.1987i)."""
+    zNode = np.concatenate([[0.0], np.cumsum(np.full(30, 100.0))])
+    e, h = O.mt1DAnalyticField(100.0, np.full(30, 0.01), zNode, True)
+    Z = e[0] / h[0]
+    assert abs(Z.real - 0.19869) < 2e-5 and abs(Z.imag - 0.19869) < 2e-5
+
+
+def test_layered_model_2d_equals_1d():
+    """Laterally uniform model: Zxy ~ +Z1D, Zyx ~ -Z1D up to discretisation error."""
+    mesh, data, _ = S.make_config("tiny")
+    O.setupTensorMesh2D(mesh)
+    mesh.sigma = S.true_model_sigma(mesh, block=False)
+    pred, _ = O.MT2DFwdSolver(mesh, data)
+    ny, nz = mesh.gridSize
+    nair = len(mesh.airLayer)
+    zNode = np.concatenate([[0.0], np.cumsum(mesh.zLen)])
+    Z = pred.reshape(len(data.freqs), -1, 2)
+    for f, freq in enumerate(data.freqs):
+        e, h = O.mt1DAnalyticField(freq, mesh.sigma.reshape(nz, ny)[:, 0], zNode, True)
+        z1 = e[nair] / h[nair]
+        assert np.all(np.abs(Z[f, :, 0] - z1) / abs(z1) < 0.02)
+        assert np.all(np.abs(Z[f, :, 1] + z1) / abs(z1) < 0.02)
+
+
+def test_system_matrices_are_complex_symmetric_five_point():
+    mesh, data, inv, m = make_problem("tiny")
+    keep = {}
+    oracle_eval(mesh, data, inv, m, keep=keep)
+    for A in keep["Aii"].values():
+        assert abs(A - A.T).max() == 0.0
+        assert np.diff(A.indptr).max() <= 5
+
+
+def test_adjoint_equals_explicit_jacobian():
+    """J^T v from compJacTMatVec equals Re(J^H W^T W r) with J formed as in compJacMat.jl:206-314."""
+    mesh, data, inv, m = make_problem("tiny")
+    pred, misfit, g = oracle_eval(mesh, data, inv, m, dense_dbc=True)
+    fwd = O.MT2DFwdSolver(mesh, data)[1]
+    J = O.compJacMat(mesh, data, inv.activeIdx, fwd)
+    v = inv.dataW * (inv.dataW * (pred - inv.obsData))
+    gJ = np.real(J.T @ np.conj(v)) * np.exp(m)
+    assert np.abs(g - gJ).max() / np.abs(g).max() < 1e-12
+
+
+def test_structured_boundary_derivative_equals_dense():
+    mesh, data, inv, m = make_problem("tiny")
+    _, _, g1 = oracle_eval(mesh, data, inv, m, dense_dbc=True)
+    _, _, g2 = oracle_eval(mesh, data, inv, m, dense_dbc=False)
+    assert np.abs(g1 - g2).max() / np.abs(g1).max() < 1e-13
+
+
+def test_gradient_matches_finite_differences_on_interior_cells():
+    """FD is a valid check only away from the padding/boundary cells, where the reference's
+    boundary-derivative terms are approximations."""
+    mesh, data, inv, m = make_problem("tiny")
+    _, _, g = oracle_eval(mesh, data, inv, m)
+    ny = mesh.gridSize[0]
+
+    def phi(mm):
+        s = inv.bgModel.copy(); s[inv.activeIdx] += np.exp(mm); mesh.sigma = s
+        p, _ = O.MT2DFwdSolver(mesh, data)
+        return O.compDataMisfit(p, inv)
+
+    for c in (1 * ny + 5, 2 * ny + 6, 1 * ny + 4):          # core cells (earth rows 1-2, centre columns)
+        h = 1e-5
+        mp, mm_ = m.copy(), m.copy()
+        mp[c] += h; mm_[c] -= h
+        fd = (phi(mp) - phi(mm_)) / (2 * h)
+        assert abs(g[c] - fd) / abs(fd) < 2e-2
+
+
+def test_bound_reflection_and_momentum_clip():
+    prior = HMCPrior(sigBounds=[0.01, 1.0])
+    lo, hi = np.log(0.01), np.log(1.0)
+    m = np.array([lo - 0.3, hi + 0.2, 0.5 * (lo + hi), lo - 2 * (hi - lo) - 0.1])
+    p = np.array([1.0, 2.0, 3.0, 4.0])
+    m2, p2 = O.checkParameterBound(m.copy(), p.copy(), prior)
+    assert np.all((m2 >= lo) & (m2 <= hi))
+    assert np.allclose(m2[:3], [lo + 0.3, hi - 0.2, 0.5 * (lo + hi)])
+    assert np.allclose(p2[:3], [-1.0, -2.0, 3.0])
+    mom = O.getMomentumVector(10000, np.ones(10000), np.random.default_rng(0))
+    assert np.abs(mom).max() <= 2.5
