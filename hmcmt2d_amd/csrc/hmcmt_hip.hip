@@ -38,7 +38,8 @@ struct Solver {
     const double *cY, *cZ, *dK, *dM;      // [2][vstride]
     const double* ofz;                    // [2][NZP]
     const cplx* invp;                     // [S][vstride]
-    cplx *x, *r, *p, *q, *z, *y;          // [S][vstride]
+    cplx *x, *r, *p, *q, *z, *y, *t;      // [S][vstride]
+    cplx *dinv;                           // [S][vstride] omegaJ / diag(A) on interior nodes, 0 elsewhere
     cplx *partA;                          // [S][MAXNB]  p'q   | r'z
     double *partB;                        // [S][MAXNB]  |x|^2 | |z|^2
     cplx *rho, *alphaBeta;                // [S]
@@ -412,6 +413,104 @@ __global__ __launch_bounds__(64) void k_thomas(Solver k) {
     }
 }
 
+// ---- symmetric Jacobi / FDM / Jacobi combination (default preconditioner):
+//   z0 = wJ D^-1 r ; z1 = z0 + F (r - A z0) ; z = z1 + wJ D^-1 (r - A z1)
+// point Jacobi removes the cell-scale coefficient contrast the laterally averaged FDM background
+// cannot see; both factors are complex symmetric, so the product form above is too (COCG needs that).
+__device__ __forceinline__ cplx stencil_at(const Solver& k, const cplx* u, long mo, long e, double w) {
+    const cplx c = u[e];
+    const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+    cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+    acc += k.cY[mo + e] * u[e + 1];
+    acc += k.cY[mo + e - 1] * u[e - 1];
+    acc += k.cZ[mo + e] * u[e + k.NYP];
+    acc += k.cZ[mo + e - k.NYP] * u[e - k.NYP];
+    return acc;
+}
+
+__global__ __launch_bounds__(VBLOCK) void k_dinv(Solver k, double wJ) {
+    const int s = blockIdx.y;
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        cplx d = cplx{0, 0};
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) d = wJ / cplx{k.dK[mo + e], w * k.dM[mo + e]};
+        k.dinv[so + e] = d;
+    }
+}
+
+// t = r - A (dinv .* r)
+__global__ __launch_bounds__(VBLOCK) void k_pre(Solver k) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx *r = k.r + so, *di = k.dinv + so;
+    cplx* t = k.t + so;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        cplx out = cplx{0, 0};
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+            const cplx c = di[e] * r[e];
+            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+            acc += k.cY[mo + e] * (di[e + 1] * r[e + 1]);
+            acc += k.cY[mo + e - 1] * (di[e - 1] * r[e - 1]);
+            acc += k.cZ[mo + e] * (di[e + k.NYP] * r[e + k.NYP]);
+            acc += k.cZ[mo + e - k.NYP] * (di[e - k.NYP] * r[e - k.NYP]);
+            out = r[e] - acc;
+        }
+        t[e] = out;
+    }
+}
+
+// z += dinv .* r
+__global__ __launch_bounds__(VBLOCK) void k_mid(Solver k) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    const long so = (long)s * k.vstride;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) k.z[so + e] += k.dinv[so + e] * k.r[so + e];
+}
+
+// t = z + dinv .* (r - A z) ; partA = r't ; partZZ = |t|^2     (t becomes the preconditioned residual)
+__global__ __launch_bounds__(VBLOCK) void k_post(Solver k, double* partZZ) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    __shared__ double sh[8];
+    __shared__ double sh2[8];
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx *r = k.r + so, *z = k.z + so, *di = k.dinv + so;
+    cplx* t = k.t + so;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    double ar = 0, ai = 0, zz = 0, dummy = 0;
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        cplx out = cplx{0, 0};
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+            const cplx rv = r[e];
+            out = z[e] + di[e] * (rv - stencil_at(k, z, mo, e, w));
+            ar += rv.re * out.re - rv.im * out.im;
+            ai += rv.re * out.im + rv.im * out.re;
+            zz += cabs2(out);
+        }
+        t[e] = out;
+    }
+    block_sum2(ar, ai, sh);
+    block_sum2(zz, dummy, sh2);
+    if (threadIdx.x == 0) {
+        k.partA[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
+        partZZ[(long)s * MAXNB + blockIdx.x] = zz;
+    }
+}
+
 // true residual norm check: partB = |b - A x|^2 with b passed separately (verify option)
 __global__ __launch_bounds__(VBLOCK) void k_trueres(Solver k, const cplx* b, const cplx* x, double* partRes, double* partBn) {
     const int s = blockIdx.y;
@@ -629,20 +728,33 @@ int launch_transform(hmcmt_ctx* ctx, const cplx* A, const double* Bsw, cplx* C, 
     return 0;
 }
 
+// z = P^-1 r for the active systems and the partial sums of r'z, |z|^2 (partA / d_partZZ)
 int apply_precond(hmcmt_ctx* ctx) {
     Solver& k = ctx->sv;
-    dim3 vg(k.NB, k.S);
+    dim3 vg(k.NB, k.S), vb(VBLOCK);
     if (ctx->opt.precond == HMCMT_PRECOND_JACOBI) {
-        ProfScope ps(ctx, 3);
-        hipLaunchKernelGGL(k_jacobi, vg, dim3(VBLOCK), 0, ctx->stream, k);
+        { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_jacobi, vg, vb, 0, ctx->stream, k); }
+        { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_dots, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
         return 0;
     }
-    launch_transform(ctx, k.r, ctx->d_V, k.y, k.active);
+    const bool smooth = ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI;
+    if (smooth) { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_pre, vg, vb, 0, ctx->stream, k); }
+    int rc = launch_transform(ctx, smooth ? k.t : k.r, ctx->d_V, k.y, k.active);
+    if (rc) return rc;
     {
         ProfScope ps(ctx, 1);
         hipLaunchKernelGGL(k_thomas, dim3((k.ny - 1 + 63) / 64, k.S), dim3(64), 0, ctx->stream, k);
     }
-    launch_transform(ctx, k.y, ctx->d_Vt, k.z, k.active);
+    rc = launch_transform(ctx, k.y, ctx->d_Vt, k.z, k.active);
+    if (rc) return rc;
+    if (smooth) {
+        { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_mid, vg, vb, 0, ctx->stream, k); }
+        { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+        std::swap(k.z, k.t);                            // the smoothed result is the preconditioned residual
+    } else {
+        ProfScope ps(ctx, 3);
+        hipLaunchKernelGGL(k_dots, vg, vb, 0, ctx->stream, k, ctx->d_partZZ);
+    }
     return 0;
 }
 
@@ -658,17 +770,14 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     if (ctx->opt.verify) HIPCHK(hipMemcpyAsync(ctx->d_b, k.r, vecBytes, hipMemcpyDeviceToDevice, ctx->stream));
     // all systems of the requested modes start active
     {
-        std::vector<int> act(S, 0);
-        for (int s = 0; s < S; ++s) act[s] = (s < k.nFreq) ? (ctx->hp.compTE ? 1 : 0) : (ctx->hp.compTM ? 1 : 0);
-        std::memcpy(ctx->h_iters, act.data(), sizeof(int) * S);     // reuse pinned buffer as staging
+        std::memcpy(ctx->h_iters, ctx->hp.sysOn.data(), sizeof(int) * S);   // reuse pinned buffer as staging
         HIPCHK(hipMemcpyAsync(k.active, ctx->h_iters, sizeof(int) * S, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     HIPCHK(hipMemsetAsync(k.iters, 0, sizeof(int) * S, ctx->stream));
     HIPCHK(hipMemsetAsync(k.status, 0, sizeof(int) * S, ctx->stream));
     // z = P^-1 r ; rho = r'z ; p = z
-    apply_precond(ctx);
-    { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_dots, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+    { int prc = apply_precond(ctx); if (prc) return prc; }
     { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_check, dim3(1), dim3(128), 0, ctx->stream, k, ctx->d_partZZ, 1, ctx->opt.maxit); }
     { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_pupdate, vg, vb, 0, ctx->stream, k, 1); }
     int& guess = kind == 0 ? ctx->lastItFwd : ctx->lastItAdj;
@@ -680,8 +789,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
         ++it;
         { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv, vg, vb, 0, ctx->stream, k); }
         { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update, vg, vb, 0, ctx->stream, k); }
-        apply_precond(ctx);
-        { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_dots, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+        { int prc = apply_precond(ctx); if (prc) return prc; }
         { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_check, dim3(1), dim3(128), 0, ctx->stream, k, ctx->d_partZZ, 0, ctx->opt.maxit); }
         { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_pupdate, vg, vb, 0, ctx->stream, k, 0); }
         if (it >= nextCheck || it == ctx->opt.maxit) {
@@ -740,8 +848,10 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         hipLaunchKernelGGL(k_rowmean, grid1(v.nz, 64), dim3(64), 0, st, v);
         hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, st, v, 0, 1, 1, 0);
         hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, st, v);
-        if (ctx->opt.precond == HMCMT_PRECOND_FDM)
+        if (ctx->opt.precond != HMCMT_PRECOND_JACOBI)
             hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 0, st, v);
+        if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI)
+            hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, 0.7);
         HIPCHK(hipMemsetAsync(v.X, 0, vecBytes, st));
         hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, S), dim3(64), 0, st, v);
         hipLaunchKernelGGL(k_rhs, dim3((nodes + 255) / 256, S), dim3(256), 0, st, v);
@@ -791,7 +901,7 @@ extern "C" {
 
 void hmcmt_default_options(hmcmt_options* o) {
     if (!o) return;
-    o->precond = HMCMT_PRECOND_FDM;
+    o->precond = HMCMT_PRECOND_FDM_JACOBI;
     o->maxit = 2000;
     o->tol = 1e-11;
     o->check_every = 2;
@@ -831,7 +941,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     const size_t VS = (size_t)v.vstride, S = (size_t)h.S;
     int rc;
 #define UP(field, vec) { decltype(vec)::value_type* p_ = nullptr; if ((rc = dupload(ctx, &p_, vec))) return rc; v.field = p_; }
-    UP(yLen, h.yLen) UP(zLen, h.zLen) UP(omega, h.omega) UP(lam, h.lam)
+    UP(yLen, h.yLen) UP(zLen, h.zLen) UP(omega, h.omega) UP(lam, h.lam) UP(sysOn, h.sysOn)
     UP(cell2act, h.cell2act) UP(bg, h.bg) UP(act, h.act)
     UP(rxIdn, h.rxIdn) UP(rxDy1, h.rxDy1) UP(rxDy2, h.rxDy2) UP(rxKL, h.rxKL) UP(rxKR, h.rxKR) UP(rxWL, h.rxWL) UP(rxWR, h.rxWR)
     UP(predSys, h.predSys) UP(predRx, h.predRx) UP(datSys, h.datSys) UP(datRx, h.datRx)
@@ -870,7 +980,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     k.chunk = (v.vstride + k.NB - 1) / k.NB;
     k.omega = v.omega; k.cY = v.cY; k.cZ = v.cZ; k.dK = v.dK; k.dM = v.dM; k.ofz = v.ofz; k.invp = v.invp;
     k.r = v.R;
-    DA(k.p, S * VS) DA(k.q, S * VS) DA(k.z, S * VS) DA(k.y, S * VS)
+    DA(k.p, S * VS) DA(k.q, S * VS) DA(k.z, S * VS) DA(k.y, S * VS) DA(k.t, S * VS) DA(k.dinv, S * VS)
     DA(k.partA, S * MAXNB) DA(k.partB, S * MAXNB) DA(ctx->d_partZZ, S * MAXNB)
     DA(ctx->d_partRes, S * MAXNB) DA(ctx->d_partBn, S * MAXNB)
     DA(k.rho, S) DA(k.alphaBeta, S) DA(k.active, S) DA(k.iters, S) DA(k.status, S) DA(k.nactive, 1) DA(k.errEst, S)
@@ -925,7 +1035,7 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
 
 int hmcmt_set_options(hmcmt_ctx* ctx, const hmcmt_options* o) {
     if (!ctx || !o) return HMCMT_EINVAL;
-    if (o->precond != HMCMT_PRECOND_JACOBI && o->precond != HMCMT_PRECOND_FDM) { ctx->err = "unknown preconditioner"; return HMCMT_EINVAL; }
+    if (o->precond < HMCMT_PRECOND_JACOBI || o->precond > HMCMT_PRECOND_FDM_JACOBI) { ctx->err = "unknown preconditioner"; return HMCMT_EINVAL; }
     if (!(o->tol > 0) || o->maxit < 1) { ctx->err = "tol must be > 0 and maxit >= 1"; return HMCMT_EINVAL; }
     ctx->opt = *o;
     ctx->lastItFwd = ctx->lastItAdj = 0;

@@ -16,7 +16,7 @@ struct HostProblem {
     bool compTE = false, compTM = false;
     std::vector<double> yLen, zLen, omega, lam, Vpad, Vtpad, bg, dataW;
     std::vector<double> rxDy1, rxDy2, rxWL, rxWR;
-    std::vector<int> cell2act, act, rxIdn, rxKL, rxKR, predSys, predRx, datSys, datRx, srStart, srList;
+    std::vector<int> cell2act, act, rxIdn, rxKL, rxKR, predSys, predRx, datSys, datRx, srStart, srList, sysOn;
     std::vector<cplx> obs;
     std::string error;
 
@@ -191,6 +191,8 @@ struct HostProblem {
             cell2act[c] = a; act[a] = (int)c;
         }
         bg.assign(bgModel, bgModel + nCell);
+        sysOn.resize(S);
+        for (int s = 0; s < S; ++s) sysOn[s] = (s < nFreq) ? (compTE ? 1 : 0) : (compTM ? 1 : 0);
         return build_fdm();
     }
 };

@@ -24,6 +24,7 @@ struct View {
     const double* zLen;            // [nz]
     const double* omega;           // [S]
     const double* lam;             // [NYP] generalised eigenvalues of the y-operator (0 in the pad)
+    const int* sysOn;              // [S] 0 for the systems of a polarisation without data (never solved)
     // model-dependent
     const double* m;               // [nAC] ln(sigma) on active cells
     double* sigma;                 // [nCell]
@@ -227,6 +228,14 @@ HD void item_rhs(const View& v, int s, int iy, int iz) {
 
 // --- impedance and its derivative at one receiver of one system
 HD void item_rx(const View& v, int s, int r, bool wantDeriv) {
+    if (!v.sysOn[s]) {                                    // polarisation absent from the data set
+        v.Zrx[(long)s * v.nRx + r] = cplx{0, 0};
+        if (wantDeriv) {
+            v.rxN0[(long)s * v.nRx + r] = 0;
+            for (int i = 0; i < 11; ++i) v.rxD[((long)s * v.nRx + r) * 11 + i] = cplx{0, 0};
+        }
+        return;
+    }
     const bool tm = s >= v.nFreq;
     const cplx* F0 = v.X + (long)s * v.vstride + nidx(v, 0, v.zid);
     const cplx* F1 = F0 + v.NYP;
@@ -308,6 +317,11 @@ HD void item_colw(const View& v, int s, int ky) {           // MT1DSensitivity.j
 // --- dBC^T w by columns of the 1-D sensitivities (getBCDerivMatrix, MT1DSensitivity.jl:253-333)
 //     prof 0: left edge column, 1: right edge column, 2: lateral-mean profile
 HD void item_bcsens(const View& v, int s, int prof, int c) {
+    if (!v.sysOn[s]) {
+        const long o_ = (long)s * v.nz + c;
+        if (prof == 0) v.gL[o_] = cplx{0, 0}; else if (prof == 1) v.gR[o_] = cplx{0, 0}; else v.gMn[o_] = cplx{0, 0};
+        return;
+    }
     const bool tm = s >= v.nFreq;
     const double w = v.omega[s];
     const long o = (long)s * v.nz;
@@ -341,6 +355,7 @@ HD void item_gradcell(const View& v, int mode, int cell) {
     double acc = 0.0;
     for (int f = 0; f < v.nFreq; ++f) {
         const int s = mode * v.nFreq + f;
+        if (!v.sysOn[s]) continue;
         const cplx* L = v.Lam + (long)s * v.vstride;
         if (mode == 0) {
             // -i w (1/4 area) sum over the 4 corner nodes e*lambda (compJacTMatVec.jl:83,235)
@@ -378,6 +393,7 @@ HD void item_gradfinal(const View& v, int a) {
     const int ky = cell % v.ny, kz = cell / v.ny;
     double g = v.gPart[cell] + v.gPart[(long)v.nCell + cell];
     for (int s = 0; s < v.S; ++s) {
+        if (!v.sysOn[s]) continue;
         const long o = (long)s * v.nz + kz;
         cplx b = v.gMn[o] * v.colw[(long)s * v.ny + ky];
         if (ky == 0) b += v.gL[o];
@@ -386,7 +402,7 @@ HD void item_gradfinal(const View& v, int a) {
     }
     if (kz == v.zid) {
         for (int s = 0; s < v.S; ++s)
-            for (int r = 0; r < v.nRx; ++r) {
+            for (int r = 0; r < v.nRx && v.sysOn[s]; ++r) {
                 const long k = (long)s * v.nRx + r;
                 const int o = ky - v.rxN0[k];
                 if (o >= 0 && o < 3) g += (v.rxCoef[k] * v.rxD[k * 11 + 8 + o]).re;

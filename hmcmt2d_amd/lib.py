@@ -21,6 +21,7 @@ HEADERS = [os.path.join(CSRC, h) for h in ("hmcmt_math.h", "hmcmt_items.h", "hmc
 
 HMCMT_NCAT = 7
 CATEGORIES = ["fdm_transform", "tridiagonal", "spmv", "vector_ops", "assembly_bc", "receivers", "gradient"]
+PRECOND = {"jacobi": 0, "fdm": 1, "fdmj": 2}
 ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "EHIP", -10: "ENOCONV", -11: "EBREAKDOWN", -13: "ENOMEM"}
 
 
@@ -114,13 +115,13 @@ def _dp(a):
 class HipContext:
     """One GPU context: the drop-in for the reference's per-call solver state."""
 
-    def __init__(self, mtMesh, mtData, invParam, device_id=0, precond="fdm", tol=None, maxit=None,
+    def __init__(self, mtMesh, mtData, invParam, device_id=0, precond="fdmj", tol=None, maxit=None,
                  verify=False, check_every=None):
         self.lib = load_library()
         self.args = CreateArgs(mtMesh, mtData, invParam)
         opts = Options()
         self.lib.hmcmt_default_options(C.byref(opts))
-        opts.precond = {"jacobi": 0, "fdm": 1}[precond]
+        opts.precond = PRECOND[precond]
         if precond == "jacobi" and maxit is None:
             maxit = 20000
         if tol is not None:
@@ -149,7 +150,7 @@ class HipContext:
     def set_options(self, **kw):
         for k, v in kw.items():
             if k == "precond":
-                v = {"jacobi": 0, "fdm": 1}[v]
+                v = PRECOND[v]
             setattr(self.opts, k, v)
         self._check(self.lib.hmcmt_set_options(self.h, C.byref(self.opts)))
 

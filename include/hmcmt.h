@@ -47,12 +47,13 @@ extern "C" {
 #define HMCMT_ENOMEM    -13   /* device allocation failed (cf. MUMPS -13) */
 
 #define HMCMT_PRECOND_JACOBI 0
-#define HMCMT_PRECOND_FDM    1   /* fast diagonalisation with a laterally averaged background (default) */
+#define HMCMT_PRECOND_FDM    1   /* fast diagonalisation with a laterally averaged background */
+#define HMCMT_PRECOND_FDM_JACOBI 2 /* damped point-Jacobi / FDM / point-Jacobi, symmetric product form (default) */
 
 typedef struct hmcmt_ctx hmcmt_ctx;
 
 typedef struct hmcmt_options {
-    int32_t precond;      /* HMCMT_PRECOND_* ; default FDM */
+    int32_t precond;      /* HMCMT_PRECOND_* ; default FDM_JACOBI */
     int32_t maxit;        /* iteration cap per solve; default 2000 (FDM) */
     double  tol;          /* stop when ||P^-1 r|| <= tol*||x|| (error estimate); default 1e-11 */
     int32_t check_every;  /* host convergence poll interval in iterations; default 2 */

@@ -64,7 +64,7 @@ def main():
             ctx.set_options(precond="jacobi", maxit=50000)
             t0 = time.time(); p2, m2, g2 = ctx.grad(m); tj = time.time() - t0
             print(f"  jacobi: {tj*1e3:.1f} ms stats {ctx.stats()}  grad diff vs fdm {np.abs(g2-g).max()/np.abs(g).max():.3e}")
-            ctx.set_options(precond="fdm", maxit=2000)
+            ctx.set_options(precond="fdmj", maxit=2000)
         # timing
         ctx.set_options(verify=0)
         for _ in range(2):

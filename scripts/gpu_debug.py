@@ -34,7 +34,7 @@ P = np.zeros(shape, dtype=complex)
 P[:, 1:ctx.nz, 1:ctx.ny] = A[:, 1:ctx.nz, 1:ctx.ny]
 q_g = ctx.debug_spmv(P).reshape(shape); q_e = E.apply("spmv", P).reshape(shape)
 print("spmv relerr", np.abs(q_g - q_e).max() / np.abs(q_e).max())
-z_g = ctx.debug_precond(P).reshape(shape); z_e = E.apply("fdm", P).reshape(shape)
+z_g = ctx.debug_precond(P).reshape(shape); z_e = E.apply("fdmj", P).reshape(shape)
 print("fdm precond relerr", np.abs(z_g - z_e).max() / np.abs(z_e).max())
 ex_g, hx_g = ctx.fields()
 Xe = E.get("X").reshape(shape)

@@ -38,7 +38,7 @@ struct Emul {
         colw.assign((size_t)h.S * h.ny, cplx{0, 0}); bcsB.assign(h.S, cplx{0, 0});
         gPart.assign((size_t)2 * h.nCell, 0); grad.assign(h.nAC, 0); m.assign(h.nAC, 0);
         iters.assign(2 * h.S, 0);
-        v.yLen = h.yLen.data(); v.zLen = h.zLen.data(); v.omega = h.omega.data(); v.lam = h.lam.data();
+        v.yLen = h.yLen.data(); v.zLen = h.zLen.data(); v.omega = h.omega.data(); v.lam = h.lam.data(); v.sysOn = h.sysOn.data();
         v.m = m.data(); v.sigma = sigma.data(); v.cell2act = h.cell2act.data(); v.bg = h.bg.data(); v.act = h.act.data();
         v.sigMeanA = sigMeanA.data(); v.sigMeanG = sigMeanG.data();
         v.cY = cY.data(); v.cZ = cZ.data(); v.dK = dK.data(); v.dM = dM.data();
@@ -60,9 +60,24 @@ struct Emul {
 
     bool interior(int iy, int iz) const { return iy >= 1 && iy <= v.ny - 1 && iz >= 1 && iz <= v.nz - 1; }
 
-    // z = P^-1 r for system s (precond 1: FDM, 0: Jacobi)
+    // z = P^-1 r for system s (kind 2: Jacobi/FDM/Jacobi product form, 1: FDM, 0: Jacobi)
     void precond(int s, int kind, const cplx* r, cplx* z) {
         const int NYP = v.NYP, nz = v.nz;
+        if (kind == 2) {
+            const int mode = s >= v.nFreq;
+            const double wJ = 0.7;
+            std::vector<cplx> z0((size_t)v.vstride, cplx{0, 0}), t((size_t)v.vstride, cplx{0, 0}), z1((size_t)v.vstride, cplx{0, 0});
+            auto dinv = [&](int iy, int iz) { long mo = (long)mode * v.vstride + nidx(v, iy, iz); return wJ / cplx{v.dK[mo], v.omega[s] * v.dM[mo]}; };
+            for (int iz = 1; iz <= nz - 1; ++iz) for (int iy = 1; iy <= v.ny - 1; ++iy) z0[nidx(v, iy, iz)] = dinv(iy, iz) * r[nidx(v, iy, iz)];
+            for (int iz = 1; iz <= nz - 1; ++iz) for (int iy = 1; iy <= v.ny - 1; ++iy) t[nidx(v, iy, iz)] = r[nidx(v, iy, iz)] - stencil_apply(v, s, z0.data(), iy, iz);
+            precond(s, 1, t.data(), z1.data());
+            for (long o = 0; o < v.vstride; ++o) z1[o] += z0[o];
+            for (int iz = 1; iz <= nz - 1; ++iz) for (int iy = 1; iy <= v.ny - 1; ++iy) {
+                long o = nidx(v, iy, iz);
+                z[o] = z1[o] + dinv(iy, iz) * (r[o] - stencil_apply(v, s, z1.data(), iy, iz));
+            }
+            return;
+        }
         if (kind == 0) {
             const int mode = s >= v.nFreq;
             for (int iz = 1; iz <= nz - 1; ++iz)
@@ -158,7 +173,7 @@ struct Emul {
         for (int s = 0; s < V.S; ++s) for (int col = 0; col <= V.ny; ++col) item_bc_forward(V, s, col);
         for (int s = 0; s < V.S; ++s)
             for (int iz = 0; iz < V.NZP; ++iz) for (int iy = 0; iy <= V.ny; ++iy) item_rhs(V, s, iy, iz);
-        for (int s = 0; s < V.S; ++s) iters[s] = cocg(s, X.data() + (long)s * V.vstride, kind, tol, maxit);
+        for (int s = 0; s < V.S; ++s) iters[s] = V.sysOn[s] ? cocg(s, X.data() + (long)s * V.vstride, kind, tol, maxit) : 0;
         for (int s = 0; s < V.S; ++s) for (int r = 0; r < V.nRx; ++r) item_rx(V, s, r, wantGrad);
         for (int p = 0; p < V.nData; ++p) item_resid(V, p);
         double mf = 0;
@@ -170,7 +185,7 @@ struct Emul {
         std::fill(srcB.begin(), srcB.end(), cplx{0, 0});
         for (int s = 0; s < V.S; ++s) for (int row = 0; row < 2; ++row) for (int iy = 0; iy <= V.ny; ++iy) item_src(V, s, row, iy);
         std::fill(Lam.begin(), Lam.end(), cplx{0, 0});
-        for (int s = 0; s < V.S; ++s) iters[V.S + s] = cocg(s, Lam.data() + (long)s * V.vstride, kind, tol, maxit);
+        for (int s = 0; s < V.S; ++s) iters[V.S + s] = V.sysOn[s] ? cocg(s, Lam.data() + (long)s * V.vstride, kind, tol, maxit) : 0;
         for (int s = 0; s < V.S; ++s) {
             for (int iz = 1; iz <= V.nz; ++iz) item_wside(V, s, iz);
             for (int ky = 0; ky < V.ny; ++ky) item_colw(V, s, ky);
@@ -263,7 +278,7 @@ int emul_apply(void* h, int which, const double* in, double* out) {
             for (int iz = 1; iz <= v.nz - 1; ++iz)
                 for (int iy = 1; iy <= v.ny - 1; ++iy) ys[nidx(v, iy, iz)] = stencil_apply(v, s, xs, iy, iz);
         } else {
-            e->precond(s, which == 1 ? 1 : 0, xs, ys);
+            e->precond(s, which == 1 ? 1 : (which == 3 ? 2 : 0), xs, ys);
         }
     }
     return 0;

@@ -56,7 +56,7 @@ class Emul:
         lib().emul_dims(self.h, d)
         self.NYP, self.NZP, self.S, self.ny, self.nz, self.zid = list(d)
 
-    def grad(self, m, want_grad=True, precond=1, tol=1e-12, maxit=20000):
+    def grad(self, m, want_grad=True, precond=2, tol=1e-12, maxit=20000):
         m = np.ascontiguousarray(m, dtype=np.float64)
         pred = np.zeros(self.args.nData, dtype=np.complex128)
         grad = np.zeros(self.args.nAC)
@@ -80,7 +80,7 @@ class Emul:
         """which: 'spmv' | 'fdm' | 'jacobi' on vectors in the padded nodal layout [S][NZP][NYP]."""
         x = np.ascontiguousarray(x, dtype=np.complex128)
         y = np.empty_like(x)
-        lib().emul_apply(self.h, {"spmv": 0, "fdm": 1, "jacobi": 2}[which], x.ctypes.data_as(c_double_p),
+        lib().emul_apply(self.h, {"spmv": 0, "fdm": 1, "jacobi": 2, "fdmj": 3}[which], x.ctypes.data_as(c_double_p),
                          y.ctypes.data_as(c_double_p))
         return y
 

@@ -32,7 +32,7 @@ def test_header_symbols_are_exported(so):
 def test_default_options(so):
     o = L.Options()
     L.load_library().hmcmt_default_options(ctypes.byref(o))
-    assert o.precond == 1 and o.maxit >= 100 and 0 < o.tol < 1e-8 and o.check_every >= 1
+    assert o.precond == 2 and o.maxit >= 100 and 0 < o.tol < 1e-8 and o.check_every >= 1
 
 
 @pytest.mark.skipif(HAVE_GPU, reason="checks the no-device error path")

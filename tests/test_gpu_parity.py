@@ -70,7 +70,11 @@ def test_jacobi_and_fdm_preconditioners_agree(tiny_ctx):
     p0, f0, g0 = ctx.grad(m)
     it_jac = ctx.iters().max()
     ctx.set_options(precond="fdm", maxit=2000)
+    p2, f2, g2 = ctx.grad(m)
+    it_plain = ctx.iters().max()
+    ctx.set_options(precond="fdmj")
     assert relmax(p0, p1) < 1e-9 and relmax(g0, g1) < 1e-7 and it_jac > 3 * it_fdm
+    assert relmax(p2, p1) < 1e-9 and relmax(g2, g1) < 1e-7 and it_plain >= it_fdm
 
 
 def test_kernels_against_host_instantiation(tiny_ctx):
@@ -87,7 +91,10 @@ def test_kernels_against_host_instantiation(tiny_ctx):
     assert relmax(ctx.debug_transform(1, A).reshape(shape), A @ V.T) < 1e-13
     P = np.zeros(shape, complex); P[:, 1:ctx.nz, 1:ctx.ny] = A[:, 1:ctx.nz, 1:ctx.ny]
     assert relmax(ctx.debug_spmv(P), E.apply("spmv", P)) < 1e-13
+    assert relmax(ctx.debug_precond(P), E.apply("fdmj", P)) < 1e-11
+    ctx.set_options(precond="fdm"); ctx.grad(m)
     assert relmax(ctx.debug_precond(P), E.apply("fdm", P)) < 1e-11
+    ctx.set_options(precond="fdmj")
 
 
 def test_operator_symmetry_properties():
