@@ -107,10 +107,16 @@ def main():
     nAC, nData = ctx.nAC, ctx.nData
 
     K, W = args.steps, args.warmup
+    # synthetic leapfrog trajectories: position steps dm = dt*p with dt = 0.03 (examples/dprism3d/startupfile:5),
+    # momentum redrawn every L = 8 steps (timestep 6..10) from the clipped N(0,1) of getMomentumVector
     rng = np.random.default_rng([20250114, 7, rank])
     m0 = S.rough_state(nAC, seed=1 + rank)
-    p = np.clip(rng.standard_normal(nAC), -2.5, 2.5)
-    traj = np.stack([m0 + 0.03 * k * p / max(1, K + W) * 8 for k in range(K + W)])   # |dm| <= 0.6 over the run
+    Ltraj, dt = 8, 0.03
+    traj = np.empty((K + W, nAC))
+    for k in range(K + W):
+        if k % Ltraj == 0:
+            p = np.clip(rng.standard_normal(nAC), -2.5, 2.5)
+        traj[k] = m0 + dt * (k % Ltraj) * p
     dev = torch.device("cuda", local)
     d_m = torch.from_numpy(traj).to(dev)
     d_pred = torch.zeros(2 * nData, dtype=torch.float64, device=dev)

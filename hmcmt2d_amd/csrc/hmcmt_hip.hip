@@ -511,6 +511,25 @@ __global__ __launch_bounds__(VBLOCK) void k_post(Solver k, double* partZZ) {
     }
 }
 
+// warm start: r <- r - A x over interior nodes, x including whatever sits on its boundary nodes
+// (forward: Dirichlet values, so with r = 0 on entry this is the reference's rhs -Aio*bc minus Aii*x0)
+__global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r) {
+    const int s = blockIdx.y;
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx* u = x + so;
+    cplx* r = k.r + so;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        cplx out = cplx{0, 0};
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1)
+            out = (zero_r ? cplx{0, 0} : r[e]) - stencil_at(k, u, mo, e, w);
+        r[e] = out;
+    }
+}
+
 // true residual norm check: partB = |b - A x|^2 with b passed separately (verify option)
 __global__ __launch_bounds__(VBLOCK) void k_trueres(Solver k, const cplx* b, const cplx* x, double* partRes, double* partBn) {
     const int s = blockIdx.y;
@@ -546,7 +565,17 @@ __global__ __launch_bounds__(VBLOCK) void k_trueres(Solver k, const cplx* b, con
 #define TID1 (blockIdx.x * blockDim.x + threadIdx.x)
 
 __global__ void k_sigma(View v) { int c = TID1; if (c < v.nCell) item_sigma(v, c); }
-__global__ void k_rowmean(View v) { int kz = TID1; if (kz < v.nz) item_rowmean(v, kz); }
+// lateral means of one cell row per wave (deterministic shuffle reduction)
+__global__ __launch_bounds__(64) void k_rowmean(View v) {
+    const int kz = blockIdx.x;
+    double sa = 0.0, sl = 0.0;
+    for (int ky = threadIdx.x; ky < v.ny; ky += 64) {
+        const double s = v.sigma[(long)kz * v.ny + ky];
+        sa += s; sl += log(s);
+    }
+    sa = wave_sum(sa); sl = wave_sum(sl);
+    if (threadIdx.x == 0) { v.sigMeanA[kz] = sa / v.ny; v.sigMeanG[kz] = exp(sl / v.ny); }
+}
 __global__ void k_coef(View v, int te_doK, int te_doM, int tm_doK, int tm_doM) {
     int e = TID1;
     if (e >= v.NZP * (v.ny + 1)) return;
@@ -559,9 +588,21 @@ __global__ void k_pivot(View v) {
     int j = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
     if (j < v.ny - 1) item_pivot(v, s, j);
 }
+__global__ void k_bc_layers(View v) {
+    int col = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, s = blockIdx.z;
+    if (col <= v.ny) item_bc_layers(v, s, j, col);
+}
 __global__ void k_bc_forward(View v) {
     int col = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
     if (col <= v.ny) item_bc_forward(v, s, col);
+}
+__global__ void k_sens_layers(View v) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
+    if (j <= v.nz) item_sens_layers(v, s, prof, j);
+}
+__global__ void k_sens_profile(View v) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 3 * v.S) item_sens_profile(v, e / 3, e % 3);
 }
 __global__ void k_rhs(View v) {
     int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
@@ -599,6 +640,10 @@ __global__ void k_gradcell(View v) {
     int c = blockIdx.x * blockDim.x + threadIdx.x, mode = blockIdx.y;
     if (c < v.nCell) item_gradcell(v, mode, c);
 }
+__global__ void k_qterm(View v) {
+    int ky = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (ky < v.ny) item_qterm(v, s, ky);
+}
 __global__ void k_gradfinal(View v) { int a = TID1; if (a < v.nAC) item_gradfinal(v, a); }
 
 // copy padded nodal layout -> reference layout [(ny+1)*(nz+1)] per frequency
@@ -623,6 +668,8 @@ struct hmcmt_ctx {
     hmcmt_stats stats{};
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;       // sigma-only sensitivity tables run beside the forward solve
+    hipEvent_t evModel = nullptr, evSens = nullptr;
     std::vector<void*> allocs;
     std::string err;
     // device scalars / buffers not in View
@@ -640,6 +687,7 @@ struct hmcmt_ctx {
     std::vector<int> itersLast;           // [2*S]
     int lastItFwd = 0, lastItAdj = 0;
     bool haveModel = false;
+    bool haveFwd = false, haveAdj = false;   // previous fields usable as initial guesses
     // profiling
     unsigned profMask = 0;            // bit c: time category c with HIP events
     std::vector<hipEvent_t> evPool;
@@ -845,18 +893,29 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     {
         ProfScope ps(ctx, 4);
         hipLaunchKernelGGL(k_sigma, grid1(v.nCell, 256), dim3(256), 0, st, v);
-        hipLaunchKernelGGL(k_rowmean, grid1(v.nz, 64), dim3(64), 0, st, v);
+        hipLaunchKernelGGL(k_rowmean, dim3(v.nz), dim3(64), 0, st, v);
+        if (wantGrad) {   // sensitivity tables depend on sigma only: computed on the side stream, joined before k_bcsens
+            HIPCHK(hipEventRecord(ctx->evModel, st));
+            HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evModel, 0));
+            hipLaunchKernelGGL(k_sens_layers, dim3((v.nz + 1 + 63) / 64, 3, S), dim3(64), 0, ctx->side, v);
+            hipLaunchKernelGGL(k_sens_profile, dim3((3 * S + 63) / 64), dim3(64), 0, ctx->side, v);
+            HIPCHK(hipEventRecord(ctx->evSens, ctx->side));
+        }
         hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, st, v, 0, 1, 1, 0);
         hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, st, v);
         if (ctx->opt.precond != HMCMT_PRECOND_JACOBI)
             hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 0, st, v);
         if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI)
             hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, 0.7);
-        HIPCHK(hipMemsetAsync(v.X, 0, vecBytes, st));
+        const bool warmF = ctx->opt.warm_start && ctx->haveFwd && !ctx->opt.verify;   // verify checks against the cold rhs
+        if (!warmF) HIPCHK(hipMemsetAsync(v.X, 0, vecBytes, st));
+        hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, S), dim3(64), 0, st, v);
         hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, S), dim3(64), 0, st, v);
-        hipLaunchKernelGGL(k_rhs, dim3((nodes + 255) / 256, S), dim3(256), 0, st, v);
+        // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X
+        hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, 1);
     }
     int rc = solve(ctx, v.X, 0);
+    ctx->haveFwd = (rc == 0 && ctx->stats.status == 0);
     if (rc) return rc;
     {
         ProfScope ps(ctx, 5);
@@ -871,14 +930,20 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             HIPCHK(hipMemsetAsync(v.R, 0, vecBytes, st));
             HIPCHK(hipMemsetAsync(v.srcB, 0, sizeof(cplx) * 4 * S, st));
             hipLaunchKernelGGL(k_src, dim3((2 * (v.ny + 1) + 127) / 128, S), dim3(128), 0, st, v);
-            HIPCHK(hipMemsetAsync(v.Lam, 0, vecBytes, st));
+            if (ctx->opt.warm_start && ctx->haveAdj && !ctx->opt.verify)
+                hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, 0);
+            else
+                HIPCHK(hipMemsetAsync(v.Lam, 0, vecBytes, st));
         }
         rc = solve(ctx, v.Lam, 1);
+        ctx->haveAdj = (rc == 0 && ctx->stats.status == 0);
         if (rc) return rc;
         ProfScope ps(ctx, 6);
         hipLaunchKernelGGL(k_wb, dim3((v.nz + v.ny + 127) / 128, S), dim3(128), 0, st, v);
+        HIPCHK(hipStreamWaitEvent(st, ctx->evSens, 0));
         hipLaunchKernelGGL(k_bcsens, dim3((v.nz + 63) / 64, 3, S), dim3(64), 0, st, v);
         hipLaunchKernelGGL(k_gradcell, dim3((v.nCell + 127) / 128, 2), dim3(128), 0, st, v);
+        hipLaunchKernelGGL(k_qterm, dim3((v.ny + 63) / 64, S), dim3(64), 0, st, v);
         hipLaunchKernelGGL(k_gradfinal, grid1(v.nAC, 128), dim3(128), 0, st, v);
     }
     HIPCHK(hipGetLastError());
@@ -906,6 +971,7 @@ void hmcmt_default_options(hmcmt_options* o) {
     o->tol = 1e-11;
     o->check_every = 2;
     o->verify = 0;
+    o->warm_start = 1;
 }
 
 const char* hmcmt_last_error(const hmcmt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
@@ -921,6 +987,9 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (ctx->h_status) hipHostFree(ctx->h_status);
     if (ctx->h_err) hipHostFree(ctx->h_err);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
+    if (ctx->evModel) hipEventDestroy(ctx->evModel);
+    if (ctx->evSens) hipEventDestroy(ctx->evSens);
+    if (ctx->side) hipStreamDestroy(ctx->side);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -934,6 +1003,9 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     if (ctx->hp.NZP > MAXNZP) { ctx->err = "nz too large for the tridiagonal kernel (nz+1 > 1024)"; return HMCMT_EINVAL; }
     HIPCHK(hipSetDevice(device_id));
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evModel, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evSens, hipEventDisableTiming));
     const HostProblem& h = ctx->hp;
     View& v = ctx->v;
     v.ny = h.ny; v.nz = h.nz; v.NYP = h.NYP; v.NZP = h.NZP; v.nFreq = h.nFreq; v.S = h.S; v.nRx = h.nRx;
@@ -972,7 +1044,10 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     DA(v.pred, h.nData) DA(v.vbar, h.nData) DA(v.misfitPart, h.nData)
     DA(v.srcB, S * 4) DA(v.wL, S * h.nz) DA(v.wR, S * h.nz) DA(v.colw, S * h.ny)
     DA(v.gL, S * h.nz) DA(v.gR, S * h.nz) DA(v.gMn, S * h.nz) DA(v.bcsL, S * h.nz) DA(v.bcsR, S * h.nz) DA(v.bcsB, S)
-    DA(v.gPart, 2 * (size_t)h.nCell) DA(v.grad, h.nAC)
+    DA(v.fwdTab, S * 5 * (size_t)h.nz * (h.ny + 1)) DA(v.sensTab, S * 15 * (size_t)(h.nz + 1))
+    DA(v.sensEu, S * 3 * (size_t)(h.nz + 1)) DA(v.sensEd, S * 3 * (size_t)(h.nz + 1)) DA(v.sensMix, S * 12 * (size_t)h.nz)
+    DA(v.sensDz1, S * 3 * (size_t)h.nz) DA(v.sensZ1, S * 3) DA(v.sensDead, S * 3)
+    DA(v.qPart, S * h.ny) DA(v.gPart, 2 * (size_t)h.nCell) DA(v.grad, h.nAC)
     DA(ctx->d_m, h.nAC) DA(ctx->d_misfit, 1)
     Solver& k = ctx->sv;
     k.S = h.S; k.NYP = h.NYP; k.NZP = h.NZP; k.ny = h.ny; k.nz = h.nz; k.nFreq = h.nFreq; k.vstride = v.vstride;
@@ -1039,6 +1114,7 @@ int hmcmt_set_options(hmcmt_ctx* ctx, const hmcmt_options* o) {
     if (!(o->tol > 0) || o->maxit < 1) { ctx->err = "tol must be > 0 and maxit >= 1"; return HMCMT_EINVAL; }
     ctx->opt = *o;
     ctx->lastItFwd = ctx->lastItAdj = 0;
+    ctx->haveFwd = ctx->haveAdj = false;
     return 0;
 }
 

@@ -83,6 +83,15 @@ struct View {
     cplx* bcsL;                    // [S][nz]  sensitivity-version boundary fields (TM term)
     cplx* bcsR;                    // [S][nz]
     cplx* bcsB;                    // [S]      mean-profile bottom value
+    cplx* fwdTab;                  // [S][5][nz][ny+1] per-layer terms of the forward 1-D columns
+    cplx* sensTab;                 // [S][3][5][nz+1]  per-layer terms of the sensitivity profiles
+    cplx* sensEu;                  // [S][3][nz+1]     up-going amplitude per row (scratch in stage 2)
+    cplx* sensEd;                  // [S][3][nz+1]
+    cplx* sensMix;                 // [S][3][4][nz]
+    cplx* sensDz1;                 // [S][3][nz]       d z1 / d sigma_c
+    cplx* sensZ1;                  // [S][3]
+    int* sensDead;                 // [S][3]           cut-off row or nz+1
+    double* qPart;                 // [S][ny] Q-term (explicit sigma-dependence of the data functional) per system
     double* gPart;                 // [2][nCell] P-term partial sums per mode
     double* grad;                  // [nAC]
 };
@@ -175,24 +184,35 @@ HD void item_pivot(const View& v, int s, int j) {
     }
 }
 
+// --- per-layer terms of the 1-D column under boundary node column `col` (0 = left edge, ny = right
+//     edge, else the width-weighted mean of the two adjacent cell columns, mt2DTE.jl:127-131)
+HD void item_bc_layers(const View& v, int s, int j, int col) {
+    if (!v.sysOn[s]) return;
+    double sig;
+    if (col == 0) sig = v.sigma[(long)j * v.ny];
+    else if (col == v.ny) sig = v.sigma[(long)j * v.ny + v.ny - 1];
+    else {
+        const double ya = v.yLen[col - 1], yb = v.yLen[col];
+        sig = (v.sigma[(long)j * v.ny + col - 1] * ya + v.sigma[(long)j * v.ny + col] * yb) / (ya + yb);
+    }
+    cplx t[5];
+    layer_forward(sig, v.omega[s], v.zLen[j], t);
+    const long ls = v.ny + 1, qs = (long)v.nz * ls;
+    cplx* T = v.fwdTab + (long)s * 5 * qs + (long)j * ls + col;
+    for (int q = 0; q < 5; ++q) T[q * qs] = t[q];
+}
+
 // --- Dirichlet values of the forward problem written into X's boundary nodes
 //     (getBoundaryMT2DTE/TM, mt2DTE.jl:100-134, mt2DTM.jl:100-134).  col = 0..ny.
 HD void item_bc_forward(const View& v, int s, int col) {
+    if (!v.sysOn[s]) return;
     const bool tm = s >= v.nFreq;
-    const double w = v.omega[s];
     cplx* X = v.X + (long)s * v.vstride;
     X[nidx(v, col, 0)] = cplx{1.0, 0.0};                  // top row incl. corners
-    if (col == 0 || col == v.ny) {
-        const int ky = col == 0 ? 0 : v.ny - 1;
-        bc1d_forward(w, v.nz, v.zLen, v.sigma + ky, v.sigma + ky, v.ny, 1.0, 0.0, tm,
-                     X + nidx(v, col, 1), v.NYP);
-    } else {
-        const double ya = v.yLen[col - 1], yb = v.yLen[col];
-        // (sig[i-1]*yLen[i-1] + sig[i]*yLen[i]) / (yLen[i-1]+yLen[i])  -- weights applied first
-        cplx b = bc1d_forward(w, v.nz, v.zLen, v.sigma + (col - 1), v.sigma + col, v.ny,
-                              ya / (ya + yb), yb / (ya + yb), tm, nullptr, 0);
-        X[nidx(v, col, v.nz)] = b;
-    }
+    const long ls = v.ny + 1, qs = (long)v.nz * ls;
+    const cplx* T = v.fwdTab + (long)s * 5 * qs + col;
+    if (col == 0 || col == v.ny) bc1d_forward_tab(v.omega[s], v.nz, T, qs, ls, tm, X + nidx(v, col, 1), v.NYP);
+    else X[nidx(v, col, v.nz)] = bc1d_forward_tab(v.omega[s], v.nz, T, qs, ls, tm, nullptr, 0);
 }
 
 // --- y = K u + i w D u at one interior node (u on the padded nodal grid incl. boundary values)
@@ -314,28 +334,49 @@ HD void item_colw(const View& v, int s, int ky) {           // MT1DSensitivity.j
     v.colw[(long)s * v.ny + ky] = c;
 }
 
-// --- dBC^T w by columns of the 1-D sensitivities (getBCDerivMatrix, MT1DSensitivity.jl:253-333)
-//     prof 0: left edge column, 1: right edge column, 2: lateral-mean profile
+// --- 1-D sensitivities (getBCDerivMatrix, MT1DSensitivity.jl:253-333) in three stages.
+//     prof 0: left edge column, 1: right edge column, 2: lateral-mean profile (:313-314)
+HD void item_sens_layers(const View& v, int s, int prof, int j) {      // j = 0..nz (nz = half-space copy)
+    if (!v.sysOn[s]) return;
+    const int jj = j < v.nz ? j : v.nz - 1;
+    const double sig = prof == 0 ? v.sigma[(long)jj * v.ny] : (prof == 1 ? v.sigma[(long)jj * v.ny + v.ny - 1] : v.sigMeanA[jj]);
+    cplx t[5];
+    layer_sens(sig, v.omega[s], v.zLen[jj], t);
+    const long n1 = v.nz + 1;
+    cplx* T = v.sensTab + ((long)s * 3 + prof) * 5 * n1 + j;
+    for (int q = 0; q < 5; ++q) T[q * n1] = t[q];
+}
+HD void item_sens_profile(const View& v, int s, int prof) {
+    if (!v.sysOn[s]) return;
+    const bool tm = s >= v.nFreq;
+    const long n1 = v.nz + 1, sp = (long)s * 3 + prof;
+    const cplx* T = v.sensTab + sp * 5 * n1;
+    cplx* fout = nullptr;
+    long fstride = 1;
+    if (tm) {                                             // `bc` of getBCderivTM (compJacTMatVec.jl:309,315)
+        if (prof == 0) fout = v.bcsL + (long)s * v.nz;
+        else if (prof == 1) fout = v.bcsR + (long)s * v.nz;
+        else { fout = v.bcsB + s; fstride = 0; }          // only the bottom value of the mean profile
+    }
+    v.sensDead[sp] = sens_profile(v.omega[s], v.nz, v.zLen, tm, T, T + n1, T + 2 * n1, T + 3 * n1, T + 4 * n1,
+                                  v.sensEu + sp * n1, v.sensEd + sp * n1, v.sensMix + sp * 4 * v.nz,
+                                  v.sensDz1 + sp * v.nz, v.sensZ1 + sp, fout, fstride);
+}
+// dBC^T w, one derivative column c of one profile
 HD void item_bcsens(const View& v, int s, int prof, int c) {
+    const long o = (long)s * v.nz + c;
     if (!v.sysOn[s]) {
-        const long o_ = (long)s * v.nz + c;
-        if (prof == 0) v.gL[o_] = cplx{0, 0}; else if (prof == 1) v.gR[o_] = cplx{0, 0}; else v.gMn[o_] = cplx{0, 0};
+        if (prof == 0) v.gL[o] = cplx{0, 0}; else if (prof == 1) v.gR[o] = cplx{0, 0}; else v.gMn[o] = cplx{0, 0};
         return;
     }
     const bool tm = s >= v.nFreq;
-    const double w = v.omega[s];
-    const long o = (long)s * v.nz;
-    if (prof == 0)
-        v.gL[o + c] = bc1d_sens_column(w, v.nz, v.zLen, v.sigma, v.ny, tm, c, v.wL + o, 1,
-                                       (tm && c == 0) ? v.bcsL + o : nullptr, 1);
-    else if (prof == 1)
-        v.gR[o + c] = bc1d_sens_column(w, v.nz, v.zLen, v.sigma + (v.ny - 1), v.ny, tm, c, v.wR + o, 1,
-                                       (tm && c == 0) ? v.bcsR + o : nullptr, 1);
-    else {
-        // mean profile: only its bottom field value is a boundary value (fstride 0: last write wins)
-        v.gMn[o + c] = bc1d_sens_column(w, v.nz, v.zLen, v.sigMeanA, 1, tm, c, nullptr, 0,
-                                        (tm && c == 0) ? v.bcsB + s : nullptr, 0);
-    }
+    const long n1 = v.nz + 1, sp = (long)s * 3 + prof;
+    const cplx* T = v.sensTab + sp * 5 * n1;
+    const cplx* w = prof == 0 ? v.wL + (long)s * v.nz : (prof == 1 ? v.wR + (long)s * v.nz : nullptr);
+    const cplx g = bc1d_sens_column(v.omega[s], v.nz, v.zLen, tm, c, T, T + n1, T + 2 * n1, T + 3 * n1,
+                                    v.sensEu + sp * n1, v.sensEd + sp * n1, v.sensMix + sp * 4 * v.nz,
+                                    v.sensDz1 + sp * v.nz, v.sensZ1[sp], v.sensDead[sp], w, 1);
+    if (prof == 0) v.gL[o] = g; else if (prof == 1) v.gR[o] = g; else v.gMn[o] = g;
 }
 
 // --- TM field with the sensitivity-version boundary values (compJacTMatVec.jl:307,315):
@@ -385,6 +426,19 @@ HD void item_gradcell(const View& v, int mode, int cell) {
     v.gPart[(long)mode * v.nCell + cell] = acc;
 }
 
+// --- Q-term of one system for one receiver-layer cell: Re sum_r conj(v_r) dZ_r/dsigma_c
+//     (compJacTMatVec.jl:209, :280)
+HD void item_qterm(const View& v, int s, int ky) {
+    double g = 0.0;
+    if (v.sysOn[s])
+        for (int r = 0; r < v.nRx; ++r) {
+            const long k = (long)s * v.nRx + r;
+            const int o = ky - v.rxN0[k];
+            if (o >= 0 && o < 3) g += (v.rxCoef[k] * v.rxD[k * 11 + 8 + o]).re;
+        }
+    v.qPart[(long)s * v.ny + ky] = g;
+}
+
 // --- final assembly of the gradient w.r.t. m = ln(sigma) for one active cell:
 //     P-terms + boundary terms + Q-terms, real part, chain rule (compJacTMatVec.jl:244,318,325-327;
 //     HMCSampler.jl:306)
@@ -400,14 +454,8 @@ HD void item_gradfinal(const View& v, int a) {
         if (ky == v.ny - 1) b += v.gR[o];
         g += b.re;
     }
-    if (kz == v.zid) {
-        for (int s = 0; s < v.S; ++s)
-            for (int r = 0; r < v.nRx && v.sysOn[s]; ++r) {
-                const long k = (long)s * v.nRx + r;
-                const int o = ky - v.rxN0[k];
-                if (o >= 0 && o < 3) g += (v.rxCoef[k] * v.rxD[k * 11 + 8 + o]).re;
-            }
-    }
+    if (kz == v.zid)
+        for (int s = 0; s < v.S; ++s) g += v.qPart[(long)s * v.ny + ky];
     v.grad[a] = exp(v.m[a]) * g;
 }
 

@@ -95,181 +95,263 @@ HD cplx ctanh_(cplx z) {
 // ---------------------------------------------------------------------------------------------
 // 1-D layered-earth fields used as Dirichlet values (mt1DField.jl:23-98).
 //
-// The column profile is sigma_j = wa*sa[j*stride] + wb*sb[j*stride] (wb = 0 for an edge column;
-// wa,wb = width weights of the two adjacent columns for a bottom node, mt2DTE.jl:127-131).
-// `out` (nullable, stride `ostride`) receives F_j/F_0 for j = 1..nz (E for TE, H for TM,
-// mt2DTE.jl:115-124); the return value is F_nz/F_0 (bottom value).
-// k^2 keeps the displacement term mu0*eps0*omega^2 (mt1DField.jl:48,52,66).
+// The transcendental work (one complex sqrt, tanh and two exps per layer) is independent across
+// layers, so it is done by a massively parallel table kernel (layer_forward); the two serial
+// recurrences then only multiply and divide.  k^2 keeps the displacement term mu0*eps0*omega^2
+// (mt1DField.jl:48,52,66).
 // ---------------------------------------------------------------------------------------------
 HD cplx k_eps(double sig, double omega) {
     return csqrt_(cplx{MU0 * EPS0 * omega * omega, -MU0 * sig * omega});
 }
 
-HD cplx bc1d_forward(double omega, int nz, const double* zLen, const double* sa, const double* sb,
-                     int stride, double wa, double wb, bool compH, cplx* out, int ostride) {
+// per-layer terms: out[0] k, out[1] 1/k, out[2] tanh(i k h), out[3] exp(i k h), out[4] exp(-i k h)
+HD void layer_forward(double sig, double omega, double h, cplx out[5]) {
+    const cplx k = k_eps(sig, omega);
+    const cplx ikh = mul_i(k * h);
+    out[0] = k;
+    out[1] = crecip(k);
+    out[2] = ctanh_(ikh);
+    out[3] = cexp_(ikh);
+    out[4] = cexp_(-ikh);
+}
+
+// Serial part for one column.  T points at this column's k-entry of layer 0; the five quantities are
+// `qs` elements apart and consecutive layers `ls` elements apart.  `out` (nullable, stride `ostride`)
+// receives F_j/F_0 for j = 1..nz (E for TE, H for TM, mt2DTE.jl:115-124); returns F_nz/F_0.
+// Both recurrences are latency-bound chains, so table entries are fetched RB layers at a time
+// before the dependent arithmetic of those layers starts.
+constexpr int RB = 4;
+HD cplx bc1d_forward_tab(double omega, int nz, const cplx* T, long qs, long ls, bool compH, cplx* out, long ostride) {
     const double omu0 = omega * MU0;
-    auto sig_at = [&](int j) -> double {
-        double s = wa * sa[(long)j * stride];
-        if (wb != 0.0) s += wb * sb[(long)j * stride];
-        return s;
-    };
+    const cplx one = cplx{1.0, 0.0};
     // impedance recurrence bottom -> top (:48-56); half-space has the last layer's conductivity
-    cplx k = k_eps(sig_at(nz - 1), omega);
-    cplx ztmp = omu0 / k;
-    for (int j = nz - 1; j >= 0; --j) {
-        k = k_eps(sig_at(j), omega);
-        cplx zp = omu0 / k;
-        cplx th = ctanh_(mul_i(k * zLen[j]));
-        ztmp = zp * (ztmp + zp * th) / (zp + ztmp * th);
-    }
-    // top-layer up/down-going amplitudes (:62-63); k is the top layer's wavenumber here
-    cplx a = omu0 / (ztmp * k);
-    cplx eu = 0.5 * (cplx{1.0, 0.0} - a);
-    cplx ed = 0.5 * (cplx{1.0, 0.0} + a);
-    cplx kj = k;
-    cplx f0 = compH ? ((ed - eu) * kj) / omu0 : (eu + ed);
-    cplx last = cplx{1.0, 0.0};
-    bool dead = false;
-    for (int i = 0; i < nz; ++i) {                      // :69-83, layer i -> i+1
-        cplx fn = cplx{0.0, 0.0};
-        if (!dead) {
-            cplx kn = (i + 1 < nz) ? k_eps(sig_at(i + 1), omega) : kj;   // half-space copy
-            cplx kr = kj / kn;
-            cplx ikh = mul_i(kj * zLen[i]);
-            cplx ep = cexp_(ikh), em = cexp_(-ikh);
-            cplx one = cplx{1.0, 0.0};
-            // (pInv*eUD)*e, same association as the reference
-            cplx m11 = (0.5 * (one + kr)) * ep, m12 = (0.5 * (one - kr)) * em;
-            cplx m21 = (0.5 * (one - kr)) * ep, m22 = (0.5 * (one + kr)) * em;
-            cplx nu = m11 * eu + m12 * ed;
-            cplx nd = m21 * eu + m22 * ed;
-            double e2 = cabs_(nu + nd), e1 = cabs_(eu + ed);
-            if (e2 - e1 > 0.0 || isnan(e2)) {
-                dead = true;                             // overflow cut-off: zero from here down
-            } else {
-                eu = nu; ed = nd; kj = kn;
-                fn = compH ? ((ed - eu) * kj) / omu0 : (eu + ed);
+    cplx ztmp = omu0 * T[qs + (long)(nz - 1) * ls];
+    for (int j0 = nz - 1; j0 >= 0; j0 -= RB) {
+        cplx ki[RB], th[RB];
+#pragma unroll
+        for (int t = 0; t < RB; ++t) {
+            const long j = j0 - t >= 0 ? j0 - t : 0;
+            ki[t] = T[qs + j * ls]; th[t] = T[2 * qs + j * ls];
+        }
+#pragma unroll
+        for (int t = 0; t < RB; ++t) {
+            if (j0 - t >= 0) {
+                const cplx zp = omu0 * ki[t];
+                ztmp = zp * (ztmp + zp * th[t]) / (zp + ztmp * th[t]);
             }
         }
-        last = fn / f0;
-        if (out) out[(long)i * ostride] = last;
+    }
+    // top-layer up/down-going amplitudes (:62-63)
+    cplx kj = T[0];
+    const cplx a = omu0 / (ztmp * kj);
+    cplx eu = 0.5 * (one - a), ed = 0.5 * (one + a);
+    const cplx f0 = compH ? ((ed - eu) * kj) / omu0 : (eu + ed);
+    const cplx if0 = crecip(f0);
+    cplx last = one;
+    bool dead = false;
+    for (int i0 = 0; i0 < nz; i0 += RB) {               // :69-83, layer i -> i+1
+        cplx kn_[RB], kin_[RB], ep_[RB], em_[RB];
+#pragma unroll
+        for (int t = 0; t < RB; ++t) {
+            const long i = i0 + t < nz ? i0 + t : nz - 1, in = i + 1 < nz ? i + 1 : nz - 1;
+            kn_[t] = T[in * ls]; kin_[t] = T[qs + in * ls]; ep_[t] = T[3 * qs + i * ls]; em_[t] = T[4 * qs + i * ls];
+        }
+#pragma unroll
+        for (int t = 0; t < RB; ++t) {
+            const int i = i0 + t;
+            if (i < nz) {
+                cplx fn = cplx{0.0, 0.0};
+                if (!dead) {
+                    const bool lastLayer = i + 1 >= nz;  // half-space copy below the last layer
+                    const cplx kn = lastLayer ? kj : kn_[t];
+                    const cplx kr = lastLayer ? one : kj * kin_[t];
+                    // (pInv*eUD)*e, same association as the reference
+                    const cplx m11 = (0.5 * (one + kr)) * ep_[t], m12 = (0.5 * (one - kr)) * em_[t];
+                    const cplx m21 = (0.5 * (one - kr)) * ep_[t], m22 = (0.5 * (one + kr)) * em_[t];
+                    const cplx nu = m11 * eu + m12 * ed;
+                    const cplx nd = m21 * eu + m22 * ed;
+                    const double e2 = cabs2(nu + nd), e1 = cabs2(eu + ed);   // |.|^2: same ordering as |.|
+                    if (e2 - e1 > 0.0 || isnan(e2)) {
+                        dead = true;                     // overflow cut-off: zero from here down
+                    } else {
+                        eu = nu; ed = nd; kj = kn;
+                        fn = compH ? ((ed - eu) * kj) / omu0 : (eu + ed);
+                    }
+                }
+                last = fn * if0;
+                if (out) out[(long)i * ostride] = last;
+            }
+        }
     }
     return last;
 }
 
 // ---------------------------------------------------------------------------------------------
-// 1-D boundary-field sensitivities (MT1DSensitivity.jl:25-243), one derivative column per call.
-//
-// For the profile sig[j*stride] (j = 0..nz-1, half-space copy appended) this walks the rows of the
-// reference's dense (nz+1) x nz matrix dE (source 'E', TE) or dH (source 'H', TM) for ONE column
-// c = derivative w.r.t. sig[c], and returns  sum_{row=1..nz} dF[row][c] * w[(row-1)*wstride]
-// (w == nullptr: returns dF[nz][c] alone, the bottom-row entry used for the mean profile).
-// If `fout` is non-null it also receives the field values F[row], row = 1..nz (the `bc` the
-// reference's getBCderivTM returns, compJacTMatVec.jl:309,315) -- no displacement term here
-// (MT1DSensitivity.jl:59), derivative w.r.t. the appended half-space dropped (:162-164), overflow
-// cut-off zeroes only the lower-right block (:145-155).
+// 1-D boundary-field sensitivities (MT1DSensitivity.jl:25-243) in three stages:
+//   layer_sens          per layer:   ka (no displacement term, :59), 1/ka, exp(+-i ka h), exp(-2 i ka h)
+//   sens_profile        per profile: top impedance z1 and d z1/d sig[c] (compImpJacMatrix :188-243),
+//                                    up/down-going amplitudes per row, mixing terms, cut-off row
+//   bc1d_sens_column    per derivative column c: walks the rows of the reference's dense (nz+1) x nz
+//                                    matrix dE (source 'E', TE) or dH (source 'H', TM)
+// Derivative w.r.t. the appended half-space is dropped (:162-164); the overflow cut-off zeroes only
+// the lower-right block (:145-155).
 // ---------------------------------------------------------------------------------------------
 HD cplx k_noeps(double sig, double omu) { return csqrt_(cplx{0.0, -omu * sig}); }
 
-HD cplx bc1d_sens_column(double omega, int nz, const double* zLen, const double* sig, int stride,
-                         bool srcH, int c, const cplx* w, int wstride, cplx* fout, int fstride) {
-    const double omu = omega * MU0;
-    const cplx one = cplx{1.0, 0.0};
-    const int nL = nz + 1;                               // layers incl. the half-space copy
-    auto sg = [&](int j) -> double { return sig[(long)(j < nz ? j : nz - 1) * stride]; };
+// out[0] ka, out[1] 1/ka, out[2] exp(i ka h), out[3] 1/exp(i ka h), out[4] exp(-2 i ka h)
+HD void layer_sens(double sig, double omega, double h, cplx out[5]) {
+    const cplx k = k_noeps(sig, omega * MU0);
+    out[0] = k;
+    out[1] = crecip(k);
+    out[2] = cexp_(mul_i(k * h));
+    out[3] = crecip(out[2]);
+    out[4] = cexp_((cplx{0.0, -2.0} * k) * h);
+}
 
-    // --- compImpJacMatrix (:188-243): top impedance z1 and d z1 / d sig[c]
-    cplx Z = cplx{0.0, 0.0}, prod = one, dsig_c = cplx{0.0, 0.0};
-    const cplx iom = cplx{0.0, omu};
-    for (int j = nL - 1; j >= 0; --j) {
-        cplx k = csqrt_(-(iom * sg(j)));
-        cplx Zt = omu / k;
-        cplx dZt = (cplx{0.0, omu * omu}) / (2.0 * (k * k * k));
-        if (j == nL - 1) {
-            Z = Zt;                                       // derivative w.r.t. the copy is dropped
-            continue;
+// Arrays of one profile (unit stride): ka, kinv [nz+1] (entry nz = half-space copy), expt, expr, ex2 [nz],
+// eu, ed [nz+1], mix [4][nz], dz1 [nz].  Returns the cut-off row (first row >= 1 whose amplitudes were
+// rejected) or nz+1; *z1out = top impedance.  fout (nullable): field value F[row], row = 1..nz, written
+// to fout[(row-1)*fstride] (fstride 0: only the bottom value survives).
+HD int sens_profile(double omega, int nz, const double* zLen, bool srcH, const cplx* ka, const cplx* kinv,
+                    const cplx* expt, const cplx* expr, const cplx* ex2, cplx* eu, cplx* ed, cplx* mix,
+                    cplx* dz1, cplx* z1out, cplx* fout, long fstride) {
+    const double omu = omega * MU0;
+    const cplx one = cplx{1.0, 0.0}, iom = cplx{0.0, omu};
+    const int nL = nz + 1;
+    // --- compImpJacMatrix; scratch: eu <- dZ/dZ_below, ed <- dZ/dsigma per layer
+    cplx Z = omu * kinv[nL - 1];
+    for (int j0 = nL - 2; j0 >= 0; j0 -= RB) {
+        cplx ki[RB], e2_[RB];
+#pragma unroll
+        for (int t = 0; t < RB; ++t) { const int j = j0 - t >= 0 ? j0 - t : 0; ki[t] = kinv[j]; e2_[t] = ex2[j]; }
+#pragma unroll
+        for (int t = 0; t < RB; ++t) {
+            const int j = j0 - t;
+            if (j >= 0) {
+                const cplx Zt = omu * ki[t];
+                const cplx dZt = (cplx{0.0, 0.5 * omu * omu}) * (ki[t] * ki[t] * ki[t]);
+                const cplx iS = crecip(Zt + Z);
+                const cplx ex = e2_[t];
+                const cplx L = ((Zt - Z) * iS) * ex;
+                const cplx i1L = crecip(one + L);
+                const cplx dL = ((2.0 * Z) * (iS * iS)) * ex * dZt + ((cplx{0.0, -2.0 * zLen[j]}) * L) * ((-(iom) / 2.0) * ki[t]);
+                eu[j] = ((4.0 * (Zt * Zt)) * ex) * ((i1L * iS) * (i1L * iS));
+                ed[j] = dZt * (one - L) * i1L + (Zt * (-2.0)) * (i1L * i1L) * dL;
+                Z = Zt * (one - L) * i1L;
+            }
         }
-        cplx RI = (Zt - Z) / (Zt + Z);
-        cplx ex = cexp_((cplx{0.0, -2.0} * k) * zLen[j]);
-        cplx L = RI * ex;
-        cplx Ztmp = Zt * (one - L) / (one + L);
-        cplx dL = (2.0 * Z) / ((Zt + Z) * (Zt + Z)) * ex * dZt +
-                  ((cplx{0.0, -2.0 * zLen[j]}) * L) * (-(iom) / 2.0 / k);
-        cplx dZ_ZP1 = (4.0 * (Zt * Zt)) * ex / (((one + L) * (Zt + Z)) * ((one + L) * (Zt + Z)));
-        cplx dZ_sig = dZt * (one - L) / (one + L) + (Zt * (-2.0)) / ((one + L) * (one + L)) * dL;
-        if (j == c) dsig_c = dZ_sig;
-        else if (j < c) prod = prod * dZ_ZP1;
-        Z = Ztmp;
     }
     const cplx z1 = Z;
-    const cplx dz1 = (c == 0) ? dsig_c : prod * dsig_c;   // zimpDeri[c] (:231-239)
-
-    // --- top layer (:63-92)
-    cplx ka = k_noeps(sg(0), omu);
-    auto dka_of = [&](cplx kk) -> cplx { return (cplx{0.0, -omu / 2.0}) / kk; };
-    cplx dk0 = (c == 0) ? dka_of(ka) : cplx{0.0, 0.0};    // dka[0][c]
-    cplx eu, ed, dEu, dEd, dHu, dHd;
+    *z1out = z1;
+    cplx prod = one;
+    for (int c = 0; c < nz; ++c) { dz1[c] = prod * ed[c]; prod = prod * eu[c]; }
+    // --- amplitudes (:63-92, :126-157)
+    cplx u, d;
     if (!srcH) {
-        cplx a = omu / (z1 * ka);
-        eu = 0.5 * (one - a);
-        ed = 0.5 * (one + a);
-        dEu = (0.5 * a) * (dz1 / z1 + dk0 / ka);
-        dEd = -dEu;
-        dHu = -(eu / omu) * dk0 - (ka / omu) * dEu;
-        dHd = (ed / omu) * dk0 + (ka / omu) * dEd;
+        const cplx a = omu / (z1 * ka[0]);
+        u = 0.5 * (one - a); d = 0.5 * (one + a);
     } else {
-        cplx hu = 0.5 * (one - z1 * ka / omu);
-        cplx hd = 0.5 * (one + z1 * ka / omu);
-        eu = -(omu / ka) * hu;
-        ed = (omu / ka) * hd;
-        dHu = (-0.5 / omu) * (z1 * dk0 + ka * dz1);
-        dHd = -dHu;
-        dEu = 0.5 * (dz1 + (omu / (ka * ka)) * dk0);
-        dEd = 0.5 * (dz1 - (omu / (ka * ka)) * dk0);
+        const cplx hu = 0.5 * (one - z1 * ka[0] / omu), hd = 0.5 * (one + z1 * ka[0] / omu);
+        u = -(omu * kinv[0]) * hu; d = (omu * kinv[0]) * hd;
     }
-
-    cplx acc = cplx{0.0, 0.0};
-    bool dead = false;
-    for (int j = 0; j < nz; ++j) {                        // row j -> j+1 (:126-157)
-        const int row = j + 1;
-        cplx dF = cplx{0.0, 0.0}, fval = cplx{0.0, 0.0};
-        if (!dead) {
-            cplx kn = k_noeps(sg(j + 1), omu);
-            cplx dkj = (c == j) ? dka_of(ka) : cplx{0.0, 0.0};          // dka[j][c]
-            cplx dkn = (c == j + 1) ? dka_of(kn) : cplx{0.0, 0.0};      // dka[j+1][c] (c<nz only)
-            cplx expt = cexp_(mul_i(ka * zLen[j]));
-            cplx expr = one / expt;
-            cplx dexpt = (c == j) ? (mul_i(zLen[j] * expt)) * dkj : cplx{0.0, 0.0};
-            cplx dexpr = (c == j) ? (-(mul_i(zLen[j] * expr))) * dkj : cplx{0.0, 0.0};
-            cplx kr = ka / kn;
-            cplx dkr = dkj / kn - (ka / (kn * kn)) * dkn;
-            cplx mix11 = (one + kr) * expt, mix12 = (one - kr) * expr;
-            cplx mix21 = (one - kr) * expt, mix22 = (one + kr) * expr;
-            cplx dmix11 = (one + kr) * dexpt + expt * dkr;
-            cplx dmix12 = (one - kr) * dexpr - expr * dkr;
-            cplx dmix21 = (one - kr) * dexpt - expt * dkr;
-            cplx dmix22 = (one + kr) * dexpr + expr * dkr;
-            // eLayer[:, j+1] = (pInv*eUD)*eLayer[:, j]
-            cplx nu = ((0.5 * (one + kr)) * expt) * eu + ((0.5 * (one - kr)) * expr) * ed;
-            cplx nd = ((0.5 * (one - kr)) * expt) * eu + ((0.5 * (one + kr)) * expr) * ed;
-            cplx nEu = 0.5 * (dmix11 * eu + mix11 * dEu + dmix12 * ed + mix12 * dEd);
-            cplx nEd = 0.5 * (dmix21 * eu + mix21 * dEu + dmix22 * ed + mix22 * dEd);
-            cplx nHu = -(nu / omu) * dkn - (kn / omu) * nEu;
-            cplx nHd = (nd / omu) * dkn + (kn / omu) * nEd;
-            double e2 = cabs_(nu + nd), e1 = cabs_(eu + ed);
-            if (e2 - e1 > 0.0 || isnan(e2)) {
-                dead = true;
-                // rows > j+1 are never computed (zero); row j+1 keeps columns c <= j only
-                if (c <= j) dF = srcH ? (nHu + nHd) : (nEu + nEd);
-            } else {
-                dF = srcH ? (nHu + nHd) : (nEu + nEd);
-                fval = srcH ? ((nd - nu) * kn) / omu : (nu + nd);
-            }
-            eu = nu; ed = nd; dEu = nEu; dEd = nEd; dHu = nHu; dHd = nHd; ka = kn;
+    eu[0] = u; ed[0] = d;
+    int dead = nz + 1;
+    for (int j0 = 0; j0 < nz; j0 += RB) {
+        cplx ka_[RB], kan_[RB], kin_[RB], et_[RB], er_[RB];
+#pragma unroll
+        for (int t = 0; t < RB; ++t) {
+            const int j = j0 + t < nz ? j0 + t : nz - 1;
+            ka_[t] = ka[j]; kan_[t] = ka[j + 1]; kin_[t] = kinv[j + 1]; et_[t] = expt[j]; er_[t] = expr[j];
         }
-        if (fout) fout[(long)j * fstride] = fval;
-        if (w) acc += dF * w[(long)(row - 1) * wstride];
-        else if (row == nz) acc = dF;
+#pragma unroll
+        for (int t = 0; t < RB; ++t) {
+            const int j = j0 + t;
+            if (j < nz) {
+                cplx fval = cplx{0.0, 0.0};
+                if (dead > nz) {
+                    const cplx kr = (j + 1 < nz) ? ka_[t] * kin_[t] : one;   // half-space copy: exactly 1
+                    const cplx m11 = (one + kr) * et_[t], m12 = (one - kr) * er_[t];
+                    const cplx m21 = (one - kr) * et_[t], m22 = (one + kr) * er_[t];
+                    mix[j] = m11; mix[nz + j] = m12; mix[2 * nz + j] = m21; mix[3 * nz + j] = m22;
+                    const cplx nu = ((0.5 * (one + kr)) * et_[t]) * u + ((0.5 * (one - kr)) * er_[t]) * d;
+                    const cplx nd = ((0.5 * (one - kr)) * et_[t]) * u + ((0.5 * (one + kr)) * er_[t]) * d;
+                    eu[j + 1] = nu; ed[j + 1] = nd;      // kept un-zeroed: the derivative row j+1 uses them
+                    const double e2 = cabs2(nu + nd), e1 = cabs2(u + d);
+                    if (e2 - e1 > 0.0 || isnan(e2)) dead = j + 1;
+                    else {
+                        u = nu; d = nd;
+                        fval = srcH ? ((nd - nu) * kan_[t]) / omu : (nu + nd);
+                    }
+                } else {
+                    mix[j] = mix[nz + j] = mix[2 * nz + j] = mix[3 * nz + j] = cplx{0, 0};
+                    eu[j + 1] = ed[j + 1] = cplx{0, 0};
+                }
+                if (fout) fout[(long)j * fstride] = fval;
+            }
+        }
+    }
+    return dead;
+}
+
+// Returns sum_{row=1..nz} dF[row][c] * w[(row-1)*wstride]  (w == nullptr: dF[nz][c], the bottom-row entry
+// used for the mean profile).
+HD cplx bc1d_sens_column(double omega, int nz, const double* zLen, bool srcH, int c, const cplx* ka,
+                         const cplx* kinv, const cplx* expt, const cplx* expr, const cplx* eu, const cplx* ed,
+                         const cplx* mix, const cplx* dz1, cplx z1, int dead, const cplx* w, long wstride) {
+    const double omu = omega * MU0;
+    const cplx one = cplx{1.0, 0.0};
+    const cplx dkc = (cplx{0.0, -omu / 2.0}) * kinv[c];   // dka[c][c] = (-i omu/2)/ka[c]
+    // --- top row (:63-92)
+    const cplx dk0 = (c == 0) ? dkc : cplx{0.0, 0.0};
+    cplx dEu, dEd;
+    if (!srcH) {
+        const cplx a = omu / (z1 * ka[0]);
+        dEu = (0.5 * a) * (dz1[c] / z1 + dk0 * kinv[0]);
+        dEd = -dEu;
+    } else {
+        dEu = 0.5 * (dz1[c] + (omu * (kinv[0] * kinv[0])) * dk0);
+        dEd = 0.5 * (dz1[c] - (omu * (kinv[0] * kinv[0])) * dk0);
+    }
+    cplx acc = cplx{0.0, 0.0};
+    const int last = dead <= nz ? dead : nz;              // rows beyond the cut-off row are zero
+    for (int j0 = 0; j0 < last; j0 += RB) {               // row j -> j+1 (:126-157)
+        cplx mx[RB][4], eu_[RB], ed_[RB], eun[RB], edn[RB], kan[RB], wv[RB];
+#pragma unroll
+        for (int t = 0; t < RB; ++t) {
+            const int j = j0 + t < last ? j0 + t : last - 1;
+            mx[t][0] = mix[j]; mx[t][1] = mix[nz + j]; mx[t][2] = mix[2 * nz + j]; mx[t][3] = mix[3 * nz + j];
+            eu_[t] = eu[j]; ed_[t] = ed[j]; eun[t] = eu[j + 1]; edn[t] = ed[j + 1]; kan[t] = ka[j + 1];
+            wv[t] = w ? w[(long)j * wstride] : cplx{0.0, 0.0};
+        }
+#pragma unroll
+        for (int t = 0; t < RB; ++t) {
+            const int j = j0 + t;
+            if (j < last) {
+                const int row = j + 1;
+                cplx nEu = 0.5 * (mx[t][0] * dEu + mx[t][1] * dEd);
+                cplx nEd = 0.5 * (mx[t][2] * dEu + mx[t][3] * dEd);
+                cplx dkn = cplx{0.0, 0.0};
+                if (c == j || c == j + 1) {               // the only columns with d(mix)/d sig[c] != 0
+                    const cplx dkj = (c == j) ? dkc : cplx{0.0, 0.0};
+                    dkn = (c == j + 1) ? dkc : cplx{0.0, 0.0};   // c <= nz-1, so never the half-space copy
+                    const cplx kr = (j + 1 < nz) ? ka[j] * kinv[j + 1] : one;
+                    const cplx dexpt = (c == j) ? (mul_i(zLen[j] * expt[j])) * dkj : cplx{0.0, 0.0};
+                    const cplx dexpr = (c == j) ? (-(mul_i(zLen[j] * expr[j]))) * dkj : cplx{0.0, 0.0};
+                    const cplx dkr = dkj * kinv[j + 1] - (ka[j] * (kinv[j + 1] * kinv[j + 1])) * dkn;
+                    const cplx dmix11 = (one + kr) * dexpt + expt[j] * dkr, dmix12 = (one - kr) * dexpr - expr[j] * dkr;
+                    const cplx dmix21 = (one - kr) * dexpt - expt[j] * dkr, dmix22 = (one + kr) * dexpr + expr[j] * dkr;
+                    nEu += 0.5 * (dmix11 * eu_[t] + dmix12 * ed_[t]);
+                    nEd += 0.5 * (dmix21 * eu_[t] + dmix22 * ed_[t]);
+                }
+                cplx dF;
+                if (!srcH) dF = nEu + nEd;
+                else dF = ((edn[t] - eun[t]) / omu) * dkn + (kan[t] / omu) * (nEd - nEu);
+                if (row == dead && c > j) dF = cplx{0.0, 0.0};   // cut-off row keeps columns c <= j only
+                dEu = nEu; dEd = nEd;
+                if (w) acc += dF * wv[t];
+                else if (row == nz) acc = dF;
+            }
+        }
     }
     return acc;
 }

@@ -33,7 +33,7 @@ class HmcmtError(RuntimeError):
 
 class Options(C.Structure):
     _fields_ = [("precond", C.c_int32), ("maxit", C.c_int32), ("tol", C.c_double),
-                ("check_every", C.c_int32), ("verify", C.c_int32)]
+                ("check_every", C.c_int32), ("verify", C.c_int32), ("warm_start", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -116,7 +116,7 @@ class HipContext:
     """One GPU context: the drop-in for the reference's per-call solver state."""
 
     def __init__(self, mtMesh, mtData, invParam, device_id=0, precond="fdmj", tol=None, maxit=None,
-                 verify=False, check_every=None):
+                 verify=False, check_every=None, warm_start=True):
         self.lib = load_library()
         self.args = CreateArgs(mtMesh, mtData, invParam)
         opts = Options()
@@ -131,6 +131,7 @@ class HipContext:
         if check_every is not None:
             opts.check_every = check_every
         opts.verify = int(verify)
+        opts.warm_start = int(warm_start)
         self.opts = opts
         h = C.c_void_p()
         rc = self.lib.hmcmt_create(C.byref(h), device_id, *self.args.as_tuple(), C.byref(opts))

@@ -58,6 +58,7 @@ typedef struct hmcmt_options {
     double  tol;          /* stop when ||P^-1 r|| <= tol*||x|| (error estimate); default 1e-11 */
     int32_t check_every;  /* host convergence poll interval in iterations; default 2 */
     int32_t verify;       /* 1: also compute true relative residuals ||b-Ax||/||b|| after each solve */
+    int32_t warm_start;   /* 1 (default): start both solves from the previous evaluation's fields */
 } hmcmt_options;
 
 typedef struct hmcmt_stats {

@@ -17,7 +17,9 @@ struct Emul {
     View v;
     std::vector<double> sigma, sigMeanA, sigMeanG, cY, cZ, dK, dM, mzq, dgz, ofz, mzs, misfitPart, gPart, grad, m;
     std::vector<cplx> invp, X, Lam, R, Zrx, rxD, rxCoef, pred, vbar, srcB, wL, wR, colw, gL, gR, gMn, bcsL, bcsR, bcsB;
-    std::vector<int> rxN0;
+    std::vector<int> rxN0, sensDead;
+    std::vector<double> qPart;
+    std::vector<cplx> fwdTab, sensTab, sensEu, sensEd, sensMix, sensDz1, sensZ1;
     std::vector<int> iters;
 
     void bind() {
@@ -37,6 +39,9 @@ struct Emul {
         wL.assign((size_t)h.S * h.nz, cplx{0, 0}); wR = wL; gL = wL; gR = wL; gMn = wL; bcsL = wL; bcsR = wL;
         colw.assign((size_t)h.S * h.ny, cplx{0, 0}); bcsB.assign(h.S, cplx{0, 0});
         gPart.assign((size_t)2 * h.nCell, 0); grad.assign(h.nAC, 0); m.assign(h.nAC, 0);
+        fwdTab.assign((size_t)h.S * 5 * h.nz * (h.ny + 1), cplx{0, 0}); sensTab.assign((size_t)h.S * 15 * (h.nz + 1), cplx{0, 0});
+        sensEu.assign((size_t)h.S * 3 * (h.nz + 1), cplx{0, 0}); sensEd = sensEu; sensMix.assign((size_t)h.S * 12 * h.nz, cplx{0, 0});
+        sensDz1.assign((size_t)h.S * 3 * h.nz, cplx{0, 0}); sensZ1.assign((size_t)h.S * 3, cplx{0, 0}); sensDead.assign((size_t)h.S * 3, 0);
         iters.assign(2 * h.S, 0);
         v.yLen = h.yLen.data(); v.zLen = h.zLen.data(); v.omega = h.omega.data(); v.lam = h.lam.data(); v.sysOn = h.sysOn.data();
         v.m = m.data(); v.sigma = sigma.data(); v.cell2act = h.cell2act.data(); v.bg = h.bg.data(); v.act = h.act.data();
@@ -53,6 +58,9 @@ struct Emul {
         v.srcB = srcB.data(); v.wL = wL.data(); v.wR = wR.data(); v.colw = colw.data();
         v.gL = gL.data(); v.gR = gR.data(); v.gMn = gMn.data(); v.bcsL = bcsL.data(); v.bcsR = bcsR.data();
         v.bcsB = bcsB.data(); v.gPart = gPart.data(); v.grad = grad.data();
+        qPart.assign((size_t)h.S * h.ny, 0); v.qPart = qPart.data();
+        v.fwdTab = fwdTab.data(); v.sensTab = sensTab.data(); v.sensEu = sensEu.data(); v.sensEd = sensEd.data();
+        v.sensMix = sensMix.data(); v.sensDz1 = sensDz1.data(); v.sensZ1 = sensZ1.data(); v.sensDead = sensDead.data();
         // constant halves of the stencils: TE stiffness, TM mass
         for (int iz = 0; iz < v.NZP; ++iz)
             for (int iy = 0; iy <= v.ny; ++iy) { item_coef(v, 0, iy, iz, true, false); item_coef(v, 1, iy, iz, false, true); }
@@ -170,6 +178,7 @@ struct Emul {
         for (int mode = 0; mode < 2; ++mode) for (int iz = 0; iz < V.NZP; ++iz) item_fdm_z(V, mode, iz);
         for (int s = 0; s < V.S; ++s) for (int j = 0; j < V.ny - 1; ++j) item_pivot(V, s, j);
         std::fill(X.begin(), X.end(), cplx{0, 0});
+        for (int s = 0; s < V.S; ++s) for (int j = 0; j < V.nz; ++j) for (int col = 0; col <= V.ny; ++col) item_bc_layers(V, s, j, col);
         for (int s = 0; s < V.S; ++s) for (int col = 0; col <= V.ny; ++col) item_bc_forward(V, s, col);
         for (int s = 0; s < V.S; ++s)
             for (int iz = 0; iz < V.NZP; ++iz) for (int iy = 0; iy <= V.ny; ++iy) item_rhs(V, s, iy, iz);
@@ -190,8 +199,13 @@ struct Emul {
             for (int iz = 1; iz <= V.nz; ++iz) item_wside(V, s, iz);
             for (int ky = 0; ky < V.ny; ++ky) item_colw(V, s, ky);
         }
-        for (int s = 0; s < V.S; ++s) for (int prof = 0; prof < 3; ++prof) for (int c = 0; c < V.nz; ++c) item_bcsens(V, s, prof, c);
+        for (int s = 0; s < V.S; ++s) for (int prof = 0; prof < 3; ++prof) {
+            for (int j = 0; j <= V.nz; ++j) item_sens_layers(V, s, prof, j);
+            item_sens_profile(V, s, prof);
+            for (int c = 0; c < V.nz; ++c) item_bcsens(V, s, prof, c);
+        }
         for (int mode = 0; mode < 2; ++mode) for (int c = 0; c < V.nCell; ++c) item_gradcell(V, mode, c);
+        for (int s = 0; s < V.S; ++s) for (int ky = 0; ky < V.ny; ++ky) item_qterm(V, s, ky);
         for (int a = 0; a < V.nAC; ++a) item_gradfinal(V, a);
     }
 };
