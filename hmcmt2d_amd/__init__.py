@@ -11,7 +11,8 @@ from .structs import (TensorMesh2D, MTData, HMCPrior, HMCParameter, HMCStatus, I
 from .invsetup import setupInverseDataModel, setActiveElement, compDataWeightMat
 from .fileio import (readEMModel2D, writeEMModel2D, readMT2DData, writeMT2DData, readstartupFile,
                      outputHMCSamples, getPosteriorModel)
-from .sampler import (compDataGradient, compDataMisfit, getHamiltonian, proposeLeapfrog, runHMCSampler,
+from .sampler import (compDataGradient, compDataMisfit, getHamiltonian, proposeLeapfrog, proposeLeapfrogDevice,
+                      runHMCSampler,
                       parallelHMCSampler, getKineticEnergy, getKineticGradient, getMomentumVector,
                       setMassMatrix, checkParameterBound, get_context, release_context)
 from .lib import HipContext, HmcmtError, build_library

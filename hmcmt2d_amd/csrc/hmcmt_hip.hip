@@ -656,6 +656,78 @@ __global__ void k_unpad(View v, const cplx* src, cplx* dst, int s0) {
     dst[(long)f * nn + e] = src[(long)(s0 + f) * v.vstride + nidx(v, iy, iz)];
 }
 
+// ----------------------------------------------------------------------------------------------
+// leapfrog vector kernels (proposeLeapfrog, HMCSampler.jl:206-269; diagonal mass)
+// ----------------------------------------------------------------------------------------------
+struct LfView {
+    int n;
+    const double *mref, *invM, *wmVal;
+    const long long *wmRow, *wmCol;
+    double *m, *p, *g;            // model, momentum, data gradient (in) / total gradient (out)
+    double *part;                 // [LFNB] partial maxima / sums
+    double *scal;                 // [0] mnorm
+    int* flag;                    // non-zero: non-finite value met
+};
+constexpr int LFNB = 64;
+
+// g <- g + lambda*Wm*(m - mref) ; p <- p - c*dt*g      (HMCSampler.jl:223-228, 255-263)
+__global__ void k_lf_momentum(LfView L, double lambda, double cdt) {
+    const int a = TID1;
+    if (a >= L.n) return;
+    double acc = 0.0;
+    for (long long t = L.wmRow[a]; t < L.wmRow[a + 1]; ++t) {
+        const long long j = L.wmCol[t];
+        acc += L.wmVal[t] * (L.m[j] - L.mref[j]);
+    }
+    const double g = L.g[a] + lambda * acc;
+    L.g[a] = g;
+    L.p[a] -= cdt * g;
+}
+// partial max |dt*invM*p|   (HMCSampler.jl:237-240)
+__global__ __launch_bounds__(256) void k_lf_dmmax(LfView L, double dt) {
+    __shared__ double sh[4];
+    double mx = 0.0;
+    for (int a = blockIdx.x * 256 + threadIdx.x; a < L.n; a += 256 * LFNB) mx = fmax(mx, fabs(dt * L.invM[a] * L.p[a]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) L.part[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+// m += dm (clamped to max |dm| = 3), reflect at the ln-sigma bounds, flip momentum (:241-247, :515-559)
+__global__ void k_lf_step(LfView L, double dt, double lo, double hi) {
+    const int a = TID1;
+    if (a >= L.n) return;
+    double mx = 0.0;
+    for (int b = 0; b < LFNB; ++b) mx = fmax(mx, L.part[b]);
+    double dm = dt * L.invM[a] * L.p[a];
+    if (mx > 3.0) dm = dm / mx * 3.0;
+    double m = L.m[a] + dm, p = L.p[a];
+    if (!isfinite(m)) { atomicExch(L.flag, 1); return; }
+    for (int it = 0; it < 500 && !(m <= hi && m >= lo); ++it) {
+        if (m < lo) { m = 2.0 * lo - m; p = -p; }
+        if (m > hi) { m = 2.0 * hi - m; p = -p; }
+    }
+    L.m[a] = m; L.p[a] = p;
+}
+// mnorm = 0.5*lambda*(m-mref)' Wm (m-mref)   (HMCSampler.jl:389-391): partial sums, then block 0 finishes
+__global__ __launch_bounds__(256) void k_lf_mnorm(LfView L, double lambda) {
+    __shared__ double sh[8];
+    double acc = 0.0, dummy = 0.0;
+    for (int a = blockIdx.x * 256 + threadIdx.x; a < L.n; a += 256 * LFNB) {
+        double row = 0.0;
+        for (long long t = L.wmRow[a]; t < L.wmRow[a + 1]; ++t) { const long long j = L.wmCol[t]; row += L.wmVal[t] * (L.m[j] - L.mref[j]); }
+        acc += (L.m[a] - L.mref[a]) * row;
+    }
+    block_sum2(acc, dummy, sh);
+    if (threadIdx.x == 0) L.part[blockIdx.x] = acc;
+}
+__global__ void k_lf_mnorm_final(LfView L, double lambda) {
+    double acc = 0.0;
+    for (int b = 0; b < LFNB; ++b) acc += L.part[b];
+    L.scal[0] = 0.5 * lambda * acc;
+}
+
 }  // namespace
 
 // ----------------------------------------------------------------------------------------------
@@ -1291,16 +1363,90 @@ int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z) {
     return 0;
 }
 
-int hmcmt_set_prior(hmcmt_ctx* ctx, const double*, const int64_t*, const int64_t*, const double*, const double*) {
-    if (!ctx) return HMCMT_EINVAL;
-    ctx->err = "hmcmt_set_prior: not built yet";
-    return HMCMT_EINVAL;
+int hmcmt_set_prior(hmcmt_ctx* ctx, const double* mref, const int64_t* rowptr, const int64_t* colind,
+                    const double* val, const double* invM) {
+    if (!ctx || !mref || !rowptr || !colind || !val || !invM) return HMCMT_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->v.nAC;
+    const int64_t nnz = rowptr[n];
+    if (rowptr[0] != 0 || nnz < 0) { ctx->err = "Wm row pointer must be 0-based CSR"; return HMCMT_EINVAL; }
+    for (int64_t t = 0; t < nnz; ++t)
+        if (colind[t] < 0 || colind[t] >= n) { ctx->err = "Wm column index out of range"; return HMCMT_EINVAL; }
+    std::vector<double> v_mref(mref, mref + n), v_invM(invM, invM + n), v_val(val, val + nnz);
+    std::vector<long long> v_row(rowptr, rowptr + n + 1), v_col(colind, colind + nnz);
+    int rc;
+    if ((rc = dupload(ctx, &ctx->d_mref, v_mref))) return rc;
+    if ((rc = dupload(ctx, &ctx->d_invM, v_invM))) return rc;
+    if ((rc = dupload(ctx, &ctx->d_wmVal, v_val))) return rc;
+    if ((rc = dupload(ctx, &ctx->d_wmRow, v_row))) return rc;
+    if ((rc = dupload(ctx, &ctx->d_wmCol, v_col))) return rc;
+    if (!ctx->d_p) {
+        if ((rc = dalloc(ctx, &ctx->d_p, (size_t)n))) return rc;
+        if ((rc = dalloc(ctx, &ctx->d_mcur, (size_t)n))) return rc;
+        if ((rc = dalloc(ctx, &ctx->d_g, (size_t)n))) return rc;
+        if ((rc = dalloc(ctx, &ctx->d_lfPart, (size_t)LFNB))) return rc;
+        if ((rc = dalloc(ctx, &ctx->d_lfScal, (size_t)4))) return rc;
+        if ((rc = dalloc(ctx, &ctx->d_lfFlag, (size_t)1))) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->havePrior = true;
+    return 0;
 }
-int hmcmt_leapfrog(hmcmt_ctx* ctx, const double*, const double*, double, int32_t, double, double, double,
-                   double*, double*, double*, double*, double*, int32_t*) {
-    if (!ctx) return HMCMT_EINVAL;
-    ctx->err = "hmcmt_leapfrog: not built yet";
-    return HMCMT_EINVAL;
+
+int hmcmt_leapfrog(hmcmt_ctx* ctx, const double* m0, const double* p0, double dt, int32_t L, double regParam,
+                   double lnSigMin, double lnSigMax, double* m1, double* p1, double* pred, double* misfit,
+                   double* mnorm, int32_t* nfevals) {
+    if (!ctx || !m0 || !p0 || !m1 || !p1) return HMCMT_EINVAL;
+    if (!ctx->havePrior) { ctx->err = "hmcmt_set_prior has not been called"; return HMCMT_EINVAL; }
+    if (L < 1 || !(dt > 0) || !(lnSigMax > lnSigMin)) { ctx->err = "need L >= 1, dt > 0, lnSigMax > lnSigMin"; return HMCMT_EINVAL; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->v.nAC, nData = ctx->v.nData;
+    for (int i = 0; i < n; ++i)
+        if (!std::isfinite(m0[i]) || !std::isfinite(p0[i])) { ctx->err = "non-finite model or momentum"; return HMCMT_EBREAKDOWN; }
+    hipStream_t st = ctx->stream;
+    std::memcpy(ctx->h_stage, m0, sizeof(double) * n);
+    std::memcpy(ctx->h_stage + n, p0, sizeof(double) * n);
+    HIPCHK(hipMemcpyAsync(ctx->d_mcur, ctx->h_stage, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->d_p, ctx->h_stage + n, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(ctx->d_lfFlag, 0, sizeof(int), st));
+    LfView lf{n, ctx->d_mref, ctx->d_invM, ctx->d_wmVal, ctx->d_wmRow, ctx->d_wmCol, ctx->d_mcur, ctx->d_p, ctx->d_g,
+              ctx->d_lfPart, ctx->d_lfScal, ctx->d_lfFlag};
+    const dim3 g1((n + 127) / 128), b1(128);
+    int evals = 0;
+    int rc = evaluate(ctx, ctx->d_mcur, true, nullptr, nullptr, ctx->d_g);
+    if (rc) return rc;
+    if ((rc = finish_status(ctx))) return rc;
+    ++evals;
+    hipLaunchKernelGGL(k_lf_momentum, g1, b1, 0, st, lf, regParam, 0.5 * dt);
+    for (int k = 1; k <= L; ++k) {
+        hipLaunchKernelGGL(k_lf_dmmax, dim3(LFNB), dim3(256), 0, st, lf, dt);
+        hipLaunchKernelGGL(k_lf_step, g1, b1, 0, st, lf, dt, lnSigMin, lnSigMax);
+        rc = evaluate(ctx, ctx->d_mcur, true, nullptr, nullptr, ctx->d_g);
+        if (rc) return rc;
+        if ((rc = finish_status(ctx))) return rc;
+        ++evals;
+        hipLaunchKernelGGL(k_lf_momentum, g1, b1, 0, st, lf, regParam, (k < L ? 1.0 : 0.5) * dt);
+    }
+    hipLaunchKernelGGL(k_lf_mnorm, dim3(LFNB), dim3(256), 0, st, lf, regParam);
+    hipLaunchKernelGGL(k_lf_mnorm_final, dim3(1), dim3(1), 0, st, lf, regParam);
+    double* hs = ctx->h_stage;
+    HIPCHK(hipMemcpyAsync(hs, ctx->d_mcur, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hs + n, ctx->d_p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hs + 2 * n, ctx->v.pred, sizeof(cplx) * nData, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hs + 2 * n + 2 * nData, ctx->d_misfit, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hs + 2 * n + 2 * nData + 1, ctx->d_lfScal, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx->h_nactive, ctx->d_lfFlag, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    prof_collect(ctx);
+    if (*ctx->h_nactive) { ctx->err = "non-finite model value during the trajectory"; return HMCMT_EBREAKDOWN; }
+    std::memcpy(m1, hs, sizeof(double) * n);
+    std::memcpy(p1, hs + n, sizeof(double) * n);
+    if (pred) std::memcpy(pred, hs + 2 * n, sizeof(cplx) * nData);
+    if (misfit) *misfit = hs[2 * n + 2 * nData];
+    if (mnorm) *mnorm = hs[2 * n + 2 * nData + 1];
+    if (nfevals) *nfevals = evals;
+    return 0;
 }
 
 }  // extern "C"

@@ -155,8 +155,28 @@ def proposeLeapfrog(hmcParamCurrent: HMCParameter, mtMesh, mtData, invParam, hmc
     return propModel, propMomentum
 
 
+def proposeLeapfrogDevice(hmcParamCurrent: HMCParameter, mtMesh, mtData, invParam, hmcprior, rng=None,
+                          intstep=None, ctx: HipContext | None = None):
+    """Same contract as proposeLeapfrog, with the whole trajectory kept on the GPU
+    (`hmcmt_leapfrog`): only (m, p) go in and (m', p', predData, misfit) come out.  The prior
+    (refModel, Wm, mass) must have been registered with `ctx.set_prior`."""
+    ctx = ctx or get_context(mtMesh, mtData, invParam)
+    if intstep is None:
+        intstep = int(rng.integers(hmcprior.timestep[0], hmcprior.timestep[1] + 1))
+    lo, hi = np.log(hmcprior.sigBounds[0]), np.log(hmcprior.sigBounds[1])
+    m1, p1, pred, misfit, mnorm, nf = ctx.leapfrog(hmcParamCurrent.rhomodel, hmcParamCurrent.momentum, hmcprior.dt,
+                                                   intstep, hmcprior.regParam, lo, hi)
+    hmcprior.nfevals += nf
+    invParam.strModel = m1.copy()
+    sigma = invParam.bgModel.copy()
+    sigma[invParam.activeIdx] += np.exp(m1)
+    mtMesh.sigma = sigma
+    ctx._cache = (m1.copy(), pred, misfit)                 # getHamiltonian reuses the proposal's forward
+    return m1, p1
+
+
 def runHMCSampler(mtMesh, mtData, invParam, hmcprior, rng=None, rhoref=None, ctx: HipContext | None = None,
-                  verbose=False, reuse_forward=True):
+                  verbose=False, reuse_forward=True, device_leapfrog=False):
     """Returns (hmcmodel[nparam, nsamples], hmcstats, hmcdata[ndata, nsamples+1])."""
     _check_solver(hmcprior)
     rng = rng or np.random.default_rng()
@@ -181,6 +201,8 @@ def runHMCSampler(mtMesh, mtData, invParam, hmcprior, rng=None, rhoref=None, ctx
     invParam.refModel = strModel.copy()
     startD, startK, startH, startM, predData = getHamiltonian(mtData, mtMesh, invParam, hmcprior, cur, ctx,
                                                               reuse_forward)
+    if device_leapfrog:
+        ctx.set_prior(invParam.refModel, invParam.Wm, cur.invM)
     nsamples = hmcprior.totalsamples
     hmcmodel = np.zeros((nparam, nsamples))
     hmcdata = np.zeros((ndata, nsamples + 1), dtype=np.complex128)
@@ -188,7 +210,8 @@ def runHMCSampler(mtMesh, mtData, invParam, hmcprior, rng=None, rhoref=None, ctx
     stats.hmstats[:, 0] = [startD, startM, startK, startH]
     hmcdata[:, 0] = predData
     for it in range(1, nsamples + 1):
-        propModel, propMomentum = proposeLeapfrog(cur, mtMesh, mtData, invParam, hmcprior, rng, None, ctx)
+        propose = proposeLeapfrogDevice if device_leapfrog else proposeLeapfrog
+        propModel, propMomentum = propose(cur, mtMesh, mtData, invParam, hmcprior, rng, None, ctx)
         prop.rhomodel, prop.momentum = propModel.copy(), propMomentum.copy()
         finishD, finishK, finishH, finishM, predData = getHamiltonian(mtData, mtMesh, invParam, hmcprior, prop,
                                                                       ctx, reuse_forward)

@@ -197,3 +197,52 @@ def test_sampler_short_chain_on_gpu_matches_oracle_chain():
     sampler.release_context(inv_p)
     assert np.array_equal(sp_.acceptstats, so["acceptstats"])
     assert relmax(mp, mo) < 1e-7 and relmax(dp, do) < 1e-7 and relmax(sp_.hmstats, so["hmstats"]) < 1e-7
+
+
+def test_device_leapfrog_matches_host_loop_and_golden():
+    """hmcmt_leapfrog (trajectory on the GPU) vs the host-side proposeLeapfrog loop over the same
+    context, and vs the oracle's golden trajectory (3 steps, with a bound reflection)."""
+    import copy
+    from hmcmt2d_amd import sampler
+    from hmcmt2d_amd.structs import initHMCParameter
+    g = np.load(os.path.join(GOLDEN, "tiny.npz"))
+    mesh, data, inv, m = make_problem("tiny")
+    inv.refModel = g["lf_mref"].copy()
+    prior = HMCPrior(dt=float(g["lf_dt"]), timestep=[3, 3], sigBounds=list(g["lf_bounds"]), regParam=1.0)
+    ctx = HipContext(mesh, data, inv, warm_start=False)
+    hp = initHMCParameter(len(m)); hp.invM[:] = 1.0; hp.sqrtM[:] = 1.0
+    hp.rhomodel, hp.momentum = g["lf_m0"].copy(), g["lf_p0"].copy()
+    pa = copy.deepcopy(prior)
+    m_host, p_host = sampler.proposeLeapfrog(hp, mesh, data, copy.deepcopy(inv), pa, None, 3, ctx)
+    ctx.set_prior(inv.refModel, inv.Wm, hp.invM)
+    pb = copy.deepcopy(prior)
+    inv_b = copy.deepcopy(inv)
+    m_dev, p_dev = sampler.proposeLeapfrogDevice(hp, mesh, data, inv_b, pb, None, 3, ctx)
+    assert pa.nfevals == pb.nfevals == 4
+    assert relmax(m_dev, m_host) < 1e-12 and relmax(p_dev, p_host) < 1e-9
+    assert relmax(m_dev, g["lf_m1"]) < 1e-9 and relmax(p_dev, g["lf_p1"]) < 1e-6
+    # Hamiltonian terms at the proposal come back with the trajectory
+    hp2 = initHMCParameter(len(m)); hp2.invM[:] = 1.0; hp2.momentum = p_dev
+    d, k, h, mn, pred = sampler.getHamiltonian(data, mesh, inv_b, pb, hp2, ctx)
+    pf, mf = ctx.forward(m_dev)
+    d_mn = 0.5 * float((m_dev - inv.refModel) @ (inv.Wm @ (m_dev - inv.refModel)))
+    assert abs(d - mf) / mf < 1e-9 and abs(mn - d_mn) / max(d_mn, 1e-30) < 1e-12
+    # error path: trajectory from a NaN momentum
+    with pytest.raises(HmcmtError):
+        ctx.leapfrog(g["lf_m0"], np.full(len(m), np.nan), 0.03, 2, 1.0, -9.0, 0.0)
+    ctx.close()
+
+
+def test_device_leapfrog_chain_equals_host_chain():
+    import copy
+    from hmcmt2d_amd import sampler
+    mesh, data, inv, m = make_problem("tiny")
+    prior = HMCPrior(totalsamples=3, burninsamples=1, dt=0.02, timestep=[2, 3], sigBounds=[1e-4, 1.0])
+    out = []
+    for dev in (False, True):
+        inv_c, prior_c = copy.deepcopy(inv), copy.deepcopy(prior)
+        res = sampler.runHMCSampler(copy.deepcopy(mesh), data, inv_c, prior_c, np.random.default_rng(5), device_leapfrog=dev)
+        sampler.release_context(inv_c)
+        out.append(res)
+    assert np.array_equal(out[0][1].acceptstats, out[1][1].acceptstats)
+    assert relmax(out[1][0], out[0][0]) < 1e-8 and relmax(out[1][1].hmstats, out[0][1].hmstats) < 1e-8
