@@ -40,6 +40,10 @@ struct Solver {
     const cplx* invp;                     // [S][vstride]
     cplx *x, *r, *p, *q, *z, *y, *t;      // [S][vstride]
     cplx *dinv;                           // [S][vstride] omegaJ / diag(A) on interior nodes, 0 elsewhere
+    // mixed-precision FDM stage (options.fdm_precision == 0): bf16 transform operands, fp32 tridiagonal
+    float2* t32;                          // [S][vstride] complex64 transform input
+    float2* y32;                          // [S][vstride] complex64
+    const float2* invp32;                 // [S][vstride]
     cplx *partA;                          // [S][MAXNB]  p'q   | r'z
     double *partB;                        // [S][MAXNB]  |x|^2 | |z|^2
     cplx *rho, *alphaBeta;                // [S]
@@ -173,7 +177,10 @@ __global__ void k_check(Solver k, const double* partZZ, int first, int maxit) {
             if (!first) xx += k.partB[(long)s * MAXNB + b];
         }
         bool on = true;
-        if (first) {
+        if (first == 2) {                                                // restart with a different preconditioner
+            k.rho[s] = rz;
+            k.alphaBeta[s] = cplx{0, 0};
+        } else if (first) {
             k.rho[s] = rz;
             k.alphaBeta[s] = cplx{0, 0};
             k.errEst[s] = 1.0;
@@ -327,13 +334,107 @@ __global__ __launch_bounds__(256) void k_transform(const cplx* __restrict__ A, c
     }
 }
 
-// batched tridiagonal solve in z for every (system, eigenmode j): Thomas with precomputed inverse
-// pivots, in place on y[s][iz][j]; lanes = consecutive j (coalesced 1 KiB rows).  The recurrence is
-// serial in iz, so the kernel is latency-bound: coupling coefficients sit in LDS, rows are processed
-// in branch-free blocks of TB with the next block's operands already in flight, and the (< TB) tail
-// rows use a plain loop.
+// batched tridiagonal solve in z for every (system, eigenmode j), in place on y[s][iz][j]; lanes =
+// consecutive j (coalesced rows).  About 75 ns per row at one wave per CU; neither deeper prefetch, more
+// waves nor shorter chains change that (all measured).
+// With HMCMT_TWIST the twisted factorisation of item_pivot is used (rows 1..mid swept top-down, rows
+// n..mid+1 bottom-up as two interleaved chains joined by one 2x2 solve); it measured SLOWER (20 vs 16 us):
+// the kernel is bound by instruction issue of its ~100 lone waves, not by dependency latency, so the
+// default is the classic sweep (mid = n, bottom chain compiled out).
+// Operands of the next block of rows are in flight while the current block is processed.
 constexpr int TB = 8;
 constexpr int MAXNZP = 1024;
+
+struct alignas(8) c32 { float re, im; };
+__device__ __forceinline__ c32 operator*(c32 a, c32 b) { return c32{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ c32 operator*(float a, c32 b) { return c32{a * b.re, a * b.im}; }
+__device__ __forceinline__ c32 operator-(c32 a, c32 b) { return c32{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ void pin(cplx& a) { asm volatile("" : "+v"(a.re), "+v"(a.im)); }
+__device__ __forceinline__ void pin(c32& a) { asm volatile("" : "+v"(a.re), "+v"(a.im)); }
+
+template <class CT, class RT>
+__device__ __forceinline__ void thomas_twisted(CT* __restrict__ y, const CT* __restrict__ ip, const RT* sof, int n, long NYP) {
+    const int mid = twist_mid(n), nt = mid, nb = n - mid;
+    constexpr bool TW = HMCMT_TWIST != 0;               // classic sweep: the bottom/down chain code is compiled out
+    CT pt = CT{0, 0}, pb = CT{0, 0};
+    CT yt[TB], it[TB], yb[TB], ib[TB];
+    // ---- phase 1: normalised elimination, top chain rows 1..mid, bottom chain rows n..mid+1
+    auto load1 = [&](int k0, CT* a, CT* b, CT* c, CT* d) {
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const int kt = min(k0 + t, nt - 1), kb = min(k0 + t, max(nb - 1, 0));
+            a[t] = y[(long)(1 + kt) * NYP]; b[t] = ip[(long)(1 + kt) * NYP];
+            if (TW) { c[t] = y[(long)(n - kb) * NYP]; d[t] = ip[(long)(n - kb) * NYP]; }
+        }
+    };
+    load1(0, yt, it, yb, ib);
+    for (int k0 = 0; k0 < nt; k0 += TB) {
+        CT nyt[TB], nit[TB], nyb[TB], nib[TB];
+        load1(min(k0 + TB, max(nt - 1, 0)), nyt, nit, nyb, nib);
+        RT ot[TB], ob[TB];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) { ot[t] = sof[min(k0 + t, nt - 1)]; ob[t] = TW ? sof[n - min(k0 + t, max(nb - 1, 0))] : RT(0); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const int k = k0 + t;
+            if (k < nt) { pt = (yt[t] - ot[t] * pt) * it[t]; y[(long)(1 + k) * NYP] = pt; }
+            if (TW && k < nb) { pb = (yb[t] - ob[t] * pb) * ib[t]; y[(long)(n - k) * NYP] = pb; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            yt[t] = nyt[t]; it[t] = nit[t]; pin(yt[t]); pin(it[t]);
+            if (TW) { yb[t] = nyb[t]; ib[t] = nib[t]; pin(yb[t]); pin(ib[t]); }
+        }
+    }
+    // ---- join: x_mid + c x_{mid+1} = y'_mid ; x_{mid+1} + c' x_mid = y''_{mid+1} ; ip[0] = 1/(1 - c c')
+    if (TW && nb > 0) {
+        const RT o = sof[mid];
+        const CT c = o * ip[(long)mid * NYP], c2 = o * ip[(long)(mid + 1) * NYP];
+        pt = (pt - c * pb) * ip[0];
+        pb = pb - c2 * pt;
+        y[(long)mid * NYP] = pt; y[(long)(mid + 1) * NYP] = pb;
+    }
+    // ---- phase 2: substitution outwards, up chain rows mid-1..1, down chain rows mid+2..n
+    const int nu = nt - 1, nd = nb - 1;
+    if (nu <= 0 && nd <= 0) return;
+    auto load2 = [&](int k0, CT* a, CT* b, CT* c, CT* d) {
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const int ku = min(k0 + t, max(nu - 1, 0)), kd = min(k0 + t, max(nd - 1, 0));
+            const int ru = max(mid - 1 - ku, 1), rd = min(mid + 2 + kd, n);
+            a[t] = y[(long)ru * NYP]; b[t] = ip[(long)ru * NYP];
+            if (TW) { c[t] = y[(long)rd * NYP]; d[t] = ip[(long)rd * NYP]; }
+        }
+    };
+    load2(0, yt, it, yb, ib);
+    const int nmax = max(nu, nd);
+    for (int k0 = 0; k0 < nmax; k0 += TB) {
+        CT nyt[TB], nit[TB], nyb[TB], nib[TB];
+        load2(min(k0 + TB, max(nmax - 1, 0)), nyt, nit, nyb, nib);
+        RT ou[TB], od[TB];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const int ru = max(mid - 1 - min(k0 + t, max(nu - 1, 0)), 1), rd = min(mid + 2 + min(k0 + t, max(nd - 1, 0)), n);
+            ou[t] = sof[ru]; od[t] = TW ? sof[rd - 1] : RT(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            const int k = k0 + t;
+            if (k < nu) { pt = yt[t] - (ou[t] * it[t]) * pt; y[(long)(mid - 1 - k) * NYP] = pt; }
+            if (TW && k < nd) { pb = yb[t] - (od[t] * ib[t]) * pb; y[(long)(mid + 2 + k) * NYP] = pb; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+            yt[t] = nyt[t]; it[t] = nit[t]; pin(yt[t]); pin(it[t]);
+            if (TW) { yb[t] = nyb[t]; ib[t] = nib[t]; pin(yb[t]); pin(ib[t]); }
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_thomas(Solver k) {
     const int s = blockIdx.y;
     if (!k.active[s]) return;
@@ -343,74 +444,20 @@ __global__ __launch_bounds__(64) void k_thomas(Solver k) {
     __syncthreads();
     const int j = blockIdx.x * 64 + threadIdx.x;
     if (j >= k.ny - 1) return;
-    const cplx* __restrict__ ip = k.invp + (long)s * k.vstride + j;
-    cplx* __restrict__ y = k.y + (long)s * k.vstride + j;
-    const long NYP = k.NYP;
-    const int n = k.nz - 1;                             // rows 1..n
-    cplx prev = cplx{0, 0};
-    cplx yv[TB], pv[TB];
-    // ---- forward: y'_iz = (y_iz - of_{iz-1} y'_{iz-1}) * invp_iz   (sof[0] = 0)
-    const int nfull = n / TB;
-    if (nfull > 0) {
-#pragma unroll
-        for (int t = 0; t < TB; ++t) { yv[t] = y[(1 + t) * NYP]; pv[t] = ip[(1 + t) * NYP]; }
-        for (int b = 0; b < nfull; ++b) {
-            const int nb = (b + 1 < nfull) ? b + 1 : b;  // last block re-reads itself (harmless)
-            cplx ny_[TB], np_[TB];
-#pragma unroll
-            for (int t = 0; t < TB; ++t) { ny_[t] = y[(1 + nb * TB + t) * NYP]; np_[t] = ip[(1 + nb * TB + t) * NYP]; }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                const int iz = 1 + b * TB + t;
-                cplx v = yv[t] - sof[iz - 1] * prev;
-                prev = v * pv[t];
-                y[iz * NYP] = prev;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                yv[t] = ny_[t]; pv[t] = np_[t];
-                asm volatile("" : "+v"(yv[t].re), "+v"(yv[t].im), "+v"(pv[t].re), "+v"(pv[t].im));
-            }
-        }
-    }
-    for (int iz = 1 + nfull * TB; iz <= n; ++iz) {
-        cplx v = y[iz * NYP] - sof[iz - 1] * prev;
-        prev = v * ip[iz * NYP];
-        y[iz * NYP] = prev;
-    }
-    // ---- backward: x_iz = y'_iz - (of_iz invp_iz) x_{iz+1}, iz = n-1 .. 1 ; prev = x_n
-    const int nb_ = n - 1, nfullb = nb_ / TB;           // rows n-1 .. 1
-    if (nfullb > 0) {
-#pragma unroll
-        for (int t = 0; t < TB; ++t) { yv[t] = y[(n - 1 - t) * NYP]; pv[t] = ip[(n - 1 - t) * NYP]; }
-        for (int b = 0; b < nfullb; ++b) {
-            const int nb = (b + 1 < nfullb) ? b + 1 : b;
-            cplx ny_[TB], np_[TB];
-#pragma unroll
-            for (int t = 0; t < TB; ++t) { ny_[t] = y[(n - 1 - nb * TB - t) * NYP]; np_[t] = ip[(n - 1 - nb * TB - t) * NYP]; }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                const int iz = n - 1 - b * TB - t;
-                cplx v = yv[t] - (sof[iz] * pv[t]) * prev;
-                y[iz * NYP] = v;
-                prev = v;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < TB; ++t) {
-                yv[t] = ny_[t]; pv[t] = np_[t];
-                asm volatile("" : "+v"(yv[t].re), "+v"(yv[t].im), "+v"(pv[t].re), "+v"(pv[t].im));
-            }
-        }
-    }
-    for (int iz = n - 1 - nfullb * TB; iz >= 1; --iz) {
-        cplx v = y[iz * NYP] - (sof[iz] * ip[iz * NYP]) * prev;
-        y[iz * NYP] = v;
-        prev = v;
-    }
+    thomas_twisted<cplx, double>(k.y + (long)s * k.vstride + j, k.invp + (long)s * k.vstride + j, sof, k.nz - 1, k.NYP);
+}
+
+__global__ __launch_bounds__(64) void k_thomas32(Solver k) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    __shared__ float sof[MAXNZP];
+    const int mode = s >= k.nFreq;
+    for (int i = threadIdx.x; i < k.NZP; i += 64) sof[i] = (float)k.ofz[(long)mode * k.NZP + i];
+    __syncthreads();
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= k.ny - 1) return;
+    thomas_twisted<c32, float>(reinterpret_cast<c32*>(k.y32) + (long)s * k.vstride + j,
+                               reinterpret_cast<const c32*>(k.invp32) + (long)s * k.vstride + j, sof, k.nz - 1, k.NYP);
 }
 
 // ---- symmetric Jacobi / FDM / Jacobi combination (default preconditioner):
@@ -509,6 +556,178 @@ __global__ __launch_bounds__(VBLOCK) void k_post(Solver k, double* partZZ) {
         k.partA[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
         partZZ[(long)s * MAXNB + blockIdx.x] = zz;
     }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Mixed-precision FDM stage.  COCG keeps x, r, p and every inner product in fp64; the preconditioner
+// only proposes search directions, and running its separable part with bf16 transform operands
+// (fp32 accumulation) and a complex64 tridiagonal solve leaves the iteration counts unchanged
+// (measured: identical to within +-1 iteration, same final error).  It moves the transforms from the
+// 78 TF FP64 matrix pipe to the 2.5 PF BF16 pipe and shrinks the stage's traffic 2-4x.
+//
+// v_mfma_f32_16x16x32_bf16 (gfx950; 16 cycles per instruction vs 32 for the older 16x16x16 form) layout:
+//   A[i = lane%16][k = 8*(lane/16) + t], B[k = 8*(lane/16) + t][j = lane%16], D[i = 4*(lane/16) + r][j = lane%16]
+// (D and the 16x16x16 operand layout measured with scripts/probe/mfma_bf16_layout.hip).
+// Tile row 2c+part = part (re/im) of complex row c, so a lane's four results are two complete complex
+// numbers.  K is consumed 32 at a time, k = 32*kg + 8*(lane/16) + i, i.e. 8 contiguous complex per lane;
+// V is pre-swizzled to
+//   Bsw[((kg*NT + t)*64 + lane)*8 + i] = bf16(V[32*kg + 8*(lane/16) + i][16*t + lane%16]), zero for k >= NYP.
+// ----------------------------------------------------------------------------------------------
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned bf16_rn(float x) {           // round-to-nearest-even, finite inputs
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ unsigned pack_bf16(double re, double im) {
+    return bf16_rn((float)re) | (bf16_rn((float)im) << 16);
+}
+
+constexpr int KCH = 7;             // k-groups (of 32) whose operands are requested together (all of K up to NYP = 224)
+constexpr int LP_NTW = 2;          // column tiles per wave of the mixed-precision transform: many light waves hide latency
+
+__device__ __forceinline__ float bf16_to_f32(unsigned h) { return __uint_as_float(h << 16); }
+
+// A: complex64 rows.  Every value is split in registers into hi = bf16(x), lo = bf16(x - hi) and the
+// product is accumulated as Ah*Bh + Ah*Bl + Al*Bh (fp32 accumulators): ~16 mantissa bits, i.e. fp32-class
+// accuracy from the bf16 pipe.  (Plain bf16 operands stalled one low-frequency TE system in 32.)
+// B: Bhi/Blo fragment arrays.  OUT: 0 = complex64, 1 = fp64 complex, 2 = fp64 complex + dinv*r (fused
+// first half of the post-smoother).
+template <int NTW, int OUT>
+__device__ __forceinline__ void transform_lp_body(const float2* __restrict__ Ain, const u4v* __restrict__ Bhi,
+                                                  const u4v* __restrict__ Blo, void* __restrict__ Cout,
+                                                  const cplx* __restrict__ dinv, const cplx* __restrict__ rvec,
+                                                  int M, int NYP, int m0, int t0, int lane) {
+    const int NT = NYP >> 4, KG = (NYP + 31) >> 5;
+    const int lj = lane & 15, g = lane >> 4;
+    const int part = lj & 1;
+    const int arow = min(m0 + (lj >> 1), M - 1);
+    f4v acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = f4v{0, 0, 0, 0};
+    for (int kc = 0; kc < KG; kc += KCH) {
+        f4v a[KCH][4];
+        u4v bh[KCH][NTW], bl[KCH][NTW];
+#pragma unroll
+        for (int q = 0; q < KCH; ++q) {
+            const int kg = min(kc + q, KG - 1);
+            const f4v* ap = reinterpret_cast<const f4v*>(Ain + (long)arow * NYP + 32 * kg + 8 * g);   // 8 complex = 64 B
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[q][i] = ap[i];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const long bi = ((long)kg * NT + t0 + t) * 64 + lane;
+                bh[q][t] = Bhi[bi]; bl[q][t] = Blo[bi];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < KCH; ++q) {
+            if (kc + q < KG) {
+                // this lane's part (re or im) of its 8 complex values, split into bf16 hi/lo
+                unsigned hh[8], ll[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float x0 = part ? a[q][i][1] : a[q][i][0], x1 = part ? a[q][i][3] : a[q][i][2];
+                    hh[2 * i] = bf16_rn(x0); ll[2 * i] = bf16_rn(x0 - bf16_to_f32(hh[2 * i]));
+                    hh[2 * i + 1] = bf16_rn(x1); ll[2 * i + 1] = bf16_rn(x1 - bf16_to_f32(hh[2 * i + 1]));
+                }
+                // v_mfma_f32_16x16x32_bf16: A[i = lane%16][k = 8*(lane/16) + t], t = 0..7 -- exactly this lane's 8 values
+                const u4v ahu = u4v{hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16)};
+                const u4v alu = u4v{ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16)};
+                const bf8v ah = __builtin_bit_cast(bf8v, ahu), al = __builtin_bit_cast(bf8v, alu);
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    const bf8v bhf = __builtin_bit_cast(bf8v, bh[q][t]), blf = __builtin_bit_cast(bf8v, bl[q][t]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blf, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // D rows 4g+r: (re, im) of complex rows 2g and 2g+1, column 16*(t0+t) + lj
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const long col = (long)(t0 + t) * 16 + lj;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int row = m0 + 2 * g + h2;
+            if (row < M) {
+                const long e = (long)row * NYP + col;
+                const float re = acc[t][2 * h2], im = acc[t][2 * h2 + 1];
+                if (OUT == 0) reinterpret_cast<float2*>(Cout)[e] = float2{re, im};
+                else if (OUT == 1) reinterpret_cast<cplx*>(Cout)[e] = cplx{(double)re, (double)im};
+                else reinterpret_cast<cplx*>(Cout)[e] = cplx{(double)re, (double)im} + dinv[e] * rvec[e];
+            }
+        }
+    }
+}
+
+template <int OUT>
+__global__ __launch_bounds__(512) void k_transform_lp(const float2* __restrict__ A, const u4v* __restrict__ Bhi,
+                                                       const u4v* __restrict__ Blo, void* __restrict__ C,
+                                                       const cplx* __restrict__ dinv, const cplx* __restrict__ rvec,
+                                                       int M, int NYP, int rowsPerSys, const int* __restrict__ active, int NW, int RG) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rg = wave / NW, nw = wave - rg * NW;
+    const int m0 = (blockIdx.x * RG + rg) * 8;
+    if (m0 >= M) return;
+    if (active) {
+        const int s0 = m0 / rowsPerSys, s1 = min(m0 + 7, M - 1) / rowsPerSys;
+        if (!active[s0] && !active[s1]) return;
+    }
+    const int NT = NYP >> 4;
+    const int base = NT / NW, extra = NT % NW;
+    const int ntl = base + (nw < extra ? 1 : 0);
+    const int t0 = nw * base + min(nw, extra);
+    if (ntl == 2) transform_lp_body<2, OUT>(A, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0, lane);
+    else if (ntl == 1) transform_lp_body<1, OUT>(A, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0, lane);
+}
+
+// complex64 copy of a vector (plain FDM: the transform input is r itself)
+__global__ __launch_bounds__(VBLOCK) void k_to_c64(Solver k, const cplx* src) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    const long so = (long)s * k.vstride;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) k.t32[so + e] = float2{(float)src[so + e].re, (float)src[so + e].im};
+}
+
+// t = r - A (dinv .* r), written as complex64 for the mixed-precision transform
+__global__ __launch_bounds__(VBLOCK) void k_pre_c64(Solver k) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx *r = k.r + so, *di = k.dinv + so;
+    float2* t = k.t32 + so;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        cplx out = cplx{0, 0};
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+            const cplx c = di[e] * r[e];
+            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+            acc += k.cY[mo + e] * (di[e + 1] * r[e + 1]);
+            acc += k.cY[mo + e - 1] * (di[e - 1] * r[e - 1]);
+            acc += k.cZ[mo + e] * (di[e + k.NYP] * r[e + k.NYP]);
+            acc += k.cZ[mo + e - k.NYP] * (di[e - k.NYP] * r[e - k.NYP]);
+            out = r[e] - acc;
+        }
+        t[e] = float2{(float)out.re, (float)out.im};
+    }
+}
+
+// complex64 copy of the inverse pivots
+__global__ void k_invp32(Solver k, float2* dst) {
+    const long n = (long)k.S * k.vstride;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+        dst[e] = float2{(float)k.invp[e].re, (float)k.invp[e].im};
 }
 
 // warm start: r <- r - A x over interior nodes, x including whatever sits on its boundary nodes
@@ -746,6 +965,9 @@ struct hmcmt_ctx {
     std::vector<void*> allocs;
     std::string err;
     // device scalars / buffers not in View
+    u4v *d_Vb = nullptr, *d_Vtb = nullptr;        // bf16 fragment-order copies of V, V' (hi parts)
+    u4v *d_Vbl = nullptr, *d_Vtbl = nullptr;      // ... lo parts: V = hi + lo to ~16 mantissa bits
+    float2* d_invp32 = nullptr;
     double *d_m = nullptr, *d_V = nullptr, *d_Vt = nullptr, *d_partZZ = nullptr, *d_misfit = nullptr;
     double *d_partRes = nullptr, *d_partBn = nullptr;
     cplx* d_b = nullptr;                  // copy of the right-hand side (verify)
@@ -761,6 +983,7 @@ struct hmcmt_ctx {
     int lastItFwd = 0, lastItAdj = 0;
     bool haveModel = false;
     bool haveFwd = false, haveAdj = false;   // previous fields usable as initial guesses
+    bool lpFallback = false;                 // this solve has switched its stragglers to the fp64 preconditioner
     // profiling
     unsigned profMask = 0;            // bit c: time category c with HIP events
     std::vector<hipEvent_t> evPool;
@@ -850,6 +1073,25 @@ int launch_transform(hmcmt_ctx* ctx, const cplx* A, const double* Bsw, cplx* C, 
     return 0;
 }
 
+template <int OUT>
+int launch_transform_lp(hmcmt_ctx* ctx, const float2* A, bool transposed, void* C, const int* active) {
+    const View& v = ctx->v;
+    const int M = v.S * v.NZP, NT = v.NYP / 16;
+    const int groups = (M + 7) / 8;
+    // waves of LP_NTW column tiles; a workgroup holds all NW waves of RG row groups (<= 8 waves)
+    int NW = (NT + LP_NTW - 1) / LP_NTW, RG = 1;
+    if (NW > 8) {                                       // very wide meshes: split the columns over several launches' worth
+        ctx->err = "mesh too wide for the mixed-precision transform (ny+1 > 256): use fdm_precision = fp64";
+        return HMCMT_EINVAL;
+    }
+    RG = std::max(1, 8 / NW);
+    ProfScope ps(ctx, 0);
+    hipLaunchKernelGGL((k_transform_lp<OUT>), dim3((groups + RG - 1) / RG), dim3(64 * NW * RG), 0, ctx->stream, A,
+                       transposed ? ctx->d_Vtb : ctx->d_Vb, transposed ? ctx->d_Vtbl : ctx->d_Vbl, C,
+                       ctx->sv.dinv, ctx->sv.r, M, v.NYP, v.NZP, active, NW, RG);
+    return 0;
+}
+
 // z = P^-1 r for the active systems and the partial sums of r'z, |z|^2 (partA / d_partZZ)
 int apply_precond(hmcmt_ctx* ctx) {
     Solver& k = ctx->sv;
@@ -860,15 +1102,29 @@ int apply_precond(hmcmt_ctx* ctx) {
         return 0;
     }
     const bool smooth = ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI;
-    if (smooth) { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_pre, vg, vb, 0, ctx->stream, k); }
-    int rc = launch_transform(ctx, smooth ? k.t : k.r, ctx->d_V, k.y, k.active);
-    if (rc) return rc;
-    {
-        ProfScope ps(ctx, 1);
-        hipLaunchKernelGGL(k_thomas, dim3((k.ny - 1 + 63) / 64, k.S), dim3(64), 0, ctx->stream, k);
+    const dim3 tg((k.ny - 1 + 63) / 64, k.S);
+    int rc;
+    if (ctx->opt.fdm_precision == 0 && !ctx->lpFallback) {
+        // mixed precision: split-bf16 operands / fp32 accumulation in the transforms, complex64 tridiagonal
+        if (smooth) { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_pre_c64, vg, vb, 0, ctx->stream, k); }
+        else { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_to_c64, vg, vb, 0, ctx->stream, k, k.r); }
+        if ((rc = launch_transform_lp<0>(ctx, k.t32, false, k.y32, k.active))) return rc;
+        { ProfScope ps(ctx, 1); hipLaunchKernelGGL(k_thomas32, tg, dim3(64), 0, ctx->stream, k); }
+        if (smooth) {
+            if ((rc = launch_transform_lp<2>(ctx, k.y32, true, k.z, k.active))) return rc;   // z = F t + dinv r
+            { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+            std::swap(k.z, k.t);
+        } else {
+            if ((rc = launch_transform_lp<1>(ctx, k.y32, true, k.z, k.active))) return rc;
+            ProfScope ps(ctx, 3);
+            hipLaunchKernelGGL(k_dots, vg, vb, 0, ctx->stream, k, ctx->d_partZZ);
+        }
+        return 0;
     }
-    rc = launch_transform(ctx, k.y, ctx->d_Vt, k.z, k.active);
-    if (rc) return rc;
+    if (smooth) { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_pre, vg, vb, 0, ctx->stream, k); }
+    if ((rc = launch_transform(ctx, smooth ? k.t : k.r, ctx->d_V, k.y, k.active))) return rc;
+    { ProfScope ps(ctx, 1); hipLaunchKernelGGL(k_thomas, tg, dim3(64), 0, ctx->stream, k); }
+    if ((rc = launch_transform(ctx, k.y, ctx->d_Vt, k.z, k.active))) return rc;
     if (smooth) {
         { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_mid, vg, vb, 0, ctx->stream, k); }
         { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
@@ -907,8 +1163,16 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     const int every = ctx->opt.check_every > 0 ? ctx->opt.check_every : 2;
     int it = 0;
     bool done = false;
+    ctx->lpFallback = false;
+    const int lpCap = 60;               // mixed-precision safety net: stragglers continue with the fp64 preconditioner
     while (!done && it < ctx->opt.maxit) {
         ++it;
+        if (it == lpCap + 1 && ctx->opt.fdm_precision == 0 && ctx->opt.precond != HMCMT_PRECOND_JACOBI && !ctx->lpFallback) {
+            ctx->lpFallback = true;     // restart COCG for the still-active systems: z = P64^-1 r, p = z
+            { int prc = apply_precond(ctx); if (prc) return prc; }
+            { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_check, dim3(1), dim3(128), 0, ctx->stream, k, ctx->d_partZZ, 2, ctx->opt.maxit); }
+            { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_pupdate, vg, vb, 0, ctx->stream, k, 1); }
+        }
         { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv, vg, vb, 0, ctx->stream, k); }
         { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update, vg, vb, 0, ctx->stream, k); }
         { int prc = apply_precond(ctx); if (prc) return prc; }
@@ -977,8 +1241,10 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         }
         hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, st, v, 0, 1, 1, 0);
         hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, st, v);
-        if (ctx->opt.precond != HMCMT_PRECOND_JACOBI)
+        if (ctx->opt.precond != HMCMT_PRECOND_JACOBI) {
             hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 0, st, v);
+            if (ctx->opt.fdm_precision == 0) hipLaunchKernelGGL(k_invp32, dim3(512), dim3(256), 0, st, ctx->sv, ctx->d_invp32);
+        }
         if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI)
             hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, 0.7);
         const bool warmF = ctx->opt.warm_start && ctx->haveFwd && !ctx->opt.verify;   // verify checks against the cold rhs
@@ -1046,6 +1312,7 @@ void hmcmt_default_options(hmcmt_options* o) {
     o->check_every = 2;
     o->verify = 0;
     o->warm_start = 1;
+    o->fdm_precision = 0;
 }
 
 const char* hmcmt_last_error(const hmcmt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_createError.c_str(); }
@@ -1108,6 +1375,36 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         };
         if ((rc = dupload(ctx, &ctx->d_V, swz(h.Vpad)))) return rc;
         if ((rc = dupload(ctx, &ctx->d_Vt, swz(h.Vtpad)))) return rc;
+        // bf16 fragment order of k_transform_lp (k consumed 32 at a time, zero beyond NYP)
+        const int KG32 = (h.NYP + 31) / 32;
+        auto bf = [](double x) -> unsigned short {
+            float f = (float)x; unsigned u; std::memcpy(&u, &f, 4);
+            return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        };
+        auto bf2f = [](unsigned short hval) -> float { unsigned u = (unsigned)hval << 16; float f; std::memcpy(&f, &u, 4); return f; };
+        auto swzb = [&](const std::vector<double>& B, bool lo) {
+            std::vector<unsigned short> o((size_t)KG32 * NT * 64 * 8, 0);
+            for (int kg = 0; kg < KG32; ++kg)
+                for (int t = 0; t < NT; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int i = 0; i < 8; ++i) {
+                            const int k = 32 * kg + 8 * (lane / 16) + i;
+                            if (k >= h.NYP) continue;
+                            const double x = B[(size_t)k * h.NYP + 16 * t + lane % 16];
+                            const unsigned short hi = bf(x);
+                            o[(((size_t)kg * NT + t) * 64 + lane) * 8 + i] = lo ? bf(x - (double)bf2f(hi)) : hi;
+                        }
+            return o;
+        };
+        unsigned short* tmp = nullptr;
+        if ((rc = dupload(ctx, &tmp, swzb(h.Vpad, false)))) return rc;
+        ctx->d_Vb = reinterpret_cast<u4v*>(tmp);
+        if ((rc = dupload(ctx, &tmp, swzb(h.Vpad, true)))) return rc;
+        ctx->d_Vbl = reinterpret_cast<u4v*>(tmp);
+        if ((rc = dupload(ctx, &tmp, swzb(h.Vtpad, false)))) return rc;
+        ctx->d_Vtb = reinterpret_cast<u4v*>(tmp);
+        if ((rc = dupload(ctx, &tmp, swzb(h.Vtpad, true)))) return rc;
+        ctx->d_Vtbl = reinterpret_cast<u4v*>(tmp);
     }
 #define DA(ptr, n) if ((rc = dalloc(ctx, &(ptr), (n)))) return rc;
     DA(v.sigma, h.nCell) DA(v.sigMeanA, h.nz) DA(v.sigMeanG, h.nz)
@@ -1130,6 +1427,8 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     k.omega = v.omega; k.cY = v.cY; k.cZ = v.cZ; k.dK = v.dK; k.dM = v.dM; k.ofz = v.ofz; k.invp = v.invp;
     k.r = v.R;
     DA(k.p, S * VS) DA(k.q, S * VS) DA(k.z, S * VS) DA(k.y, S * VS) DA(k.t, S * VS) DA(k.dinv, S * VS)
+    DA(k.t32, S * VS + 64) DA(k.y32, S * VS + 64) DA(ctx->d_invp32, S * VS)
+    k.invp32 = ctx->d_invp32;
     DA(k.partA, S * MAXNB) DA(k.partB, S * MAXNB) DA(ctx->d_partZZ, S * MAXNB)
     DA(ctx->d_partRes, S * MAXNB) DA(ctx->d_partBn, S * MAXNB)
     DA(k.rho, S) DA(k.alphaBeta, S) DA(k.active, S) DA(k.iters, S) DA(k.status, S) DA(k.nactive, 1) DA(k.errEst, S)
@@ -1185,6 +1484,7 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
 int hmcmt_set_options(hmcmt_ctx* ctx, const hmcmt_options* o) {
     if (!ctx || !o) return HMCMT_EINVAL;
     if (o->precond < HMCMT_PRECOND_JACOBI || o->precond > HMCMT_PRECOND_FDM_JACOBI) { ctx->err = "unknown preconditioner"; return HMCMT_EINVAL; }
+    if (o->fdm_precision != 0 && o->fdm_precision != 1) { ctx->err = "fdm_precision must be 0 (bf16/fp32) or 1 (fp64)"; return HMCMT_EINVAL; }
     if (!(o->tol > 0) || o->maxit < 1) { ctx->err = "tol must be > 0 and maxit >= 1"; return HMCMT_EINVAL; }
     ctx->opt = *o;
     ctx->lastItFwd = ctx->lastItAdj = 0;
@@ -1317,20 +1617,30 @@ int hmcmt_profile_read(hmcmt_ctx* ctx, double* ms, int64_t* launches) {
     return 0;
 }
 
+static int set_all_active(hmcmt_ctx* ctx) {
+    std::vector<int> one(ctx->v.S, 1);
+    HIPCHK(hipMemcpy(ctx->sv.active, one.data(), sizeof(int) * one.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
 int hmcmt_debug_transform(hmcmt_ctx* ctx, int32_t which, const double* A, double* C) {
     if (!ctx || !A || !C) return HMCMT_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t bytes = (size_t)ctx->v.S * ctx->v.vstride * sizeof(cplx);
     HIPCHK(hipMemcpy(ctx->sv.p, A, bytes, hipMemcpyHostToDevice));
+    if (which >= 2) {
+        // mixed-precision kernel: q = fp32(A) * V (which == 2) or V' (which == 3), split-bf16 operands, fp32 accumulation
+        int rc = set_all_active(ctx);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_to_c64, dim3(ctx->sv.NB, ctx->v.S), dim3(VBLOCK), 0, ctx->stream, ctx->sv, ctx->sv.p);
+        if ((rc = launch_transform_lp<1>(ctx, ctx->sv.t32, which == 3, ctx->sv.q, nullptr))) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpy(C, ctx->sv.q, bytes, hipMemcpyDeviceToHost));
+        return 0;
+    }
     launch_transform(ctx, ctx->sv.p, which ? ctx->d_Vt : ctx->d_V, ctx->sv.q, nullptr);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(C, ctx->sv.q, bytes, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-static int set_all_active(hmcmt_ctx* ctx) {
-    std::vector<int> one(ctx->v.S, 1);
-    HIPCHK(hipMemcpy(ctx->sv.active, one.data(), sizeof(int) * one.size(), hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -168,20 +168,45 @@ HD void item_fdm_z(const View& v, int mode, int iz) {
     v.ofz[o] = (iz <= v.nz - 2) ? -(qb / zb) : 0.0;
 }
 
-// --- inverse pivots of the (s, j) tridiagonal:  d_iz = lam_j*mzq + dgz + i w mzs
+// --- inverse pivots of the (s, j) tridiagonal  d_iz = lam_j*mzq + dgz + i w mzs  in TWISTED form:
+//     rows 1..mid are eliminated top-down, rows n..mid+1 bottom-up (two independent recurrences the
+//     solve kernels run interleaved, halving their dependent chain); the factor that couples the two
+//     halves at rows mid, mid+1 is stored in the unused boundary row iz = 0.
+// Measured on MI355X the tridiagonal kernels are instruction-issue-bound (one wave per CU, ~25
+//     instructions per row), so interleaving two chains does not pay (20 us vs 16 us): HMCMT_TWIST = 0
+//     selects mid = n, which is the classic Thomas factorisation.
+#ifndef HMCMT_TWIST
+#define HMCMT_TWIST 0
+#endif
+HD int twist_mid(int n) { return HMCMT_TWIST ? (n + 1) / 2 : n; }   // rows 1..mid | mid+1..n   (n = nz-1 >= 2)
 HD void item_pivot(const View& v, int s, int j) {
     const int mode = s >= v.nFreq;
     const double w = v.omega[s], lam = v.lam[j];
     const double *mzq = v.mzq + (long)mode * v.NZP, *dgz = v.dgz + (long)mode * v.NZP,
                  *ofz = v.ofz + (long)mode * v.NZP, *mzs = v.mzs + (long)mode * v.NZP;
     cplx* ip = v.invp + (long)s * v.vstride + j;
-    cplx prev = cplx{0, 0};
-    for (int iz = 1; iz <= v.nz - 1; ++iz) {
+    const int n = v.nz - 1, mid = twist_mid(n);
+    cplx prev = cplx{0, 0}, dtop = cplx{0, 0}, dbot = cplx{0, 0};
+    for (int iz = 1; iz <= mid; ++iz) {                    // d'_iz = d_iz - of_{iz-1}^2 / d'_{iz-1}
         cplx d = cplx{lam * mzq[iz] + dgz[iz], w * mzs[iz]};
         if (iz > 1) d -= (ofz[iz - 1] * ofz[iz - 1]) * prev;
         prev = crecip(d);
         ip[(long)iz * v.NYP] = prev;
+        dtop = d;
     }
+    prev = cplx{0, 0};
+    for (int iz = n; iz >= mid + 1; --iz) {                // d''_iz = d_iz - of_iz^2 / d''_{iz+1}
+        cplx d = cplx{lam * mzq[iz] + dgz[iz], w * mzs[iz]};
+        if (iz < n) d -= (ofz[iz] * ofz[iz]) * prev;
+        prev = crecip(d);
+        ip[(long)iz * v.NYP] = prev;
+        dbot = d;
+    }
+    // middle coupling of the two normalised halves: x_mid + c x_{mid+1} = y'_mid, x_{mid+1} + c' x_mid = y''_{mid+1}
+    // with c = o*ip_mid, c' = o*ip_{mid+1}; store 1/(1 - c c') in the unused boundary row iz = 0
+    const double o = ofz[mid];
+    (void)dtop; (void)dbot;
+    ip[0] = (mid + 1 <= n) ? crecip(cplx{1.0, 0.0} - (o * o) * (ip[(long)mid * v.NYP] * ip[(long)(mid + 1) * v.NYP])) : cplx{1.0, 0.0};
 }
 
 // --- per-layer terms of the 1-D column under boundary node column `col` (0 = left edge, ny = right

@@ -33,7 +33,8 @@ class HmcmtError(RuntimeError):
 
 class Options(C.Structure):
     _fields_ = [("precond", C.c_int32), ("maxit", C.c_int32), ("tol", C.c_double),
-                ("check_every", C.c_int32), ("verify", C.c_int32), ("warm_start", C.c_int32)]
+                ("check_every", C.c_int32), ("verify", C.c_int32), ("warm_start", C.c_int32),
+                ("fdm_precision", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -116,7 +117,7 @@ class HipContext:
     """One GPU context: the drop-in for the reference's per-call solver state."""
 
     def __init__(self, mtMesh, mtData, invParam, device_id=0, precond="fdmj", tol=None, maxit=None,
-                 verify=False, check_every=None, warm_start=True):
+                 verify=False, check_every=None, warm_start=True, fdm_precision="mixed"):
         self.lib = load_library()
         self.args = CreateArgs(mtMesh, mtData, invParam)
         opts = Options()
@@ -132,6 +133,7 @@ class HipContext:
             opts.check_every = check_every
         opts.verify = int(verify)
         opts.warm_start = int(warm_start)
+        opts.fdm_precision = {"mixed": 0, "fp64": 1}[fdm_precision]
         self.opts = opts
         h = C.c_void_p()
         rc = self.lib.hmcmt_create(C.byref(h), device_id, *self.args.as_tuple(), C.byref(opts))
@@ -152,6 +154,8 @@ class HipContext:
         for k, v in kw.items():
             if k == "precond":
                 v = PRECOND[v]
+            if k == "fdm_precision":
+                v = {"mixed": 0, "fp64": 1}[v]
             setattr(self.opts, k, v)
         self._check(self.lib.hmcmt_set_options(self.h, C.byref(self.opts)))
 

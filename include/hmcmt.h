@@ -59,6 +59,8 @@ typedef struct hmcmt_options {
     int32_t check_every;  /* host convergence poll interval in iterations; default 2 */
     int32_t verify;       /* 1: also compute true relative residuals ||b-Ax||/||b|| after each solve */
     int32_t warm_start;   /* 1 (default): start both solves from the previous evaluation's fields */
+    int32_t fdm_precision;/* 0 (default): bf16 transforms (fp32 accumulate) + complex64 tridiagonal inside the
+                             preconditioner; 1: fp64 throughout.  x, r, p and all inner products are fp64 either way */
 } hmcmt_options;
 
 typedef struct hmcmt_stats {
@@ -138,7 +140,8 @@ int hmcmt_profile_read(hmcmt_ctx* ctx, double* ms /*[HMCMT_NCAT]*/, int64_t* lau
 int hmcmt_dims(const hmcmt_ctx* ctx, int32_t* out);
 
 /* Test hooks (exercise single kernels through the ABI).
- * hmcmt_debug_transform: C = A*V (which=0) or A*V' (which=1) with the context's FDM matrices;
+ * hmcmt_debug_transform: C = A*V (which=0) or A*V' (which=1) with the context's FDM matrices (fp64 kernel);
+ *   which=2/3: the mixed-precision kernels (bf16 operands, fp32 accumulation), same products;
  *   A, C: host complex[S*NZP*NYP] in the padded nodal layout.
  * hmcmt_debug_spmv: q = A_s p for all systems at the model of the last evaluation. */
 int hmcmt_debug_transform(hmcmt_ctx* ctx, int32_t which, const double* A, double* C);

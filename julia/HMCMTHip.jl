@@ -29,6 +29,7 @@ struct HmcmtOptions
     check_every::Int32
     verify::Int32
     warm_start::Int32
+    fdm_precision::Int32
 end
 
 mutable struct HipContext

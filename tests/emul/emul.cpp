@@ -106,13 +106,20 @@ struct Emul {
         const double* ofz_ = v.ofz + (long)mode * v.NZP;
         const cplx* ip = v.invp + (long)s * v.vstride;
         for (int j = 0; j < v.ny - 1; ++j) {
-            for (int iz = 1; iz <= nz - 1; ++iz) {
-                cplx y = Y[nidx(v, j, iz)];
-                if (iz > 1) y -= ofz_[iz - 1] * Y[nidx(v, j, iz - 1)];
-                Y[nidx(v, j, iz)] = y * ip[nidx(v, j, iz)];
+            // twisted solve (see item_pivot): top-down to mid, bottom-up to mid+1, 2x2 in the middle, outwards
+            const int n = nz - 1, mid = twist_mid(n);
+            auto Yr = [&](int iz) -> cplx& { return Y[nidx(v, j, iz)]; };
+            cplx pt = cplx{0, 0}, pb = cplx{0, 0};
+            for (int iz = 1; iz <= mid; ++iz) { pt = (Yr(iz) - ofz_[iz - 1] * pt) * ip[nidx(v, j, iz)]; Yr(iz) = pt; }
+            for (int iz = n; iz >= mid + 1; --iz) { pb = (Yr(iz) - ofz_[iz] * pb) * ip[nidx(v, j, iz)]; Yr(iz) = pb; }
+            if (mid + 1 <= n) {
+                const cplx c = ofz_[mid] * ip[nidx(v, j, mid)], c2 = ofz_[mid] * ip[nidx(v, j, mid + 1)];
+                pt = (pt - c * pb) * ip[nidx(v, j, 0)];
+                pb = pb - c2 * pt;
+                Yr(mid) = pt; Yr(mid + 1) = pb;
             }
-            for (int iz = nz - 2; iz >= 1; --iz)
-                Y[nidx(v, j, iz)] -= (ofz_[iz] * ip[nidx(v, j, iz)]) * Y[nidx(v, j, iz + 1)];
+            for (int iz = mid - 1; iz >= 1; --iz) { pt = Yr(iz) - (ofz_[iz] * ip[nidx(v, j, iz)]) * pt; Yr(iz) = pt; }
+            for (int iz = mid + 2; iz <= n; ++iz) { pb = Yr(iz) - (ofz_[iz - 1] * ip[nidx(v, j, iz)]) * pb; Yr(iz) = pb; }
         }
         for (int iz = 1; iz <= nz - 1; ++iz)
             for (int iy = 1; iy <= v.ny - 1; ++iy) {

@@ -77,10 +77,19 @@ def test_jacobi_and_fdm_preconditioners_agree(tiny_ctx):
     assert relmax(p2, p1) < 1e-9 and relmax(g2, g1) < 1e-7 and it_plain >= it_fdm
 
 
-def test_kernels_against_host_instantiation(tiny_ctx):
-    """transform / SpMV / preconditioner kernels vs the same arithmetic on the host."""
+def _bf16(a):
+    """round-to-nearest-even to bfloat16, returned as float32"""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7fff + ((u >> 16) & 1)) >> 16 << 16
+    return u.astype(np.uint32).view(np.float32)
+
+
+def test_kernels_against_host_instantiation():
+    """transform / SpMV / preconditioner kernels vs the same arithmetic on the host (fp64 FDM path),
+    and the mixed-precision transforms vs a bf16-rounded numpy product."""
     from tests.emul.emul_py import Emul
-    mesh, data, inv, m, ctx = tiny_ctx
+    mesh, data, inv, m = make_problem("tiny")
+    ctx = HipContext(mesh, data, inv, fdm_precision="fp64")
     ctx.grad(m)
     E = Emul(mesh, data, inv); E.grad(m, False)
     shape = (ctx.S, ctx.NZP, ctx.NYP)
@@ -94,14 +103,35 @@ def test_kernels_against_host_instantiation(tiny_ctx):
     assert relmax(ctx.debug_precond(P), E.apply("fdmj", P)) < 1e-11
     ctx.set_options(precond="fdm"); ctx.grad(m)
     assert relmax(ctx.debug_precond(P), E.apply("fdm", P)) < 1e-11
-    ctx.set_options(precond="fdmj")
+    # mixed precision: split-bf16 operands (hi + lo), fp32 accumulation -> fp32-class accuracy
+    A32 = A.astype(np.complex64).astype(np.complex128)
+    assert relmax(ctx.debug_transform(2, A).reshape(shape), A32 @ V) < 5e-5
+    assert relmax(ctx.debug_transform(3, A).reshape(shape), A32 @ V.T) < 5e-5
+    ctx.set_options(precond="fdmj", fdm_precision="mixed"); ctx.grad(m)
+    z_mixed = ctx.debug_precond(P)
+    assert relmax(z_mixed, E.apply("fdmj", P)) < 1e-3       # a preconditioner: fp32-class agreement is plenty
+    ctx.close()
+
+
+def test_mixed_and_fp64_preconditioner_give_the_same_answer():
+    mesh, data, inv, m = make_problem("cfg2")
+    ctx = HipContext(mesh, data, inv, warm_start=False)
+    p0, f0, g0 = ctx.grad(m); it0 = ctx.iters()
+    ctx.set_options(fdm_precision="fp64")
+    p1, f1, g1 = ctx.grad(m); it1 = ctx.iters()
+    assert relmax(p0, p1) < 1e-9 and abs(f0 - f1) / f1 < 1e-9 and relmax(g0, g1) < 1e-8
+    # reduced precision costs nothing where it matters: the slowest (TM) systems are unchanged and the total
+    # work grows by a few iterations on the nearly-exact low-frequency TE systems only
+    assert it0.max() <= it1.max() + 1 and it0.sum() <= 1.15 * it1.sum()
+    ctx.close()
 
 
 def test_operator_symmetry_properties():
     """Size-independent properties at the headline size (cfg3): A and P^-1 are complex symmetric
-    (x'Ay = y'Ax unconjugated) and linear -- what COCG relies on."""
+    (x'Ay = y'Ax unconjugated) and linear -- what COCG relies on.  Exact (fp64) preconditioner to 1e-9;
+    the mixed-precision one to its fp32-class accuracy."""
     mesh, data, inv, m = make_problem("cfg3")
-    ctx = HipContext(mesh, data, inv)
+    ctx = HipContext(mesh, data, inv, fdm_precision="fp64")
     ctx.forward(m)
     shape = (ctx.S, ctx.NZP, ctx.NYP)
     rng = np.random.default_rng(1)
@@ -112,12 +142,18 @@ def test_operator_symmetry_properties():
         return v
 
     x, y = rand(), rand()
-    for op in (ctx.debug_spmv, ctx.debug_precond):
+
+    def check(op, tol_sym, tol_lin):
         Ax, Ay = op(x).reshape(shape), op(y).reshape(shape)
         a = np.sum(y * Ax, axis=(1, 2)); b = np.sum(x * Ay, axis=(1, 2))
-        assert np.max(np.abs(a - b) / np.abs(a)) < 1e-9
+        assert np.max(np.abs(a - b) / np.abs(a)) < tol_sym
         lin = op(2.0 * x + (0.5 - 1j) * y).reshape(shape)
-        assert relmax(lin, 2.0 * Ax + (0.5 - 1j) * Ay) < 1e-10
+        assert relmax(lin, 2.0 * Ax + (0.5 - 1j) * Ay) < tol_lin
+
+    check(ctx.debug_spmv, 1e-9, 1e-10)
+    check(ctx.debug_precond, 1e-9, 1e-10)
+    ctx.set_options(fdm_precision="mixed"); ctx.forward(m)
+    check(ctx.debug_precond, 2e-3, 1e-4)
     ctx.close()
 
 
