@@ -44,6 +44,9 @@ struct Solver {
     float2* t32;                          // [S][vstride] complex64 transform input
     float2* y32;                          // [S][vstride] complex64
     const float2* invp32;                 // [S][vstride]
+    cplx *p2, *r2;                        // second buffers of p and r for the fused (halo-recomputing) kernels
+    cplx *partPQ;                         // [S][MAXNB]  p'q of the fused path
+    cplx *rho2;                           // [2][S] rho by iteration parity (fused path)
     cplx *partA;                          // [S][MAXNB]  p'q   | r'z
     double *partB;                        // [S][MAXNB]  |x|^2 | |z|^2
     cplx *rho, *alphaBeta;                // [S]
@@ -730,6 +733,122 @@ __global__ void k_invp32(Solver k, float2* dst) {
         dst[e] = float2{(float)k.invp[e].re, (float)k.invp[e].im};
 }
 
+// ----------------------------------------------------------------------------------------------
+// Fused COCG iteration of the default path (Jacobi/FDM/Jacobi preconditioner, mixed precision):
+//   k_spmv_fused   : scalar bookkeeping (convergence test on the error estimate, beta), p = z + beta p
+//                    recomputed on each node's 5-point halo, q = A p, partial p'q
+//   k_update_fused : alpha, x += alpha p, r' = r - alpha q recomputed on the halo, Jacobi pre-smoothing
+//                    t = r' - A (dinv .* r') written as complex64 for the transform, partial |x|^2
+// Every block of a system reduces that system's partial sums itself (same order -> same value), so no
+// separate scalar kernel and no grid synchronisation is needed; p and r are double-buffered because
+// blocks read their neighbours' old values while writing new ones.  Block 0 of each system owns the
+// per-system records (rho by parity, iteration count, error estimate, active flag, active counter).
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* partZZ, const cplx* pin_, cplx* pout, int it, int maxit) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    __shared__ double sh[8];
+    cplx rz = cplx{0, 0};
+    double zz = 0, xx = 0;
+    for (int b = 0; b < k.NB; ++b) {
+        rz += k.partA[(long)s * MAXNB + b];
+        zz += partZZ[(long)s * MAXNB + b];
+        xx += k.partB[(long)s * MAXNB + b];
+    }
+    const bool first = it == 1;
+    bool on = true;
+    int st = 0;
+    if (first) { if (zz == 0.0) on = false; }
+    else if (zz <= k.tol2 * xx) on = false;
+    else if (it - 1 >= maxit) { on = false; st = HMCMT_ENOCONV; }
+    if (!(isfinite(rz.re) && isfinite(rz.im) && isfinite(zz) && isfinite(xx))) { on = false; st = HMCMT_EBREAKDOWN; }
+    const cplx be = first ? cplx{0, 0} : rz / k.rho2[(long)((it - 1) & 1) * k.S + s];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        k.rho2[(long)(it & 1) * k.S + s] = rz;
+        k.iters[s] = it - 1;
+        k.errEst[s] = first ? (zz == 0.0 ? 0.0 : 1.0) : sqrt(zz / xx);
+        if (st) k.status[s] = st;
+    }
+    if (!on) {
+        // every block of this system takes the same decision; block 0 records it after all of them have
+        // read the old flag (they read it at entry; a late block that already sees 0 returns just the same)
+        if (blockIdx.x == 0 && threadIdx.x == 0) { k.active[s] = 0; atomicSub(k.nactive, 1); }
+        return;
+    }
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx *z = k.z + so, *pi = pin_ + so;
+    cplx *po = pout + so, *q = k.q + so;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    double ar = 0, ai = 0;
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        cplx pc = cplx{0, 0};
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+            // z and p vanish on boundary / pad nodes, so the halo needs no masking
+            auto pn = [&](long x) -> cplx { return first ? z[x] : z[x] + be * pi[x]; };
+            pc = pn(e);
+            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+            cplx acc = cplx{dk * pc.re - dm * pc.im, dk * pc.im + dm * pc.re};
+            acc += k.cY[mo + e] * pn(e + 1);
+            acc += k.cY[mo + e - 1] * pn(e - 1);
+            acc += k.cZ[mo + e] * pn(e + k.NYP);
+            acc += k.cZ[mo + e - k.NYP] * pn(e - k.NYP);
+            q[e] = acc;
+            ar += pc.re * acc.re - pc.im * acc.im;
+            ai += pc.re * acc.im + pc.im * acc.re;
+        }
+        po[e] = pc;
+    }
+    block_sum2(ar, ai, sh);
+    if (threadIdx.x == 0) k.partPQ[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
+}
+
+__global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const cplx* pcur, const cplx* rin, cplx* rout, int it) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    __shared__ double sh[8];
+    cplx pq = cplx{0, 0};
+    for (int b = 0; b < k.NB; ++b) pq += k.partPQ[(long)s * MAXNB + b];
+    const cplx al = k.rho2[(long)(it & 1) * k.S + s] / pq;
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx *p = pcur + so, *q = k.q + so, *ri = rin + so, *di = k.dinv + so;
+    cplx *x = k.x + so, *ro = rout + so;
+    float2* t = k.t32 + so;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    double xx = 0, dummy = 0;
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        cplx rn = cplx{0, 0}, out = cplx{0, 0};
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+            // r, q and dinv vanish outside the interior, so the halo needs no masking
+            auto rnew = [&](long y) -> cplx { return ri[y] - al * q[y]; };
+            rn = rnew(e);
+            const cplx c = di[e] * rn;
+            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+            acc += k.cY[mo + e] * (di[e + 1] * rnew(e + 1));
+            acc += k.cY[mo + e - 1] * (di[e - 1] * rnew(e - 1));
+            acc += k.cZ[mo + e] * (di[e + k.NYP] * rnew(e + k.NYP));
+            acc += k.cZ[mo + e - k.NYP] * (di[e - k.NYP] * rnew(e - k.NYP));
+            out = rn - acc;
+            const cplx xv = x[e] + al * p[e];
+            x[e] = xv;
+            xx += cabs2(xv);
+        }
+        ro[e] = rn;
+        t[e] = float2{(float)out.re, (float)out.im};
+    }
+    block_sum2(xx, dummy, sh);
+    if (threadIdx.x == 0) {
+        k.partB[(long)s * MAXNB + blockIdx.x] = xx;
+        if (blockIdx.x == 0) k.alphaBeta[s] = al;
+    }
+}
+
 // warm start: r <- r - A x over interior nodes, x including whatever sits on its boundary nodes
 // (forward: Dirichlet values, so with r = 0 on entry this is the reference's rhs -Aio*bc minus Aii*x0)
 __global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r) {
@@ -980,12 +1099,17 @@ struct hmcmt_ctx {
     double* h_stage = nullptr;            // m / grad / pred / misfit staging
     size_t stageDoubles = 0;
     std::vector<int> itersLast;           // [2*S]
+    int *d_itersAll = nullptr, *d_statusAll = nullptr;   // [2][S] per solve kind
+    double* d_errAll = nullptr;
+    bool solveDone[2] = {true, true};
     int lastItFwd = 0, lastItAdj = 0;
     bool haveModel = false;
     bool haveFwd = false, haveAdj = false;   // previous fields usable as initial guesses
     bool lpFallback = false;                 // this solve has switched its stragglers to the fp64 preconditioner
     // profiling
     unsigned profMask = 0;            // bit c: time category c with HIP events
+    int profEvery = 1;                // ... in every profEvery-th evaluation only (the brackets cost ~20 % if always on)
+    long long evalCount = 0;
     std::vector<hipEvent_t> evPool;
     std::vector<int> evCat;
     size_t evUsed = 0;
@@ -1034,7 +1158,7 @@ int dupload(hmcmt_ctx* ctx, T** p, const std::vector<T>& h) {
 struct ProfScope {
     hmcmt_ctx* c; int cat; size_t idx;
     ProfScope(hmcmt_ctx* ctx, int cat_) : c(ctx), cat(cat_), idx((size_t)-1) {
-        if (!((c->profMask >> cat) & 1u)) return;
+        if (!((c->profMask >> cat) & 1u) || (c->evalCount % c->profEvery) != 0) return;
         if (c->evUsed + 2 > c->evPool.size()) {
             for (int i = 0; i < 512; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c->evPool.push_back(e); c->evCat.push_back(0); }
         }
@@ -1146,18 +1270,10 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     dim3 vg(k.NB, S), vb(VBLOCK);
     const size_t vecBytes = (size_t)S * k.vstride * sizeof(cplx);
     if (ctx->opt.verify) HIPCHK(hipMemcpyAsync(ctx->d_b, k.r, vecBytes, hipMemcpyDeviceToDevice, ctx->stream));
-    // all systems of the requested modes start active
-    {
-        std::memcpy(ctx->h_iters, ctx->hp.sysOn.data(), sizeof(int) * S);   // reuse pinned buffer as staging
-        HIPCHK(hipMemcpyAsync(k.active, ctx->h_iters, sizeof(int) * S, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
+    // all systems of the requested modes start active (device copy: no host round trip)
+    HIPCHK(hipMemcpyAsync(k.active, ctx->v.sysOn, sizeof(int) * S, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(k.iters, 0, sizeof(int) * S, ctx->stream));
     HIPCHK(hipMemsetAsync(k.status, 0, sizeof(int) * S, ctx->stream));
-    // z = P^-1 r ; rho = r'z ; p = z
-    { int prc = apply_precond(ctx); if (prc) return prc; }
-    { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_check, dim3(1), dim3(128), 0, ctx->stream, k, ctx->d_partZZ, 1, ctx->opt.maxit); }
-    { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_pupdate, vg, vb, 0, ctx->stream, k, 1); }
     int& guess = kind == 0 ? ctx->lastItFwd : ctx->lastItAdj;
     int nextCheck = guess > 2 ? guess : 4;
     const int every = ctx->opt.check_every > 0 ? ctx->opt.check_every : 2;
@@ -1165,41 +1281,85 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     bool done = false;
     ctx->lpFallback = false;
     const int lpCap = 60;               // mixed-precision safety net: stragglers continue with the fp64 preconditioner
-    while (!done && it < ctx->opt.maxit) {
-        ++it;
-        if (it == lpCap + 1 && ctx->opt.fdm_precision == 0 && ctx->opt.precond != HMCMT_PRECOND_JACOBI && !ctx->lpFallback) {
-            ctx->lpFallback = true;     // restart COCG for the still-active systems: z = P64^-1 r, p = z
-            { int prc = apply_precond(ctx); if (prc) return prc; }
-            { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_check, dim3(1), dim3(128), 0, ctx->stream, k, ctx->d_partZZ, 2, ctx->opt.maxit); }
-            { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_pupdate, vg, vb, 0, ctx->stream, k, 1); }
+    const dim3 tg((k.ny - 1 + 63) / 64, S);
+    const bool fused = ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0;
+    cplx* const r_entry = k.r;
+    if (fused) {
+        int nOn = 0;
+        for (int s = 0; s < S; ++s) nOn += ctx->hp.sysOn[s];
+        *ctx->h_nactive = nOn;
+        HIPCHK(hipMemcpyAsync(k.nactive, ctx->h_nactive, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemsetAsync(k.partB, 0, sizeof(double) * S * MAXNB, ctx->stream));
+        { int prc = apply_precond(ctx); if (prc) return prc; }          // z = P^-1 r and the partial sums of r'z, |z|^2
+        cplx* pb[2] = {k.p, k.p2};
+        cplx* rb[2] = {k.r, k.r2};
+        int rcur = 0;
+        while (!done && it < ctx->opt.maxit + 1 && it < lpCap) {
+            ++it;
+            // decide convergence of the state after iteration it-1, p = z + beta p, q = A p
+            { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv_fused, vg, vb, 0, ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit); }
+            if (it - 1 >= nextCheck || it - 1 == ctx->opt.maxit) {
+                HIPCHK(hipMemcpyAsync(ctx->h_nactive, k.nactive, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                if (*ctx->h_nactive == 0) { done = true; break; }
+                nextCheck = it - 1 + every;
+            }
+            { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused, vg, vb, 0, ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it); }
+            rcur ^= 1;
+            k.r = rb[rcur];
+            int prc;
+            if ((prc = launch_transform_lp<0>(ctx, k.t32, false, k.y32, k.active))) return prc;
+            { ProfScope ps(ctx, 1); hipLaunchKernelGGL(k_thomas32, tg, dim3(64), 0, ctx->stream, k); }
+            if ((prc = launch_transform_lp<2>(ctx, k.y32, true, k.z, k.active))) return prc;   // z = F t + dinv r
+            { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+            std::swap(k.z, k.t);
         }
-        { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv, vg, vb, 0, ctx->stream, k); }
-        { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update, vg, vb, 0, ctx->stream, k); }
-        { int prc = apply_precond(ctx); if (prc) return prc; }
-        { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_check, dim3(1), dim3(128), 0, ctx->stream, k, ctx->d_partZZ, 0, ctx->opt.maxit); }
-        { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_pupdate, vg, vb, 0, ctx->stream, k, 0); }
-        if (it >= nextCheck || it == ctx->opt.maxit) {
+        if (!done) {
+            // stragglers (or the iteration cap): read the counter once more, then hand over to the classic loop
             HIPCHK(hipMemcpyAsync(ctx->h_nactive, k.nactive, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
             if (*ctx->h_nactive == 0) done = true;
-            nextCheck = it + every;
+        }
+        k.p = pb[it & 1];                // current search direction (only needed by the classic restart below)
+        k.p2 = pb[(it - 1) & 1];
+        if (done) it = std::max(0, it - 1);
+    }
+    if (!done) {
+        const bool restart = fused;      // coming from the fused loop: restart COCG with the fp64 preconditioner
+        if (restart) ctx->lpFallback = true;
+        // z = P^-1 r ; rho = r'z ; p = z
+        { int prc = apply_precond(ctx); if (prc) return prc; }
+        { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_check, dim3(1), dim3(128), 0, ctx->stream, k, ctx->d_partZZ, restart ? 2 : 1, ctx->opt.maxit); }
+        { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_pupdate, vg, vb, 0, ctx->stream, k, 1); }
+        while (!done && it < ctx->opt.maxit) {
+            ++it;
+            if (it == lpCap + 1 && ctx->opt.fdm_precision == 0 && ctx->opt.precond != HMCMT_PRECOND_JACOBI && !ctx->lpFallback) {
+                ctx->lpFallback = true;     // restart COCG for the still-active systems: z = P64^-1 r, p = z
+                { int prc = apply_precond(ctx); if (prc) return prc; }
+                { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_check, dim3(1), dim3(128), 0, ctx->stream, k, ctx->d_partZZ, 2, ctx->opt.maxit); }
+                { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_pupdate, vg, vb, 0, ctx->stream, k, 1); }
+            }
+            { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv, vg, vb, 0, ctx->stream, k); }
+            { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update, vg, vb, 0, ctx->stream, k); }
+            { int prc = apply_precond(ctx); if (prc) return prc; }
+            { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_check, dim3(1), dim3(128), 0, ctx->stream, k, ctx->d_partZZ, 0, ctx->opt.maxit); }
+            { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_pupdate, vg, vb, 0, ctx->stream, k, 0); }
+            if (it >= nextCheck || it == ctx->opt.maxit) {
+                HIPCHK(hipMemcpyAsync(ctx->h_nactive, k.nactive, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                if (*ctx->h_nactive == 0) done = true;
+                nextCheck = it + every;
+            }
         }
     }
+    // the fused loop ping-pongs r between the caller's buffer and r2: leave the struct as it was found
+    if (k.r != r_entry) { k.r2 = k.r; k.r = r_entry; }
     guess = it;
-    HIPCHK(hipMemcpyAsync(ctx->h_iters, k.iters, sizeof(int) * S, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->h_status, k.status, sizeof(int) * S, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->h_err, k.errEst, sizeof(double) * S, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    int mx = 0, sum = 0;
-    for (int s = 0; s < S; ++s) {
-        ctx->itersLast[kind * S + s] = ctx->h_iters[s];
-        mx = std::max(mx, ctx->h_iters[s]); sum += ctx->h_iters[s];
-        if (ctx->h_status[s] != 0 && ctx->stats.status == 0) ctx->stats.status = ctx->h_status[s];
-        if (ctx->h_err[s] > ctx->stats.err_est_max) ctx->stats.err_est_max = ctx->h_err[s];
-    }
-    if (kind == 0) { ctx->stats.iters_fwd_max = mx; ctx->stats.iters_fwd_sum = sum; }
-    else { ctx->stats.iters_adj_max = mx; ctx->stats.iters_adj_sum = sum; }
-    if (!done && ctx->stats.status == 0) ctx->stats.status = HMCMT_ENOCONV;
+    ctx->solveDone[kind] = done;
+    // iteration counts / status / error estimates stay on the device; evaluate() reads both solves back at once
+    HIPCHK(hipMemcpyAsync(ctx->d_itersAll + (size_t)kind * S, k.iters, sizeof(int) * S, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_statusAll + (size_t)kind * S, k.status, sizeof(int) * S, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_errAll + (size_t)kind * S, k.errEst, sizeof(double) * S, hipMemcpyDeviceToDevice, ctx->stream));
     if (ctx->opt.verify) {
         hipLaunchKernelGGL(k_trueres, vg, vb, 0, ctx->stream, k, ctx->d_b, x, ctx->d_partRes, ctx->d_partBn);
         std::vector<double> pr((size_t)S * MAXNB), pb((size_t)S * MAXNB);
@@ -1226,6 +1386,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     const int S = v.S;
     ctx->stats = hmcmt_stats{};
     ctx->stats.nsystems = S;
+    ++ctx->evalCount;
     const int nodes = v.NZP * (v.ny + 1);
     const size_t vecBytes = (size_t)S * v.vstride * sizeof(cplx);
     {
@@ -1255,7 +1416,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, 1);
     }
     int rc = solve(ctx, v.X, 0);
-    ctx->haveFwd = (rc == 0 && ctx->stats.status == 0);
+    ctx->haveFwd = (rc == 0 && ctx->solveDone[0]);
     if (rc) return rc;
     {
         ProfScope ps(ctx, 5);
@@ -1276,7 +1437,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
                 HIPCHK(hipMemsetAsync(v.Lam, 0, vecBytes, st));
         }
         rc = solve(ctx, v.Lam, 1);
-        ctx->haveAdj = (rc == 0 && ctx->stats.status == 0);
+        ctx->haveAdj = (rc == 0 && ctx->solveDone[1]);
         if (rc) return rc;
         ProfScope ps(ctx, 6);
         hipLaunchKernelGGL(k_wb, dim3((v.nz + v.ny + 127) / 128, S), dim3(128), 0, st, v);
@@ -1288,6 +1449,30 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     }
     HIPCHK(hipGetLastError());
     ctx->haveModel = true;
+    return 0;
+}
+
+// after the final stream sync of an evaluation: read both solves' records back and fill the statistics
+int collect_stats(hmcmt_ctx* ctx, bool withAdjoint) {
+    const int S = ctx->v.S, nk = withAdjoint ? 2 : 1;
+    HIPCHK(hipMemcpyAsync(ctx->h_iters, ctx->d_itersAll, sizeof(int) * nk * S, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_status, ctx->d_statusAll, sizeof(int) * nk * S, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_err, ctx->d_errAll, sizeof(double) * nk * S, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int kind = 0; kind < nk; ++kind) {
+        int mx = 0, sum = 0;
+        for (int s = 0; s < S; ++s) {
+            const int itv = ctx->h_iters[kind * S + s];
+            ctx->itersLast[kind * S + s] = itv;
+            mx = std::max(mx, itv); sum += itv;
+            if (ctx->h_status[kind * S + s] != 0 && ctx->stats.status == 0) ctx->stats.status = ctx->h_status[kind * S + s];
+            if (ctx->h_err[kind * S + s] > ctx->stats.err_est_max) ctx->stats.err_est_max = ctx->h_err[kind * S + s];
+        }
+        if (kind == 0) { ctx->stats.iters_fwd_max = mx; ctx->stats.iters_fwd_sum = sum; }
+        else { ctx->stats.iters_adj_max = mx; ctx->stats.iters_adj_sum = sum; }
+        if (!ctx->solveDone[kind] && ctx->stats.status == 0) ctx->stats.status = HMCMT_ENOCONV;
+    }
+    if (!withAdjoint) for (int s = 0; s < S; ++s) ctx->itersLast[S + s] = 0;
     return 0;
 }
 
@@ -1428,17 +1613,18 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     k.r = v.R;
     DA(k.p, S * VS) DA(k.q, S * VS) DA(k.z, S * VS) DA(k.y, S * VS) DA(k.t, S * VS) DA(k.dinv, S * VS)
     DA(k.t32, S * VS + 64) DA(k.y32, S * VS + 64) DA(ctx->d_invp32, S * VS)
+    DA(k.p2, S * VS) DA(k.r2, S * VS) DA(k.partPQ, S * MAXNB) DA(k.rho2, 2 * S)
     k.invp32 = ctx->d_invp32;
     DA(k.partA, S * MAXNB) DA(k.partB, S * MAXNB) DA(ctx->d_partZZ, S * MAXNB)
     DA(ctx->d_partRes, S * MAXNB) DA(ctx->d_partBn, S * MAXNB)
     DA(k.rho, S) DA(k.alphaBeta, S) DA(k.active, S) DA(k.iters, S) DA(k.status, S) DA(k.nactive, 1) DA(k.errEst, S)
-    DA(ctx->d_b, S * VS)
+    DA(ctx->d_b, S * VS) DA(ctx->d_itersAll, 2 * S) DA(ctx->d_statusAll, 2 * S) DA(ctx->d_errAll, 2 * S)
     DA(ctx->d_fieldsOut, (size_t)h.nFreq * (h.ny + 1) * (h.nz + 1))
 #undef DA
     HIPCHK(hipHostMalloc((void**)&ctx->h_nactive, sizeof(int)));
-    HIPCHK(hipHostMalloc((void**)&ctx->h_iters, sizeof(int) * h.S));
-    HIPCHK(hipHostMalloc((void**)&ctx->h_status, sizeof(int) * h.S));
-    HIPCHK(hipHostMalloc((void**)&ctx->h_err, sizeof(double) * h.S));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_iters, sizeof(int) * 2 * h.S));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_status, sizeof(int) * 2 * h.S));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_err, sizeof(double) * 2 * h.S));
     ctx->stageDoubles = (size_t)h.nAC * 4 + (size_t)h.nData * 2 + 16;
     HIPCHK(hipHostMalloc((void**)&ctx->h_stage, sizeof(double) * ctx->stageDoubles));
     ctx->itersLast.assign(2 * h.S, 0);
@@ -1515,7 +1701,7 @@ int hmcmt_grad_device(hmcmt_ctx* ctx, const double* d_m, double* d_pred, double*
     HIPCHK(hipSetDevice(ctx->device));
     int rc = evaluate(ctx, d_m, true, d_pred, d_misfit, d_grad);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if ((rc = collect_stats(ctx, true))) return rc;      // includes the stream synchronisation
     prof_collect(ctx);
     return finish_status(ctx);
 }
@@ -1525,7 +1711,7 @@ int hmcmt_forward_device(hmcmt_ctx* ctx, const double* d_m, double* d_pred, doub
     HIPCHK(hipSetDevice(ctx->device));
     int rc = evaluate(ctx, d_m, false, d_pred, d_misfit, nullptr);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if ((rc = collect_stats(ctx, false))) return rc;
     prof_collect(ctx);
     return finish_status(ctx);
 }
@@ -1544,7 +1730,7 @@ static int host_eval(hmcmt_ctx* ctx, const double* m, double* pred, double* misf
     HIPCHK(hipMemcpyAsync(hs, ctx->v.pred, sizeof(cplx) * nData, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(hs + 2 * nData, ctx->d_misfit, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (wantGrad) HIPCHK(hipMemcpyAsync(hs + 2 * nData + 1, ctx->v.grad, sizeof(double) * nAC, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if ((rc = collect_stats(ctx, wantGrad))) return rc;   // includes the stream synchronisation
     prof_collect(ctx);
     if (pred) std::memcpy(pred, hs, sizeof(cplx) * nData);
     if (misfit) *misfit = hs[2 * nData];
@@ -1607,6 +1793,12 @@ int hmcmt_profile(hmcmt_ctx* ctx, int32_t enable) {
     }
     ctx->profMask = (unsigned)enable;
     for (int i = 0; i < HMCMT_NCAT; ++i) { ctx->profMs[i] = 0; ctx->profN[i] = 0; }
+    return 0;
+}
+
+int hmcmt_profile_every(hmcmt_ctx* ctx, int32_t n) {
+    if (!ctx || n < 1) return HMCMT_EINVAL;
+    ctx->profEvery = n;
     return 0;
 }
 
@@ -1725,6 +1917,7 @@ int hmcmt_leapfrog(hmcmt_ctx* ctx, const double* m0, const double* p0, double dt
     int evals = 0;
     int rc = evaluate(ctx, ctx->d_mcur, true, nullptr, nullptr, ctx->d_g);
     if (rc) return rc;
+    if ((rc = collect_stats(ctx, true))) return rc;
     if ((rc = finish_status(ctx))) return rc;
     ++evals;
     hipLaunchKernelGGL(k_lf_momentum, g1, b1, 0, st, lf, regParam, 0.5 * dt);
@@ -1733,6 +1926,7 @@ int hmcmt_leapfrog(hmcmt_ctx* ctx, const double* m0, const double* p0, double dt
         hipLaunchKernelGGL(k_lf_step, g1, b1, 0, st, lf, dt, lnSigMin, lnSigMax);
         rc = evaluate(ctx, ctx->d_mcur, true, nullptr, nullptr, ctx->d_g);
         if (rc) return rc;
+        if ((rc = collect_stats(ctx, true))) return rc;
         if ((rc = finish_status(ctx))) return rc;
         ++evals;
         hipLaunchKernelGGL(k_lf_momentum, g1, b1, 0, st, lf, regParam, (k < L ? 1.0 : 0.5) * dt);

@@ -88,6 +88,7 @@ def load_library():
                                    C.POINTER(C.c_int32)]
     lib.hmcmt_get_fields.argtypes = [vp, C.c_int32, c_double_p, c_double_p]
     lib.hmcmt_profile.argtypes = [vp, C.c_int32]
+    lib.hmcmt_profile_every.argtypes = [vp, C.c_int32]
     lib.hmcmt_profile_read.argtypes = [vp, c_double_p, c_int64_p]
     lib.hmcmt_dims.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.hmcmt_debug_transform.argtypes = [vp, C.c_int32, c_double_p, c_double_p]
@@ -95,8 +96,8 @@ def load_library():
     lib.hmcmt_debug_precond.argtypes = [vp, c_double_p, c_double_p]
     for name in ("hmcmt_create", "hmcmt_destroy", "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters",
                  "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_set_prior",
-                 "hmcmt_leapfrog", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_read", "hmcmt_dims",
-                 "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond"):
+                 "hmcmt_leapfrog", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read",
+                 "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -105,7 +106,7 @@ def load_library():
 EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "hmcmt_last_error",
                     "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters", "hmcmt_grad", "hmcmt_forward",
                     "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_set_prior", "hmcmt_leapfrog",
-                    "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_read", "hmcmt_dims",
+                    "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_dims",
                     "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond"]
 
 
@@ -229,8 +230,10 @@ class HipContext:
         return m1, p1, pred, mis.value, mnorm.value, nf.value
 
     # -- instrumentation ----------------------------------------------------------------------
-    def profile(self, enable=True):
-        """enable: True (all categories), False, or an iterable of category names to time."""
+    def profile(self, enable=True, every=1):
+        """enable: True (all categories), False, or an iterable of category names to time;
+        every: bracket the kernels of every n-th evaluation only."""
+        self._check(self.lib.hmcmt_profile_every(self.h, int(every)))
         if enable is True:
             mask = (1 << HMCMT_NCAT) - 1
         elif not enable:
