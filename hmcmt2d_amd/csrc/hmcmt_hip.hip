@@ -44,7 +44,8 @@ struct Solver {
     float2* t32;                          // [S][vstride] complex64 transform input
     float2* y32;                          // [S][vstride] complex64
     const float2* invp32;                 // [S][vstride]
-    cplx *p2, *r2;                        // second buffers of p and r for the fused (halo-recomputing) kernels
+    cplx *p2, *r2;                        // second buffers of p and r for the fused kernels
+    int RT, NTR;                          // rows per tile / row tiles per system of the fused kernels (NTR <= MAXNB)
     cplx *partPQ;                         // [S][MAXNB]  p'q of the fused path
     cplx *rho2;                           // [2][S] rho by iteration parity (fused path)
     cplx *partA;                          // [S][MAXNB]  p'q   | r'z
@@ -744,17 +745,18 @@ __global__ void k_invp32(Solver k, float2* dst) {
 // blocks read their neighbours' old values while writing new ones.  Block 0 of each system owns the
 // per-system records (rho by parity, iteration count, error estimate, active flag, active counter).
 // ----------------------------------------------------------------------------------------------
+// Both kernels work on tiles of RT interior rows of one system: the tile plus one halo row above and below
+// is staged in LDS (dynamic, (RT+2)*NYP complex [+ RT*NYP]), so every global value is read once.
 __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* partZZ, const cplx* pin_, cplx* pout, int it, int maxit) {
     const int s = blockIdx.y;
     if (!k.active[s]) return;
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    cplx* pn = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]
     __shared__ double sh[8];
     cplx rz = cplx{0, 0};
     double zz = 0, xx = 0;
-    for (int b = 0; b < k.NB; ++b) {
-        rz += k.partA[(long)s * MAXNB + b];
-        zz += partZZ[(long)s * MAXNB + b];
-        xx += k.partB[(long)s * MAXNB + b];
-    }
+    for (int b = 0; b < k.NB; ++b) { rz += k.partA[(long)s * MAXNB + b]; zz += partZZ[(long)s * MAXNB + b]; }
+    for (int b = 0; b < k.NTR; ++b) xx += k.partB[(long)s * MAXNB + b];
     const bool first = it == 1;
     bool on = true;
     int st = 0;
@@ -770,8 +772,8 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
         if (st) k.status[s] = st;
     }
     if (!on) {
-        // every block of this system takes the same decision; block 0 records it after all of them have
-        // read the old flag (they read it at entry; a late block that already sees 0 returns just the same)
+        // every block of this system takes the same decision; block 0 records it (a block that starts late and
+        // already sees the cleared flag returns just the same)
         if (blockIdx.x == 0 && threadIdx.x == 0) { k.active[s] = 0; atomicSub(k.nactive, 1); }
         return;
     }
@@ -780,26 +782,35 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
     const double w = k.omega[s];
     const cplx *z = k.z + so, *pi = pin_ + so;
     cplx *po = pout + so, *q = k.q + so;
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);   // own rows iz0..iz1
+    // stage rows iz0-1 .. iz1+1 of the new direction (z, p vanish on boundary / pad nodes: no masking needed)
+    const int nrows = iz1 - iz0 + 3;
+    for (int i = threadIdx.x; i < nrows * NYP; i += VBLOCK) {
+        const int lr = i / NYP, iy = i - lr * NYP;
+        const long e = (long)(iz0 - 1 + lr) * NYP + iy;
+        const cplx v = first ? z[e] : z[e] + be * pi[e];
+        pn[i] = v;
+        if (lr >= 1 && lr <= nrows - 2) po[e] = v;
+    }
+    __syncthreads();
     double ar = 0, ai = 0;
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
-        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
-        cplx pc = cplx{0, 0};
-        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
-            // z and p vanish on boundary / pad nodes, so the halo needs no masking
-            auto pn = [&](long x) -> cplx { return first ? z[x] : z[x] + be * pi[x]; };
-            pc = pn(e);
+    const int nown = (iz1 - iz0 + 1) * NYP;
+    for (int i = threadIdx.x; i < nown; i += VBLOCK) {
+        const int lr = i / NYP, iy = i - lr * NYP;
+        if (iy >= 1 && iy <= k.ny - 1) {
+            const long e = (long)(iz0 + lr) * NYP + iy;
+            const int l = (lr + 1) * NYP + iy;
+            const cplx pc = pn[l];
             const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
             cplx acc = cplx{dk * pc.re - dm * pc.im, dk * pc.im + dm * pc.re};
-            acc += k.cY[mo + e] * pn(e + 1);
-            acc += k.cY[mo + e - 1] * pn(e - 1);
-            acc += k.cZ[mo + e] * pn(e + k.NYP);
-            acc += k.cZ[mo + e - k.NYP] * pn(e - k.NYP);
+            acc += k.cY[mo + e] * pn[l + 1];
+            acc += k.cY[mo + e - 1] * pn[l - 1];
+            acc += k.cZ[mo + e] * pn[l + NYP];
+            acc += k.cZ[mo + e - NYP] * pn[l - NYP];
             q[e] = acc;
             ar += pc.re * acc.re - pc.im * acc.im;
             ai += pc.re * acc.im + pc.im * acc.re;
         }
-        po[e] = pc;
     }
     block_sum2(ar, ai, sh);
     if (threadIdx.x == 0) k.partPQ[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
@@ -808,9 +819,14 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
 __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const cplx* pcur, const cplx* rin, cplx* rout, int it) {
     const int s = blockIdx.y;
     if (!k.active[s]) return;
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);
+    const int nrows = iz1 - iz0 + 3;
+    cplx* cs = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]  dinv .* r'
+    cplx* rs = cs + (long)(k.RT + 2) * NYP;               // [RT][NYP]      r' of the own rows
     __shared__ double sh[8];
     cplx pq = cplx{0, 0};
-    for (int b = 0; b < k.NB; ++b) pq += k.partPQ[(long)s * MAXNB + b];
+    for (int b = 0; b < k.NTR; ++b) pq += k.partPQ[(long)s * MAXNB + b];
     const cplx al = k.rho2[(long)(it & 1) * k.S + s] / pq;
     const int mode = s >= k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
@@ -818,28 +834,38 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const cplx* p
     const cplx *p = pcur + so, *q = k.q + so, *ri = rin + so, *di = k.dinv + so;
     cplx *x = k.x + so, *ro = rout + so;
     float2* t = k.t32 + so;
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
     double xx = 0, dummy = 0;
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
-        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
-        cplx rn = cplx{0, 0}, out = cplx{0, 0};
-        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
-            // r, q and dinv vanish outside the interior, so the halo needs no masking
-            auto rnew = [&](long y) -> cplx { return ri[y] - al * q[y]; };
-            rn = rnew(e);
-            const cplx c = di[e] * rn;
-            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
-            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
-            acc += k.cY[mo + e] * (di[e + 1] * rnew(e + 1));
-            acc += k.cY[mo + e - 1] * (di[e - 1] * rnew(e - 1));
-            acc += k.cZ[mo + e] * (di[e + k.NYP] * rnew(e + k.NYP));
-            acc += k.cZ[mo + e - k.NYP] * (di[e - k.NYP] * rnew(e - k.NYP));
-            out = rn - acc;
-            const cplx xv = x[e] + al * p[e];
+    // r' = r - alpha q and dinv .* r' on rows iz0-1 .. iz1+1 (r, q, dinv vanish outside the interior: no masking)
+    for (int i = threadIdx.x; i < nrows * NYP; i += VBLOCK) {
+        const int lr = i / NYP, iy = i - lr * NYP;
+        const long e = (long)(iz0 - 1 + lr) * NYP + iy;
+        const cplx rn = ri[e] - al * q[e];
+        cs[i] = di[e] * rn;
+        if (lr >= 1 && lr <= nrows - 2) {
+            rs[i - NYP] = rn;
+            ro[e] = rn;
+            const cplx xv = x[e] + al * p[e];             // p vanishes outside the interior
             x[e] = xv;
             xx += cabs2(xv);
         }
-        ro[e] = rn;
+    }
+    __syncthreads();
+    const int nown = (iz1 - iz0 + 1) * NYP;
+    for (int i = threadIdx.x; i < nown; i += VBLOCK) {
+        const int lr = i / NYP, iy = i - lr * NYP;
+        const long e = (long)(iz0 + lr) * NYP + iy;
+        cplx out = cplx{0, 0};
+        if (iy >= 1 && iy <= k.ny - 1) {
+            const int l = (lr + 1) * NYP + iy;
+            const cplx c = cs[l];
+            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+            acc += k.cY[mo + e] * cs[l + 1];
+            acc += k.cY[mo + e - 1] * cs[l - 1];
+            acc += k.cZ[mo + e] * cs[l + NYP];
+            acc += k.cZ[mo + e - NYP] * cs[l - NYP];
+            out = rs[i] - acc;
+        }
         t[e] = float2{(float)out.re, (float)out.im};
     }
     block_sum2(xx, dummy, sh);
@@ -1297,14 +1323,14 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
         while (!done && it < ctx->opt.maxit + 1 && it < lpCap) {
             ++it;
             // decide convergence of the state after iteration it-1, p = z + beta p, q = A p
-            { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv_fused, vg, vb, 0, ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit); }
+            { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv_fused, dim3(k.NTR, S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit); }
             if (it - 1 >= nextCheck || it - 1 == ctx->opt.maxit) {
                 HIPCHK(hipMemcpyAsync(ctx->h_nactive, k.nactive, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(hipStreamSynchronize(ctx->stream));
                 if (*ctx->h_nactive == 0) { done = true; break; }
                 nextCheck = it - 1 + every;
             }
-            { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused, vg, vb, 0, ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it); }
+            { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused, dim3(k.NTR, S), vb, (size_t)(2 * k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it); }
             rcur ^= 1;
             k.r = rb[rcur];
             int prc;
@@ -1609,6 +1635,8 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     k.S = h.S; k.NYP = h.NYP; k.NZP = h.NZP; k.ny = h.ny; k.nz = h.nz; k.nFreq = h.nFreq; k.vstride = v.vstride;
     k.NB = std::max(1, std::min(MAXNB, (1024 + h.S - 1) / h.S));
     k.chunk = (v.vstride + k.NB - 1) / k.NB;
+    k.RT = std::max(4, (h.nz - 1 + MAXNB - 1) / MAXNB);
+    k.NTR = (h.nz - 1 + k.RT - 1) / k.RT;
     k.omega = v.omega; k.cY = v.cY; k.cZ = v.cZ; k.dK = v.dK; k.dM = v.dM; k.ofz = v.ofz; k.invp = v.invp;
     k.r = v.R;
     DA(k.p, S * VS) DA(k.q, S * VS) DA(k.z, S * VS) DA(k.y, S * VS) DA(k.t, S * VS) DA(k.dinv, S * VS)
