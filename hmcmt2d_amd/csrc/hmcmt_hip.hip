@@ -894,6 +894,50 @@ __global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r
     }
 }
 
+// ---- initial guess extrapolated along the model path (options.warm_start == 2) ----
+// The fields are smooth functions of the model, and a leapfrog trajectory moves the model along an
+// almost straight line, so x(m_new) ~ x_k + alpha (x_k - x_{k-1}) with alpha the projection of
+// m_new - m_k on m_k - m_{k-1}.  State per solve kind, all on the device (no host round trip):
+// hist[0..nAC) = m_k, hist[nAC..2nAC) = m_{k-1}, ext = {alpha, keep, count}.  A repeated model
+// (getHamiltonian after the last leapfrog step) keeps the history untouched.
+__global__ __launch_bounds__(1024) void k_extrap_alpha(const double* __restrict__ mNew, double* hist, int nAC, double* ext) {
+    __shared__ double sh[4][16];
+    double a = 0, b = 0, c = 0, n = 0;
+    for (int i = threadIdx.x; i < nAC; i += 1024) {
+        const double mk = hist[i], d1 = mk - hist[nAC + i], d0 = mNew[i] - mk;
+        a += d0 * d1; b += d1 * d1; c += d0 * d0; n += mk * mk;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o); b += __shfl_down(b, o); c += __shfl_down(c, o); n += __shfl_down(n, o);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = a; sh[1][w] = b; sh[2][w] = c; sh[3][w] = n; }
+    __syncthreads();
+    a = b = c = n = 0;
+    for (int j = 0; j < 16; ++j) { a += sh[0][j]; b += sh[1][j]; c += sh[2][j]; n += sh[3][j]; }
+    const int count = (int)ext[2];
+    const bool keep = count >= 1 && c <= 1e-28 * n;
+    double alpha = 0;
+    if (!keep && count >= 2 && b > 0) alpha = fmin(2.0, fmax(-1.0, a / b));
+    __syncthreads();
+    if (!keep)
+        for (int i = threadIdx.x; i < nAC; i += 1024) { hist[nAC + i] = hist[i]; hist[i] = mNew[i]; }
+    if (threadIdx.x == 0) { ext[0] = alpha; ext[1] = keep ? 1.0 : 0.0; if (!keep) ext[2] = (double)min(count + 1, 2); }
+}
+
+// x <- x + alpha (x - xprev), xprev <- old x
+__global__ __launch_bounds__(VBLOCK) void k_extrap(Solver k, cplx* x, cplx* xprev, const double* __restrict__ ext) {
+    if (ext[1] != 0.0) return;
+    const double alpha = ext[0];
+    const long so = (long)blockIdx.y * k.vstride;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const cplx t = x[so + e], q = xprev[so + e];
+        xprev[so + e] = t;
+        x[so + e] = t + alpha * (t - q);
+    }
+}
+
 // true residual norm check: partB = |b - A x|^2 with b passed separately (verify option)
 __global__ __launch_bounds__(VBLOCK) void k_trueres(Solver k, const cplx* b, const cplx* x, double* partRes, double* partBn) {
     const int s = blockIdx.y;
@@ -1131,6 +1175,9 @@ struct hmcmt_ctx {
     int lastItFwd = 0, lastItAdj = 0;
     bool haveModel = false;
     bool haveFwd = false, haveAdj = false;   // previous fields usable as initial guesses
+    cplx* d_prevField[2] = {nullptr, nullptr};   // previous solutions (warm_start == 2), per solve kind
+    double* d_mHist[2] = {nullptr, nullptr};     // [2][nAC] model history per solve kind
+    double* d_ext[2] = {nullptr, nullptr};       // {alpha, keep, count}
     bool lpFallback = false;                 // this solve has switched its stragglers to the fp64 preconditioner
     // profiling
     unsigned profMask = 0;            // bit c: time category c with HIP events
@@ -1435,7 +1482,14 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI)
             hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, 0.7);
         const bool warmF = ctx->opt.warm_start && ctx->haveFwd && !ctx->opt.verify;   // verify checks against the cold rhs
-        if (!warmF) HIPCHK(hipMemsetAsync(v.X, 0, vecBytes, st));
+        if (!warmF) {
+            HIPCHK(hipMemsetAsync(v.X, 0, vecBytes, st));
+            HIPCHK(hipMemsetAsync(ctx->d_ext[0], 0, 4 * sizeof(double), st));
+        }
+        if (ctx->opt.warm_start == 2 && !ctx->opt.verify) {
+            hipLaunchKernelGGL(k_extrap_alpha, dim3(1), dim3(1024), 0, st, d_m, ctx->d_mHist[0], v.nAC, ctx->d_ext[0]);
+            hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
+        }
         hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, S), dim3(64), 0, st, v);
         hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, S), dim3(64), 0, st, v);
         // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X
@@ -1457,10 +1511,16 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             HIPCHK(hipMemsetAsync(v.R, 0, vecBytes, st));
             HIPCHK(hipMemsetAsync(v.srcB, 0, sizeof(cplx) * 4 * S, st));
             hipLaunchKernelGGL(k_src, dim3((2 * (v.ny + 1) + 127) / 128, S), dim3(128), 0, st, v);
-            if (ctx->opt.warm_start && ctx->haveAdj && !ctx->opt.verify)
-                hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, 0);
-            else
+            const bool warmA = ctx->opt.warm_start && ctx->haveAdj && !ctx->opt.verify;
+            if (!warmA) {
                 HIPCHK(hipMemsetAsync(v.Lam, 0, vecBytes, st));
+                HIPCHK(hipMemsetAsync(ctx->d_ext[1], 0, 4 * sizeof(double), st));
+            }
+            if (ctx->opt.warm_start == 2 && !ctx->opt.verify) {
+                hipLaunchKernelGGL(k_extrap_alpha, dim3(1), dim3(1024), 0, st, d_m, ctx->d_mHist[1], v.nAC, ctx->d_ext[1]);
+                hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, ctx->d_prevField[1], ctx->d_ext[1]);
+            }
+            if (warmA) hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, 0);
         }
         rc = solve(ctx, v.Lam, 1);
         ctx->haveAdj = (rc == 0 && ctx->solveDone[1]);
@@ -1522,7 +1582,7 @@ void hmcmt_default_options(hmcmt_options* o) {
     o->tol = 1e-11;
     o->check_every = 2;
     o->verify = 0;
-    o->warm_start = 1;
+    o->warm_start = 2;
     o->fdm_precision = 0;
 }
 
@@ -1631,6 +1691,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     DA(v.sensDz1, S * 3 * (size_t)h.nz) DA(v.sensZ1, S * 3) DA(v.sensDead, S * 3)
     DA(v.qPart, S * h.ny) DA(v.gPart, 2 * (size_t)h.nCell) DA(v.grad, h.nAC)
     DA(ctx->d_m, h.nAC) DA(ctx->d_misfit, 1)
+    for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], S * VS) DA(ctx->d_mHist[kd], 2 * (size_t)h.nAC) DA(ctx->d_ext[kd], 4) }
     Solver& k = ctx->sv;
     k.S = h.S; k.NYP = h.NYP; k.NZP = h.NZP; k.ny = h.ny; k.nz = h.nz; k.nFreq = h.nFreq; k.vstride = v.vstride;
     k.NB = std::max(1, std::min(MAXNB, (1024 + h.S - 1) / h.S));
@@ -1700,6 +1761,7 @@ int hmcmt_set_options(hmcmt_ctx* ctx, const hmcmt_options* o) {
     if (o->precond < HMCMT_PRECOND_JACOBI || o->precond > HMCMT_PRECOND_FDM_JACOBI) { ctx->err = "unknown preconditioner"; return HMCMT_EINVAL; }
     if (o->fdm_precision != 0 && o->fdm_precision != 1) { ctx->err = "fdm_precision must be 0 (bf16/fp32) or 1 (fp64)"; return HMCMT_EINVAL; }
     if (!(o->tol > 0) || o->maxit < 1) { ctx->err = "tol must be > 0 and maxit >= 1"; return HMCMT_EINVAL; }
+    if (o->warm_start < 0 || o->warm_start > 2) { ctx->err = "warm_start must be 0, 1 or 2"; return HMCMT_EINVAL; }
     ctx->opt = *o;
     ctx->lastItFwd = ctx->lastItAdj = 0;
     ctx->haveFwd = ctx->haveAdj = false;

@@ -22,6 +22,11 @@ HEADERS = [os.path.join(CSRC, h) for h in ("hmcmt_math.h", "hmcmt_items.h", "hmc
 HMCMT_NCAT = 7
 CATEGORIES = ["fdm_transform", "tridiagonal", "spmv", "vector_ops", "assembly_bc", "receivers", "gradient"]
 PRECOND = {"jacobi": 0, "fdm": 1, "fdmj": 2}
+# initial guess of both solves: cold start, the previous evaluation's fields, or those extrapolated along the model path
+def _warm_start_code(v):
+    if isinstance(v, bool):
+        return 2 if v else 0
+    return {"cold": 0, "previous": 1, "extrapolate": 2, 0: 0, 1: 1, 2: 2}[v]
 ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "EHIP", -10: "ENOCONV", -11: "EBREAKDOWN", -13: "ENOMEM"}
 
 
@@ -133,7 +138,7 @@ class HipContext:
         if check_every is not None:
             opts.check_every = check_every
         opts.verify = int(verify)
-        opts.warm_start = int(warm_start)
+        opts.warm_start = _warm_start_code(warm_start)
         opts.fdm_precision = {"mixed": 0, "fp64": 1}[fdm_precision]
         self.opts = opts
         h = C.c_void_p()
@@ -157,6 +162,8 @@ class HipContext:
                 v = PRECOND[v]
             if k == "fdm_precision":
                 v = {"mixed": 0, "fp64": 1}[v]
+            if k == "warm_start":
+                v = _warm_start_code(v)
             setattr(self.opts, k, v)
         self._check(self.lib.hmcmt_set_options(self.h, C.byref(self.opts)))
 

@@ -282,3 +282,34 @@ def test_device_leapfrog_chain_equals_host_chain():
         out.append(res)
     assert np.array_equal(out[0][1].acceptstats, out[1][1].acceptstats)
     assert relmax(out[1][0], out[0][0]) < 1e-8 and relmax(out[1][1].hmstats, out[0][1].hmstats) < 1e-8
+
+
+def test_initial_guess_modes_agree_and_extrapolation_saves_iterations():
+    """warm_start only changes the initial guess (cold / previous fields / fields extrapolated along the
+    model path): every mode converges to the same answer, and along a straight model path -- what a
+    leapfrog trajectory is locally -- extrapolation needs the fewest iterations.  A repeated model
+    (getHamiltonian after the last leapfrog step) is recognised and costs no iterations."""
+    mesh, data, inv, m = make_problem("cfg2")
+    rng = np.random.default_rng(5)
+    d = 0.02 * rng.standard_normal(m.size)
+    path = [m + j * d for j in range(5)]
+    out, its = {}, {}
+    for mode in ("cold", "previous", "extrapolate"):
+        ctx = HipContext(mesh, data, inv, warm_start=mode)
+        for mj in path:
+            out[mode] = ctx.grad(mj)
+            st = ctx.stats()
+            assert st["status"] == 0
+        its[mode] = st["iters_fwd_sum"] + st["iters_adj_sum"]
+        if mode == "extrapolate":
+            ctx.grad(path[-1])
+            st = ctx.stats()
+            assert st["iters_fwd_max"] <= 3 and st["iters_adj_max"] <= 3, st
+            p2, f2, g2 = ctx.grad(path[-1] + d)             # and the history survived the repeat
+            assert ctx.stats()["iters_fwd_sum"] + ctx.stats()["iters_adj_sum"] <= its[mode] * 1.1
+        ctx.close()
+    for mode in ("previous", "extrapolate"):
+        assert relmax(out[mode][0], out["cold"][0]) < 1e-9
+        assert abs(out[mode][1] - out["cold"][1]) / out["cold"][1] < 1e-9
+        assert relmax(out[mode][2], out["cold"][2]) < 1e-7
+    assert its["extrapolate"] < its["previous"] < its["cold"]
