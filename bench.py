@@ -37,18 +37,15 @@ def build_problem(name, seed):
     return mesh, data, inv0, sig_true
 
 
-def cpu_baseline(name):
-    """Oracle (numpy/scipy restatement, direct solver) on a bounded sample: THREE of the config's
-    frequencies (TE + TM), single thread; value extrapolates linearly in the number of frequencies
-    (the reference's frequency loop is serial, MT2DFwdSolver.jl:140-146)."""
+def _cpu_worker(job):
+    """One worker process = one core: the oracle's compDataGradient restricted to the given frequencies."""
+    name, fs = job
     from threadpoolctl import threadpool_limits
     from oracle import hmcmt_oracle as O
     from hmcmt2d_amd import synthetic as S, invsetup as I
     from hmcmt2d_amd.structs import HMCPrior
     mesh, data, _ = S.make_config(name)
-    nF = len(data.freqs)
-    fs = [data.freqs[0], data.freqs[nF // 2], data.freqs[-1]]
-    d1 = S.make_data_layout(fs, data.rxLoc[:, 0])
+    d1 = S.make_data_layout(list(fs), data.rxLoc[:, 0])
     ny, nz = mesh.gridSize
     nair = len(mesh.airLayer)
     mesh.sigma = np.concatenate([np.full(ny * nair, S.SIG_AIR), np.full(ny * (nz - nair), 0.01)])
@@ -59,11 +56,69 @@ def cpu_baseline(name):
         O.setupTensorMesh2D(mesh)
         t0 = time.time()
         O.compDataGradient(mesh, d1, inv, HMCPrior(), True)      # dense dBC, as the reference forms it
-        dt = time.time() - t0
-    return {"value": len(fs) / (dt * nF), "unit": "steps/s", "cores": 1, "kind": "port",
-            "sample": f"oracle compDataGradient (numpy/scipy, SuperLU direct solves, dense dBC as the reference) "
-                      f"at {len(fs)} of {nF} frequencies ({fs[0]:.3g}, {fs[1]:.3g}, {fs[2]:.3g} Hz; TE+TM) of {name}: "
-                      f"{dt:.2f} s, scaled x{nF}/{len(fs)} to a full step"}
+        return time.time() - t0
+
+
+def cpu_baseline(name):
+    """Oracle (numpy/scipy restatement, SuperLU direct solves, dense dBC) on a bounded sample, using every
+    host core: one single-threaded worker process per core, each evaluating compDataGradient on its own
+    frequency (TE + TM) of the config -- the frequency loop is the reference's only parallelisable axis
+    (MT2DFwdSolver.jl:140-146, compJacTMatVec.jl:202-325).  value = frequencies done / wall time / nFreq.
+    Runs BEFORE this process touches the GPU (the workers are spawned, not forked)."""
+    import multiprocessing as mp
+    from hmcmt2d_amd import synthetic as S
+    _, data, _ = S.make_config(name)
+    nF = len(data.freqs)
+    cores = max(1, min(len(os.sched_getaffinity(0)), nF))
+    per = 2                                                      # frequencies per worker: ~10-20 core-seconds in all
+    jobs = [(name, tuple(float(data.freqs[((j * nF) // cores + i * (nF // per)) % nF]) for i in range(per)))
+            for j in range(cores)]
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(cores) as pool:
+        t0 = time.time()
+        times = pool.map(_cpu_worker, jobs, chunksize=1)
+        wall = time.time() - t0
+    # wall includes each worker's imports and set-up; the rate uses the slowest worker's own timer
+    tmax = max(times)
+    return {"value": per * len(jobs) / (tmax * nF), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle compDataGradient (numpy/scipy, SuperLU direct solves, dense dBC as the reference) at "
+                      f"{per} of {nF} frequencies (TE+TM) of {name} per worker, one single-threaded worker process per core on "
+                      f"{cores} cores concurrently: slowest worker {tmax:.2f} s (sum {sum(times):.1f} core-s, wall "
+                      f"incl. start-up {wall:.1f} s), scaled to {nF} frequencies"}
+
+
+def pmc_traffic(cat):
+    """HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in separate runs of
+    this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM'), summarised by scripts/pmc_summary.py into
+    profiles/pmc_traffic.json; None when that file has no entry."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)["per_launch_bytes"].get(cat)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def sampler_leg(step, forward, K, W, Ltraj, nsamples=6):
+    """samples/s with the reference's cost structure -- per sample one trajectory of (1 + L)
+    gradient evaluations plus one forward-only solve at the proposal (HMCSampler.jl:136,141) -- on the synthetic
+    trajectories of the timed region (L = Ltraj - 1 = 7 position steps, timestep 6..10 in
+    examples/dprism3d/startupfile).  The proposal's model equals the last gradient's, which the library
+    recognises (the forward-only solve then costs about one iteration)."""
+    import torch
+    first = ((W + Ltraj - 1) // Ltraj) * Ltraj            # trajectories start at multiples of Ltraj
+    n = min(nsamples, (W + K - first) // Ltraj)
+    if n < 1:
+        return None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        k0 = first + i * Ltraj
+        for j in range(Ltraj):
+            step(k0 + j)                         # gradient at the start model and after each of the L position steps
+        forward(k0 + Ltraj - 1)                  # getHamiltonian's forward-only solve at the proposal
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"samples_per_s": n / dt, "samples": n, "evals_per_sample": f"{Ltraj} gradients + 1 forward-only"}
 
 
 def main():
@@ -73,12 +128,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sampler", action="store_true", help="skip the untimed samples/s leg")
     args = ap.parse_args()
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.config)          # before this process touches the GPU: the workers are spawned
+    import torch
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
@@ -130,7 +189,7 @@ def main():
     if not os.environ.get("HMCMT_BENCH_NOPROF"):
         # HIP events around the two heaviest kernel families, in every 6th step of the timed region
         # (bracketing every launch of every step costs ~20 % of the throughput)
-        ctx.profile(["fdm_transform", "tridiagonal"], every=6)
+        ctx.profile(["fdm_transform", "tridiagonal", "spmv", "vector_ops"], every=6)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -150,24 +209,45 @@ def main():
         elapsed = float(t.item())
     misfit = float(d_mis.item())
     gnorm = float(torch.linalg.vector_norm(d_grad).item())
+    def forward(k):
+        ctx.forward_device(d_m[k].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr())
+
+    samples = None
+    if rank == 0 and not args.no_sampler:
+        samples = sampler_leg(step, forward, K, W, Ltraj)
 
     if rank == 0:
-        # Algorithmic bytes per launch, interior unknowns only: U = S*(nz-1)*(ny-1) complex values.
-        #   tridiagonal (complex64, two sweeps): read y twice, write y twice, read the inverse pivots twice = 6*8*U
-        #   transforms  (complex64 in/out around bf16 MFMA): forward reads t (8U) writes y (8U); backward reads y (8U),
-        #   dinv and r (16U each) and writes z (16U): (16 + 56)/2 = 36*U per launch on average
+        # Algorithmic bytes per launch: U = S*(nz-1)*(ny-1) interior unknowns, complex128 = 16 B,
+        # complex64 = 8 B; the real stencil coefficients are shared by all frequencies of a mode (not counted).
+        #   tridiagonal  k_thomas32       : read rhs (8) + inverse pivots (8), write solution (8)            = 24 U
+        #   transforms   k_transform_lp<0>: read t (8), write y (8) = 16 U;  <2>: read y (8), dinv (16), r (16),
+        #                write z (16) = 56 U                                              -> 36 U per launch on average
+        #   spmv         k_spmv_fused     : read z, p (32), write p, q (32) = 64 U;  k_post: read r, z, dinv (48),
+        #                write t (16) = 64 U                                              -> 64 U per launch
+        #   vector_ops   k_update_fused   : read p, q, r, x, dinv (80), write x, r (32), t as complex64 (8) = 120 U
         nyi, nzi = ctx.ny - 1, ctx.nz - 1
         U = ctx.S * nzi * nyi
-        fams = {"k_thomas32 (batched complex64 tridiagonal solve)": ("tridiagonal", 48.0 * U),
-                "k_transform_lp (split-bf16 MFMA transforms of the FDM preconditioner)": ("fdm_transform", 36.0 * U)}
+        fams = {"k_thomas32 (batched complex64 tridiagonal solve of the FDM stage)": ("tridiagonal", 24.0 * U, 1),
+                "k_transform_lp<0>,<2> (split-bf16 MFMA eigen-transforms of the FDM stage)": ("fdm_transform", 36.0 * U, 2),
+                "k_spmv_fused, k_post (5-point stencil products fused with the p-update / Jacobi post-smoothing)": ("spmv", 64.0 * U, 2),
+                "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 120.0 * U, 1)}
         roofs = []
-        for kname, (cat, nbytes) in fams.items():
+        it_bytes = it_us = 0.0
+        for kname, (cat, nbytes, per_it) in fams.items():
             ms_c, n_c = prof[cat]
             avg_us = 1e3 * ms_c / max(n_c, 1)
             ach = nbytes / (avg_us * 1e-6) / 1e9 if n_c else 0.0
+            it_bytes += per_it * nbytes
+            it_us += per_it * avg_us
             roofs.append({"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_us,
-                          "launches_timed": n_c, "bytes_per_launch": nbytes, "ms_timed": ms_c})
+                          "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(cat), "avg_launch_us": avg_us,
+                          "launches_timed": n_c, "launches_per_iteration": per_it, "bytes_per_launch": nbytes,
+                          "ms_timed": ms_c})
+        iteration = {"kernels": 6, "bytes": it_bytes, "us": it_us,
+                     "achieved": it_bytes / (it_us * 1e-6) / 1e9 if it_us else 0.0, "unit": "GB/s",
+                     "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS if it_us else 0.0,
+                     "note": "one preconditioned COCG iteration of all systems = 6 launches; the working set "
+                             "(~15 vectors) fits the 256 MB Infinity Cache at cfg3, so launches are latency- not HBM-bound"}
         roofs.sort(key=lambda r: -r["ms_timed"])
         out = {
             "metric": "leapfrog steps/sec (= fwd+grad evals/sec), 200x100 mesh x 16 freq",
@@ -181,11 +261,12 @@ def main():
                        "solver": "batched fp64 COCG, Jacobi/fast-diagonalisation/Jacobi preconditioner (FDM stage in split-bf16/fp32), tol 1e-11 (error estimate), warm start",
                        "iters_fwd_max": st["iters_fwd_max"], "iters_adj_max": st["iters_adj_max"],
                        "parallelism": f"chains x{world}" if world > 1 else "1 chain"},
-            "roofline": roofs[0], "roofline_other": roofs[1:],
+            "roofline": roofs[0], "roofline_other": roofs[1:], "roofline_iteration": iteration,
+            "samples": samples,
             "check": {"misfit_last": misfit, "grad_l2_last": gnorm, "solver_status": st["status"]},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(name)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     ctx.close()
     if dist is not None:

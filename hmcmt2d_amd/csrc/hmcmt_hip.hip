@@ -894,6 +894,28 @@ __global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r
     }
 }
 
+// start of a solve: every requested system active, records cleared (one launch instead of five copies/memsets)
+__global__ void k_solve_begin(Solver k, const int* __restrict__ sysOn) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < k.S * MAXNB) k.partB[t] = 0.0;
+    if (t < k.S) { k.active[t] = sysOn[t]; k.iters[t] = 0; k.status[t] = 0; }
+    if (t == 0) {
+        int n = 0;
+        for (int s = 0; s < k.S; ++s) n += sysOn[s];
+        *k.nactive = n;
+    }
+}
+
+// end of a solve: per-system records of this solve kind into the packed read-back buffer
+// rec = [2 kinds][S] iters (int) | [2][S] status (int) | [2][S] error estimate (double)
+__global__ void k_solve_end(Solver k, int kind, int* __restrict__ recI, double* __restrict__ recE) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= k.S) return;
+    recI[kind * k.S + s] = k.iters[s];
+    recI[(2 + kind) * k.S + s] = k.status[s];
+    recE[kind * k.S + s] = k.errEst[s];
+}
+
 // ---- initial guess extrapolated along the model path (options.warm_start == 2) ----
 // The fields are smooth functions of the model, and a leapfrog trajectory moves the model along an
 // almost straight line, so x(m_new) ~ x_k + alpha (x_k - x_{k-1}) with alpha the projection of
@@ -925,13 +947,15 @@ __global__ __launch_bounds__(1024) void k_extrap_alpha(const double* __restrict_
     if (threadIdx.x == 0) { ext[0] = alpha; ext[1] = keep ? 1.0 : 0.0; if (!keep) ext[2] = (double)min(count + 1, 2); }
 }
 
-// x <- x + alpha (x - xprev), xprev <- old x
+// x <- x + alpha (x - xprev), xprev <- old x, on interior nodes (runs beside k_bc_forward, which writes X's boundary nodes)
 __global__ __launch_bounds__(VBLOCK) void k_extrap(Solver k, cplx* x, cplx* xprev, const double* __restrict__ ext) {
     if (ext[1] != 0.0) return;
     const double alpha = ext[0];
     const long so = (long)blockIdx.y * k.vstride;
     const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
     for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        if (iz < 1 || iz > k.nz - 1 || iy < 1 || iy > k.ny - 1) continue;
         const cplx t = x[so + e], q = xprev[so + e];
         xprev[so + e] = t;
         x[so + e] = t + alpha * (t - q);
@@ -1150,7 +1174,7 @@ struct hmcmt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;       // sigma-only sensitivity tables run beside the forward solve
-    hipEvent_t evModel = nullptr, evSens = nullptr;
+    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr;
     std::vector<void*> allocs;
     std::string err;
     // device scalars / buffers not in View
@@ -1163,14 +1187,11 @@ struct hmcmt_ctx {
     cplx* d_fieldsOut = nullptr;
     // pinned host staging
     int* h_nactive = nullptr;
-    int* h_iters = nullptr;
-    int* h_status = nullptr;
-    double* h_err = nullptr;
+    double* h_rec = nullptr;              // packed per-solve records: [2][S] iters, [2][S] status (int), [2][S] err (double)
     double* h_stage = nullptr;            // m / grad / pred / misfit staging
     size_t stageDoubles = 0;
     std::vector<int> itersLast;           // [2*S]
-    int *d_itersAll = nullptr, *d_statusAll = nullptr;   // [2][S] per solve kind
-    double* d_errAll = nullptr;
+    double* d_rec = nullptr;              // device copy of h_rec, filled by k_solve_end
     bool solveDone[2] = {true, true};
     int lastItFwd = 0, lastItAdj = 0;
     bool haveModel = false;
@@ -1344,9 +1365,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     const size_t vecBytes = (size_t)S * k.vstride * sizeof(cplx);
     if (ctx->opt.verify) HIPCHK(hipMemcpyAsync(ctx->d_b, k.r, vecBytes, hipMemcpyDeviceToDevice, ctx->stream));
     // all systems of the requested modes start active (device copy: no host round trip)
-    HIPCHK(hipMemcpyAsync(k.active, ctx->v.sysOn, sizeof(int) * S, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(k.iters, 0, sizeof(int) * S, ctx->stream));
-    HIPCHK(hipMemsetAsync(k.status, 0, sizeof(int) * S, ctx->stream));
+    hipLaunchKernelGGL(k_solve_begin, dim3((S * MAXNB + 255) / 256), dim3(256), 0, ctx->stream, k, ctx->v.sysOn);
     int& guess = kind == 0 ? ctx->lastItFwd : ctx->lastItAdj;
     int nextCheck = guess > 2 ? guess : 4;
     const int every = ctx->opt.check_every > 0 ? ctx->opt.check_every : 2;
@@ -1358,11 +1377,6 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     const bool fused = ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0;
     cplx* const r_entry = k.r;
     if (fused) {
-        int nOn = 0;
-        for (int s = 0; s < S; ++s) nOn += ctx->hp.sysOn[s];
-        *ctx->h_nactive = nOn;
-        HIPCHK(hipMemcpyAsync(k.nactive, ctx->h_nactive, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemsetAsync(k.partB, 0, sizeof(double) * S * MAXNB, ctx->stream));
         { int prc = apply_precond(ctx); if (prc) return prc; }          // z = P^-1 r and the partial sums of r'z, |z|^2
         cplx* pb[2] = {k.p, k.p2};
         cplx* rb[2] = {k.r, k.r2};
@@ -1430,9 +1444,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     guess = it;
     ctx->solveDone[kind] = done;
     // iteration counts / status / error estimates stay on the device; evaluate() reads both solves back at once
-    HIPCHK(hipMemcpyAsync(ctx->d_itersAll + (size_t)kind * S, k.iters, sizeof(int) * S, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_statusAll + (size_t)kind * S, k.status, sizeof(int) * S, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_errAll + (size_t)kind * S, k.errEst, sizeof(double) * S, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_solve_end, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, k, kind, (int*)ctx->d_rec, ctx->d_rec + 2 * S);
     if (ctx->opt.verify) {
         hipLaunchKernelGGL(k_trueres, vg, vb, 0, ctx->stream, k, ctx->d_b, x, ctx->d_partRes, ctx->d_partBn);
         std::vector<double> pr((size_t)S * MAXNB), pb((size_t)S * MAXNB);
@@ -1462,13 +1474,41 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     ++ctx->evalCount;
     const int nodes = v.NZP * (v.ny + 1);
     const size_t vecBytes = (size_t)S * v.vstride * sizeof(cplx);
+    // initial guesses (options.warm_start): verify checks against the cold right-hand side
+    const bool warmF = ctx->opt.warm_start && ctx->haveFwd && !ctx->opt.verify;
+    const bool warmA = ctx->opt.warm_start && ctx->haveAdj && !ctx->opt.verify;
+    const bool extrap = ctx->opt.warm_start == 2 && !ctx->opt.verify;
     {
         ProfScope ps(ctx, 4);
         hipLaunchKernelGGL(k_sigma, grid1(v.nCell, 256), dim3(256), 0, st, v);
         hipLaunchKernelGGL(k_rowmean, dim3(v.nz), dim3(64), 0, st, v);
-        if (wantGrad) {   // sensitivity tables depend on sigma only: computed on the side stream, joined before k_bcsens
+        // initial guesses: zero on a cold start, otherwise the previous fields, optionally extrapolated
+        if (!warmF) {
+            HIPCHK(hipMemsetAsync(v.X, 0, vecBytes, st));
+            HIPCHK(hipMemsetAsync(ctx->d_ext[0], 0, 4 * sizeof(double), st));
+        }
+        if (wantGrad && !warmA) {
+            HIPCHK(hipMemsetAsync(v.Lam, 0, vecBytes, st));
+            HIPCHK(hipMemsetAsync(ctx->d_ext[1], 0, 4 * sizeof(double), st));
+        }
+        // side stream, beside the coefficient / boundary-value kernels and the forward solve: the extrapolation of
+        // both initial guesses (interior nodes only -- k_bc_forward owns the boundary nodes of X) and the
+        // sigma-only sensitivity tables (joined before k_bcsens)
+        if (extrap || wantGrad) {
             HIPCHK(hipEventRecord(ctx->evModel, st));
             HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evModel, 0));
+        }
+        if (extrap) {
+            hipLaunchKernelGGL(k_extrap_alpha, dim3(1), dim3(1024), 0, ctx->side, d_m, ctx->d_mHist[0], v.nAC, ctx->d_ext[0]);
+            hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
+            HIPCHK(hipEventRecord(ctx->evExtF, ctx->side));
+            if (wantGrad) {
+                hipLaunchKernelGGL(k_extrap_alpha, dim3(1), dim3(1024), 0, ctx->side, d_m, ctx->d_mHist[1], v.nAC, ctx->d_ext[1]);
+                hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.Lam, ctx->d_prevField[1], ctx->d_ext[1]);
+                HIPCHK(hipEventRecord(ctx->evExtA, ctx->side));
+            }
+        }
+        if (wantGrad) {
             hipLaunchKernelGGL(k_sens_layers, dim3((v.nz + 1 + 63) / 64, 3, S), dim3(64), 0, ctx->side, v);
             hipLaunchKernelGGL(k_sens_profile, dim3((3 * S + 63) / 64), dim3(64), 0, ctx->side, v);
             HIPCHK(hipEventRecord(ctx->evSens, ctx->side));
@@ -1481,17 +1521,9 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         }
         if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI)
             hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, 0.7);
-        const bool warmF = ctx->opt.warm_start && ctx->haveFwd && !ctx->opt.verify;   // verify checks against the cold rhs
-        if (!warmF) {
-            HIPCHK(hipMemsetAsync(v.X, 0, vecBytes, st));
-            HIPCHK(hipMemsetAsync(ctx->d_ext[0], 0, 4 * sizeof(double), st));
-        }
-        if (ctx->opt.warm_start == 2 && !ctx->opt.verify) {
-            hipLaunchKernelGGL(k_extrap_alpha, dim3(1), dim3(1024), 0, st, d_m, ctx->d_mHist[0], v.nAC, ctx->d_ext[0]);
-            hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
-        }
         hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, S), dim3(64), 0, st, v);
         hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, S), dim3(64), 0, st, v);
+        if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtF, 0));
         // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X
         hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, 1);
     }
@@ -1511,15 +1543,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             HIPCHK(hipMemsetAsync(v.R, 0, vecBytes, st));
             HIPCHK(hipMemsetAsync(v.srcB, 0, sizeof(cplx) * 4 * S, st));
             hipLaunchKernelGGL(k_src, dim3((2 * (v.ny + 1) + 127) / 128, S), dim3(128), 0, st, v);
-            const bool warmA = ctx->opt.warm_start && ctx->haveAdj && !ctx->opt.verify;
-            if (!warmA) {
-                HIPCHK(hipMemsetAsync(v.Lam, 0, vecBytes, st));
-                HIPCHK(hipMemsetAsync(ctx->d_ext[1], 0, 4 * sizeof(double), st));
-            }
-            if (ctx->opt.warm_start == 2 && !ctx->opt.verify) {
-                hipLaunchKernelGGL(k_extrap_alpha, dim3(1), dim3(1024), 0, st, d_m, ctx->d_mHist[1], v.nAC, ctx->d_ext[1]);
-                hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, ctx->d_prevField[1], ctx->d_ext[1]);
-            }
+            if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtA, 0));
             if (warmA) hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, 0);
         }
         rc = solve(ctx, v.Lam, 1);
@@ -1541,18 +1565,19 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
 // after the final stream sync of an evaluation: read both solves' records back and fill the statistics
 int collect_stats(hmcmt_ctx* ctx, bool withAdjoint) {
     const int S = ctx->v.S, nk = withAdjoint ? 2 : 1;
-    HIPCHK(hipMemcpyAsync(ctx->h_iters, ctx->d_itersAll, sizeof(int) * nk * S, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->h_status, ctx->d_statusAll, sizeof(int) * nk * S, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->h_err, ctx->d_errAll, sizeof(double) * nk * S, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_rec, ctx->d_rec, sizeof(double) * 4 * S, hipMemcpyDeviceToHost, ctx->stream));
+    const int* h_iters = reinterpret_cast<const int*>(ctx->h_rec);
+    const int* h_status = h_iters + 2 * S;
+    const double* h_err = ctx->h_rec + 2 * S;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int kind = 0; kind < nk; ++kind) {
         int mx = 0, sum = 0;
         for (int s = 0; s < S; ++s) {
-            const int itv = ctx->h_iters[kind * S + s];
+            const int itv = h_iters[kind * S + s];
             ctx->itersLast[kind * S + s] = itv;
             mx = std::max(mx, itv); sum += itv;
-            if (ctx->h_status[kind * S + s] != 0 && ctx->stats.status == 0) ctx->stats.status = ctx->h_status[kind * S + s];
-            if (ctx->h_err[kind * S + s] > ctx->stats.err_est_max) ctx->stats.err_est_max = ctx->h_err[kind * S + s];
+            if (h_status[kind * S + s] != 0 && ctx->stats.status == 0) ctx->stats.status = h_status[kind * S + s];
+            if (h_err[kind * S + s] > ctx->stats.err_est_max) ctx->stats.err_est_max = h_err[kind * S + s];
         }
         if (kind == 0) { ctx->stats.iters_fwd_max = mx; ctx->stats.iters_fwd_sum = sum; }
         else { ctx->stats.iters_adj_max = mx; ctx->stats.iters_adj_sum = sum; }
@@ -1595,12 +1620,12 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     for (void* p : ctx->allocs) hipFree(p);
     for (hipEvent_t e : ctx->evPool) hipEventDestroy(e);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
-    if (ctx->h_iters) hipHostFree(ctx->h_iters);
-    if (ctx->h_status) hipHostFree(ctx->h_status);
-    if (ctx->h_err) hipHostFree(ctx->h_err);
+    if (ctx->h_rec) hipHostFree(ctx->h_rec);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
     if (ctx->evModel) hipEventDestroy(ctx->evModel);
     if (ctx->evSens) hipEventDestroy(ctx->evSens);
+    if (ctx->evExtF) hipEventDestroy(ctx->evExtF);
+    if (ctx->evExtA) hipEventDestroy(ctx->evExtA);
     if (ctx->side) hipStreamDestroy(ctx->side);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1618,6 +1643,8 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->evModel, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evSens, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evExtF, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evExtA, hipEventDisableTiming));
     const HostProblem& h = ctx->hp;
     View& v = ctx->v;
     v.ny = h.ny; v.nz = h.nz; v.NYP = h.NYP; v.NZP = h.NZP; v.nFreq = h.nFreq; v.S = h.S; v.nRx = h.nRx;
@@ -1707,13 +1734,11 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     DA(k.partA, S * MAXNB) DA(k.partB, S * MAXNB) DA(ctx->d_partZZ, S * MAXNB)
     DA(ctx->d_partRes, S * MAXNB) DA(ctx->d_partBn, S * MAXNB)
     DA(k.rho, S) DA(k.alphaBeta, S) DA(k.active, S) DA(k.iters, S) DA(k.status, S) DA(k.nactive, 1) DA(k.errEst, S)
-    DA(ctx->d_b, S * VS) DA(ctx->d_itersAll, 2 * S) DA(ctx->d_statusAll, 2 * S) DA(ctx->d_errAll, 2 * S)
+    DA(ctx->d_b, S * VS) DA(ctx->d_rec, 4 * S)
     DA(ctx->d_fieldsOut, (size_t)h.nFreq * (h.ny + 1) * (h.nz + 1))
 #undef DA
     HIPCHK(hipHostMalloc((void**)&ctx->h_nactive, sizeof(int)));
-    HIPCHK(hipHostMalloc((void**)&ctx->h_iters, sizeof(int) * 2 * h.S));
-    HIPCHK(hipHostMalloc((void**)&ctx->h_status, sizeof(int) * 2 * h.S));
-    HIPCHK(hipHostMalloc((void**)&ctx->h_err, sizeof(double) * 2 * h.S));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_rec, sizeof(double) * 4 * h.S));
     ctx->stageDoubles = (size_t)h.nAC * 4 + (size_t)h.nData * 2 + 16;
     HIPCHK(hipHostMalloc((void**)&ctx->h_stage, sizeof(double) * ctx->stageDoubles));
     ctx->itersLast.assign(2 * h.S, 0);
