@@ -355,6 +355,16 @@ __device__ __forceinline__ c32 operator*(float a, c32 b) { return c32{a * b.re, 
 __device__ __forceinline__ c32 operator-(c32 a, c32 b) { return c32{a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ void pin(cplx& a) { asm volatile("" : "+v"(a.re), "+v"(a.im)); }
 __device__ __forceinline__ void pin(c32& a) { asm volatile("" : "+v"(a.re), "+v"(a.im)); }
+// a - b*x with four single (unpacked) FMAs, dependent depth two: the serial tridiagonal sweeps are latency
+// chains, and the packed v_pk_* forms hipcc's SLP pass would pick are slower per dependent step
+__device__ __forceinline__ c32 cmsub(c32 a, c32 b, c32 x) {
+    float re, im;
+    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(re) : "v"(b.re), "v"(x.re), "v"(a.re));
+    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(im) : "v"(b.re), "v"(x.im), "v"(a.im));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(re) : "v"(b.im), "v"(x.im), "v"(re));
+    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(im) : "v"(b.im), "v"(x.re), "v"(im));
+    return c32{re, im};
+}
 
 template <class CT, class RT>
 __device__ __forceinline__ void thomas_twisted(CT* __restrict__ y, const CT* __restrict__ ip, const RT* sof, int n, long NYP) {
@@ -689,6 +699,197 @@ __global__ __launch_bounds__(512) void k_transform_lp(const float2* __restrict__
     const int t0 = nw * base + min(nw, extra);
     if (ntl == 2) transform_lp_body<2, OUT>(A, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0, lane);
     else if (ntl == 1) transform_lp_body<1, OUT>(A, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0, lane);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Forward half of the mixed-precision FDM stage in ONE kernel: Y = T V for a slab of 16 eigen-modes of one
+// system (all rows; split-bf16 MFMA as above), then the complex64 tridiagonal solves of those 16 modes with
+// the slab resident in LDS, then the coalesced write of the solved slab.  Replaces k_transform_lp<0> +
+// k_thomas32 (one launch, no round trip of Y through global memory, and the serial sweeps read LDS).
+// The recurrences are pre-multiplied off the serial chain by the MFMA waves:
+//   a = y*ip, b = sof[row-1]*ip, c = sof[row]*ip   (ip = inverse pivot, sof = z off-diagonal)
+//   down: x_row = a_row - b_row x_{row-1}  (rows 1..n);  up: x_row = x_row - c_row x_{row+1}  (rows n-1..1)
+// so each serial step is one complex multiply-subtract (two dependent FMAs).
+// LDS: sof[NZP] floats (padded to 128 B) + 3 slabs [NZP][16] complex64.
+// ----------------------------------------------------------------------------------------------
+constexpr int FW_TB = 8;           // rows requested ahead of the serial chain
+constexpr int FW_PRE = 8;          // inverse pivots per thread requested at kernel entry
+#ifndef HMCMT_FW_NTW
+#define HMCMT_FW_NTW 2
+#endif
+constexpr int FW_NTW = HMCMT_FW_NTW; // column tiles per slab: 2 -> 32 modes, ceil(NT/2)*S workgroups (224 at cfg3: one round on 256 CUs)
+
+template <int NTW>                 // column tiles (of 16 modes) per slab
+__global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restrict__ A, const u4v* __restrict__ Bhi,
+                                                 const u4v* __restrict__ Blo, const float2* __restrict__ ip32,
+                                                 float2* __restrict__ Y, long long* stamps = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    const int NYP = k.NYP, NZP = k.NZP, n = k.nz - 1;
+    constexpr int SW = 16 * NTW;
+#define FW_STAMP(i) if (stamps && threadIdx.x == 0) stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime();
+    FW_STAMP(0)
+    // sof first (padded to a multiple of 128 B), then the three slabs
+    float* sof = reinterpret_cast<float*>(smem);
+    // each slab has 2 FW_TB padding rows in front of row 0 and behind row NZP-1, the inner FW_TB zeroed: the serial sweeps run whole blocks
+    // of FW_TB rows without conditionals (a = b = c = 0 there, so x = 0)
+    const int NZL = NZP + 4 * FW_TB;                   // (the outer FW_TB rows of each side are only ever requested ahead)
+    c32* sa = reinterpret_cast<c32*>(smem + (((long)NZP * 4 + 127) & ~127L)) + 2 * FW_TB * SW;
+    c32* sb = sa + (long)NZL * SW;
+    c32* sc = sb + (long)NZL * SW;
+    const int mode = s >= k.nFreq;
+    for (int i = threadIdx.x; i < NZP; i += blockDim.x) sof[i] = (float)k.ofz[(long)mode * NZP + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int NT = NYP >> 4, KG = (NYP + 31) >> 5;
+    const int t0 = blockIdx.x * NTW;                   // first column tile of this slab
+    const int lj = lane & 15, g = lane >> 4, part = lj & 1;
+    const long so = (long)s * k.vstride;
+    const float2* As = A + so;
+    // this thread's inverse pivots of the pre-multiplication pass, requested now so that their latency hides
+    // behind the transform
+    float2 ipv[FW_PRE];
+#pragma unroll
+    for (int e = 0; e < FW_PRE; ++e) {
+        const int idx = threadIdx.x + e * blockDim.x;
+        const int row = idx / SW, c = t0 * 16 + (idx % SW);
+        ipv[e] = (idx < NZP * SW && row >= 1 && row <= n && c < k.ny - 1) ? ip32[so + (long)row * NYP + c] : float2{0.f, 0.f};
+    }
+    for (int m0 = wave * 8; m0 < NZP; m0 += nwave * 8) {
+        const int arow = min(m0 + (lj >> 1), NZP - 1);
+        f4v acc[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t] = f4v{0, 0, 0, 0};
+        for (int kc = 0; kc < KG; kc += KCH) {
+            f4v a[KCH][4];
+            u4v bh[KCH][NTW], bl[KCH][NTW];
+#pragma unroll
+            for (int q = 0; q < KCH; ++q) {
+                const int kg = min(kc + q, KG - 1);
+                const f4v* ap = reinterpret_cast<const f4v*>(As + (long)arow * NYP + 32 * kg + 8 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[q][i] = ap[i];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    const long bi = ((long)kg * NT + min(t0 + t, NT - 1)) * 64 + lane;
+                    bh[q][t] = Bhi[bi]; bl[q][t] = Blo[bi];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < KCH; ++q) {
+                if (kc + q < KG) {
+                    unsigned hh[8], ll[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float x0 = part ? a[q][i][1] : a[q][i][0], x1 = part ? a[q][i][3] : a[q][i][2];
+                        hh[2 * i] = bf16_rn(x0); ll[2 * i] = bf16_rn(x0 - bf16_to_f32(hh[2 * i]));
+                        hh[2 * i + 1] = bf16_rn(x1); ll[2 * i + 1] = bf16_rn(x1 - bf16_to_f32(hh[2 * i + 1]));
+                    }
+                    const u4v ahu = u4v{hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16)};
+                    const u4v alu = u4v{ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16)};
+                    const bf8v ah = __builtin_bit_cast(bf8v, ahu), al = __builtin_bit_cast(bf8v, alu);
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) {
+                        const bf8v bhf = __builtin_bit_cast(bf8v, bh[q][t]), blf = __builtin_bit_cast(bf8v, bl[q][t]);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blf, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // D rows 4g+r: (re, im) of complex rows 2g and 2g+1 of this group, column 16 t + lj of the slab
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int row = m0 + 2 * g + h2;
+                if (row < NZP) sa[row * SW + t * 16 + lj] = c32{acc[t][2 * h2], acc[t][2 * h2 + 1]};
+            }
+    }
+    __syncthreads();
+    FW_STAMP(1)
+    // pre-multiply the recurrences (kept apart from the MFMA waves' epilogue on purpose: computing these
+    // products right behind the last MFMA gave sporadically wrong values on gfx950)
+    auto premul = [&](int idx, float2 ipf) {
+        const int row = idx / SW, c = t0 * 16 + (idx % SW);
+        c32 bv = c32{0, 0}, cv = c32{0, 0};
+        if (row >= 1 && row <= n && c < k.ny - 1) {
+            const c32 ip = c32{ipf.x, ipf.y};
+            sa[idx] = sa[idx] * ip; bv = sof[row - 1] * ip; cv = sof[row] * ip;
+        }
+        sb[idx] = bv; sc[idx] = cv;
+    };
+#pragma unroll
+    for (int e = 0; e < FW_PRE; ++e) {
+        const int idx = threadIdx.x + e * blockDim.x;
+        if (idx < NZP * SW) premul(idx, ipv[e]);
+    }
+    for (int idx = threadIdx.x + FW_PRE * blockDim.x; idx < NZP * SW; idx += blockDim.x) {
+        const int row = idx / SW, c = t0 * 16 + (idx % SW);
+        premul(idx, (row >= 1 && row <= n && c < k.ny - 1) ? ip32[so + (long)row * NYP + c] : float2{0.f, 0.f});
+    }
+    for (int idx = threadIdx.x; idx < FW_TB * SW; idx += blockDim.x) {
+        const c32 z = c32{0, 0};
+        sa[idx - FW_TB * SW] = z; sb[idx - FW_TB * SW] = z; sc[idx - FW_TB * SW] = z;
+        sa[NZP * SW + idx] = z; sb[NZP * SW + idx] = z; sc[NZP * SW + idx] = z;
+    }
+    __syncthreads();
+    FW_STAMP(2)
+    if (wave == 0 && lane < SW && t0 * 16 + lane < k.ny - 1) {
+        // rows are addressed from one moving base with compile-time offsets (no clamps: the padding rows
+        // absorb the blocks' overhang), so a step is 4 FMAs + 2 LDS reads + 1 LDS write
+        c32 pt = c32{0, 0};
+        c32 av[FW_TB], bv[FW_TB];
+        // ---- down sweep, rows 1..n in whole blocks (rows beyond n: zeros in, zeros out)
+        {
+            c32* pa = sa + SW + lane;
+            const c32* pb = sb + SW + lane;
+#pragma unroll
+            for (int t = 0; t < FW_TB; ++t) { av[t] = pa[t * SW]; bv[t] = pb[t * SW]; }
+            for (int r0 = 1; r0 <= n; r0 += FW_TB) {
+                c32 na[FW_TB], nb[FW_TB];
+#pragma unroll
+                for (int t = 0; t < FW_TB; ++t) { na[t] = pa[(FW_TB + t) * SW]; nb[t] = pb[(FW_TB + t) * SW]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(av[t], bv[t], pt); pa[t * SW] = pt; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < FW_TB; ++t) { av[t] = na[t]; bv[t] = nb[t]; pin(av[t]); pin(bv[t]); }
+                pa += FW_TB * SW; pb += FW_TB * SW;
+            }
+        }
+        // ---- up sweep, rows n-1..1 in whole blocks (rows above 1: zeros in, zeros out); starts from x_n
+        {
+            pt = sa[n * SW + lane];
+            c32* pa = sa + (n - 1) * SW + lane;
+            const c32* pc = sc + (n - 1) * SW + lane;
+#pragma unroll
+            for (int t = 0; t < FW_TB; ++t) { av[t] = pa[-t * SW]; bv[t] = pc[-t * SW]; }
+            for (int r0 = n - 1; r0 >= 1; r0 -= FW_TB) {
+                c32 na[FW_TB], nb[FW_TB];
+#pragma unroll
+                for (int t = 0; t < FW_TB; ++t) { na[t] = pa[-(FW_TB + t) * SW]; nb[t] = pc[-(FW_TB + t) * SW]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(av[t], bv[t], pt); pa[-t * SW] = pt; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < FW_TB; ++t) { av[t] = na[t]; bv[t] = nb[t]; pin(av[t]); pin(bv[t]); }
+                pa -= FW_TB * SW; pc -= FW_TB * SW;
+            }
+        }
+    }
+    FW_STAMP(3)
+    __syncthreads();
+    // solved slab -> Y (rows of SW complex64)
+    for (int idx = threadIdx.x; idx < NZP * SW; idx += blockDim.x) {
+        const int row = idx / SW, c = t0 * 16 + (idx % SW);
+        if (c < NYP) { const c32 v = sa[idx]; Y[so + (long)row * NYP + c] = float2{v.re, v.im}; }
+    }
+    FW_STAMP(4)
 }
 
 // complex64 copy of a vector (plain FDM: the transform input is r itself)
@@ -1199,6 +1400,8 @@ struct hmcmt_ctx {
     cplx* d_prevField[2] = {nullptr, nullptr};   // previous solutions (warm_start == 2), per solve kind
     double* d_mHist[2] = {nullptr, nullptr};     // [2][nAC] model history per solve kind
     double* d_ext[2] = {nullptr, nullptr};       // {alpha, keep, count}
+    bool fusedFwd = true;                    // forward transform + tridiagonal solve in one kernel (HMCMT_FUSED_FWD=0: separate)
+    size_t maxLds = 64 * 1024;               // dynamic LDS the fused kernels may request
     bool lpFallback = false;                 // this solve has switched its stragglers to the fp64 preconditioner
     // profiling
     unsigned profMask = 0;            // bit c: time category c with HIP events
@@ -1310,6 +1513,25 @@ int launch_transform_lp(hmcmt_ctx* ctx, const float2* A, bool transposed, void* 
     return 0;
 }
 
+// forward half of the mixed-precision FDM stage: y32 = tridiag^-1 (t32 V); fused kernel when its LDS slabs fit
+int launch_fdm_fwd(hmcmt_ctx* ctx) {
+    Solver& k = ctx->sv;
+    constexpr int NTW = FW_NTW;
+    const size_t lds = (size_t)3 * (k.NZP + 4 * FW_TB) * 16 * NTW * sizeof(c32) + (((size_t)k.NZP * sizeof(float) + 127) & ~(size_t)127);
+    if (ctx->fusedFwd && lds <= ctx->maxLds) {
+        const int G = (k.NZP + 7) / 8, per = (G + 7) / 8, nw = (G + per - 1) / per;
+        ProfScope ps(ctx, 1);
+        hipLaunchKernelGGL(k_fdm_fwd<NTW>, dim3((k.NYP / 16 + NTW - 1) / NTW, k.S), dim3(64 * nw), lds, ctx->stream, k, k.t32, ctx->d_Vb, ctx->d_Vbl,
+                           ctx->d_invp32, k.y32);
+        return 0;
+    }
+    int rc;
+    if ((rc = launch_transform_lp<0>(ctx, k.t32, false, k.y32, k.active))) return rc;
+    const dim3 tg((k.ny - 1 + 63) / 64, k.S);
+    { ProfScope ps(ctx, 1); hipLaunchKernelGGL(k_thomas32, tg, dim3(64), 0, ctx->stream, k); }
+    return 0;
+}
+
 // z = P^-1 r for the active systems and the partial sums of r'z, |z|^2 (partA / d_partZZ)
 int apply_precond(hmcmt_ctx* ctx) {
     Solver& k = ctx->sv;
@@ -1326,8 +1548,7 @@ int apply_precond(hmcmt_ctx* ctx) {
         // mixed precision: split-bf16 operands / fp32 accumulation in the transforms, complex64 tridiagonal
         if (smooth) { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_pre_c64, vg, vb, 0, ctx->stream, k); }
         else { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_to_c64, vg, vb, 0, ctx->stream, k, k.r); }
-        if ((rc = launch_transform_lp<0>(ctx, k.t32, false, k.y32, k.active))) return rc;
-        { ProfScope ps(ctx, 1); hipLaunchKernelGGL(k_thomas32, tg, dim3(64), 0, ctx->stream, k); }
+        if ((rc = launch_fdm_fwd(ctx))) return rc;
         if (smooth) {
             if ((rc = launch_transform_lp<2>(ctx, k.y32, true, k.z, k.active))) return rc;   // z = F t + dinv r
             { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
@@ -1395,8 +1616,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             rcur ^= 1;
             k.r = rb[rcur];
             int prc;
-            if ((prc = launch_transform_lp<0>(ctx, k.t32, false, k.y32, k.active))) return prc;
-            { ProfScope ps(ctx, 1); hipLaunchKernelGGL(k_thomas32, tg, dim3(64), 0, ctx->stream, k); }
+            if ((prc = launch_fdm_fwd(ctx))) return prc;
             if ((prc = launch_transform_lp<2>(ctx, k.y32, true, k.z, k.active))) return prc;   // z = F t + dinv r
             { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
             std::swap(k.z, k.t);
@@ -1644,6 +1864,13 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     HIPCHK(hipEventCreateWithFlags(&ctx->evModel, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evSens, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evExtF, hipEventDisableTiming));
+    {
+        const char* e = getenv("HMCMT_FUSED_FWD");
+        ctx->fusedFwd = !(e && e[0] == '0');
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<FW_NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
+            ctx->maxLds = 160 * 1024;
+        else (void)hipGetLastError();
+    }
     HIPCHK(hipEventCreateWithFlags(&ctx->evExtA, hipEventDisableTiming));
     const HostProblem& h = ctx->hp;
     View& v = ctx->v;
@@ -1977,6 +2204,57 @@ int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z) {
     apply_precond(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(z, ctx->sv.z, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// forward half of the mixed-precision FDM stage on a caller-supplied vector: out[0..n) = fused kernel,
+// out[n..2n) = separate transform + tridiagonal kernels (complex64 pairs widened to double), n = S*vstride
+int hmcmt_debug_fdm_fwd(hmcmt_ctx* ctx, const double* t, double* out) {
+    if (!ctx || !t || !out) return HMCMT_EINVAL;
+    if (!ctx->haveModel) { ctx->err = "no evaluation has been run yet"; return HMCMT_EINVAL; }
+    HIPCHK(hipSetDevice(ctx->device));
+    Solver& k = ctx->sv;
+    const size_t n = (size_t)ctx->v.S * ctx->v.vstride;
+    HIPCHK(hipMemcpy(k.r, t, n * sizeof(cplx), hipMemcpyHostToDevice));
+    int rc = set_all_active(ctx);
+    if (rc) return rc;
+    std::vector<float2> h(n);
+    if (getenv("HMCMT_FWD_STAMPS")) {
+        const int gx = (k.NYP / 16 + FW_NTW - 1) / FW_NTW, nb = gx * k.S;
+        long long* d_st = nullptr;
+        HIPCHK(hipMalloc((void**)&d_st, sizeof(long long) * 8 * nb));
+        HIPCHK(hipMemset(d_st, 0, sizeof(long long) * 8 * nb));
+        const size_t lds = (size_t)3 * (k.NZP + 4 * FW_TB) * 16 * FW_NTW * sizeof(c32) + (((size_t)k.NZP * sizeof(float) + 127) & ~(size_t)127);
+        const int G = (k.NZP + 7) / 8, per = (G + 7) / 8, nw = (G + per - 1) / per;
+        hipLaunchKernelGGL(k_to_c64, dim3(k.NB, k.S), dim3(VBLOCK), 0, ctx->stream, k, k.r);
+        for (int rep = 0; rep < 3; ++rep)
+            hipLaunchKernelGGL(k_fdm_fwd<FW_NTW>, dim3(gx, k.S), dim3(64 * nw), lds, ctx->stream, k, k.t32, ctx->d_Vb, ctx->d_Vbl,
+                               ctx->d_invp32, k.y32, d_st);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        std::vector<long long> st(8 * (size_t)nb);
+        HIPCHK(hipMemcpy(st.data(), d_st, sizeof(long long) * 8 * nb, hipMemcpyDeviceToHost));
+        hipFree(d_st);
+        double d[4] = {0, 0, 0, 0};
+        long long tmin = st[0], tmax = st[4];
+        for (int b = 0; b < nb; ++b) {
+            for (int i = 0; i < 4; ++i) d[i] += double(st[8 * b + i + 1] - st[8 * b + i]) / nb;
+            tmin = std::min(tmin, st[8 * b]); tmax = std::max(tmax, st[8 * b + 4]);
+        }
+        fprintf(stderr, "k_fdm_fwd stamps (s_memtime ticks, mean over %d blocks): transform %.0f premul %.0f chain %.0f write %.0f | first start -> last end %lld\n",
+                nb, d[0], d[1], d[2], d[3], tmax - tmin);
+    }
+    const bool keep = ctx->fusedFwd;
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(k_to_c64, dim3(k.NB, k.S), dim3(VBLOCK), 0, ctx->stream, k, k.r);
+        HIPCHK(hipMemsetAsync(k.y32, 0xff, n * sizeof(float2), ctx->stream));
+        ctx->fusedFwd = pass == 0;
+        rc = launch_fdm_fwd(ctx);
+        ctx->fusedFwd = keep;
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(h.data(), k.y32, n * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < n; ++i) { out[2 * (pass * n + i)] = h[i].x; out[2 * (pass * n + i) + 1] = h[i].y; }
+    }
     return 0;
 }
 

@@ -99,10 +99,12 @@ def load_library():
     lib.hmcmt_debug_transform.argtypes = [vp, C.c_int32, c_double_p, c_double_p]
     lib.hmcmt_debug_spmv.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_precond.argtypes = [vp, c_double_p, c_double_p]
+    lib.hmcmt_debug_fdm_fwd.argtypes = [vp, c_double_p, c_double_p]
     for name in ("hmcmt_create", "hmcmt_destroy", "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters",
                  "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_set_prior",
                  "hmcmt_leapfrog", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read",
-                 "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond"):
+                 "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond",
+                 "hmcmt_debug_fdm_fwd"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -112,7 +114,7 @@ EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "h
                     "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters", "hmcmt_grad", "hmcmt_forward",
                     "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_set_prior", "hmcmt_leapfrog",
                     "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_dims",
-                    "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond"]
+                    "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd"]
 
 
 def _dp(a):
@@ -260,6 +262,12 @@ class HipContext:
         if a.size != self.S * self.NZP * self.NYP:
             raise ValueError("vector must be in the padded nodal layout [S][NZP][NYP]")
         return a
+
+    def debug_fdm_fwd(self, T):
+        T = self._vec(T)
+        out = np.empty((2,) + T.shape, dtype=np.complex128)
+        self._check(self.lib.hmcmt_debug_fdm_fwd(self.h, _dp(T), _dp(out)))
+        return out[0], out[1]
 
     def debug_transform(self, which, A):
         A = self._vec(A)

@@ -149,6 +149,7 @@ int hmcmt_dims(const hmcmt_ctx* ctx, int32_t* out);
 int hmcmt_debug_transform(hmcmt_ctx* ctx, int32_t which, const double* A, double* C);
 int hmcmt_debug_spmv(hmcmt_ctx* ctx, const double* p, double* q);
 int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z);
+int hmcmt_debug_fdm_fwd(hmcmt_ctx* ctx, const double* t, double* out);   /* [2][S*vstride] complex: fused kernel | separate kernels */
 
 #ifdef __cplusplus
 }

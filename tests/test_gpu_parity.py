@@ -313,3 +313,23 @@ def test_initial_guess_modes_agree_and_extrapolation_saves_iterations():
         assert abs(out[mode][1] - out["cold"][1]) / out["cold"][1] < 1e-9
         assert relmax(out[mode][2], out["cold"][2]) < 1e-7
     assert its["extrapolate"] < its["previous"] < its["cold"]
+
+
+def test_fused_forward_fdm_kernel_matches_separate_kernels():
+    """k_fdm_fwd (eigen-transform + tridiagonal solves of a 16-mode slab in one kernel, slab in LDS) against
+    k_transform_lp<0> + k_thomas32 on the same input at the headline size: same arithmetic up to the
+    pre-multiplied recurrences, i.e. fp32 rounding.  Repeated: an earlier version of the kernel produced
+    sporadically (timing-dependent) wrong rows."""
+    mesh, data, inv, m = make_problem("cfg3")
+    ctx = HipContext(mesh, data, inv)
+    ctx.grad(m)
+    rng = np.random.default_rng(0)
+    shape = (ctx.S, ctx.NZP, ctx.NYP)
+    for _ in range(4):
+        T = np.zeros(shape, complex)
+        T[:, 1:ctx.nz, 1:ctx.ny] = (rng.standard_normal((ctx.S, ctx.nz - 1, ctx.ny - 1))
+                                    + 1j * rng.standard_normal((ctx.S, ctx.nz - 1, ctx.ny - 1)))
+        fused, sep = (a.reshape(shape) for a in ctx.debug_fdm_fwd(T))
+        scale = np.abs(sep).reshape(ctx.S, -1).max(1)[:, None, None]
+        assert np.isfinite(fused).all() and (np.abs(fused - sep) / scale).max() < 1e-4
+    ctx.close()
