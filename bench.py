@@ -189,7 +189,7 @@ def main():
     if not os.environ.get("HMCMT_BENCH_NOPROF"):
         # HIP events around the two heaviest kernel families, in every 6th step of the timed region
         # (bracketing every launch of every step costs ~20 % of the throughput)
-        ctx.profile(["fdm_transform", "tridiagonal", "spmv", "vector_ops"], every=6)
+        ctx.profile(["fdm_transform", "tridiagonal", "spmv", "vector_ops", "post_smoother"], every=6)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -219,17 +219,18 @@ def main():
     if rank == 0:
         # Algorithmic bytes per launch: U = S*(nz-1)*(ny-1) interior unknowns, complex128 = 16 B,
         # complex64 = 8 B; the real stencil coefficients are shared by all frequencies of a mode (not counted).
-        #   tridiagonal  k_thomas32       : read rhs (8) + inverse pivots (8), write solution (8)            = 24 U
-        #   transforms   k_transform_lp<0>: read t (8), write y (8) = 16 U;  <2>: read y (8), dinv (16), r (16),
-        #                write z (16) = 56 U                                              -> 36 U per launch on average
-        #   spmv         k_spmv_fused     : read z, p (32), write p, q (32) = 64 U;  k_post: read r, z, dinv (48),
-        #                write t (16) = 64 U                                              -> 64 U per launch
-        #   vector_ops   k_update_fused   : read p, q, r, x, dinv (80), write x, r (32), t as complex64 (8) = 120 U
+        # One preconditioned COCG iteration = these five launches:
+        #   k_fdm_fwd        forward eigen-transform + tridiagonal solves: read t (8) + inverse pivots (8), write y (8) = 24 U
+        #   k_transform_lp<2> back transform + first Jacobi half: read y (8), dinv (16), r (16), write z (16)        = 56 U
+        #   k_post           second Jacobi half + dots: read r, z, dinv (48), write t (16)                            = 64 U
+        #   k_spmv_fused     p = z + beta p, q = A p, p'q: read z, p (32), write p, q (32)                            = 64 U
+        #   k_update_fused   x, r updates + Jacobi pre-smoothing: read p, q, r, x, dinv (80), write x, r (32), t (8)  = 120 U
         nyi, nzi = ctx.ny - 1, ctx.nz - 1
         U = ctx.S * nzi * nyi
-        fams = {"k_thomas32 (batched complex64 tridiagonal solve of the FDM stage)": ("tridiagonal", 24.0 * U, 1),
-                "k_transform_lp<0>,<2> (split-bf16 MFMA eigen-transforms of the FDM stage)": ("fdm_transform", 36.0 * U, 2),
-                "k_spmv_fused, k_post (5-point stencil products fused with the p-update / Jacobi post-smoothing)": ("spmv", 64.0 * U, 2),
+        fams = {"k_fdm_fwd (split-bf16 MFMA eigen-transform + LDS-resident complex64 tridiagonal sweeps, one launch)": ("tridiagonal", 24.0 * U, 1),
+                "k_transform_lp<2> (split-bf16 MFMA back transform fused with the first Jacobi half)": ("fdm_transform", 56.0 * U, 1),
+                "k_post (second Jacobi half: 5-point stencil + dot products)": ("post_smoother", 64.0 * U, 1),
+                "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 64.0 * U, 1),
                 "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 120.0 * U, 1)}
         roofs = []
         it_bytes = it_us = 0.0
@@ -239,14 +240,22 @@ def main():
             ach = nbytes / (avg_us * 1e-6) / 1e9 if n_c else 0.0
             it_bytes += per_it * nbytes
             it_us += per_it * avg_us
-            roofs.append({"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(cat), "avg_launch_us": avg_us,
-                          "launches_timed": n_c, "launches_per_iteration": per_it, "bytes_per_launch": nbytes,
-                          "ms_timed": ms_c})
-        iteration = {"kernels": 6, "bytes": it_bytes, "us": it_us,
+            entry = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(cat), "avg_launch_us": avg_us,
+                     "launches_timed": n_c, "launches_per_iteration": per_it, "bytes_per_launch": nbytes,
+                     "ms_timed": ms_c}
+            if cat in ("tridiagonal", "fdm_transform") and n_c:
+                # the two MFMA kernels, for reference: three bf16 products (hi*hi, hi*lo, lo*hi) of a
+                # [2*S*NZP real rows] x [NYP] x [K = NYP padded to 32] real matrix product
+                kpad = 32 * ((ctx.NYP + 31) // 32)
+                flops = 3 * 2.0 * (2 * ctx.S * ctx.NZP) * ctx.NYP * kpad
+                entry["mfma"] = {"flops_per_launch": flops, "achieved_tflops": flops / (avg_us * 1e-6) / 1e12,
+                                 "peak_tflops_bf16_dense": 2500.0}
+            roofs.append(entry)
+        iteration = {"kernels": 5, "bytes": it_bytes, "us": it_us,
                      "achieved": it_bytes / (it_us * 1e-6) / 1e9 if it_us else 0.0, "unit": "GB/s",
                      "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS if it_us else 0.0,
-                     "note": "one preconditioned COCG iteration of all systems = 6 launches; the working set "
+                     "note": "one preconditioned COCG iteration of all systems = 5 launches; the working set "
                              "(~15 vectors) fits the 256 MB Infinity Cache at cfg3, so launches are latency- not HBM-bound"}
         roofs.sort(key=lambda r: -r["ms_timed"])
         out = {

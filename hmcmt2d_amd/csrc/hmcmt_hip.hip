@@ -724,11 +724,16 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
                                                  const u4v* __restrict__ Blo, const float2* __restrict__ ip32,
                                                  float2* __restrict__ Y, long long* stamps = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int s = blockIdx.y;
+    // 1-D grid of nslab*S workgroups.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has
+    // its own L2: all slabs of a system are placed on ONE XCD so that system's rows are fetched into one L2 once
+    const int nslab = ((k.NYP >> 4) + NTW - 1) / NTW;
+    int s, slab;
+    if ((k.S & 7) == 0) { const int q = blockIdx.x >> 3; s = (q / nslab) * 8 + (blockIdx.x & 7); slab = q % nslab; }
+    else { s = blockIdx.x / nslab; slab = blockIdx.x % nslab; }
     if (!k.active[s]) return;
     const int NYP = k.NYP, NZP = k.NZP, n = k.nz - 1;
     constexpr int SW = 16 * NTW;
-#define FW_STAMP(i) if (stamps && threadIdx.x == 0) stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#define FW_STAMP(i) if (stamps && threadIdx.x == 0) stamps[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();
     FW_STAMP(0)
     // sof first (padded to a multiple of 128 B), then the three slabs
     float* sof = reinterpret_cast<float*>(smem);
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int NT = NYP >> 4, KG = (NYP + 31) >> 5;
-    const int t0 = blockIdx.x * NTW;                   // first column tile of this slab
+    const int t0 = slab * NTW;                         // first column tile of this slab
     const int lj = lane & 15, g = lane >> 4, part = lj & 1;
     const long so = (long)s * k.vstride;
     const float2* As = A + so;
@@ -1521,7 +1526,7 @@ int launch_fdm_fwd(hmcmt_ctx* ctx) {
     if (ctx->fusedFwd && lds <= ctx->maxLds) {
         const int G = (k.NZP + 7) / 8, per = (G + 7) / 8, nw = (G + per - 1) / per;
         ProfScope ps(ctx, 1);
-        hipLaunchKernelGGL(k_fdm_fwd<NTW>, dim3((k.NYP / 16 + NTW - 1) / NTW, k.S), dim3(64 * nw), lds, ctx->stream, k, k.t32, ctx->d_Vb, ctx->d_Vbl,
+        hipLaunchKernelGGL(k_fdm_fwd<NTW>, dim3(((k.NYP / 16 + NTW - 1) / NTW) * k.S), dim3(64 * nw), lds, ctx->stream, k, k.t32, ctx->d_Vb, ctx->d_Vbl,
                            ctx->d_invp32, k.y32);
         return 0;
     }
@@ -1551,7 +1556,7 @@ int apply_precond(hmcmt_ctx* ctx) {
         if ((rc = launch_fdm_fwd(ctx))) return rc;
         if (smooth) {
             if ((rc = launch_transform_lp<2>(ctx, k.y32, true, k.z, k.active))) return rc;   // z = F t + dinv r
-            { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+            { ProfScope ps(ctx, 7); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
             std::swap(k.z, k.t);
         } else {
             if ((rc = launch_transform_lp<1>(ctx, k.y32, true, k.z, k.active))) return rc;
@@ -1566,7 +1571,7 @@ int apply_precond(hmcmt_ctx* ctx) {
     if ((rc = launch_transform(ctx, k.y, ctx->d_Vt, k.z, k.active))) return rc;
     if (smooth) {
         { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_mid, vg, vb, 0, ctx->stream, k); }
-        { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+        { ProfScope ps(ctx, 7); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
         std::swap(k.z, k.t);                            // the smoothed result is the preconditioned residual
     } else {
         ProfScope ps(ctx, 3);
@@ -1618,7 +1623,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             int prc;
             if ((prc = launch_fdm_fwd(ctx))) return prc;
             if ((prc = launch_transform_lp<2>(ctx, k.y32, true, k.z, k.active))) return prc;   // z = F t + dinv r
-            { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+            { ProfScope ps(ctx, 7); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
             std::swap(k.z, k.t);
         }
         if (!done) {
@@ -2228,7 +2233,7 @@ int hmcmt_debug_fdm_fwd(hmcmt_ctx* ctx, const double* t, double* out) {
         const int G = (k.NZP + 7) / 8, per = (G + 7) / 8, nw = (G + per - 1) / per;
         hipLaunchKernelGGL(k_to_c64, dim3(k.NB, k.S), dim3(VBLOCK), 0, ctx->stream, k, k.r);
         for (int rep = 0; rep < 3; ++rep)
-            hipLaunchKernelGGL(k_fdm_fwd<FW_NTW>, dim3(gx, k.S), dim3(64 * nw), lds, ctx->stream, k, k.t32, ctx->d_Vb, ctx->d_Vbl,
+            hipLaunchKernelGGL(k_fdm_fwd<FW_NTW>, dim3(gx * k.S), dim3(64 * nw), lds, ctx->stream, k, k.t32, ctx->d_Vb, ctx->d_Vbl,
                                ctx->d_invp32, k.y32, d_st);
         HIPCHK(hipStreamSynchronize(ctx->stream));
         std::vector<long long> st(8 * (size_t)nb);

@@ -19,8 +19,9 @@ SOURCES = [os.path.join(CSRC, "hmcmt_hip.hip")]
 HEADERS = [os.path.join(CSRC, h) for h in ("hmcmt_math.h", "hmcmt_items.h", "hmcmt_host.h")] + \
           [os.path.join(HERE, "..", "include", "hmcmt.h")]
 
-HMCMT_NCAT = 7
-CATEGORIES = ["fdm_transform", "tridiagonal", "spmv", "vector_ops", "assembly_bc", "receivers", "gradient"]
+HMCMT_NCAT = 8
+CATEGORIES = ["fdm_transform", "tridiagonal", "spmv", "vector_ops", "assembly_bc", "receivers", "gradient",
+              "post_smoother"]
 PRECOND = {"jacobi": 0, "fdm": 1, "fdmj": 2}
 # initial guess of both solves: cold start, the previous evaluation's fields, or those extrapolated along the model path
 def _warm_start_code(v):

@@ -133,7 +133,7 @@ int hmcmt_get_fields(hmcmt_ctx* ctx, int32_t adjoint, double* exTE, double* hxTM
 /* Kernel-time accounting with HIP events on the context's stream.
  * categories: 0 fdm-transform (MFMA), 1 tridiagonal, 2 stencil SpMV, 3 vector ops,
  *             4 assembly+boundary, 5 receivers+sources, 6 gradient accumulation */
-#define HMCMT_NCAT 7
+#define HMCMT_NCAT 8
 int hmcmt_profile(hmcmt_ctx* ctx, int32_t category_mask);     /* bit c enables category c; 0 = off; resets the counters */
 int hmcmt_profile_every(hmcmt_ctx* ctx, int32_t n);           /* time only every n-th evaluation (event brackets cost ~20 % when always on) */
 int hmcmt_profile_read(hmcmt_ctx* ctx, double* ms /*[HMCMT_NCAT]*/, int64_t* launches /*[HMCMT_NCAT]*/);

@@ -16,8 +16,8 @@ import os
 import sys
 from collections import defaultdict
 
-CATS = {"fdm_transform": ("k_transform_lp",), "tridiagonal": ("k_thomas32",),
-        "spmv": ("k_spmv_fused", "k_post"), "vector_ops": ("k_update_fused",)}
+CATS = {"fdm_transform": ("k_transform_lp",), "tridiagonal": ("k_fdm_fwd", "k_thomas32"),
+        "spmv": ("k_spmv_fused",), "post_smoother": ("k_post",), "vector_ops": ("k_update_fused",)}
 
 
 def per_kernel(d, counter):
