@@ -697,8 +697,11 @@ __global__ __launch_bounds__(512) void k_transform_lp(const float2* __restrict__
     const int base = NT / NW, extra = NT % NW;
     const int ntl = base + (nw < extra ? 1 : 0);
     const int t0 = nw * base + min(nw, extra);
-    if (ntl == 2) transform_lp_body<2, OUT>(A, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0, lane);
-    else if (ntl == 1) transform_lp_body<1, OUT>(A, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0, lane);
+    // two column tiles at a time (a wave owns more than two only on meshes wider than 256 nodes)
+    for (int tt = 0; tt < ntl; tt += 2) {
+        if (ntl - tt >= 2) transform_lp_body<2, OUT>(A, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0 + tt, lane);
+        else transform_lp_body<1, OUT>(A, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0 + tt, lane);
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1406,6 +1409,7 @@ struct hmcmt_ctx {
     double* d_mHist[2] = {nullptr, nullptr};     // [2][nAC] model history per solve kind
     double* d_ext[2] = {nullptr, nullptr};       // {alpha, keep, count}
     bool fusedFwd = true;                    // forward transform + tridiagonal solve in one kernel (HMCMT_FUSED_FWD=0: separate)
+    bool fusedFwdForce = false;              // HMCMT_FUSED_FWD=2: also where the heuristic prefers the separate kernels
     size_t maxLds = 64 * 1024;               // dynamic LDS the fused kernels may request
     bool lpFallback = false;                 // this solve has switched its stragglers to the fp64 preconditioner
     // profiling
@@ -1505,12 +1509,8 @@ int launch_transform_lp(hmcmt_ctx* ctx, const float2* A, bool transposed, void* 
     const int M = v.S * v.NZP, NT = v.NYP / 16;
     const int groups = (M + 7) / 8;
     // waves of LP_NTW column tiles; a workgroup holds all NW waves of RG row groups (<= 8 waves)
-    int NW = (NT + LP_NTW - 1) / LP_NTW, RG = 1;
-    if (NW > 8) {                                       // very wide meshes: split the columns over several launches' worth
-        ctx->err = "mesh too wide for the mixed-precision transform (ny+1 > 256): use fdm_precision = fp64";
-        return HMCMT_EINVAL;
-    }
-    RG = std::max(1, 8 / NW);
+    const int NW = std::min(8, (NT + LP_NTW - 1) / LP_NTW);      // wider meshes: a wave loops over its tiles
+    const int RG = std::max(1, 8 / NW);
     ProfScope ps(ctx, 0);
     hipLaunchKernelGGL((k_transform_lp<OUT>), dim3((groups + RG - 1) / RG), dim3(64 * NW * RG), 0, ctx->stream, A,
                        transposed ? ctx->d_Vtb : ctx->d_Vb, transposed ? ctx->d_Vtbl : ctx->d_Vbl, C,
@@ -1521,13 +1521,26 @@ int launch_transform_lp(hmcmt_ctx* ctx, const float2* A, bool transposed, void* 
 // forward half of the mixed-precision FDM stage: y32 = tridiag^-1 (t32 V); fused kernel when its LDS slabs fit
 int launch_fdm_fwd(hmcmt_ctx* ctx) {
     Solver& k = ctx->sv;
-    constexpr int NTW = FW_NTW;
-    const size_t lds = (size_t)3 * (k.NZP + 4 * FW_TB) * 16 * NTW * sizeof(c32) + (((size_t)k.NZP * sizeof(float) + 127) & ~(size_t)127);
-    if (ctx->fusedFwd && lds <= ctx->maxLds) {
+    auto ldsFor = [&](int ntw) {
+        return (size_t)3 * (k.NZP + 4 * FW_TB) * 16 * ntw * sizeof(c32) + (((size_t)k.NZP * sizeof(float) + 127) & ~(size_t)127);
+    };
+    // The fused kernel pays off while every slab workgroup of a launch is resident at once and re-reading a
+    // system's rows per slab is cheap: 32-mode slabs that fit LDS on meshes up to 256 nodes wide (measured:
+    // 21 vs 29 us at 200x100 cells; at 400x200 the separate kernels win, 146 vs 219 us).  HMCMT_FUSED_FWD=2
+    // forces it (16-mode slabs if need be), =0 disables it.
+    int ntw = 0;
+    if (ctx->fusedFwd) {
+        if (ldsFor(FW_NTW) <= ctx->maxLds && (k.NYP <= 256 || ctx->fusedFwdForce)) ntw = FW_NTW;
+        else if (ctx->fusedFwdForce && ldsFor(1) <= ctx->maxLds) ntw = 1;
+    }
+    if (ntw) {
         const int G = (k.NZP + 7) / 8, per = (G + 7) / 8, nw = (G + per - 1) / per;
+        const dim3 grid(((k.NYP / 16 + ntw - 1) / ntw) * k.S), block(64 * nw);
         ProfScope ps(ctx, 1);
-        hipLaunchKernelGGL(k_fdm_fwd<NTW>, dim3(((k.NYP / 16 + NTW - 1) / NTW) * k.S), dim3(64 * nw), lds, ctx->stream, k, k.t32, ctx->d_Vb, ctx->d_Vbl,
-                           ctx->d_invp32, k.y32);
+        if (ntw == 1)
+            hipLaunchKernelGGL(k_fdm_fwd<1>, grid, block, ldsFor(1), ctx->stream, k, k.t32, ctx->d_Vb, ctx->d_Vbl, ctx->d_invp32, k.y32, (long long*)nullptr);
+        else
+            hipLaunchKernelGGL(k_fdm_fwd<FW_NTW>, grid, block, ldsFor(FW_NTW), ctx->stream, k, k.t32, ctx->d_Vb, ctx->d_Vbl, ctx->d_invp32, k.y32, (long long*)nullptr);
         return 0;
     }
     int rc;
@@ -1872,7 +1885,9 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     {
         const char* e = getenv("HMCMT_FUSED_FWD");
         ctx->fusedFwd = !(e && e[0] == '0');
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<FW_NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
+        ctx->fusedFwdForce = e && e[0] == '2';
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<FW_NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
             ctx->maxLds = 160 * 1024;
         else (void)hipGetLastError();
     }
