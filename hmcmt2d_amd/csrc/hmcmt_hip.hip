@@ -1226,23 +1226,23 @@ __global__ void k_coef(View v, int te_doK, int te_doM, int tm_doK, int tm_doM) {
     if (tm_doK || tm_doM) item_coef(v, 1, iy, iz, tm_doK, tm_doM);
 }
 __global__ void k_fdm_z(View v) { int e = TID1; if (e < 2 * v.NZP) item_fdm_z(v, e / v.NZP, e % v.NZP); }
-__global__ void k_pivot(View v) {
+__global__ __launch_bounds__(64) void k_pivot(View v) {
     int j = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
     if (j < v.ny - 1) item_pivot(v, s, j);
 }
-__global__ void k_bc_layers(View v) {
+__global__ __launch_bounds__(64) void k_bc_layers(View v) {
     int col = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, s = blockIdx.z;
     if (col <= v.ny) item_bc_layers(v, s, j, col);
 }
-__global__ void k_bc_forward(View v) {
+__global__ __launch_bounds__(64) void k_bc_forward(View v) {
     int col = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
     if (col <= v.ny) item_bc_forward(v, s, col);
 }
-__global__ void k_sens_layers(View v) {
+__global__ __launch_bounds__(64) void k_sens_layers(View v) {
     int j = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
     if (j <= v.nz) item_sens_layers(v, s, prof, j);
 }
-__global__ void k_sens_profile(View v) {
+__global__ __launch_bounds__(64) void k_sens_profile(View v) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < 3 * v.S) item_sens_profile(v, e / 3, e % 3);
 }
@@ -1274,7 +1274,7 @@ __global__ void k_wb(View v) {
     if (e < v.nz) item_wside(v, s, e + 1);
     else if (e < v.nz + v.ny) item_colw(v, s, e - v.nz);
 }
-__global__ void k_bcsens(View v) {
+__global__ __launch_bounds__(64) void k_bcsens(View v) {
     int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
     if (c < v.nz) item_bcsens(v, s, prof, c);
 }
@@ -1282,7 +1282,7 @@ __global__ void k_gradcell(View v) {
     int c = blockIdx.x * blockDim.x + threadIdx.x, mode = blockIdx.y;
     if (c < v.nCell) item_gradcell(v, mode, c);
 }
-__global__ void k_qterm(View v) {
+__global__ __launch_bounds__(64) void k_qterm(View v) {
     int ky = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
     if (ky < v.ny) item_qterm(v, s, ky);
 }

@@ -124,8 +124,11 @@ constexpr int RB = 4;
 HD cplx bc1d_forward_tab(double omega, int nz, const cplx* T, long qs, long ls, bool compH, cplx* out, long ostride) {
     const double omu0 = omega * MU0;
     const cplx one = cplx{1.0, 0.0};
-    // impedance recurrence bottom -> top (:48-56); half-space has the last layer's conductivity
-    cplx ztmp = omu0 * T[qs + (long)(nz - 1) * ls];
+    // impedance recurrence bottom -> top (:48-56); half-space has the last layer's conductivity.
+    // Z_j = zp (Z + zp th) / (zp + Z th) is a Moebius map: it is carried projectively, Z = N/D, so the serial
+    // chain has no division (a robust complex division is ~3 dependent fp64 divides); N and D are rescaled
+    // by an exact power of two once per block, and divided once at the top.
+    cplx zn = omu0 * T[qs + (long)(nz - 1) * ls], zd = one;
     for (int j0 = nz - 1; j0 >= 0; j0 -= RB) {
         cplx ki[RB], th[RB];
 #pragma unroll
@@ -137,15 +140,24 @@ HD cplx bc1d_forward_tab(double omega, int nz, const cplx* T, long qs, long ls, 
         for (int t = 0; t < RB; ++t) {
             if (j0 - t >= 0) {
                 const cplx zp = omu0 * ki[t];
-                ztmp = zp * (ztmp + zp * th[t]) / (zp + ztmp * th[t]);
+                const cplx nn = zp * (zn + (zp * th[t]) * zd);
+                zd = zp * zd + zn * th[t];
+                zn = nn;
             }
         }
+        const int e = -ilogb(fmax(fmax(fabs(zd.re), fabs(zd.im)), fmax(fabs(zn.re), fabs(zn.im))));
+        if (e > -1000 && e < 1000) {                     // (zero / inf / nan: leave alone, the division below reports it)
+            zn = cplx{ldexp(zn.re, e), ldexp(zn.im, e)};
+            zd = cplx{ldexp(zd.re, e), ldexp(zd.im, e)};
+        }
     }
+    const cplx ztmp = zn / zd;
     // top-layer up/down-going amplitudes (:62-63)
     cplx kj = T[0];
     const cplx a = omu0 / (ztmp * kj);
     cplx eu = 0.5 * (one - a), ed = 0.5 * (one + a);
-    const cplx f0 = compH ? ((ed - eu) * kj) / omu0 : (eu + ed);
+    const double iomu0 = 1.0 / omu0;
+    const cplx f0 = compH ? ((ed - eu) * kj) * iomu0 : (eu + ed);
     const cplx if0 = crecip(f0);
     cplx last = one;
     bool dead = false;
@@ -175,7 +187,7 @@ HD cplx bc1d_forward_tab(double omega, int nz, const cplx* T, long qs, long ls, 
                         dead = true;                     // overflow cut-off: zero from here down
                     } else {
                         eu = nu; ed = nd; kj = kn;
-                        fn = compH ? ((ed - eu) * kj) / omu0 : (eu + ed);
+                        fn = compH ? ((ed - eu) * kj) * iomu0 : (eu + ed);
                     }
                 }
                 last = fn * if0;
