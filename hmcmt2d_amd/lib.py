@@ -15,9 +15,9 @@ from .marshal import CreateArgs, CREATE_ARGTYPES, c_double_p, c_int64_p
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "libhmcmt_hip.so")
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = [os.path.join(CSRC, "hmcmt_hip.hip")]
+SOURCES = [os.path.join(CSRC, "hmcmt_hip.hip"), os.path.join(CSRC, "mumps_shim.hip")]
 HEADERS = [os.path.join(CSRC, h) for h in ("hmcmt_math.h", "hmcmt_items.h", "hmcmt_host.h")] + \
-          [os.path.join(HERE, "..", "include", "hmcmt.h")]
+          [os.path.join(HERE, "..", "include", "hmcmt.h"), os.path.join(HERE, "..", "include", "hmcmt_mumps.h")]
 
 HMCMT_NCAT = 8
 CATEGORIES = ["fdm_transform", "tridiagonal", "spmv", "vector_ops", "assembly_bc", "receivers", "gradient",

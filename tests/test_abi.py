@@ -15,10 +15,10 @@ def so():
     return ctypes.CDLL(L.build_library())
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "hmcmt.h")).read()
+def declared_functions(header="hmcmt.h", pattern=r"\b(hmcmt_[a-z_]+)\s*\("):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(hmcmt_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(pattern, text)))
 
 
 def test_header_symbols_are_exported(so):
@@ -27,6 +27,17 @@ def test_header_symbols_are_exported(so):
     for n in names:
         assert hasattr(so, n), f"{n} declared in include/hmcmt.h but not exported"
     assert set(names) == set(L.EXPORTED_SYMBOLS)
+
+
+def test_mumps_interface_symbols_are_exported(so):
+    """include/hmcmt_mumps.h: the eight Fortran-convention symbols MUMPS/src/MUMPSfuncs.jl binds (:32,49,105,115,
+    128,139,155,170) plus the statistics call."""
+    names = declared_functions("hmcmt_mumps.h", r"\b([a-z_]+mumps[a-z_]*)\s*\(")
+    assert set(names) == {"factor_mumps_cmplx_", "factor_mumps_", "solve_mumps_cmplx_", "solve_mumps_",
+                          "solve_mumps_cmplx_sparse_rhs_", "solve_mumps_sparse_rhs_", "destroy_mumps_cmplx_",
+                          "destroy_mumps_", "hmcmt_mumps_last_solve"}
+    for n in names:
+        assert hasattr(so, n), f"{n} declared in include/hmcmt_mumps.h but not exported"
 
 
 def test_default_options(so):
