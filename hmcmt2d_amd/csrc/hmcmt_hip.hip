@@ -41,7 +41,8 @@ struct Solver {
     cplx *x, *r, *p, *q, *z, *y, *t;      // [S][vstride]
     cplx *dinv;                           // [S][vstride] omegaJ / diag(A) on interior nodes, 0 elsewhere
     // mixed-precision FDM stage (options.fdm_precision == 0): bf16 transform operands, fp32 tridiagonal
-    float2* t32;                          // [S][vstride] complex64 transform input
+    float2* t32;                          // [S][vstride] complex64 transform input (or its pre-split bf16 form, see store_t32)
+    int splitT;                           // 1: t32 / y32 hold bf16 hi/lo planes instead of complex64
     float2* y32;                          // [S][vstride] complex64
     const float2* invp32;                 // [S][vstride]
     cplx *p2, *r2;                        // second buffers of p and r for the fused kernels
@@ -610,7 +611,7 @@ __device__ __forceinline__ float bf16_to_f32(unsigned h) { return __uint_as_floa
 // accuracy from the bf16 pipe.  (Plain bf16 operands stalled one low-frequency TE system in 32.)
 // B: Bhi/Blo fragment arrays.  OUT: 0 = complex64, 1 = fp64 complex, 2 = fp64 complex + dinv*r (fused
 // first half of the post-smoother).
-template <int NTW, int OUT>
+template <int NTW, int OUT, int FMT>     // FMT 0: A is complex64 (split here); 1: A is pre-split (store_t32)
 __device__ __forceinline__ void transform_lp_body(const float2* __restrict__ Ain, const u4v* __restrict__ Bhi,
                                                   const u4v* __restrict__ Blo, void* __restrict__ Cout,
                                                   const cplx* __restrict__ dinv, const cplx* __restrict__ rvec,
@@ -623,14 +624,21 @@ __device__ __forceinline__ void transform_lp_body(const float2* __restrict__ Ain
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[t] = f4v{0, 0, 0, 0};
     for (int kc = 0; kc < KG; kc += KCH) {
-        f4v a[KCH][4];
+        f4v a[FMT ? 1 : KCH][4];
+        u4v ahs[FMT ? KCH : 1], als[FMT ? KCH : 1];
         u4v bh[KCH][NTW], bl[KCH][NTW];
 #pragma unroll
         for (int q = 0; q < KCH; ++q) {
             const int kg = min(kc + q, KG - 1);
-            const f4v* ap = reinterpret_cast<const f4v*>(Ain + (long)arow * NYP + 32 * kg + 8 * g);   // 8 complex = 64 B
+            if (FMT) {
+                const u4v* hp = reinterpret_cast<const u4v*>(reinterpret_cast<const unsigned short*>(Ain) +
+                                                             (long)arow * 4 * NYP + part * NYP + 32 * kg + 8 * g);
+                ahs[q] = hp[0]; als[q] = hp[NYP / 4];            // the lo planes start 2*NYP bf16 = NYP/4 x 16 B later
+            } else {
+                const f4v* ap = reinterpret_cast<const f4v*>(Ain + (long)arow * NYP + 32 * kg + 8 * g);   // 8 complex = 64 B
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[q][i] = ap[i];
+                for (int i = 0; i < 4; ++i) a[q][i] = ap[i];
+            }
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
                 const long bi = ((long)kg * NT + t0 + t) * 64 + lane;
@@ -640,17 +648,21 @@ __device__ __forceinline__ void transform_lp_body(const float2* __restrict__ Ain
 #pragma unroll
         for (int q = 0; q < KCH; ++q) {
             if (kc + q < KG) {
-                // this lane's part (re or im) of its 8 complex values, split into bf16 hi/lo
-                unsigned hh[8], ll[8];
+                u4v ahu, alu;
+                if (FMT) { ahu = ahs[q]; alu = als[q]; }
+                else {
+                    // this lane's part (re or im) of its 8 complex values, split into bf16 hi/lo
+                    unsigned hh[8], ll[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float x0 = part ? a[q][i][1] : a[q][i][0], x1 = part ? a[q][i][3] : a[q][i][2];
-                    hh[2 * i] = bf16_rn(x0); ll[2 * i] = bf16_rn(x0 - bf16_to_f32(hh[2 * i]));
-                    hh[2 * i + 1] = bf16_rn(x1); ll[2 * i + 1] = bf16_rn(x1 - bf16_to_f32(hh[2 * i + 1]));
+                    for (int i = 0; i < 4; ++i) {
+                        const float x0 = part ? a[q][i][1] : a[q][i][0], x1 = part ? a[q][i][3] : a[q][i][2];
+                        hh[2 * i] = bf16_rn(x0); ll[2 * i] = bf16_rn(x0 - bf16_to_f32(hh[2 * i]));
+                        hh[2 * i + 1] = bf16_rn(x1); ll[2 * i + 1] = bf16_rn(x1 - bf16_to_f32(hh[2 * i + 1]));
+                    }
+                    ahu = u4v{hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16)};
+                    alu = u4v{ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16)};
                 }
                 // v_mfma_f32_16x16x32_bf16: A[i = lane%16][k = 8*(lane/16) + t], t = 0..7 -- exactly this lane's 8 values
-                const u4v ahu = u4v{hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16)};
-                const u4v alu = u4v{ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16)};
                 const bf8v ah = __builtin_bit_cast(bf8v, ahu), al = __builtin_bit_cast(bf8v, alu);
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) {
@@ -680,7 +692,7 @@ __device__ __forceinline__ void transform_lp_body(const float2* __restrict__ Ain
     }
 }
 
-template <int OUT>
+template <int OUT, int FMT>
 __global__ __launch_bounds__(512) void k_transform_lp(const float2* __restrict__ A, const u4v* __restrict__ Bhi,
                                                        const u4v* __restrict__ Blo, void* __restrict__ C,
                                                        const cplx* __restrict__ dinv, const cplx* __restrict__ rvec,
@@ -699,9 +711,23 @@ __global__ __launch_bounds__(512) void k_transform_lp(const float2* __restrict__
     const int t0 = nw * base + min(nw, extra);
     // two column tiles at a time (a wave owns more than two only on meshes wider than 256 nodes)
     for (int tt = 0; tt < ntl; tt += 2) {
-        if (ntl - tt >= 2) transform_lp_body<2, OUT>(A, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0 + tt, lane);
-        else transform_lp_body<1, OUT>(A, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0 + tt, lane);
+        if (ntl - tt >= 2) transform_lp_body<2, OUT, FMT>(A, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0 + tt, lane);
+        else transform_lp_body<1, OUT, FMT>(A, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0 + tt, lane);
     }
+}
+
+// ---- pre-split transform operands (fused forward path).  The bf16 hi/lo split of a transform input is the
+// same for every workgroup that reads the row (7 slab workgroups in k_fdm_fwd, 7 waves in k_transform_lp), so
+// the producing kernel does it once: a row of NYP complex64 values (8 B each) is stored instead as four
+// planes of NYP bf16 -- hi(re), hi(im), lo(re), lo(im) -- in the same 8 NYP bytes.  A lane's MFMA A-operand
+// (8 consecutive k of one part) is then one 16-byte load per hi / lo, with no conversion work.
+__device__ __forceinline__ void store_t32(const Solver& k, float2* tsys, int row, int iy, float re, float im) {
+    if (!k.splitT) { tsys[(long)row * k.NYP + iy] = float2{re, im}; return; }
+    unsigned short* b = reinterpret_cast<unsigned short*>(tsys) + (long)row * 4 * k.NYP + iy;
+    const unsigned hr = bf16_rn(re), hi = bf16_rn(im);
+    b[0] = (unsigned short)hr; b[k.NYP] = (unsigned short)hi;
+    b[2 * k.NYP] = (unsigned short)bf16_rn(re - bf16_to_f32(hr));
+    b[3 * k.NYP] = (unsigned short)bf16_rn(im - bf16_to_f32(hi));
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -770,14 +796,14 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
 #pragma unroll
         for (int t = 0; t < NTW; ++t) acc[t] = f4v{0, 0, 0, 0};
         for (int kc = 0; kc < KG; kc += KCH) {
-            f4v a[KCH][4];
+            u4v ahs[KCH], als[KCH];                    // pre-split input (store_t32): one 16-byte load per hi / lo
             u4v bh[KCH][NTW], bl[KCH][NTW];
 #pragma unroll
             for (int q = 0; q < KCH; ++q) {
                 const int kg = min(kc + q, KG - 1);
-                const f4v* ap = reinterpret_cast<const f4v*>(As + (long)arow * NYP + 32 * kg + 8 * g);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[q][i] = ap[i];
+                const u4v* hp = reinterpret_cast<const u4v*>(reinterpret_cast<const unsigned short*>(As) +
+                                                             (long)arow * 4 * NYP + part * NYP + 32 * kg + 8 * g);
+                ahs[q] = hp[0]; als[q] = hp[NYP / 4];
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) {
                     const long bi = ((long)kg * NT + min(t0 + t, NT - 1)) * 64 + lane;
@@ -787,16 +813,7 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
 #pragma unroll
             for (int q = 0; q < KCH; ++q) {
                 if (kc + q < KG) {
-                    unsigned hh[8], ll[8];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float x0 = part ? a[q][i][1] : a[q][i][0], x1 = part ? a[q][i][3] : a[q][i][2];
-                        hh[2 * i] = bf16_rn(x0); ll[2 * i] = bf16_rn(x0 - bf16_to_f32(hh[2 * i]));
-                        hh[2 * i + 1] = bf16_rn(x1); ll[2 * i + 1] = bf16_rn(x1 - bf16_to_f32(hh[2 * i + 1]));
-                    }
-                    const u4v ahu = u4v{hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16)};
-                    const u4v alu = u4v{ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16)};
-                    const bf8v ah = __builtin_bit_cast(bf8v, ahu), al = __builtin_bit_cast(bf8v, alu);
+                    const bf8v ah = __builtin_bit_cast(bf8v, ahs[q]), al = __builtin_bit_cast(bf8v, als[q]);
 #pragma unroll
                     for (int t = 0; t < NTW; ++t) {
                         const bf8v bhf = __builtin_bit_cast(bf8v, bh[q][t]), blf = __builtin_bit_cast(bf8v, bl[q][t]);
@@ -895,9 +912,20 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
     // solved slab -> Y (rows of SW complex64)
     for (int idx = threadIdx.x; idx < NZP * SW; idx += blockDim.x) {
         const int row = idx / SW, c = t0 * 16 + (idx % SW);
-        if (c < NYP) { const c32 v = sa[idx]; Y[so + (long)row * NYP + c] = float2{v.re, v.im}; }
+        if (c < NYP) { const c32 v = sa[idx]; store_t32(k, Y + so, row, c, v.re, v.im); }   // pre-split for k_transform_lp<2>
     }
     FW_STAMP(4)
+}
+
+// pre-split planes -> complex64 (hi + lo), tests only
+__global__ void k_unsplit(Solver k, const float2* __restrict__ src, float2* __restrict__ dst) {
+    const long n = (long)k.S * k.vstride;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / k.NYP;
+        const int iy = (int)(e - row * k.NYP);
+        const unsigned short* b = reinterpret_cast<const unsigned short*>(src) + row * 4 * k.NYP + iy;
+        dst[e] = float2{bf16_to_f32(b[0]) + bf16_to_f32(b[2 * k.NYP]), bf16_to_f32(b[k.NYP]) + bf16_to_f32(b[3 * k.NYP])};
+    }
 }
 
 // complex64 copy of a vector (plain FDM: the transform input is r itself)
@@ -906,7 +934,10 @@ __global__ __launch_bounds__(VBLOCK) void k_to_c64(Solver k, const cplx* src) {
     if (!k.active[s]) return;
     const long so = (long)s * k.vstride;
     const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) k.t32[so + e] = float2{(float)src[so + e].re, (float)src[so + e].im};
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        store_t32(k, k.t32 + so, iz, iy, (float)src[so + e].re, (float)src[so + e].im);
+    }
 }
 
 // t = r - A (dinv .* r), written as complex64 for the mixed-precision transform
@@ -932,7 +963,7 @@ __global__ __launch_bounds__(VBLOCK) void k_pre_c64(Solver k) {
             acc += k.cZ[mo + e - k.NYP] * (di[e - k.NYP] * r[e - k.NYP]);
             out = r[e] - acc;
         }
-        t[e] = float2{(float)out.re, (float)out.im};
+        store_t32(k, t, iz, iy, (float)out.re, (float)out.im);
     }
 }
 
@@ -1075,7 +1106,7 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const cplx* p
             acc += k.cZ[mo + e - NYP] * cs[l - NYP];
             out = rs[i] - acc;
         }
-        t[e] = float2{(float)out.re, (float)out.im};
+        store_t32(k, t, iz0 + lr, iy, (float)out.re, (float)out.im);
     }
     block_sum2(xx, dummy, sh);
     if (threadIdx.x == 0) {
@@ -1512,27 +1543,38 @@ int launch_transform_lp(hmcmt_ctx* ctx, const float2* A, bool transposed, void* 
     const int NW = std::min(8, (NT + LP_NTW - 1) / LP_NTW);      // wider meshes: a wave loops over its tiles
     const int RG = std::max(1, 8 / NW);
     ProfScope ps(ctx, 0);
-    hipLaunchKernelGGL((k_transform_lp<OUT>), dim3((groups + RG - 1) / RG), dim3(64 * NW * RG), 0, ctx->stream, A,
-                       transposed ? ctx->d_Vtb : ctx->d_Vb, transposed ? ctx->d_Vtbl : ctx->d_Vbl, C,
-                       ctx->sv.dinv, ctx->sv.r, M, v.NYP, v.NZP, active, NW, RG);
+    const dim3 grid((groups + RG - 1) / RG), block(64 * NW * RG);
+    const u4v *bh = transposed ? ctx->d_Vtb : ctx->d_Vb, *bl = transposed ? ctx->d_Vtbl : ctx->d_Vbl;
+    if (ctx->sv.splitT)        // the input was written pre-split (store_t32 / k_fdm_fwd)
+        hipLaunchKernelGGL((k_transform_lp<OUT, 1>), grid, block, 0, ctx->stream, A, bh, bl, C, ctx->sv.dinv, ctx->sv.r, M, v.NYP,
+                           v.NZP, active, NW, RG);
+    else
+        hipLaunchKernelGGL((k_transform_lp<OUT, 0>), grid, block, 0, ctx->stream, A, bh, bl, C, ctx->sv.dinv, ctx->sv.r, M, v.NYP,
+                           v.NZP, active, NW, RG);
     return 0;
 }
 
 // forward half of the mixed-precision FDM stage: y32 = tridiag^-1 (t32 V); fused kernel when its LDS slabs fit
-int launch_fdm_fwd(hmcmt_ctx* ctx) {
-    Solver& k = ctx->sv;
-    auto ldsFor = [&](int ntw) {
-        return (size_t)3 * (k.NZP + 4 * FW_TB) * 16 * ntw * sizeof(c32) + (((size_t)k.NZP * sizeof(float) + 127) & ~(size_t)127);
-    };
+// slab width (in 16-mode tiles) of the fused forward kernel for this problem, 0 = use the separate kernels
+size_t fdm_fwd_lds(const Solver& k, int ntw) {
+    return (size_t)3 * (k.NZP + 4 * FW_TB) * 16 * ntw * sizeof(c32) + (((size_t)k.NZP * sizeof(float) + 127) & ~(size_t)127);
+}
+int fdm_fwd_ntw(const hmcmt_ctx* ctx) {
+    const Solver& k = ctx->sv;
     // The fused kernel pays off while every slab workgroup of a launch is resident at once and re-reading a
     // system's rows per slab is cheap: 32-mode slabs that fit LDS on meshes up to 256 nodes wide (measured:
     // 21 vs 29 us at 200x100 cells; at 400x200 the separate kernels win, 146 vs 219 us).  HMCMT_FUSED_FWD=2
     // forces it (16-mode slabs if need be), =0 disables it.
-    int ntw = 0;
-    if (ctx->fusedFwd) {
-        if (ldsFor(FW_NTW) <= ctx->maxLds && (k.NYP <= 256 || ctx->fusedFwdForce)) ntw = FW_NTW;
-        else if (ctx->fusedFwdForce && ldsFor(1) <= ctx->maxLds) ntw = 1;
-    }
+    if (!ctx->fusedFwd) return 0;
+    if (fdm_fwd_lds(k, FW_NTW) <= ctx->maxLds && (k.NYP <= 256 || ctx->fusedFwdForce)) return FW_NTW;
+    if (ctx->fusedFwdForce && fdm_fwd_lds(k, 1) <= ctx->maxLds) return 1;
+    return 0;
+}
+
+int launch_fdm_fwd(hmcmt_ctx* ctx) {
+    Solver& k = ctx->sv;
+    auto ldsFor = [&](int ntw) { return fdm_fwd_lds(k, ntw); };
+    const int ntw = k.splitT ? fdm_fwd_ntw(ctx) : 0;       // (k.splitT is set from fdm_fwd_ntw: the operand format goes with the path)
     if (ntw) {
         const int G = (k.NZP + 7) / 8, per = (G + 7) / 8, nw = (G + per - 1) / per;
         const dim3 grid(((k.NYP / 16 + ntw - 1) / ntw) * k.S), block(64 * nw);
@@ -2024,6 +2066,7 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
         hmcmt_destroy(ctx);
         return rc;
     }
+    ctx->sv.splitT = fdm_fwd_ntw(ctx) > 0;
     *out = ctx;
     return 0;
 }
@@ -2264,14 +2307,22 @@ int hmcmt_debug_fdm_fwd(hmcmt_ctx* ctx, const double* t, double* out) {
                 nb, d[0], d[1], d[2], d[3], tmax - tmin);
     }
     const bool keep = ctx->fusedFwd;
+    const int keepSplit = k.splitT;
     for (int pass = 0; pass < 2; ++pass) {
+        ctx->fusedFwd = pass == 0;
+        k.splitT = pass == 0 && fdm_fwd_ntw(ctx) > 0;      // the operand format goes with the path
         hipLaunchKernelGGL(k_to_c64, dim3(k.NB, k.S), dim3(VBLOCK), 0, ctx->stream, k, k.r);
         HIPCHK(hipMemsetAsync(k.y32, 0xff, n * sizeof(float2), ctx->stream));
-        ctx->fusedFwd = pass == 0;
         rc = launch_fdm_fwd(ctx);
+        const float2* res = k.y32;
+        if (!rc && k.splitT) {                              // pre-split result -> complex64 (hi + lo), into t32
+            hipLaunchKernelGGL(k_unsplit, dim3(512), dim3(256), 0, ctx->stream, k, k.y32, k.t32);
+            res = k.t32;
+        }
         ctx->fusedFwd = keep;
+        k.splitT = keepSplit;
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(h.data(), k.y32, n * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(h.data(), res, n * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         for (size_t i = 0; i < n; ++i) { out[2 * (pass * n + i)] = h[i].x; out[2 * (pass * n + i) + 1] = h[i].y; }
     }
