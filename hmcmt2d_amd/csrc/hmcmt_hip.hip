@@ -1157,48 +1157,76 @@ __global__ void k_solve_end(Solver k, int kind, int* __restrict__ recI, double* 
 }
 
 // ---- initial guess extrapolated along the model path (options.warm_start == 2) ----
-// The fields are smooth functions of the model, and a leapfrog trajectory moves the model along an
-// almost straight line, so x(m_new) ~ x_k + alpha (x_k - x_{k-1}) with alpha the projection of
-// m_new - m_k on m_k - m_{k-1}.  State per solve kind, all on the device (no host round trip):
-// hist[0..nAC) = m_k, hist[nAC..2nAC) = m_{k-1}, ext = {alpha, keep, count}.  A repeated model
-// (getHamiltonian after the last leapfrog step) keeps the history untouched.
+// The fields are smooth functions of the model, and a leapfrog trajectory moves the model along an almost
+// straight line at almost constant speed.  With the last three models on that line at "times"
+// tau = -1-gamma, -1, 0 (unit = the last step; gamma, alpha = projections of the previous / the new step on
+// the last one) the guess is the Lagrange extrapolation of the last three fields to tau = alpha:
+//     x0 = w2 x_k + w1 x_{k-1} + w0 x_{k-2}      (uniform steps: 3, -3, 1)
+// when the three steps are nearly collinear, else the linear one  x0 = x_k + alpha (x_k - x_{k-1})
+// (e.g. across a momentum refresh).  State per solve kind, all on the device (no host round trip):
+// hist = [m_k | m_{k-1} | m_{k-2}], ext = {w0, w1, w2, keep, count}.  A repeated model (getHamiltonian after
+// the last leapfrog step) keeps the history untouched.
 __global__ __launch_bounds__(1024) void k_extrap_alpha(const double* __restrict__ mNew, double* hist, int nAC, double* ext) {
-    __shared__ double sh[4][16];
-    double a = 0, b = 0, c = 0, n = 0;
+    __shared__ double sh[6][16];
+    double a[6] = {0, 0, 0, 0, 0, 0};       // <d0,d0> <d0,d1> <d1,d1> <d1,d2> <d2,d2> <mk,mk>
     for (int i = threadIdx.x; i < nAC; i += 1024) {
-        const double mk = hist[i], d1 = mk - hist[nAC + i], d0 = mNew[i] - mk;
-        a += d0 * d1; b += d1 * d1; c += d0 * d0; n += mk * mk;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        a += __shfl_down(a, o); b += __shfl_down(b, o); c += __shfl_down(c, o); n += __shfl_down(n, o);
+        const double mk = hist[i], mk1 = hist[nAC + i], mk2 = hist[2 * nAC + i];
+        const double d0 = mNew[i] - mk, d1 = mk - mk1, d2 = mk1 - mk2;
+        a[0] += d0 * d0; a[1] += d0 * d1; a[2] += d1 * d1; a[3] += d1 * d2; a[4] += d2 * d2; a[5] += mk * mk;
     }
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { sh[0][w] = a; sh[1][w] = b; sh[2][w] = c; sh[3][w] = n; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        for (int o = 32; o > 0; o >>= 1) a[q] += __shfl_down(a[q], o);
+        if ((threadIdx.x & 63) == 0) sh[q][w] = a[q];
+    }
     __syncthreads();
-    a = b = c = n = 0;
-    for (int j = 0; j < 16; ++j) { a += sh[0][j]; b += sh[1][j]; c += sh[2][j]; n += sh[3][j]; }
-    const int count = (int)ext[2];
-    const bool keep = count >= 1 && c <= 1e-28 * n;
-    double alpha = 0;
-    if (!keep && count >= 2 && b > 0) alpha = fmin(2.0, fmax(-1.0, a / b));
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        a[q] = 0;
+        for (int j = 0; j < 16; ++j) a[q] += sh[q][j];
+    }
+    const int count = (int)ext[4];
+    const bool keep = count >= 1 && a[0] <= 1e-28 * a[5];
+    double w0 = 0, w1 = 0, w2 = 1;
+    if (!keep && count >= 2 && a[2] > 0) {
+        const double alpha = fmin(2.0, fmax(-1.0, a[1] / a[2]));
+        w2 = 1.0 + alpha; w1 = -alpha;
+        if (count >= 3 && a[4] > 0) {
+            const double gamma = a[3] / a[2];
+            const double c01 = a[1] / sqrt(a[0] * a[2]), c12 = a[3] / sqrt(a[2] * a[4]);
+            if (c01 > 0.95 && c12 > 0.95 && gamma > 0.5 && gamma < 2.0 && alpha > 0.5 && alpha < 2.0) {
+                w0 = alpha * (alpha + 1.0) / (gamma * (1.0 + gamma));
+                w1 = -alpha * (alpha + 1.0 + gamma) / gamma;
+                w2 = (alpha + 1.0 + gamma) * (alpha + 1.0) / (1.0 + gamma);
+            }
+        }
+    }
     __syncthreads();
     if (!keep)
-        for (int i = threadIdx.x; i < nAC; i += 1024) { hist[nAC + i] = hist[i]; hist[i] = mNew[i]; }
-    if (threadIdx.x == 0) { ext[0] = alpha; ext[1] = keep ? 1.0 : 0.0; if (!keep) ext[2] = (double)min(count + 1, 2); }
+        for (int i = threadIdx.x; i < nAC; i += 1024) {
+            hist[2 * nAC + i] = hist[nAC + i]; hist[nAC + i] = hist[i]; hist[i] = mNew[i];
+        }
+    if (threadIdx.x == 0) {
+        ext[0] = w0; ext[1] = w1; ext[2] = w2; ext[3] = keep ? 1.0 : 0.0;
+        if (!keep) ext[4] = (double)min(count + 1, 3);
+    }
 }
 
-// x <- x + alpha (x - xprev), xprev <- old x, on interior nodes (runs beside k_bc_forward, which writes X's boundary nodes)
-__global__ __launch_bounds__(VBLOCK) void k_extrap(Solver k, cplx* x, cplx* xprev, const double* __restrict__ ext) {
-    if (ext[1] != 0.0) return;
-    const double alpha = ext[0];
+// x <- w2 x + w1 xp1 + w0 xp2, history shifted (xp2 <- xp1 <- old x), on interior nodes (runs beside k_bc_forward,
+// which writes X's boundary nodes)
+__global__ __launch_bounds__(VBLOCK) void k_extrap(Solver k, cplx* x, cplx* xp1, cplx* xp2, const double* __restrict__ ext) {
+    if (ext[3] != 0.0) return;
+    const double w0 = ext[0], w1 = ext[1], w2 = ext[2];
     const long so = (long)blockIdx.y * k.vstride;
     const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
     for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
         const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
         if (iz < 1 || iz > k.nz - 1 || iy < 1 || iy > k.ny - 1) continue;
-        const cplx t = x[so + e], q = xprev[so + e];
-        xprev[so + e] = t;
-        x[so + e] = t + alpha * (t - q);
+        const cplx t = x[so + e], q1 = xp1[so + e], q2 = xp2[so + e];
+        xp2[so + e] = q1;
+        xp1[so + e] = t;
+        x[so + e] = w2 * t + w1 * q1 + w0 * q2;
     }
 }
 
@@ -1436,9 +1464,9 @@ struct hmcmt_ctx {
     int lastItFwd = 0, lastItAdj = 0;
     bool haveModel = false;
     bool haveFwd = false, haveAdj = false;   // previous fields usable as initial guesses
-    cplx* d_prevField[2] = {nullptr, nullptr};   // previous solutions (warm_start == 2), per solve kind
-    double* d_mHist[2] = {nullptr, nullptr};     // [2][nAC] model history per solve kind
-    double* d_ext[2] = {nullptr, nullptr};       // {alpha, keep, count}
+    cplx* d_prevField[2] = {nullptr, nullptr};   // the two previous solutions (warm_start == 2), per solve kind: [2][S*vstride]
+    double* d_mHist[2] = {nullptr, nullptr};     // [3][nAC] model history per solve kind
+    double* d_ext[2] = {nullptr, nullptr};       // {w0, w1, w2, keep, count}
     bool fusedFwd = true;                    // forward transform + tridiagonal solve in one kernel (HMCMT_FUSED_FWD=0: separate)
     bool fusedFwdForce = false;              // HMCMT_FUSED_FWD=2: also where the heuristic prefers the separate kernels
     size_t maxLds = 64 * 1024;               // dynamic LDS the fused kernels may request
@@ -1765,11 +1793,11 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         // initial guesses: zero on a cold start, otherwise the previous fields, optionally extrapolated
         if (!warmF) {
             HIPCHK(hipMemsetAsync(v.X, 0, vecBytes, st));
-            HIPCHK(hipMemsetAsync(ctx->d_ext[0], 0, 4 * sizeof(double), st));
+            HIPCHK(hipMemsetAsync(ctx->d_ext[0], 0, 8 * sizeof(double), st));
         }
         if (wantGrad && !warmA) {
             HIPCHK(hipMemsetAsync(v.Lam, 0, vecBytes, st));
-            HIPCHK(hipMemsetAsync(ctx->d_ext[1], 0, 4 * sizeof(double), st));
+            HIPCHK(hipMemsetAsync(ctx->d_ext[1], 0, 8 * sizeof(double), st));
         }
         // side stream, beside the coefficient / boundary-value kernels and the forward solve: the extrapolation of
         // both initial guesses (interior nodes only -- k_bc_forward owns the boundary nodes of X) and the
@@ -1780,11 +1808,11 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         }
         if (extrap) {
             hipLaunchKernelGGL(k_extrap_alpha, dim3(1), dim3(1024), 0, ctx->side, d_m, ctx->d_mHist[0], v.nAC, ctx->d_ext[0]);
-            hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
+            hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_prevField[0] + vecBytes / sizeof(cplx), ctx->d_ext[0]);
             HIPCHK(hipEventRecord(ctx->evExtF, ctx->side));
             if (wantGrad) {
                 hipLaunchKernelGGL(k_extrap_alpha, dim3(1), dim3(1024), 0, ctx->side, d_m, ctx->d_mHist[1], v.nAC, ctx->d_ext[1]);
-                hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.Lam, ctx->d_prevField[1], ctx->d_ext[1]);
+                hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.Lam, ctx->d_prevField[1], ctx->d_prevField[1] + vecBytes / sizeof(cplx), ctx->d_ext[1]);
                 HIPCHK(hipEventRecord(ctx->evExtA, ctx->side));
             }
         }
@@ -2007,7 +2035,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     DA(v.sensDz1, S * 3 * (size_t)h.nz) DA(v.sensZ1, S * 3) DA(v.sensDead, S * 3)
     DA(v.qPart, S * h.ny) DA(v.gPart, 2 * (size_t)h.nCell) DA(v.grad, h.nAC)
     DA(ctx->d_m, h.nAC) DA(ctx->d_misfit, 1)
-    for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], S * VS) DA(ctx->d_mHist[kd], 2 * (size_t)h.nAC) DA(ctx->d_ext[kd], 4) }
+    for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], 2 * S * VS) DA(ctx->d_mHist[kd], 3 * (size_t)h.nAC) DA(ctx->d_ext[kd], 8) }
     Solver& k = ctx->sv;
     k.S = h.S; k.NYP = h.NYP; k.NZP = h.NZP; k.ny = h.ny; k.nz = h.nz; k.nFreq = h.nFreq; k.vstride = v.vstride;
     k.NB = std::max(1, std::min(MAXNB, (1024 + h.S - 1) / h.S));

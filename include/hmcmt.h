@@ -59,7 +59,8 @@ typedef struct hmcmt_options {
     int32_t check_every;  /* host convergence poll interval in iterations; default 2 */
     int32_t verify;       /* 1: also compute true relative residuals ||b-Ax||/||b|| after each solve */
     int32_t warm_start;   /* initial guess of both solves: 0 zero, 1 the previous evaluation's fields, 2 (default) those
-                             fields extrapolated linearly along the model path (leapfrog trajectories are nearly straight) */
+                             fields extrapolated along the model path from the last two or three evaluations (leapfrog
+                             trajectories are nearly straight lines at nearly constant speed) */
     int32_t fdm_precision;/* 0 (default): bf16 transforms (fp32 accumulate) + complex64 tridiagonal inside the
                              preconditioner; 1: fp64 throughout.  x, r, p and all inner products are fp64 either way */
 } hmcmt_options;
