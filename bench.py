@@ -213,8 +213,27 @@ def main():
         ctx.forward_device(d_m[k].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr())
 
     samples = None
+    structured = None
     if rank == 0 and not args.no_sampler:
         samples = sampler_leg(step, forward, K, W, Ltraj)
+        # Secondary, untimed-region figure: the same trajectories laid around the TRUE model (2 layers + a 10x
+        # conductive block) instead of the homogeneous reference model of SURVEY 8(d).  Lateral structure is what
+        # the laterally averaged FDM background cannot see, so this state needs 2-3x the iterations; it is the
+        # regime a converged chain samples in.
+        nst = min(K + W, 24)
+        d_ms = torch.from_numpy(traj[:nst] - m0 + m_true).to(dev)
+        for k in range(min(8, nst)):
+            ctx.grad_device(d_ms[k].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr(), d_grad.data_ptr())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(8, nst):
+            ctx.grad_device(d_ms[k].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr(), d_grad.data_ptr())
+        torch.cuda.synchronize()
+        sst = ctx.stats()
+        if nst > 8:
+            structured = {"steps_per_s": (nst - 8) / (time.perf_counter() - t1), "steps": nst - 8,
+                          "iters_fwd_max": sst["iters_fwd_max"], "iters_adj_max": sst["iters_adj_max"],
+                          "state": "true model (100 over 10 ohm-m + 10 ohm-m block) + the same dt*j*p trajectories"}
 
     if rank == 0:
         # Algorithmic bytes per launch: U = S*(nz-1)*(ny-1) interior unknowns, complex128 = 16 B,
@@ -271,7 +290,7 @@ def main():
                        "iters_fwd_max": st["iters_fwd_max"], "iters_adj_max": st["iters_adj_max"],
                        "parallelism": f"chains x{world}" if world > 1 else "1 chain"},
             "roofline": roofs[0], "roofline_other": roofs[1:], "roofline_iteration": iteration,
-            "samples": samples,
+            "samples": samples, "structured_state": structured,
             "check": {"misfit_last": misfit, "grad_l2_last": gnorm, "solver_status": st["status"]},
         }
         if cpu is not None:

@@ -1164,69 +1164,82 @@ __global__ void k_solve_end(Solver k, int kind, int* __restrict__ recI, double* 
 //     x0 = w2 x_k + w1 x_{k-1} + w0 x_{k-2}      (uniform steps: 3, -3, 1)
 // when the three steps are nearly collinear, else the linear one  x0 = x_k + alpha (x_k - x_{k-1})
 // (e.g. across a momentum refresh).  State per solve kind, all on the device (no host round trip):
-// hist = [m_k | m_{k-1} | m_{k-2}], ext = {w0, w1, w2, keep, count}.  A repeated model (getHamiltonian after
+// hist = [m_k | m_{k-1} | m_{k-2} | m_{k-3}], ext = {w_k, w_{k-1}, w_{k-2}, w_{k-3}, keep, count}; with four
+// collinear steps the cubic through the last four fields is used.  A repeated model (getHamiltonian after
 // the last leapfrog step) keeps the history untouched.
-__global__ __launch_bounds__(1024) void k_extrap_alpha(const double* __restrict__ mNew, double* hist, int nAC, double* ext) {
-    __shared__ double sh[6][16];
-    double a[6] = {0, 0, 0, 0, 0, 0};       // <d0,d0> <d0,d1> <d1,d1> <d1,d2> <d2,d2> <mk,mk>
+constexpr int EXT_NP = 4;          // fields kept per solve kind: the current one + 3 earlier ones
+
+__global__ __launch_bounds__(1024) void k_extrap_alpha(const double* __restrict__ mNew, double* hist, int nAC, double* ext, int maxNp) {
+    // steps d0 = m_new - m_k, d_j = m_{k-j+1} - m_{k-j}; sums <d_j,d1> and <d_j,d_j> (j = 0..3), <m_k,m_k>
+    __shared__ double sh[9][16];
+    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = threadIdx.x; i < nAC; i += 1024) {
-        const double mk = hist[i], mk1 = hist[nAC + i], mk2 = hist[2 * nAC + i];
-        const double d0 = mNew[i] - mk, d1 = mk - mk1, d2 = mk1 - mk2;
-        a[0] += d0 * d0; a[1] += d0 * d1; a[2] += d1 * d1; a[3] += d1 * d2; a[4] += d2 * d2; a[5] += mk * mk;
+        const double mk = hist[i], mk1 = hist[nAC + i], mk2 = hist[2 * nAC + i], mk3 = hist[3 * nAC + i];
+        const double d0 = mNew[i] - mk, d1 = mk - mk1, d2 = mk1 - mk2, d3 = mk2 - mk3;
+        a[0] += d0 * d1; a[1] += d1 * d1; a[2] += d2 * d1; a[3] += d3 * d1;
+        a[4] += d0 * d0; a[5] += d2 * d2; a[6] += d3 * d3; a[7] += mk * mk;
     }
     const int w = threadIdx.x >> 6;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
+    for (int q = 0; q < 8; ++q) {
         for (int o = 32; o > 0; o >>= 1) a[q] += __shfl_down(a[q], o);
         if ((threadIdx.x & 63) == 0) sh[q][w] = a[q];
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
+    for (int q = 0; q < 8; ++q) {
         a[q] = 0;
         for (int j = 0; j < 16; ++j) a[q] += sh[q][j];
     }
-    const int count = (int)ext[4];
-    const bool keep = count >= 1 && a[0] <= 1e-28 * a[5];
-    double w0 = 0, w1 = 0, w2 = 1;
-    if (!keep && count >= 2 && a[2] > 0) {
-        const double alpha = fmin(2.0, fmax(-1.0, a[1] / a[2]));
-        w2 = 1.0 + alpha; w1 = -alpha;
-        if (count >= 3 && a[4] > 0) {
-            const double gamma = a[3] / a[2];
-            const double c01 = a[1] / sqrt(a[0] * a[2]), c12 = a[3] / sqrt(a[2] * a[4]);
-            if (c01 > 0.95 && c12 > 0.95 && gamma > 0.5 && gamma < 2.0 && alpha > 0.5 && alpha < 2.0) {
-                w0 = alpha * (alpha + 1.0) / (gamma * (1.0 + gamma));
-                w1 = -alpha * (alpha + 1.0 + gamma) / gamma;
-                w2 = (alpha + 1.0 + gamma) * (alpha + 1.0) / (1.0 + gamma);
+    const int count = (int)ext[5];
+    const bool keep = count >= 1 && a[4] <= 1e-28 * a[7];
+    double wts[EXT_NP] = {1, 0, 0, 0};                       // weights of x_k, x_{k-1}, x_{k-2}, x_{k-3}
+    if (!keep && count >= 2 && a[1] > 0) {
+        const double alpha = fmin(2.0, fmax(-1.0, a[0] / a[1]));
+        wts[0] = 1.0 + alpha; wts[1] = -alpha;
+        // "times" of the models on the line through the last step: 0, -1, -1-g2, -1-g2-g3
+        const double g2 = a[2] / a[1], g3 = a[3] / a[1];
+        const bool c0 = a[4] > 0 && a[0] / sqrt(a[4] * a[1]) > 0.95 && alpha > 0.5 && alpha < 2.0;
+        const bool c2 = count >= 3 && a[5] > 0 && a[2] / sqrt(a[5] * a[1]) > 0.95 && g2 > 0.5 && g2 < 2.0;
+        const bool c3 = count >= 4 && a[6] > 0 && a[3] / sqrt(a[6] * a[1]) > 0.95 && g3 > 0.5 && g3 < 2.0;
+        const int np = min(maxNp, (c0 && c2) ? (c3 ? 4 : 3) : 2);
+        if (np > 2) {
+            const double tau[4] = {0.0, -1.0, -1.0 - g2, -1.0 - g2 - g3};
+            for (int i = 0; i < EXT_NP; ++i) {
+                double l = i < np ? 1.0 : 0.0;
+                for (int j = 0; j < np; ++j)
+                    if (j != i && i < np) l *= (alpha - tau[j]) / (tau[i] - tau[j]);
+                wts[i] = l;
             }
         }
     }
     __syncthreads();
     if (!keep)
         for (int i = threadIdx.x; i < nAC; i += 1024) {
-            hist[2 * nAC + i] = hist[nAC + i]; hist[nAC + i] = hist[i]; hist[i] = mNew[i];
+            hist[3 * nAC + i] = hist[2 * nAC + i]; hist[2 * nAC + i] = hist[nAC + i]; hist[nAC + i] = hist[i]; hist[i] = mNew[i];
         }
     if (threadIdx.x == 0) {
-        ext[0] = w0; ext[1] = w1; ext[2] = w2; ext[3] = keep ? 1.0 : 0.0;
-        if (!keep) ext[4] = (double)min(count + 1, 3);
+        for (int i = 0; i < EXT_NP; ++i) ext[i] = wts[i];
+        ext[4] = keep ? 1.0 : 0.0;
+        if (!keep) ext[5] = (double)min(count + 1, EXT_NP);
     }
 }
 
-// x <- w2 x + w1 xp1 + w0 xp2, history shifted (xp2 <- xp1 <- old x), on interior nodes (runs beside k_bc_forward,
-// which writes X's boundary nodes)
-__global__ __launch_bounds__(VBLOCK) void k_extrap(Solver k, cplx* x, cplx* xp1, cplx* xp2, const double* __restrict__ ext) {
-    if (ext[3] != 0.0) return;
-    const double w0 = ext[0], w1 = ext[1], w2 = ext[2];
-    const long so = (long)blockIdx.y * k.vstride;
+// x <- sum_j w_j x_{k-j}, history shifted (xp3 <- xp2 <- xp1 <- old x), on interior nodes (runs beside
+// k_bc_forward, which writes X's boundary nodes); xp = [3][S*vstride]
+__global__ __launch_bounds__(VBLOCK) void k_extrap(Solver k, cplx* x, cplx* xp, const double* __restrict__ ext) {
+    if (ext[4] != 0.0) return;
+    const double w0 = ext[0], w1 = ext[1], w2 = ext[2], w3 = ext[3];
+    const long so = (long)blockIdx.y * k.vstride, hs = (long)k.S * k.vstride;
     const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
     for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
         const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
         if (iz < 1 || iz > k.nz - 1 || iy < 1 || iy > k.ny - 1) continue;
-        const cplx t = x[so + e], q1 = xp1[so + e], q2 = xp2[so + e];
-        xp2[so + e] = q1;
-        xp1[so + e] = t;
-        x[so + e] = w2 * t + w1 * q1 + w0 * q2;
+        const cplx t = x[so + e], q1 = xp[so + e], q2 = xp[hs + so + e], q3 = xp[2 * hs + so + e];
+        xp[2 * hs + so + e] = q2;
+        xp[hs + so + e] = q1;
+        xp[so + e] = t;
+        x[so + e] = w0 * t + w1 * q1 + w2 * q2 + w3 * q3;
     }
 }
 
@@ -1467,6 +1480,7 @@ struct hmcmt_ctx {
     cplx* d_prevField[2] = {nullptr, nullptr};   // the two previous solutions (warm_start == 2), per solve kind: [2][S*vstride]
     double* d_mHist[2] = {nullptr, nullptr};     // [3][nAC] model history per solve kind
     double* d_ext[2] = {nullptr, nullptr};       // {w0, w1, w2, keep, count}
+    int extrapNp = 4;                        // fields used by the initial-guess extrapolation (HMCMT_EXTRAP_POINTS = 2..4)
     bool fusedFwd = true;                    // forward transform + tridiagonal solve in one kernel (HMCMT_FUSED_FWD=0: separate)
     bool fusedFwdForce = false;              // HMCMT_FUSED_FWD=2: also where the heuristic prefers the separate kernels
     size_t maxLds = 64 * 1024;               // dynamic LDS the fused kernels may request
@@ -1807,12 +1821,12 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evModel, 0));
         }
         if (extrap) {
-            hipLaunchKernelGGL(k_extrap_alpha, dim3(1), dim3(1024), 0, ctx->side, d_m, ctx->d_mHist[0], v.nAC, ctx->d_ext[0]);
-            hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_prevField[0] + vecBytes / sizeof(cplx), ctx->d_ext[0]);
+            hipLaunchKernelGGL(k_extrap_alpha, dim3(1), dim3(1024), 0, ctx->side, d_m, ctx->d_mHist[0], v.nAC, ctx->d_ext[0], ctx->extrapNp);
+            hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
             HIPCHK(hipEventRecord(ctx->evExtF, ctx->side));
             if (wantGrad) {
-                hipLaunchKernelGGL(k_extrap_alpha, dim3(1), dim3(1024), 0, ctx->side, d_m, ctx->d_mHist[1], v.nAC, ctx->d_ext[1]);
-                hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.Lam, ctx->d_prevField[1], ctx->d_prevField[1] + vecBytes / sizeof(cplx), ctx->d_ext[1]);
+                hipLaunchKernelGGL(k_extrap_alpha, dim3(1), dim3(1024), 0, ctx->side, d_m, ctx->d_mHist[1], v.nAC, ctx->d_ext[1], ctx->extrapNp);
+                hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.Lam, ctx->d_prevField[1], ctx->d_ext[1]);
                 HIPCHK(hipEventRecord(ctx->evExtA, ctx->side));
             }
         }
@@ -1956,6 +1970,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         const char* e = getenv("HMCMT_FUSED_FWD");
         ctx->fusedFwd = !(e && e[0] == '0');
         ctx->fusedFwdForce = e && e[0] == '2';
+        if (const char* ep = getenv("HMCMT_EXTRAP_POINTS")) ctx->extrapNp = std::max(2, std::min(EXT_NP, atoi(ep)));
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<FW_NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
             ctx->maxLds = 160 * 1024;
@@ -2035,7 +2050,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     DA(v.sensDz1, S * 3 * (size_t)h.nz) DA(v.sensZ1, S * 3) DA(v.sensDead, S * 3)
     DA(v.qPart, S * h.ny) DA(v.gPart, 2 * (size_t)h.nCell) DA(v.grad, h.nAC)
     DA(ctx->d_m, h.nAC) DA(ctx->d_misfit, 1)
-    for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], 2 * S * VS) DA(ctx->d_mHist[kd], 3 * (size_t)h.nAC) DA(ctx->d_ext[kd], 8) }
+    for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], 3 * S * VS) DA(ctx->d_mHist[kd], 4 * (size_t)h.nAC) DA(ctx->d_ext[kd], 8) }
     Solver& k = ctx->sv;
     k.S = h.S; k.NYP = h.NYP; k.NZP = h.NZP; k.ny = h.ny; k.nz = h.nz; k.nFreq = h.nFreq; k.vstride = v.vstride;
     k.NB = std::max(1, std::min(MAXNB, (1024 + h.S - 1) / h.S));
