@@ -214,7 +214,7 @@ def main():
 
     samples = None
     structured = None
-    if rank == 0 and not args.no_sampler:
+    if world == 1 and not args.no_sampler:            # (single-GPU runs only: keeps the ranks of an N-GPU run symmetric)
         samples = sampler_leg(step, forward, K, W, Ltraj)
         # Secondary, untimed-region figure: the same trajectories laid around the TRUE model (2 layers + a 10x
         # conductive block) instead of the homogeneous reference model of SURVEY 8(d).  Lateral structure is what
