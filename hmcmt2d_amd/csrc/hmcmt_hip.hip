@@ -1813,13 +1813,23 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             HIPCHK(hipMemsetAsync(v.Lam, 0, vecBytes, st));
             HIPCHK(hipMemsetAsync(ctx->d_ext[1], 0, 8 * sizeof(double), st));
         }
+        if (extrap || wantGrad) HIPCHK(hipEventRecord(ctx->evModel, st));
+        hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, st, v, 0, 1, 1, 0);
+        hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, st, v);
+        if (ctx->opt.precond != HMCMT_PRECOND_JACOBI) {
+            hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 0, st, v);
+            if (ctx->opt.fdm_precision == 0) hipLaunchKernelGGL(k_invp32, dim3(512), dim3(256), 0, st, ctx->sv, ctx->d_invp32);
+        }
+        if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI)
+            hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, 0.7);
+        hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, S), dim3(64), 0, st, v);
+        hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, S), dim3(64), 0, st, v);
+        // (issued by the host AFTER the main stream's coefficient / boundary-value kernels, so the main queue never
+        // runs dry while the host is busy with these launches)
         // side stream, beside the coefficient / boundary-value kernels and the forward solve: the extrapolation of
         // both initial guesses (interior nodes only -- k_bc_forward owns the boundary nodes of X) and the
         // sigma-only sensitivity tables (joined before k_bcsens)
-        if (extrap || wantGrad) {
-            HIPCHK(hipEventRecord(ctx->evModel, st));
-            HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evModel, 0));
-        }
+        if (extrap || wantGrad) HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evModel, 0));
         if (extrap) {
             hipLaunchKernelGGL(k_extrap_alpha, dim3(1), dim3(1024), 0, ctx->side, d_m, ctx->d_mHist[0], v.nAC, ctx->d_ext[0], ctx->extrapNp);
             hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
@@ -1835,16 +1845,6 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             hipLaunchKernelGGL(k_sens_profile, dim3((3 * S + 63) / 64), dim3(64), 0, ctx->side, v);
             HIPCHK(hipEventRecord(ctx->evSens, ctx->side));
         }
-        hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, st, v, 0, 1, 1, 0);
-        hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, st, v);
-        if (ctx->opt.precond != HMCMT_PRECOND_JACOBI) {
-            hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 0, st, v);
-            if (ctx->opt.fdm_precision == 0) hipLaunchKernelGGL(k_invp32, dim3(512), dim3(256), 0, st, ctx->sv, ctx->d_invp32);
-        }
-        if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI)
-            hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, 0.7);
-        hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, S), dim3(64), 0, st, v);
-        hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, S), dim3(64), 0, st, v);
         if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtF, 0));
         // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X
         hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, 1);

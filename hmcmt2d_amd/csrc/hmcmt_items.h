@@ -419,6 +419,7 @@ HD void item_gradcell(const View& v, int mode, int cell) {
     const int ky = cell % v.ny, kz = cell / v.ny;
     const double area = v.yLen[ky] * v.zLen[kz];
     double acc = 0.0;
+#pragma unroll 4
     for (int f = 0; f < v.nFreq; ++f) {
         const int s = mode * v.nFreq + f;
         if (!v.sysOn[s]) continue;
@@ -471,13 +472,14 @@ HD void item_gradfinal(const View& v, int a) {
     const int cell = v.act[a];
     const int ky = cell % v.ny, kz = cell / v.ny;
     double g = v.gPart[cell] + v.gPart[(long)v.nCell + cell];
+    // branch-free over the systems (select, not `continue`) so that the loads of several systems are in flight
+#pragma unroll 8
     for (int s = 0; s < v.S; ++s) {
-        if (!v.sysOn[s]) continue;
         const long o = (long)s * v.nz + kz;
         cplx b = v.gMn[o] * v.colw[(long)s * v.ny + ky];
         if (ky == 0) b += v.gL[o];
         if (ky == v.ny - 1) b += v.gR[o];
-        g += b.re;
+        g += v.sysOn[s] ? b.re : 0.0;
     }
     if (kz == v.zid)
         for (int s = 0; s < v.S; ++s) g += v.qPart[(long)s * v.ny + ky];
