@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hmcmt2d_amd import synthetic as S
 from hmcmt2d_amd.lib import HipContext, HmcmtError
-from scripts.gpu_check import problem
+from scripts.common import problem
 from tests.emul.emul_py import Emul
 
 name = sys.argv[1] if len(sys.argv) > 1 else "tiny"

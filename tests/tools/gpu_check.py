@@ -1,6 +1,6 @@
 """Bring-up check on a GPU box: HIP path vs oracle on small configs, kernel unit checks, timings.
 
-    python scripts/gpu_check.py [cfg ...]      (default: tiny cfg2 cfg3)
+    python tests/tools/gpu_check.py [cfg ...]      (default: tiny cfg2 cfg3)
 """
 import os
 import sys
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hmcmt2d_amd import synthetic as S, invsetup as I            # noqa: E402
 from hmcmt2d_amd.lib import HipContext                            # noqa: E402
 from hmcmt2d_amd.structs import HMCPrior                          # noqa: E402
