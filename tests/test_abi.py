@@ -67,3 +67,15 @@ def test_create_rejects_bad_arguments_before_touching_the_device():
     data.dataType = "Rho_Pha"
     with pytest.raises(ValueError):
         L.HipContext(mesh, data, inv)
+
+
+@pytest.mark.skipif(HAVE_GPU, reason="needs a GPU-less box")
+def test_mumps_interface_without_a_device_fails_loudly():
+    """No CPU fallback behind the MUMPS symbols either: factor reports stat < 0, which the wrapper raises
+    (MUMPSfuncs.jl:59-73)."""
+    import numpy as np
+    import scipy.sparse as sp
+    from hmcmt2d_amd import mumps as M
+    A = sp.csc_matrix(np.array([[2.0, -1.0], [-1.0, 2.0]]))
+    with pytest.raises(RuntimeError, match="MUMPS: error"):
+        M.factorMUMPS(A, 1)
