@@ -1763,7 +1763,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     }
     // the fused loop ping-pongs r between the caller's buffer and r2: leave the struct as it was found
     if (k.r != r_entry) { k.r2 = k.r; k.r = r_entry; }
-    guess = it;
+    guess = it;        // (launched iterations; collect_stats replaces it with the iterations actually needed)
     ctx->solveDone[kind] = done;
     // iteration counts / status / error estimates stay on the device; evaluate() reads both solves back at once
     hipLaunchKernelGGL(k_solve_end, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, k, kind, (int*)ctx->d_rec, ctx->d_rec + 2 * S);
@@ -1903,6 +1903,9 @@ int collect_stats(hmcmt_ctx* ctx, bool withAdjoint) {
         }
         if (kind == 0) { ctx->stats.iters_fwd_max = mx; ctx->stats.iters_fwd_sum = sum; }
         else { ctx->stats.iters_adj_max = mx; ctx->stats.iters_adj_sum = sum; }
+        // first convergence poll of the next evaluation: where this one actually finished (the loop itself only
+        // knows how many iterations it launched, which includes the empty ones behind the last poll)
+        if (ctx->solveDone[kind] && mx > 0) (kind == 0 ? ctx->lastItFwd : ctx->lastItAdj) = mx;
         if (!ctx->solveDone[kind] && ctx->stats.status == 0) ctx->stats.status = HMCMT_ENOCONV;
     }
     if (!withAdjoint) for (int s = 0; s < S; ++s) ctx->itersLast[S + s] = 0;
