@@ -237,20 +237,24 @@ def main():
 
     if rank == 0:
         # Algorithmic bytes per launch: U = S*(nz-1)*(ny-1) interior unknowns, complex128 = 16 B,
-        # complex64 = 8 B; the real stencil coefficients are shared by all frequencies of a mode (not counted).
-        # One preconditioned COCG iteration = these five launches:
-        #   k_fdm_fwd        forward eigen-transform + tridiagonal solves: read t (8) + inverse pivots (8), write y (8) = 24 U
-        #   k_transform_lp<2> back transform + first Jacobi half: read y (8), dinv (16), r (16), write z (16)        = 56 U
-        #   k_post           second Jacobi half + dots: read r, z, dinv (48), write t (16)                            = 64 U
-        #   k_spmv_fused     p = z + beta p, q = A p, p'q: read z, p (32), write p, q (32)                            = 64 U
-        #   k_update_fused   x, r updates + Jacobi pre-smoothing: read p, q, r, x, dinv (80), write x, r (32), t (8)  = 120 U
+        # complex64 / split-bf16 = 8 B; the real stencil coefficients are shared by all frequencies of a mode (not
+        # counted).  One preconditioned COCG iteration = these four launches on the fused path (five when the back
+        # transform and the post-smoother run as separate kernels: wide meshes, HMCMT_FUSED_BACK=0):
+        #   k_fdm_fwd      forward eigen-transform + tridiagonal solves: read t (8) + inverse pivots (8), write y (8) = 24 U
+        #   k_back_post    back transform + both Jacobi halves + dots: read y (8), dinv (16), r (16), write t (16)   = 56 U
+        #                  (separate: k_transform_lp<2> 56 U with z written, k_post: read r, z, dinv (48), write t (16) = 64 U)
+        #   k_spmv_fused   p = z + beta p, q = A p, p'q: read z, p (32), write p, q (32)                             = 64 U
+        #   k_update_fused x, r updates + Jacobi pre-smoothing: read p, q, r, x, dinv (80), write x, r (32), t (8)   = 120 U
         nyi, nzi = ctx.ny - 1, ctx.nz - 1
         U = ctx.S * nzi * nyi
+        back_fused = prof["post_smoother"][1] == 0
         fams = {"k_fdm_fwd (split-bf16 MFMA eigen-transform + LDS-resident complex64 tridiagonal sweeps, one launch)": ("tridiagonal", 24.0 * U, 1),
-                "k_transform_lp<2> (split-bf16 MFMA back transform fused with the first Jacobi half)": ("fdm_transform", 56.0 * U, 1),
-                "k_post (second Jacobi half: 5-point stencil + dot products)": ("post_smoother", 64.0 * U, 1),
+                ("k_back_post (split-bf16 MFMA back transform + both Jacobi halves of the post-smoother + dot products)" if back_fused else
+                 "k_transform_lp<2> (split-bf16 MFMA back transform fused with the first Jacobi half)"): ("fdm_transform", 56.0 * U, 1),
                 "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 64.0 * U, 1),
                 "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 120.0 * U, 1)}
+        if not back_fused:
+            fams["k_post (second Jacobi half: 5-point stencil + dot products)"] = ("post_smoother", 64.0 * U, 1)
         roofs = []
         it_bytes = it_us = 0.0
         for kname, (cat, nbytes, per_it) in fams.items():
@@ -271,10 +275,10 @@ def main():
                 entry["mfma"] = {"flops_per_launch": flops, "achieved_tflops": flops / (avg_us * 1e-6) / 1e12,
                                  "peak_tflops_bf16_dense": 2500.0}
             roofs.append(entry)
-        iteration = {"kernels": 5, "bytes": it_bytes, "us": it_us,
+        iteration = {"kernels": len(fams), "bytes": it_bytes, "us": it_us,
                      "achieved": it_bytes / (it_us * 1e-6) / 1e9 if it_us else 0.0, "unit": "GB/s",
                      "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS if it_us else 0.0,
-                     "note": "one preconditioned COCG iteration of all systems = 5 launches; the working set "
+                     "note": "one preconditioned COCG iteration of all systems = %d launches;" % len(fams) + " the working set "
                              "(~15 vectors) fits the 256 MB Infinity Cache at cfg3, so launches are latency- not HBM-bound"}
         roofs.sort(key=lambda r: -r["ms_timed"])
         out = {

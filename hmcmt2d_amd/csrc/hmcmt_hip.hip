@@ -78,6 +78,21 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* sh /* [
     }
 }
 
+// the same for workgroups of up to 8 waves (sh: [2*8])
+__device__ __forceinline__ void block_sum2_8(double& a, double& b, double* sh) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) { sh[w] = a; sh[8 + w] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        double sa = 0, sb = 0;
+        for (int i = 0; i < nw; ++i) { sa += sh[i]; sb += sh[8 + i]; }
+        a = sa; b = sb;
+    }
+}
+
 __device__ __forceinline__ cplx sum_partA(const Solver& k, int s) {
     cplx t = cplx{0, 0};
     for (int b = 0; b < k.NB; ++b) t += k.partA[(long)s * MAXNB + b];
@@ -610,12 +625,12 @@ __device__ __forceinline__ float bf16_to_f32(unsigned h) { return __uint_as_floa
 // product is accumulated as Ah*Bh + Ah*Bl + Al*Bh (fp32 accumulators): ~16 mantissa bits, i.e. fp32-class
 // accuracy from the bf16 pipe.  (Plain bf16 operands stalled one low-frequency TE system in 32.)
 // B: Bhi/Blo fragment arrays.  OUT: 0 = complex64, 1 = fp64 complex, 2 = fp64 complex + dinv*r (fused
-// first half of the post-smoother).
+// first half of the post-smoother), 3 = the same into an LDS tile whose row 0 is matrix row rowBase.
 template <int NTW, int OUT, int FMT>     // FMT 0: A is complex64 (split here); 1: A is pre-split (store_t32)
 __device__ __forceinline__ void transform_lp_body(const float2* __restrict__ Ain, const u4v* __restrict__ Bhi,
                                                   const u4v* __restrict__ Blo, void* __restrict__ Cout,
                                                   const cplx* __restrict__ dinv, const cplx* __restrict__ rvec,
-                                                  int M, int NYP, int m0, int t0, int lane) {
+                                                  int M, int NYP, int m0, int t0, int lane, int rowBase = 0) {
     const int NT = NYP >> 4, KG = (NYP + 31) >> 5;
     const int lj = lane & 15, g = lane >> 4;
     const int part = lj & 1;
@@ -686,7 +701,10 @@ __device__ __forceinline__ void transform_lp_body(const float2* __restrict__ Ain
                 const float re = acc[t][2 * h2], im = acc[t][2 * h2 + 1];
                 if (OUT == 0) reinterpret_cast<float2*>(Cout)[e] = float2{re, im};
                 else if (OUT == 1) reinterpret_cast<cplx*>(Cout)[e] = cplx{(double)re, (double)im};
-                else reinterpret_cast<cplx*>(Cout)[e] = cplx{(double)re, (double)im} + dinv[e] * rvec[e];
+                else if (OUT == 2) reinterpret_cast<cplx*>(Cout)[e] = cplx{(double)re, (double)im} + dinv[e] * rvec[e];
+                else reinterpret_cast<cplx*>(Cout)[(long)(row - rowBase) * NYP + col] = cplx{(double)re, (double)im} + dinv[e] * rvec[e];
+            } else if (OUT == 3) {
+                reinterpret_cast<cplx*>(Cout)[(long)(row - rowBase) * NYP + col] = cplx{0.0, 0.0};     // (Cout: an LDS tile)
             }
         }
     }
@@ -915,6 +933,86 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
         if (c < NYP) { const c32 v = sa[idx]; store_t32(k, Y + so, row, c, v.re, v.im); }   // pre-split for k_transform_lp<2>
     }
     FW_STAMP(4)
+}
+
+// ----------------------------------------------------------------------------------------------
+// Back half of the mixed-precision FDM stage fused with BOTH Jacobi halves of the post-smoother:
+//   z = V y + dinv .* r   (split-bf16 MFMA, as k_transform_lp<2>)      on a tile of 16 rows kept in LDS
+//   t = z + dinv .* (r - A z), partial r't and |t|^2                   on the tile's 14 inner rows
+// One workgroup = 14 consecutive interior rows of one system plus one halo row on each side (two MFMA row
+// groups); the halo rows are transformed twice (by the neighbouring workgroups too: +14 % transform work) in
+// exchange for one launch less per iteration and no round trip of z through global memory.
+// Replaces k_transform_lp<2> + k_post on the fused path.
+// ----------------------------------------------------------------------------------------------
+constexpr int BP_OWN = 14;         // interior rows owned by a workgroup (tile = BP_OWN + 2 = two 8-row MFMA groups)
+
+template <int FMT>
+__global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __restrict__ Y, const u4v* __restrict__ Bhi,
+                                                   const u4v* __restrict__ Blo, double* partZZ, int NW) {
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    __shared__ double sh[16];
+    __shared__ double sh2[16];
+    cplx* zt = reinterpret_cast<cplx*>(smem_);             // [16][NYP]
+    const int NYP = k.NYP, NZP = k.NZP;
+    const int iz0 = 1 + blockIdx.x * BP_OWN, iz1 = min(iz0 + BP_OWN - 1, k.nz - 1), rbase = iz0 - 1;
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx *r = k.r + so, *di = k.dinv + so;
+    cplx* t = k.t + so;
+    {
+        const int lane = threadIdx.x & 63, nw = threadIdx.x >> 6;
+        const int NT = NYP >> 4;
+        const int base = NT / NW, extra = NT % NW;
+        const int ntl = base + (nw < extra ? 1 : 0);
+        const int t0 = nw * base + min(nw, extra);
+        for (int rg = 0; rg < 2; ++rg)
+            for (int tt = 0; tt < ntl; tt += 2) {
+                if (ntl - tt >= 2) transform_lp_body<2, 3, FMT>(Y + so, Bhi, Blo, zt, di, r, NZP, NYP, rbase + 8 * rg, t0 + tt, lane, rbase);
+                else transform_lp_body<1, 3, FMT>(Y + so, Bhi, Blo, zt, di, r, NZP, NYP, rbase + 8 * rg, t0 + tt, lane, rbase);
+            }
+    }
+    __syncthreads();
+    double ar = 0, ai = 0, zz = 0, dummy = 0;
+    const int nown = (iz1 - iz0 + 1) * NYP;
+    for (int i = threadIdx.x; i < nown; i += blockDim.x) {
+        const int lr = i / NYP, iy = i - lr * NYP;
+        const long e = (long)(iz0 + lr) * NYP + iy;
+        cplx out = cplx{0, 0};
+        if (iy >= 1 && iy <= k.ny - 1) {
+            const int l = (lr + 1) * NYP + iy;
+            const cplx c = zt[l];
+            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+            acc += k.cY[mo + e] * zt[l + 1];
+            acc += k.cY[mo + e - 1] * zt[l - 1];
+            acc += k.cZ[mo + e] * zt[l + NYP];
+            acc += k.cZ[mo + e - NYP] * zt[l - NYP];
+            const cplx rv = r[e];
+            out = c + di[e] * (rv - acc);
+            ar += rv.re * out.re - rv.im * out.im;
+            ai += rv.re * out.im + rv.im * out.re;
+            zz += cabs2(out);
+        }
+        t[e] = out;
+    }
+    // the two boundary rows of t stay zero (the stencil kernels read them as halo rows)
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < NYP; i += blockDim.x) t[i] = cplx{0, 0};
+    if (iz1 == k.nz - 1) for (int i = threadIdx.x; i < NYP; i += blockDim.x) t[(long)k.nz * NYP + i] = cplx{0, 0};
+    block_sum2_8(ar, ai, sh);
+    block_sum2_8(zz, dummy, sh2);
+    if (threadIdx.x == 0) {
+        k.partA[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
+        partZZ[(long)s * MAXNB + blockIdx.x] = zz;
+    }
+    // the consumers add up k.NB partial sums per system: clear the slots this launch does not use
+    if (blockIdx.x == 0)
+        for (int b = gridDim.x + threadIdx.x; b < k.NB; b += blockDim.x) {
+            k.partA[(long)s * MAXNB + b] = cplx{0, 0};
+            partZZ[(long)s * MAXNB + b] = 0.0;
+        }
 }
 
 // pre-split planes -> complex64 (hi + lo), tests only
@@ -1482,6 +1580,8 @@ struct hmcmt_ctx {
     double* d_ext[2] = {nullptr, nullptr};       // {w0, w1, w2, keep, count}
     int extrapNp = 4;                        // fields used by the initial-guess extrapolation (HMCMT_EXTRAP_POINTS = 2..4)
     bool fusedFwd = true;                    // forward transform + tridiagonal solve in one kernel (HMCMT_FUSED_FWD=0: separate)
+    bool fusedBack = true;                   // back transform + post-smoother in one kernel (HMCMT_FUSED_BACK=0: separate)
+    size_t maxLdsBack = 64 * 1024;
     bool fusedFwdForce = false;              // HMCMT_FUSED_FWD=2: also where the heuristic prefers the separate kernels
     size_t maxLds = 64 * 1024;               // dynamic LDS the fused kernels may request
     bool lpFallback = false;                 // this solve has switched its stragglers to the fp64 preconditioner
@@ -1597,6 +1697,25 @@ int launch_transform_lp(hmcmt_ctx* ctx, const float2* A, bool transposed, void* 
 }
 
 // forward half of the mixed-precision FDM stage: y32 = tridiag^-1 (t32 V); fused kernel when its LDS slabs fit
+// back half of the FDM stage + post-smoother: fused kernel on the pre-split path when its 16-row tile fits LDS
+int launch_back_post(hmcmt_ctx* ctx) {
+    Solver& k = ctx->sv;
+    const int NT = k.NYP / 16, NW = std::min(8, (NT + LP_NTW - 1) / LP_NTW);
+    const size_t lds = (size_t)16 * k.NYP * sizeof(cplx);
+    dim3 vg(k.NB, k.S), vb(VBLOCK);
+    if (k.splitT && ctx->fusedBack && lds <= ctx->maxLdsBack) {
+        const int nwg = (k.nz - 1 + BP_OWN - 1) / BP_OWN;
+        ProfScope ps(ctx, 0);
+        hipLaunchKernelGGL(k_back_post<1>, dim3(nwg, k.S), dim3(64 * NW), lds, ctx->stream, k, k.y32, ctx->d_Vtb, ctx->d_Vtbl,
+                           ctx->d_partZZ, NW);
+        return 0;
+    }
+    int rc;
+    if ((rc = launch_transform_lp<2>(ctx, k.y32, true, k.z, k.active))) return rc;   // z = F t + dinv r
+    { ProfScope ps(ctx, 7); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+    return 0;
+}
+
 // slab width (in 16-mode tiles) of the fused forward kernel for this problem, 0 = use the separate kernels
 size_t fdm_fwd_lds(const Solver& k, int ntw) {
     return (size_t)3 * (k.NZP + 4 * FW_TB) * 16 * ntw * sizeof(c32) + (((size_t)k.NZP * sizeof(float) + 127) & ~(size_t)127);
@@ -1652,8 +1771,7 @@ int apply_precond(hmcmt_ctx* ctx) {
         else { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_to_c64, vg, vb, 0, ctx->stream, k, k.r); }
         if ((rc = launch_fdm_fwd(ctx))) return rc;
         if (smooth) {
-            if ((rc = launch_transform_lp<2>(ctx, k.y32, true, k.z, k.active))) return rc;   // z = F t + dinv r
-            { ProfScope ps(ctx, 7); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+            if ((rc = launch_back_post(ctx))) return rc;                                     // z = F t + dinv r, then the second Jacobi half
             std::swap(k.z, k.t);
         } else {
             if ((rc = launch_transform_lp<1>(ctx, k.y32, true, k.z, k.active))) return rc;
@@ -1719,8 +1837,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             k.r = rb[rcur];
             int prc;
             if ((prc = launch_fdm_fwd(ctx))) return prc;
-            if ((prc = launch_transform_lp<2>(ctx, k.y32, true, k.z, k.active))) return prc;   // z = F t + dinv r
-            { ProfScope ps(ctx, 7); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+            if ((prc = launch_back_post(ctx))) return prc;
             std::swap(k.z, k.t);
         }
         if (!done) {
@@ -1973,6 +2090,10 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         const char* e = getenv("HMCMT_FUSED_FWD");
         ctx->fusedFwd = !(e && e[0] == '0');
         ctx->fusedFwdForce = e && e[0] == '2';
+        if (const char* eb = getenv("HMCMT_FUSED_BACK")) ctx->fusedBack = eb[0] != '0';
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_back_post<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
+            ctx->maxLdsBack = 160 * 1024;
+        else (void)hipGetLastError();
         if (const char* ep = getenv("HMCMT_EXTRAP_POINTS")) ctx->extrapNp = std::max(2, std::min(EXT_NP, atoi(ep)));
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<FW_NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)

@@ -16,7 +16,7 @@ import os
 import sys
 from collections import defaultdict
 
-CATS = {"fdm_transform": ("k_transform_lp",), "tridiagonal": ("k_fdm_fwd", "k_thomas32"),
+CATS = {"fdm_transform": ("k_back_post", "k_transform_lp"), "tridiagonal": ("k_fdm_fwd", "k_thomas32"),
         "spmv": ("k_spmv_fused",), "post_smoother": ("k_post",), "vector_ops": ("k_update_fused",)}
 
 
