@@ -1404,9 +1404,34 @@ __global__ __launch_bounds__(64) void k_bc_layers(View v) {
     int col = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, s = blockIdx.z;
     if (col <= v.ny) item_bc_layers(v, s, j, col);
 }
+// One thread per boundary column.  The two edge columns need the whole 1-D field (left / right boundary values):
+// their lane writes it to LDS inside the recurrence (same code path as every other lane) and the wave copies it
+// out afterwards.
 __global__ __launch_bounds__(64) void k_bc_forward(View v) {
-    int col = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
-    if (col <= v.ny) item_bc_forward(v, s, col);
+    __shared__ cplx edge[2][MAXNZP];                      // slot 0: column 0, slot 1: column ny
+    const int col0 = blockIdx.x * blockDim.x, col = col0 + threadIdx.x, s = blockIdx.y;
+    if (!v.sysOn[s]) return;
+    const bool tm = s >= v.nFreq;
+    cplx* X = v.X + (long)s * v.vstride;
+    const long ls = v.ny + 1, qs = (long)v.nz * ls;
+    if (col <= v.ny) {
+        X[nidx(v, col, 0)] = cplx{1.0, 0.0};              // top row incl. corners
+        const cplx* T = v.fwdTab + (long)s * 5 * qs + col;
+        // ONE instantiation of the recurrence for every lane (a separate call for the edge lanes would make their
+        // wave run the whole chain twice, once per divergent path: that was the kernel's critical path)
+        const bool isEdge = col == 0 || col == v.ny;
+        cplx* e = edge[col == 0 ? 0 : 1];
+        const cplx last = bc1d_forward_tab_f(v.omega[s], v.nz, T, qs, ls, tm, [&](int i, cplx val) { if (isEdge) e[i] = val; });
+        if (!isEdge) X[nidx(v, col, v.nz)] = last;
+    }
+    const bool has0 = col0 == 0, hasN = col0 <= v.ny && v.ny < col0 + (int)blockDim.x;
+    if (has0 || hasN) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < v.nz; i += blockDim.x) {
+            if (has0) X[nidx(v, 0, 1 + i)] = edge[0][i];
+            if (hasN) X[nidx(v, v.ny, 1 + i)] = edge[1][i];
+        }
+    }
 }
 __global__ __launch_bounds__(64) void k_sens_layers(View v) {
     int j = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;

@@ -121,7 +121,12 @@ HD void layer_forward(double sig, double omega, double h, cplx out[5]) {
 // Both recurrences are latency-bound chains, so table entries are fetched RB layers at a time
 // before the dependent arithmetic of those layers starts.
 constexpr int RB = 4;
-HD cplx bc1d_forward_tab(double omega, int nz, const cplx* T, long qs, long ls, bool compH, cplx* out, long ostride) {
+// outf(i, value) receives the normalised field below layer i (edge columns); the plain-pointer overload below keeps
+// the original interface.  On the device the edge lanes buffer these values in LDS: a global store per layer
+// inside the loop would sit in the same in-order vmcnt queue as the table loads and add a store round trip to
+// every block of the recurrence (measured: 196 -> %s us for k_bc_forward).
+template <class OutF>
+HD cplx bc1d_forward_tab_f(double omega, int nz, const cplx* T, long qs, long ls, bool compH, OutF outf) {
     const double omu0 = omega * MU0;
     const cplx one = cplx{1.0, 0.0};
     // impedance recurrence bottom -> top (:48-56); half-space has the last layer's conductivity.
@@ -191,11 +196,15 @@ HD cplx bc1d_forward_tab(double omega, int nz, const cplx* T, long qs, long ls, 
                     }
                 }
                 last = fn * if0;
-                if (out) out[(long)i * ostride] = last;
+                outf(i, last);
             }
         }
     }
     return last;
+}
+
+HD cplx bc1d_forward_tab(double omega, int nz, const cplx* T, long qs, long ls, bool compH, cplx* out, long ostride) {
+    return bc1d_forward_tab_f(omega, nz, T, qs, ls, compH, [=](int i, cplx v) { if (out) out[(long)i * ostride] = v; });
 }
 
 // ---------------------------------------------------------------------------------------------
