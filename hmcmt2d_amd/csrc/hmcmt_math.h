@@ -335,13 +335,34 @@ HD cplx bc1d_sens_column(double omega, int nz, const double* zLen, bool srcH, in
     }
     cplx acc = cplx{0.0, 0.0};
     const int last = dead <= nz ? dead : nz;              // rows beyond the cut-off row are zero
+    // d(mix)/d sig[c] is non-zero in rows j = c-1 and j = c only.  Those two contributions depend on the profile
+    // tables, not on the running derivative, so each lane evaluates them ONCE here instead of inside the row loop
+    // (where, with one column per lane, some lane of the wave would take that branch in almost every row and the
+    // whole wave would pay for it).
+    cplx hU[2] = {cplx{0.0, 0.0}, cplx{0.0, 0.0}}, hD[2] = {cplx{0.0, 0.0}, cplx{0.0, 0.0}};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = c - 1 + q;                          // q = 0: c == j + 1, q = 1: c == j
+        if (j >= 0 && j < last) {
+            const cplx dkj = (q == 1) ? dkc : cplx{0.0, 0.0};
+            const cplx dkn = (q == 0) ? dkc : cplx{0.0, 0.0};   // c <= nz-1, so never the half-space copy
+            const cplx kr = (j + 1 < nz) ? ka[j] * kinv[j + 1] : one;
+            const cplx dexpt = (q == 1) ? (mul_i(zLen[j] * expt[j])) * dkj : cplx{0.0, 0.0};
+            const cplx dexpr = (q == 1) ? (-(mul_i(zLen[j] * expr[j]))) * dkj : cplx{0.0, 0.0};
+            const cplx dkr = dkj * kinv[j + 1] - (ka[j] * (kinv[j + 1] * kinv[j + 1])) * dkn;
+            const cplx dmix11 = (one + kr) * dexpt + expt[j] * dkr, dmix12 = (one - kr) * dexpr - expr[j] * dkr;
+            const cplx dmix21 = (one - kr) * dexpt - expt[j] * dkr, dmix22 = (one + kr) * dexpr + expr[j] * dkr;
+            hU[q] = 0.5 * (dmix11 * eu[j] + dmix12 * ed[j]);
+            hD[q] = 0.5 * (dmix21 * eu[j] + dmix22 * ed[j]);
+        }
+    }
     for (int j0 = 0; j0 < last; j0 += RB) {               // row j -> j+1 (:126-157)
-        cplx mx[RB][4], eu_[RB], ed_[RB], eun[RB], edn[RB], kan[RB], wv[RB];
+        cplx mx[RB][4], eun[RB], edn[RB], kan[RB], wv[RB];
 #pragma unroll
         for (int t = 0; t < RB; ++t) {
             const int j = j0 + t < last ? j0 + t : last - 1;
             mx[t][0] = mix[j]; mx[t][1] = mix[nz + j]; mx[t][2] = mix[2 * nz + j]; mx[t][3] = mix[3 * nz + j];
-            eu_[t] = eu[j]; ed_[t] = ed[j]; eun[t] = eu[j + 1]; edn[t] = ed[j + 1]; kan[t] = ka[j + 1];
+            eun[t] = eu[j + 1]; edn[t] = ed[j + 1]; kan[t] = ka[j + 1];
             wv[t] = w ? w[(long)j * wstride] : cplx{0.0, 0.0};
         }
 #pragma unroll
@@ -351,19 +372,9 @@ HD cplx bc1d_sens_column(double omega, int nz, const double* zLen, bool srcH, in
                 const int row = j + 1;
                 cplx nEu = 0.5 * (mx[t][0] * dEu + mx[t][1] * dEd);
                 cplx nEd = 0.5 * (mx[t][2] * dEu + mx[t][3] * dEd);
-                cplx dkn = cplx{0.0, 0.0};
-                if (c == j || c == j + 1) {               // the only columns with d(mix)/d sig[c] != 0
-                    const cplx dkj = (c == j) ? dkc : cplx{0.0, 0.0};
-                    dkn = (c == j + 1) ? dkc : cplx{0.0, 0.0};   // c <= nz-1, so never the half-space copy
-                    const cplx kr = (j + 1 < nz) ? ka[j] * kinv[j + 1] : one;
-                    const cplx dexpt = (c == j) ? (mul_i(zLen[j] * expt[j])) * dkj : cplx{0.0, 0.0};
-                    const cplx dexpr = (c == j) ? (-(mul_i(zLen[j] * expr[j]))) * dkj : cplx{0.0, 0.0};
-                    const cplx dkr = dkj * kinv[j + 1] - (ka[j] * (kinv[j + 1] * kinv[j + 1])) * dkn;
-                    const cplx dmix11 = (one + kr) * dexpt + expt[j] * dkr, dmix12 = (one - kr) * dexpr - expr[j] * dkr;
-                    const cplx dmix21 = (one - kr) * dexpt - expt[j] * dkr, dmix22 = (one + kr) * dexpr + expr[j] * dkr;
-                    nEu += 0.5 * (dmix11 * eu_[t] + dmix12 * ed_[t]);
-                    nEd += 0.5 * (dmix21 * eu_[t] + dmix22 * ed_[t]);
-                }
+                const cplx dkn = (c == j + 1) ? dkc : cplx{0.0, 0.0};
+                if (c == j + 1) { nEu += hU[0]; nEd += hD[0]; }
+                else if (c == j) { nEu += hU[1]; nEd += hD[1]; }
                 cplx dF;
                 if (!srcH) dF = nEu + nEd;
                 else dF = ((edn[t] - eun[t]) / omu) * dkn + (kan[t] / omu) * (nEd - nEu);
