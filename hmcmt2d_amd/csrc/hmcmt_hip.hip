@@ -2204,7 +2204,13 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     k.S = h.S; k.NYP = h.NYP; k.NZP = h.NZP; k.ny = h.ny; k.nz = h.nz; k.nFreq = h.nFreq; k.vstride = v.vstride;
     k.NB = std::max(1, std::min(MAXNB, (1024 + h.S - 1) / h.S));
     k.chunk = (v.vstride + k.NB - 1) / k.NB;
-    k.RT = std::max(4, (h.nz - 1 + MAXNB - 1) / MAXNB);
+    // rows per tile of the stencil kernels: about 512 workgroups per launch, at most 8 rows (measured at cfg3:
+    // 4 rows 484, 6 rows 489, 8 rows 492, 12 rows 456 steps/s), at least what MAXNB partial sums per system allow
+    {
+        const int want = std::min(8, std::max(2, (int)(((long)(h.nz - 1) * h.S + 511) / 512)));
+        const char* e = getenv("HMCMT_RT");
+        k.RT = std::max(e ? atoi(e) : want, (h.nz - 1 + MAXNB - 1) / MAXNB);
+    }
     k.NTR = (h.nz - 1 + k.RT - 1) / k.RT;
     k.omega = v.omega; k.cY = v.cY; k.cZ = v.cZ; k.dK = v.dK; k.dM = v.dM; k.ofz = v.ofz; k.invp = v.invp;
     k.r = v.R;
