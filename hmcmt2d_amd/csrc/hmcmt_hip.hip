@@ -808,20 +808,29 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
         const int row = idx / SW, c = t0 * 16 + (idx % SW);
         ipv[e] = (idx < NZP * SW && row >= 1 && row <= n && c < k.ny - 1) ? ip32[so + (long)row * NYP + c] : float2{0.f, 0.f};
     }
-    for (int m0 = wave * 8; m0 < NZP; m0 += nwave * 8) {
-        const int arow = min(m0 + (lj >> 1), NZP - 1);
-        f4v acc[NTW];
+    // Two row groups per pass (this wave's group and the one nwave groups further down): the V fragments of a
+    // k-group are loaded once for both, and the four accumulator chains keep the MFMA pipe busier than two.
+    constexpr int KC = 4;                                  // k-groups requested together
+    for (int m0 = wave * 8; m0 < NZP; m0 += 2 * nwave * 8) {
+        const int m1 = m0 + nwave * 8;                     // second row group (may lie beyond the last row: clamped, not stored)
+        const int arow[2] = {min(m0 + (lj >> 1), NZP - 1), min(m1 + (lj >> 1), NZP - 1)};
+        f4v acc[2][NTW];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[t] = f4v{0, 0, 0, 0};
-        for (int kc = 0; kc < KG; kc += KCH) {
-            u4v ahs[KCH], als[KCH];                    // pre-split input (store_t32): one 16-byte load per hi / lo
-            u4v bh[KCH][NTW], bl[KCH][NTW];
+        for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
-            for (int q = 0; q < KCH; ++q) {
+            for (int t = 0; t < NTW; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
+        for (int kc = 0; kc < KG; kc += KC) {
+            u4v ahs[2][KC], als[2][KC];                // pre-split input (store_t32): one 16-byte load per hi / lo
+            u4v bh[KC][NTW], bl[KC][NTW];
+#pragma unroll
+            for (int q = 0; q < KC; ++q) {
                 const int kg = min(kc + q, KG - 1);
-                const u4v* hp = reinterpret_cast<const u4v*>(reinterpret_cast<const unsigned short*>(As) +
-                                                             (long)arow * 4 * NYP + part * NYP + 32 * kg + 8 * g);
-                ahs[q] = hp[0]; als[q] = hp[NYP / 4];
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg) {
+                    const u4v* hp = reinterpret_cast<const u4v*>(reinterpret_cast<const unsigned short*>(As) +
+                                                                 (long)arow[rg] * 4 * NYP + part * NYP + 32 * kg + 8 * g);
+                    ahs[rg][q] = hp[0]; als[rg][q] = hp[NYP / 4];
+                }
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) {
                     const long bi = ((long)kg * NT + min(t0 + t, NT - 1)) * 64 + lane;
@@ -829,27 +838,32 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
                 }
             }
 #pragma unroll
-            for (int q = 0; q < KCH; ++q) {
+            for (int q = 0; q < KC; ++q) {
                 if (kc + q < KG) {
-                    const bf8v ah = __builtin_bit_cast(bf8v, ahs[q]), al = __builtin_bit_cast(bf8v, als[q]);
 #pragma unroll
                     for (int t = 0; t < NTW; ++t) {
                         const bf8v bhf = __builtin_bit_cast(bf8v, bh[q][t]), blf = __builtin_bit_cast(bf8v, bl[q][t]);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blf, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[t], 0, 0, 0);
+#pragma unroll
+                        for (int rg = 0; rg < 2; ++rg) {
+                            const bf8v ah = __builtin_bit_cast(bf8v, ahs[rg][q]), al = __builtin_bit_cast(bf8v, als[rg][q]);
+                            acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
+                            acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blf, acc[rg][t], 0, 0, 0);
+                            acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
-        // D rows 4g+r: (re, im) of complex rows 2g and 2g+1 of this group, column 16 t + lj of the slab
+        // D rows 4g+r: (re, im) of complex rows 2g and 2g+1 of a group, column 16 t + lj of the slab
 #pragma unroll
-        for (int t = 0; t < NTW; ++t)
+        for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const int row = m0 + 2 * g + h2;
-                if (row < NZP) sa[row * SW + t * 16 + lj] = c32{acc[t][2 * h2], acc[t][2 * h2 + 1]};
-            }
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int row = (rg ? m1 : m0) + 2 * g + h2;
+                    if (row < NZP) sa[row * SW + t * 16 + lj] = c32{acc[rg][t][2 * h2], acc[rg][t][2 * h2 + 1]};
+                }
     }
     __syncthreads();
     FW_STAMP(1)
