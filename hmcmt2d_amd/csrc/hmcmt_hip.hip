@@ -1529,8 +1529,7 @@ __global__ void k_lf_momentum(LfView L, double lambda, double cdt) {
         const long long j = L.wmCol[t];
         acc += L.wmVal[t] * (L.m[j] - L.mref[j]);
     }
-    const double g = L.g[a] + lambda * acc;
-    L.g[a] = g;
+    const double g = L.g[a] + lambda * acc;       // L.g stays the data gradient (hmcmt_leapfrog memoises it)
     L.p[a] -= cdt * g;
 }
 // partial max |dt*invM*p|   (HMCSampler.jl:237-240)
@@ -1640,6 +1639,13 @@ struct hmcmt_ctx {
     double *d_lfPart = nullptr, *d_lfScal = nullptr;
     int* d_lfFlag = nullptr;
     bool havePrior = false;
+    // results of the last two host-API evaluations, keyed by the model: a sampler re-evaluates the model it has
+    // just evaluated (getHamiltonian at the proposal, HMCSampler.jl:364; the first gradient of the next trajectory,
+    // :217) or, after a rejection, the start model of the trajectory before -- those calls cost a memcmp
+    struct Memo { std::vector<double> m, pred, grad; double misfit = 0; bool valid = false, hasGrad = false; hmcmt_stats stats{}; };
+    Memo memo[2];
+    int memoNext = 0;
+    long long memoHits = 0;
 };
 
 static std::string g_createError;
@@ -2292,6 +2298,7 @@ int hmcmt_set_options(hmcmt_ctx* ctx, const hmcmt_options* o) {
     ctx->opt = *o;
     ctx->lastItFwd = ctx->lastItAdj = 0;
     ctx->haveFwd = ctx->haveAdj = false;
+    ctx->memo[0].valid = ctx->memo[1].valid = false;
     return 0;
 }
 
@@ -2333,12 +2340,42 @@ int hmcmt_forward_device(hmcmt_ctx* ctx, const double* d_m, double* d_pred, doub
     return finish_status(ctx);
 }
 
+static hmcmt_ctx::Memo* memo_find(hmcmt_ctx* ctx, const double* m, bool needGrad) {
+    const size_t bytes = sizeof(double) * ctx->v.nAC;
+    for (auto& e : ctx->memo)
+        if (e.valid && (!needGrad || e.hasGrad) && std::memcmp(e.m.data(), m, bytes) == 0) return &e;
+    return nullptr;
+}
+static void memo_store(hmcmt_ctx* ctx, const double* m, const double* pred, double misfit, const double* grad) {
+    const int nAC = ctx->v.nAC, nData = ctx->v.nData;
+    hmcmt_ctx::Memo* e = memo_find(ctx, m, false);
+    if (e && e->hasGrad && !grad) return;                 // keep the richer entry of the same model
+    if (!e) { e = &ctx->memo[ctx->memoNext]; ctx->memoNext ^= 1; }
+    e->m.assign(m, m + nAC);
+    e->pred.assign(pred, pred + 2 * nData);
+    e->misfit = misfit;
+    e->hasGrad = grad != nullptr;
+    if (grad) e->grad.assign(grad, grad + nAC);
+    e->stats = ctx->stats;
+    e->valid = true;
+}
+
 static int host_eval(hmcmt_ctx* ctx, const double* m, double* pred, double* misfit, double* grad, bool wantGrad) {
     if (!ctx || !m || (wantGrad && !grad)) return HMCMT_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     const int nAC = ctx->v.nAC, nData = ctx->v.nData;
     for (int i = 0; i < nAC; ++i)
         if (!std::isfinite(m[i])) { ctx->err = "non-finite model value"; return HMCMT_EBREAKDOWN; }
+    if (!ctx->opt.verify)
+        if (const hmcmt_ctx::Memo* e = memo_find(ctx, m, wantGrad)) {     // this very model was evaluated a moment ago
+            if (pred) std::memcpy(pred, e->pred.data(), sizeof(cplx) * nData);
+            if (misfit) *misfit = e->misfit;
+            if (wantGrad) std::memcpy(grad, e->grad.data(), sizeof(double) * nAC);
+            ctx->stats = e->stats;                                           // (this call itself iterated nothing)
+            ctx->stats.iters_fwd_max = ctx->stats.iters_adj_max = ctx->stats.iters_fwd_sum = ctx->stats.iters_adj_sum = 0;
+            ++ctx->memoHits;
+            return 0;
+        }
     std::memcpy(ctx->h_stage, m, sizeof(double) * nAC);
     HIPCHK(hipMemcpyAsync(ctx->d_m, ctx->h_stage, sizeof(double) * nAC, hipMemcpyHostToDevice, ctx->stream));
     int rc = evaluate(ctx, ctx->d_m, wantGrad, nullptr, nullptr, nullptr);
@@ -2352,7 +2389,9 @@ static int host_eval(hmcmt_ctx* ctx, const double* m, double* pred, double* misf
     if (pred) std::memcpy(pred, hs, sizeof(cplx) * nData);
     if (misfit) *misfit = hs[2 * nData];
     if (wantGrad) std::memcpy(grad, hs + 2 * nData + 1, sizeof(double) * nAC);
-    return finish_status(ctx);
+    rc = finish_status(ctx);
+    if (rc == 0) memo_store(ctx, m, hs, hs[2 * nData], wantGrad ? hs + 2 * nData + 1 : nullptr);
+    return rc;
 }
 
 int hmcmt_grad(hmcmt_ctx* ctx, const double* m, double* pred, double* misfit, double* grad) {
@@ -2591,11 +2630,19 @@ int hmcmt_leapfrog(hmcmt_ctx* ctx, const double* m0, const double* p0, double dt
               ctx->d_lfPart, ctx->d_lfScal, ctx->d_lfFlag};
     const dim3 g1((n + 127) / 128), b1(128);
     int evals = 0;
-    int rc = evaluate(ctx, ctx->d_mcur, true, nullptr, nullptr, ctx->d_g);
-    if (rc) return rc;
-    if ((rc = collect_stats(ctx, true))) return rc;
-    if ((rc = finish_status(ctx))) return rc;
-    ++evals;
+    int rc = 0;
+    if (const hmcmt_ctx::Memo* e = ctx->opt.verify ? nullptr : memo_find(ctx, m0, true)) {
+        // the gradient at the start model is known (end of the previous trajectory, or its start after a rejection)
+        std::memcpy(ctx->h_stage + 2 * n, e->grad.data(), sizeof(double) * n);
+        HIPCHK(hipMemcpyAsync(ctx->d_g, ctx->h_stage + 2 * n, sizeof(double) * n, hipMemcpyHostToDevice, st));
+        ++ctx->memoHits;
+    } else {
+        rc = evaluate(ctx, ctx->d_mcur, true, nullptr, nullptr, ctx->d_g);
+        if (rc) return rc;
+        if ((rc = collect_stats(ctx, true))) return rc;
+        if ((rc = finish_status(ctx))) return rc;
+    }
+    ++evals;                                                 // counted as the reference counts it (hmcprior.nfevals, :217)
     hipLaunchKernelGGL(k_lf_momentum, g1, b1, 0, st, lf, regParam, 0.5 * dt);
     for (int k = 1; k <= L; ++k) {
         hipLaunchKernelGGL(k_lf_dmmax, dim3(LFNB), dim3(256), 0, st, lf, dt);
@@ -2616,10 +2663,12 @@ int hmcmt_leapfrog(hmcmt_ctx* ctx, const double* m0, const double* p0, double dt
     HIPCHK(hipMemcpyAsync(hs + 2 * n + 2 * nData, ctx->d_misfit, sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(hs + 2 * n + 2 * nData + 1, ctx->d_lfScal, sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(ctx->h_nactive, ctx->d_lfFlag, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hs + 2 * n + 2 * nData + 2, ctx->d_g, sizeof(double) * n, hipMemcpyDeviceToHost, st));   // for the memo
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     prof_collect(ctx);
     if (*ctx->h_nactive) { ctx->err = "non-finite model value during the trajectory"; return HMCMT_EBREAKDOWN; }
+    memo_store(ctx, hs, hs + 2 * n, hs[2 * n + 2 * nData], hs + 2 * n + 2 * nData + 2);   // the end model's data gradient
     std::memcpy(m1, hs, sizeof(double) * n);
     std::memcpy(p1, hs + n, sizeof(double) * n);
     if (pred) std::memcpy(pred, hs + 2 * n, sizeof(cplx) * nData);

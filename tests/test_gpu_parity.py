@@ -337,3 +337,27 @@ def test_fused_forward_fdm_kernel_matches_separate_kernels():
         scale = np.abs(sep).reshape(ctx.S, -1).max(1)[:, None, None]
         assert np.isfinite(fused).all() and (np.abs(fused - sep) / scale).max() < 1e-4
     ctx.close()
+
+
+def test_repeated_models_are_answered_from_the_memo():
+    """A sampler re-evaluates models it has just evaluated (getHamiltonian at the proposal, the first gradient of the
+    next trajectory, the start model again after a rejection).  The host entry points answer those from the results of
+    the last two evaluations: same numbers, no iterations; a forward-only result does not satisfy a gradient request."""
+    mesh, data, inv, m = make_problem("cfg2")
+    ctx = HipContext(mesh, data, inv)
+    m2 = m + 0.01
+    p1, f1, g1 = ctx.grad(m)
+    pf, ff = ctx.forward(m2)                                 # forward-only entry for m2
+    assert ctx.stats()["iters_fwd_max"] > 0
+    pa, fa = ctx.forward(m)                                  # m: answered from the memo of the gradient call
+    assert ctx.stats()["iters_fwd_max"] == 0 and np.array_equal(pa, p1) and fa == f1
+    pb, fb, gb = ctx.grad(m)
+    assert ctx.stats()["iters_fwd_max"] == 0 and np.array_equal(gb, g1) and np.array_equal(pb, p1)
+    pc, fc, gc = ctx.grad(m2)                                # forward-only memo has no gradient: a real evaluation
+    assert ctx.stats()["iters_adj_max"] > 0 and relmax(pc, pf) < 1e-9
+    pd, fd, gd = ctx.grad(m2)
+    assert ctx.stats()["iters_adj_max"] == 0 and np.array_equal(gd, gc)
+    ctx.set_options(tol=1e-9)                                # options changed: memo dropped
+    ctx.grad(m2)
+    assert ctx.stats()["iters_adj_max"] > 0
+    ctx.close()
