@@ -361,3 +361,27 @@ def test_repeated_models_are_answered_from_the_memo():
     ctx.grad(m2)
     assert ctx.stats()["iters_adj_max"] > 0
     ctx.close()
+
+
+def test_posterior_statistics_match_the_oracle_chain():
+    """BASELINE north star: posterior means / variances match the CPU direct-solver path on the same synthetic model.
+    30-sample chains from the same seed (tiny config): identical accept / reject decisions, every sample within 1e-8,
+    hence mean within 1e-8 and standard deviation within 1e-7 (host leapfrog loop and device trajectory alike)."""
+    import copy
+    from oracle import hmcmt_oracle as O
+    from hmcmt2d_amd import sampler
+    n = 30
+    mesh, data, inv, m = make_problem("tiny")
+    prior = HMCPrior(totalsamples=n, burninsamples=2, dt=0.01, timestep=[2, 4], sigBounds=[1e-4, 1.0])
+    mesh_o, inv_o, prior_o = copy.deepcopy(mesh), copy.deepcopy(inv), copy.deepcopy(prior)
+    O.setupTensorMesh2D(mesh_o)
+    mo, so, do = O.runHMCSampler(mesh_o, data, inv_o, prior_o, np.random.default_rng(11), dense_dbc=False)
+    for dev in (False, True):
+        inv_p, prior_p = copy.deepcopy(inv), copy.deepcopy(prior)
+        mp, sp_, dp = sampler.runHMCSampler(copy.deepcopy(mesh), data, inv_p, prior_p, np.random.default_rng(11),
+                                            device_leapfrog=dev)
+        sampler.release_context(inv_p)
+        assert np.array_equal(sp_.acceptstats, so["acceptstats"]) and prior_p.nfevals == prior_o.nfevals
+        assert max(relmax(mp[:, i], mo[:, i]) for i in range(n)) < 1e-8
+        assert relmax(mp.mean(1), mo.mean(1)) < 1e-8 and relmax(mp.std(1), mo.std(1)) < 1e-7
+        assert relmax(dp, do) < 1e-7
