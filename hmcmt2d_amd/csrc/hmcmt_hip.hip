@@ -43,6 +43,7 @@ struct Solver {
     // mixed-precision FDM stage (options.fdm_precision == 0): bf16 transform operands, fp32 tridiagonal
     float2* t32;                          // [S][vstride] complex64 transform input (or its pre-split bf16 form, see store_t32)
     int splitT;                           // 1: t32 / y32 hold bf16 hi/lo planes instead of complex64
+    int twist;                            // = View.twist: the inverse pivots are those of the twisted factorisation
     float2* y32;                          // [S][vstride] complex64
     const float2* invp32;                 // [S][vstride]
     cplx *p2, *r2;                        // second buffers of p and r for the fused kernels
@@ -382,10 +383,9 @@ __device__ __forceinline__ c32 cmsub(c32 a, c32 b, c32 x) {
     return c32{re, im};
 }
 
-template <class CT, class RT>
+template <class CT, class RT, bool TW>                   // TW = false: classic sweep, the bottom/down chain code is compiled out
 __device__ __forceinline__ void thomas_twisted(CT* __restrict__ y, const CT* __restrict__ ip, const RT* sof, int n, long NYP) {
-    const int mid = twist_mid(n), nt = mid, nb = n - mid;
-    constexpr bool TW = HMCMT_TWIST != 0;               // classic sweep: the bottom/down chain code is compiled out
+    const int mid = twist_mid(n, TW ? 1 : 0), nt = mid, nb = n - mid;
     CT pt = CT{0, 0}, pb = CT{0, 0};
     CT yt[TB], it[TB], yb[TB], ib[TB];
     // ---- phase 1: normalised elimination, top chain rows 1..mid, bottom chain rows n..mid+1
@@ -474,7 +474,8 @@ __global__ __launch_bounds__(64) void k_thomas(Solver k) {
     __syncthreads();
     const int j = blockIdx.x * 64 + threadIdx.x;
     if (j >= k.ny - 1) return;
-    thomas_twisted<cplx, double>(k.y + (long)s * k.vstride + j, k.invp + (long)s * k.vstride + j, sof, k.nz - 1, k.NYP);
+    if (k.twist) thomas_twisted<cplx, double, true>(k.y + (long)s * k.vstride + j, k.invp + (long)s * k.vstride + j, sof, k.nz - 1, k.NYP);
+    else thomas_twisted<cplx, double, false>(k.y + (long)s * k.vstride + j, k.invp + (long)s * k.vstride + j, sof, k.nz - 1, k.NYP);
 }
 
 __global__ __launch_bounds__(64) void k_thomas32(Solver k) {
@@ -486,8 +487,10 @@ __global__ __launch_bounds__(64) void k_thomas32(Solver k) {
     __syncthreads();
     const int j = blockIdx.x * 64 + threadIdx.x;
     if (j >= k.ny - 1) return;
-    thomas_twisted<c32, float>(reinterpret_cast<c32*>(k.y32) + (long)s * k.vstride + j,
-                               reinterpret_cast<const c32*>(k.invp32) + (long)s * k.vstride + j, sof, k.nz - 1, k.NYP);
+    if (k.twist) thomas_twisted<c32, float, true>(reinterpret_cast<c32*>(k.y32) + (long)s * k.vstride + j,
+                                                   reinterpret_cast<const c32*>(k.invp32) + (long)s * k.vstride + j, sof, k.nz - 1, k.NYP);
+    else thomas_twisted<c32, float, false>(reinterpret_cast<c32*>(k.y32) + (long)s * k.vstride + j,
+                                            reinterpret_cast<const c32*>(k.invp32) + (long)s * k.vstride + j, sof, k.nz - 1, k.NYP);
 }
 
 // ---- symmetric Jacobi / FDM / Jacobi combination (default preconditioner):
@@ -782,14 +785,20 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
     constexpr int SW = 16 * NTW;
 #define FW_STAMP(i) if (stamps && threadIdx.x == 0) stamps[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();
     FW_STAMP(0)
-    // sof first (padded to a multiple of 128 B), then the three slabs
+    // LDS: sof[NZP] (padded to 128 B), the join factors sj[SW], then three slabs sa / sb / sc.  A slab consists of
+    // one region (classic sweep) or two (twisted factorisation, k.twist): region 0 holds matrix rows 0..mid in
+    // order, region 1 holds rows n+1, n, .., mid+1 -- MIRRORED, so that both halves of the factorisation walk
+    // their region in the same direction and one instruction stream serves the top chain (lanes 0..SW-1) and the
+    // bottom chain (lanes SW..2SW-1) of the sweeping wave.  Every region has 2 FW_TB padding rows in front and
+    // behind (the inner FW_TB initialised): the sweeps run whole blocks of FW_TB rows without conditionals.
+    const int tw = k.twist, mid = twist_mid(n, tw);
+    const int RCAP = tw ? mid + 1 : NZP, RL = RCAP + 4 * FW_TB, nreg = tw ? 2 : 1;
     float* sof = reinterpret_cast<float*>(smem);
-    // each slab has 2 FW_TB padding rows in front of row 0 and behind row NZP-1, the inner FW_TB zeroed: the serial sweeps run whole blocks
-    // of FW_TB rows without conditionals (a = b = c = 0 there, so x = 0)
-    const int NZL = NZP + 4 * FW_TB;                   // (the outer FW_TB rows of each side are only ever requested ahead)
-    c32* sa = reinterpret_cast<c32*>(smem + (((long)NZP * 4 + 127) & ~127L)) + 2 * FW_TB * SW;
-    c32* sb = sa + (long)NZL * SW;
-    c32* sc = sb + (long)NZL * SW;
+    c32* sj = reinterpret_cast<c32*>(smem + (((long)NZP * 4 + 127) & ~127L));
+    c32* sa = sj + SW + 2 * FW_TB * SW;                  // -> region 0, row 0
+    c32* sb = sa + (long)nreg * RL * SW;
+    c32* sc = sb + (long)nreg * RL * SW;
+    auto lidx = [&](int row) { return (tw && row > mid) ? RL + (n + 1 - row) : row; };   // slab row of a matrix row
     const int mode = s >= k.nFreq;
     for (int i = threadIdx.x; i < NZP; i += blockDim.x) sof[i] = (float)k.ofz[(long)mode * NZP + i];
     __syncthreads();
@@ -862,21 +871,28 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const int row = (rg ? m1 : m0) + 2 * g + h2;
-                    if (row < NZP) sa[row * SW + t * 16 + lj] = c32{acc[rg][t][2 * h2], acc[rg][t][2 * h2 + 1]};
+                    if (row < NZP) sa[lidx(row) * SW + t * 16 + lj] = c32{acc[rg][t][2 * h2], acc[rg][t][2 * h2 + 1]};
                 }
     }
     __syncthreads();
     FW_STAMP(1)
-    // pre-multiply the recurrences (kept apart from the MFMA waves' epilogue on purpose: computing these
-    // products right behind the last MFMA gave sporadically wrong values on gfx950)
+    // Pre-multiply the recurrences (kept apart from the MFMA waves' epilogue on purpose: computing these products
+    // right behind the last MFMA gave sporadically wrong values on gfx950).  With ip the inverse
+    // pivot and o_r the off-diagonal between rows r and r+1:  a = y*ip, and the coefficient of the elimination
+    // sweep p1 / of the substitution sweep p2 is  o_{r-1}*ip / o_r*ip  for a top row (swept downwards, then
+    // upwards) and  o_r*ip / o_{r-1}*ip  for a bottom row (swept upwards, then downwards).
     auto premul = [&](int idx, float2 ipf) {
-        const int row = idx / SW, c = t0 * 16 + (idx % SW);
-        c32 bv = c32{0, 0}, cv = c32{0, 0};
+        const int row = idx / SW, j = idx % SW, c = t0 * 16 + j;
+        const int l = lidx(row) * SW + j;
+        c32 p1 = c32{0, 0}, p2 = c32{0, 0};
         if (row >= 1 && row <= n && c < k.ny - 1) {
             const c32 ip = c32{ipf.x, ipf.y};
-            sa[idx] = sa[idx] * ip; bv = sof[row - 1] * ip; cv = sof[row] * ip;
+            const c32 bb = sof[row - 1] * ip, cc = sof[row] * ip;
+            sa[l] = sa[l] * ip;
+            const bool bottom = tw && row > mid;
+            p1 = bottom ? cc : bb; p2 = bottom ? bb : cc;
         }
-        sb[idx] = bv; sc[idx] = cv;
+        sb[l] = p1; sc[l] = p2;
     };
 #pragma unroll
     for (int e = 0; e < FW_PRE; ++e) {
@@ -887,25 +903,42 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
         const int row = idx / SW, c = t0 * 16 + (idx % SW);
         premul(idx, (row >= 1 && row <= n && c < k.ny - 1) ? ip32[so + (long)row * NYP + c] : float2{0.f, 0.f});
     }
-    for (int idx = threadIdx.x; idx < FW_TB * SW; idx += blockDim.x) {
+    // padding rows: in front of a region zeros (the substitution sweep runs into them: 0 - 0*x = 0); behind a
+    // region identity rows for the elimination sweep (a = 0, p1 = -1: x stays), zero p2
+    for (int idx = threadIdx.x; idx < nreg * FW_TB * SW; idx += blockDim.x) {
+        const int reg = idx / (FW_TB * SW), o = idx % (FW_TB * SW);
         const c32 z = c32{0, 0};
-        sa[idx - FW_TB * SW] = z; sb[idx - FW_TB * SW] = z; sc[idx - FW_TB * SW] = z;
-        sa[NZP * SW + idx] = z; sb[NZP * SW + idx] = z; sc[NZP * SW + idx] = z;
+        const long front = (long)reg * RL * SW - (long)FW_TB * SW + o;
+        const int last = tw ? (reg == 0 ? mid : n + 1 - (mid + 1)) : NZP - 1;          // last initialised row of the region
+        const long back = ((long)reg * RL + last + 1) * SW + o;
+        sa[front] = z; sb[front] = z; sc[front] = z;
+        sa[back] = z; sb[back] = c32{-1.f, 0.f}; sc[back] = z;
+    }
+    if (threadIdx.x < SW) {                                 // join factor 1 / (1 - c c') of the two halves (item_pivot)
+        const int c = t0 * 16 + threadIdx.x;
+        const float2 jf = (tw && c < k.ny - 1) ? ip32[so + c] : float2{1.f, 0.f};
+        sj[threadIdx.x] = c32{jf.x, jf.y};
     }
     __syncthreads();
     FW_STAMP(2)
-    if (wave == 0 && lane < SW && t0 * 16 + lane < k.ny - 1) {
-        // rows are addressed from one moving base with compile-time offsets (no clamps: the padding rows
-        // absorb the blocks' overhang), so a step is 4 FMAs + 2 LDS reads + 1 LDS write
+    if (wave == 0 && lane < nreg * SW && t0 * 16 + (lane % SW) < k.ny - 1) {
+        // rows are addressed from one moving base with compile-time offsets (no clamps: the padding rows absorb the
+        // blocks' overhang), so a step is 4 FMAs + 2 LDS reads + 1 LDS write
+        const int half = lane / SW, col = lane % SW;
+        const int last = tw ? (half == 0 ? mid : n - mid) : n;      // rows 1..last of this lane's region are real
+        const int steps = tw ? mid : n;                             // both halves run the longer count (identity rows)
+        c32* ra = sa + (long)half * RL * SW + col;
+        const c32* rb = sb + (long)half * RL * SW + col;
+        const c32* rc = sc + (long)half * RL * SW + col;
         c32 pt = c32{0, 0};
         c32 av[FW_TB], bv[FW_TB];
-        // ---- down sweep, rows 1..n in whole blocks (rows beyond n: zeros in, zeros out)
+        // ---- elimination, region rows 1..steps
         {
-            c32* pa = sa + SW + lane;
-            const c32* pb = sb + SW + lane;
+            c32* pa = ra + SW;
+            const c32* pb = rb + SW;
 #pragma unroll
             for (int t = 0; t < FW_TB; ++t) { av[t] = pa[t * SW]; bv[t] = pb[t * SW]; }
-            for (int r0 = 1; r0 <= n; r0 += FW_TB) {
+            for (int r0 = 1; r0 <= steps; r0 += FW_TB) {
                 c32 na[FW_TB], nb[FW_TB];
 #pragma unroll
                 for (int t = 0; t < FW_TB; ++t) { na[t] = pa[(FW_TB + t) * SW]; nb[t] = pb[(FW_TB + t) * SW]; }
@@ -918,14 +951,26 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
                 pa += FW_TB * SW; pb += FW_TB * SW;
             }
         }
-        // ---- up sweep, rows n-1..1 in whole blocks (rows above 1: zeros in, zeros out); starts from x_n
+        // ---- join of the two halves: x_mid = (y'_mid - c y''_{mid+1}) J ;  x_{mid+1} = y''_{mid+1} - c' x_mid
+        pt = ra[last * SW];                                   // (the identity rows left it unchanged)
+        if (tw) {
+            const c32 p2last = rc[last * SW];
+            const float pre = pt.re, pim = pt.im;               // (plain floats: shuffling struct members kept pt in scratch)
+            const float ore = __shfl_xor(pre, SW), oim = __shfl_xor(pim, SW);
+            const c32 xmid = (c32{pre, pim} - p2last * c32{ore, oim}) * sj[col];       // meaningful in the top half
+            const float xre = xmid.re, xim = xmid.im;
+            const float mre = __shfl_xor(xre, SW), mim = __shfl_xor(xim, SW);
+            const c32 xbot = c32{pre, pim} - p2last * c32{mre, mim};
+            pt = half == 0 ? c32{xre, xim} : xbot;
+            ra[last * SW] = pt;
+        }
+        // ---- substitution, region rows last-1 .. 1 (rows in front of 1: zeros in, zeros out)
         {
-            pt = sa[n * SW + lane];
-            c32* pa = sa + (n - 1) * SW + lane;
-            const c32* pc = sc + (n - 1) * SW + lane;
+            c32* pa = ra + (long)(last - 1) * SW;
+            const c32* pc = rc + (long)(last - 1) * SW;
 #pragma unroll
             for (int t = 0; t < FW_TB; ++t) { av[t] = pa[-t * SW]; bv[t] = pc[-t * SW]; }
-            for (int r0 = n - 1; r0 >= 1; r0 -= FW_TB) {
+            for (int r0 = steps - 1; r0 >= 1; r0 -= FW_TB) {
                 c32 na[FW_TB], nb[FW_TB];
 #pragma unroll
                 for (int t = 0; t < FW_TB; ++t) { na[t] = pa[-(FW_TB + t) * SW]; nb[t] = pc[-(FW_TB + t) * SW]; }
@@ -943,8 +988,8 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
     __syncthreads();
     // solved slab -> Y (rows of SW complex64)
     for (int idx = threadIdx.x; idx < NZP * SW; idx += blockDim.x) {
-        const int row = idx / SW, c = t0 * 16 + (idx % SW);
-        if (c < NYP) { const c32 v = sa[idx]; store_t32(k, Y + so, row, c, v.re, v.im); }   // pre-split for k_transform_lp<2>
+        const int row = idx / SW, j = idx % SW, c = t0 * 16 + j;
+        if (c < NYP) { const c32 v = sa[lidx(row) * SW + j]; store_t32(k, Y + so, row, c, v.re, v.im); }   // pre-split for the back transform
     }
     FW_STAMP(4)
 }
@@ -1620,6 +1665,7 @@ struct hmcmt_ctx {
     bool fusedFwd = true;                    // forward transform + tridiagonal solve in one kernel (HMCMT_FUSED_FWD=0: separate)
     bool fusedBack = true;                   // back transform + post-smoother in one kernel (HMCMT_FUSED_BACK=0: separate)
     size_t maxLdsBack = 64 * 1024;
+    bool twistOn = true;                     // HMCMT_TWIST=0: classic one-sided sweeps in the fused kernel as well
     bool fusedFwdForce = false;              // HMCMT_FUSED_FWD=2: also where the heuristic prefers the separate kernels
     size_t maxLds = 64 * 1024;               // dynamic LDS the fused kernels may request
     bool lpFallback = false;                 // this solve has switched its stragglers to the fp64 preconditioner
@@ -1762,8 +1808,10 @@ int launch_back_post(hmcmt_ctx* ctx) {
 }
 
 // slab width (in 16-mode tiles) of the fused forward kernel for this problem, 0 = use the separate kernels
-size_t fdm_fwd_lds(const Solver& k, int ntw) {
-    return (size_t)3 * (k.NZP + 4 * FW_TB) * 16 * ntw * sizeof(c32) + (((size_t)k.NZP * sizeof(float) + 127) & ~(size_t)127);
+size_t fdm_fwd_lds(const Solver& k, int ntw, int twist) {
+    const int n = k.nz - 1, mid = twist_mid(n, twist);
+    const size_t rl = (size_t)(twist ? mid + 1 : k.NZP) + 4 * FW_TB, nreg = twist ? 2 : 1, sw = 16 * (size_t)ntw;
+    return (((size_t)k.NZP * sizeof(float) + 127) & ~(size_t)127) + (sw + 2 * FW_TB * sw + 3 * nreg * rl * sw + 2 * FW_TB * sw) * sizeof(c32);
 }
 int fdm_fwd_ntw(const hmcmt_ctx* ctx) {
     const Solver& k = ctx->sv;
@@ -1772,14 +1820,15 @@ int fdm_fwd_ntw(const hmcmt_ctx* ctx) {
     // 21 vs 29 us at 200x100 cells; at 400x200 the separate kernels win, 146 vs 219 us).  HMCMT_FUSED_FWD=2
     // forces it (16-mode slabs if need be), =0 disables it.
     if (!ctx->fusedFwd) return 0;
-    if (fdm_fwd_lds(k, FW_NTW) <= ctx->maxLds && (k.NYP <= 256 || ctx->fusedFwdForce)) return FW_NTW;
-    if (ctx->fusedFwdForce && fdm_fwd_lds(k, 1) <= ctx->maxLds) return 1;
+    const int tw = ctx->twistOn ? 1 : 0;
+    if (fdm_fwd_lds(k, FW_NTW, tw) <= ctx->maxLds && (k.NYP <= 256 || ctx->fusedFwdForce)) return FW_NTW;
+    if (ctx->fusedFwdForce && fdm_fwd_lds(k, 1, tw) <= ctx->maxLds) return 1;
     return 0;
 }
 
 int launch_fdm_fwd(hmcmt_ctx* ctx) {
     Solver& k = ctx->sv;
-    auto ldsFor = [&](int ntw) { return fdm_fwd_lds(k, ntw); };
+    auto ldsFor = [&](int ntw) { return fdm_fwd_lds(k, ntw, k.twist); };
     const int ntw = k.splitT ? fdm_fwd_ntw(ctx) : 0;       // (k.splitT is set from fdm_fwd_ntw: the operand format goes with the path)
     if (ntw) {
         const int G = (k.NZP + 7) / 8, per = (G + 7) / 8, nw = (G + per - 1) / per;
@@ -2135,6 +2184,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         const char* e = getenv("HMCMT_FUSED_FWD");
         ctx->fusedFwd = !(e && e[0] == '0');
         ctx->fusedFwdForce = e && e[0] == '2';
+        if (const char* et = getenv("HMCMT_TWIST")) ctx->twistOn = et[0] != '0';
         if (const char* eb = getenv("HMCMT_FUSED_BACK")) ctx->fusedBack = eb[0] != '0';
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_back_post<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
             ctx->maxLdsBack = 160 * 1024;
@@ -2285,6 +2335,7 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
         return rc;
     }
     ctx->sv.splitT = fdm_fwd_ntw(ctx) > 0;
+    ctx->sv.twist = ctx->v.twist = ctx->sv.splitT && ctx->twistOn;     // the fused forward kernel sweeps both ways at once
     *out = ctx;
     return 0;
 }
@@ -2538,7 +2589,7 @@ int hmcmt_debug_fdm_fwd(hmcmt_ctx* ctx, const double* t, double* out) {
         long long* d_st = nullptr;
         HIPCHK(hipMalloc((void**)&d_st, sizeof(long long) * 8 * nb));
         HIPCHK(hipMemset(d_st, 0, sizeof(long long) * 8 * nb));
-        const size_t lds = (size_t)3 * (k.NZP + 4 * FW_TB) * 16 * FW_NTW * sizeof(c32) + (((size_t)k.NZP * sizeof(float) + 127) & ~(size_t)127);
+        const size_t lds = fdm_fwd_lds(k, FW_NTW, k.twist);
         const int G = (k.NZP + 7) / 8, per = (G + 7) / 8, nw = (G + per - 1) / per;
         hipLaunchKernelGGL(k_to_c64, dim3(k.NB, k.S), dim3(VBLOCK), 0, ctx->stream, k, k.r);
         for (int rep = 0; rep < 3; ++rep)

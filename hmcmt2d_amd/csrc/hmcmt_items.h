@@ -17,6 +17,7 @@ namespace hmcmt {
 struct View {
     // sizes
     int ny, nz, NYP, NZP, nFreq, S, nRx, nData, nAC, nCell;
+    int twist;                     // 1: twisted (two-sided) factorisation of the FDM tridiagonals, see item_pivot
     int zid;                       // node row of the receivers (mt2DTE.jl:66-67), 0-based
     long vstride;                  // NZP*NYP elements per system
     // mesh (constant)
@@ -172,20 +173,18 @@ HD void item_fdm_z(const View& v, int mode, int iz) {
 //     rows 1..mid are eliminated top-down, rows n..mid+1 bottom-up (two independent recurrences the
 //     solve kernels run interleaved, halving their dependent chain); the factor that couples the two
 //     halves at rows mid, mid+1 is stored in the unused boundary row iz = 0.
-// Measured on MI355X the tridiagonal kernels are instruction-issue-bound (one wave per CU, ~25
-//     instructions per row), so interleaving two chains does not pay (20 us vs 16 us): HMCMT_TWIST = 0
-//     selects mid = n, which is the classic Thomas factorisation.
-#ifndef HMCMT_TWIST
-#define HMCMT_TWIST 0
-#endif
-HD int twist_mid(int n) { return HMCMT_TWIST ? (n + 1) / 2 : n; }   // rows 1..mid | mid+1..n   (n = nz-1 >= 2)
+// View.twist selects it at run time: the fused forward kernel (k_fdm_fwd) runs the two halves in the two lane
+//     halves of its sweeping wave and halves its serial chain; the stand-alone tridiagonal kernels, which read
+//     global memory, are instruction-issue-bound and do not gain (20 us vs 16 us), so they use twist = 0
+//     (mid = n: the classic Thomas factorisation) unless they have to follow the fused kernel's pivots.
+HD int twist_mid(int n, int twist) { return twist ? (n + 1) / 2 : n; }   // rows 1..mid | mid+1..n   (n = nz-1 >= 2)
 HD void item_pivot(const View& v, int s, int j) {
     const int mode = s >= v.nFreq;
     const double w = v.omega[s], lam = v.lam[j];
     const double *mzq = v.mzq + (long)mode * v.NZP, *dgz = v.dgz + (long)mode * v.NZP,
                  *ofz = v.ofz + (long)mode * v.NZP, *mzs = v.mzs + (long)mode * v.NZP;
     cplx* ip = v.invp + (long)s * v.vstride + j;
-    const int n = v.nz - 1, mid = twist_mid(n);
+    const int n = v.nz - 1, mid = twist_mid(n, v.twist);
     cplx prev = cplx{0, 0}, dtop = cplx{0, 0}, dbot = cplx{0, 0};
     for (int iz = 1; iz <= mid; ++iz) {                    // d'_iz = d_iz - of_{iz-1}^2 / d'_{iz-1}
         cplx d = cplx{lam * mzq[iz] + dgz[iz], w * mzs[iz]};

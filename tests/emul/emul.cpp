@@ -107,7 +107,7 @@ struct Emul {
         const cplx* ip = v.invp + (long)s * v.vstride;
         for (int j = 0; j < v.ny - 1; ++j) {
             // twisted solve (see item_pivot): top-down to mid, bottom-up to mid+1, 2x2 in the middle, outwards
-            const int n = nz - 1, mid = twist_mid(n);
+            const int n = nz - 1, mid = twist_mid(n, v.twist);
             auto Yr = [&](int iz) -> cplx& { return Y[nidx(v, j, iz)]; };
             cplx pt = cplx{0, 0}, pb = cplx{0, 0};
             for (int iz = 1; iz <= mid; ++iz) { pt = (Yr(iz) - ofz_[iz - 1] * pt) * ip[nidx(v, j, iz)]; Yr(iz) = pt; }
