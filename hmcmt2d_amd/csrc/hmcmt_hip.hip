@@ -628,12 +628,12 @@ __device__ __forceinline__ float bf16_to_f32(unsigned h) { return __uint_as_floa
 // product is accumulated as Ah*Bh + Ah*Bl + Al*Bh (fp32 accumulators): ~16 mantissa bits, i.e. fp32-class
 // accuracy from the bf16 pipe.  (Plain bf16 operands stalled one low-frequency TE system in 32.)
 // B: Bhi/Blo fragment arrays.  OUT: 0 = complex64, 1 = fp64 complex, 2 = fp64 complex + dinv*r (fused
-// first half of the post-smoother), 3 = the same into an LDS tile whose row 0 is matrix row rowBase.
+// first half of the post-smoother).
 template <int NTW, int OUT, int FMT>     // FMT 0: A is complex64 (split here); 1: A is pre-split (store_t32)
 __device__ __forceinline__ void transform_lp_body(const float2* __restrict__ Ain, const u4v* __restrict__ Bhi,
                                                   const u4v* __restrict__ Blo, void* __restrict__ Cout,
                                                   const cplx* __restrict__ dinv, const cplx* __restrict__ rvec,
-                                                  int M, int NYP, int m0, int t0, int lane, int rowBase = 0) {
+                                                  int M, int NYP, int m0, int t0, int lane) {
     const int NT = NYP >> 4, KG = (NYP + 31) >> 5;
     const int lj = lane & 15, g = lane >> 4;
     const int part = lj & 1;
@@ -704,10 +704,7 @@ __device__ __forceinline__ void transform_lp_body(const float2* __restrict__ Ain
                 const float re = acc[t][2 * h2], im = acc[t][2 * h2 + 1];
                 if (OUT == 0) reinterpret_cast<float2*>(Cout)[e] = float2{re, im};
                 else if (OUT == 1) reinterpret_cast<cplx*>(Cout)[e] = cplx{(double)re, (double)im};
-                else if (OUT == 2) reinterpret_cast<cplx*>(Cout)[e] = cplx{(double)re, (double)im} + dinv[e] * rvec[e];
-                else reinterpret_cast<cplx*>(Cout)[(long)(row - rowBase) * NYP + col] = cplx{(double)re, (double)im} + dinv[e] * rvec[e];
-            } else if (OUT == 3) {
-                reinterpret_cast<cplx*>(Cout)[(long)(row - rowBase) * NYP + col] = cplx{0.0, 0.0};     // (Cout: an LDS tile)
+                else reinterpret_cast<cplx*>(Cout)[e] = cplx{(double)re, (double)im} + dinv[e] * rvec[e];
             }
         }
     }
@@ -1022,16 +1019,77 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
     const cplx *r = k.r + so, *di = k.dinv + so;
     cplx* t = k.t + so;
     {
+        // both row groups of the tile in one pass over k: a wave's V fragments are loaded once for the two groups
         const int lane = threadIdx.x & 63, nw = threadIdx.x >> 6;
-        const int NT = NYP >> 4;
+        const int NT = NYP >> 4, KG = (NYP + 31) >> 5;
         const int base = NT / NW, extra = NT % NW;
         const int ntl = base + (nw < extra ? 1 : 0);
         const int t0 = nw * base + min(nw, extra);
-        for (int rg = 0; rg < 2; ++rg)
-            for (int tt = 0; tt < ntl; tt += 2) {
-                if (ntl - tt >= 2) transform_lp_body<2, 3, FMT>(Y + so, Bhi, Blo, zt, di, r, NZP, NYP, rbase + 8 * rg, t0 + tt, lane, rbase);
-                else transform_lp_body<1, 3, FMT>(Y + so, Bhi, Blo, zt, di, r, NZP, NYP, rbase + 8 * rg, t0 + tt, lane, rbase);
+        const int lj = lane & 15, g = lane >> 4, part = lj & 1;
+        const float2* Ys = Y + so;
+        constexpr int KC = 4;
+        for (int tt = 0; tt < ntl; tt += 2) {
+            const int ntw = min(2, ntl - tt);
+            const int arow[2] = {min(rbase + (lj >> 1), NZP - 1), min(rbase + 8 + (lj >> 1), NZP - 1)};
+            f4v acc[2][2];
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
+            for (int kc = 0; kc < KG; kc += KC) {
+                u4v ahs[2][KC], als[2][KC], bh[KC][2], bl[KC][2];
+#pragma unroll
+                for (int q = 0; q < KC; ++q) {
+                    const int kg = min(kc + q, KG - 1);
+#pragma unroll
+                    for (int rg = 0; rg < 2; ++rg) {
+                        const u4v* hp = reinterpret_cast<const u4v*>(reinterpret_cast<const unsigned short*>(Ys) +
+                                                                     (long)arow[rg] * 4 * NYP + part * NYP + 32 * kg + 8 * g);
+                        ahs[rg][q] = hp[0]; als[rg][q] = hp[NYP / 4];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const long bi = ((long)kg * NT + min(t0 + tt + t, NT - 1)) * 64 + lane;
+                        bh[q][t] = Bhi[bi]; bl[q][t] = Blo[bi];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < KC; ++q) {
+                    if (kc + q < KG) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const bf8v bhf = __builtin_bit_cast(bf8v, bh[q][t]), blf = __builtin_bit_cast(bf8v, bl[q][t]);
+#pragma unroll
+                            for (int rg = 0; rg < 2; ++rg) {
+                                const bf8v ah = __builtin_bit_cast(bf8v, ahs[rg][q]), al = __builtin_bit_cast(bf8v, als[rg][q]);
+                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
+                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blf, acc[rg][t], 0, 0, 0);
+                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
             }
+            // z = V y + dinv .* r into the tile (rows beyond the mesh: zero)
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (t < ntw) {
+                        const int col = (t0 + tt + t) * 16 + lj;
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const int lr = 8 * rg + 2 * g + h2, row = rbase + lr;
+                            cplx val = cplx{0.0, 0.0};
+                            if (row < NZP) {
+                                const long e = (long)row * NYP + col;
+                                val = cplx{(double)acc[rg][t][2 * h2], (double)acc[rg][t][2 * h2 + 1]} + di[e] * r[e];
+                            }
+                            zt[(long)lr * NYP + col] = val;
+                        }
+                    }
+                }
+        }
     }
     __syncthreads();
     double ar = 0, ai = 0, zz = 0, dummy = 0;
