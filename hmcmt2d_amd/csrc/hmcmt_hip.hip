@@ -94,6 +94,24 @@ __device__ __forceinline__ void block_sum2_8(double& a, double& b, double* sh) {
     }
 }
 
+// sum of n <= 64 per-block partials by one wave: lane b fetches partial b (one memory latency instead of n in a
+// row), a fixed butterfly of xor-shuffles adds them up, every lane gets the total -- the same value in every wave
+// of every block, so all blocks of a system still agree on alpha / beta / convergence
+__device__ __forceinline__ double wave_total(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double total_part(const double* part, int n) {
+    const int l = threadIdx.x & 63;
+    return wave_total(l < n ? part[l] : 0.0);
+}
+__device__ __forceinline__ cplx total_part(const cplx* part, int n) {
+    const int l = threadIdx.x & 63;
+    const cplx v = l < n ? part[l] : cplx{0, 0};
+    return cplx{wave_total(v.re), wave_total(v.im)};
+}
+
 __device__ __forceinline__ cplx sum_partA(const Solver& k, int s) {
     cplx t = cplx{0, 0};
     for (int b = 0; b < k.NB; ++b) t += k.partA[(long)s * MAXNB + b];
@@ -1208,10 +1226,9 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
     extern __shared__ __attribute__((aligned(16))) char smem_[];
     cplx* pn = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]
     __shared__ double sh[8];
-    cplx rz = cplx{0, 0};
-    double zz = 0, xx = 0;
-    for (int b = 0; b < k.NB; ++b) { rz += k.partA[(long)s * MAXNB + b]; zz += partZZ[(long)s * MAXNB + b]; }
-    for (int b = 0; b < k.NTR; ++b) xx += k.partB[(long)s * MAXNB + b];
+    const cplx rz = total_part(k.partA + (long)s * MAXNB, k.NB);
+    double zz = total_part(partZZ + (long)s * MAXNB, k.NB);
+    const double xx = total_part(k.partB + (long)s * MAXNB, k.NTR);
     const bool first = it == 1;
     bool on = true;
     int st = 0;
@@ -1280,8 +1297,7 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const cplx* p
     cplx* cs = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]  dinv .* r'
     cplx* rs = cs + (long)(k.RT + 2) * NYP;               // [RT][NYP]      r' of the own rows
     __shared__ double sh[8];
-    cplx pq = cplx{0, 0};
-    for (int b = 0; b < k.NTR; ++b) pq += k.partPQ[(long)s * MAXNB + b];
+    const cplx pq = total_part(k.partPQ + (long)s * MAXNB, k.NTR);
     const cplx al = k.rho2[(long)(it & 1) * k.S + s] / pq;
     const int mode = s >= k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
