@@ -816,10 +816,21 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
     auto lidx = [&](int row) { return (tw && row > mid) ? RL + (n + 1 - row) : row; };   // slab row of a matrix row
     const int mode = s >= k.nFreq;
     for (int i = threadIdx.x; i < NZP; i += blockDim.x) sof[i] = (float)k.ofz[(long)mode * NZP + i];
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int NT = NYP >> 4, KG = (NYP + 31) >> 5;
     const int t0 = slab * NTW;                         // first column tile of this slab
+    // The slab's V fragments (hi and lo, all k-groups) are needed by every wave: staged once in LDS (in the space of
+    // sb / sc, which are not written before the transform is over) instead of 7 times through the vector L1.
+    // vst[((kg*NTW + t)*2 + hl)*64 + lane]
+    u4v* vst = reinterpret_cast<u4v*>(sb - 2 * FW_TB * SW);
+    const bool stageV = (size_t)KG * NTW * 2 * 64 * sizeof(u4v) <= (size_t)2 * nreg * RL * SW * sizeof(c32);
+    if (stageV)
+        for (int i = threadIdx.x; i < KG * NTW * 2 * 64; i += blockDim.x) {
+            const int l = i & 63, hl = (i >> 6) & 1, t = (i >> 7) % NTW, kg = (i >> 7) / NTW;
+            const long bi = ((long)kg * NT + min(t0 + t, NT - 1)) * 64 + l;
+            vst[i] = hl ? Blo[bi] : Bhi[bi];
+        }
+    __syncthreads();
     const int lj = lane & 15, g = lane >> 4, part = lj & 1;
     const long so = (long)s * k.vstride;
     const float2* As = A + so;
@@ -857,8 +868,12 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
                 }
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) {
-                    const long bi = ((long)kg * NT + min(t0 + t, NT - 1)) * 64 + lane;
-                    bh[q][t] = Bhi[bi]; bl[q][t] = Blo[bi];
+                    if (stageV) {
+                        bh[q][t] = vst[((kg * NTW + t) * 2 + 0) * 64 + lane]; bl[q][t] = vst[((kg * NTW + t) * 2 + 1) * 64 + lane];
+                    } else {
+                        const long bi = ((long)kg * NT + min(t0 + t, NT - 1)) * 64 + lane;
+                        bh[q][t] = Bhi[bi]; bl[q][t] = Blo[bi];
+                    }
                 }
             }
 #pragma unroll
