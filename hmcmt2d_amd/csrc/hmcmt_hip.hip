@@ -1061,9 +1061,22 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
         const int lj = lane & 15, g = lane >> 4, part = lj & 1;
         const float2* Ys = Y + so;
         constexpr int KC = 4;
+        // The tile's 16 rows of y are the A-operand of every wave: staged once in LDS in fragment order
+        // (ast[((rg*KG + kg)*2 + hl)*64 + lane] = what lane `lane` feeds the MFMA for row group rg, k-group kg)
+        // instead of 7 times through the vector L1.
+        u4v* ast = reinterpret_cast<u4v*>(zt + (long)16 * NYP);
+        for (int i = threadIdx.x; i < 2 * KG * 2 * 64; i += blockDim.x) {
+            const int l = i & 63, hl = (i >> 6) & 1, kg = (i >> 7) % KG, rg = (i >> 7) / KG;
+            const int llj = l & 15, lg = l >> 4;
+            const int arow = min(rbase + 8 * rg + (llj >> 1), NZP - 1);
+            const u4v* hp = reinterpret_cast<const u4v*>(reinterpret_cast<const unsigned short*>(Ys) +
+                                                         (long)arow * 4 * NYP + (llj & 1) * NYP + 32 * kg + 8 * lg);
+            ast[i] = hp[hl ? NYP / 4 : 0];
+        }
+        __syncthreads();
+        (void)part; (void)g;
         for (int tt = 0; tt < ntl; tt += 2) {
             const int ntw = min(2, ntl - tt);
-            const int arow[2] = {min(rbase + (lj >> 1), NZP - 1), min(rbase + 8 + (lj >> 1), NZP - 1)};
             f4v acc[2][2];
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg)
@@ -1076,9 +1089,7 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
                     const int kg = min(kc + q, KG - 1);
 #pragma unroll
                     for (int rg = 0; rg < 2; ++rg) {
-                        const u4v* hp = reinterpret_cast<const u4v*>(reinterpret_cast<const unsigned short*>(Ys) +
-                                                                     (long)arow[rg] * 4 * NYP + part * NYP + 32 * kg + 8 * g);
-                        ahs[rg][q] = hp[0]; als[rg][q] = hp[NYP / 4];
+                        ahs[rg][q] = ast[((rg * KG + kg) * 2 + 0) * 64 + lane]; als[rg][q] = ast[((rg * KG + kg) * 2 + 1) * 64 + lane];
                     }
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
@@ -1881,7 +1892,7 @@ int launch_transform_lp(hmcmt_ctx* ctx, const float2* A, bool transposed, void* 
 int launch_back_post(hmcmt_ctx* ctx) {
     Solver& k = ctx->sv;
     const int NT = k.NYP / 16, NW = std::min(8, (NT + LP_NTW - 1) / LP_NTW);
-    const size_t lds = (size_t)16 * k.NYP * sizeof(cplx);
+    const size_t lds = (size_t)16 * k.NYP * sizeof(cplx) + (size_t)2 * ((k.NYP + 31) / 32) * 2 * 64 * 16;   // z tile + staged A fragments
     dim3 vg(k.NB, k.S), vb(VBLOCK);
     if (k.splitT && ctx->fusedBack && lds <= ctx->maxLdsBack) {
         const int nwg = (k.nz - 1 + BP_OWN - 1) / BP_OWN;
@@ -2275,8 +2286,9 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         ctx->fusedFwdForce = e && e[0] == '2';
         if (const char* et = getenv("HMCMT_TWIST")) ctx->twistOn = et[0] != '0';
         if (const char* eb = getenv("HMCMT_FUSED_BACK")) ctx->fusedBack = eb[0] != '0';
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_back_post<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
-            ctx->maxLdsBack = 160 * 1024;
+        // (this kernel also has a few hundred bytes of static LDS: ask for less than the full 160 KB)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_back_post<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) == hipSuccess)
+            ctx->maxLdsBack = 152 * 1024;
         else (void)hipGetLastError();
         if (const char* ep = getenv("HMCMT_EXTRAP_POINTS")) ctx->extrapNp = std::max(2, std::min(EXT_NP, atoi(ep)));
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<FW_NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
