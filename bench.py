@@ -248,9 +248,13 @@ def main():
         nyi, nzi = ctx.ny - 1, ctx.nz - 1
         U = ctx.S * nzi * nyi
         back_fused = prof["post_smoother"][1] == 0
-        fams = {"k_fdm_fwd (split-bf16 MFMA eigen-transform + LDS-resident complex64 tridiagonal sweeps, one launch)": ("tridiagonal", 24.0 * U, 1),
+        fwd_fused = ctx.NYP <= 256                      # the library's own rule (launch_fdm_fwd): wide meshes run the separate kernels
+        fams = {("k_fdm_fwd (split-bf16 MFMA eigen-transform + LDS-resident complex64 tridiagonal sweeps, one launch)" if fwd_fused else
+                 "k_thomas32 (batched complex64 tridiagonal solve of the FDM stage)"): ("tridiagonal", 24.0 * U, 1),
                 ("k_back_post (split-bf16 MFMA back transform + both Jacobi halves of the post-smoother + dot products)" if back_fused else
-                 "k_transform_lp<2> (split-bf16 MFMA back transform fused with the first Jacobi half)"): ("fdm_transform", 56.0 * U, 1),
+                 "k_transform_lp<2> (split-bf16 MFMA back transform fused with the first Jacobi half)" if fwd_fused else
+                 "k_transform_lp<0>,<2> (split-bf16 MFMA forward and back transforms: 16 U and 56 U)"):
+                    ("fdm_transform", 56.0 * U if fwd_fused else 36.0 * U, 1 if fwd_fused else 2),
                 "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 64.0 * U, 1),
                 "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 120.0 * U, 1)}
         if not back_fused:
