@@ -385,3 +385,50 @@ def test_posterior_statistics_match_the_oracle_chain():
         assert max(relmax(mp[:, i], mo[:, i]) for i in range(n)) < 1e-8
         assert relmax(mp.mean(1), mo.mean(1)) < 1e-8 and relmax(mp.std(1), mo.std(1)) < 1e-7
         assert relmax(dp, do) < 1e-7
+
+
+@pytest.mark.parametrize("ny,nz,nfreq,npad_y,npad_z,nair", [(17, 9, 1, 3, 3, 2), (33, 14, 2, 4, 4, 7), (47, 21, 5, 7, 8, 4)])
+def test_ragged_shapes_against_the_oracle(ny, nz, nfreq, npad_y, npad_z, nair):
+    """Shapes that are multiples of nothing (row tiles, 16-mode tiles, 8-row MFMA groups, waves all end ragged), a
+    single frequency, a receiver exactly on a node, a masked (ragged) data set and a model with fixed cells: predicted
+    data and gradient against the oracle."""
+    from hmcmt2d_amd import synthetic as S, invsetup as I
+    mesh = S.make_mesh(ny, nz, npad_y=npad_y, npad_z=npad_z, nair=nair)
+    yN = np.concatenate([[0.0], np.cumsum(mesh.yLen)]) - mesh.origin[0]
+    rx = np.array([yN[ny // 2], yN[ny // 2] + 130.0, yN[ny // 2 + 2] - 40.0, -350.0])     # first one on a node
+    data = S.make_data_layout(S.log_freqs(nfreq) if nfreq > 1 else [3.7], np.sort(rx))
+    rng = np.random.default_rng(ny)
+    keep = rng.random(len(data.rxID)) > 0.25                                              # drop a quarter of the data
+    data.dataID = keep.copy()
+    data.rxID, data.freqID, data.dtID = data.rxID[keep], data.freqID[keep], data.dtID[keep]
+    n = int(keep.sum())
+    obs = (0.02 + 0.01 * rng.standard_normal(n)) * np.where(data.dtID == 1, 1.0, -1.0) * (1 + 1j)
+    err = np.full(n, 2e-3)
+    nt = mesh.gridSize[1]
+    mesh.sigma = np.concatenate([np.full(ny * nair, S.SIG_AIR), np.full(ny * (nt - nair), 0.01)])
+    mesh.sigma[ny * nair + 5] = 0.3                                                        # a fixed (inactive) earth cell
+    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR, 0.3], 0.0, 0.0, obs, err)
+    m = np.log(0.01) + 0.4 * rng.standard_normal(len(inv.strModel))
+    ctx = HipContext(mesh, data, inv, verify=True)
+    pred, misfit, grad = ctx.grad(m)
+    st = ctx.stats()
+    assert st["status"] == 0 and st["true_res_max"] < 1e-8
+    po, mo, go = oracle_eval(mesh, data, inv, m)
+    # Gradient bar: 1e-7 of max|g| away from the deepest rows.  In the deepest rows next to the side padding
+    # the gradient is dominated by the bottom row of the reference's 1-D sensitivity matrix, which is rounding noise
+    # at the higher frequencies (MT1DSensitivity.jl:145-155, SURVEY App. B.7): two correct evaluations of the
+    # reference formula differ there in the third digit, and so do the oracle and the GPU (5e-6 of max|g|).
+    deep = (inv.activeIdx // ny) >= nt - 5
+
+    def gerr(g, ref, mask):
+        return np.abs(g - ref)[mask].max() / np.abs(ref).max()
+
+    assert relmax(pred, po) < 1e-9 and abs(misfit - mo) / mo < 1e-9
+    assert gerr(grad, go, ~deep) < 1e-7 and gerr(grad, go, deep) < 5e-6
+    ctx.close()
+    ctx = HipContext(mesh, data, inv)                       # and the default (warm, extrapolating, memoising) path on a short walk
+    for j in range(4):
+        pj, fj, gj = ctx.grad(m + 0.02 * j)
+    po, mo, go = oracle_eval(mesh, data, inv, m + 0.06)
+    assert relmax(pj, po) < 1e-9 and gerr(gj, go, ~deep) < 1e-7 and gerr(gj, go, deep) < 5e-6
+    ctx.close()
