@@ -43,3 +43,25 @@ def oracle_eval(mesh, data, inv, m, dense_dbc=False, keep=None):
 
 def relmax(a, b):
     return float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max())
+
+
+def ragged_problem(ny, nz, nfreq, npad_y, npad_z, nair):
+    """A configuration whose sizes are multiples of nothing: a single or a few frequencies, one receiver exactly on a
+    node, a quarter of the data masked out, one fixed earth cell, a rough model.  Returns (mesh, data, inv, m)."""
+    mesh = S.make_mesh(ny, nz, npad_y=npad_y, npad_z=npad_z, nair=nair)
+    yN = np.concatenate([[0.0], np.cumsum(mesh.yLen)]) - mesh.origin[0]
+    rx = np.array([yN[ny // 2], yN[ny // 2] + 130.0, yN[ny // 2 + 2] - 40.0, -350.0])     # first one on a node
+    data = S.make_data_layout(S.log_freqs(nfreq) if nfreq > 1 else [3.7], np.sort(rx))
+    rng = np.random.default_rng(ny)
+    keep = rng.random(len(data.rxID)) > 0.25                                              # drop a quarter of the data
+    data.dataID = keep.copy()
+    data.rxID, data.freqID, data.dtID = data.rxID[keep], data.freqID[keep], data.dtID[keep]
+    n = int(keep.sum())
+    obs = (0.02 + 0.01 * rng.standard_normal(n)) * np.where(data.dtID == 1, 1.0, -1.0) * (1 + 1j)
+    err = np.full(n, 2e-3)
+    nt = mesh.gridSize[1]
+    mesh.sigma = np.concatenate([np.full(ny * nair, S.SIG_AIR), np.full(ny * (nt - nair), 0.01)])
+    mesh.sigma[ny * nair + 5] = 0.3                                                        # a fixed (inactive) earth cell
+    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR, 0.3], 0.0, 0.0, obs, err)
+    m = np.log(0.01) + 0.4 * rng.standard_normal(len(inv.strModel))
+    return mesh, data, inv, m

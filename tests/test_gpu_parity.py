@@ -392,23 +392,9 @@ def test_ragged_shapes_against_the_oracle(ny, nz, nfreq, npad_y, npad_z, nair):
     """Shapes that are multiples of nothing (row tiles, 16-mode tiles, 8-row MFMA groups, waves all end ragged), a
     single frequency, a receiver exactly on a node, a masked (ragged) data set and a model with fixed cells: predicted
     data and gradient against the oracle."""
-    from hmcmt2d_amd import synthetic as S, invsetup as I
-    mesh = S.make_mesh(ny, nz, npad_y=npad_y, npad_z=npad_z, nair=nair)
-    yN = np.concatenate([[0.0], np.cumsum(mesh.yLen)]) - mesh.origin[0]
-    rx = np.array([yN[ny // 2], yN[ny // 2] + 130.0, yN[ny // 2 + 2] - 40.0, -350.0])     # first one on a node
-    data = S.make_data_layout(S.log_freqs(nfreq) if nfreq > 1 else [3.7], np.sort(rx))
-    rng = np.random.default_rng(ny)
-    keep = rng.random(len(data.rxID)) > 0.25                                              # drop a quarter of the data
-    data.dataID = keep.copy()
-    data.rxID, data.freqID, data.dtID = data.rxID[keep], data.freqID[keep], data.dtID[keep]
-    n = int(keep.sum())
-    obs = (0.02 + 0.01 * rng.standard_normal(n)) * np.where(data.dtID == 1, 1.0, -1.0) * (1 + 1j)
-    err = np.full(n, 2e-3)
+    from tests.helpers import ragged_problem
+    mesh, data, inv, m = ragged_problem(ny, nz, nfreq, npad_y, npad_z, nair)
     nt = mesh.gridSize[1]
-    mesh.sigma = np.concatenate([np.full(ny * nair, S.SIG_AIR), np.full(ny * (nt - nair), 0.01)])
-    mesh.sigma[ny * nair + 5] = 0.3                                                        # a fixed (inactive) earth cell
-    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR, 0.3], 0.0, 0.0, obs, err)
-    m = np.log(0.01) + 0.4 * rng.standard_normal(len(inv.strModel))
     ctx = HipContext(mesh, data, inv, verify=True)
     pred, misfit, grad = ctx.grad(m)
     st = ctx.stats()
@@ -417,7 +403,8 @@ def test_ragged_shapes_against_the_oracle(ny, nz, nfreq, npad_y, npad_z, nair):
     # Gradient bar: 1e-7 of max|g| away from the deepest rows.  In the deepest rows next to the side padding
     # the gradient is dominated by the bottom row of the reference's 1-D sensitivity matrix, which is rounding noise
     # at the higher frequencies (MT1DSensitivity.jl:145-155): two correct evaluations of the
-    # reference formula differ there in the third digit, and so do the oracle and the GPU (5e-6 of max|g|).
+    # reference formula differ there in the third digit (tests/test_oracle_kat.py::test_reference_gradient_is_ill_
+    # conditioned_in_the_deepest_rows), and so do the oracle and the GPU (5e-6 of max|g|).
     deep = (inv.activeIdx // ny) >= nt - 5
 
     def gerr(g, ref, mask):

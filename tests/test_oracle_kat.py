@@ -123,3 +123,21 @@ def test_bound_reflection_and_momentum_clip():
     assert np.allclose(p2[:3], [-1.0, -2.0, 3.0])
     mom = O.getMomentumVector(10000, np.ones(10000), np.random.default_rng(0))
     assert np.abs(mom).max() <= 2.5
+
+
+def test_reference_gradient_is_ill_conditioned_in_the_deepest_rows():
+    """The justification of the gradient tolerances in tests/test_gpu_parity.py::test_ragged_shapes_against_the_oracle:
+    perturbing the model by 1e-14 (relative) moves the reference formula's own gradient by ~1e-7 of max|g|, and the
+    entries that move most are the deepest rows next to the side padding -- there the bottom row of the 1-D
+    sensitivity matrix is rounding noise (MT1DSensitivity.jl:145-155): third digit of those entries."""
+    from tests.helpers import oracle_eval, ragged_problem
+    mesh, data, inv, m = ragged_problem(47, 21, 5, 7, 8, 4)
+    ny = mesh.gridSize[0]
+    _, _, g0 = oracle_eval(mesh, data, inv, m)
+    _, _, g1 = oracle_eval(mesh, data, inv, m * (1 + 1e-14))
+    deep = (inv.activeIdx // ny) >= mesh.gridSize[1] - 5
+    d = np.abs(g1 - g0)
+    worst = np.argsort(d)[-6:]
+    assert deep[worst].all()
+    assert d[deep].max() / np.abs(g0).max() > 1e-8 and d[deep].max() > 10 * d[~deep].max()
+    assert (d[worst] / np.abs(g0[worst])).max() > 1e-4          # third to fourth digit of the entries themselves
