@@ -102,7 +102,11 @@ int hmcmt_get_stats(const hmcmt_ctx* ctx, hmcmt_stats* out);
 /* per-system iteration counts of the last call: iters[2*S] (forward, then adjoint) */
 int hmcmt_get_iters(const hmcmt_ctx* ctx, int32_t* iters);
 
-/* Host-buffer entry points (synchronous). pred: complex[nData]; grad: [nAC]. */
+/* Host-buffer entry points (synchronous). pred: complex[nData]; grad: [nAC].
+ * A model identical (bit for bit) to one of the last two evaluated through these entry points is answered from their
+ * stored results without touching the GPU (a sampler re-evaluates the proposal's model and, after a rejection, the
+ * previous start model); hmcmt_get_stats then reports zero iterations.  Dropped by hmcmt_set_options and when
+ * options.verify is set. */
 int hmcmt_grad(hmcmt_ctx* ctx, const double* m, double* pred, double* misfit, double* grad);
 int hmcmt_forward(hmcmt_ctx* ctx, const double* m, double* pred, double* misfit);
 
@@ -126,7 +130,8 @@ int hmcmt_leapfrog(hmcmt_ctx* ctx, const double* m0, const double* p0, double dt
                    double* m1, double* p1, double* pred, double* misfit, double* mnorm,
                    int32_t* nfevals);
 
-/* Solution fields of the last evaluation in the reference's layout: complex[(ny+1)*(nz+1)*nFreq],
+/* Solution fields of the last evaluation THAT RAN (a call answered from the stored results runs nothing) in the
+ * reference's layout: complex[(ny+1)*(nz+1)*nFreq],
  * node index (iz*(ny+1)+iy) fastest, then frequency (MT2DFwdSolver.jl:111-112).  adjoint=1 returns
  * the adjoint fields instead (interior = eVal of compJacTMatVec.jl:221, boundary 0). */
 int hmcmt_get_fields(hmcmt_ctx* ctx, int32_t adjoint, double* exTE, double* hxTM);
