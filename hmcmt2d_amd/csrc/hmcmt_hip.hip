@@ -2732,6 +2732,43 @@ int hmcmt_debug_fdm_fwd(hmcmt_ctx* ctx, const double* t, double* out) {
     return 0;
 }
 
+// back half of the FDM stage + post-smoother on caller-supplied vectors: out[0..n) = fused kernel (k_back_post),
+// out[n..2n) = k_transform_lp<2> + k_post, n = S*vstride complex; sums[0..2) / [2..4) = sum over systems of the
+// r't partials (re, im) of the two paths, sums[4] / [5] = of the |t|^2 partials
+int hmcmt_debug_back_post(hmcmt_ctx* ctx, const double* y, const double* r, double* out, double* sums) {
+    if (!ctx || !y || !r || !out || !sums) return HMCMT_EINVAL;
+    if (!ctx->haveModel) { ctx->err = "no evaluation has been run yet"; return HMCMT_EINVAL; }
+    HIPCHK(hipSetDevice(ctx->device));
+    Solver& k = ctx->sv;
+    const size_t n = (size_t)ctx->v.S * ctx->v.vstride;
+    int rc = set_all_active(ctx);
+    if (rc) return rc;
+    const bool keep = ctx->fusedBack;
+    std::vector<cplx> pa((size_t)k.S * MAXNB);
+    std::vector<double> pz((size_t)k.S * MAXNB);
+    for (int pass = 0; pass < 2; ++pass) {
+        // y -> y32 in the operand format of the path (through t32, the buffer k_to_c64 writes), r -> k.r
+        HIPCHK(hipMemcpy(k.r, y, n * sizeof(cplx), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_to_c64, dim3(k.NB, k.S), dim3(VBLOCK), 0, ctx->stream, k, k.r);
+        HIPCHK(hipMemcpyAsync(k.y32, k.t32, n * sizeof(float2), hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(k.r, r, n * sizeof(cplx), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemsetAsync(k.t, 0xff, n * sizeof(cplx), ctx->stream));
+        ctx->fusedBack = pass == 0;
+        rc = launch_back_post(ctx);
+        ctx->fusedBack = keep;
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(out + 2 * pass * n, k.t, n * sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(pa.data(), k.partA, pa.size() * sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(pz.data(), ctx->d_partZZ, pz.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        double are = 0, aim = 0, zz = 0;
+        for (int s = 0; s < k.S; ++s)
+            for (int b = 0; b < k.NB; ++b) { are += pa[(size_t)s * MAXNB + b].re; aim += pa[(size_t)s * MAXNB + b].im; zz += pz[(size_t)s * MAXNB + b]; }
+        sums[2 * pass] = are; sums[2 * pass + 1] = aim; sums[4 + pass] = zz;
+    }
+    return 0;
+}
+
 int hmcmt_set_prior(hmcmt_ctx* ctx, const double* mref, const int64_t* rowptr, const int64_t* colind,
                     const double* val, const double* invM) {
     if (!ctx || !mref || !rowptr || !colind || !val || !invM) return HMCMT_EINVAL;

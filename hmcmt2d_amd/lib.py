@@ -101,11 +101,12 @@ def load_library():
     lib.hmcmt_debug_spmv.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_precond.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_fdm_fwd.argtypes = [vp, c_double_p, c_double_p]
+    lib.hmcmt_debug_back_post.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_double_p]
     for name in ("hmcmt_create", "hmcmt_destroy", "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters",
                  "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_set_prior",
                  "hmcmt_leapfrog", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read",
                  "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond",
-                 "hmcmt_debug_fdm_fwd"):
+                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -115,7 +116,8 @@ EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "h
                     "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters", "hmcmt_grad", "hmcmt_forward",
                     "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_set_prior", "hmcmt_leapfrog",
                     "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_dims",
-                    "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd"]
+                    "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
+                    "hmcmt_debug_back_post"]
 
 
 def _dp(a):
@@ -269,6 +271,13 @@ class HipContext:
         out = np.empty((2,) + T.shape, dtype=np.complex128)
         self._check(self.lib.hmcmt_debug_fdm_fwd(self.h, _dp(T), _dp(out)))
         return out[0], out[1]
+
+    def debug_back_post(self, Yv, R):
+        Yv, R = self._vec(Yv), self._vec(R)
+        out = np.empty((2,) + Yv.shape, dtype=np.complex128)
+        sums = np.zeros(6)
+        self._check(self.lib.hmcmt_debug_back_post(self.h, _dp(Yv), _dp(R), _dp(out), _dp(sums)))
+        return out[0], out[1], sums
 
     def debug_transform(self, which, A):
         A = self._vec(A)

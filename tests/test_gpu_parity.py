@@ -419,3 +419,31 @@ def test_ragged_shapes_against_the_oracle(ny, nz, nfreq, npad_y, npad_z, nair):
     po, mo, go = oracle_eval(mesh, data, inv, m + 0.06)
     assert relmax(pj, po) < 1e-9 and gerr(gj, go, ~deep) < 1e-7 and gerr(gj, go, deep) < 5e-6
     ctx.close()
+
+
+def test_fused_back_post_kernel_matches_separate_kernels():
+    """k_back_post (back transform of a 16-row LDS tile + both Jacobi halves + dot products in one kernel) against
+    k_transform_lp<2> + k_post on the same input at the headline size, repeated (timing-dependent faults of MFMA
+    epilogues are sporadic): same arithmetic, so agreement to rounding of the fp32 accumulation order."""
+    mesh, data, inv, m = make_problem("cfg3")
+    ctx = HipContext(mesh, data, inv)
+    ctx.grad(m)
+    rng = np.random.default_rng(1)
+    shape = (ctx.S, ctx.NZP, ctx.NYP)
+
+    def rnd():
+        A = np.zeros(shape, complex)
+        A[:, 1:ctx.nz, 1:ctx.ny] = (rng.standard_normal((ctx.S, ctx.nz - 1, ctx.ny - 1))
+                                    + 1j * rng.standard_normal((ctx.S, ctx.nz - 1, ctx.ny - 1)))
+        return A
+
+    for _ in range(4):
+        Yv, R = rnd(), rnd()
+        Yv[:, :, ctx.ny - 1:] = 0                            # modes live in columns 0 .. ny-2
+        fused, sep, sums = ctx.debug_back_post(Yv, R)
+        fused, sep = fused.reshape(shape), sep.reshape(shape)
+        scale = np.abs(sep).reshape(ctx.S, -1).max(1)[:, None, None]
+        assert np.isfinite(fused).all() and (np.abs(fused - sep) / scale).max() < 1e-6
+        assert abs(sums[0] - sums[2]) + abs(sums[1] - sums[3]) < 1e-6 * (abs(sums[2]) + abs(sums[3]))
+        assert abs(sums[4] - sums[5]) < 1e-6 * sums[5]
+    ctx.close()
