@@ -647,6 +647,9 @@ __device__ __forceinline__ float bf16_to_f32(unsigned h) { return __uint_as_floa
 // accuracy from the bf16 pipe.  (Plain bf16 operands stalled one low-frequency TE system in 32.)
 // B: Bhi/Blo fragment arrays.  OUT: 0 = complex64, 1 = fp64 complex, 2 = fp64 complex + dinv*r (fused
 // first half of the post-smoother).
+constexpr int LP_NRG = 2;          // row groups (of 8 complex rows) a wave transforms per pass, sharing its V fragments
+constexpr int LP_KC = 4;           // k-groups requested together
+
 template <int NTW, int OUT, int FMT>     // FMT 0: A is complex64 (split here); 1: A is pre-split (store_t32)
 __device__ __forceinline__ void transform_lp_body(const float2* __restrict__ Ain, const u4v* __restrict__ Bhi,
                                                   const u4v* __restrict__ Blo, void* __restrict__ Cout,
@@ -655,25 +658,32 @@ __device__ __forceinline__ void transform_lp_body(const float2* __restrict__ Ain
     const int NT = NYP >> 4, KG = (NYP + 31) >> 5;
     const int lj = lane & 15, g = lane >> 4;
     const int part = lj & 1;
-    const int arow = min(m0 + (lj >> 1), M - 1);
-    f4v acc[NTW];
+    int arow[LP_NRG];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) acc[t] = f4v{0, 0, 0, 0};
-    for (int kc = 0; kc < KG; kc += KCH) {
-        f4v a[FMT ? 1 : KCH][4];
-        u4v ahs[FMT ? KCH : 1], als[FMT ? KCH : 1];
-        u4v bh[KCH][NTW], bl[KCH][NTW];
+    for (int rg = 0; rg < LP_NRG; ++rg) arow[rg] = min(m0 + 8 * rg + (lj >> 1), M - 1);
+    f4v acc[LP_NRG][NTW];
 #pragma unroll
-        for (int q = 0; q < KCH; ++q) {
+    for (int rg = 0; rg < LP_NRG; ++rg)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
+    for (int kc = 0; kc < KG; kc += LP_KC) {
+        f4v a[LP_NRG][FMT ? 1 : LP_KC][4];
+        u4v ahs[LP_NRG][FMT ? LP_KC : 1], als[LP_NRG][FMT ? LP_KC : 1];
+        u4v bh[LP_KC][NTW], bl[LP_KC][NTW];
+#pragma unroll
+        for (int q = 0; q < LP_KC; ++q) {
             const int kg = min(kc + q, KG - 1);
-            if (FMT) {
-                const u4v* hp = reinterpret_cast<const u4v*>(reinterpret_cast<const unsigned short*>(Ain) +
-                                                             (long)arow * 4 * NYP + part * NYP + 32 * kg + 8 * g);
-                ahs[q] = hp[0]; als[q] = hp[NYP / 4];            // the lo planes start 2*NYP bf16 = NYP/4 x 16 B later
-            } else {
-                const f4v* ap = reinterpret_cast<const f4v*>(Ain + (long)arow * NYP + 32 * kg + 8 * g);   // 8 complex = 64 B
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a[q][i] = ap[i];
+            for (int rg = 0; rg < LP_NRG; ++rg) {
+                if (FMT) {
+                    const u4v* hp = reinterpret_cast<const u4v*>(reinterpret_cast<const unsigned short*>(Ain) +
+                                                                 (long)arow[rg] * 4 * NYP + part * NYP + 32 * kg + 8 * g);
+                    ahs[rg][q] = hp[0]; als[rg][q] = hp[NYP / 4];            // the lo planes start 2*NYP bf16 = NYP/4 x 16 B later
+                } else {
+                    const f4v* ap = reinterpret_cast<const f4v*>(Ain + (long)arow[rg] * NYP + 32 * kg + 8 * g);   // 8 complex = 64 B
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[rg][q][i] = ap[i];
+                }
             }
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
@@ -682,50 +692,59 @@ __device__ __forceinline__ void transform_lp_body(const float2* __restrict__ Ain
             }
         }
 #pragma unroll
-        for (int q = 0; q < KCH; ++q) {
+        for (int q = 0; q < LP_KC; ++q) {
             if (kc + q < KG) {
-                u4v ahu, alu;
-                if (FMT) { ahu = ahs[q]; alu = als[q]; }
-                else {
-                    // this lane's part (re or im) of its 8 complex values, split into bf16 hi/lo
-                    unsigned hh[8], ll[8];
+                bf8v ah[LP_NRG], al[LP_NRG];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float x0 = part ? a[q][i][1] : a[q][i][0], x1 = part ? a[q][i][3] : a[q][i][2];
-                        hh[2 * i] = bf16_rn(x0); ll[2 * i] = bf16_rn(x0 - bf16_to_f32(hh[2 * i]));
-                        hh[2 * i + 1] = bf16_rn(x1); ll[2 * i + 1] = bf16_rn(x1 - bf16_to_f32(hh[2 * i + 1]));
+                for (int rg = 0; rg < LP_NRG; ++rg) {
+                    u4v ahu, alu;
+                    if (FMT) { ahu = ahs[rg][q]; alu = als[rg][q]; }
+                    else {
+                        // this lane's part (re or im) of its 8 complex values, split into bf16 hi/lo
+                        unsigned hh[8], ll[8];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float x0 = part ? a[rg][q][i][1] : a[rg][q][i][0], x1 = part ? a[rg][q][i][3] : a[rg][q][i][2];
+                            hh[2 * i] = bf16_rn(x0); ll[2 * i] = bf16_rn(x0 - bf16_to_f32(hh[2 * i]));
+                            hh[2 * i + 1] = bf16_rn(x1); ll[2 * i + 1] = bf16_rn(x1 - bf16_to_f32(hh[2 * i + 1]));
+                        }
+                        ahu = u4v{hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16)};
+                        alu = u4v{ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16)};
                     }
-                    ahu = u4v{hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16)};
-                    alu = u4v{ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16)};
+                    // v_mfma_f32_16x16x32_bf16: A[i = lane%16][k = 8*(lane/16) + t], t = 0..7 -- exactly this lane's 8 values
+                    ah[rg] = __builtin_bit_cast(bf8v, ahu); al[rg] = __builtin_bit_cast(bf8v, alu);
                 }
-                // v_mfma_f32_16x16x32_bf16: A[i = lane%16][k = 8*(lane/16) + t], t = 0..7 -- exactly this lane's 8 values
-                const bf8v ah = __builtin_bit_cast(bf8v, ahu), al = __builtin_bit_cast(bf8v, alu);
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) {
                     const bf8v bhf = __builtin_bit_cast(bf8v, bh[q][t]), blf = __builtin_bit_cast(bf8v, bl[q][t]);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blf, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int rg = 0; rg < LP_NRG; ++rg) {
+                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rg], bhf, acc[rg][t], 0, 0, 0);
+                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rg], blf, acc[rg][t], 0, 0, 0);
+                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rg], bhf, acc[rg][t], 0, 0, 0);
+                    }
                 }
             }
         }
     }
-    // D rows 4g+r: (re, im) of complex rows 2g and 2g+1, column 16*(t0+t) + lj
+    // D rows 4g+r: (re, im) of complex rows 2g and 2g+1 of a group, column 16*(t0+t) + lj
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-        const long col = (long)(t0 + t) * 16 + lj;
+    for (int rg = 0; rg < LP_NRG; ++rg)
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const int row = m0 + 2 * g + h2;
-            if (row < M) {
-                const long e = (long)row * NYP + col;
-                const float re = acc[t][2 * h2], im = acc[t][2 * h2 + 1];
-                if (OUT == 0) reinterpret_cast<float2*>(Cout)[e] = float2{re, im};
-                else if (OUT == 1) reinterpret_cast<cplx*>(Cout)[e] = cplx{(double)re, (double)im};
-                else reinterpret_cast<cplx*>(Cout)[e] = cplx{(double)re, (double)im} + dinv[e] * rvec[e];
+        for (int t = 0; t < NTW; ++t) {
+            const long col = (long)(t0 + t) * 16 + lj;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int row = m0 + 8 * rg + 2 * g + h2;
+                if (row < M) {
+                    const long e = (long)row * NYP + col;
+                    const float re = acc[rg][t][2 * h2], im = acc[rg][t][2 * h2 + 1];
+                    if (OUT == 0) reinterpret_cast<float2*>(Cout)[e] = float2{re, im};
+                    else if (OUT == 1) reinterpret_cast<cplx*>(Cout)[e] = cplx{(double)re, (double)im};
+                    else reinterpret_cast<cplx*>(Cout)[e] = cplx{(double)re, (double)im} + dinv[e] * rvec[e];
+                }
             }
         }
-    }
 }
 
 template <int OUT, int FMT>
@@ -735,11 +754,13 @@ __global__ __launch_bounds__(512) void k_transform_lp(const float2* __restrict__
                                                        int M, int NYP, int rowsPerSys, const int* __restrict__ active, int NW, int RG) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rg = wave / NW, nw = wave - rg * NW;
-    const int m0 = (blockIdx.x * RG + rg) * 8;
+    const int m0 = (blockIdx.x * RG + rg) * 8 * LP_NRG;
     if (m0 >= M) return;
     if (active) {
-        const int s0 = m0 / rowsPerSys, s1 = min(m0 + 7, M - 1) / rowsPerSys;
-        if (!active[s0] && !active[s1]) return;
+        const int s0 = m0 / rowsPerSys, s1 = min(m0 + 8 * LP_NRG - 1, M - 1) / rowsPerSys;
+        bool any = false;
+        for (int sy = s0; sy <= s1; ++sy) any = any || active[sy];
+        if (!any) return;
     }
     const int NT = NYP >> 4;
     const int base = NT / NW, extra = NT % NW;
@@ -1871,8 +1892,8 @@ template <int OUT>
 int launch_transform_lp(hmcmt_ctx* ctx, const float2* A, bool transposed, void* C, const int* active) {
     const View& v = ctx->v;
     const int M = v.S * v.NZP, NT = v.NYP / 16;
-    const int groups = (M + 7) / 8;
-    // waves of LP_NTW column tiles; a workgroup holds all NW waves of RG row groups (<= 8 waves)
+    const int groups = (M + 8 * LP_NRG - 1) / (8 * LP_NRG);
+    // waves of LP_NTW column tiles; a workgroup holds all NW waves of RG row-group sets (<= 8 waves)
     const int NW = std::min(8, (NT + LP_NTW - 1) / LP_NTW);      // wider meshes: a wave loops over its tiles
     const int RG = std::max(1, 8 / NW);
     ProfScope ps(ctx, 0);
