@@ -647,43 +647,64 @@ __device__ __forceinline__ float bf16_to_f32(unsigned h) { return __uint_as_floa
 // accuracy from the bf16 pipe.  (Plain bf16 operands stalled one low-frequency TE system in 32.)
 // B: Bhi/Blo fragment arrays.  OUT: 0 = complex64, 1 = fp64 complex, 2 = fp64 complex + dinv*r (fused
 // first half of the post-smoother).
-constexpr int LP_NRG = 2;          // row groups (of 8 complex rows) a wave transforms per pass, sharing its V fragments
+constexpr int LP_NRG = 2;          // row groups (of 8 complex rows) a workgroup transforms per pass
 constexpr int LP_KC = 4;           // k-groups requested together
 
-template <int NTW, int OUT, int FMT>     // FMT 0: A is complex64 (split here); 1: A is pre-split (store_t32)
-__device__ __forceinline__ void transform_lp_body(const float2* __restrict__ Ain, const u4v* __restrict__ Bhi,
+// A-operand fragments of LP_NRG row groups starting at row m0, staged in LDS by the whole workgroup in fragment order:
+//   ast[((rg*KG + kg)*2 + hl)*64 + lane] = the 8 bf16 (hi or lo) lane `lane` feeds the MFMA for row group rg, k-group kg.
+// Every wave of the workgroup multiplies the same rows with its own column tiles, so the rows are fetched (and, for
+// complex64 input, split into bf16 hi/lo) once per workgroup instead of once per wave.
+template <int FMT>       // FMT 0: A is complex64 (split here); 1: A is pre-split (store_t32)
+__device__ __forceinline__ void stage_lp_fragments(u4v* __restrict__ ast, const float2* __restrict__ Ain, int M, int NYP, int m0) {
+    const int KG = (NYP + 31) >> 5;
+    for (int i = threadIdx.x; i < LP_NRG * KG * 64; i += blockDim.x) {
+        const int l = i & 63, kg = (i >> 6) % KG, rg = (i >> 6) / KG;
+        const int lj = l & 15, g = l >> 4, part = lj & 1;
+        const int arow = min(m0 + 8 * rg + (lj >> 1), M - 1);
+        u4v ahu, alu;
+        if (FMT) {
+            const u4v* hp = reinterpret_cast<const u4v*>(reinterpret_cast<const unsigned short*>(Ain) +
+                                                         (long)arow * 4 * NYP + part * NYP + 32 * kg + 8 * g);
+            ahu = hp[0]; alu = hp[NYP / 4];                  // the lo planes start 2*NYP bf16 = NYP/4 x 16 B later
+        } else {
+            const f4v* ap = reinterpret_cast<const f4v*>(Ain + (long)arow * NYP + 32 * kg + 8 * g);   // 8 complex = 64 B
+            unsigned hh[8], ll[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4v v = ap[q];
+                const float x0 = part ? v[1] : v[0], x1 = part ? v[3] : v[2];
+                hh[2 * q] = bf16_rn(x0); ll[2 * q] = bf16_rn(x0 - bf16_to_f32(hh[2 * q]));
+                hh[2 * q + 1] = bf16_rn(x1); ll[2 * q + 1] = bf16_rn(x1 - bf16_to_f32(hh[2 * q + 1]));
+            }
+            ahu = u4v{hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16)};
+            alu = u4v{ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16)};
+        }
+        ast[((rg * KG + kg) * 2 + 0) * 64 + l] = ahu;
+        ast[((rg * KG + kg) * 2 + 1) * 64 + l] = alu;
+    }
+}
+
+template <int NTW, int OUT>
+__device__ __forceinline__ void transform_lp_body(const u4v* __restrict__ ast, const u4v* __restrict__ Bhi,
                                                   const u4v* __restrict__ Blo, void* __restrict__ Cout,
                                                   const cplx* __restrict__ dinv, const cplx* __restrict__ rvec,
                                                   int M, int NYP, int m0, int t0, int lane) {
     const int NT = NYP >> 4, KG = (NYP + 31) >> 5;
     const int lj = lane & 15, g = lane >> 4;
-    const int part = lj & 1;
-    int arow[LP_NRG];
-#pragma unroll
-    for (int rg = 0; rg < LP_NRG; ++rg) arow[rg] = min(m0 + 8 * rg + (lj >> 1), M - 1);
     f4v acc[LP_NRG][NTW];
 #pragma unroll
     for (int rg = 0; rg < LP_NRG; ++rg)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
     for (int kc = 0; kc < KG; kc += LP_KC) {
-        f4v a[LP_NRG][FMT ? 1 : LP_KC][4];
-        u4v ahs[LP_NRG][FMT ? LP_KC : 1], als[LP_NRG][FMT ? LP_KC : 1];
+        u4v ahs[LP_NRG][LP_KC], als[LP_NRG][LP_KC];
         u4v bh[LP_KC][NTW], bl[LP_KC][NTW];
 #pragma unroll
         for (int q = 0; q < LP_KC; ++q) {
             const int kg = min(kc + q, KG - 1);
 #pragma unroll
             for (int rg = 0; rg < LP_NRG; ++rg) {
-                if (FMT) {
-                    const u4v* hp = reinterpret_cast<const u4v*>(reinterpret_cast<const unsigned short*>(Ain) +
-                                                                 (long)arow[rg] * 4 * NYP + part * NYP + 32 * kg + 8 * g);
-                    ahs[rg][q] = hp[0]; als[rg][q] = hp[NYP / 4];            // the lo planes start 2*NYP bf16 = NYP/4 x 16 B later
-                } else {
-                    const f4v* ap = reinterpret_cast<const f4v*>(Ain + (long)arow[rg] * NYP + 32 * kg + 8 * g);   // 8 complex = 64 B
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) a[rg][q][i] = ap[i];
-                }
+                ahs[rg][q] = ast[((rg * KG + kg) * 2 + 0) * 64 + lane]; als[rg][q] = ast[((rg * KG + kg) * 2 + 1) * 64 + lane];
             }
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
@@ -694,34 +715,16 @@ __device__ __forceinline__ void transform_lp_body(const float2* __restrict__ Ain
 #pragma unroll
         for (int q = 0; q < LP_KC; ++q) {
             if (kc + q < KG) {
-                bf8v ah[LP_NRG], al[LP_NRG];
-#pragma unroll
-                for (int rg = 0; rg < LP_NRG; ++rg) {
-                    u4v ahu, alu;
-                    if (FMT) { ahu = ahs[rg][q]; alu = als[rg][q]; }
-                    else {
-                        // this lane's part (re or im) of its 8 complex values, split into bf16 hi/lo
-                        unsigned hh[8], ll[8];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float x0 = part ? a[rg][q][i][1] : a[rg][q][i][0], x1 = part ? a[rg][q][i][3] : a[rg][q][i][2];
-                            hh[2 * i] = bf16_rn(x0); ll[2 * i] = bf16_rn(x0 - bf16_to_f32(hh[2 * i]));
-                            hh[2 * i + 1] = bf16_rn(x1); ll[2 * i + 1] = bf16_rn(x1 - bf16_to_f32(hh[2 * i + 1]));
-                        }
-                        ahu = u4v{hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16)};
-                        alu = u4v{ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16)};
-                    }
-                    // v_mfma_f32_16x16x32_bf16: A[i = lane%16][k = 8*(lane/16) + t], t = 0..7 -- exactly this lane's 8 values
-                    ah[rg] = __builtin_bit_cast(bf8v, ahu); al[rg] = __builtin_bit_cast(bf8v, alu);
-                }
+                // v_mfma_f32_16x16x32_bf16: A[i = lane%16][k = 8*(lane/16) + t], t = 0..7 -- exactly a lane's 8 staged values
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) {
                     const bf8v bhf = __builtin_bit_cast(bf8v, bh[q][t]), blf = __builtin_bit_cast(bf8v, bl[q][t]);
 #pragma unroll
                     for (int rg = 0; rg < LP_NRG; ++rg) {
-                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rg], bhf, acc[rg][t], 0, 0, 0);
-                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rg], blf, acc[rg][t], 0, 0, 0);
-                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rg], bhf, acc[rg][t], 0, 0, 0);
+                        const bf8v ah = __builtin_bit_cast(bf8v, ahs[rg][q]), al = __builtin_bit_cast(bf8v, als[rg][q]);
+                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
+                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blf, acc[rg][t], 0, 0, 0);
+                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
                     }
                 }
             }
@@ -751,10 +754,11 @@ template <int OUT, int FMT>
 __global__ __launch_bounds__(512) void k_transform_lp(const float2* __restrict__ A, const u4v* __restrict__ Bhi,
                                                        const u4v* __restrict__ Blo, void* __restrict__ C,
                                                        const cplx* __restrict__ dinv, const cplx* __restrict__ rvec,
-                                                       int M, int NYP, int rowsPerSys, const int* __restrict__ active, int NW, int RG) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rg = wave / NW, nw = wave - rg * NW;
-    const int m0 = (blockIdx.x * RG + rg) * 8 * LP_NRG;
+                                                       int M, int NYP, int rowsPerSys, const int* __restrict__ active, int NW) {
+    extern __shared__ __attribute__((aligned(16))) char smem_lp[];
+    u4v* ast = reinterpret_cast<u4v*>(smem_lp);
+    const int lane = threadIdx.x & 63, nw = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * 8 * LP_NRG;                 // one set of LP_NRG row groups per workgroup, all waves on it
     if (m0 >= M) return;
     if (active) {
         const int s0 = m0 / rowsPerSys, s1 = min(m0 + 8 * LP_NRG - 1, M - 1) / rowsPerSys;
@@ -762,14 +766,16 @@ __global__ __launch_bounds__(512) void k_transform_lp(const float2* __restrict__
         for (int sy = s0; sy <= s1; ++sy) any = any || active[sy];
         if (!any) return;
     }
+    stage_lp_fragments<FMT>(ast, A, M, NYP, m0);
+    __syncthreads();
     const int NT = NYP >> 4;
     const int base = NT / NW, extra = NT % NW;
     const int ntl = base + (nw < extra ? 1 : 0);
     const int t0 = nw * base + min(nw, extra);
     // two column tiles at a time (a wave owns more than two only on meshes wider than 256 nodes)
     for (int tt = 0; tt < ntl; tt += 2) {
-        if (ntl - tt >= 2) transform_lp_body<2, OUT, FMT>(A, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0 + tt, lane);
-        else transform_lp_body<1, OUT, FMT>(A, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0 + tt, lane);
+        if (ntl - tt >= 2) transform_lp_body<2, OUT>(ast, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0 + tt, lane);
+        else transform_lp_body<1, OUT>(ast, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0 + tt, lane);
     }
 }
 
@@ -1895,16 +1901,16 @@ int launch_transform_lp(hmcmt_ctx* ctx, const float2* A, bool transposed, void* 
     const int groups = (M + 8 * LP_NRG - 1) / (8 * LP_NRG);
     // waves of LP_NTW column tiles; a workgroup holds all NW waves of RG row-group sets (<= 8 waves)
     const int NW = std::min(8, (NT + LP_NTW - 1) / LP_NTW);      // wider meshes: a wave loops over its tiles
-    const int RG = std::max(1, 8 / NW);
     ProfScope ps(ctx, 0);
-    const dim3 grid((groups + RG - 1) / RG), block(64 * NW * RG);
+    const dim3 grid(groups), block(64 * NW);
+    const size_t lds = (size_t)LP_NRG * ((v.NYP + 31) / 32) * 2 * 64 * sizeof(u4v);       // staged A fragments
     const u4v *bh = transposed ? ctx->d_Vtb : ctx->d_Vb, *bl = transposed ? ctx->d_Vtbl : ctx->d_Vbl;
     if (ctx->sv.splitT)        // the input was written pre-split (store_t32 / k_fdm_fwd)
-        hipLaunchKernelGGL((k_transform_lp<OUT, 1>), grid, block, 0, ctx->stream, A, bh, bl, C, ctx->sv.dinv, ctx->sv.r, M, v.NYP,
-                           v.NZP, active, NW, RG);
+        hipLaunchKernelGGL((k_transform_lp<OUT, 1>), grid, block, lds, ctx->stream, A, bh, bl, C, ctx->sv.dinv, ctx->sv.r, M, v.NYP,
+                           v.NZP, active, NW);
     else
-        hipLaunchKernelGGL((k_transform_lp<OUT, 0>), grid, block, 0, ctx->stream, A, bh, bl, C, ctx->sv.dinv, ctx->sv.r, M, v.NYP,
-                           v.NZP, active, NW, RG);
+        hipLaunchKernelGGL((k_transform_lp<OUT, 0>), grid, block, lds, ctx->stream, A, bh, bl, C, ctx->sv.dinv, ctx->sv.r, M, v.NYP,
+                           v.NZP, active, NW);
     return 0;
 }
 
