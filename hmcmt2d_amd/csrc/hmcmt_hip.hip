@@ -25,7 +25,7 @@ using namespace hmcmt;
 
 namespace {
 
-constexpr int MAXNB = 32;          // max partial-sum blocks per system
+constexpr int MAXNB = 64;          // max partial-sum blocks per system (<= 64: one wave sums them, total_part)
 constexpr int VBLOCK = 256;        // threads of the vector kernels
 
 // ----------------------------------------------------------------------------------------------
@@ -2400,12 +2400,14 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], 3 * S * VS) DA(ctx->d_mHist[kd], 4 * (size_t)h.nAC) DA(ctx->d_ext[kd], 8) }
     Solver& k = ctx->sv;
     k.S = h.S; k.NYP = h.NYP; k.NZP = h.NZP; k.ny = h.ny; k.nz = h.nz; k.nFreq = h.nFreq; k.vstride = v.vstride;
-    k.NB = std::max(1, std::min(MAXNB, (1024 + h.S - 1) / h.S));
+    k.NB = std::max(1, std::min(32, (1024 + h.S - 1) / h.S));
     k.chunk = (v.vstride + k.NB - 1) / k.NB;
     // rows per tile of the stencil kernels: about 512 workgroups per launch, at most 8 rows (measured at cfg3:
     // 4 rows 484, 6 rows 489, 8 rows 492, 12 rows 456 steps/s), at least what MAXNB partial sums per system allow
     {
-        const int want = std::min(8, std::max(2, (int)(((long)(h.nz - 1) * h.S + 511) / 512)));
+        // ... and few enough that two workgroups of k_update_fused fit a CU's LDS ((2 RT + 2) rows of NYP complex128)
+        const int ldsRows = std::max(1, (int)((80 * 1024 / ((size_t)h.NYP * sizeof(cplx)) - 2) / 2));
+        const int want = std::min(std::min(8, ldsRows), std::max(2, (int)(((long)(h.nz - 1) * h.S + 511) / 512)));
         const char* e = getenv("HMCMT_RT");
         k.RT = std::max(e ? atoi(e) : want, (h.nz - 1 + MAXNB - 1) / MAXNB);
     }
