@@ -1602,7 +1602,7 @@ __global__ __launch_bounds__(64) void k_bc_forward(View v) {
     const long ls = v.ny + 1, qs = (long)v.nz * ls;
     if (col <= v.ny) {
         X[nidx(v, col, 0)] = cplx{1.0, 0.0};              // top row incl. corners
-        const cplx* T = v.fwdTab + (long)s * 5 * qs + col;
+        const cplx* T = v.fwdTab + (long)s * FWD_NQ * qs + col;
         // ONE instantiation of the recurrence for every lane (a separate call for the edge lanes would make their
         // wave run the whole chain twice, once per divergent path: that was the kernel's critical path)
         const bool isEdge = col == 0 || col == v.ny;
@@ -2392,7 +2392,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     DA(v.pred, h.nData) DA(v.vbar, h.nData) DA(v.misfitPart, h.nData)
     DA(v.srcB, S * 4) DA(v.wL, S * h.nz) DA(v.wR, S * h.nz) DA(v.colw, S * h.ny)
     DA(v.gL, S * h.nz) DA(v.gR, S * h.nz) DA(v.gMn, S * h.nz) DA(v.bcsL, S * h.nz) DA(v.bcsR, S * h.nz) DA(v.bcsB, S)
-    DA(v.fwdTab, S * 5 * (size_t)h.nz * (h.ny + 1)) DA(v.sensTab, S * 15 * (size_t)(h.nz + 1))
+    DA(v.fwdTab, S * FWD_NQ * (size_t)h.nz * (h.ny + 1)) DA(v.sensTab, S * 15 * (size_t)(h.nz + 1))
     DA(v.sensEu, S * 3 * (size_t)(h.nz + 1)) DA(v.sensEd, S * 3 * (size_t)(h.nz + 1)) DA(v.sensMix, S * 12 * (size_t)h.nz)
     DA(v.sensDz1, S * 3 * (size_t)h.nz) DA(v.sensZ1, S * 3) DA(v.sensDead, S * 3)
     DA(v.qPart, S * h.ny) DA(v.gPart, 2 * (size_t)h.nCell) DA(v.grad, h.nAC)

@@ -84,7 +84,7 @@ struct View {
     cplx* bcsL;                    // [S][nz]  sensitivity-version boundary fields (TM term)
     cplx* bcsR;                    // [S][nz]
     cplx* bcsB;                    // [S]      mean-profile bottom value
-    cplx* fwdTab;                  // [S][5][nz][ny+1] per-layer terms of the forward 1-D columns
+    cplx* fwdTab;                  // [S][FWD_NQ][nz][ny+1] per-layer terms of the forward 1-D columns (layer_forward)
     cplx* sensTab;                 // [S][3][5][nz+1]  per-layer terms of the sensitivity profiles
     cplx* sensEu;                  // [S][3][nz+1]     up-going amplitude per row (scratch in stage 2)
     cplx* sensEd;                  // [S][3][nz+1]
@@ -210,20 +210,21 @@ HD void item_pivot(const View& v, int s, int j) {
 
 // --- per-layer terms of the 1-D column under boundary node column `col` (0 = left edge, ny = right
 //     edge, else the width-weighted mean of the two adjacent cell columns, mt2DTE.jl:127-131)
+HD double bc_column_sigma(const View& v, int j, int col) {
+    if (col == 0) return v.sigma[(long)j * v.ny];
+    if (col == v.ny) return v.sigma[(long)j * v.ny + v.ny - 1];
+    const double ya = v.yLen[col - 1], yb = v.yLen[col];
+    return (v.sigma[(long)j * v.ny + col - 1] * ya + v.sigma[(long)j * v.ny + col] * yb) / (ya + yb);
+}
 HD void item_bc_layers(const View& v, int s, int j, int col) {
     if (!v.sysOn[s]) return;
-    double sig;
-    if (col == 0) sig = v.sigma[(long)j * v.ny];
-    else if (col == v.ny) sig = v.sigma[(long)j * v.ny + v.ny - 1];
-    else {
-        const double ya = v.yLen[col - 1], yb = v.yLen[col];
-        sig = (v.sigma[(long)j * v.ny + col - 1] * ya + v.sigma[(long)j * v.ny + col] * yb) / (ya + yb);
-    }
-    cplx t[5];
-    layer_forward(sig, v.omega[s], v.zLen[j], t);
+    const bool lastLayer = j + 1 >= v.nz;
+    const double sig = bc_column_sigma(v, j, col), sigNext = lastLayer ? sig : bc_column_sigma(v, j + 1, col);
+    cplx t[FWD_NQ];
+    layer_forward(sig, sigNext, lastLayer, v.omega[s], v.zLen[j], t);
     const long ls = v.ny + 1, qs = (long)v.nz * ls;
-    cplx* T = v.fwdTab + (long)s * 5 * qs + (long)j * ls + col;
-    for (int q = 0; q < 5; ++q) T[q * qs] = t[q];
+    cplx* T = v.fwdTab + (long)s * FWD_NQ * qs + (long)j * ls + col;
+    for (int q = 0; q < FWD_NQ; ++q) T[q * qs] = t[q];
 }
 
 // --- Dirichlet values of the forward problem written into X's boundary nodes
@@ -234,7 +235,7 @@ HD void item_bc_forward(const View& v, int s, int col) {
     cplx* X = v.X + (long)s * v.vstride;
     X[nidx(v, col, 0)] = cplx{1.0, 0.0};                  // top row incl. corners
     const long ls = v.ny + 1, qs = (long)v.nz * ls;
-    const cplx* T = v.fwdTab + (long)s * 5 * qs + col;
+    const cplx* T = v.fwdTab + (long)s * FWD_NQ * qs + col;
     if (col == 0 || col == v.ny) bc1d_forward_tab(v.omega[s], v.nz, T, qs, ls, tm, X + nidx(v, col, 1), v.NYP);
     else X[nidx(v, col, v.nz)] = bc1d_forward_tab(v.omega[s], v.nz, T, qs, ls, tm, nullptr, 0);
 }

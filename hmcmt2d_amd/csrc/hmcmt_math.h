@@ -104,27 +104,36 @@ HD cplx k_eps(double sig, double omega) {
     return csqrt_(cplx{MU0 * EPS0 * omega * omega, -MU0 * sig * omega});
 }
 
-// per-layer terms: out[0] k, out[1] 1/k, out[2] tanh(i k h), out[3] exp(i k h), out[4] exp(-i k h)
-HD void layer_forward(double sig, double omega, double h, cplx out[5]) {
+// Per-layer terms of one column, everything of the two recurrences that does not depend on the running state
+// (so the serial kernel is left with two 2x2 complex matrix-vector products per layer):
+//   out[0] k                                  out[1] zp = w mu0 / k            out[2] th = tanh(i k h)
+//   out[3] zp * (zp * th)                     -- impedance recurrence (mt1DField.jl:48-56) in projective form
+//   out[4..7] m11 m12 m21 m22 = (pInv*eUD)*e  -- amplitude propagation into the next layer (:69-75), with
+//             kr = k / k_next (1 for the last layer: half-space copy), e = exp(+-i k h)
+constexpr int FWD_NQ = 8;
+HD void layer_forward(double sig, double sigNext, bool lastLayer, double omega, double h, cplx out[FWD_NQ]) {
+    const cplx one = cplx{1.0, 0.0};
     const cplx k = k_eps(sig, omega);
     const cplx ikh = mul_i(k * h);
+    const cplx zp = (omega * MU0) * crecip(k);
+    const cplx th = ctanh_(ikh);
+    const cplx ep = cexp_(ikh), em = cexp_(-ikh);
+    const cplx kr = lastLayer ? one : k * crecip(k_eps(sigNext, omega));
     out[0] = k;
-    out[1] = crecip(k);
-    out[2] = ctanh_(ikh);
-    out[3] = cexp_(ikh);
-    out[4] = cexp_(-ikh);
+    out[1] = zp;
+    out[2] = th;
+    out[3] = zp * (zp * th);
+    out[4] = (0.5 * (one + kr)) * ep; out[5] = (0.5 * (one - kr)) * em;
+    out[6] = (0.5 * (one - kr)) * ep; out[7] = (0.5 * (one + kr)) * em;
 }
 
-// Serial part for one column.  T points at this column's k-entry of layer 0; the five quantities are
-// `qs` elements apart and consecutive layers `ls` elements apart.  `out` (nullable, stride `ostride`)
-// receives F_j/F_0 for j = 1..nz (E for TE, H for TM, mt2DTE.jl:115-124); returns F_nz/F_0.
-// Both recurrences are latency-bound chains, so table entries are fetched RB layers at a time
-// before the dependent arithmetic of those layers starts.
+// Serial part for one column.  T points at this column's k-entry of layer 0; the FWD_NQ quantities are
+// `qs` elements apart and consecutive layers `ls` elements apart.  outf(i, value) receives F_{i+1}/F_0, the
+// normalised field below layer i (E for TE, H for TM, mt2DTE.jl:115-124); returns F_nz/F_0.
+// Table entries are fetched RB layers at a time before the dependent arithmetic of those layers starts.
+// (On the device the edge lanes buffer the outf values in LDS: a global store per layer inside the loop would sit
+// in the same in-order vmcnt queue as the table loads.)
 constexpr int RB = 4;
-// outf(i, value) receives the normalised field below layer i (edge columns); the plain-pointer overload below keeps
-// the original interface.  On the device the edge lanes buffer these values in LDS: a global store per layer
-// inside the loop would sit in the same in-order vmcnt queue as the table loads and add a store round trip to
-// every block of the recurrence (measured: 196 -> %s us for k_bc_forward).
 template <class OutF>
 HD cplx bc1d_forward_tab_f(double omega, int nz, const cplx* T, long qs, long ls, bool compH, OutF outf) {
     const double omu0 = omega * MU0;
@@ -133,29 +142,38 @@ HD cplx bc1d_forward_tab_f(double omega, int nz, const cplx* T, long qs, long ls
     // Z_j = zp (Z + zp th) / (zp + Z th) is a Moebius map: it is carried projectively, Z = N/D, so the serial
     // chain has no division (a robust complex division is ~3 dependent fp64 divides); N and D are rescaled
     // by an exact power of two once per block, and divided once at the top.
-    cplx zn = omu0 * T[qs + (long)(nz - 1) * ls], zd = one;
-    for (int j0 = nz - 1; j0 >= 0; j0 -= RB) {
-        cplx ki[RB], th[RB];
-#pragma unroll
-        for (int t = 0; t < RB; ++t) {
-            const long j = j0 - t >= 0 ? j0 - t : 0;
-            ki[t] = T[qs + j * ls]; th[t] = T[2 * qs + j * ls];
-        }
-#pragma unroll
-        for (int t = 0; t < RB; ++t) {
-            if (j0 - t >= 0) {
-                const cplx zp = omu0 * ki[t];
-                const cplx nn = zp * (zn + (zp * th[t]) * zd);
-                zd = zp * zd + zn * th[t];
-                zn = nn;
-            }
-        }
+    cplx zn = T[qs + (long)(nz - 1) * ls], zd = one;
+    auto rescale = [&]() {
         const int e = -ilogb(fmax(fmax(fabs(zd.re), fabs(zd.im)), fmax(fabs(zn.re), fabs(zn.im))));
         if (e > -1000 && e < 1000) {                     // (zero / inf / nan: leave alone, the division below reports it)
             zn = cplx{ldexp(zn.re, e), ldexp(zn.im, e)};
             zd = cplx{ldexp(zd.re, e), ldexp(zd.im, e)};
         }
+    };
+    int j0 = nz - 1;
+    for (; j0 - (RB - 1) >= 0; j0 -= RB) {               // whole blocks, all entries requested up front
+        cplx c1[RB], c2[RB], c3[RB];
+#pragma unroll
+        for (int t = 0; t < RB; ++t) {
+            const long j = j0 - t;
+            c1[t] = T[qs + j * ls]; c3[t] = T[2 * qs + j * ls]; c2[t] = T[3 * qs + j * ls];
+        }
+#pragma unroll
+        for (int t = 0; t < RB; ++t) {
+            const cplx nn = c1[t] * zn + c2[t] * zd;
+            zd = c1[t] * zd + zn * c3[t];
+            zn = nn;
+        }
+        rescale();
     }
+    for (; j0 >= 0; --j0) {                              // the remaining layers
+        const long j = j0;
+        const cplx a1 = T[qs + j * ls], a3 = T[2 * qs + j * ls], a2 = T[3 * qs + j * ls];
+        const cplx nn = a1 * zn + a2 * zd;
+        zd = a1 * zd + zn * a3;
+        zn = nn;
+    }
+    rescale();
     const cplx ztmp = zn / zd;
     // top-layer up/down-going amplitudes (:62-63)
     cplx kj = T[0];
@@ -166,39 +184,42 @@ HD cplx bc1d_forward_tab_f(double omega, int nz, const cplx* T, long qs, long ls
     const cplx if0 = crecip(f0);
     cplx last = one;
     bool dead = false;
-    for (int i0 = 0; i0 < nz; i0 += RB) {               // :69-83, layer i -> i+1
-        cplx kn_[RB], kin_[RB], ep_[RB], em_[RB];
-#pragma unroll
-        for (int t = 0; t < RB; ++t) {
-            const long i = i0 + t < nz ? i0 + t : nz - 1, in = i + 1 < nz ? i + 1 : nz - 1;
-            kn_[t] = T[in * ls]; kin_[t] = T[qs + in * ls]; ep_[t] = T[3 * qs + i * ls]; em_[t] = T[4 * qs + i * ls];
-        }
-#pragma unroll
-        for (int t = 0; t < RB; ++t) {
-            const int i = i0 + t;
-            if (i < nz) {
-                cplx fn = cplx{0.0, 0.0};
-                if (!dead) {
-                    const bool lastLayer = i + 1 >= nz;  // half-space copy below the last layer
-                    const cplx kn = lastLayer ? kj : kn_[t];
-                    const cplx kr = lastLayer ? one : kj * kin_[t];
-                    // (pInv*eUD)*e, same association as the reference
-                    const cplx m11 = (0.5 * (one + kr)) * ep_[t], m12 = (0.5 * (one - kr)) * em_[t];
-                    const cplx m21 = (0.5 * (one - kr)) * ep_[t], m22 = (0.5 * (one + kr)) * em_[t];
-                    const cplx nu = m11 * eu + m12 * ed;
-                    const cplx nd = m21 * eu + m22 * ed;
-                    const double e2 = cabs2(nu + nd), e1 = cabs2(eu + ed);   // |.|^2: same ordering as |.|
-                    if (e2 - e1 > 0.0 || isnan(e2)) {
-                        dead = true;                     // overflow cut-off: zero from here down
-                    } else {
-                        eu = nu; ed = nd; kj = kn;
-                        fn = compH ? ((ed - eu) * kj) * iomu0 : (eu + ed);
-                    }
-                }
-                last = fn * if0;
-                outf(i, last);
+    // one layer i -> i+1 (:69-83)
+    auto down = [&](int i, cplx kn, cplx a11, cplx a12, cplx a21, cplx a22) {
+        cplx fn = cplx{0.0, 0.0};
+        if (!dead) {
+            const cplx nu = a11 * eu + a12 * ed;
+            const cplx nd = a21 * eu + a22 * ed;
+            const double e2 = cabs2(nu + nd), e1 = cabs2(eu + ed);   // |.|^2: same ordering as |.|
+            if (e2 - e1 > 0.0 || isnan(e2)) {
+                dead = true;                     // overflow cut-off: zero from here down
+            } else {
+                eu = nu; ed = nd; kj = kn;
+                fn = compH ? ((ed - eu) * kj) * iomu0 : (eu + ed);
             }
         }
+        last = fn * if0;
+        outf(i, last);
+    };
+    // whole blocks of RB layers with all table entries requested up front and no conditions around them (inside a
+    // conditional the compiler sinks the loads next to their use: a second memory round trip per block), then the
+    // remaining layers one by one; the last layer of all takes kn = kj (half-space copy below it)
+    int i0 = 0;
+    for (; i0 + RB < nz; i0 += RB) {
+        cplx kn_[RB], m11[RB], m12[RB], m21[RB], m22[RB];
+#pragma unroll
+        for (int t = 0; t < RB; ++t) {
+            const long i = i0 + t;
+            kn_[t] = T[(i + 1) * ls];
+            m11[t] = T[4 * qs + i * ls]; m12[t] = T[5 * qs + i * ls]; m21[t] = T[6 * qs + i * ls]; m22[t] = T[7 * qs + i * ls];
+        }
+#pragma unroll
+        for (int t = 0; t < RB; ++t) down(i0 + t, kn_[t], m11[t], m12[t], m21[t], m22[t]);
+    }
+    for (; i0 < nz; ++i0) {
+        const long i = i0;
+        const cplx kn = (i0 + 1 >= nz) ? kj : T[(i + 1) * ls];
+        down(i0, kn, T[4 * qs + i * ls], T[5 * qs + i * ls], T[6 * qs + i * ls], T[7 * qs + i * ls]);
     }
     return last;
 }

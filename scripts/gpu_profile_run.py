@@ -10,6 +10,6 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 mesh, data, inv = problem(name, False)
 m = S.rough_state(len(inv.strModel))
 ctx = HipContext(mesh, data, inv)
-for _ in range(n):
-    ctx.grad(m)
+for j in range(n):
+    ctx.grad(m + 1e-3 * j)          # (distinct models: identical ones are answered from the memo)
 print(ctx.stats())

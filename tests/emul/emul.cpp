@@ -39,7 +39,7 @@ struct Emul {
         wL.assign((size_t)h.S * h.nz, cplx{0, 0}); wR = wL; gL = wL; gR = wL; gMn = wL; bcsL = wL; bcsR = wL;
         colw.assign((size_t)h.S * h.ny, cplx{0, 0}); bcsB.assign(h.S, cplx{0, 0});
         gPart.assign((size_t)2 * h.nCell, 0); grad.assign(h.nAC, 0); m.assign(h.nAC, 0);
-        fwdTab.assign((size_t)h.S * 5 * h.nz * (h.ny + 1), cplx{0, 0}); sensTab.assign((size_t)h.S * 15 * (h.nz + 1), cplx{0, 0});
+        fwdTab.assign((size_t)h.S * hmcmt::FWD_NQ * h.nz * (h.ny + 1), cplx{0, 0}); sensTab.assign((size_t)h.S * 15 * (h.nz + 1), cplx{0, 0});
         sensEu.assign((size_t)h.S * 3 * (h.nz + 1), cplx{0, 0}); sensEd = sensEu; sensMix.assign((size_t)h.S * 12 * h.nz, cplx{0, 0});
         sensDz1.assign((size_t)h.S * 3 * h.nz, cplx{0, 0}); sensZ1.assign((size_t)h.S * 3, cplx{0, 0}); sensDead.assign((size_t)h.S * 3, 0);
         iters.assign(2 * h.S, 0);
