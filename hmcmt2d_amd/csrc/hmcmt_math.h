@@ -134,6 +134,7 @@ HD void layer_forward(double sig, double sigNext, bool lastLayer, double omega, 
 // (On the device the edge lanes buffer the outf values in LDS: a global store per layer inside the loop would sit
 // in the same in-order vmcnt queue as the table loads.)
 constexpr int RB = 4;
+constexpr int RBF = 8;             // layers per block of the forward recurrences (4: 92 us, 8: 68 us, 16: 75 us for k_bc_forward)
 template <class OutF>
 HD cplx bc1d_forward_tab_f(double omega, int nz, const cplx* T, long qs, long ls, bool compH, OutF outf) {
     const double omu0 = omega * MU0;
@@ -151,15 +152,15 @@ HD cplx bc1d_forward_tab_f(double omega, int nz, const cplx* T, long qs, long ls
         }
     };
     int j0 = nz - 1;
-    for (; j0 - (RB - 1) >= 0; j0 -= RB) {               // whole blocks, all entries requested up front
-        cplx c1[RB], c2[RB], c3[RB];
+    for (; j0 - (RBF - 1) >= 0; j0 -= RBF) {               // whole blocks, all entries requested up front
+        cplx c1[RBF], c2[RBF], c3[RBF];
 #pragma unroll
-        for (int t = 0; t < RB; ++t) {
+        for (int t = 0; t < RBF; ++t) {
             const long j = j0 - t;
             c1[t] = T[qs + j * ls]; c3[t] = T[2 * qs + j * ls]; c2[t] = T[3 * qs + j * ls];
         }
 #pragma unroll
-        for (int t = 0; t < RB; ++t) {
+        for (int t = 0; t < RBF; ++t) {
             const cplx nn = c1[t] * zn + c2[t] * zd;
             zd = c1[t] * zd + zn * c3[t];
             zn = nn;
@@ -201,20 +202,20 @@ HD cplx bc1d_forward_tab_f(double omega, int nz, const cplx* T, long qs, long ls
         last = fn * if0;
         outf(i, last);
     };
-    // whole blocks of RB layers with all table entries requested up front and no conditions around them (inside a
+    // whole blocks of RBF layers with all table entries requested up front and no conditions around them (inside a
     // conditional the compiler sinks the loads next to their use: a second memory round trip per block), then the
     // remaining layers one by one; the last layer of all takes kn = kj (half-space copy below it)
     int i0 = 0;
-    for (; i0 + RB < nz; i0 += RB) {
-        cplx kn_[RB], m11[RB], m12[RB], m21[RB], m22[RB];
+    for (; i0 + RBF < nz; i0 += RBF) {
+        cplx kn_[RBF], m11[RBF], m12[RBF], m21[RBF], m22[RBF];
 #pragma unroll
-        for (int t = 0; t < RB; ++t) {
+        for (int t = 0; t < RBF; ++t) {
             const long i = i0 + t;
             kn_[t] = T[(i + 1) * ls];
             m11[t] = T[4 * qs + i * ls]; m12[t] = T[5 * qs + i * ls]; m21[t] = T[6 * qs + i * ls]; m22[t] = T[7 * qs + i * ls];
         }
 #pragma unroll
-        for (int t = 0; t < RB; ++t) down(i0 + t, kn_[t], m11[t], m12[t], m21[t], m22[t]);
+        for (int t = 0; t < RBF; ++t) down(i0 + t, kn_[t], m11[t], m12[t], m21[t], m22[t]);
     }
     for (; i0 < nz; ++i0) {
         const long i = i0;
