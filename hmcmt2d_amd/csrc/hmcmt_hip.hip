@@ -1452,12 +1452,15 @@ __global__ void k_solve_end(Solver k, int kind, int* __restrict__ recI, double* 
 // collinear steps the cubic through the last four fields is used.  A repeated model (getHamiltonian after
 // the last leapfrog step) keeps the history untouched.
 constexpr int EXT_NP = 4;          // fields kept per solve kind: the current one + 3 earlier ones
+constexpr int EXT_NBLK = 32;       // blocks of the partial-sum pass
 
-__global__ __launch_bounds__(1024) void k_extrap_alpha(const double* __restrict__ mNew, double* hist, int nAC, double* ext, int maxNp) {
-    // steps d0 = m_new - m_k, d_j = m_{k-j+1} - m_{k-j}; sums <d_j,d1> and <d_j,d_j> (j = 0..3), <m_k,m_k>
-    __shared__ double sh[9][16];
-    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = threadIdx.x; i < nAC; i += 1024) {
+// pass 1: per-block partial sums of <d_j,d1>, <d_j,d_j> (j = 0..3; steps d0 = m_new - m_k, d_j = m_{k-j+1} - m_{k-j})
+// and <m_k,m_k>  ->  part[block][8]
+__global__ __launch_bounds__(256) void k_extrap_sums(const double* __restrict__ mNew, const double* __restrict__ hist, int nAC,
+                                                      double* __restrict__ part) {
+    __shared__ double sh[8][4];
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nAC; i += EXT_NBLK * 256) {
         const double mk = hist[i], mk1 = hist[nAC + i], mk2 = hist[2 * nAC + i], mk3 = hist[3 * nAC + i];
         const double d0 = mNew[i] - mk, d1 = mk - mk1, d2 = mk1 - mk2, d3 = mk2 - mk3;
         a[0] += d0 * d1; a[1] += d1 * d1; a[2] += d2 * d1; a[3] += d3 * d1;
@@ -1470,11 +1473,19 @@ __global__ __launch_bounds__(1024) void k_extrap_alpha(const double* __restrict_
         if ((threadIdx.x & 63) == 0) sh[q][w] = a[q];
     }
     __syncthreads();
+    if (threadIdx.x < 8) part[blockIdx.x * 8 + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+
+// pass 2 (one wave): the extrapolation weights from the partial sums
+__global__ __launch_bounds__(64) void k_extrap_weights(const double* __restrict__ part, double* ext, int maxNp) {
+    double a[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        a[q] = 0;
-        for (int j = 0; j < 16; ++j) a[q] += sh[q][j];
+        double v = threadIdx.x < EXT_NBLK ? part[threadIdx.x * 8 + q] : 0.0;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        a[q] = v;
     }
+    if (threadIdx.x != 0) return;
     const int count = (int)ext[5];
     const bool keep = count >= 1 && a[4] <= 1e-28 * a[7];
     double wts[EXT_NP] = {1, 0, 0, 0};                       // weights of x_k, x_{k-1}, x_{k-2}, x_{k-3}
@@ -1497,16 +1508,16 @@ __global__ __launch_bounds__(1024) void k_extrap_alpha(const double* __restrict_
             }
         }
     }
-    __syncthreads();
-    if (!keep)
-        for (int i = threadIdx.x; i < nAC; i += 1024) {
-            hist[3 * nAC + i] = hist[2 * nAC + i]; hist[2 * nAC + i] = hist[nAC + i]; hist[nAC + i] = hist[i]; hist[i] = mNew[i];
-        }
-    if (threadIdx.x == 0) {
-        for (int i = 0; i < EXT_NP; ++i) ext[i] = wts[i];
-        ext[4] = keep ? 1.0 : 0.0;
-        if (!keep) ext[5] = (double)min(count + 1, EXT_NP);
-    }
+    for (int i = 0; i < EXT_NP; ++i) ext[i] = wts[i];
+    ext[4] = keep ? 1.0 : 0.0;
+    if (!keep) ext[5] = (double)min(count + 1, EXT_NP);
+}
+
+// pass 3: the model history moves on (unless the model is a repeat)
+__global__ __launch_bounds__(256) void k_extrap_shift(const double* __restrict__ mNew, double* hist, int nAC, const double* __restrict__ ext) {
+    if (ext[4] != 0.0) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nAC) { hist[3 * nAC + i] = hist[2 * nAC + i]; hist[2 * nAC + i] = hist[nAC + i]; hist[nAC + i] = hist[i]; hist[i] = mNew[i]; }
 }
 
 // x <- sum_j w_j x_{k-j}, history shifted (xp3 <- xp2 <- xp1 <- old x), on interior nodes (runs beside
@@ -1763,7 +1774,8 @@ struct hmcmt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;       // sigma-only sensitivity tables run beside the forward solve
-    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr;
+    hipStream_t side2 = nullptr;      // inverse pivots of the FDM tridiagonals run beside the boundary-value kernels
+    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evFdmz = nullptr, evPiv = nullptr;
     std::vector<void*> allocs;
     std::string err;
     // device scalars / buffers not in View
@@ -2121,6 +2133,15 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     return 0;
 }
 
+// weights of the initial-guess extrapolation for solve kind kd (side stream): partial sums, weights, history shift
+void launch_extrap_weights(hmcmt_ctx* ctx, const double* d_m, int kd) {
+    const int nAC = ctx->v.nAC;
+    double* part = ctx->d_ext[kd] + 8;
+    hipLaunchKernelGGL(k_extrap_sums, dim3(EXT_NBLK), dim3(256), 0, ctx->side, d_m, ctx->d_mHist[kd], nAC, part);
+    hipLaunchKernelGGL(k_extrap_weights, dim3(1), dim3(64), 0, ctx->side, part, ctx->d_ext[kd], ctx->extrapNp);
+    hipLaunchKernelGGL(k_extrap_shift, dim3((nAC + 255) / 256), dim3(256), 0, ctx->side, d_m, ctx->d_mHist[kd], nAC, ctx->d_ext[kd]);
+}
+
 // the whole hot path on device buffers
 int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, double* d_misfit, double* d_grad) {
     View v = ctx->v;
@@ -2152,12 +2173,18 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             HIPCHK(hipMemsetAsync(ctx->d_ext[1], 0, 8 * sizeof(double), st));
         }
         if (extrap || wantGrad) HIPCHK(hipEventRecord(ctx->evModel, st));
-        hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, st, v, 0, 1, 1, 0);
         hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, st, v);
-        if (ctx->opt.precond != HMCMT_PRECOND_JACOBI) {
-            hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 0, st, v);
-            if (ctx->opt.fdm_precision == 0) hipLaunchKernelGGL(k_invp32, dim3(512), dim3(256), 0, st, ctx->sv, ctx->d_invp32);
+        const bool pivots = ctx->opt.precond != HMCMT_PRECOND_JACOBI;
+        if (pivots) {
+            // the inverse pivots of the FDM tridiagonals (a serial recurrence per mode and system, ~40 us) are not
+            // needed before the first preconditioner apply: second side stream, beside the boundary-value kernels
+            HIPCHK(hipEventRecord(ctx->evFdmz, st));
+            HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->evFdmz, 0));
+            hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 0, ctx->side2, v);
+            if (ctx->opt.fdm_precision == 0) hipLaunchKernelGGL(k_invp32, dim3(512), dim3(256), 0, ctx->side2, ctx->sv, ctx->d_invp32);
+            HIPCHK(hipEventRecord(ctx->evPiv, ctx->side2));
         }
+        hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, st, v, 0, 1, 1, 0);
         if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI)
             hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, 0.7);
         hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, S), dim3(64), 0, st, v);
@@ -2169,11 +2196,11 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         // sigma-only sensitivity tables (joined before k_bcsens)
         if (extrap || wantGrad) HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evModel, 0));
         if (extrap) {
-            hipLaunchKernelGGL(k_extrap_alpha, dim3(1), dim3(1024), 0, ctx->side, d_m, ctx->d_mHist[0], v.nAC, ctx->d_ext[0], ctx->extrapNp);
+            launch_extrap_weights(ctx, d_m, 0);
             hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
             HIPCHK(hipEventRecord(ctx->evExtF, ctx->side));
             if (wantGrad) {
-                hipLaunchKernelGGL(k_extrap_alpha, dim3(1), dim3(1024), 0, ctx->side, d_m, ctx->d_mHist[1], v.nAC, ctx->d_ext[1], ctx->extrapNp);
+                launch_extrap_weights(ctx, d_m, 1);
                 hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.Lam, ctx->d_prevField[1], ctx->d_ext[1]);
                 HIPCHK(hipEventRecord(ctx->evExtA, ctx->side));
             }
@@ -2186,6 +2213,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtF, 0));
         // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X
         hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, 1);
+        if (pivots) HIPCHK(hipStreamWaitEvent(st, ctx->evPiv, 0));
     }
     int rc = solve(ctx, v.X, 0);
     ctx->haveFwd = (rc == 0 && ctx->solveDone[0]);
@@ -2288,6 +2316,9 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (ctx->evModel) hipEventDestroy(ctx->evModel);
     if (ctx->evSens) hipEventDestroy(ctx->evSens);
     if (ctx->evExtF) hipEventDestroy(ctx->evExtF);
+    if (ctx->evFdmz) hipEventDestroy(ctx->evFdmz);
+    if (ctx->evPiv) hipEventDestroy(ctx->evPiv);
+    if (ctx->side2) hipStreamDestroy(ctx->side2);
     if (ctx->evExtA) hipEventDestroy(ctx->evExtA);
     if (ctx->side) hipStreamDestroy(ctx->side);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -2307,6 +2338,9 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     HIPCHK(hipEventCreateWithFlags(&ctx->evModel, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evSens, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evExtF, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evFdmz, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evPiv, hipEventDisableTiming));
+    HIPCHK(hipStreamCreate(&ctx->side2));
     {
         const char* e = getenv("HMCMT_FUSED_FWD");
         ctx->fusedFwd = !(e && e[0] == '0');
@@ -2397,7 +2431,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     DA(v.sensDz1, S * 3 * (size_t)h.nz) DA(v.sensZ1, S * 3) DA(v.sensDead, S * 3)
     DA(v.qPart, S * h.ny) DA(v.gPart, 2 * (size_t)h.nCell) DA(v.grad, h.nAC)
     DA(ctx->d_m, h.nAC) DA(ctx->d_misfit, 1)
-    for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], 3 * S * VS) DA(ctx->d_mHist[kd], 4 * (size_t)h.nAC) DA(ctx->d_ext[kd], 8) }
+    for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], 3 * S * VS) DA(ctx->d_mHist[kd], 4 * (size_t)h.nAC) DA(ctx->d_ext[kd], 8 + 8 * EXT_NBLK) }
     Solver& k = ctx->sv;
     k.S = h.S; k.NYP = h.NYP; k.NZP = h.NZP; k.ny = h.ny; k.nz = h.nz; k.nFreq = h.nFreq; k.vstride = v.vstride;
     k.NB = std::max(1, std::min(32, (1024 + h.S - 1) / h.S));
