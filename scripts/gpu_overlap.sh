@@ -11,6 +11,11 @@ ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'
 starts = [i for i, k in enumerate(ks) if k[2] == 'k_sigma']
 a, b = starts[-2], starts[-1]
 t0 = ks[a][0]
-for s, e, n, q in ks[a:b]:
-    if (s - t0) / 1e3 < 420: print(f"{(s - t0) / 1e3:8.1f} .. {(e - t0) / 1e3:8.1f} us  q{q}  {n}")
+import os
+lo, hi = float(os.environ.get("OVL_FROM", "0")), float(os.environ.get("OVL_TO", "420"))
+tend = ks[b][0]
+print("evaluation wall", (tend - t0) / 1e3, "us")
+for s, e, n, q in ks[a:b + 3]:
+    t = (s - t0) / 1e3
+    if hi > 0 and lo <= t < hi or hi < 0 and t > (tend - t0) / 1e3 + hi: print(f"{t:8.1f} .. {(e - t0) / 1e3:8.1f} us  q{q}  {n}")
 PY
