@@ -58,10 +58,26 @@ struct Solver {
     double tol2;
 };
 
+// Sum over the 64 lanes of a wave, the total returned in EVERY lane.  Data-parallel-primitive moves inside the rows
+// of 16 lanes (quad_perm xor 1, xor 2, row_ror 4, row_ror 8: ~4 cycles each) and one v_readlane per row instead of a
+// butterfly of 6 ds_bpermute round trips per 32-bit half (~1 us for the three sums at the end of k_back_post).
+// The order of the additions is fixed, and the final value is formed from lanes 0/16/32/48 only, so it is the same
+// bit pattern in every lane and in every workgroup that reduces the same numbers.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    v += dpp_mov_f64<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x124>(v);         // row_ror:4
+    v += dpp_mov_f64<0x128>(v);         // row_ror:8  -> the sum of the lane's row of 16
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
 // block-wide deterministic sum of up to 2 doubles; result valid in thread 0
@@ -94,14 +110,24 @@ __device__ __forceinline__ void block_sum2_8(double& a, double& b, double* sh) {
     }
 }
 
-// sum of n <= 64 per-block partials by one wave: lane b fetches partial b (one memory latency instead of n in a
-// row), a fixed butterfly of xor-shuffles adds them up, every lane gets the total -- the same value in every wave
-// of every block, so all blocks of a system still agree on alpha / beta / convergence
-__device__ __forceinline__ double wave_total(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+__device__ __forceinline__ void block_sum3_8(double& a, double& b, double& c, double* sh, int nw) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_sum(c);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) { sh[w] = a; sh[8 + w] = b; sh[16 + w] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sa = 0, sb = 0, sc = 0;
+        for (int i = 0; i < nw; ++i) { sa += sh[i]; sb += sh[8 + i]; sc += sh[16 + i]; }
+        a = sa; b = sb; c = sc;
+    }
 }
+
+// sum of n <= 64 per-block partials by one wave: lane b fetches partial b (one memory latency instead of n in a
+// row), a fixed sequence of lane exchanges (wave_sum) adds them up, every lane gets the total -- the same value in every wave
+// of every block, so all blocks of a system still agree on alpha / beta / convergence
+__device__ __forceinline__ double wave_total(double v) { return wave_sum(v); }
 __device__ __forceinline__ double total_part(const double* part, int n) {
     const int l = threadIdx.x & 63;
     return wave_total(l < n ? part[l] : 0.0);
@@ -1064,143 +1090,200 @@ constexpr int BP_OWN = 14;         // interior rows owned by a workgroup (tile =
 
 template <int FMT>
 __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __restrict__ Y, const u4v* __restrict__ Bhi,
-                                                   const u4v* __restrict__ Blo, double* partZZ, int NW) {
+                                                   const u4v* __restrict__ Blo, double* partZZ, int NW, long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
-    const int s = blockIdx.y;
-    if (!k.active[s]) return;
-    __shared__ double sh[16];
-    __shared__ double sh2[16];
+    const int s = blockIdx.y, bx = blockIdx.x, nwg = gridDim.x;
+    const int act = k.active[s];       // tested below, after the first loads are on their way
+#define BP_STAMP(i) if (stamps && threadIdx.x == 0) stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime();
+    BP_STAMP(0)
+    const int bd = NW << 6;            // = blockDim.x, from the kernel argument (a scalar; the implicit-argument load is a vector load here)
+    __shared__ double sh[24];
     cplx* zt = reinterpret_cast<cplx*>(smem_);             // [16][NYP]
     const int NYP = k.NYP, NZP = k.NZP;
-    const int iz0 = 1 + blockIdx.x * BP_OWN, iz1 = min(iz0 + BP_OWN - 1, k.nz - 1), rbase = iz0 - 1;
+    const int iz0 = 1 + bx * BP_OWN, iz1 = min(iz0 + BP_OWN - 1, k.nz - 1), rbase = iz0 - 1;
     const int mode = s >= k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
     const double w = k.omega[s];
     const cplx *r = k.r + so, *di = k.dinv + so;
     cplx* t = k.t + so;
+    const int nown = (iz1 - iz0 + 1) * NYP;
+    // Every phase below is a short dependent chain (global load -> LDS -> barrier -> MFMA -> LDS -> barrier -> stencil),
+    // so loads are issued as early as their addresses are known and unconditionally (clamped indices): inside
+    // `if (row < NZP)` / `if (interior)` the compiler keeps each load next to its use and the phase costs one
+    // memory round trip per element instead of one per batch (s_memtime stamps: epilogue 3.5 -> us, stencil 4.7 -> us).
+    constexpr int SU = 4;               // stencil elements per thread and batch
+    struct Sten { double dk, dm, cy0, cy1, cz0, cz1; cplx rv, dv; int e, iy; };
+    // (uniform base + 32-bit lane offset: one address register per element instead of two per load)
+    const double *dKm = k.dK + mo, *dMm = k.dM + mo, *cYm = k.cY + mo, *cZm = k.cZ + mo, *cZu = k.cZ + mo - NYP;
+    const float rNYP = 1.0f / (float)NYP;
+    auto ld_st = [&](int i, Sten& q) {
+        const int ic = min(i, nown - 1), lr = (int)(((float)ic + 0.5f) * rNYP);      // ic / NYP (exact: ic < 4096)
+        q.iy = ic - lr * NYP;
+        q.e = (iz0 + lr) * NYP + q.iy;
+        const unsigned e = (unsigned)q.e;
+        q.dk = dKm[e]; q.dm = dMm[e];
+        q.cy0 = cYm[e]; q.cy1 = cYm[e - 1u];
+        q.cz0 = cZm[e]; q.cz1 = cZu[e];
+        q.rv = r[e]; q.dv = di[e];
+    };
+    Sten st[SU], st2[SU];           // 14 NYP <= 8 x blockDim elements: two batches per thread
     {
         // both row groups of the tile in one pass over k: a wave's V fragments are loaded once for the two groups
-        const int lane = threadIdx.x & 63, nw = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63, nw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: tile ranges uniform
         const int NT = NYP >> 4, KG = (NYP + 31) >> 5;
-        const int base = NT / NW, extra = NT % NW;
+        const int base = NT == 2 * NW ? 2 : 1, extra = NT - base * NW;      // NW = ceil(NT / 2) waves: no division
         const int ntl = base + (nw < extra ? 1 : 0);
         const int t0 = nw * base + min(nw, extra);
-        const int lj = lane & 15, g = lane >> 4, part = lj & 1;
+        const int lj = lane & 15, g = lane >> 4;
         const float2* Ys = Y + so;
-        constexpr int KC = 4;
-        // The tile's 16 rows of y are the A-operand of every wave: staged once in LDS in fragment order
-        // (ast[((rg*KG + kg)*2 + hl)*64 + lane] = what lane `lane` feeds the MFMA for row group rg, k-group kg)
-        // instead of 7 times through the vector L1.
-        u4v* ast = reinterpret_cast<u4v*>(zt + (long)16 * NYP);
-        for (int i = threadIdx.x; i < 2 * KG * 2 * 64; i += blockDim.x) {
-            const int l = i & 63, hl = (i >> 6) & 1, kg = (i >> 7) % KG, rg = (i >> 7) / KG;
-            const int llj = l & 15, lg = l >> 4;
-            const int arow = min(rbase + 8 * rg + (llj >> 1), NZP - 1);
-            const u4v* hp = reinterpret_cast<const u4v*>(reinterpret_cast<const unsigned short*>(Ys) +
-                                                         (long)arow * 4 * NYP + (llj & 1) * NYP + 32 * kg + 8 * lg);
-            ast[i] = hp[hl ? NYP / 4 : 0];
-        }
-        __syncthreads();
-        (void)part; (void)g;
-        for (int tt = 0; tt < ntl; tt += 2) {
-            const int ntw = min(2, ntl - tt);
-            f4v acc[2][2];
+        constexpr int KC = 8;
+        // epilogue operands dinv, r of the wave's 2 x 2 x 2 accumulator elements per lane
+        cplx dv[2][2][2], rv[2][2][2];
+        auto ld_dr = [&]() {
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
-            for (int kc = 0; kc < KG; kc += KC) {
-                u4v ahs[2][KC], als[2][KC], bh[KC][2], bl[KC][2];
-#pragma unroll
-                for (int q = 0; q < KC; ++q) {
-                    const int kg = min(kc + q, KG - 1);
-#pragma unroll
-                    for (int rg = 0; rg < 2; ++rg) {
-                        ahs[rg][q] = ast[((rg * KG + kg) * 2 + 0) * 64 + lane]; als[rg][q] = ast[((rg * KG + kg) * 2 + 1) * 64 + lane];
-                    }
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    // row = rbase + 8 rg + h2 (uniform) + 2 g (lane), clamped to the mesh (those elements are zeroed below)
+                    const int ru = min(rbase + 8 * rg + h2, NZP - 1);
+                    const unsigned lo = (unsigned)(min(2 * g, NZP - 1 - ru) * NYP + lj);
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        const long bi = ((long)kg * NT + min(t0 + tt + t, NT - 1)) * 64 + lane;
-                        bh[q][t] = Bhi[bi]; bl[q][t] = Blo[bi];
+                        const long ub = (long)ru * NYP + min(t0 + t, NT - 1) * 16;
+                        dv[rg][t][h2] = (di + ub)[lo]; rv[rg][t][h2] = (r + ub)[lo];
                     }
                 }
+        };
+        // The tile's 16 rows of y are the A-operand of every wave: staged once in LDS in fragment order
+        // (ast[((rg*KG + kg)*2 + hl)*64 + lane] = what lane `lane` feeds the MFMA for row group rg, k-group kg)
+        // instead of 7 times through the vector L1.  nast = 256 KG <= 4 x blockDim elements: one batch of 4 per thread.
+        // Wave kg stages k-group kg (the launcher starts NW = KG waves): its 4 fragments (row group, hi/lo).
+        u4v* ast = reinterpret_cast<u4v*>(zt + (long)16 * NYP);
+        constexpr int SG = 4;
+        u4v tmp[SG];
+        {
+            const int llj = lane & 15, lg = lane >> 4;
+            const char* yb = reinterpret_cast<const char*>(Ys) + (long)(32 * nw) * 2;       // uniform part (k-group)
 #pragma unroll
-                for (int q = 0; q < KC; ++q) {
-                    if (kc + q < KG) {
+            for (int u = 0; u < SG; ++u) {
+                const int rg = u >> 1, hl = u & 1;
+                const int arow = min(rbase + 8 * rg + (llj >> 1), NZP - 1);
+                const unsigned off = (unsigned)(((arow * 4 + (llj & 1) + 2 * hl) * NYP + 8 * lg) * 2);   // bytes (bf16 planes re, im, re_lo, im_lo)
+                tmp[u] = *reinterpret_cast<const u4v*>(yb + off);
+            }
+        }
+        // all V fragments of the wave's (at most) two column tiles: KG <= KC k-groups (NYP <= 256, checked by the
+        // launcher).  Issued behind the staging loads and in k order: the staging barrier does not wait for them and
+        // the MFMAs of k-group q start when fragment q has arrived.
+        u4v bh[KC][2], bl[KC][2];
+        {
+            const unsigned loff = (unsigned)lane * 16u;
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            const bf8v bhf = __builtin_bit_cast(bf8v, bh[q][t]), blf = __builtin_bit_cast(bf8v, bl[q][t]);
+            for (int q = 0; q < KC; ++q)
 #pragma unroll
-                            for (int rg = 0; rg < 2; ++rg) {
-                                const bf8v ah = __builtin_bit_cast(bf8v, ahs[rg][q]), al = __builtin_bit_cast(bf8v, als[rg][q]);
-                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
-                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blf, acc[rg][t], 0, 0, 0);
-                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
-                            }
-                        }
+                for (int t = 0; t < 2; ++t) {
+                    const long ub = ((long)min(q, KG - 1) * NT + min(t0 + t, NT - 1)) * 64;
+                    bh[q][t] = *reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(Bhi + ub) + loff);
+                    bl[q][t] = *reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(Blo + ub) + loff);
+                }
+        }
+        BP_STAMP(7)
+        if (!act) return;                                  // (uniform; nothing has been stored yet)
+#pragma unroll
+        for (int u = 0; u < SG; ++u) ast[(((u >> 1) * KG + nw) * 2 + (u & 1)) * 64 + lane] = tmp[u];
+        __syncthreads();
+        BP_STAMP(1)
+        ld_dr();                                             // in flight during the MFMA loop
+        f4v acc[2][2];
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < KC; ++q) {
+            if (q < KG) {
+                bf8v ah[2], al[2];
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg) {
+                    ah[rg] = __builtin_bit_cast(bf8v, ast[((rg * KG + q) * 2 + 0) * 64 + lane]);
+                    al[rg] = __builtin_bit_cast(bf8v, ast[((rg * KG + q) * 2 + 1) * 64 + lane]);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf8v bhf = __builtin_bit_cast(bf8v, bh[q][t]), blf = __builtin_bit_cast(bf8v, bl[q][t]);
+#pragma unroll
+                    for (int rg = 0; rg < 2; ++rg) {
+                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rg], bhf, acc[rg][t], 0, 0, 0);
+                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rg], blf, acc[rg][t], 0, 0, 0);
+                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rg], bhf, acc[rg][t], 0, 0, 0);
                     }
                 }
             }
-            // z = V y + dinv .* r into the tile (rows beyond the mesh: zero)
+        }
+        BP_STAMP(2)
+        // coefficients of the first stencil batch: in flight during the epilogue and the barrier
 #pragma unroll
-            for (int rg = 0; rg < 2; ++rg)
+        for (int u = 0; u < SU; ++u) ld_st(threadIdx.x + u * bd, st[u]);
+        // z = V y + dinv .* r into the tile (rows beyond the mesh: zero)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    if (t < ntw) {
-                        const int col = (t0 + tt + t) * 16 + lj;
+        for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
-                        for (int h2 = 0; h2 < 2; ++h2) {
-                            const int lr = 8 * rg + 2 * g + h2, row = rbase + lr;
-                            cplx val = cplx{0.0, 0.0};
-                            if (row < NZP) {
-                                const long e = (long)row * NYP + col;
-                                val = cplx{(double)acc[rg][t][2 * h2], (double)acc[rg][t][2 * h2 + 1]} + di[e] * r[e];
-                            }
-                            zt[(long)lr * NYP + col] = val;
-                        }
+            for (int t = 0; t < 2; ++t) {
+                if (t < ntl) {
+                    const int col = (t0 + t) * 16 + lj;
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int lr = 8 * rg + 2 * g + h2;
+                        cplx val = cplx{(double)acc[rg][t][2 * h2], (double)acc[rg][t][2 * h2 + 1]} + dv[rg][t][h2] * rv[rg][t][h2];
+                        if (rbase + lr >= NZP) val = cplx{0.0, 0.0};
+                        zt[(long)lr * NYP + col] = val;
                     }
                 }
-        }
+            }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) ld_st(threadIdx.x + (SU + u) * bd, st2[u]);
     }
+    BP_STAMP(3)
     __syncthreads();
-    double ar = 0, ai = 0, zz = 0, dummy = 0;
-    const int nown = (iz1 - iz0 + 1) * NYP;
-    for (int i = threadIdx.x; i < nown; i += blockDim.x) {
-        const int lr = i / NYP, iy = i - lr * NYP;
-        const long e = (long)(iz0 + lr) * NYP + iy;
-        cplx out = cplx{0, 0};
-        if (iy >= 1 && iy <= k.ny - 1) {
-            const int l = (lr + 1) * NYP + iy;
+    BP_STAMP(4)
+    double ar = 0, ai = 0, zz = 0;
+    auto stencil = [&](int i, const Sten& q) {
+        if (i < nown) {
+            const int l = q.e - (rbase * NYP);                 // tile-local index: tile row 0 = mesh row rbase
             const cplx c = zt[l];
-            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
-            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
-            acc += k.cY[mo + e] * zt[l + 1];
-            acc += k.cY[mo + e - 1] * zt[l - 1];
-            acc += k.cZ[mo + e] * zt[l + NYP];
-            acc += k.cZ[mo + e - NYP] * zt[l - NYP];
-            const cplx rv = r[e];
-            out = c + di[e] * (rv - acc);
-            ar += rv.re * out.re - rv.im * out.im;
-            ai += rv.re * out.im + rv.im * out.re;
+            cplx acc = cplx{q.dk * c.re - w * q.dm * c.im, q.dk * c.im + w * q.dm * c.re};
+            acc += q.cy0 * zt[l + 1];
+            acc += q.cy1 * zt[l - 1];
+            acc += q.cz0 * zt[l + NYP];
+            acc += q.cz1 * zt[l - NYP];
+            cplx out = c + q.dv * (q.rv - acc);
+            if (q.iy < 1 || q.iy > k.ny - 1) out = cplx{0, 0};
+            ar += q.rv.re * out.re - q.rv.im * out.im;
+            ai += q.rv.re * out.im + q.rv.im * out.re;
             zz += cabs2(out);
+            t[q.e] = out;
         }
-        t[e] = out;
-    }
+    };
+#pragma unroll
+    for (int u = 0; u < SU; ++u) stencil(threadIdx.x + u * bd, st[u]);
+#pragma unroll
+    for (int u = 0; u < SU; ++u) stencil(threadIdx.x + (SU + u) * bd, st2[u]);
     // the two boundary rows of t stay zero (the stencil kernels read them as halo rows)
-    if (blockIdx.x == 0) for (int i = threadIdx.x; i < NYP; i += blockDim.x) t[i] = cplx{0, 0};
-    if (iz1 == k.nz - 1) for (int i = threadIdx.x; i < NYP; i += blockDim.x) t[(long)k.nz * NYP + i] = cplx{0, 0};
-    block_sum2_8(ar, ai, sh);
-    block_sum2_8(zz, dummy, sh2);
+    if (bx == 0) for (int i = threadIdx.x; i < NYP; i += bd) t[i] = cplx{0, 0};
+    if (iz1 == k.nz - 1) for (int i = threadIdx.x; i < NYP; i += bd) t[(long)k.nz * NYP + i] = cplx{0, 0};
+    BP_STAMP(5)
+    block_sum3_8(ar, ai, zz, sh, NW);
     if (threadIdx.x == 0) {
-        k.partA[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
-        partZZ[(long)s * MAXNB + blockIdx.x] = zz;
+        k.partA[(long)s * MAXNB + bx] = cplx{ar, ai};
+        partZZ[(long)s * MAXNB + bx] = zz;
     }
     // the consumers add up k.NB partial sums per system: clear the slots this launch does not use
-    if (blockIdx.x == 0)
-        for (int b = gridDim.x + threadIdx.x; b < k.NB; b += blockDim.x) {
+    if (bx == 0)
+        for (int b = nwg + threadIdx.x; b < k.NB; b += bd) {
             k.partA[(long)s * MAXNB + b] = cplx{0, 0};
             partZZ[(long)s * MAXNB + b] = 0.0;
         }
+    BP_STAMP(6)
 }
 
 // pre-split planes -> complex64 (hi + lo), tests only
@@ -1469,7 +1552,7 @@ __global__ __launch_bounds__(256) void k_extrap_sums(const double* __restrict__ 
     const int w = threadIdx.x >> 6;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        for (int o = 32; o > 0; o >>= 1) a[q] += __shfl_down(a[q], o);
+        a[q] = wave_sum(a[q]);
         if ((threadIdx.x & 63) == 0) sh[q][w] = a[q];
     }
     __syncthreads();
@@ -1481,9 +1564,7 @@ __global__ __launch_bounds__(64) void k_extrap_weights(const double* __restrict_
     double a[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        double v = threadIdx.x < EXT_NBLK ? part[threadIdx.x * 8 + q] : 0.0;
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        a[q] = v;
+        a[q] = wave_sum(threadIdx.x < EXT_NBLK ? part[threadIdx.x * 8 + q] : 0.0);
     }
     if (threadIdx.x != 0) return;
     const int count = (int)ext[5];
@@ -1803,6 +1884,7 @@ struct hmcmt_ctx {
     int extrapNp = 4;                        // fields used by the initial-guess extrapolation (HMCMT_EXTRAP_POINTS = 2..4)
     bool fusedFwd = true;                    // forward transform + tridiagonal solve in one kernel (HMCMT_FUSED_FWD=0: separate)
     bool fusedBack = true;                   // back transform + post-smoother in one kernel (HMCMT_FUSED_BACK=0: separate)
+    long long* backStamps = nullptr;         // HMCMT_BACK_STAMPS: per-block s_memtime stamps of k_back_post (debug entry only)
     size_t maxLdsBack = 64 * 1024;
     bool twistOn = true;                     // HMCMT_TWIST=0: classic one-sided sweeps in the fused kernel as well
     bool fusedFwdForce = false;              // HMCMT_FUSED_FWD=2: also where the heuristic prefers the separate kernels
@@ -1933,11 +2015,11 @@ int launch_back_post(hmcmt_ctx* ctx) {
     const int NT = k.NYP / 16, NW = std::min(8, (NT + LP_NTW - 1) / LP_NTW);
     const size_t lds = (size_t)16 * k.NYP * sizeof(cplx) + (size_t)2 * ((k.NYP + 31) / 32) * 2 * 64 * 16;   // z tile + staged A fragments
     dim3 vg(k.NB, k.S), vb(VBLOCK);
-    if (k.splitT && ctx->fusedBack && lds <= ctx->maxLdsBack) {
+    if (k.splitT && ctx->fusedBack && lds <= ctx->maxLdsBack && k.NYP <= 256) {      // the kernel holds all of a wave's V fragments: 8 k-groups, 2 tiles
         const int nwg = (k.nz - 1 + BP_OWN - 1) / BP_OWN;
         ProfScope ps(ctx, 0);
         hipLaunchKernelGGL(k_back_post<1>, dim3(nwg, k.S), dim3(64 * NW), lds, ctx->stream, k, k.y32, ctx->d_Vtb, ctx->d_Vtbl,
-                           ctx->d_partZZ, NW);
+                           ctx->d_partZZ, NW, ctx->backStamps);
         return 0;
     }
     int rc;
@@ -2818,6 +2900,28 @@ int hmcmt_debug_back_post(hmcmt_ctx* ctx, const double* y, const double* r, doub
         HIPCHK(hipMemsetAsync(k.t, 0xff, n * sizeof(cplx), ctx->stream));
         ctx->fusedBack = pass == 0;
         rc = launch_back_post(ctx);
+        if (!rc && pass == 0 && getenv("HMCMT_BACK_STAMPS")) {
+            const int nb = ((k.nz - 1 + BP_OWN - 1) / BP_OWN) * k.S;
+            long long* d_st = nullptr;
+            HIPCHK(hipMalloc((void**)&d_st, sizeof(long long) * 8 * nb));
+            HIPCHK(hipMemset(d_st, 0, sizeof(long long) * 8 * nb));
+            ctx->backStamps = d_st;
+            for (int rep = 0; rep < 3 && !rc; ++rep) rc = launch_back_post(ctx);
+            ctx->backStamps = nullptr;
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            std::vector<long long> st(8 * (size_t)nb);
+            HIPCHK(hipMemcpy(st.data(), d_st, sizeof(long long) * 8 * nb, hipMemcpyDeviceToHost));
+            hipFree(d_st);
+            double d[7] = {0, 0, 0, 0, 0, 0, 0};
+            long long tmin = st[0], tmax = st[6];
+            for (int b = 0; b < nb; ++b) {
+                for (int i = 0; i < 6; ++i) d[i] += double(st[8 * b + i + 1] - st[8 * b + i]) / nb;
+                d[6] += double(st[8 * b + 7] - st[8 * b]) / nb;
+                tmin = std::min(tmin, st[8 * b]); tmax = std::max(tmax, st[8 * b + 6]);
+            }
+            fprintf(stderr, "k_back_post stamps (s_memtime ticks, mean over %d blocks): stage %.0f mfma(first pair) %.0f epilogue+rest %.0f barrier %.0f stencil %.0f reduce %.0f | start -> loads issued %.0f | first start -> last end %lld\n",
+                    nb, d[0], d[1], d[2], d[3], d[4], d[5], d[6], tmax - tmin);
+        }
         ctx->fusedBack = keep;
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(out + 2 * pass * n, k.t, n * sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream));
