@@ -1175,17 +1175,29 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
         // all V fragments of the wave's (at most) two column tiles: KG <= KC k-groups (NYP <= 256, checked by the
         // launcher).  Issued behind the staging loads and in k order: the staging barrier does not wait for them and
         // the MFMAs of k-group q start when fragment q has arrived.
+        // Order matters twice.  (1) The vector memory path of a CU serves the requests of all its waves in order, so
+        // one wave's V loads would sit in front of another wave's staging loads and the staging barrier would wait for
+        // (nearly) all of V: a barrier makes sure every wave has issued its staging loads first.  (2) Every workgroup
+        // streams the same V; the 32 workgroups of an XCD (one tile index, 32 systems) start at different k-groups so
+        // that they are on different L2 channels instead of all asking for the same lines at once.
+        __syncthreads();
         u4v bh[KC][2], bl[KC][2];
+        const int rot = s % KG;
         {
             const unsigned loff = (unsigned)lane * 16u;
+            const int tl0 = min(t0, NT - 1), tl1 = min(t0 + 1, NT - 1);
+            const char* ph = reinterpret_cast<const char*>(Bhi + (long)tl0 * 64) + loff;
+            const char* pl = reinterpret_cast<const char*>(Blo + (long)tl0 * 64) + loff;
+            const long d1 = (long)(tl1 - tl0) * 1024, stride = (long)NT * 1024;   // bytes: second tile, next k-group
 #pragma unroll
-            for (int q = 0; q < KC; ++q)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const long ub = ((long)min(q, KG - 1) * NT + min(t0 + t, NT - 1)) * 64;
-                    bh[q][t] = *reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(Bhi + ub) + loff);
-                    bl[q][t] = *reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(Blo + ub) + loff);
+            for (int q = 0; q < KC; ++q) {
+                if (q < KG) {
+                    const int kg = rot + q - (rot + q >= KG ? KG : 0);
+                    const char *qh = ph + kg * stride, *ql = pl + kg * stride;
+                    bh[q][0] = *reinterpret_cast<const u4v*>(qh); bh[q][1] = *reinterpret_cast<const u4v*>(qh + d1);
+                    bl[q][0] = *reinterpret_cast<const u4v*>(ql); bl[q][1] = *reinterpret_cast<const u4v*>(ql + d1);
                 }
+            }
         }
         BP_STAMP(7)
         if (!act) return;                                  // (uniform; nothing has been stored yet)
@@ -1202,11 +1214,12 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
 #pragma unroll
         for (int q = 0; q < KC; ++q) {
             if (q < KG) {
+                const int kg = rot + q - (rot + q >= KG ? KG : 0);
                 bf8v ah[2], al[2];
 #pragma unroll
                 for (int rg = 0; rg < 2; ++rg) {
-                    ah[rg] = __builtin_bit_cast(bf8v, ast[((rg * KG + q) * 2 + 0) * 64 + lane]);
-                    al[rg] = __builtin_bit_cast(bf8v, ast[((rg * KG + q) * 2 + 1) * 64 + lane]);
+                    ah[rg] = __builtin_bit_cast(bf8v, ast[((rg * KG + kg) * 2 + 0) * 64 + lane]);
+                    al[rg] = __builtin_bit_cast(bf8v, ast[((rg * KG + kg) * 2 + 1) * 64 + lane]);
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
