@@ -54,6 +54,7 @@ struct Solver {
     double *partB;                        // [S][MAXNB]  |x|^2 | |z|^2
     cplx *rho, *alphaBeta;                // [S]
     int *active, *iters, *status, *nactive;
+    int* nactHost;                        // pinned host copy of *nactive (device address): the convergence polls only synchronise
     double *errEst;                       // [S] (zz/xx)
     double tol2;
 };
@@ -267,7 +268,7 @@ __global__ void k_check(Solver k, const double* partZZ, int first, int maxit) {
         else atomicAdd(&cnt, 1);
     }
     __syncthreads();
-    if (threadIdx.x == 0) *k.nactive = cnt;
+    if (threadIdx.x == 0) { *k.nactive = cnt; *k.nactHost = cnt; }
 }
 
 // p = z + beta p   (first: p = z)
@@ -1369,23 +1370,60 @@ __global__ void k_invp32(Solver k, float2* dst) {
 // ----------------------------------------------------------------------------------------------
 // Both kernels work on tiles of RT interior rows of one system: the tile plus one halo row above and below
 // is staged in LDS (dynamic, (RT+2)*NYP complex [+ RT*NYP]), so every global value is read once.
+//
+// k_spmv_fused is a chain of short phases (scalars -> stage tile -> barrier -> stencil -> reduce), each a memory round
+// trip long: its loads are issued as early as their addresses are known, in batches of SB elements per thread,
+// unconditionally (clamped indices) and apart from their use -- the per-system partial sums, rho and the first staging
+// batch go out together before the active flag is even tested, the stencil coefficients of the first batch before
+// the staging barrier (11.0 -> 10.3 us; the same treatment of k_update_fused, which moves twice the bytes and sits
+// at 5 TB/s, changed nothing, and neither did computing its dinv from dK, dM instead of loading it).
+constexpr int SB = 4;                  // elements per thread and batch
+struct StenCo { double dk, dm, cy0, cy1, cz0, cz1; };
+
+__device__ __forceinline__ int div_small(int i, float rcp) { return (int)(((float)i + 0.5f) * rcp); }   // i / n for i < 2^20, rcp = 1/n
+
 __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* partZZ, const cplx* pin_, cplx* pout, int it, int maxit) {
     const int s = blockIdx.y;
-    if (!k.active[s]) return;
     extern __shared__ __attribute__((aligned(16))) char smem_[];
     cplx* pn = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]
     __shared__ double sh[8];
-    const cplx rz = total_part(k.partA + (long)s * MAXNB, k.NB);
-    double zz = total_part(partZZ + (long)s * MAXNB, k.NB);
-    const double xx = total_part(k.partB + (long)s * MAXNB, k.NTR);
     const bool first = it == 1;
+    const int act = k.active[s];
+    const int ln = threadIdx.x & 63;
+    // the system's partial sums (lane b fetches partial b), rho of the previous iteration
+    const cplx paL = ln < k.NB ? k.partA[(long)s * MAXNB + ln] : cplx{0, 0};
+    const double pzL = ln < k.NB ? partZZ[(long)s * MAXNB + ln] : 0.0;
+    const double pbL = ln < k.NTR ? k.partB[(long)s * MAXNB + ln] : 0.0;
+    const cplx rhoPrev = k.rho2[(long)((it - 1) & 1) * k.S + s];
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx *z = k.z + so, *pi = pin_ + so;
+    cplx *po = pout + so, *q = k.q + so;
+    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);   // own rows iz0..iz1
+    const float rNYP = 1.0f / (float)NYP;
+    // rows iz0-1 .. iz1+1 of the new direction (z, p vanish on boundary / pad nodes: no masking needed)
+    const int nrows = iz1 - iz0 + 3, ntot = nrows * NYP, ebase = (iz0 - 1) * NYP;
+    cplx zv[SB], pv[SB];
+    auto ld_stage = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const unsigned e = (unsigned)(ebase + min(i0 + u * VBLOCK, ntot - 1));
+            zv[u] = z[e];
+            pv[u] = first ? cplx{0, 0} : pi[e];
+        }
+    };
+    ld_stage(threadIdx.x);
+    if (!act) return;
+    const cplx rz = cplx{wave_sum(paL.re), wave_sum(paL.im)};
+    const double zz = wave_sum(pzL), xx = wave_sum(pbL);
     bool on = true;
     int st = 0;
     if (first) { if (zz == 0.0) on = false; }
     else if (zz <= k.tol2 * xx) on = false;
     else if (it - 1 >= maxit) { on = false; st = HMCMT_ENOCONV; }
     if (!(isfinite(rz.re) && isfinite(rz.im) && isfinite(zz) && isfinite(xx))) { on = false; st = HMCMT_EBREAKDOWN; }
-    const cplx be = first ? cplx{0, 0} : rz / k.rho2[(long)((it - 1) & 1) * k.S + s];
+    const cplx be = first ? cplx{0, 0} : rz / rhoPrev;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         k.rho2[(long)(it & 1) * k.S + s] = rz;
         k.iters[s] = it - 1;
@@ -1395,42 +1433,55 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
     if (!on) {
         // every block of this system takes the same decision; block 0 records it (a block that starts late and
         // already sees the cleared flag returns just the same)
-        if (blockIdx.x == 0 && threadIdx.x == 0) { k.active[s] = 0; atomicSub(k.nactive, 1); }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { k.active[s] = 0; if (atomicSub(k.nactive, 1) == 1) *k.nactHost = 0; }
         return;
     }
-    const int mode = s >= k.nFreq;
-    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
-    const double w = k.omega[s];
-    const cplx *z = k.z + so, *pi = pin_ + so;
-    cplx *po = pout + so, *q = k.q + so;
-    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);   // own rows iz0..iz1
-    // stage rows iz0-1 .. iz1+1 of the new direction (z, p vanish on boundary / pad nodes: no masking needed)
-    const int nrows = iz1 - iz0 + 3;
-    for (int i = threadIdx.x; i < nrows * NYP; i += VBLOCK) {
-        const int lr = i / NYP, iy = i - lr * NYP;
-        const long e = (long)(iz0 - 1 + lr) * NYP + iy;
-        const cplx v = first ? z[e] : z[e] + be * pi[e];
-        pn[i] = v;
-        if (lr >= 1 && lr <= nrows - 2) po[e] = v;
+    for (int i0 = threadIdx.x; i0 < ntot; i0 += SB * VBLOCK) {
+        if (i0 != (int)threadIdx.x) ld_stage(i0);
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int i = i0 + u * VBLOCK;
+            if (i < ntot) {
+                const cplx v = first ? zv[u] : zv[u] + be * pv[u];
+                pn[i] = v;
+                if (i >= NYP && i < ntot - NYP) po[ebase + i] = v;
+            }
+        }
     }
+    const int nown = (iz1 - iz0 + 1) * NYP, obase = iz0 * NYP;
+    const double *dKm = k.dK + mo, *dMm = k.dM + mo, *cYm = k.cY + mo, *cZm = k.cZ + mo, *cZu = k.cZ + mo - NYP;
+    StenCo co[SB];
+    auto ld_co = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const unsigned e = (unsigned)(obase + min(i0 + u * VBLOCK, nown - 1));
+            co[u].dk = dKm[e]; co[u].dm = dMm[e];
+            co[u].cy0 = cYm[e]; co[u].cy1 = cYm[e - 1u];
+            co[u].cz0 = cZm[e]; co[u].cz1 = cZu[e];
+        }
+    };
+    ld_co(threadIdx.x);
     __syncthreads();
     double ar = 0, ai = 0;
-    const int nown = (iz1 - iz0 + 1) * NYP;
-    for (int i = threadIdx.x; i < nown; i += VBLOCK) {
-        const int lr = i / NYP, iy = i - lr * NYP;
-        if (iy >= 1 && iy <= k.ny - 1) {
-            const long e = (long)(iz0 + lr) * NYP + iy;
-            const int l = (lr + 1) * NYP + iy;
-            const cplx pc = pn[l];
-            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
-            cplx acc = cplx{dk * pc.re - dm * pc.im, dk * pc.im + dm * pc.re};
-            acc += k.cY[mo + e] * pn[l + 1];
-            acc += k.cY[mo + e - 1] * pn[l - 1];
-            acc += k.cZ[mo + e] * pn[l + NYP];
-            acc += k.cZ[mo + e - NYP] * pn[l - NYP];
-            q[e] = acc;
-            ar += pc.re * acc.re - pc.im * acc.im;
-            ai += pc.re * acc.im + pc.im * acc.re;
+    for (int i0 = threadIdx.x; i0 < nown; i0 += SB * VBLOCK) {
+        if (i0 != (int)threadIdx.x) ld_co(i0);
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int i = i0 + u * VBLOCK;
+            const int iy = i - div_small(i, rNYP) * NYP;
+            if (i < nown && iy >= 1 && iy <= k.ny - 1) {
+                const int l = i + NYP;
+                const cplx pc = pn[l];
+                const double dm = w * co[u].dm;
+                cplx acc = cplx{co[u].dk * pc.re - dm * pc.im, co[u].dk * pc.im + dm * pc.re};
+                acc += co[u].cy0 * pn[l + 1];
+                acc += co[u].cy1 * pn[l - 1];
+                acc += co[u].cz0 * pn[l + NYP];
+                acc += co[u].cz1 * pn[l - NYP];
+                q[obase + i] = acc;
+                ar += pc.re * acc.re - pc.im * acc.im;
+                ai += pc.re * acc.im + pc.im * acc.re;
+            }
         }
     }
     block_sum2(ar, ai, sh);
@@ -1523,6 +1574,7 @@ __global__ void k_solve_begin(Solver k, const int* __restrict__ sysOn) {
         int n = 0;
         for (int s = 0; s < k.S; ++s) n += sysOn[s];
         *k.nactive = n;
+        *k.nactHost = n;
     }
 }
 
@@ -1886,7 +1938,7 @@ struct hmcmt_ctx {
     double* h_stage = nullptr;            // m / grad / pred / misfit staging
     size_t stageDoubles = 0;
     std::vector<int> itersLast;           // [2*S]
-    double* d_rec = nullptr;              // device copy of h_rec, filled by k_solve_end
+    double* d_recHost = nullptr;          // device address of h_rec (pinned, mapped): k_solve_end writes it directly
     bool solveDone[2] = {true, true};
     int lastItFwd = 0, lastItAdj = 0;
     bool haveModel = false;
@@ -2155,9 +2207,8 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             // decide convergence of the state after iteration it-1, p = z + beta p, q = A p
             { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv_fused, dim3(k.NTR, S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit); }
             if (it - 1 >= nextCheck || it - 1 == ctx->opt.maxit) {
-                HIPCHK(hipMemcpyAsync(ctx->h_nactive, k.nactive, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(hipStreamSynchronize(ctx->stream));
-                if (*ctx->h_nactive == 0) { done = true; break; }
+                if (*(volatile int*)ctx->h_nactive == 0) { done = true; break; }
                 nextCheck = it - 1 + every;
             }
             { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused, dim3(k.NTR, S), vb, (size_t)(2 * k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it); }
@@ -2170,9 +2221,8 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
         }
         if (!done) {
             // stragglers (or the iteration cap): read the counter once more, then hand over to the classic loop
-            HIPCHK(hipMemcpyAsync(ctx->h_nactive, k.nactive, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            if (*ctx->h_nactive == 0) done = true;
+            if (*(volatile int*)ctx->h_nactive == 0) done = true;
         }
         k.p = pb[it & 1];                // current search direction (only needed by the classic restart below)
         k.p2 = pb[(it - 1) & 1];
@@ -2199,9 +2249,8 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_check, dim3(1), dim3(128), 0, ctx->stream, k, ctx->d_partZZ, 0, ctx->opt.maxit); }
             { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_pupdate, vg, vb, 0, ctx->stream, k, 0); }
             if (it >= nextCheck || it == ctx->opt.maxit) {
-                HIPCHK(hipMemcpyAsync(ctx->h_nactive, k.nactive, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHK(hipStreamSynchronize(ctx->stream));
-                if (*ctx->h_nactive == 0) done = true;
+                if (*(volatile int*)ctx->h_nactive == 0) done = true;
                 nextCheck = it + every;
             }
         }
@@ -2211,7 +2260,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     guess = it;        // (launched iterations; collect_stats replaces it with the iterations actually needed)
     ctx->solveDone[kind] = done;
     // iteration counts / status / error estimates stay on the device; evaluate() reads both solves back at once
-    hipLaunchKernelGGL(k_solve_end, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, k, kind, (int*)ctx->d_rec, ctx->d_rec + 2 * S);
+    hipLaunchKernelGGL(k_solve_end, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, k, kind, (int*)ctx->d_recHost, ctx->d_recHost + 2 * S);
     if (ctx->opt.verify) {
         hipLaunchKernelGGL(k_trueres, vg, vb, 0, ctx->stream, k, ctx->d_b, x, ctx->d_partRes, ctx->d_partBn);
         std::vector<double> pr((size_t)S * MAXNB), pb((size_t)S * MAXNB);
@@ -2348,7 +2397,6 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
 // after the final stream sync of an evaluation: read both solves' records back and fill the statistics
 int collect_stats(hmcmt_ctx* ctx, bool withAdjoint) {
     const int S = ctx->v.S, nk = withAdjoint ? 2 : 1;
-    HIPCHK(hipMemcpyAsync(ctx->h_rec, ctx->d_rec, sizeof(double) * 4 * S, hipMemcpyDeviceToHost, ctx->stream));
     const int* h_iters = reinterpret_cast<const int*>(ctx->h_rec);
     const int* h_status = h_iters + 2 * S;
     const double* h_err = ctx->h_rec + 2 * S;
@@ -2550,11 +2598,13 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     DA(k.partA, S * MAXNB) DA(k.partB, S * MAXNB) DA(ctx->d_partZZ, S * MAXNB)
     DA(ctx->d_partRes, S * MAXNB) DA(ctx->d_partBn, S * MAXNB)
     DA(k.rho, S) DA(k.alphaBeta, S) DA(k.active, S) DA(k.iters, S) DA(k.status, S) DA(k.nactive, 1) DA(k.errEst, S)
-    DA(ctx->d_b, S * VS) DA(ctx->d_rec, 4 * S)
+    DA(ctx->d_b, S * VS)
     DA(ctx->d_fieldsOut, (size_t)h.nFreq * (h.ny + 1) * (h.nz + 1))
 #undef DA
-    HIPCHK(hipHostMalloc((void**)&ctx->h_nactive, sizeof(int)));
-    HIPCHK(hipHostMalloc((void**)&ctx->h_rec, sizeof(double) * 4 * h.S));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_nactive, sizeof(int), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void**)&k.nactHost, ctx->h_nactive, 0));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_rec, sizeof(double) * 4 * h.S, hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void**)&ctx->d_recHost, ctx->h_rec, 0));
     ctx->stageDoubles = (size_t)h.nAC * 4 + (size_t)h.nData * 2 + 16;
     HIPCHK(hipHostMalloc((void**)&ctx->h_stage, sizeof(double) * ctx->stageDoubles));
     ctx->itersLast.assign(2 * h.S, 0);
