@@ -1948,6 +1948,8 @@ struct hmcmt_ctx {
     double* d_ext[2] = {nullptr, nullptr};       // {w0, w1, w2, keep, count}
     int extrapNp = 4;                        // fields used by the initial-guess extrapolation (HMCMT_EXTRAP_POINTS = 2..4)
     bool fusedFwd = true;                    // forward transform + tridiagonal solve in one kernel (HMCMT_FUSED_FWD=0: separate)
+    View sideView; const double* sideM = nullptr;   // deferred side-stream launches of the adjoint half (launch_adjoint_side)
+    bool sidePending = false, sideExtrap = false, sideSens = false;
     bool fusedBack = true;                   // back transform + post-smoother in one kernel (HMCMT_FUSED_BACK=0: separate)
     long long* backStamps = nullptr;         // HMCMT_BACK_STAMPS: per-block s_memtime stamps of k_back_post (debug entry only)
     size_t maxLdsBack = 64 * 1024;
@@ -2175,6 +2177,8 @@ int apply_precond(hmcmt_ctx* ctx) {
     return 0;
 }
 
+void launch_adjoint_side(hmcmt_ctx* ctx);
+
 // Solves A x = r for all systems (x zero on interior on entry; r destroyed).  kind 0 forward, 1 adjoint.
 int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     Solver& k = ctx->sv;
@@ -2199,6 +2203,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     cplx* const r_entry = k.r;
     if (fused) {
         { int prc = apply_precond(ctx); if (prc) return prc; }          // z = P^-1 r and the partial sums of r'z, |z|^2
+        if (kind == 0) launch_adjoint_side(ctx);
         cplx* pb[2] = {k.p, k.p2};
         cplx* rb[2] = {k.r, k.r2};
         int rcur = 0;
@@ -2286,6 +2291,26 @@ void launch_extrap_weights(hmcmt_ctx* ctx, const double* d_m, int kd) {
     hipLaunchKernelGGL(k_extrap_shift, dim3((nAC + 255) / 256), dim3(256), 0, ctx->side, d_m, ctx->d_mHist[kd], nAC, ctx->d_ext[kd]);
 }
 
+// side stream, beside the forward solve: the adjoint initial guess and the sigma-only sensitivity tables (joined
+// before the adjoint residual / before k_bcsens).  Called when the main queue is well filled, so that the host's
+// dozen API calls do not leave the device idle.
+void launch_adjoint_side(hmcmt_ctx* ctx) {
+    if (!ctx->sidePending) return;
+    ctx->sidePending = false;
+    const View& v = ctx->sideView;
+    const int S = v.S;
+    if (ctx->sideExtrap) {
+        launch_extrap_weights(ctx, ctx->sideM, 1);
+        hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.Lam, ctx->d_prevField[1], ctx->d_ext[1]);
+        hipEventRecord(ctx->evExtA, ctx->side);
+    }
+    if (ctx->sideSens) {
+        hipLaunchKernelGGL(k_sens_layers, dim3((v.nz + 1 + 63) / 64, 3, S), dim3(64), 0, ctx->side, v);
+        hipLaunchKernelGGL(k_sens_profile, dim3((3 * S + 63) / 64), dim3(64), 0, ctx->side, v);
+        hipEventRecord(ctx->evSens, ctx->side);
+    }
+}
+
 // the whole hot path on device buffers
 int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, double* d_misfit, double* d_grad) {
     View v = ctx->v;
@@ -2319,47 +2344,44 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         if (extrap || wantGrad) HIPCHK(hipEventRecord(ctx->evModel, st));
         hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, st, v);
         const bool pivots = ctx->opt.precond != HMCMT_PRECOND_JACOBI;
-        if (pivots) {
-            // the inverse pivots of the FDM tridiagonals (a serial recurrence per mode and system, ~40 us) are not
-            // needed before the first preconditioner apply: second side stream, beside the boundary-value kernels
-            HIPCHK(hipEventRecord(ctx->evFdmz, st));
-            HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->evFdmz, 0));
-            hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 0, ctx->side2, v);
-            if (ctx->opt.fdm_precision == 0) hipLaunchKernelGGL(k_invp32, dim3(512), dim3(256), 0, ctx->side2, ctx->sv, ctx->d_invp32);
-            HIPCHK(hipEventRecord(ctx->evPiv, ctx->side2));
-        }
+        if (pivots) HIPCHK(hipEventRecord(ctx->evFdmz, st));
+        // The start of an evaluation is bound by the host's launch rate (the queues are empty after the previous
+        // evaluation's sync), so the order of the API calls is the schedule: first the main stream's coefficient and
+        // boundary-value kernels (0.17 ms of device work), then what must be finished when they are -- the
+        // extrapolated forward guess (side stream) and the inverse pivots (second side stream) --, then the
+        // forward residual, and only then the side-stream work the adjoint half needs.
         hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, st, v, 0, 1, 1, 0);
         if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI)
             hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, 0.7);
         hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, S), dim3(64), 0, st, v);
         hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, S), dim3(64), 0, st, v);
-        // (issued by the host AFTER the main stream's coefficient / boundary-value kernels, so the main queue never
-        // runs dry while the host is busy with these launches)
-        // side stream, beside the coefficient / boundary-value kernels and the forward solve: the extrapolation of
-        // both initial guesses (interior nodes only -- k_bc_forward owns the boundary nodes of X) and the
-        // sigma-only sensitivity tables (joined before k_bcsens)
+        // side stream: the extrapolation of the forward initial guess (interior nodes only -- k_bc_forward owns the
+        // boundary nodes of X)
         if (extrap || wantGrad) HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evModel, 0));
         if (extrap) {
             launch_extrap_weights(ctx, d_m, 0);
             hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
             HIPCHK(hipEventRecord(ctx->evExtF, ctx->side));
-            if (wantGrad) {
-                launch_extrap_weights(ctx, d_m, 1);
-                hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.Lam, ctx->d_prevField[1], ctx->d_ext[1]);
-                HIPCHK(hipEventRecord(ctx->evExtA, ctx->side));
-            }
         }
-        if (wantGrad) {
-            hipLaunchKernelGGL(k_sens_layers, dim3((v.nz + 1 + 63) / 64, 3, S), dim3(64), 0, ctx->side, v);
-            hipLaunchKernelGGL(k_sens_profile, dim3((3 * S + 63) / 64), dim3(64), 0, ctx->side, v);
-            HIPCHK(hipEventRecord(ctx->evSens, ctx->side));
+        if (pivots) {
+            // the inverse pivots of the FDM tridiagonals (a serial recurrence per mode and system, ~70 us) are not
+            // needed before the first preconditioner apply: second side stream, beside the boundary-value kernels
+            HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->evFdmz, 0));
+            hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 0, ctx->side2, v);
+            if (ctx->opt.fdm_precision == 0) hipLaunchKernelGGL(k_invp32, dim3(512), dim3(256), 0, ctx->side2, ctx->sv, ctx->d_invp32);
+            HIPCHK(hipEventRecord(ctx->evPiv, ctx->side2));
         }
         if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtF, 0));
         // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X
         hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, 1);
         if (pivots) HIPCHK(hipStreamWaitEvent(st, ctx->evPiv, 0));
+        // (the adjoint half's side-stream work -- its initial guess, the sigma-only sensitivity tables -- is launched
+        // from inside the forward solve, once the main queue holds the first preconditioner apply: launch_adjoint_side)
+        ctx->sideView = v; ctx->sideM = d_m; ctx->sideExtrap = extrap && wantGrad; ctx->sideSens = wantGrad;
+        ctx->sidePending = wantGrad;
     }
     int rc = solve(ctx, v.X, 0);
+    launch_adjoint_side(ctx);            // (no-op when the solve has already done it)
     ctx->haveFwd = (rc == 0 && ctx->solveDone[0]);
     if (rc) return rc;
     {
