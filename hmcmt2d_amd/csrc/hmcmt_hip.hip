@@ -1801,11 +1801,38 @@ __global__ void k_misfit(View v, double* out) {
     block_sum2(a, b, sh);
     if (threadIdx.x == 0) *out = a;
 }
+// Between the two solves: per (system, receiver) the impedance (+ its derivatives), then the residual / misfit terms of
+// the data that address this receiver and their sum of conj(W'W r) -- one launch instead of three in a row on the
+// critical path (a datum belongs to exactly one (system, receiver), so there is no cross-thread dependency; the
+// misfit itself, a reduction over all data, is not needed by the adjoint half and is summed after the sources).
+__global__ void k_rxall(View v, int wantGrad) {
+    const int e = TID1;
+    if (e >= v.S * v.nRx) return;
+    const int s = e / v.nRx, r = e % v.nRx;
+    item_rx(v, s, r, wantGrad != 0);
+    cplx c = cplx{0, 0};
+    for (int t = v.srStart[e]; t < v.srStart[e + 1]; ++t) {
+        const int p = v.srList[t];
+        item_resid(v, p);
+        c += v.vbar[p];
+    }
+    if (wantGrad) v.rxCoef[e] = c;
+}
 __global__ void k_rxcoef(View v) { int e = TID1; if (e < v.S * v.nRx) item_rxcoef(v, e / v.nRx, e % v.nRx); }
-__global__ void k_src(View v) {
+// adjoint sources; workgroup (0,0) also adds up the misfit terms (a reduction nothing on the device waits for: no
+// launch of its own on the critical path between the solves)
+__global__ __launch_bounds__(128) void k_src(View v, double* misfitOut) {
     int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
-    if (e >= 2 * (v.ny + 1)) return;
-    item_src(v, s, e / (v.ny + 1), e % (v.ny + 1));
+    if (e < 2 * (v.ny + 1)) item_src(v, s, e / (v.ny + 1), e % (v.ny + 1));
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        __shared__ double sh[2];
+        double a = 0;
+        for (int p = threadIdx.x; p < v.nData; p += 128) a += v.misfitPart[p];
+        a = wave_sum(a);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) *misfitOut = sh[0] + sh[1];
+    }
 }
 __global__ void k_wb(View v) {
     int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
@@ -2203,7 +2230,6 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     cplx* const r_entry = k.r;
     if (fused) {
         { int prc = apply_precond(ctx); if (prc) return prc; }          // z = P^-1 r and the partial sums of r'z, |z|^2
-        if (kind == 0) launch_adjoint_side(ctx);
         cplx* pb[2] = {k.p, k.p2};
         cplx* rb[2] = {k.r, k.r2};
         int rcur = 0;
@@ -2223,6 +2249,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             if ((prc = launch_fdm_fwd(ctx))) return prc;
             if ((prc = launch_back_post(ctx))) return prc;
             std::swap(k.z, k.t);
+            if (kind == 0 && it == 2) launch_adjoint_side(ctx);   // (the queue holds two iterations: the host has time for a dozen calls)
         }
         if (!done) {
             // stragglers (or the iteration cap): read the counter once more, then hand over to the classic loop
@@ -2376,7 +2403,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, 1);
         if (pivots) HIPCHK(hipStreamWaitEvent(st, ctx->evPiv, 0));
         // (the adjoint half's side-stream work -- its initial guess, the sigma-only sensitivity tables -- is launched
-        // from inside the forward solve, once the main queue holds the first preconditioner apply: launch_adjoint_side)
+        // from inside the forward solve, once the main queue holds two iterations: launch_adjoint_side)
         ctx->sideView = v; ctx->sideM = d_m; ctx->sideExtrap = extrap && wantGrad; ctx->sideSens = wantGrad;
         ctx->sidePending = wantGrad;
     }
@@ -2386,17 +2413,14 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     if (rc) return rc;
     {
         ProfScope ps(ctx, 5);
-        hipLaunchKernelGGL(k_rx, grid1(S * v.nRx, 64), dim3(64), 0, st, v, wantGrad ? 1 : 0);
-        hipLaunchKernelGGL(k_resid, grid1(v.nData, 128), dim3(128), 0, st, v);
-        hipLaunchKernelGGL(k_misfit, dim3(1), dim3(256), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit);
+        hipLaunchKernelGGL(k_rxall, grid1(S * v.nRx, 64), dim3(64), 0, st, v, wantGrad ? 1 : 0);
+        if (!wantGrad) hipLaunchKernelGGL(k_misfit, dim3(1), dim3(256), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit);
     }
     if (wantGrad) {
         {
             ProfScope ps(ctx, 5);
-            hipLaunchKernelGGL(k_rxcoef, grid1(S * v.nRx, 64), dim3(64), 0, st, v);
-            HIPCHK(hipMemsetAsync(v.R, 0, vecBytes, st));
-            HIPCHK(hipMemsetAsync(v.srcB, 0, sizeof(cplx) * 4 * S, st));
-            hipLaunchKernelGGL(k_src, dim3((2 * (v.ny + 1) + 127) / 128, S), dim3(128), 0, st, v);
+            HIPCHK(hipMemsetAsync(v.R, 0, vecBytes, st));       // (k_src assigns the two receiver rows and all of srcB)
+            hipLaunchKernelGGL(k_src, dim3((2 * (v.ny + 1) + 127) / 128, S), dim3(128), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit);
             if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtA, 0));
             if (warmA) hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, 0);
         }

@@ -13,7 +13,7 @@ import numpy as np
 from .marshal import CreateArgs, CREATE_ARGTYPES, c_double_p, c_int64_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libhmcmt_hip.so")
+SO_PATH = os.environ.get("HMCMT_LIB_PATH") or os.path.join(HERE, "libhmcmt_hip.so")   # (override: A/B runs of two builds)
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = [os.path.join(CSRC, "hmcmt_hip.hip"), os.path.join(CSRC, "mumps_shim.hip")]
 HEADERS = [os.path.join(CSRC, h) for h in ("hmcmt_math.h", "hmcmt_items.h", "hmcmt_host.h")] + \

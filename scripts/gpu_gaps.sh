@@ -4,14 +4,20 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/gaps
-rocprofv3 --kernel-trace --output-format csv -d /tmp/gaps -- python3 $R/scripts/gpu_profile_run.py ${1:-cfg3} 8 > /tmp/gaps.log 2>&1
+# usage: gpu_gaps.sh [cfg]        host-API evaluations on distinct models (scripts/gpu_profile_run.py)
+#        gpu_gaps.sh bench        the timed loop of bench.py (device API, leapfrog-like trajectories)
+if [ "$1" = bench ]; then
+    HMCMT_BENCH_NOPROF=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/gaps -- python3 $R/bench.py --steps 12 --warmup 6 --no-cpu-baseline > /tmp/gaps.log 2>&1
+else
+    rocprofv3 --kernel-trace --output-format csv -d /tmp/gaps -- python3 $R/scripts/gpu_profile_run.py ${1:-cfg3} 8 > /tmp/gaps.log 2>&1
+fi
 python3 - <<'PY'
 import csv, glob, os, collections
 rows = list(csv.DictReader(open(glob.glob('/tmp/gaps/*/*kernel_trace.csv')[0])))
 ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('(anonymous namespace)::','').replace('void ','').split('(')[0].split('<')[0], r['Queue_Id']) for r in rows)
 starts = [i for i, k in enumerate(ks) if k[2] == 'k_sigma']
 gmin = float(os.environ.get("GAP_MIN", "6"))
-for ev in (-3, -2):
+for ev in ((12, 13) if os.environ.get('GAPS_BENCH') else (-3, -2)):
     a, b = starts[ev], starts[ev + 1]
     seg = ks[a:b + 1]
     mainq = collections.Counter(k[3] for k in seg).most_common(1)[0][0]
