@@ -1015,24 +1015,35 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
         const c32* rb = sb + (long)half * RL * SW + col;
         const c32* rc = sc + (long)half * RL * SW + col;
         c32 pt = c32{0, 0};
-        c32 av[FW_TB], bv[FW_TB];
-        // ---- elimination, region rows 1..steps
+        // ---- elimination, region rows 1..steps.  Blocks of FW_TB rows, two register sets used alternately: while one
+        // block is swept, the next one is on its way from LDS (no register copies between blocks; the prefetch of the
+        // block behind the last one reads padding rows)
         {
             c32* pa = ra + SW;
             const c32* pb = rb + SW;
+            c32 a0[FW_TB], b0[FW_TB], a1[FW_TB], b1[FW_TB];
+            const int nblk = (steps + FW_TB - 1) / FW_TB;
 #pragma unroll
-            for (int t = 0; t < FW_TB; ++t) { av[t] = pa[t * SW]; bv[t] = pb[t * SW]; }
-            for (int r0 = 1; r0 <= steps; r0 += FW_TB) {
-                c32 na[FW_TB], nb[FW_TB];
+            for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[t * SW]; b0[t] = pb[t * SW]; }
+            int bk = 0;
+            for (; bk + 1 < nblk; bk += 2) {
 #pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { na[t] = pa[(FW_TB + t) * SW]; nb[t] = pb[(FW_TB + t) * SW]; }
+                for (int t = 0; t < FW_TB; ++t) { a1[t] = pa[(FW_TB + t) * SW]; b1[t] = pb[(FW_TB + t) * SW]; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(av[t], bv[t], pt); pa[t * SW] = pt; }
+                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a0[t], b0[t], pt); pa[t * SW] = pt; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { av[t] = na[t]; bv[t] = nb[t]; pin(av[t]); pin(bv[t]); }
-                pa += FW_TB * SW; pb += FW_TB * SW;
+                for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[(2 * FW_TB + t) * SW]; b0[t] = pb[(2 * FW_TB + t) * SW]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a1[t], b1[t], pt); pa[(FW_TB + t) * SW] = pt; }
+                __builtin_amdgcn_sched_barrier(0);
+                pa += 2 * FW_TB * SW; pb += 2 * FW_TB * SW;
+            }
+            if (bk < nblk) {
+#pragma unroll
+                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a0[t], b0[t], pt); pa[t * SW] = pt; }
             }
         }
         // ---- join of the two halves: x_mid = (y'_mid - c y''_{mid+1}) J ;  x_{mid+1} = y''_{mid+1} - c' x_mid
@@ -1048,23 +1059,33 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
             pt = half == 0 ? c32{xre, xim} : xbot;
             ra[last * SW] = pt;
         }
-        // ---- substitution, region rows last-1 .. 1 (rows in front of 1: zeros in, zeros out)
+        // ---- substitution, region rows last-1 .. 1 (rows in front of 1: zeros in, zeros out), same scheme downwards
         {
             c32* pa = ra + (long)(last - 1) * SW;
             const c32* pc = rc + (long)(last - 1) * SW;
+            c32 a0[FW_TB], b0[FW_TB], a1[FW_TB], b1[FW_TB];
+            const int nblk = (steps - 1 + FW_TB - 1) / FW_TB;
 #pragma unroll
-            for (int t = 0; t < FW_TB; ++t) { av[t] = pa[-t * SW]; bv[t] = pc[-t * SW]; }
-            for (int r0 = steps - 1; r0 >= 1; r0 -= FW_TB) {
-                c32 na[FW_TB], nb[FW_TB];
+            for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[-t * SW]; b0[t] = pc[-t * SW]; }
+            int bk = 0;
+            for (; bk + 1 < nblk; bk += 2) {
 #pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { na[t] = pa[-(FW_TB + t) * SW]; nb[t] = pc[-(FW_TB + t) * SW]; }
+                for (int t = 0; t < FW_TB; ++t) { a1[t] = pa[-(FW_TB + t) * SW]; b1[t] = pc[-(FW_TB + t) * SW]; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(av[t], bv[t], pt); pa[-t * SW] = pt; }
+                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a0[t], b0[t], pt); pa[-t * SW] = pt; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { av[t] = na[t]; bv[t] = nb[t]; pin(av[t]); pin(bv[t]); }
-                pa -= FW_TB * SW; pc -= FW_TB * SW;
+                for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[-(2 * FW_TB + t) * SW]; b0[t] = pc[-(2 * FW_TB + t) * SW]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a1[t], b1[t], pt); pa[-(FW_TB + t) * SW] = pt; }
+                __builtin_amdgcn_sched_barrier(0);
+                pa -= 2 * FW_TB * SW; pc -= 2 * FW_TB * SW;
+            }
+            if (bk < nblk) {
+#pragma unroll
+                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a0[t], b0[t], pt); pa[-t * SW] = pt; }
             }
         }
     }
