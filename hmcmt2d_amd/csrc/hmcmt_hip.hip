@@ -1835,7 +1835,7 @@ __global__ void k_rhs(View v) {
     if (e >= v.NZP * (v.ny + 1)) return;
     item_rhs(v, s, e % (v.ny + 1), e / (v.ny + 1));
 }
-__global__ void k_rx(View v, int wantDeriv) {
+__global__ __launch_bounds__(64) void k_rx(View v, int wantDeriv) {
     int e = TID1;
     if (e < v.S * v.nRx) item_rx(v, e / v.nRx, e % v.nRx, wantDeriv != 0);
 }
@@ -1851,7 +1851,7 @@ __global__ void k_misfit(View v, double* out) {
 // the data that address this receiver and their sum of conj(W'W r) -- one launch instead of three in a row on the
 // critical path (a datum belongs to exactly one (system, receiver), so there is no cross-thread dependency; the
 // misfit itself, a reduction over all data, is not needed by the adjoint half and is summed after the sources).
-__global__ void k_rxall(View v, int wantGrad) {
+__global__ __launch_bounds__(64) void k_rxall(View v, int wantGrad) {        // (64: registers instead of 200 B of spills)
     const int e = TID1;
     if (e >= v.S * v.nRx) return;
     const int s = e / v.nRx, r = e % v.nRx;

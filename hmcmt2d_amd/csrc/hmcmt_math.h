@@ -466,6 +466,25 @@ HD cplx rx_impedance(bool tm, double omega, int ny, const cplx* F0, const cplx* 
     return tm ? aux / fld : fld / aux;
 }
 
+// arr[slot] += v for a run-time slot, as predicated adds over the (unrolled) slots: a dynamically indexed local
+// array would live in scratch memory on the GPU (a memory round trip per access; k_rx: 21 us); slots outside
+// [0, N) are ignored
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HMCMT_UNROLL _Pragma("unroll")
+#else
+#define HMCMT_UNROLL
+#endif
+template <int N>
+HD void slot_add(cplx (&arr)[N], int slot, cplx v) {
+    // (every slot gets an addend, v or 0: written as `if (j == slot) arr[j] += v` the compiler folds the unrolled
+    // chain back into one dynamically indexed access)
+    HMCMT_UNROLL
+    for (int j = 0; j < N; ++j) {
+        const bool hit = j == slot;
+        arr[j] += cplx{hit ? v.re : 0.0, hit ? v.im : 0.0};
+    }
+}
+
 // Derivative of the impedance of one receiver w.r.t. the two node rows and the receiver-layer
 // conductivities (dataFuncSens.jl:44-123 TE, :219-298 TM; Impedance branch :118-123, :293-298).
 // (kL, kR, wL, wR) from `linearInterp` (sensUtils.jl:133-161, normalised weights).
@@ -479,15 +498,16 @@ HD void rx_impedance_deriv(bool tm, double omega, int ny, const cplx* F0, const 
     const double ww[2] = {wL, wR};
     const int n0 = (kk[0] < kk[1] ? kk[0] : kk[1]) - 1;
     *n0_out = n0;
-    for (int i = 0; i < 4; ++i) { d0[i] = cplx{0, 0}; d1[i] = cplx{0, 0}; }
-    for (int i = 0; i < 3; ++i) dq[i] = cplx{0, 0};
     // field at the receiver with normalised weights
     cplx fld = wL * F0[kL] + wR * F0[kR];
     cplx aux = cplx{0, 0};
     // d(aux)/dF and d(aux)/dsig accumulated in a0[], a1[], aq[]
     cplx a0[4], a1[4], aq[3];
+    HMCMT_UNROLL
     for (int i = 0; i < 4; ++i) { a0[i] = cplx{0, 0}; a1[i] = cplx{0, 0}; }
+    HMCMT_UNROLL
     for (int i = 0; i < 3; ++i) aq[i] = cplx{0, 0};
+    HMCMT_UNROLL
     for (int t = 0; t < 2; ++t) {
         const int k = kk[t];
         const double w = ww[t];
@@ -501,28 +521,28 @@ HD void rx_impedance_deriv(bool tm, double omega, int ny, const cplx* F0, const 
             const double sv = (0.5 * (sig1[k - 1] * dy[k - 1]) + 0.5 * (sig1[k] * dy[k])) / avl;
             const cplx ak = 1.0 / (dy[k] * (iw * MU0)), akm = 1.0 / (dy[k - 1] * (iw * MU0));
             // Hy0 = HyH - (dHzQ - sv*ExQ)*hz
-            a0[o] += w * (g + (sv * hz) * cplx{0.75, 0} + (hz / avl) * 0.75 * (ak + akm));
-            a1[o] += w * (-g + (sv * hz) * cplx{0.25, 0} + (hz / avl) * 0.25 * (ak + akm));
-            a0[o + 1] += w * (-(hz / avl) * 0.75 * ak);
-            a1[o + 1] += w * (-(hz / avl) * 0.25 * ak);
-            a0[o - 1] += w * (-(hz / avl) * 0.75 * akm);
-            a1[o - 1] += w * (-(hz / avl) * 0.25 * akm);
+            slot_add<4>(a0, o, w * (g + (sv * hz) * cplx{0.75, 0} + (hz / avl) * 0.75 * (ak + akm)));
+            slot_add<4>(a1, o, w * (-g + (sv * hz) * cplx{0.25, 0} + (hz / avl) * 0.25 * (ak + akm)));
+            slot_add<4>(a0, o + 1, w * (-(hz / avl) * 0.75 * ak));
+            slot_add<4>(a1, o + 1, w * (-(hz / avl) * 0.25 * ak));
+            slot_add<4>(a0, o - 1, w * (-(hz / avl) * 0.75 * akm));
+            slot_add<4>(a1, o - 1, w * (-(hz / avl) * 0.25 * akm));
             const cplx ExQ = 0.75 * F0[k] + 0.25 * F1[k];
             // d sv / d sig[k-1] = 0.5*dy[k-1]/avl ; cells k-1 -> slot o-1, k -> slot o
-            aq[o - 1] += w * (hz * (0.5 * dy[k - 1] / avl)) * ExQ;
-            aq[o] += w * (hz * (0.5 * dy[k] / avl)) * ExQ;
+            slot_add<3>(aq, o - 1, w * (hz * (0.5 * dy[k - 1] / avl)) * ExQ);
+            slot_add<3>(aq, o, w * (hz * (0.5 * dy[k] / avl)) * ExQ);
         } else {
             aux += w * tm_Ey0(k, omega, F0, F1, dy, sig1, dz1);
             const double rv = (0.5 * (dy[k - 1] / sig1[k - 1]) + 0.5 * (dy[k] / sig1[k])) / avl;
             const double bk = 1.0 / (dy[k] * sig1[k]), bkm = 1.0 / (dy[k - 1] * sig1[k - 1]);
             const cplx iwm = cplx{0.0, omega * MU0};
             // Ey0 = EyH - (dEzQ + iwm*HxQ)*hz ; EzQ_c = -(0.75 dF0_c + 0.25 dF1_c) * b_c
-            a0[o] += w * (cplx{-rv / dz1, 0} - (hz / avl) * 0.75 * (bk + bkm) * cplx{1, 0} - (hz * 0.75) * iwm);
-            a1[o] += w * (cplx{rv / dz1, 0} - (hz / avl) * 0.25 * (bk + bkm) * cplx{1, 0} - (hz * 0.25) * iwm);
-            a0[o + 1] += w * cplx{(hz / avl) * 0.75 * bk, 0};
-            a1[o + 1] += w * cplx{(hz / avl) * 0.25 * bk, 0};
-            a0[o - 1] += w * cplx{(hz / avl) * 0.75 * bkm, 0};
-            a1[o - 1] += w * cplx{(hz / avl) * 0.25 * bkm, 0};
+            slot_add<4>(a0, o, w * (cplx{-rv / dz1, 0} - (hz / avl) * 0.75 * (bk + bkm) * cplx{1, 0} - (hz * 0.75) * iwm));
+            slot_add<4>(a1, o, w * (cplx{rv / dz1, 0} - (hz / avl) * 0.25 * (bk + bkm) * cplx{1, 0} - (hz * 0.25) * iwm));
+            slot_add<4>(a0, o + 1, w * cplx{(hz / avl) * 0.75 * bk, 0});
+            slot_add<4>(a1, o + 1, w * cplx{(hz / avl) * 0.25 * bk, 0});
+            slot_add<4>(a0, o - 1, w * cplx{(hz / avl) * 0.75 * bkm, 0});
+            slot_add<4>(a1, o - 1, w * cplx{(hz / avl) * 0.25 * bkm, 0});
             const cplx JyH = (F1[k] - F0[k]) / dz1;
             auto EzQ = [&](int c) -> cplx {
                 cplx j0 = -((F0[c + 1] - F0[c]) / dy[c]);
@@ -530,23 +550,27 @@ HD void rx_impedance_deriv(bool tm, double omega, int ny, const cplx* F0, const 
                 return (0.75 * j0 + 0.25 * j1) / sig1[c];
             };
             // d rv/d sig[k-1] = -0.5*dy[k-1]/(sig^2*avl); d EzQ_c/d sig_c = -EzQ_c/sig_c
-            aq[o - 1] += w * (JyH * (-0.5 * dy[k - 1] / (sig1[k - 1] * sig1[k - 1] * avl)) -
-                              (hz / avl) * (EzQ(k - 1) / sig1[k - 1]));
-            aq[o] += w * (JyH * (-0.5 * dy[k] / (sig1[k] * sig1[k] * avl)) +
-                          (hz / avl) * (EzQ(k) / sig1[k]));
+            slot_add<3>(aq, o - 1, w * (JyH * (-0.5 * dy[k - 1] / (sig1[k - 1] * sig1[k - 1] * avl)) -
+                              (hz / avl) * (EzQ(k - 1) / sig1[k - 1])));
+            slot_add<3>(aq, o, w * (JyH * (-0.5 * dy[k] / (sig1[k] * sig1[k] * avl)) +
+                          (hz / avl) * (EzQ(k) / sig1[k])));
         }
     }
     // chain to Z.  TE: Z = fld/aux ; TM: Z = aux/fld.   d fld / dF0[kL] = wL, dF0[kR] = wR
     cplx f0c[4] = {cplx{0, 0}, cplx{0, 0}, cplx{0, 0}, cplx{0, 0}};
-    if (kL - n0 >= 0 && kL - n0 < 4) f0c[kL - n0] += cplx{wL, 0};
-    if (kR - n0 >= 0 && kR - n0 < 4) f0c[kR - n0] += cplx{wR, 0};
+    slot_add<4>(f0c, kL - n0, cplx{wL, 0});
+    slot_add<4>(f0c, kR - n0, cplx{wR, 0});
     if (!tm) {
         const cplx ia = 1.0 / aux, c2 = fld / (aux * aux);
+        HMCMT_UNROLL
         for (int i = 0; i < 4; ++i) { d0[i] = ia * f0c[i] - c2 * a0[i]; d1[i] = -(c2 * a1[i]); }
+        HMCMT_UNROLL
         for (int i = 0; i < 3; ++i) dq[i] = -(c2 * aq[i]);
     } else {
         const cplx ifl = 1.0 / fld, c2 = aux / (fld * fld);
+        HMCMT_UNROLL
         for (int i = 0; i < 4; ++i) { d0[i] = ifl * a0[i] - c2 * f0c[i]; d1[i] = ifl * a1[i]; }
+        HMCMT_UNROLL
         for (int i = 0; i < 3; ++i) dq[i] = ifl * aq[i];
     }
 }
