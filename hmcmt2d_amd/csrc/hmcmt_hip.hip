@@ -1994,7 +1994,7 @@ struct hmcmt_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;       // sigma-only sensitivity tables run beside the forward solve
     hipStream_t side2 = nullptr;      // inverse pivots of the FDM tridiagonals run beside the boundary-value kernels
-    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evFdmz = nullptr, evPiv = nullptr;
+    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evFdmz = nullptr, evPiv = nullptr, evWb = nullptr, evBcs = nullptr;
     std::vector<void*> allocs;
     std::string err;
     // device scalars / buffers not in View
@@ -2475,10 +2475,16 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         if (rc) return rc;
         ProfScope ps(ctx, 6);
         hipLaunchKernelGGL(k_wb, dim3((v.nz + v.ny + 127) / 128, S), dim3(128), 0, st, v);
-        HIPCHK(hipStreamWaitEvent(st, ctx->evSens, 0));
-        hipLaunchKernelGGL(k_bcsens, dim3((v.nz + 63) / 64, 3, S), dim3(64), 0, st, v);
+        // dBC^T w (serial chains, 78 us on a handful of CUs) on the side stream -- behind the sensitivity tables it
+        // needs anyway -- beside the cell and receiver-layer terms on the main stream; joined before the assembly
+        HIPCHK(hipEventRecord(ctx->evWb, st));
+        HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evWb, 0));
+        hipLaunchKernelGGL(k_bcsens, dim3((v.nz + 63) / 64, 3, S), dim3(64), 0, ctx->side, v);
+        HIPCHK(hipEventRecord(ctx->evBcs, ctx->side));
+        HIPCHK(hipStreamWaitEvent(st, ctx->evSens, 0));         // (k_gradcell reads the sensitivity-version boundary values)
         hipLaunchKernelGGL(k_gradcell, dim3((v.nCell + 127) / 128, 2), dim3(128), 0, st, v);
         hipLaunchKernelGGL(k_qterm, dim3((v.ny + 63) / 64, S), dim3(64), 0, st, v);
+        HIPCHK(hipStreamWaitEvent(st, ctx->evBcs, 0));
         hipLaunchKernelGGL(k_gradfinal, grid1(v.nAC, 128), dim3(128), 0, st, v);
     }
     HIPCHK(hipGetLastError());
@@ -2553,6 +2559,8 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (ctx->evExtF) hipEventDestroy(ctx->evExtF);
     if (ctx->evFdmz) hipEventDestroy(ctx->evFdmz);
     if (ctx->evPiv) hipEventDestroy(ctx->evPiv);
+    if (ctx->evWb) hipEventDestroy(ctx->evWb);
+    if (ctx->evBcs) hipEventDestroy(ctx->evBcs);
     if (ctx->side2) hipStreamDestroy(ctx->side2);
     if (ctx->evExtA) hipEventDestroy(ctx->evExtA);
     if (ctx->side) hipStreamDestroy(ctx->side);
@@ -2575,6 +2583,8 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     HIPCHK(hipEventCreateWithFlags(&ctx->evExtF, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evFdmz, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evPiv, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evWb, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evBcs, hipEventDisableTiming));
     HIPCHK(hipStreamCreate(&ctx->side2));
     {
         const char* e = getenv("HMCMT_FUSED_FWD");
