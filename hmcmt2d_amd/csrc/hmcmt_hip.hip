@@ -1994,7 +1994,7 @@ struct hmcmt_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;       // sigma-only sensitivity tables run beside the forward solve
     hipStream_t side2 = nullptr;      // inverse pivots of the FDM tridiagonals run beside the boundary-value kernels
-    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evFdmz = nullptr, evPiv = nullptr, evWb = nullptr, evBcs = nullptr;
+    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evFdmz = nullptr, evPiv = nullptr, evWb = nullptr, evBcs = nullptr, evPoll = nullptr;
     std::vector<void*> allocs;
     std::string err;
     // device scalars / buffers not in View
@@ -2283,11 +2283,11 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             ++it;
             // decide convergence of the state after iteration it-1, p = z + beta p, q = A p
             { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv_fused, dim3(k.NTR, S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit); }
-            if (it - 1 >= nextCheck || it - 1 == ctx->opt.maxit) {
-                HIPCHK(hipStreamSynchronize(ctx->stream));
-                if (*(volatile int*)ctx->h_nactive == 0) { done = true; break; }
-                nextCheck = it - 1 + every;
-            }
+            // Convergence poll: the host waits for THIS launch only (an event), with the rest of the iteration already
+            // queued behind it -- if the solve goes on, the device never idles while the host wakes up; if it is over,
+            // the three queued launches exit at once (all systems inactive, ~10 us) inside the host's wake-up time.
+            const bool poll = it - 1 >= nextCheck || it - 1 == ctx->opt.maxit;
+            if (poll) HIPCHK(hipEventRecord(ctx->evPoll, ctx->stream));
             { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused, dim3(k.NTR, S), vb, (size_t)(2 * k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it); }
             rcur ^= 1;
             k.r = rb[rcur];
@@ -2295,6 +2295,11 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             if ((prc = launch_fdm_fwd(ctx))) return prc;
             if ((prc = launch_back_post(ctx))) return prc;
             std::swap(k.z, k.t);
+            if (poll) {
+                HIPCHK(hipEventSynchronize(ctx->evPoll));
+                if (*(volatile int*)ctx->h_nactive == 0) { done = true; break; }
+                nextCheck = it - 1 + every;
+            }
             if (kind == 0 && it == 2) launch_adjoint_side(ctx);   // (the queue holds two iterations: the host has time for a dozen calls)
         }
         if (!done) {
@@ -2561,6 +2566,7 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (ctx->evPiv) hipEventDestroy(ctx->evPiv);
     if (ctx->evWb) hipEventDestroy(ctx->evWb);
     if (ctx->evBcs) hipEventDestroy(ctx->evBcs);
+    if (ctx->evPoll) hipEventDestroy(ctx->evPoll);
     if (ctx->side2) hipStreamDestroy(ctx->side2);
     if (ctx->evExtA) hipEventDestroy(ctx->evExtA);
     if (ctx->side) hipStreamDestroy(ctx->side);
@@ -2585,6 +2591,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     HIPCHK(hipEventCreateWithFlags(&ctx->evPiv, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evWb, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evBcs, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evPoll, hipEventDisableTiming));
     HIPCHK(hipStreamCreate(&ctx->side2));
     {
         const char* e = getenv("HMCMT_FUSED_FWD");
