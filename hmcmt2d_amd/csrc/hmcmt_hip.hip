@@ -2105,6 +2105,7 @@ void prof_collect(hmcmt_ctx* c) {
     hipStreamSynchronize(c->stream);
     for (size_t i = 0; i + 1 < c->evUsed; i += 2) {
         float ms = 0;
+        if (c->evCat[i] < 0) continue;                    // (a launch known to have been empty: solve())
         if (hipEventElapsedTime(&ms, c->evPool[i], c->evPool[i + 1]) == hipSuccess) {
             c->profMs[c->evCat[i]] += std::max(0.0, (double)ms - c->profOverheadMs);
             c->profN[c->evCat[i]] += 1;
@@ -2288,6 +2289,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             // the three queued launches exit at once (all systems inactive, ~10 us) inside the host's wake-up time.
             const bool poll = it - 1 >= nextCheck || it - 1 == ctx->opt.maxit;
             if (poll) HIPCHK(hipEventRecord(ctx->evPoll, ctx->stream));
+            const size_t evMark = ctx->evUsed;
             { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused, dim3(k.NTR, S), vb, (size_t)(2 * k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it); }
             rcur ^= 1;
             k.r = rb[rcur];
@@ -2297,7 +2299,12 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             std::swap(k.z, k.t);
             if (poll) {
                 HIPCHK(hipEventSynchronize(ctx->evPoll));
-                if (*(volatile int*)ctx->h_nactive == 0) { done = true; break; }
+                if (*(volatile int*)ctx->h_nactive == 0) {
+                    // the three launches behind the event found every system inactive: not samples of the kernels' timing
+                    for (size_t i = evMark; i + 1 < ctx->evUsed; i += 2) ctx->evCat[i] = -1;
+                    done = true;
+                    break;
+                }
                 nextCheck = it - 1 + every;
             }
             if (kind == 0 && it == 2) launch_adjoint_side(ctx);   // (the queue holds two iterations: the host has time for a dozen calls)
