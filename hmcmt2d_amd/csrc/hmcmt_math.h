@@ -186,19 +186,17 @@ HD cplx bc1d_forward_tab_f(double omega, int nz, const cplx* T, long qs, long ls
     cplx last = one;
     bool dead = false;
     // one layer i -> i+1 (:69-83)
+    // The serial chain is the 2x2 product alone: the cut-off test (three more dependent levels) only feeds the `dead`
+    // flag, which masks the outputs -- the amplitudes are advanced unconditionally (behind the cut-off their values
+    // are never used), so the test runs beside the chain instead of on it.
     auto down = [&](int i, cplx kn, cplx a11, cplx a12, cplx a21, cplx a22) {
-        cplx fn = cplx{0.0, 0.0};
-        if (!dead) {
-            const cplx nu = a11 * eu + a12 * ed;
-            const cplx nd = a21 * eu + a22 * ed;
-            const double e2 = cabs2(nu + nd), e1 = cabs2(eu + ed);   // |.|^2: same ordering as |.|
-            if (e2 - e1 > 0.0 || isnan(e2)) {
-                dead = true;                     // overflow cut-off: zero from here down
-            } else {
-                eu = nu; ed = nd; kj = kn;
-                fn = compH ? ((ed - eu) * kj) * iomu0 : (eu + ed);
-            }
-        }
+        const cplx nu = a11 * eu + a12 * ed;
+        const cplx nd = a21 * eu + a22 * ed;
+        const double e2 = cabs2(nu + nd), e1 = cabs2(eu + ed);       // |.|^2: same ordering as |.|
+        dead = dead || e2 - e1 > 0.0 || isnan(e2);                   // overflow cut-off: zero from here down
+        eu = nu; ed = nd; kj = kn;
+        cplx fn = compH ? ((ed - eu) * kj) * iomu0 : (eu + ed);
+        if (dead) fn = cplx{0.0, 0.0};
         last = fn * if0;
         outf(i, last);
     };
