@@ -1994,7 +1994,8 @@ struct hmcmt_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;       // sigma-only sensitivity tables run beside the forward solve
     hipStream_t side2 = nullptr;      // inverse pivots of the FDM tridiagonals run beside the boundary-value kernels
-    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evFdmz = nullptr, evPiv = nullptr, evWb = nullptr, evBcs = nullptr, evPoll = nullptr;
+    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evFdmz = nullptr, evPiv = nullptr, evWb = nullptr, evBcs = nullptr, evPoll = nullptr, evRec = nullptr;
+    bool statsPending = false, pendingAdj = false;   // records of an asynchronous evaluation not read yet
     std::vector<void*> allocs;
     std::string err;
     // device scalars / buffers not in View
@@ -2252,6 +2253,7 @@ int apply_precond(hmcmt_ctx* ctx) {
 }
 
 void launch_adjoint_side(hmcmt_ctx* ctx);
+int collect_pending(hmcmt_ctx* ctx);
 
 // Solves A x = r for all systems (x zero on interior on entry; r destroyed).  kind 0 forward, 1 adjoint.
 int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
@@ -2404,6 +2406,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     if (d_grad) v.grad = d_grad;
     hipStream_t st = ctx->stream;
     const int S = v.S;
+    { int prc = collect_pending(ctx); if (prc) return prc; }      // (an earlier asynchronous evaluation's records / status)
     ctx->stats = hmcmt_stats{};
     ctx->stats.nsystems = S;
     ++ctx->evalCount;
@@ -2466,6 +2469,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         ctx->sidePending = wantGrad;
     }
     int rc = solve(ctx, v.X, 0);
+    if (!wantGrad) HIPCHK(hipEventRecord(ctx->evRec, st));          // behind the last k_solve_end
     launch_adjoint_side(ctx);            // (no-op when the solve has already done it)
     ctx->haveFwd = (rc == 0 && ctx->solveDone[0]);
     if (rc) return rc;
@@ -2483,6 +2487,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             if (warmA) hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, 0);
         }
         rc = solve(ctx, v.Lam, 1);
+        HIPCHK(hipEventRecord(ctx->evRec, st));                        // behind the last k_solve_end
         ctx->haveAdj = (rc == 0 && ctx->solveDone[1]);
         if (rc) return rc;
         ProfScope ps(ctx, 6);
@@ -2504,13 +2509,12 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     return 0;
 }
 
-// after the final stream sync of an evaluation: read both solves' records back and fill the statistics
-int collect_stats(hmcmt_ctx* ctx, bool withAdjoint) {
+// the per-solve records (written by k_solve_end into mapped pinned memory) -> statistics; the caller has waited for them
+void parse_stats(hmcmt_ctx* ctx, bool withAdjoint) {
     const int S = ctx->v.S, nk = withAdjoint ? 2 : 1;
     const int* h_iters = reinterpret_cast<const int*>(ctx->h_rec);
     const int* h_status = h_iters + 2 * S;
     const double* h_err = ctx->h_rec + 2 * S;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int kind = 0; kind < nk; ++kind) {
         int mx = 0, sum = 0;
         for (int s = 0; s < S; ++s) {
@@ -2528,7 +2532,27 @@ int collect_stats(hmcmt_ctx* ctx, bool withAdjoint) {
         if (!ctx->solveDone[kind] && ctx->stats.status == 0) ctx->stats.status = HMCMT_ENOCONV;
     }
     if (!withAdjoint) for (int s = 0; s < S; ++s) ctx->itersLast[S + s] = 0;
+}
+
+// after an evaluation: wait for the whole stream, then the statistics
+int collect_stats(hmcmt_ctx* ctx, bool withAdjoint) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    parse_stats(ctx, withAdjoint);
+    ctx->statsPending = false;
     return 0;
+}
+
+int finish_status(hmcmt_ctx* ctx);
+
+// An asynchronous evaluation (hmcmt_grad_device_async) leaves its records unread: they are picked up -- waiting only
+// for the event behind its last k_solve_end, not for its gradient tail -- before the next evaluation is issued
+// (its first poll wants the iteration counts, and k_solve_end will overwrite the records) or by hmcmt_wait.
+int collect_pending(hmcmt_ctx* ctx) {
+    if (!ctx->statsPending) return 0;
+    HIPCHK(hipEventSynchronize(ctx->evRec));
+    parse_stats(ctx, ctx->pendingAdj);
+    ctx->statsPending = false;
+    return finish_status(ctx);
 }
 
 int finish_status(hmcmt_ctx* ctx) {
@@ -2574,6 +2598,7 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (ctx->evWb) hipEventDestroy(ctx->evWb);
     if (ctx->evBcs) hipEventDestroy(ctx->evBcs);
     if (ctx->evPoll) hipEventDestroy(ctx->evPoll);
+    if (ctx->evRec) hipEventDestroy(ctx->evRec);
     if (ctx->side2) hipStreamDestroy(ctx->side2);
     if (ctx->evExtA) hipEventDestroy(ctx->evExtA);
     if (ctx->side) hipStreamDestroy(ctx->side);
@@ -2599,6 +2624,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     HIPCHK(hipEventCreateWithFlags(&ctx->evWb, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evBcs, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evPoll, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evRec, hipEventDisableTiming));
     HIPCHK(hipStreamCreate(&ctx->side2));
     {
         const char* e = getenv("HMCMT_FUSED_FWD");
@@ -2807,6 +2833,25 @@ int hmcmt_grad_device(hmcmt_ctx* ctx, const double* d_m, double* d_pred, double*
     if ((rc = collect_stats(ctx, true))) return rc;      // includes the stream synchronisation
     prof_collect(ctx);
     return finish_status(ctx);
+}
+
+int hmcmt_grad_device_async(hmcmt_ctx* ctx, const double* d_m, double* d_pred, double* d_misfit, double* d_grad) {
+    if (!ctx || !d_m || !d_grad) return HMCMT_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = evaluate(ctx, d_m, true, d_pred, d_misfit, d_grad);
+    if (rc) return rc;
+    ctx->statsPending = true;
+    ctx->pendingAdj = true;
+    return 0;
+}
+
+int hmcmt_wait(hmcmt_ctx* ctx) {
+    if (!ctx) return HMCMT_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int rc = collect_pending(ctx);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    return rc;
 }
 
 int hmcmt_forward_device(hmcmt_ctx* ctx, const double* d_m, double* d_pred, double* d_misfit) {
@@ -3185,13 +3230,15 @@ int hmcmt_leapfrog(hmcmt_ctx* ctx, const double* m0, const double* p0, double dt
     for (int k = 1; k <= L; ++k) {
         hipLaunchKernelGGL(k_lf_dmmax, dim3(LFNB), dim3(256), 0, st, lf, dt);
         hipLaunchKernelGGL(k_lf_step, g1, b1, 0, st, lf, dt, lnSigMin, lnSigMax);
-        rc = evaluate(ctx, ctx->d_mcur, true, nullptr, nullptr, ctx->d_g);
+        rc = evaluate(ctx, ctx->d_mcur, true, nullptr, nullptr, ctx->d_g);      // (reports a failure of the step before)
         if (rc) return rc;
-        if ((rc = collect_stats(ctx, true))) return rc;
-        if ((rc = finish_status(ctx))) return rc;
+        // asynchronous, as hmcmt_grad_device_async: the next step's launches overlap this step's gradient tail
+        ctx->statsPending = true;
+        ctx->pendingAdj = true;
         ++evals;
         hipLaunchKernelGGL(k_lf_momentum, g1, b1, 0, st, lf, regParam, (k < L ? 1.0 : 0.5) * dt);
     }
+    if ((rc = collect_pending(ctx))) return rc;
     hipLaunchKernelGGL(k_lf_mnorm, dim3(LFNB), dim3(256), 0, st, lf, regParam);
     hipLaunchKernelGGL(k_lf_mnorm_final, dim3(1), dim3(1), 0, st, lf, regParam);
     double* hs = ctx->h_stage;

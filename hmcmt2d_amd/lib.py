@@ -88,6 +88,8 @@ def load_library():
     lib.hmcmt_forward.argtypes = [vp, c_double_p, c_double_p, c_double_p]
     lib.hmcmt_grad_device.argtypes = [vp, vp, vp, vp, vp]
     lib.hmcmt_forward_device.argtypes = [vp, vp, vp, vp]
+    lib.hmcmt_grad_device_async.argtypes = [vp, vp, vp, vp, vp]
+    lib.hmcmt_wait.argtypes = [vp]
     lib.hmcmt_set_prior.argtypes = [vp, c_double_p, c_int64_p, c_int64_p, c_double_p, c_double_p]
     lib.hmcmt_leapfrog.argtypes = [vp, c_double_p, c_double_p, C.c_double, C.c_int32, C.c_double, C.c_double,
                                    C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
@@ -103,8 +105,8 @@ def load_library():
     lib.hmcmt_debug_fdm_fwd.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_back_post.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_double_p]
     for name in ("hmcmt_create", "hmcmt_destroy", "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters",
-                 "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_set_prior",
-                 "hmcmt_leapfrog", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read",
+                 "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async",
+                 "hmcmt_wait", "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read",
                  "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond",
                  "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post"):
         getattr(lib, name).restype = C.c_int
@@ -114,8 +116,8 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "hmcmt_last_error",
                     "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters", "hmcmt_grad", "hmcmt_forward",
-                    "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_set_prior", "hmcmt_leapfrog",
-                    "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_dims",
+                    "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async", "hmcmt_wait",
+                    "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_dims",
                     "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
                     "hmcmt_debug_back_post"]
 
@@ -207,6 +209,13 @@ class HipContext:
     def grad_device(self, d_m, d_pred, d_misfit, d_grad):
         """Raw device pointers (ints), e.g. torch tensors' data_ptr()."""
         self._check(self.lib.hmcmt_grad_device(self.h, d_m, d_pred, d_misfit, d_grad))
+
+    def grad_device_async(self, d_m, d_pred, d_misfit, d_grad):
+        """Enqueue only (hmcmt_grad_device_async); finish with wait()."""
+        self._check(self.lib.hmcmt_grad_device_async(self.h, d_m, d_pred, d_misfit, d_grad))
+
+    def wait(self):
+        self._check(self.lib.hmcmt_wait(self.h))
 
     def forward_device(self, d_m, d_pred, d_misfit):
         self._check(self.lib.hmcmt_forward_device(self.h, d_m, d_pred, d_misfit))

@@ -115,6 +115,17 @@ int hmcmt_forward(hmcmt_ctx* ctx, const double* m, double* pred, double* misfit)
 int hmcmt_grad_device(hmcmt_ctx* ctx, const double* d_m, double* d_pred, double* d_misfit, double* d_grad);
 int hmcmt_forward_device(hmcmt_ctx* ctx, const double* d_m, double* d_pred, double* d_misfit);
 
+/* Asynchronous variant for a device-resident caller (a leapfrog loop whose next model is computed on the device from
+ * this gradient, bench.py): returns when the evaluation is ENQUEUED; the outputs are ordered on the context's stream.
+ * The call still blocks at its two convergence polls, but not on the gradient assembly behind the adjoint solve, so
+ * the host issues the next evaluation's boundary-value stage while the device finishes this one.  Solver status and
+ * statistics of an asynchronous evaluation are collected -- and an error of it is returned -- by the next evaluation
+ * on the context or by hmcmt_wait; between hmcmt_grad_device_async and hmcmt_wait only further
+ * hmcmt_grad_device_async calls are allowed on the context. */
+int hmcmt_grad_device_async(hmcmt_ctx* ctx, const double* d_m, double* d_pred, double* d_misfit, double* d_grad);
+/* waits for everything enqueued on the context; returns the status of the last asynchronous evaluation */
+int hmcmt_wait(hmcmt_ctx* ctx);
+
 /* One leapfrog trajectory on the device (proposeLeapfrog, HMCSampler.jl:206-269; diagonal mass).
  *   m0, p0 [nAC]      current model / momentum (host)
  *   invM [nAC]        diagonal of M^-1

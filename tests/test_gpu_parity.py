@@ -448,3 +448,46 @@ def test_fused_back_post_kernel_matches_separate_kernels():
         assert abs(sums[0] - sums[2]) + abs(sums[1] - sums[3]) < 1e-6 * np.sqrt(sums[5] * (np.abs(R) ** 2).sum())
         assert abs(sums[4] - sums[5]) < 1e-6 * sums[5]
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_asynchronous_device_evaluations_match_synchronous_ones():
+    """hmcmt_grad_device_async enqueues an evaluation and returns (its records are read by the next call or by
+    hmcmt_wait): a sequence of asynchronous evaluations must leave the same numbers and the same statistics as the
+    synchronous entry point on the same models, and a failing evaluation must be reported by the call that follows."""
+    import torch
+    mesh, data, inv, m = make_problem("cfg2")
+    rng = np.random.default_rng(3)
+    ms = np.stack([m + 0.02 * k * rng.standard_normal(m.size) for k in range(5)])
+    dev = torch.device("cuda", 0)
+    d_ms = torch.from_numpy(ms).to(dev)
+
+    def run(asynchronous):
+        ctx = HipContext(mesh, data, inv)
+        d_pred = torch.zeros(2 * ctx.nData, dtype=torch.float64, device=dev)
+        d_mis = torch.zeros(1, dtype=torch.float64, device=dev)
+        d_grads = torch.zeros((len(ms), ctx.nAC), dtype=torch.float64, device=dev)
+        for k in range(len(ms)):
+            f = ctx.grad_device_async if asynchronous else ctx.grad_device
+            f(d_ms[k].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr(), d_grads[k].data_ptr())
+        if asynchronous:
+            ctx.wait()
+        torch.cuda.synchronize()
+        out = (d_grads.cpu().numpy(), d_pred.cpu().numpy(), float(d_mis.item()), ctx.stats())
+        ctx.close()
+        return out
+
+    gs, ps, fs, ss = run(False)
+    ga, pa, fa, sa = run(True)
+    assert np.array_equal(gs, ga) and np.array_equal(ps, pa) and fs == fa        # same kernels, same order: bit-identical
+    assert sa["iters_fwd_max"] == ss["iters_fwd_max"] and sa["iters_adj_max"] == ss["iters_adj_max"] and sa["status"] == 0
+
+    # an evaluation that cannot converge (maxit 2): reported by the next call, not silently dropped
+    ctx = HipContext(mesh, data, inv, maxit=2)
+    d_pred = torch.zeros(2 * ctx.nData, dtype=torch.float64, device=dev)
+    d_mis = torch.zeros(1, dtype=torch.float64, device=dev)
+    d_g = torch.zeros(ctx.nAC, dtype=torch.float64, device=dev)
+    ctx.grad_device_async(d_ms[0].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr(), d_g.data_ptr())
+    with pytest.raises(RuntimeError):
+        ctx.wait()
+    ctx.close()
