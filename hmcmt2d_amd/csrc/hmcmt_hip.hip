@@ -1867,8 +1867,16 @@ __global__ __launch_bounds__(64) void k_rxall(View v, int wantGrad) {        // 
 __global__ void k_rxcoef(View v) { int e = TID1; if (e < v.S * v.nRx) item_rxcoef(v, e / v.nRx, e % v.nRx); }
 // adjoint sources; workgroup (0,0) also adds up the misfit terms (a reduction nothing on the device waits for: no
 // launch of its own on the critical path between the solves)
-__global__ __launch_bounds__(128) void k_src(View v, double* misfitOut) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+__global__ __launch_bounds__(128) void k_src(View v, double* misfitOut, int nsrc) {
+    // blocks x < nsrc: the sources; the blocks behind them: the receiver-layer Q-terms of the gradient (item_qterm
+    // needs nothing from the adjoint solve: here they cost no launch in the gradient tail)
+    const int s = blockIdx.y;
+    if ((int)blockIdx.x >= nsrc) {
+        const int ky = (blockIdx.x - nsrc) * blockDim.x + threadIdx.x;
+        if (ky < v.ny) item_qterm(v, s, ky);
+        return;
+    }
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < 2 * (v.ny + 1)) item_src(v, s, e / (v.ny + 1), e % (v.ny + 1));
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         __shared__ double sh[2];
@@ -1885,19 +1893,40 @@ __global__ void k_wb(View v) {
     if (e < v.nz) item_wside(v, s, e + 1);
     else if (e < v.nz + v.ny) item_colw(v, s, e - v.nz);
 }
-__global__ __launch_bounds__(64) void k_bcsens(View v) {
+__global__ __launch_bounds__(64) void k_bcsens_pre(View v) {
     int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
-    if (c < v.nz) item_bcsens(v, s, prof, c);
+    if (c < v.nz) item_bcsens_pre(v, s, prof, c);
+}
+__global__ void k_bcsens_contract(View v) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
+    if (c < v.nz) item_bcsens_contract(v, s, prof, c);
 }
 __global__ void k_gradcell(View v) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x, mode = blockIdx.y;
-    if (c < v.nCell) item_gradcell(v, mode, c);
+    int c = blockIdx.x * blockDim.x + threadIdx.x, mode = blockIdx.y, grp = blockIdx.z;
+    if (c < v.nCell) item_gradcell_group(v, mode, grp, c);
 }
 __global__ __launch_bounds__(64) void k_qterm(View v) {
     int ky = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
     if (ky < v.ny) item_qterm(v, s, ky);
 }
-__global__ void k_gradfinal(View v) { int a = TID1; if (a < v.nAC) item_gradfinal(v, a); }
+// final assembly with four lanes per active cell (a latency-bound loop over the systems: 4x the threads), each
+// taking every fourth system / partial sum; the four partial sums are added in lane order
+__global__ void k_gradfinal(View v) {
+    const int t = TID1, a = t >> 2, l = t & 3;
+    double g = 0.0;
+    if (a < v.nAC) {
+        const int cell = v.act[a];
+        const int ky = cell % v.ny, kz = cell / v.ny;
+        for (int q = l; q < 2 * GRAD_NG; q += 4) g += v.gPartG[(long)q * v.nCell + cell];
+#pragma unroll 4
+        for (int s = l; s < v.S; s += 4) g += gradfinal_sys(v, s, ky, kz);
+        if (kz == v.zid)
+            for (int s = l; s < v.S; s += 4) g += v.qPart[(long)s * v.ny + ky];
+    }
+    // lanes 4a .. 4a+3 are neighbours in a wave (the grid is a multiple of 64 threads)
+    const double g1 = __shfl_down(g, 1, 4), g2 = __shfl_down(g, 2, 4), g3 = __shfl_down(g, 3, 4);
+    if (a < v.nAC && l == 0) v.grad[a] = exp(v.m[a]) * (((g + g1) + g2) + g3);
+}
 
 // copy padded nodal layout -> reference layout [(ny+1)*(nz+1)] per frequency
 __global__ void k_unpad(View v, const cplx* src, cplx* dst, int s0) {
@@ -2394,6 +2423,8 @@ void launch_adjoint_side(hmcmt_ctx* ctx) {
     if (ctx->sideSens) {
         hipLaunchKernelGGL(k_sens_layers, dim3((v.nz + 1 + 63) / 64, 3, S), dim3(64), 0, ctx->side, v);
         hipLaunchKernelGGL(k_sens_profile, dim3((3 * S + 63) / 64), dim3(64), 0, ctx->side, v);
+        // the serial half of dBC^T w (78 us on a handful of CUs) depends on sigma only: here, not after the adjoint solve
+        hipLaunchKernelGGL(k_bcsens_pre, dim3((v.nz + 63) / 64, 3, S), dim3(64), 0, ctx->side, v);
         hipEventRecord(ctx->evSens, ctx->side);
     }
 }
@@ -2482,7 +2513,8 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         {
             ProfScope ps(ctx, 5);
             HIPCHK(hipMemsetAsync(v.R, 0, vecBytes, st));       // (k_src assigns the two receiver rows and all of srcB)
-            hipLaunchKernelGGL(k_src, dim3((2 * (v.ny + 1) + 127) / 128, S), dim3(128), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit);
+            const int nsrc = (2 * (v.ny + 1) + 127) / 128;
+            hipLaunchKernelGGL(k_src, dim3(nsrc + (v.ny + 127) / 128, S), dim3(128), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit, nsrc);
             if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtA, 0));
             if (warmA) hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, 0);
         }
@@ -2492,17 +2524,10 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         if (rc) return rc;
         ProfScope ps(ctx, 6);
         hipLaunchKernelGGL(k_wb, dim3((v.nz + v.ny + 127) / 128, S), dim3(128), 0, st, v);
-        // dBC^T w (serial chains, 78 us on a handful of CUs) on the side stream -- behind the sensitivity tables it
-        // needs anyway -- beside the cell and receiver-layer terms on the main stream; joined before the assembly
-        HIPCHK(hipEventRecord(ctx->evWb, st));
-        HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evWb, 0));
-        hipLaunchKernelGGL(k_bcsens, dim3((v.nz + 63) / 64, 3, S), dim3(64), 0, ctx->side, v);
-        HIPCHK(hipEventRecord(ctx->evBcs, ctx->side));
-        HIPCHK(hipStreamWaitEvent(st, ctx->evSens, 0));         // (k_gradcell reads the sensitivity-version boundary values)
-        hipLaunchKernelGGL(k_gradcell, dim3((v.nCell + 127) / 128, 2), dim3(128), 0, st, v);
-        hipLaunchKernelGGL(k_qterm, dim3((v.ny + 63) / 64, S), dim3(64), 0, st, v);
-        HIPCHK(hipStreamWaitEvent(st, ctx->evBcs, 0));
-        hipLaunchKernelGGL(k_gradfinal, grid1(v.nAC, 128), dim3(128), 0, st, v);
+        HIPCHK(hipStreamWaitEvent(st, ctx->evSens, 0));         // sensitivity tables, boundary values, dBC (side stream)
+        hipLaunchKernelGGL(k_bcsens_contract, dim3((v.nz + 127) / 128, 2, S), dim3(128), 0, st, v);
+        hipLaunchKernelGGL(k_gradcell, dim3((v.nCell + 127) / 128, 2, GRAD_NG), dim3(128), 0, st, v);
+        hipLaunchKernelGGL(k_gradfinal, grid1(4 * v.nAC, 128), dim3(128), 0, st, v);
     }
     HIPCHK(hipGetLastError());
     ctx->haveModel = true;
@@ -2713,11 +2738,11 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     DA(v.Zrx, S * h.nRx) DA(v.rxN0, S * h.nRx) DA(v.rxD, S * h.nRx * 11) DA(v.rxCoef, S * h.nRx)
     DA(v.pred, h.nData) DA(v.vbar, h.nData) DA(v.misfitPart, h.nData)
     DA(v.srcB, S * 4) DA(v.wL, S * h.nz) DA(v.wR, S * h.nz) DA(v.colw, S * h.ny)
-    DA(v.gL, S * h.nz) DA(v.gR, S * h.nz) DA(v.gMn, S * h.nz) DA(v.bcsL, S * h.nz) DA(v.bcsR, S * h.nz) DA(v.bcsB, S)
+    DA(v.gL, S * h.nz) DA(v.gR, S * h.nz) DA(v.gMn, S * h.nz) DA(v.dBC, S * 2 * (size_t)h.nz * h.nz) DA(v.bcsL, S * h.nz) DA(v.bcsR, S * h.nz) DA(v.bcsB, S)
     DA(v.fwdTab, S * FWD_NQ * (size_t)h.nz * (h.ny + 1)) DA(v.sensTab, S * 15 * (size_t)(h.nz + 1))
     DA(v.sensEu, S * 3 * (size_t)(h.nz + 1)) DA(v.sensEd, S * 3 * (size_t)(h.nz + 1)) DA(v.sensMix, S * 12 * (size_t)h.nz)
     DA(v.sensDz1, S * 3 * (size_t)h.nz) DA(v.sensZ1, S * 3) DA(v.sensDead, S * 3)
-    DA(v.qPart, S * h.ny) DA(v.gPart, 2 * (size_t)h.nCell) DA(v.grad, h.nAC)
+    DA(v.qPart, S * h.ny) DA(v.gPart, 2 * (size_t)h.nCell) DA(v.gPartG, 2 * GRAD_NG * (size_t)h.nCell) DA(v.grad, h.nAC)
     DA(ctx->d_m, h.nAC) DA(ctx->d_misfit, 1)
     for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], 3 * S * VS) DA(ctx->d_mHist[kd], 4 * (size_t)h.nAC) DA(ctx->d_ext[kd], 8 + 8 * EXT_NBLK) }
     Solver& k = ctx->sv;

@@ -71,6 +71,7 @@ struct View {
     cplx* pred;                    // [nData]
     cplx* vbar;                    // [nData] conj(W^T W (pred-obs))
     double* misfitPart;            // [nData] 0.5*|W(pred-obs)|^2
+    double* gPartG;                // [2][GRAD_NG][nCell] P-terms by mode and frequency group (GPU launch)
     const int* srStart;            // [S*nRx+1] CSR of data per (s, rx)
     const int* srList;             // [nData]
     // boundary / gradient work arrays
@@ -81,6 +82,7 @@ struct View {
     cplx* gL;                      // [S][nz]  dBC^T w, left column cells
     cplx* gR;                      // [S][nz]
     cplx* gMn;                     // [S][nz]  last row of the mean-profile sensitivity
+    cplx* dBC;                     // [S][2][nz rows][nz cols]  d(edge column field at row j+1)/d sigma_c, left / right profile
     cplx* bcsL;                    // [S][nz]  sensitivity-version boundary fields (TM term)
     cplx* bcsR;                    // [S][nz]
     cplx* bcsB;                    // [S]      mean-profile bottom value
@@ -404,6 +406,43 @@ HD void item_bcsens(const View& v, int s, int prof, int c) {
     if (prof == 0) v.gL[o] = g; else if (prof == 1) v.gR[o] = g; else v.gMn[o] = g;
 }
 
+// The same in two steps, so that the serial recurrences are off the critical path (they depend on sigma only):
+//   item_bcsens_pre       side stream, beside the solves: the w-independent entries dF(row, c) of the left / right
+//                         profile into v.dBC (the mean profile needs its last row only: v.gMn directly)
+//   item_bcsens_contract  after the adjoint solve: g[c] = sum over rows of dF(row, c) w[row], rows in the order of
+//                         item_bcsens' accumulation (the rows beyond the cut-off hold zeros)
+HD void item_bcsens_pre(const View& v, int s, int prof, int c) {
+    const long o = (long)s * v.nz + c;
+    if (!v.sysOn[s]) { if (prof == 2) v.gMn[o] = cplx{0, 0}; return; }
+    const bool tm = s >= v.nFreq;
+    const long n1 = v.nz + 1, sp = (long)s * 3 + prof;
+    const cplx* T = v.sensTab + sp * 5 * n1;
+    cplx* out = prof < 2 ? v.dBC + ((long)s * 2 + prof) * v.nz * v.nz + c : nullptr;
+    const cplx g = bc1d_sens_column(v.omega[s], v.nz, v.zLen, tm, c, T, T + n1, T + 2 * n1, T + 3 * n1,
+                                    v.sensEu + sp * n1, v.sensEd + sp * n1, v.sensMix + sp * 4 * v.nz,
+                                    v.sensDz1 + sp * v.nz, v.sensZ1[sp], v.sensDead[sp], nullptr, 1, out, v.nz);
+    if (prof == 2) v.gMn[o] = g;
+}
+HD void item_bcsens_contract(const View& v, int s, int prof, int c) {     // prof 0 / 1
+    const long o = (long)s * v.nz + c;
+    cplx acc = cplx{0.0, 0.0};
+    if (v.sysOn[s]) {
+        const cplx* D = v.dBC + ((long)s * 2 + prof) * v.nz * v.nz + c;
+        const cplx* w = (prof == 0 ? v.wL : v.wR) + (long)s * v.nz;
+        // (batches of 8 rows requested together; the additions stay in row order)
+        int j = 0;
+        for (; j + 8 <= v.nz; j += 8) {
+            cplx d[8], ww[8];
+            HMCMT_UNROLL
+            for (int t = 0; t < 8; ++t) { d[t] = D[(long)(j + t) * v.nz]; ww[t] = w[j + t]; }
+            HMCMT_UNROLL
+            for (int t = 0; t < 8; ++t) acc += d[t] * ww[t];
+        }
+        for (; j < v.nz; ++j) acc += D[(long)j * v.nz] * w[j];
+    }
+    if (prof == 0) v.gL[o] = acc; else v.gR[o] = acc;
+}
+
 // --- TM field with the sensitivity-version boundary values (compJacTMatVec.jl:307,315):
 //     h~ = forward solution on interior nodes, getBCderivTM's bc on boundary nodes
 HD cplx tm_field_sens(const View& v, int s, int iy, int iz) {
@@ -415,12 +454,12 @@ HD cplx tm_field_sens(const View& v, int s, int iy, int iz) {
 }
 
 // --- P-terms of J^T v for one cell, summed over the frequencies of one mode
-HD void item_gradcell(const View& v, int mode, int cell) {
+HD double gradcell_freqs(const View& v, int mode, int cell, int f0, int f1) {
     const int ky = cell % v.ny, kz = cell / v.ny;
     const double area = v.yLen[ky] * v.zLen[kz];
     double acc = 0.0;
 #pragma unroll 4
-    for (int f = 0; f < v.nFreq; ++f) {
+    for (int f = f0; f < f1; ++f) {
         const int s = mode * v.nFreq + f;
         if (!v.sysOn[s]) continue;
         const cplx* L = v.Lam + (long)s * v.vstride;
@@ -449,7 +488,17 @@ HD void item_gradcell(const View& v, int mode, int cell) {
             acc += 0.5 * area / (sg * sg) * sum.re;
         }
     }
-    v.gPart[(long)mode * v.nCell + cell] = acc;
+    return acc;
+}
+HD void item_gradcell(const View& v, int mode, int cell) {
+    v.gPart[(long)mode * v.nCell + cell] = gradcell_freqs(v, mode, cell, 0, v.nFreq);
+}
+// the same over one of GRAD_NG groups of frequencies (the GPU's launch: 4x the threads of a latency-bound kernel);
+// partial sums [mode][group][cell], added up by the final assembly
+constexpr int GRAD_NG = 4;
+HD void item_gradcell_group(const View& v, int mode, int grp, int cell) {
+    const int per = (v.nFreq + GRAD_NG - 1) / GRAD_NG, f0 = grp * per, f1 = f0 + per < v.nFreq ? f0 + per : v.nFreq;
+    v.gPartG[((long)mode * GRAD_NG + grp) * v.nCell + cell] = gradcell_freqs(v, mode, cell, f0, f1);
 }
 
 // --- Q-term of one system for one receiver-layer cell: Re sum_r conj(v_r) dZ_r/dsigma_c
@@ -468,19 +517,22 @@ HD void item_qterm(const View& v, int s, int ky) {
 // --- final assembly of the gradient w.r.t. m = ln(sigma) for one active cell:
 //     P-terms + boundary terms + Q-terms, real part, chain rule (compJacTMatVec.jl:244,318,325-327;
 //     HMCSampler.jl:306)
+// boundary term of one system for one cell (branch-free select, not `continue`, so that the loads of several systems
+// are in flight)
+HD double gradfinal_sys(const View& v, int s, int ky, int kz) {
+    const long o = (long)s * v.nz + kz;
+    cplx b = v.gMn[o] * v.colw[(long)s * v.ny + ky];
+    if (ky == 0) b += v.gL[o];
+    if (ky == v.ny - 1) b += v.gR[o];
+    return v.sysOn[s] ? b.re : 0.0;
+}
 HD void item_gradfinal(const View& v, int a) {
     const int cell = v.act[a];
     const int ky = cell % v.ny, kz = cell / v.ny;
     double g = v.gPart[cell] + v.gPart[(long)v.nCell + cell];
     // branch-free over the systems (select, not `continue`) so that the loads of several systems are in flight
 #pragma unroll 8
-    for (int s = 0; s < v.S; ++s) {
-        const long o = (long)s * v.nz + kz;
-        cplx b = v.gMn[o] * v.colw[(long)s * v.ny + ky];
-        if (ky == 0) b += v.gL[o];
-        if (ky == v.ny - 1) b += v.gR[o];
-        g += v.sysOn[s] ? b.re : 0.0;
-    }
+    for (int s = 0; s < v.S; ++s) g += gradfinal_sys(v, s, ky, kz);
     if (kz == v.zid)
         for (int s = 0; s < v.S; ++s) g += v.qPart[(long)s * v.ny + ky];
     v.grad[a] = exp(v.m[a]) * g;

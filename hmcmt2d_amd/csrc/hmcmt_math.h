@@ -336,9 +336,12 @@ HD int sens_profile(double omega, int nz, const double* zLen, bool srcH, const c
 
 // Returns sum_{row=1..nz} dF[row][c] * w[(row-1)*wstride]  (w == nullptr: dF[nz][c], the bottom-row entry
 // used for the mean profile).
+// dFout (optional): the column's entries dF(row j+1, c), j = 0..nz-1, are also stored at dFout[j * dstride] (zero in
+// the rows beyond the cut-off) -- the w-independent part, precomputed off the critical path (item_bcsens_pre).
 HD cplx bc1d_sens_column(double omega, int nz, const double* zLen, bool srcH, int c, const cplx* ka,
                          const cplx* kinv, const cplx* expt, const cplx* expr, const cplx* eu, const cplx* ed,
-                         const cplx* mix, const cplx* dz1, cplx z1, int dead, const cplx* w, long wstride) {
+                         const cplx* mix, const cplx* dz1, cplx z1, int dead, const cplx* w, long wstride,
+                         cplx* dFout = nullptr, long dstride = 0) {
     const double omu = omega * MU0;
     const cplx one = cplx{1.0, 0.0};
     const cplx dkc = (cplx{0.0, -omu / 2.0}) * kinv[c];   // dka[c][c] = (-i omu/2)/ka[c]
@@ -400,11 +403,13 @@ HD cplx bc1d_sens_column(double omega, int nz, const double* zLen, bool srcH, in
                 else dF = ((edn[t] - eun[t]) / omu) * dkn + (kan[t] / omu) * (nEd - nEu);
                 if (row == dead && c > j) dF = cplx{0.0, 0.0};   // cut-off row keeps columns c <= j only
                 dEu = nEu; dEd = nEd;
+                if (dFout) dFout[(long)j * dstride] = dF;
                 if (w) acc += dF * wv[t];
                 else if (row == nz) acc = dF;
             }
         }
     }
+    if (dFout) for (int j = last; j < nz; ++j) dFout[(long)j * dstride] = cplx{0.0, 0.0};
     return acc;
 }
 
