@@ -1594,8 +1594,20 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const cplx* p
 
 // warm start: r <- r - A x over interior nodes, x including whatever sits on its boundary nodes
 // (forward: Dirichlet values, so with r = 0 on entry this is the reference's rhs -Aio*bc minus Aii*x0)
-__global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r) {
+// sysOn != nullptr: workgroup (0,0) also does k_solve_begin's bookkeeping for the solve that follows (one launch less
+// on the critical path in front of each solve)
+__global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r, const int* __restrict__ sysOn) {
     const int s = blockIdx.y;
+    if (sysOn && blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int t = threadIdx.x; t < k.S * MAXNB; t += VBLOCK) k.partB[t] = 0.0;
+        for (int t = threadIdx.x; t < k.S; t += VBLOCK) { k.active[t] = sysOn[t]; k.iters[t] = 0; k.status[t] = 0; }
+        if (threadIdx.x == 0) {
+            int n = 0;
+            for (int q = 0; q < k.S; ++q) n += sysOn[q];
+            *k.nactive = n;
+            *k.nactHost = n;
+        }
+    }
     const int mode = s >= k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
     const double w = k.omega[s];
@@ -2024,6 +2036,7 @@ struct hmcmt_ctx {
     hipStream_t side = nullptr;       // sigma-only sensitivity tables run beside the forward solve
     hipStream_t side2 = nullptr;      // inverse pivots of the FDM tridiagonals run beside the boundary-value kernels
     hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evFdmz = nullptr, evPiv = nullptr, evWb = nullptr, evBcs = nullptr, evPoll = nullptr, evRec = nullptr;
+    bool solveBegun = false;                 // k_resid0 has done k_solve_begin's work for the next solve
     bool statsPending = false, pendingAdj = false;   // records of an asynchronous evaluation not read yet
     std::vector<void*> allocs;
     std::string err;
@@ -2295,7 +2308,9 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     const size_t vecBytes = (size_t)S * k.vstride * sizeof(cplx);
     if (ctx->opt.verify) HIPCHK(hipMemcpyAsync(ctx->d_b, k.r, vecBytes, hipMemcpyDeviceToDevice, ctx->stream));
     // all systems of the requested modes start active (device copy: no host round trip)
-    hipLaunchKernelGGL(k_solve_begin, dim3((S * MAXNB + 255) / 256), dim3(256), 0, ctx->stream, k, ctx->v.sysOn);
+    if (!ctx->solveBegun)           // (otherwise done by the residual kernel in front of this solve)
+        hipLaunchKernelGGL(k_solve_begin, dim3((S * MAXNB + 255) / 256), dim3(256), 0, ctx->stream, k, ctx->v.sysOn);
+    ctx->solveBegun = false;
     int& guess = kind == 0 ? ctx->lastItFwd : ctx->lastItAdj;
     int nextCheck = guess > 2 ? guess : 4;
     const int every = ctx->opt.check_every > 0 ? ctx->opt.check_every : 2;
@@ -2474,6 +2489,15 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, 0.7);
         hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, S), dim3(64), 0, st, v);
         hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, S), dim3(64), 0, st, v);
+        if (pivots) {
+            // the inverse pivots of the FDM tridiagonals (a serial recurrence per mode and system, ~70 us) are not
+            // needed before the first preconditioner apply: second side stream, beside the boundary-value kernels (issued
+            // before the shorter extrapolation launches: 60-70 us of serial work that the first preconditioner apply waits for)
+            HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->evFdmz, 0));
+            hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 0, ctx->side2, v);
+            if (ctx->opt.fdm_precision == 0) hipLaunchKernelGGL(k_invp32, dim3(512), dim3(256), 0, ctx->side2, ctx->sv, ctx->d_invp32);
+            HIPCHK(hipEventRecord(ctx->evPiv, ctx->side2));
+        }
         // side stream: the extrapolation of the forward initial guess (interior nodes only -- k_bc_forward owns the
         // boundary nodes of X)
         if (extrap || wantGrad) HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evModel, 0));
@@ -2482,17 +2506,10 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
             HIPCHK(hipEventRecord(ctx->evExtF, ctx->side));
         }
-        if (pivots) {
-            // the inverse pivots of the FDM tridiagonals (a serial recurrence per mode and system, ~70 us) are not
-            // needed before the first preconditioner apply: second side stream, beside the boundary-value kernels
-            HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->evFdmz, 0));
-            hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 0, ctx->side2, v);
-            if (ctx->opt.fdm_precision == 0) hipLaunchKernelGGL(k_invp32, dim3(512), dim3(256), 0, ctx->side2, ctx->sv, ctx->d_invp32);
-            HIPCHK(hipEventRecord(ctx->evPiv, ctx->side2));
-        }
         if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtF, 0));
         // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X
-        hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, 1);
+        hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, 1, ctx->opt.verify ? nullptr : ctx->v.sysOn);
+        ctx->solveBegun = !ctx->opt.verify;
         if (pivots) HIPCHK(hipStreamWaitEvent(st, ctx->evPiv, 0));
         // (the adjoint half's side-stream work -- its initial guess, the sigma-only sensitivity tables -- is launched
         // from inside the forward solve, once the main queue holds two iterations: launch_adjoint_side)
@@ -2516,7 +2533,10 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             const int nsrc = (2 * (v.ny + 1) + 127) / 128;
             hipLaunchKernelGGL(k_src, dim3(nsrc + (v.ny + 127) / 128, S), dim3(128), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit, nsrc);
             if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtA, 0));
-            if (warmA) hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, 0);
+            if (warmA) {
+                hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, 0, ctx->v.sysOn);
+                ctx->solveBegun = true;
+            }
         }
         rc = solve(ctx, v.Lam, 1);
         HIPCHK(hipEventRecord(ctx->evRec, st));                        // behind the last k_solve_end
