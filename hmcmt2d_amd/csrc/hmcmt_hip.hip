@@ -2436,6 +2436,7 @@ void launch_adjoint_side(hmcmt_ctx* ctx) {
         hipEventRecord(ctx->evExtA, ctx->side);
     }
     if (ctx->sideSens) {
+        hipStreamWaitEvent(ctx->side, ctx->evPiv, 0);          // (the lateral means come from the second side stream)
         hipLaunchKernelGGL(k_sens_layers, dim3((v.nz + 1 + 63) / 64, 3, S), dim3(64), 0, ctx->side, v);
         hipLaunchKernelGGL(k_sens_profile, dim3((3 * S + 63) / 64), dim3(64), 0, ctx->side, v);
         // the serial half of dBC^T w (78 us on a handful of CUs) depends on sigma only: here, not after the adjoint solve
@@ -2465,7 +2466,6 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     {
         ProfScope ps(ctx, 4);
         hipLaunchKernelGGL(k_sigma, grid1(v.nCell, 256), dim3(256), 0, st, v);
-        hipLaunchKernelGGL(k_rowmean, dim3(v.nz), dim3(64), 0, st, v);
         // initial guesses: zero on a cold start, otherwise the previous fields, optionally extrapolated
         if (!warmF) {
             HIPCHK(hipMemsetAsync(v.X, 0, vecBytes, st));
@@ -2475,42 +2475,39 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             HIPCHK(hipMemsetAsync(v.Lam, 0, vecBytes, st));
             HIPCHK(hipMemsetAsync(ctx->d_ext[1], 0, 8 * sizeof(double), st));
         }
-        if (extrap || wantGrad) HIPCHK(hipEventRecord(ctx->evModel, st));
-        hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, st, v);
-        const bool pivots = ctx->opt.precond != HMCMT_PRECOND_JACOBI;
-        if (pivots) HIPCHK(hipEventRecord(ctx->evFdmz, st));
-        // The start of an evaluation is bound by the host's launch rate (the queues are empty after the previous
-        // evaluation's sync), so the order of the API calls is the schedule: first the main stream's coefficient and
-        // boundary-value kernels (0.17 ms of device work), then what must be finished when they are -- the
-        // extrapolated forward guess (side stream) and the inverse pivots (second side stream) --, then the
-        // forward residual, and only then the side-stream work the adjoint half needs.
-        hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, st, v, 0, 1, 1, 0);
-        if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI)
-            hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, 0.7);
+        HIPCHK(hipEventRecord(ctx->evModel, st));
+        // Three chains start from sigma and meet at the forward residual:
+        //   main    boundary-value tables and the serial 1-D recurrences (0.1 ms: the critical one)
+        //   side2   lateral means -> FDM background -> inverse pivots of its tridiagonals (serial, 60-85 us)
+        //   side    stencil coefficients, Jacobi diagonal, the extrapolated forward guess
+        // The host issues them in this order (after the previous evaluation's synchronisation the order of the API
+        // calls is the schedule); the side-stream work of the adjoint half follows from inside the forward solve.
         hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, S), dim3(64), 0, st, v);
         hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, S), dim3(64), 0, st, v);
+        const bool pivots = ctx->opt.precond != HMCMT_PRECOND_JACOBI;
+        HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->evModel, 0));
+        hipLaunchKernelGGL(k_rowmean, dim3(v.nz), dim3(64), 0, ctx->side2, v);
+        hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, ctx->side2, v);
         if (pivots) {
-            // the inverse pivots of the FDM tridiagonals (a serial recurrence per mode and system, ~70 us) are not
-            // needed before the first preconditioner apply: second side stream, beside the boundary-value kernels (issued
-            // before the shorter extrapolation launches: 60-70 us of serial work that the first preconditioner apply waits for)
-            HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->evFdmz, 0));
             hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 0, ctx->side2, v);
             if (ctx->opt.fdm_precision == 0) hipLaunchKernelGGL(k_invp32, dim3(512), dim3(256), 0, ctx->side2, ctx->sv, ctx->d_invp32);
-            HIPCHK(hipEventRecord(ctx->evPiv, ctx->side2));
         }
-        // side stream: the extrapolation of the forward initial guess (interior nodes only -- k_bc_forward owns the
-        // boundary nodes of X)
-        if (extrap || wantGrad) HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evModel, 0));
+        HIPCHK(hipEventRecord(ctx->evPiv, ctx->side2));
+        HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evModel, 0));
+        hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, ctx->side, v, 0, 1, 1, 0);
+        if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI)
+            hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, 0.7);
         if (extrap) {
+            // (interior nodes only -- k_bc_forward owns the boundary nodes of X)
             launch_extrap_weights(ctx, d_m, 0);
             hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
-            HIPCHK(hipEventRecord(ctx->evExtF, ctx->side));
         }
-        if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtF, 0));
+        HIPCHK(hipEventRecord(ctx->evExtF, ctx->side));
+        HIPCHK(hipStreamWaitEvent(st, ctx->evExtF, 0));
         // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X
         hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, 1, ctx->opt.verify ? nullptr : ctx->v.sysOn);
         ctx->solveBegun = !ctx->opt.verify;
-        if (pivots) HIPCHK(hipStreamWaitEvent(st, ctx->evPiv, 0));
+        HIPCHK(hipStreamWaitEvent(st, ctx->evPiv, 0));
         // (the adjoint half's side-stream work -- its initial guess, the sigma-only sensitivity tables -- is launched
         // from inside the forward solve, once the main queue holds two iterations: launch_adjoint_side)
         ctx->sideView = v; ctx->sideM = d_m; ctx->sideExtrap = extrap && wantGrad; ctx->sideSens = wantGrad;
