@@ -1798,8 +1798,18 @@ __global__ void k_coef(View v, int te_doK, int te_doM, int tm_doK, int tm_doM) {
 }
 __global__ void k_fdm_z(View v) { int e = TID1; if (e < 2 * v.NZP) item_fdm_z(v, e / v.NZP, e % v.NZP); }
 __global__ __launch_bounds__(64) void k_pivot(View v) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
-    if (j < v.ny - 1) item_pivot(v, s, j);
+    // the mode's coefficient rows (4 x NZP doubles) staged in LDS: the serial loop then reads LDS, not global memory
+    extern __shared__ __attribute__((aligned(16))) char smem_pv[];
+    double* tab = reinterpret_cast<double*>(smem_pv);
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y, mode = s >= v.nFreq;
+    for (int i = threadIdx.x; i < v.NZP; i += blockDim.x) {
+        tab[i] = v.mzq[(long)mode * v.NZP + i];
+        tab[v.NZP + i] = v.dgz[(long)mode * v.NZP + i];
+        tab[2 * v.NZP + i] = v.ofz[(long)mode * v.NZP + i];
+        tab[3 * v.NZP + i] = v.mzs[(long)mode * v.NZP + i];
+    }
+    __syncthreads();
+    if (j < v.ny - 1) item_pivot_tab(v, s, j, tab, tab + v.NZP, tab + 2 * v.NZP, tab + 3 * v.NZP);
 }
 __global__ __launch_bounds__(64) void k_bc_layers(View v) {
     int col = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, s = blockIdx.z;
@@ -2489,7 +2499,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         hipLaunchKernelGGL(k_rowmean, dim3(v.nz), dim3(64), 0, ctx->side2, v);
         hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, ctx->side2, v);
         if (pivots) {
-            hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 0, ctx->side2, v);
+            hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 4 * (size_t)v.NZP * sizeof(double), ctx->side2, v);
             if (ctx->opt.fdm_precision == 0) hipLaunchKernelGGL(k_invp32, dim3(512), dim3(256), 0, ctx->side2, ctx->sv, ctx->d_invp32);
         }
         HIPCHK(hipEventRecord(ctx->evPiv, ctx->side2));

@@ -180,34 +180,39 @@ HD void item_fdm_z(const View& v, int mode, int iz) {
 //     global memory, are instruction-issue-bound and do not gain (20 us vs 16 us), so they use twist = 0
 //     (mid = n: the classic Thomas factorisation) unless they have to follow the fused kernel's pivots.
 HD int twist_mid(int n, int twist) { return twist ? (n + 1) / 2 : n; }   // rows 1..mid | mid+1..n   (n = nz-1 >= 2)
-HD void item_pivot(const View& v, int s, int j) {
-    const int mode = s >= v.nFreq;
+// (mzq, dgz, ofz, mzs: the mode's four coefficient rows -- the GPU kernel passes copies staged in LDS: read from global
+// memory they cost the serial loop one memory round trip per step)
+HD void item_pivot_tab(const View& v, int s, int j, const double* mzq, const double* dgz, const double* ofz, const double* mzs) {
     const double w = v.omega[s], lam = v.lam[j];
-    const double *mzq = v.mzq + (long)mode * v.NZP, *dgz = v.dgz + (long)mode * v.NZP,
-                 *ofz = v.ofz + (long)mode * v.NZP, *mzs = v.mzs + (long)mode * v.NZP;
     cplx* ip = v.invp + (long)s * v.vstride + j;
     const int n = v.nz - 1, mid = twist_mid(n, v.twist);
-    cplx prev = cplx{0, 0}, dtop = cplx{0, 0}, dbot = cplx{0, 0};
-    for (int iz = 1; iz <= mid; ++iz) {                    // d'_iz = d_iz - of_{iz-1}^2 / d'_{iz-1}
-        cplx d = cplx{lam * mzq[iz] + dgz[iz], w * mzs[iz]};
-        if (iz > 1) d -= (ofz[iz - 1] * ofz[iz - 1]) * prev;
-        prev = crecip(d);
-        ip[(long)iz * v.NYP] = prev;
-        dtop = d;
-    }
-    prev = cplx{0, 0};
-    for (int iz = n; iz >= mid + 1; --iz) {                // d''_iz = d_iz - of_iz^2 / d''_{iz+1}
-        cplx d = cplx{lam * mzq[iz] + dgz[iz], w * mzs[iz]};
-        if (iz < n) d -= (ofz[iz] * ofz[iz]) * prev;
-        prev = crecip(d);
-        ip[(long)iz * v.NYP] = prev;
-        dbot = d;
+    // the two recurrences are independent: one loop advances both (two dependent chains of complex reciprocals in
+    // flight instead of one after the other: k_pivot 58 -> us)
+    cplx pt = cplx{0, 0}, pb = cplx{0, 0};
+    for (int t = 0; t < mid; ++t) {
+        const int it = 1 + t, ib = n - t;
+        {                                                  // d'_iz = d_iz - of_{iz-1}^2 / d'_{iz-1}
+            cplx d = cplx{lam * mzq[it] + dgz[it], w * mzs[it]};
+            if (it > 1) d -= (ofz[it - 1] * ofz[it - 1]) * pt;
+            pt = crecip(d);
+            ip[(long)it * v.NYP] = pt;
+        }
+        if (ib >= mid + 1) {                               // d''_iz = d_iz - of_iz^2 / d''_{iz+1}
+            cplx d = cplx{lam * mzq[ib] + dgz[ib], w * mzs[ib]};
+            if (ib < n) d -= (ofz[ib] * ofz[ib]) * pb;
+            pb = crecip(d);
+            ip[(long)ib * v.NYP] = pb;
+        }
     }
     // middle coupling of the two normalised halves: x_mid + c x_{mid+1} = y'_mid, x_{mid+1} + c' x_mid = y''_{mid+1}
     // with c = o*ip_mid, c' = o*ip_{mid+1}; store 1/(1 - c c') in the unused boundary row iz = 0
     const double o = ofz[mid];
-    (void)dtop; (void)dbot;
-    ip[0] = (mid + 1 <= n) ? crecip(cplx{1.0, 0.0} - (o * o) * (ip[(long)mid * v.NYP] * ip[(long)(mid + 1) * v.NYP])) : cplx{1.0, 0.0};
+    ip[0] = (mid + 1 <= n) ? crecip(cplx{1.0, 0.0} - (o * o) * (pt * pb)) : cplx{1.0, 0.0};   // (pt, pb: the pivots of rows mid, mid+1)
+}
+HD void item_pivot(const View& v, int s, int j) {
+    const int mode = s >= v.nFreq;
+    item_pivot_tab(v, s, j, v.mzq + (long)mode * v.NZP, v.dgz + (long)mode * v.NZP, v.ofz + (long)mode * v.NZP,
+                   v.mzs + (long)mode * v.NZP);
 }
 
 // --- per-layer terms of the 1-D column under boundary node column `col` (0 = left edge, ny = right
