@@ -2045,7 +2045,7 @@ struct hmcmt_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;       // sigma-only sensitivity tables run beside the forward solve
     hipStream_t side2 = nullptr;      // inverse pivots of the FDM tridiagonals run beside the boundary-value kernels
-    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evFdmz = nullptr, evPiv = nullptr, evWb = nullptr, evBcs = nullptr, evPoll = nullptr, evRec = nullptr;
+    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evPiv = nullptr, evPoll = nullptr, evRec = nullptr;
     bool solveBegun = false;                 // k_resid0 has done k_solve_begin's work for the next solve
     bool statsPending = false, pendingAdj = false;   // records of an asynchronous evaluation not read yet
     std::vector<void*> allocs;
@@ -2645,10 +2645,7 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (ctx->evModel) hipEventDestroy(ctx->evModel);
     if (ctx->evSens) hipEventDestroy(ctx->evSens);
     if (ctx->evExtF) hipEventDestroy(ctx->evExtF);
-    if (ctx->evFdmz) hipEventDestroy(ctx->evFdmz);
     if (ctx->evPiv) hipEventDestroy(ctx->evPiv);
-    if (ctx->evWb) hipEventDestroy(ctx->evWb);
-    if (ctx->evBcs) hipEventDestroy(ctx->evBcs);
     if (ctx->evPoll) hipEventDestroy(ctx->evPoll);
     if (ctx->evRec) hipEventDestroy(ctx->evRec);
     if (ctx->side2) hipStreamDestroy(ctx->side2);
@@ -2671,10 +2668,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     HIPCHK(hipEventCreateWithFlags(&ctx->evModel, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evSens, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evExtF, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ctx->evFdmz, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evPiv, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ctx->evWb, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ctx->evBcs, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evPoll, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evRec, hipEventDisableTiming));
     HIPCHK(hipStreamCreate(&ctx->side2));
