@@ -1623,6 +1623,93 @@ __global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r
     }
 }
 
+// k_resid0 + k_pre_c64 in one launch (the start of a solve on the default path): on a tile of RT rows
+//   r = b - A x0        on the tile's rows and one halo row on each side (x0 staged with two halo rows)
+//   t = r - A (dinv r)  on the tile's rows, written in the transform's input format
+// so the residual is not re-read by a second kernel and one launch disappears in front of each solve.  The residual is
+// written to a SECOND buffer (rout): the halo rows' b are read from rin while the neighbouring workgroups write theirs.
+// Workgroup (0,0) also does k_solve_begin's bookkeeping.
+__global__ __launch_bounds__(VBLOCK) void k_resid_pre(Solver k, const cplx* x, const cplx* rin, cplx* rout, int zero_r,
+                                                      const int* __restrict__ sysOn) {
+    const int s = blockIdx.y;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int t = threadIdx.x; t < k.S * MAXNB; t += VBLOCK) k.partB[t] = 0.0;
+        for (int t = threadIdx.x; t < k.S; t += VBLOCK) { k.active[t] = sysOn[t]; k.iters[t] = 0; k.status[t] = 0; }
+        if (threadIdx.x == 0) {
+            int n = 0;
+            for (int q = 0; q < k.S; ++q) n += sysOn[q];
+            *k.nactive = n;
+            *k.nactHost = n;
+        }
+    }
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1), nown = iz1 - iz0 + 1;
+    cplx* xs = reinterpret_cast<cplx*>(smem_);            // [(RT+4)][NYP]  x0 rows iz0-2 .. iz1+2; later dinv .* r (rows iz0-1 ..)
+    cplx* rs = xs + (long)(k.RT + 4) * NYP;               // [(RT+2)][NYP]  r rows iz0-1 .. iz1+1
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const float rNYP = 1.0f / (float)NYP;
+    const cplx* u = x + so;
+    for (int i = threadIdx.x; i < (nown + 4) * NYP; i += VBLOCK) {
+        const int lr = div_small(i, rNYP), g = iz0 - 2 + lr;
+        xs[i] = (g >= 0 && g <= k.nz) ? u[(long)g * NYP + (i - lr * NYP)] : cplx{0, 0};
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (nown + 2) * NYP; i += VBLOCK) {
+        const int lr = div_small(i, rNYP), iy = i - lr * NYP, g = iz0 - 1 + lr;
+        const long e = (long)g * NYP + iy;
+        cplx out = cplx{0, 0};
+        if (g >= 1 && g <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+            const int l = i + NYP;                         // the same node in xs (one more halo row in front)
+            const cplx c = xs[l];
+            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+            acc += k.cY[mo + e] * xs[l + 1];
+            acc += k.cY[mo + e - 1] * xs[l - 1];
+            acc += k.cZ[mo + e] * xs[l + NYP];
+            acc += k.cZ[mo + e - NYP] * xs[l - NYP];
+            out = (zero_r ? cplx{0, 0} : rin[so + e]) - acc;
+        }
+        rs[i] = out;
+        if (lr >= 1 && lr <= nown) rout[so + e] = out;
+    }
+    // the two boundary rows of r and of t (zeros)
+    if (blockIdx.x == 0 || iz1 == k.nz - 1) {
+        const int row = blockIdx.x == 0 ? 0 : k.nz;
+        for (int iy = threadIdx.x; iy < NYP; iy += VBLOCK) {
+            rout[so + (long)row * NYP + iy] = cplx{0, 0};
+            store_t32(k, k.t32 + so, row, iy, 0.f, 0.f);
+        }
+        if (blockIdx.x == 0 && iz1 == k.nz - 1)            // (a single tile: both rows)
+            for (int iy = threadIdx.x; iy < NYP; iy += VBLOCK) {
+                rout[so + (long)k.nz * NYP + iy] = cplx{0, 0};
+                store_t32(k, k.t32 + so, k.nz, iy, 0.f, 0.f);
+            }
+    }
+    __syncthreads();
+    const cplx* di = k.dinv + so;
+    for (int i = threadIdx.x; i < (nown + 2) * NYP; i += VBLOCK) xs[i] = di[(long)(iz0 - 1) * NYP + i] * rs[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < nown * NYP; i += VBLOCK) {
+        const int lr = div_small(i, rNYP), iy = i - lr * NYP;
+        const long e = (long)(iz0 + lr) * NYP + iy;
+        cplx out = cplx{0, 0};
+        if (iy >= 1 && iy <= k.ny - 1) {
+            const int l = i + NYP;
+            const cplx c = xs[l];
+            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+            acc += k.cY[mo + e] * xs[l + 1];
+            acc += k.cY[mo + e - 1] * xs[l - 1];
+            acc += k.cZ[mo + e] * xs[l + NYP];
+            acc += k.cZ[mo + e - NYP] * xs[l - NYP];
+            out = rs[l] - acc;
+        }
+        store_t32(k, k.t32 + so, iz0 + lr, iy, (float)out.re, (float)out.im);
+    }
+}
+
 // start of a solve: every requested system active, records cleared (one launch instead of five copies/memsets)
 __global__ void k_solve_begin(Solver k, const int* __restrict__ sysOn) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2046,7 +2133,8 @@ struct hmcmt_ctx {
     hipStream_t side = nullptr;       // sigma-only sensitivity tables run beside the forward solve
     hipStream_t side2 = nullptr;      // inverse pivots of the FDM tridiagonals run beside the boundary-value kernels
     hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evPiv = nullptr, evPoll = nullptr, evRec = nullptr;
-    bool solveBegun = false;                 // k_resid0 has done k_solve_begin's work for the next solve
+    bool solveBegun = false;                 // k_resid0 / k_resid_pre has done k_solve_begin's work for the next solve
+    bool preDone = false;                    // k_resid_pre has done the first pre-smoothing pass of the next solve
     bool statsPending = false, pendingAdj = false;   // records of an asynchronous evaluation not read yet
     std::vector<void*> allocs;
     std::string err;
@@ -2276,7 +2364,8 @@ int apply_precond(hmcmt_ctx* ctx) {
     int rc;
     if (ctx->opt.fdm_precision == 0 && !ctx->lpFallback) {
         // mixed precision: split-bf16 operands / fp32 accumulation in the transforms, complex64 tridiagonal
-        if (smooth) { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_pre_c64, vg, vb, 0, ctx->stream, k); }
+        if (smooth && ctx->preDone) ctx->preDone = false;                        // (k_resid_pre has written t)
+        else if (smooth) { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_pre_c64, vg, vb, 0, ctx->stream, k); }
         else { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_to_c64, vg, vb, 0, ctx->stream, k, k.r); }
         if ((rc = launch_fdm_fwd(ctx))) return rc;
         if (smooth) {
@@ -2473,6 +2562,10 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     const bool warmF = ctx->opt.warm_start && ctx->haveFwd && !ctx->opt.verify;
     const bool warmA = ctx->opt.warm_start && ctx->haveAdj && !ctx->opt.verify;
     const bool extrap = ctx->opt.warm_start == 2 && !ctx->opt.verify;
+    // start of a solve on the default path: residual and first pre-smoothing pass in one launch (k_resid_pre)
+    const size_t startLds = (size_t)(2 * ctx->sv.RT + 6) * v.NYP * sizeof(cplx);
+    const bool fusedStart = ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0 && !ctx->opt.verify &&
+                            startLds <= (size_t)150 * 1024 && !getenv("HMCMT_NO_FUSED_START");
     {
         ProfScope ps(ctx, 4);
         hipLaunchKernelGGL(k_sigma, grid1(v.nCell, 256), dim3(256), 0, st, v);
@@ -2515,8 +2608,14 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         HIPCHK(hipEventRecord(ctx->evExtF, ctx->side));
         HIPCHK(hipStreamWaitEvent(st, ctx->evExtF, 0));
         // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X
-        hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, 1, ctx->opt.verify ? nullptr : ctx->v.sysOn);
-        ctx->solveBegun = !ctx->opt.verify;
+        if (fusedStart) {
+            hipLaunchKernelGGL(k_resid_pre, dim3(ctx->sv.NTR, S), dim3(VBLOCK), startLds, st, ctx->sv, v.X, ctx->sv.r, ctx->sv.r2, 1, ctx->v.sysOn);
+            std::swap(ctx->sv.r, ctx->sv.r2);             // (the residual went to the second buffer; swapped back after the solve)
+            ctx->solveBegun = ctx->preDone = true;
+        } else {
+            hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, 1, ctx->opt.verify ? nullptr : ctx->v.sysOn);
+            ctx->solveBegun = !ctx->opt.verify;
+        }
         HIPCHK(hipStreamWaitEvent(st, ctx->evPiv, 0));
         // (the adjoint half's side-stream work -- its initial guess, the sigma-only sensitivity tables -- is launched
         // from inside the forward solve, once the main queue holds two iterations: launch_adjoint_side)
@@ -2524,6 +2623,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         ctx->sidePending = wantGrad;
     }
     int rc = solve(ctx, v.X, 0);
+    if (fusedStart) std::swap(ctx->sv.r, ctx->sv.r2);
     if (!wantGrad) HIPCHK(hipEventRecord(ctx->evRec, st));          // behind the last k_solve_end
     launch_adjoint_side(ctx);            // (no-op when the solve has already done it)
     ctx->haveFwd = (rc == 0 && ctx->solveDone[0]);
@@ -2540,12 +2640,17 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             const int nsrc = (2 * (v.ny + 1) + 127) / 128;
             hipLaunchKernelGGL(k_src, dim3(nsrc + (v.ny + 127) / 128, S), dim3(128), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit, nsrc);
             if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtA, 0));
-            if (warmA) {
+            if (warmA && fusedStart) {
+                hipLaunchKernelGGL(k_resid_pre, dim3(ctx->sv.NTR, S), dim3(VBLOCK), startLds, st, ctx->sv, v.Lam, ctx->sv.r, ctx->sv.r2, 0, ctx->v.sysOn);
+                std::swap(ctx->sv.r, ctx->sv.r2);
+                ctx->solveBegun = ctx->preDone = true;
+            } else if (warmA) {
                 hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, 0, ctx->v.sysOn);
                 ctx->solveBegun = true;
             }
         }
         rc = solve(ctx, v.Lam, 1);
+        if (warmA && fusedStart) std::swap(ctx->sv.r, ctx->sv.r2);
         HIPCHK(hipEventRecord(ctx->evRec, st));                        // behind the last k_solve_end
         ctx->haveAdj = (rc == 0 && ctx->solveDone[1]);
         if (rc) return rc;
@@ -2690,6 +2795,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         // the stencil kernels' tiles can pass 64 KB on wide meshes
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_resid_pre), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
     }
     HIPCHK(hipEventCreateWithFlags(&ctx->evExtA, hipEventDisableTiming));
     const HostProblem& h = ctx->hp;
