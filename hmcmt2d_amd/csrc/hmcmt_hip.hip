@@ -1898,36 +1898,53 @@ __global__ __launch_bounds__(64) void k_pivot(View v) {
     __syncthreads();
     if (j < v.ny - 1) item_pivot_tab(v, s, j, tab, tab + v.NZP, tab + 2 * v.NZP, tab + 3 * v.NZP);
 }
-__global__ __launch_bounds__(64) void k_bc_layers(View v) {
-    int col = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, s = blockIdx.z;
-    if (col <= v.ny) item_bc_layers(v, s, j, col);
+__global__ __launch_bounds__(64) void k_bc_layers(View v) {       // grid z: frequencies
+    int col = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, f = blockIdx.z;
+    if (col <= v.ny) item_bc_layers_f(v, f, j, col);
 }
 // One thread per boundary column.  The two edge columns need the whole 1-D field (left / right boundary values):
 // their lane writes it to LDS inside the recurrence (same code path as every other lane) and the wave copies it
 // out afterwards.
+// One lane = one boundary column of one FREQUENCY: the layered-earth recurrences are the same for the two
+// polarisations, so one pass yields both systems' values (bc1d_forward_tab_2).
 __global__ __launch_bounds__(64) void k_bc_forward(View v) {
-    __shared__ cplx edge[2][MAXNZP];                      // slot 0: column 0, slot 1: column ny
-    const int col0 = blockIdx.x * blockDim.x, col = col0 + threadIdx.x, s = blockIdx.y;
-    if (!v.sysOn[s]) return;
-    const bool tm = s >= v.nFreq;
-    cplx* X = v.X + (long)s * v.vstride;
+    extern __shared__ __attribute__((aligned(16))) char smem_bc[];
+    cplx* edge = reinterpret_cast<cplx*>(smem_bc);        // [mode][slot 0: column 0, slot 1: column ny][nz]
+    const int col0 = blockIdx.x * blockDim.x, col = col0 + threadIdx.x, f = blockIdx.y;
+    const bool onE = v.sysOn[f] != 0, onH = v.sysOn[v.nFreq + f] != 0;
+    if (!onE && !onH) return;
+    cplx* XE = v.X + (long)f * v.vstride;
+    cplx* XH = v.X + (long)(v.nFreq + f) * v.vstride;
     const long ls = v.ny + 1, qs = (long)v.nz * ls;
     if (col <= v.ny) {
-        X[nidx(v, col, 0)] = cplx{1.0, 0.0};              // top row incl. corners
-        const cplx* T = v.fwdTab + (long)s * FWD_NQ * qs + col;
+        if (onE) XE[nidx(v, col, 0)] = cplx{1.0, 0.0};    // top row incl. corners
+        if (onH) XH[nidx(v, col, 0)] = cplx{1.0, 0.0};
+        const cplx* T = v.fwdTab + (long)f * FWD_NQ * qs + col;
         // ONE instantiation of the recurrence for every lane (a separate call for the edge lanes would make their
         // wave run the whole chain twice, once per divergent path: that was the kernel's critical path)
         const bool isEdge = col == 0 || col == v.ny;
-        cplx* e = edge[col == 0 ? 0 : 1];
-        const cplx last = bc1d_forward_tab_f(v.omega[s], v.nz, T, qs, ls, tm, [&](int i, cplx val) { if (isEdge) e[i] = val; });
-        if (!isEdge) X[nidx(v, col, v.nz)] = last;
+        cplx* eE = edge + (long)(col == 0 ? 0 : 1) * v.nz;
+        cplx* eH = eE + 2L * v.nz;
+        cplx lastE, lastH;
+        bc1d_forward_tab_2(v.omega[f], v.nz, T, qs, ls, [&](int i, cplx val) { if (isEdge) eE[i] = val; },
+                           [&](int i, cplx val) { if (isEdge) eH[i] = val; }, lastE, lastH);
+        if (!isEdge) {
+            if (onE) XE[nidx(v, col, v.nz)] = lastE;
+            if (onH) XH[nidx(v, col, v.nz)] = lastH;
+        }
     }
     const bool has0 = col0 == 0, hasN = col0 <= v.ny && v.ny < col0 + (int)blockDim.x;
     if (has0 || hasN) {
         __syncthreads();
         for (int i = threadIdx.x; i < v.nz; i += blockDim.x) {
-            if (has0) X[nidx(v, 0, 1 + i)] = edge[0][i];
-            if (hasN) X[nidx(v, v.ny, 1 + i)] = edge[1][i];
+            if (has0) {
+                if (onE) XE[nidx(v, 0, 1 + i)] = edge[i];
+                if (onH) XH[nidx(v, 0, 1 + i)] = edge[2L * v.nz + i];
+            }
+            if (hasN) {
+                if (onE) XE[nidx(v, v.ny, 1 + i)] = edge[(long)v.nz + i];
+                if (onH) XH[nidx(v, v.ny, 1 + i)] = edge[3L * v.nz + i];
+            }
         }
     }
 }
@@ -2585,8 +2602,8 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         //   side    stencil coefficients, Jacobi diagonal, the extrapolated forward guess
         // The host issues them in this order (after the previous evaluation's synchronisation the order of the API
         // calls is the schedule); the side-stream work of the adjoint half follows from inside the forward solve.
-        hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, S), dim3(64), 0, st, v);
-        hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, S), dim3(64), 0, st, v);
+        hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, v.nFreq), dim3(64), 0, st, v);
+        hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, v.nFreq), dim3(64), 4 * (size_t)v.nz * sizeof(cplx), st, v);
         const bool pivots = ctx->opt.precond != HMCMT_PRECOND_JACOBI;
         HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->evModel, 0));
         hipLaunchKernelGGL(k_rowmean, dim3(v.nz), dim3(64), 0, ctx->side2, v);

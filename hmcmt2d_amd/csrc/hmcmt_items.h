@@ -234,6 +234,19 @@ HD void item_bc_layers(const View& v, int s, int j, int col) {
     for (int q = 0; q < FWD_NQ; ++q) T[q * qs] = t[q];
 }
 
+// The per-layer tables depend on the frequency and the column profile, not on the polarisation: the GPU computes them
+// once per frequency (slot f of fwdTab = the TE system's) for the frequencies with at least one polarisation in the data
+HD void item_bc_layers_f(const View& v, int f, int j, int col) {
+    if (!v.sysOn[f] && !v.sysOn[v.nFreq + f]) return;
+    const bool lastLayer = j + 1 >= v.nz;
+    const double sig = bc_column_sigma(v, j, col), sigNext = lastLayer ? sig : bc_column_sigma(v, j + 1, col);
+    cplx t[FWD_NQ];
+    layer_forward(sig, sigNext, lastLayer, v.omega[f], v.zLen[j], t);
+    const long ls = v.ny + 1, qs = (long)v.nz * ls;
+    cplx* T = v.fwdTab + (long)f * FWD_NQ * qs + (long)j * ls + col;
+    for (int q = 0; q < FWD_NQ; ++q) T[q * qs] = t[q];
+}
+
 // --- Dirichlet values of the forward problem written into X's boundary nodes
 //     (getBoundaryMT2DTE/TM, mt2DTE.jl:100-134, mt2DTM.jl:100-134).  col = 0..ny.
 HD void item_bc_forward(const View& v, int s, int col) {

@@ -135,8 +135,12 @@ HD void layer_forward(double sig, double sigNext, bool lastLayer, double omega, 
 // in the same in-order vmcnt queue as the table loads.)
 constexpr int RB = 4;
 constexpr int RBF = 8;             // layers per block of the forward recurrences (4: 92 us, 8: 68 us, 16: 75 us for k_bc_forward)
-template <class OutF>
-HD cplx bc1d_forward_tab_f(double omega, int nz, const cplx* T, long qs, long ls, bool compH, OutF outf) {
+// Both polarisations of one frequency in one pass: the layered-earth recurrences (impedance bottom -> top, amplitudes
+// top -> bottom) are the same for TE and TM; only the functional of the amplitudes differs -- E = Eu + Ed (TE) or
+// H = (Ed - Eu) k / (omega mu0) (TM), each normalised by its own top value.  outE(i, v) / outH(i, v) receive the
+// normalised field under layer i.
+template <class OutE, class OutH>
+HD void bc1d_forward_tab_2(double omega, int nz, const cplx* T, long qs, long ls, OutE outE, OutH outH, cplx& lastE_, cplx& lastH_) {
     const double omu0 = omega * MU0;
     const cplx one = cplx{1.0, 0.0};
     // impedance recurrence bottom -> top (:48-56); half-space has the last layer's conductivity.
@@ -181,9 +185,8 @@ HD cplx bc1d_forward_tab_f(double omega, int nz, const cplx* T, long qs, long ls
     const cplx a = omu0 / (ztmp * kj);
     cplx eu = 0.5 * (one - a), ed = 0.5 * (one + a);
     const double iomu0 = 1.0 / omu0;
-    const cplx f0 = compH ? ((ed - eu) * kj) * iomu0 : (eu + ed);
-    const cplx if0 = crecip(f0);
-    cplx last = one;
+    const cplx if0E = crecip(eu + ed), if0H = crecip(((ed - eu) * kj) * iomu0);
+    cplx lastE = one, lastH = one;
     bool dead = false;
     // one layer i -> i+1 (:69-83)
     // The serial chain is the 2x2 product alone: the cut-off test (three more dependent levels) only feeds the `dead`
@@ -195,10 +198,10 @@ HD cplx bc1d_forward_tab_f(double omega, int nz, const cplx* T, long qs, long ls
         const double e2 = cabs2(nu + nd), e1 = cabs2(eu + ed);       // |.|^2: same ordering as |.|
         dead = dead || e2 - e1 > 0.0 || isnan(e2);                   // overflow cut-off: zero from here down
         eu = nu; ed = nd; kj = kn;
-        cplx fn = compH ? ((ed - eu) * kj) * iomu0 : (eu + ed);
-        if (dead) fn = cplx{0.0, 0.0};
-        last = fn * if0;
-        outf(i, last);
+        cplx fnE = eu + ed, fnH = ((ed - eu) * kj) * iomu0;
+        if (dead) { fnE = cplx{0.0, 0.0}; fnH = cplx{0.0, 0.0}; }
+        lastE = fnE * if0E; lastH = fnH * if0H;
+        outE(i, lastE); outH(i, lastH);
     };
     // whole blocks of RBF layers with all table entries requested up front and no conditions around them (inside a
     // conditional the compiler sinks the loads next to their use: a second memory round trip per block), then the
@@ -220,7 +223,17 @@ HD cplx bc1d_forward_tab_f(double omega, int nz, const cplx* T, long qs, long ls
         const cplx kn = (i0 + 1 >= nz) ? kj : T[(i + 1) * ls];
         down(i0, kn, T[4 * qs + i * ls], T[5 * qs + i * ls], T[6 * qs + i * ls], T[7 * qs + i * ls]);
     }
-    return last;
+    lastE_ = lastE; lastH_ = lastH;
+}
+
+
+// one polarisation (compH: the TM functional)
+template <class OutF>
+HD cplx bc1d_forward_tab_f(double omega, int nz, const cplx* T, long qs, long ls, bool compH, OutF outf) {
+    cplx lE, lH;
+    bc1d_forward_tab_2(omega, nz, T, qs, ls, [&](int i, cplx v) { if (!compH) outf(i, v); },
+                       [&](int i, cplx v) { if (compH) outf(i, v); }, lE, lH);
+    return compH ? lH : lE;
 }
 
 HD cplx bc1d_forward_tab(double omega, int nz, const cplx* T, long qs, long ls, bool compH, cplx* out, long ostride) {
