@@ -1906,16 +1906,21 @@ __global__ __launch_bounds__(64) void k_bc_layers(View v) {       // grid z: fre
 // their lane writes it to LDS inside the recurrence (same code path as every other lane) and the wave copies it
 // out afterwards.
 // One lane = one boundary column of one FREQUENCY: the layered-earth recurrences are the same for the two
-// polarisations, so one pass yields both systems' values (bc1d_forward_tab_2).
+// polarisations, so one pass yields both systems' values.  Only the two edge columns need the fields under every layer;
+// their lanes store the amplitudes per layer in LDS and the workgroup evaluates the outputs afterwards in parallel
+// (fwd_outputs: ~30 fp64 instructions per layer that would otherwise sit in every wave's serial loop).
 __global__ __launch_bounds__(64) void k_bc_forward(View v) {
     extern __shared__ __attribute__((aligned(16))) char smem_bc[];
-    cplx* edge = reinterpret_cast<cplx*>(smem_bc);        // [mode][slot 0: column 0, slot 1: column ny][nz]
+    cplx* amp = reinterpret_cast<cplx*>(smem_bc);         // [slot 0: column 0, slot 1: column ny][nz][eu, ed]
+    __shared__ FwdTop top[2];
+    __shared__ int deadAt[2];
     const int col0 = blockIdx.x * blockDim.x, col = col0 + threadIdx.x, f = blockIdx.y;
     const bool onE = v.sysOn[f] != 0, onH = v.sysOn[v.nFreq + f] != 0;
     if (!onE && !onH) return;
     cplx* XE = v.X + (long)f * v.vstride;
     cplx* XH = v.X + (long)(v.nFreq + f) * v.vstride;
     const long ls = v.ny + 1, qs = (long)v.nz * ls;
+    const bool has0 = col0 == 0, hasN = col0 <= v.ny && v.ny < col0 + (int)blockDim.x;
     if (col <= v.ny) {
         if (onE) XE[nidx(v, col, 0)] = cplx{1.0, 0.0};    // top row incl. corners
         if (onH) XH[nidx(v, col, 0)] = cplx{1.0, 0.0};
@@ -1923,27 +1928,33 @@ __global__ __launch_bounds__(64) void k_bc_forward(View v) {
         // ONE instantiation of the recurrence for every lane (a separate call for the edge lanes would make their
         // wave run the whole chain twice, once per divergent path: that was the kernel's critical path)
         const bool isEdge = col == 0 || col == v.ny;
-        cplx* eE = edge + (long)(col == 0 ? 0 : 1) * v.nz;
-        cplx* eH = eE + 2L * v.nz;
+        const int slot = col == 0 ? 0 : 1;
+        cplx* ea = amp + (long)slot * 2 * v.nz;
+        int dAt = v.nz;                                   // first layer behind the overflow cut-off
+        FwdTop tp;
         cplx lastE, lastH;
-        bc1d_forward_tab_2(v.omega[f], v.nz, T, qs, ls, [&](int i, cplx val) { if (isEdge) eE[i] = val; },
-                           [&](int i, cplx val) { if (isEdge) eH[i] = val; }, lastE, lastH);
-        if (!isEdge) {
+        bc1d_forward_core(v.omega[f], v.nz, T, qs, ls, [&](int i, cplx eu, cplx ed, cplx, bool dead) {
+            if (isEdge) { ea[2 * i] = eu; ea[2 * i + 1] = ed; if (dead && dAt > i) dAt = i; }
+        }, tp, lastE, lastH);
+        if (isEdge) { top[slot] = tp; deadAt[slot] = dAt; }
+        else {
             if (onE) XE[nidx(v, col, v.nz)] = lastE;
             if (onH) XH[nidx(v, col, v.nz)] = lastH;
         }
     }
-    const bool has0 = col0 == 0, hasN = col0 <= v.ny && v.ny < col0 + (int)blockDim.x;
     if (has0 || hasN) {
         __syncthreads();
         for (int i = threadIdx.x; i < v.nz; i += blockDim.x) {
-            if (has0) {
-                if (onE) XE[nidx(v, 0, 1 + i)] = edge[i];
-                if (onH) XH[nidx(v, 0, 1 + i)] = edge[2L * v.nz + i];
-            }
-            if (hasN) {
-                if (onE) XE[nidx(v, v.ny, 1 + i)] = edge[(long)v.nz + i];
-                if (onH) XH[nidx(v, v.ny, 1 + i)] = edge[3L * v.nz + i];
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+                if (slot == 0 ? !has0 : !hasN) continue;
+                const int ecol = slot == 0 ? 0 : v.ny;
+                const cplx* T = v.fwdTab + (long)f * FWD_NQ * qs + ecol;
+                const cplx kj = T[(long)(i + 1 < v.nz ? i + 1 : v.nz - 1) * ls];      // k of the layer below (the last layer: its own)
+                cplx oE, oH;
+                fwd_outputs(top[slot], amp[((long)slot * v.nz + i) * 2], amp[((long)slot * v.nz + i) * 2 + 1], kj, i >= deadAt[slot], oE, oH);
+                if (onE) XE[nidx(v, ecol, 1 + i)] = oE;
+                if (onH) XH[nidx(v, ecol, 1 + i)] = oH;
             }
         }
     }

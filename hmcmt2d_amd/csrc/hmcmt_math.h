@@ -139,8 +139,18 @@ constexpr int RBF = 8;             // layers per block of the forward recurrence
 // top -> bottom) are the same for TE and TM; only the functional of the amplitudes differs -- E = Eu + Ed (TE) or
 // H = (Ed - Eu) k / (omega mu0) (TM), each normalised by its own top value.  outE(i, v) / outH(i, v) receive the
 // normalised field under layer i.
-template <class OutE, class OutH>
-HD void bc1d_forward_tab_2(double omega, int nz, const cplx* T, long qs, long ls, OutE outE, OutH outH, cplx& lastE_, cplx& lastH_) {
+// The normalised outputs of a layer from its amplitudes (shared by the in-loop and the deferred evaluation)
+struct FwdTop { cplx if0E, if0H; double iomu0; };
+HD void fwd_outputs(const FwdTop& tp, cplx eu, cplx ed, cplx kj, bool dead, cplx& oE, cplx& oH) {
+    cplx fnE = eu + ed, fnH = ((ed - eu) * kj) * tp.iomu0;
+    if (dead) { fnE = cplx{0.0, 0.0}; fnH = cplx{0.0, 0.0}; }
+    oE = fnE * tp.if0E; oH = fnH * tp.if0H;
+}
+// Core: amp(i, eu, ed, kj, dead) is called with the amplitudes under every layer i; the outputs of the LAST layer are
+// returned.  A caller that needs every layer's outputs evaluates fwd_outputs in amp (bc1d_forward_tab_2) or stores the
+// amplitudes and evaluates them afterwards, off the serial loop (k_bc_forward's edge columns).
+template <class Amp>
+HD void bc1d_forward_core(double omega, int nz, const cplx* T, long qs, long ls, Amp amp, FwdTop& tp, cplx& lastE_, cplx& lastH_) {
     const double omu0 = omega * MU0;
     const cplx one = cplx{1.0, 0.0};
     // impedance recurrence bottom -> top (:48-56); half-space has the last layer's conductivity.
@@ -185,8 +195,7 @@ HD void bc1d_forward_tab_2(double omega, int nz, const cplx* T, long qs, long ls
     const cplx a = omu0 / (ztmp * kj);
     cplx eu = 0.5 * (one - a), ed = 0.5 * (one + a);
     const double iomu0 = 1.0 / omu0;
-    const cplx if0E = crecip(eu + ed), if0H = crecip(((ed - eu) * kj) * iomu0);
-    cplx lastE = one, lastH = one;
+    tp.if0E = crecip(eu + ed); tp.if0H = crecip(((ed - eu) * kj) * iomu0); tp.iomu0 = iomu0;
     bool dead = false;
     // one layer i -> i+1 (:69-83)
     // The serial chain is the 2x2 product alone: the cut-off test (three more dependent levels) only feeds the `dead`
@@ -198,10 +207,7 @@ HD void bc1d_forward_tab_2(double omega, int nz, const cplx* T, long qs, long ls
         const double e2 = cabs2(nu + nd), e1 = cabs2(eu + ed);       // |.|^2: same ordering as |.|
         dead = dead || e2 - e1 > 0.0 || isnan(e2);                   // overflow cut-off: zero from here down
         eu = nu; ed = nd; kj = kn;
-        cplx fnE = eu + ed, fnH = ((ed - eu) * kj) * iomu0;
-        if (dead) { fnE = cplx{0.0, 0.0}; fnH = cplx{0.0, 0.0}; }
-        lastE = fnE * if0E; lastH = fnH * if0H;
-        outE(i, lastE); outH(i, lastH);
+        amp(i, eu, ed, kj, dead);
     };
     // whole blocks of RBF layers with all table entries requested up front and no conditions around them (inside a
     // conditional the compiler sinks the loads next to their use: a second memory round trip per block), then the
@@ -223,7 +229,18 @@ HD void bc1d_forward_tab_2(double omega, int nz, const cplx* T, long qs, long ls
         const cplx kn = (i0 + 1 >= nz) ? kj : T[(i + 1) * ls];
         down(i0, kn, T[4 * qs + i * ls], T[5 * qs + i * ls], T[6 * qs + i * ls], T[7 * qs + i * ls]);
     }
-    lastE_ = lastE; lastH_ = lastH;
+    fwd_outputs(tp, eu, ed, kj, dead, lastE_, lastH_);
+}
+
+// Both polarisations of one frequency, every layer's outputs through outE(i, v) / outH(i, v)
+template <class OutE, class OutH>
+HD void bc1d_forward_tab_2(double omega, int nz, const cplx* T, long qs, long ls, OutE outE, OutH outH, cplx& lastE_, cplx& lastH_) {
+    FwdTop tp;
+    bc1d_forward_core(omega, nz, T, qs, ls, [&](int i, cplx eu, cplx ed, cplx kj, bool dead) {
+        cplx oE, oH;
+        fwd_outputs(tp, eu, ed, kj, dead, oE, oH);
+        outE(i, oE); outH(i, oH);
+    }, tp, lastE_, lastH_);
 }
 
 
