@@ -1396,12 +1396,6 @@ __global__ __launch_bounds__(VBLOCK) void k_pre_c64(Solver k) {
     }
 }
 
-// complex64 copy of the inverse pivots
-__global__ void k_invp32(Solver k, float2* dst) {
-    const long n = (long)k.S * k.vstride;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
-        dst[e] = float2{(float)k.invp[e].re, (float)k.invp[e].im};
-}
 
 // ----------------------------------------------------------------------------------------------
 // Fused COCG iteration of the default path (Jacobi/FDM/Jacobi preconditioner, mixed precision):
@@ -1884,19 +1878,28 @@ __global__ void k_coef(View v, int te_doK, int te_doM, int tm_doK, int tm_doM) {
     if (tm_doK || tm_doM) item_coef(v, 1, iy, iz, tm_doK, tm_doM);
 }
 __global__ void k_fdm_z(View v) { int e = TID1; if (e < 2 * v.NZP) item_fdm_z(v, e / v.NZP, e % v.NZP); }
-__global__ __launch_bounds__(64) void k_pivot(View v) {
-    // the mode's coefficient rows (4 x NZP doubles) staged in LDS: the serial loop then reads LDS, not global memory
+// Inverse pivots of the FDM tridiagonals, with what used to be two more launches in front of and behind it: every
+// workgroup computes its mode's four z-coefficient rows (item_fdm_z: a hundred values) straight into LDS -- the
+// serial loop reads them from there, not from global memory -- and the first workgroup of each mode also stores
+// them for the solver's kernels; the complex64 copy of the pivots (ip32 != nullptr) is written along.
+__global__ __launch_bounds__(64) void k_pivot(View v, float2* ip32) {
     extern __shared__ __attribute__((aligned(16))) char smem_pv[];
     double* tab = reinterpret_cast<double*>(smem_pv);
     const int j = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y, mode = s >= v.nFreq;
+    const bool store = blockIdx.x == 0 && s == mode * v.nFreq;
     for (int i = threadIdx.x; i < v.NZP; i += blockDim.x) {
-        tab[i] = v.mzq[(long)mode * v.NZP + i];
-        tab[v.NZP + i] = v.dgz[(long)mode * v.NZP + i];
-        tab[2 * v.NZP + i] = v.ofz[(long)mode * v.NZP + i];
-        tab[3 * v.NZP + i] = v.mzs[(long)mode * v.NZP + i];
+        double a, b, c, d;
+        fdm_z_values(v, mode, i, a, b, c, d);
+        tab[i] = a; tab[v.NZP + i] = b; tab[2 * v.NZP + i] = c; tab[3 * v.NZP + i] = d;
+        if (store) {
+            const long o = (long)mode * v.NZP + i;
+            v.mzq[o] = a; v.dgz[o] = b; v.ofz[o] = c; v.mzs[o] = d;
+        }
     }
     __syncthreads();
-    if (j < v.ny - 1) item_pivot_tab(v, s, j, tab, tab + v.NZP, tab + 2 * v.NZP, tab + 3 * v.NZP);
+    if (j < v.ny - 1)
+        item_pivot_tab(v, s, j, tab, tab + v.NZP, tab + 2 * v.NZP, tab + 3 * v.NZP,
+                       ip32 ? reinterpret_cast<float*>(ip32 + (long)s * v.vstride + j) : nullptr);
 }
 __global__ __launch_bounds__(64) void k_bc_layers(View v) {       // grid z: frequencies
     int col = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, f = blockIdx.z;
@@ -2618,11 +2621,11 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         const bool pivots = ctx->opt.precond != HMCMT_PRECOND_JACOBI;
         HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->evModel, 0));
         hipLaunchKernelGGL(k_rowmean, dim3(v.nz), dim3(64), 0, ctx->side2, v);
-        hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, ctx->side2, v);
-        if (pivots) {
-            hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 4 * (size_t)v.NZP * sizeof(double), ctx->side2, v);
-            if (ctx->opt.fdm_precision == 0) hipLaunchKernelGGL(k_invp32, dim3(512), dim3(256), 0, ctx->side2, ctx->sv, ctx->d_invp32);
-        }
+        if (pivots)
+            hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 4 * (size_t)v.NZP * sizeof(double), ctx->side2, v,
+                               ctx->opt.fdm_precision == 0 ? ctx->d_invp32 : (float2*)nullptr);
+        else
+            hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, ctx->side2, v);
         HIPCHK(hipEventRecord(ctx->evPiv, ctx->side2));
         HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evModel, 0));
         hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, ctx->side, v, 0, 1, 1, 0);

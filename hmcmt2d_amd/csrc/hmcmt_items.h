@@ -158,17 +158,21 @@ HD void item_coef(const View& v, int mode, int iy, int iz, bool doK, bool doM) {
 
 // --- background (laterally averaged) tridiagonal in z for the fast-diagonalisation
 //     preconditioner: P = Ty (x) Mz_q + My (x) (Tz_q + i w Mz_s)   
-HD void item_fdm_z(const View& v, int mode, int iz) {
-    const long o = (long)mode * v.NZP + iz;
-    if (iz < 1 || iz > v.nz - 1) { v.mzq[o] = 0; v.dgz[o] = 0; v.ofz[o] = 0; v.mzs[o] = 0; return; }
+// (values; item_fdm_z stores them, k_pivot also computes them straight into its LDS copy)
+HD void fdm_z_values(const View& v, int mode, int iz, double& mzq, double& dgz, double& ofz, double& mzs) {
+    if (iz < 1 || iz > v.nz - 1) { mzq = 0; dgz = 0; ofz = 0; mzs = 0; return; }
     double qa, qb, sa, sb;
     if (mode == 0) { qa = qb = 1.0 / MU0; sa = v.sigMeanG[iz - 1]; sb = v.sigMeanG[iz]; }
     else { qa = 1.0 / v.sigMeanG[iz - 1]; qb = 1.0 / v.sigMeanG[iz]; sa = sb = MU0; }
     double za = v.zLen[iz - 1], zb = v.zLen[iz];
-    v.mzq[o] = 0.5 * (za * qa + zb * qb);
-    v.mzs[o] = 0.5 * (za * sa + zb * sb);
-    v.dgz[o] = qa / za + qb / zb;
-    v.ofz[o] = (iz <= v.nz - 2) ? -(qb / zb) : 0.0;
+    mzq = 0.5 * (za * qa + zb * qb);
+    mzs = 0.5 * (za * sa + zb * sb);
+    dgz = qa / za + qb / zb;
+    ofz = (iz <= v.nz - 2) ? -(qb / zb) : 0.0;
+}
+HD void item_fdm_z(const View& v, int mode, int iz) {
+    const long o = (long)mode * v.NZP + iz;
+    fdm_z_values(v, mode, iz, v.mzq[o], v.dgz[o], v.ofz[o], v.mzs[o]);
 }
 
 // --- inverse pivots of the (s, j) tridiagonal  d_iz = lam_j*mzq + dgz + i w mzs  in TWISTED form:
@@ -182,7 +186,9 @@ HD void item_fdm_z(const View& v, int mode, int iz) {
 HD int twist_mid(int n, int twist) { return twist ? (n + 1) / 2 : n; }   // rows 1..mid | mid+1..n   (n = nz-1 >= 2)
 // (mzq, dgz, ofz, mzs: the mode's four coefficient rows -- the GPU kernel passes copies staged in LDS: read from global
 // memory they cost the serial loop one memory round trip per step)
-HD void item_pivot_tab(const View& v, int s, int j, const double* mzq, const double* dgz, const double* ofz, const double* mzs) {
+// ip32 (optional): complex64 copy of the pivots for the mixed-precision FDM stage, written along
+HD void item_pivot_tab(const View& v, int s, int j, const double* mzq, const double* dgz, const double* ofz, const double* mzs,
+                       float* ip32 = nullptr) {
     const double w = v.omega[s], lam = v.lam[j];
     cplx* ip = v.invp + (long)s * v.vstride + j;
     const int n = v.nz - 1, mid = twist_mid(n, v.twist);
@@ -196,18 +202,22 @@ HD void item_pivot_tab(const View& v, int s, int j, const double* mzq, const dou
             if (it > 1) d -= (ofz[it - 1] * ofz[it - 1]) * pt;
             pt = crecip(d);
             ip[(long)it * v.NYP] = pt;
+            if (ip32) { ip32[2 * (long)it * v.NYP] = (float)pt.re; ip32[2 * (long)it * v.NYP + 1] = (float)pt.im; }
         }
         if (ib >= mid + 1) {                               // d''_iz = d_iz - of_iz^2 / d''_{iz+1}
             cplx d = cplx{lam * mzq[ib] + dgz[ib], w * mzs[ib]};
             if (ib < n) d -= (ofz[ib] * ofz[ib]) * pb;
             pb = crecip(d);
             ip[(long)ib * v.NYP] = pb;
+            if (ip32) { ip32[2 * (long)ib * v.NYP] = (float)pb.re; ip32[2 * (long)ib * v.NYP + 1] = (float)pb.im; }
         }
     }
     // middle coupling of the two normalised halves: x_mid + c x_{mid+1} = y'_mid, x_{mid+1} + c' x_mid = y''_{mid+1}
     // with c = o*ip_mid, c' = o*ip_{mid+1}; store 1/(1 - c c') in the unused boundary row iz = 0
     const double o = ofz[mid];
-    ip[0] = (mid + 1 <= n) ? crecip(cplx{1.0, 0.0} - (o * o) * (pt * pb)) : cplx{1.0, 0.0};   // (pt, pb: the pivots of rows mid, mid+1)
+    const cplx jn = (mid + 1 <= n) ? crecip(cplx{1.0, 0.0} - (o * o) * (pt * pb)) : cplx{1.0, 0.0};   // (pt, pb: the pivots of rows mid, mid+1)
+    ip[0] = jn;
+    if (ip32) { ip32[0] = (float)jn.re; ip32[1] = (float)jn.im; }
 }
 HD void item_pivot(const View& v, int s, int j) {
     const int mode = s >= v.nFreq;
