@@ -1738,53 +1738,73 @@ __global__ void k_solve_end(Solver k, int kind, int* __restrict__ recI, double* 
 // hist = [m_k | m_{k-1} | m_{k-2} | m_{k-3}], ext = {w_k, w_{k-1}, w_{k-2}, w_{k-3}, keep, count}; with four
 // collinear steps the cubic through the last four fields is used.  A repeated model (getHamiltonian after
 // the last leapfrog step) keeps the history untouched.
-constexpr int EXT_NP = 4;          // fields kept per solve kind: the current one + 3 earlier ones
+constexpr int EXT_NP = 6;          // fields kept per solve kind: the current one + EXT_NP-1 earlier ones (Lagrange order <= EXT_NP-1)
 constexpr int EXT_NBLK = 32;       // blocks of the partial-sum pass
+constexpr int EXT_NS = 2 * EXT_NP; // partial sums per block: <d_j,d1> (j = 0..NP-1), <d_j,d_j> (j = 0, 2..NP-1), <m_k,m_k>
+constexpr int EXT_KEEP = EXT_NP, EXT_COUNT = EXT_NP + 1, EXT_PART = EXT_NP + 2;   // ext = {w_0..w_{NP-1}, keep, count, partial sums...}
 
-// pass 1: per-block partial sums of <d_j,d1>, <d_j,d_j> (j = 0..3; steps d0 = m_new - m_k, d_j = m_{k-j+1} - m_{k-j})
-// and <m_k,m_k>  ->  part[block][8]
+// pass 1: per-block partial sums over the model history hist = [m_k | m_{k-1} | ... | m_{k-NP+1}]: steps
+// d0 = m_new - m_k, d_j = m_{k-j+1} - m_{k-j};  a[j] = <d_j,d1> (j < NP), a[NP] = <d0,d0>, a[NP+j-1] = <d_j,d_j>
+// (j = 2..NP-1), a[2NP-1] = <m_k,m_k>   ->  part[block][EXT_NS]
 __global__ __launch_bounds__(256) void k_extrap_sums(const double* __restrict__ mNew, const double* __restrict__ hist, int nAC,
                                                       double* __restrict__ part) {
-    __shared__ double sh[8][4];
-    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    __shared__ double sh[EXT_NS][4];
+    double a[EXT_NS];
+#pragma unroll
+    for (int q = 0; q < EXT_NS; ++q) a[q] = 0.0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nAC; i += EXT_NBLK * 256) {
-        const double mk = hist[i], mk1 = hist[nAC + i], mk2 = hist[2 * nAC + i], mk3 = hist[3 * nAC + i];
-        const double d0 = mNew[i] - mk, d1 = mk - mk1, d2 = mk1 - mk2, d3 = mk2 - mk3;
-        a[0] += d0 * d1; a[1] += d1 * d1; a[2] += d2 * d1; a[3] += d3 * d1;
-        a[4] += d0 * d0; a[5] += d2 * d2; a[6] += d3 * d3; a[7] += mk * mk;
+        double m[EXT_NP], d[EXT_NP];
+#pragma unroll
+        for (int j = 0; j < EXT_NP; ++j) m[j] = hist[(long)j * nAC + i];
+        d[0] = mNew[i] - m[0];
+#pragma unroll
+        for (int j = 1; j < EXT_NP; ++j) d[j] = m[j - 1] - m[j];
+#pragma unroll
+        for (int j = 0; j < EXT_NP; ++j) a[j] += d[j] * d[1];
+        a[EXT_NP] += d[0] * d[0];
+#pragma unroll
+        for (int j = 2; j < EXT_NP; ++j) a[EXT_NP + j - 1] += d[j] * d[j];
+        a[EXT_NS - 1] += m[0] * m[0];
     }
     const int w = threadIdx.x >> 6;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < EXT_NS; ++q) {
         a[q] = wave_sum(a[q]);
         if ((threadIdx.x & 63) == 0) sh[q][w] = a[q];
     }
     __syncthreads();
-    if (threadIdx.x < 8) part[blockIdx.x * 8 + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+    if (threadIdx.x < EXT_NS) part[blockIdx.x * EXT_NS + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
 }
 
 // pass 2 (one wave): the extrapolation weights from the partial sums
 __global__ __launch_bounds__(64) void k_extrap_weights(const double* __restrict__ part, double* ext, int maxNp) {
-    double a[8];
+    double a[EXT_NS];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        a[q] = wave_sum(threadIdx.x < EXT_NBLK ? part[threadIdx.x * 8 + q] : 0.0);
-    }
+    for (int q = 0; q < EXT_NS; ++q) a[q] = wave_sum(threadIdx.x < EXT_NBLK ? part[threadIdx.x * EXT_NS + q] : 0.0);
     if (threadIdx.x != 0) return;
-    const int count = (int)ext[5];
-    const bool keep = count >= 1 && a[4] <= 1e-28 * a[7];
-    double wts[EXT_NP] = {1, 0, 0, 0};                       // weights of x_k, x_{k-1}, x_{k-2}, x_{k-3}
-    if (!keep && count >= 2 && a[1] > 0) {
-        const double alpha = fmin(2.0, fmax(-1.0, a[0] / a[1]));
+    const int count = (int)ext[EXT_COUNT];
+    const double d1d1 = a[1], d0d0 = a[EXT_NP], mkmk = a[EXT_NS - 1];
+    const bool keep = count >= 1 && d0d0 <= 1e-28 * mkmk;
+    double wts[EXT_NP];                                       // weights of x_k, x_{k-1}, ...
+    for (int i = 0; i < EXT_NP; ++i) wts[i] = i == 0 ? 1.0 : 0.0;
+    if (!keep && count >= 2 && d1d1 > 0) {
+        const double alpha = fmin(2.0, fmax(-1.0, a[0] / d1d1));
         wts[0] = 1.0 + alpha; wts[1] = -alpha;
-        // "times" of the models on the line through the last step: 0, -1, -1-g2, -1-g2-g3
-        const double g2 = a[2] / a[1], g3 = a[3] / a[1];
-        const bool c0 = a[4] > 0 && a[0] / sqrt(a[4] * a[1]) > 0.95 && alpha > 0.5 && alpha < 2.0;
-        const bool c2 = count >= 3 && a[5] > 0 && a[2] / sqrt(a[5] * a[1]) > 0.95 && g2 > 0.5 && g2 < 2.0;
-        const bool c3 = count >= 4 && a[6] > 0 && a[3] / sqrt(a[6] * a[1]) > 0.95 && g3 > 0.5 && g3 < 2.0;
-        const int np = min(maxNp, (c0 && c2) ? (c3 ? 4 : 3) : 2);
+        // "times" of the models on the line through the last step: 0, -1, -1-g2, -1-g2-g3, ...; a further point is used
+        // while its step is nearly collinear with the last one and of comparable length
+        double tau[EXT_NP];
+        tau[0] = 0.0; tau[1] = -1.0;
+        int np = 2;
+        if (d0d0 > 0 && a[0] / sqrt(d0d0 * d1d1) > 0.95 && alpha > 0.5 && alpha < 2.0) {
+            for (int j = 2; j < EXT_NP; ++j) {
+                const double djdj = a[EXT_NP + j - 1], g = a[j] / d1d1;
+                if (!(count >= j + 1 && djdj > 0 && a[j] / sqrt(djdj * d1d1) > 0.95 && g > 0.5 && g < 2.0)) break;
+                tau[j] = tau[j - 1] - g;
+                np = j + 1;
+            }
+        }
+        np = min(maxNp, np);
         if (np > 2) {
-            const double tau[4] = {0.0, -1.0, -1.0 - g2, -1.0 - g2 - g3};
             for (int i = 0; i < EXT_NP; ++i) {
                 double l = i < np ? 1.0 : 0.0;
                 for (int j = 0; j < np; ++j)
@@ -1794,32 +1814,43 @@ __global__ __launch_bounds__(64) void k_extrap_weights(const double* __restrict_
         }
     }
     for (int i = 0; i < EXT_NP; ++i) ext[i] = wts[i];
-    ext[4] = keep ? 1.0 : 0.0;
-    if (!keep) ext[5] = (double)min(count + 1, EXT_NP);
+    ext[EXT_KEEP] = keep ? 1.0 : 0.0;
+    if (!keep) ext[EXT_COUNT] = (double)min(count + 1, EXT_NP);
 }
 
 // pass 3: the model history moves on (unless the model is a repeat)
 __global__ __launch_bounds__(256) void k_extrap_shift(const double* __restrict__ mNew, double* hist, int nAC, const double* __restrict__ ext) {
-    if (ext[4] != 0.0) return;
+    if (ext[EXT_KEEP] != 0.0) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nAC) { hist[3 * nAC + i] = hist[2 * nAC + i]; hist[2 * nAC + i] = hist[nAC + i]; hist[nAC + i] = hist[i]; hist[i] = mNew[i]; }
+    if (i < nAC) {
+#pragma unroll
+        for (int j = EXT_NP - 1; j >= 1; --j) hist[(long)j * nAC + i] = hist[(long)(j - 1) * nAC + i];
+        hist[i] = mNew[i];
+    }
 }
 
-// x <- sum_j w_j x_{k-j}, history shifted (xp3 <- xp2 <- xp1 <- old x), on interior nodes (runs beside
-// k_bc_forward, which writes X's boundary nodes); xp = [3][S*vstride]
+// x <- sum_j w_j x_{k-j}, history shifted (... <- xp1 <- xp0 <- old x), on interior nodes (runs beside
+// k_bc_forward, which writes X's boundary nodes); xp = [EXT_NP-1][S*vstride]
 __global__ __launch_bounds__(VBLOCK) void k_extrap(Solver k, cplx* x, cplx* xp, const double* __restrict__ ext) {
-    if (ext[4] != 0.0) return;
-    const double w0 = ext[0], w1 = ext[1], w2 = ext[2], w3 = ext[3];
+    if (ext[EXT_KEEP] != 0.0) return;
+    double w[EXT_NP];
+#pragma unroll
+    for (int j = 0; j < EXT_NP; ++j) w[j] = ext[j];
     const long so = (long)blockIdx.y * k.vstride, hs = (long)k.S * k.vstride;
     const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
     for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
         const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
         if (iz < 1 || iz > k.nz - 1 || iy < 1 || iy > k.ny - 1) continue;
-        const cplx t = x[so + e], q1 = xp[so + e], q2 = xp[hs + so + e], q3 = xp[2 * hs + so + e];
-        xp[2 * hs + so + e] = q2;
-        xp[hs + so + e] = q1;
-        xp[so + e] = t;
-        x[so + e] = w0 * t + w1 * q1 + w2 * q2 + w3 * q3;
+        cplx q[EXT_NP];
+        q[0] = x[so + e];
+#pragma unroll
+        for (int j = 1; j < EXT_NP; ++j) q[j] = xp[(long)(j - 1) * hs + so + e];
+        cplx acc = w[0] * q[0];
+#pragma unroll
+        for (int j = 1; j < EXT_NP; ++j) acc += w[j] * q[j];
+#pragma unroll
+        for (int j = EXT_NP - 1; j >= 1; --j) xp[(long)(j - 1) * hs + so + e] = q[j - 1];
+        x[so + e] = acc;
     }
 }
 
@@ -2191,7 +2222,7 @@ struct hmcmt_ctx {
     cplx* d_prevField[2] = {nullptr, nullptr};   // the two previous solutions (warm_start == 2), per solve kind: [2][S*vstride]
     double* d_mHist[2] = {nullptr, nullptr};     // [3][nAC] model history per solve kind
     double* d_ext[2] = {nullptr, nullptr};       // {w0, w1, w2, keep, count}
-    int extrapNp = 4;                        // fields used by the initial-guess extrapolation (HMCMT_EXTRAP_POINTS = 2..4)
+    int extrapNp = EXT_NP;                   // fields used by the initial-guess extrapolation (HMCMT_EXTRAP_POINTS = 2..EXT_NP)
     bool fusedFwd = true;                    // forward transform + tridiagonal solve in one kernel (HMCMT_FUSED_FWD=0: separate)
     View sideView; const double* sideM = nullptr;   // deferred side-stream launches of the adjoint half (launch_adjoint_side)
     bool sidePending = false, sideExtrap = false, sideSens = false;
@@ -2546,7 +2577,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
 // weights of the initial-guess extrapolation for solve kind kd (side stream): partial sums, weights, history shift
 void launch_extrap_weights(hmcmt_ctx* ctx, const double* d_m, int kd) {
     const int nAC = ctx->v.nAC;
-    double* part = ctx->d_ext[kd] + 8;
+    double* part = ctx->d_ext[kd] + EXT_PART;
     hipLaunchKernelGGL(k_extrap_sums, dim3(EXT_NBLK), dim3(256), 0, ctx->side, d_m, ctx->d_mHist[kd], nAC, part);
     hipLaunchKernelGGL(k_extrap_weights, dim3(1), dim3(64), 0, ctx->side, part, ctx->d_ext[kd], ctx->extrapNp);
     hipLaunchKernelGGL(k_extrap_shift, dim3((nAC + 255) / 256), dim3(256), 0, ctx->side, d_m, ctx->d_mHist[kd], nAC, ctx->d_ext[kd]);
@@ -2603,11 +2634,11 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         // initial guesses: zero on a cold start, otherwise the previous fields, optionally extrapolated
         if (!warmF) {
             HIPCHK(hipMemsetAsync(v.X, 0, vecBytes, st));
-            HIPCHK(hipMemsetAsync(ctx->d_ext[0], 0, 8 * sizeof(double), st));
+            HIPCHK(hipMemsetAsync(ctx->d_ext[0], 0, EXT_PART * sizeof(double), st));
         }
         if (wantGrad && !warmA) {
             HIPCHK(hipMemsetAsync(v.Lam, 0, vecBytes, st));
-            HIPCHK(hipMemsetAsync(ctx->d_ext[1], 0, 8 * sizeof(double), st));
+            HIPCHK(hipMemsetAsync(ctx->d_ext[1], 0, EXT_PART * sizeof(double), st));
         }
         HIPCHK(hipEventRecord(ctx->evModel, st));
         // Three chains start from sigma and meet at the forward residual:
@@ -2902,7 +2933,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     DA(v.sensDz1, S * 3 * (size_t)h.nz) DA(v.sensZ1, S * 3) DA(v.sensDead, S * 3)
     DA(v.qPart, S * h.ny) DA(v.gPart, 2 * (size_t)h.nCell) DA(v.gPartG, 2 * GRAD_NG * (size_t)h.nCell) DA(v.grad, h.nAC)
     DA(ctx->d_m, h.nAC) DA(ctx->d_misfit, 1)
-    for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], 3 * S * VS) DA(ctx->d_mHist[kd], 4 * (size_t)h.nAC) DA(ctx->d_ext[kd], 8 + 8 * EXT_NBLK) }
+    for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], (EXT_NP - 1) * S * VS) DA(ctx->d_mHist[kd], EXT_NP * (size_t)h.nAC) DA(ctx->d_ext[kd], EXT_PART + EXT_NS * EXT_NBLK) }
     Solver& k = ctx->sv;
     k.S = h.S; k.NYP = h.NYP; k.NZP = h.NZP; k.ny = h.ny; k.nz = h.nz; k.nFreq = h.nFreq; k.vstride = v.vstride;
     k.NB = std::max(1, std::min(32, (1024 + h.S - 1) / h.S));
