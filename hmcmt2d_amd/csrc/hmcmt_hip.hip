@@ -1735,9 +1735,10 @@ __global__ void k_solve_end(Solver k, int kind, int* __restrict__ recI, double* 
 //     x0 = w2 x_k + w1 x_{k-1} + w0 x_{k-2}      (uniform steps: 3, -3, 1)
 // when the three steps are nearly collinear, else the linear one  x0 = x_k + alpha (x_k - x_{k-1})
 // (e.g. across a momentum refresh).  State per solve kind, all on the device (no host round trip):
-// hist = [m_k | m_{k-1} | m_{k-2} | m_{k-3}], ext = {w_k, w_{k-1}, w_{k-2}, w_{k-3}, keep, count}; with four
-// collinear steps the cubic through the last four fields is used.  A repeated model (getHamiltonian after
-// the last leapfrog step) keeps the history untouched.
+// hist = [m_k | m_{k-1} | ... | m_{k-NP+1}], ext = {w_k, ..., w_{k-NP+1}, keep, count}; every further step that is
+// nearly collinear with the last one and of comparable length adds a point (and an order) to the Lagrange
+// extrapolation, up to EXT_NP fields.  A repeated model (getHamiltonian after the last leapfrog step) keeps the
+// history untouched.
 constexpr int EXT_NP = 6;          // fields kept per solve kind: the current one + EXT_NP-1 earlier ones (Lagrange order <= EXT_NP-1)
 constexpr int EXT_NBLK = 32;       // blocks of the partial-sum pass
 constexpr int EXT_NS = 2 * EXT_NP; // partial sums per block: <d_j,d1> (j = 0..NP-1), <d_j,d_j> (j = 0, 2..NP-1), <m_k,m_k>
