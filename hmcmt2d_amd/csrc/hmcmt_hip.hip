@@ -2805,6 +2805,8 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (!ctx) return HMCMT_EINVAL;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->side) hipStreamSynchronize(ctx->side);      // (side-stream work of an evaluation nobody waited for)
+    if (ctx->side2) hipStreamSynchronize(ctx->side2);
     for (void* p : ctx->allocs) hipFree(p);
     for (hipEvent_t e : ctx->evPool) hipEventDestroy(e);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
