@@ -491,3 +491,32 @@ def test_asynchronous_device_evaluations_match_synchronous_ones():
     with pytest.raises(RuntimeError):
         ctx.wait()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_fused_solve_start_matches_separate_kernels(monkeypatch):
+    """k_resid_pre (initial residual + first pre-smoothing pass + solve bookkeeping in one launch) against the separate
+    k_resid0 / k_solve_begin / k_pre_c64 launches (HMCMT_NO_FUSED_START, read per evaluation): the same formulas on
+    the same numbers, so two warm-started evaluations must agree to rounding of the fp32 stage."""
+    mesh, data, inv, m = make_problem("cfg2")
+    rng = np.random.default_rng(5)
+    ms = [m, m + 0.03 * rng.standard_normal(m.size)]
+
+    def run(separate):
+        if separate:
+            monkeypatch.setenv("HMCMT_NO_FUSED_START", "1")
+        else:
+            monkeypatch.delenv("HMCMT_NO_FUSED_START", raising=False)
+        ctx = HipContext(mesh, data, inv)
+        out = [ctx.grad(x) for x in ms]              # the second evaluation starts both solves from previous fields
+        st = ctx.stats()
+        ctx.close()
+        return out, st
+
+    (a0, a1), sa = run(False)
+    (b0, b1), sb = run(True)
+    for (pa, fa, ga), (pb, fb, gb) in ((a0, b0), (a1, b1)):
+        assert np.abs(pa - pb).max() <= 1e-9 * np.abs(pb).max()
+        assert abs(fa - fb) <= 1e-9 * abs(fb)
+        assert np.abs(ga - gb).max() <= 1e-7 * np.abs(gb).max()
+    assert sa["status"] == 0 and sb["status"] == 0
