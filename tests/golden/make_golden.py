@@ -1,5 +1,5 @@
-"""Generates the golden vectors tests/golden/{tiny,cfg2}.npz with the oracle (run in the build
-container: `python tests/golden/make_golden.py`).  Inputs: BASELINE.json-style synthetic configs
+"""Generates the golden vectors tests/golden/*.npz with the oracle (run in the build
+container: `python tests/golden/make_golden.py [names...]`; names: tiny cfg2 cfg1 cfg3s dprism3d coprod2).  Inputs: BASELINE.json-style synthetic configs
 (hmcmt2d_amd/synthetic.py), observed data = oracle forward of the true model + 3 % seeded noise,
 evaluation state m = ln(0.01) + 0.3 N(0,1) (seed 1).  Outputs: predData, misfit, gradient, the
 receiver-row fields and (tiny only) every intermediate term of J^T v.
@@ -64,6 +64,83 @@ def make(name, full):
           os.path.getsize(os.path.join(HERE, f"{name}.npz")) // 1024)
 
 
+def make_cfg3_subset():
+    """Headline mesh (200x100 cells + 7 air rows), 4 of the 16 frequencies (100, 4.64, 0.215, 0.01 Hz), TE+TM:
+    oracle pred / misfit / gradient at the rough bench state.  `obs16`/`err16` are the observations of ALL 16
+    frequencies (oracle forward of the true model + seeded noise), so that a full 16-frequency HIP run sees, at the
+    subset's frequencies, exactly the data of the subset run (its systems there must then agree with the subset run)."""
+    mesh, data16, sig_true = S.make_config("cfg3")
+    O.setupTensorMesh2D(mesh)
+    mesh.sigma = sig_true.copy()
+    pred16, _ = O.MT2DFwdSolver(mesh, data16)
+    obs16, err16 = S.noisy_observations(pred16)
+    fidx = np.array([0, 5, 10, 15])
+    sel = np.isin(data16.freqID - 1, fidx)
+    data = S.make_data_layout(data16.freqs[fidx], data16.rxLoc[:, 0])
+    obs, err = obs16[sel], err16[sel]
+    ny, nz = mesh.gridSize
+    nair = len(mesh.airLayer)
+    mesh.sigma = np.concatenate([np.full(ny * nair, S.SIG_AIR), np.full(ny * (nz - nair), 0.01)])
+    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, obs, err)
+    m = S.rough_state(len(inv.strModel))
+    inv.strModel = m.copy()
+    keep = {}
+    pred, misfit, grad = O.compDataGradient(mesh, data, inv, HMCPrior(), False, keep)
+    rows = slice(nair * (ny + 1), (nair + 2) * (ny + 1))
+    out = dict(fidx=fidx, obs16=obs16, err16=err16, obs=obs, err=err, m=m, pred=pred, misfit=misfit, grad=grad,
+               exTE_rx=keep["exTE"][rows, :], hxTM_rx=keep["hxTM"][rows, :])
+    # second state: the true model (layers + block), where the lateral structure is; gradient only in float32-free form
+    m_true = np.log(sig_true[inv.activeIdx])
+    inv.strModel = m_true.copy()
+    pred2, misfit2, grad2 = O.compDataGradient(mesh, data, inv, HMCPrior(), False)
+    out.update(pred_true=pred2, misfit_true=misfit2, grad_true=grad2)
+    np.savez_compressed(os.path.join(HERE, "cfg3s.npz"), **out)
+    print("cfg3s misfit", misfit, misfit2, "file kB", os.path.getsize(os.path.join(HERE, "cfg3s.npz")) // 1024)
+
+
+def make_example(name):
+    """The reference's own example directory (data files copied as fixtures to tests/golden/examples/<name>/:
+    startupfile, model file, data file -- inputs only): oracle compDataGradient at the file's start model and at a
+    seeded perturbation of it, through the package's readstartupFile."""
+    from hmcmt2d_amd.fileio import readstartupFile
+    mesh, data, inv, prior = readstartupFile(os.path.join(HERE, "examples", name, "startupfile"))
+    O.setupTensorMesh2D(mesh)
+    m0 = inv.strModel.copy()
+    out = dict(m0=m0)
+    pred, misfit, grad = O.compDataGradient(mesh, data, inv, HMCPrior(), True)
+    out.update(pred0=pred, misfit0=misfit, grad0=grad)
+    # The reference formula's gradient is rounding-dependent where the 1-D recurrence's overflow cut-off fires in the
+    # LAST (thick) layer: the row computed just before the cut-off is kept (MT1DSensitivity.jl:145-155 zeroes the
+    # lower-right block only) and holds amplified rounding noise.  At dprism3d's homogeneous start model a relative
+    # perturbation of 3e-14 of the model moves the reference's own gradient by 11.8 x max|g| (1e-14: by 1e-6).  So the
+    # golden holds the evaluations at m0*(1 +- 1e-14) as well: a correct implementation agrees with ONE of the
+    # rounding-equivalent evaluations of the reference formula (tests/test_gpu_parity_full.py).
+    alts = []
+    for eps in (1e-14, -1e-14):
+        inv.strModel = m0 * (1 + eps)
+        alts.append(O.compDataGradient(mesh, data, inv, HMCPrior(), False)[2])
+    out["grad0_alt"] = np.stack(alts)
+    m1 = m0 + 0.3 * np.random.default_rng(3).standard_normal(len(m0))
+    inv.strModel = m1.copy()
+    keep = {}
+    pred, misfit, grad = O.compDataGradient(mesh, data, inv, HMCPrior(), False, keep)
+    ny = mesh.gridSize[0]
+    nair = len(mesh.airLayer)
+    rows = slice(nair * (ny + 1), (nair + 2) * (ny + 1))
+    out.update(m1=m1, pred1=pred, misfit1=misfit, grad1=grad, exTE_rx=keep["exTE"][rows, :], hxTM_rx=keep["hxTM"][rows, :])
+    np.savez_compressed(os.path.join(HERE, f"example_{name}.npz"), **out)
+    print(name, "nData", len(pred), "grid", mesh.gridSize, "misfit", out["misfit0"], misfit, "file kB",
+          os.path.getsize(os.path.join(HERE, f"example_{name}.npz")) // 1024)
+
+
 if __name__ == "__main__":
-    make("tiny", True)
-    make("cfg2", False)
+    names = sys.argv[1:] or ["tiny", "cfg2", "cfg1", "cfg3s", "dprism3d", "coprod2"]
+    for nm in names:
+        if nm == "tiny":
+            make("tiny", True)
+        elif nm in ("cfg2", "cfg1"):
+            make(nm, False)
+        elif nm == "cfg3s":
+            make_cfg3_subset()
+        else:
+            make_example(nm)

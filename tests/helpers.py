@@ -65,3 +65,26 @@ def ragged_problem(ny, nz, nfreq, npad_y, npad_z, nair):
     inv = I.setupInverseDataModel(mesh, [S.SIG_AIR, 0.3], 0.0, 0.0, obs, err)
     m = np.log(0.01) + 0.4 * rng.standard_normal(len(inv.strModel))
     return mesh, data, inv, m
+
+
+def gerr_split(grad, ref, inv, mesh, deep_rows=5):
+    """(max error over the shallow cells, over the deepest `deep_rows` rows) relative to max|ref|: the reference's
+    bottom-boundary sensitivity row is rounding noise at mid/high frequencies (MT1DSensitivity.jl:145-155, SURVEY
+    App. B.7), which reaches the deepest rows of the gradient at the 1e-6 level in ANY correct evaluation."""
+    ny, nt = mesh.gridSize
+    deep = (inv.activeIdx // ny) >= nt - deep_rows
+    d = np.abs(np.asarray(grad) - np.asarray(ref))
+    sc = np.abs(ref).max()
+    return float(d[~deep].max() / sc), float(d[deep].max() / sc if deep.any() else 0.0)
+
+
+def cfg3_subset_problem(g):
+    """The headline mesh with the 4-frequency subset of tests/golden/cfg3s.npz, and the full 16-frequency problem on
+    the same observations.  Returns (mesh, data4, inv4, m, data16, inv16)."""
+    mesh, data16, _ = S.make_config("cfg3")
+    fidx = g["fidx"]
+    data = S.make_data_layout(data16.freqs[fidx], data16.rxLoc[:, 0])
+    mesh.sigma = start_sigma(mesh)
+    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, g["obs"], g["err"])
+    inv16 = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, g["obs16"], g["err16"])
+    return mesh, data, inv, S.rough_state(len(inv.strModel)), data16, inv16

@@ -35,3 +35,44 @@ def test_golden_leapfrog_trajectory():
     assert relmax(m1, g["lf_m1"]) < 1e-10 and relmax(p1, g["lf_p1"]) < 1e-9
     # the trajectory exercises the bound reflection
     assert np.any(g["lf_m0"] + 3 * 0.03 * 2.5 > np.log(prior.sigBounds[1]))
+
+
+def test_oracle_reproduces_cfg1_golden():
+    g = np.load(os.path.join(GOLDEN, "cfg1.npz"))
+    mesh, data, inv, m = make_problem("cfg1")
+    pred, misfit, grad = oracle_eval(mesh, data, inv, m)
+    assert relmax(pred, g["pred"]) < 1e-12 and relmax(grad, g["grad"]) < 1e-10
+    assert abs(misfit - float(g["misfit"])) / float(g["misfit"]) < 1e-12
+
+
+def test_oracle_reproduces_cfg3_subset_golden():
+    """Headline mesh, 4 of 16 frequencies (about 15 s of SuperLU on one core)."""
+    from tests.helpers import cfg3_subset_problem
+    g = np.load(os.path.join(GOLDEN, "cfg3s.npz"))
+    mesh, data, inv, m, data16, inv16 = cfg3_subset_problem(g)
+    assert np.array_equal(m, g["m"]) and len(data16.freqs) == 16 and len(inv16.obsData) == 16 * 41 * 2
+    assert np.array_equal(inv16.obsData[np.isin(data16.freqID - 1, g["fidx"])], inv.obsData)
+    pred, misfit, grad = oracle_eval(mesh, data, inv, m)
+    assert relmax(pred, g["pred"]) < 1e-12 and relmax(grad, g["grad"]) < 1e-9
+
+
+@pytest.mark.parametrize("name,ndata,grid,nfreq,nrx", [("dprism3d", 902, (96, 56), 11, 41), ("coprod2", 470, (76, 52), 12, 20)])
+def test_reference_example_files_are_read_and_reproduced_by_the_oracle(name, ndata, grid, nfreq, nrx):
+    """The reference's example directories (HMCMT/examples/<name>/{startupfile,*.mod,*.dat}, committed unchanged under
+    tests/golden/examples/) through readstartupFile (readstartupFile.jl:4-103, readMT2DData.jl:14-179,
+    readEMModel2D.jl:11-154), and the oracle's gradient at a seeded perturbation of the file's start model."""
+    from hmcmt2d_amd.fileio import readstartupFile
+    from hmcmt2d_amd.structs import HMCPrior
+    from oracle import hmcmt_oracle as O
+    g = np.load(os.path.join(GOLDEN, f"example_{name}.npz"))
+    mesh, data, inv, prior = readstartupFile(os.path.join(GOLDEN, "examples", name, "startupfile"))
+    assert mesh.gridSize == grid and len(inv.obsData) == ndata and len(data.freqs) == nfreq and data.rxLoc.shape[0] == nrx
+    assert data.dataType == "Impedance" and data.dataComp == ["ZXY", "ZYX"] and data.dataID.sum() == ndata
+    assert data.dataID.size == 2 * nfreq * nrx                      # coprod2: 470 of 480 present
+    assert prior.totalsamples == 10000 and prior.burninsamples == 100 and prior.timestep == [6, 10]
+    assert prior.dt == (0.03 if name == "dprism3d" else 0.015) and prior.regParam == 1.0
+    assert np.array_equal(inv.strModel, g["m0"]) and len(mesh.airLayer) == 7
+    O.setupTensorMesh2D(mesh)
+    inv.strModel = g["m1"].copy()
+    pred, misfit, grad = O.compDataGradient(mesh, data, inv, HMCPrior(), False)
+    assert relmax(pred, g["pred1"]) < 1e-12 and relmax(grad, g["grad1"]) < 1e-9
