@@ -12,6 +12,7 @@
 //       - deterministic two-stage reductions (wave shuffles + fixed partial arrays).
 //   * no host compute path: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -2528,7 +2529,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     }
     if (!done) {
         const bool restart = fused;      // coming from the fused loop: restart COCG with the fp64 preconditioner
-        if (restart) ctx->lpFallback = true;
+        if (restart) { ctx->lpFallback = true; ++ctx->stats.fallback_solves; }
         // z = P^-1 r ; rho = r'z ; p = z
         { int prc = apply_precond(ctx); if (prc) return prc; }
         { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_check, dim3(1), dim3(128), 0, ctx->stream, k, ctx->d_partZZ, restart ? 2 : 1, ctx->opt.maxit); }
@@ -2537,6 +2538,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             ++it;
             if (it == lpCap + 1 && ctx->opt.fdm_precision == 0 && ctx->opt.precond != HMCMT_PRECOND_JACOBI && !ctx->lpFallback) {
                 ctx->lpFallback = true;     // restart COCG for the still-active systems: z = P64^-1 r, p = z
+                ++ctx->stats.fallback_solves;
                 { int prc = apply_precond(ctx); if (prc) return prc; }
                 { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_check, dim3(1), dim3(128), 0, ctx->stream, k, ctx->d_partZZ, 2, ctx->opt.maxit); }
                 { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_pupdate, vg, vb, 0, ctx->stream, k, 1); }
@@ -2750,6 +2752,12 @@ void parse_stats(hmcmt_ctx* ctx, bool withAdjoint) {
         // knows how many iterations it launched, which includes the empty ones behind the last poll)
         if (ctx->solveDone[kind] && mx > 0) (kind == 0 ? ctx->lastItFwd : ctx->lastItAdj) = mx;
         if (!ctx->solveDone[kind] && ctx->stats.status == 0) ctx->stats.status = HMCMT_ENOCONV;
+    }
+    if (ctx->stats.status != 0) {
+        // a failed evaluation (breakdown, non-finite values, iteration cap) must not seed the next one: its fields may
+        // hold Inf/NaN, and so may the extrapolation history -- the next call starts cold
+        ctx->haveFwd = ctx->haveAdj = false;
+        ctx->lastItFwd = ctx->lastItAdj = 0;
     }
     if (!withAdjoint) for (int s = 0; s < S; ++s) ctx->itersLast[S + s] = 0;
 }
@@ -2978,6 +2986,14 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     return 0;
 }
 
+static const char* options_error(const hmcmt_options* o) {
+    if (o->precond < HMCMT_PRECOND_JACOBI || o->precond > HMCMT_PRECOND_FDM_JACOBI) return "unknown preconditioner";
+    if (o->fdm_precision != 0 && o->fdm_precision != 1) return "fdm_precision must be 0 (bf16/fp32) or 1 (fp64)";
+    if (!(o->tol > 0) || o->maxit < 1) return "tol must be > 0 and maxit >= 1";
+    if (o->warm_start < 0 || o->warm_start > 2) return "warm_start must be 0, 1 or 2";
+    return nullptr;
+}
+
 int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, const double* yLen,
                  const double* zLen, const double* origin, int64_t nFreq, const double* freqs, int64_t nRx,
                  const double* rxY, const double* rxZ, int64_t nComp, const int64_t* compMode, int64_t nData,
@@ -2990,6 +3006,7 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
         (nData > 0 && (!freqID || !rxID || !dtID || !obs || !dataW))) {
         g_createError = "null input array"; return HMCMT_EINVAL;
     }
+    if (opts) if (const char* e = options_error(opts)) { g_createError = e; return HMCMT_EINVAL; }
     hmcmt_ctx* ctx = new hmcmt_ctx();
     hmcmt_default_options(&ctx->opt);
     if (opts) ctx->opt = *opts;
@@ -3013,10 +3030,7 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
 
 int hmcmt_set_options(hmcmt_ctx* ctx, const hmcmt_options* o) {
     if (!ctx || !o) return HMCMT_EINVAL;
-    if (o->precond < HMCMT_PRECOND_JACOBI || o->precond > HMCMT_PRECOND_FDM_JACOBI) { ctx->err = "unknown preconditioner"; return HMCMT_EINVAL; }
-    if (o->fdm_precision != 0 && o->fdm_precision != 1) { ctx->err = "fdm_precision must be 0 (bf16/fp32) or 1 (fp64)"; return HMCMT_EINVAL; }
-    if (!(o->tol > 0) || o->maxit < 1) { ctx->err = "tol must be > 0 and maxit >= 1"; return HMCMT_EINVAL; }
-    if (o->warm_start < 0 || o->warm_start > 2) { ctx->err = "warm_start must be 0, 1 or 2"; return HMCMT_EINVAL; }
+    if (const char* e = options_error(o)) { ctx->err = e; return HMCMT_EINVAL; }
     ctx->opt = *o;
     ctx->lastItFwd = ctx->lastItAdj = 0;
     ctx->haveFwd = ctx->haveAdj = false;
@@ -3392,6 +3406,16 @@ int hmcmt_set_prior(hmcmt_ctx* ctx, const double* mref, const int64_t* rowptr, c
     std::vector<double> v_mref(mref, mref + n), v_invM(invM, invM + n), v_val(val, val + nnz);
     std::vector<long long> v_row(rowptr, rowptr + n + 1), v_col(colind, colind + nnz);
     int rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));              // (a trajectory may still be reading the previous prior)
+    // a repeated call replaces the previous prior: its buffers are released, not kept until hmcmt_destroy
+    for (void* old : {(void*)ctx->d_mref, (void*)ctx->d_invM, (void*)ctx->d_wmVal, (void*)ctx->d_wmRow, (void*)ctx->d_wmCol}) {
+        if (!old) continue;
+        auto it = std::find(ctx->allocs.begin(), ctx->allocs.end(), old);
+        if (it != ctx->allocs.end()) ctx->allocs.erase(it);
+        hipFree(old);
+    }
+    ctx->d_mref = ctx->d_invM = ctx->d_wmVal = nullptr; ctx->d_wmRow = ctx->d_wmCol = nullptr;
+    ctx->havePrior = false;
     if ((rc = dupload(ctx, &ctx->d_mref, v_mref))) return rc;
     if ((rc = dupload(ctx, &ctx->d_invM, v_invM))) return rc;
     if ((rc = dupload(ctx, &ctx->d_wmVal, v_val))) return rc;

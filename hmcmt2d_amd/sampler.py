@@ -17,30 +17,57 @@ Differences that are deliberate and documented:
 """
 from __future__ import annotations
 
+import os
 import time
+import weakref
 import numpy as np
 
 from .lib import HipContext
 from .structs import HMCParameter, HMCStatus, initHMCParameter, initHMCStatus
 
-_contexts: dict = {}
+_contexts: dict = {}          # (id(invParam), device) -> HipContext; entries die with their InvDataModel (weakref.finalize)
 
 
-def get_context(mtMesh, mtData, invParam, device_id=0, **opts) -> HipContext:
-    """One HIP context per InvDataModel (created lazily, cached)."""
-    key = id(invParam)
+def default_device() -> int:
+    """The GPU of this process: LOCAL_RANK under torch.distributed.run / torchrun (one process per GPU), else
+    HMCMT_DEVICE, else 0.  The reference's counterpart is the worker id of `pmap` (parallelHMC.jl:23-40)."""
+    for var in ("LOCAL_RANK", "HMCMT_DEVICE"):
+        v = os.environ.get(var)
+        if v not in (None, ""):
+            return int(v)
+    return 0
+
+
+def _drop_context(key):
+    ctx = _contexts.pop(key, None)
+    if ctx is not None:
+        ctx.close()
+
+
+def get_context(mtMesh, mtData, invParam, device_id=None, **opts) -> HipContext:
+    """One HIP context per (InvDataModel, device), created lazily on `device_id` (default: this process's GPU,
+    `default_device()`).  The cache entry is tied to the life of `invParam` (a recycled id() can never return a
+    context built for another problem) and is rebuilt when different solver options are requested."""
+    dev = default_device() if device_id is None else int(device_id)
+    key = (id(invParam), dev)
     ctx = _contexts.get(key)
+    if ctx is not None and (ctx._owner() is not invParam or (opts and opts != ctx._opts)):
+        _drop_context(key)
+        ctx = None
     if ctx is None:
-        ctx = HipContext(mtMesh, mtData, invParam, device_id=device_id, **opts)
+        ctx = HipContext(mtMesh, mtData, invParam, device_id=dev, **opts)
         ctx._cache = None
+        ctx._opts = dict(opts)
+        ctx._owner = weakref.ref(invParam)
+        ctx.device_id = dev
         _contexts[key] = ctx
+        weakref.finalize(invParam, _drop_context, key)
     return ctx
 
 
-def release_context(invParam):
-    ctx = _contexts.pop(id(invParam), None)
-    if ctx is not None:
-        ctx.close()
+def release_context(invParam, device_id=None):
+    for key in [k for k in _contexts if k[0] == id(invParam) and (device_id is None or k[1] == int(device_id))]:
+        _drop_context(key)
 
 
 def _check_solver(hmcprior):
@@ -176,11 +203,12 @@ def proposeLeapfrogDevice(hmcParamCurrent: HMCParameter, mtMesh, mtData, invPara
 
 
 def runHMCSampler(mtMesh, mtData, invParam, hmcprior, rng=None, rhoref=None, ctx: HipContext | None = None,
-                  verbose=False, reuse_forward=True, device_leapfrog=False):
-    """Returns (hmcmodel[nparam, nsamples], hmcstats, hmcdata[ndata, nsamples+1])."""
+                  verbose=False, reuse_forward=True, device_leapfrog=False, device_id=None):
+    """Returns (hmcmodel[nparam, nsamples], hmcstats, hmcdata[ndata, nsamples+1]).  The chain runs on GPU `device_id`
+    (default: `default_device()`, i.e. LOCAL_RANK) unless a context is passed in."""
     _check_solver(hmcprior)
     rng = rng or np.random.default_rng()
-    ctx = ctx or get_context(mtMesh, mtData, invParam)
+    ctx = ctx or get_context(mtMesh, mtData, invParam, device_id=device_id)
     nparam, ndata = len(invParam.strModel), len(invParam.obsData)
     if hmcprior.massType != "diagonal":
         raise NotImplementedError("only the reference's default diagonal mass matrix is supported "
@@ -240,15 +268,18 @@ def runHMCSampler(mtMesh, mtData, invParam, hmcprior, rng=None, rhoref=None, ctx
 
 # --------------------------------------------------------------------------------------------
 def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, outdir=None, nchains=None,
-                       run_chain=None):
+                       run_chain=None, device_id=None, context_factory=None, **sampler_kw):
     """Independent chains, one process per GPU (parallelHMC.jl:10-49).
 
     With `torch.distributed` initialised (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
-    CPU tests) rank r runs chains r, r+W, ... on its own GPU with RNG stream (seed, chain) and the
-    sample blocks are ALL-GATHERED so every rank holds every chain; rank 0 writes the per-chain
-    files the reference writes.  Without a process group the chains run one after another.
-    `pids` is kept for signature parity: its length is the number of chains (default: world size).
-    `run_chain(chain_index, rng)` can replace the sampler (used by the CPU tests).
+    CPU tests) rank r runs chains r, r+W, ... on ITS OWN GPU -- `device_id`, default `default_device()` =
+    LOCAL_RANK; with the nccl backend the process's current device is set to it before the collective --
+    with RNG stream (seed, chain), and the sample blocks are ALL-GATHERED so every rank holds every chain;
+    rank 0 writes the per-chain files the reference writes.  Without a process group the chains run one
+    after another.  `pids` is kept for signature parity: its length is the number of chains (default:
+    world size).  `context_factory(mesh, data, inv, device_id)` replaces `get_context` (the CPU tests run
+    the real sampler on an oracle-backed stand-in); `run_chain(chain_index, rng)` replaces the sampler.
+    Further keyword arguments go to runHMCSampler (e.g. device_leapfrog=True).
     Returns (hmcmodel[list], hmcstats[list], hmcdata[list]) indexed by chain.
     """
     import copy
@@ -259,6 +290,10 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
     except Exception:                                       # pragma: no cover
         have_pg = False
     world, rank = (dist.get_world_size(), dist.get_rank()) if have_pg else (1, 0)
+    dev_id = default_device() if device_id is None else int(device_id)
+    use_cuda = have_pg and dist.get_backend() == "nccl"
+    if use_cuda:
+        torch.cuda.set_device(dev_id)                       # the collective below runs on this rank's own GPU
     if nchains is None:
         nchains = len(pids) if pids is not None else world
     mine = list(range(rank, nchains, world))
@@ -270,7 +305,9 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
             model, stats, data = run_chain(c, rng)
         else:
             inv_c, prior_c, mesh_c = copy.deepcopy(invParam), copy.deepcopy(hmcprior), copy.deepcopy(mtMesh)
-            model, stats, data = runHMCSampler(mesh_c, mtData, inv_c, prior_c, rng)
+            ctx_c = context_factory(mesh_c, mtData, inv_c, dev_id) if context_factory is not None else \
+                get_context(mesh_c, mtData, inv_c, device_id=dev_id)
+            model, stats, data = runHMCSampler(mesh_c, mtData, inv_c, prior_c, rng, ctx=ctx_c, **sampler_kw)
             release_context(inv_c)
         results[c] = (model, stats, data, time.time() - t0)
 
@@ -294,8 +331,7 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
 
     local = np.concatenate([pack(s) for s in range(per)]) if per else np.zeros(0)
     if have_pg and world > 1:
-        use_cuda = dist.get_backend() == "nccl"
-        dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+        dev = torch.device("cuda", dev_id) if use_cuda else torch.device("cpu")
         send = torch.from_numpy(local).to(dev)
         recv = torch.empty(world * local.size, dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(recv, send)             # RCCL ring over xGMI on the GPU box

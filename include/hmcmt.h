@@ -72,6 +72,9 @@ typedef struct hmcmt_stats {
     double  true_res_max;                   /* max ||b-Ax||/||b|| (only with options.verify) */
     int32_t status;                         /* 0 or HMCMT_ENOCONV / HMCMT_EBREAKDOWN */
     int32_t nsystems;                       /* 2*nFreq */
+    int32_t fallback_solves;                /* solves of the last call (0..2) whose stragglers were restarted with the fp64
+                                               preconditioner after 60 mixed-precision iterations */
+    int32_t reserved_;                      /* keeps sizeof a multiple of 8 on every ABI */
 } hmcmt_stats;
 
 void hmcmt_default_options(hmcmt_options* opts);

@@ -4,24 +4,33 @@
 # Drop this module next to the reference's HMCMT package.  It overrides exactly the hot path:
 #   compDataGradient(mtMesh, mtData, invParam, hmcprior)   (HMCSampler/HMCSampler.jl:277-330)
 #   the forward solve inside getHamiltonian                (HMCSampler/HMCSampler.jl:358-397)
-# and leaves every other reference function (readstartupFile, runHMCSampler, proposeLeapfrog,
-# parallelHMCSampler, writers) untouched.  Select it with `linearsolver: hip` in the startup file.
+#   proposeLeapfrog(hmcParamCurrent, mtMesh, ...)          (HMCSampler/HMCSampler.jl:206-269), optional:
+#                                                          the whole trajectory on the GPU (hmcmt_leapfrog)
+# and leaves every other reference function (readstartupFile, runHMCSampler, parallelHMCSampler, writers)
+# untouched.  Select it with `linearsolver: hip` in the startup file.
 #
-# NOTE: this file could not be executed in the build container (no julia binary).  It is a thin
-# `ccall` layer: every call passes the reference's own arrays straight through -- Julia's
-# Vector{Float64}/Vector{ComplexF64}/Vector{Int64} have exactly the memory layout the C ABI
-# expects (interleaved re/im doubles, 1-based int64 indices).  The same ABI is exercised from
-# Python/ctypes by tests/test_gpu_parity.py.
+# One process = one GPU: under `addprocs(n)` + parallelHMCSampler (parallelHMC.jl:23-40) worker p uses device
+# (p - 2) mod ndevices (worker ids start at 2), the master process device 0; HMCMT_DEVICE overrides.
+#
+# NOTE: this file could not be executed in the build container (no julia binary; tests/test_abi.py checks its
+# struct field lists and bound symbols against include/hmcmt.h mechanically).  It is a thin `ccall` layer: every
+# call passes the reference's own arrays straight through -- Julia's Vector{Float64} / Vector{ComplexF64} /
+# Vector{Int64} have exactly the memory layout the C ABI expects (interleaved re/im doubles, 1-based int64
+# indices).  The same ABI is exercised from Python/ctypes by tests/test_gpu_parity*.py and from compiled C by
+# tests/c_abi/abi_check.c.
 #-------------------------------------------------------------------------------
 module HMCMTHip
 
+using LinearAlgebra            # diag
 using SparseArrays
+using Distributed              # myid
 using HMCMT.HMCFileIO, HMCMT.HMCStruct, HMCMT.HMCUtility
 
-export HipContext, hipContext, compDataGradient, hipForward, destroy!
+export HipContext, hipContext, compDataGradient, hipForward, setPrior!, proposeLeapfrog, hipStats, destroy!
 
 const libhmcmt = get(ENV, "HMCMT_HIP_LIB", joinpath(@__DIR__, "..", "hmcmt2d_amd", "libhmcmt_hip.so"))
 
+# field order and types of include/hmcmt.h (checked by tests/test_abi.py against the ctypes mirror)
 struct HmcmtOptions
     precond::Int32
     maxit::Int32
@@ -32,10 +41,25 @@ struct HmcmtOptions
     fdm_precision::Int32
 end
 
+struct HmcmtStats
+    iters_fwd_max::Int32
+    iters_adj_max::Int32
+    iters_fwd_sum::Int32
+    iters_adj_sum::Int32
+    err_est_max::Float64
+    true_res_max::Float64
+    status::Int32
+    nsystems::Int32
+    fallback_solves::Int32
+    reserved_::Int32
+end
+
 mutable struct HipContext
     ptr::Ptr{Cvoid}
     nAC::Int
     nData::Int
+    device::Int
+    havePrior::Bool
 end
 
 function checkerr(ctx::Ptr{Cvoid}, rc::Cint)
@@ -45,12 +69,24 @@ function checkerr(ctx::Ptr{Cvoid}, rc::Cint)
 end
 
 """
-    hipContext(mtMesh, mtData, invParam; device=0)
+    defaultDevice()
+
+GPU of this Julia process: `HMCMT_DEVICE` if set, else worker id - 2 modulo `HMCMT_NDEVICES` (default 8) on a
+worker started by `addprocs`, else 0.
+"""
+function defaultDevice()
+    haskey(ENV, "HMCMT_DEVICE") && return parse(Int, ENV["HMCMT_DEVICE"])
+    ndev = parse(Int, get(ENV, "HMCMT_NDEVICES", "8"))
+    return myid() >= 2 ? mod(myid() - 2, ndev) : 0
+end
+
+"""
+    hipContext(mtMesh, mtData, invParam; device=defaultDevice())
 
 Builds the GPU context once per run (replaces the operator set-up the reference redoes on every
 call: setupTensorMesh2D!, getBoundaryIndex, preSetRxFieldSens).
 """
-function hipContext(mtMesh::TensorMesh2D, mtData::MTData, invParam::InvDataModel; device::Integer=0)
+function hipContext(mtMesh::TensorMesh2D, mtData::MTData, invParam::InvDataModel; device::Integer=defaultDevice())
     occursin("Impedance", mtData.dataType) || error("only DataType Impedance is supported")
     ny, nz = mtMesh.gridSize
     compMode = Int64[occursin("XY", c) ? 1 : (occursin("YX", c) ? 2 : error("unsupported component $c"))
@@ -79,7 +115,7 @@ function hipContext(mtMesh::TensorMesh2D, mtData::MTData, invParam::InvDataModel
                dataID, obs, dataW,
                length(activeIdx), activeIdx, invParam.bgModel, C_NULL)
     checkerr(C_NULL, rc)
-    ctx = HipContext(ctxref[], length(activeIdx), length(obs))
+    ctx = HipContext(ctxref[], length(activeIdx), length(obs), Int(device), false)
     finalizer(destroy!, ctx)
     return ctx
 end
@@ -91,7 +127,8 @@ function destroy!(ctx::HipContext)
     end
 end
 
-const contexts = IdDict{Any,HipContext}()
+# one context per InvDataModel of this process (WeakKeyDict: the context goes with its problem)
+const contexts = WeakKeyDict{Any,HipContext}()
 getctx(mtMesh, mtData, invParam) = get!(() -> hipContext(mtMesh, mtData, invParam), contexts, invParam)
 
 """
@@ -128,6 +165,66 @@ function hipForward(mtMesh::TensorMesh2D, mtData::MTData, invParam::InvDataModel
                ctx.ptr, invParam.strModel, pred, misfit)
     checkerr(ctx.ptr, rc)
     return pred, misfit[]
+end
+
+"""
+    setPrior!(ctx, invParam, hmcParam)
+
+Registers the prior (refModel, Wm) and the diagonal of M^-1 for device-resident trajectories (hmcmt_set_prior).
+Wm is symmetric, so its CSC arrays are its CSR arrays; they go over 0-based.
+"""
+function setPrior!(ctx::HipContext, invParam::InvDataModel, hmcParam::HMCParameter)
+    Wm = invParam.Wm
+    rowptr = Vector{Int64}(Wm.colptr .- 1)
+    colind = Vector{Int64}(Wm.rowval .- 1)
+    val = Vector{Float64}(Wm.nzval)
+    invM = Vector{Float64}(diag(hmcParam.invM))
+    rc = ccall((:hmcmt_set_prior, libhmcmt), Cint,
+               (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}),
+               ctx.ptr, invParam.refModel, rowptr, colind, val, invM)
+    checkerr(ctx.ptr, rc)
+    ctx.havePrior = true
+    return ctx
+end
+
+"""
+    proposeLeapfrog(hmcParamCurrent, mtMesh, mtData, invParam, hmcprior) -> (propModel, propMomentum)
+
+Same signature and return values as HMCSampler.proposeLeapfrog (HMCSampler.jl:206-269); the L + 1 gradient
+evaluations, the momentum / position updates, the step clamp and the bound reflection run on the GPU
+(hmcmt_leapfrog).  The forward response at the proposal comes back with the trajectory: getHamiltonian's
+`hipForward` at the same model is then answered from the library's memo without a solve.
+"""
+function proposeLeapfrog(hmcParamCurrent::HMCParameter, mtMesh::TensorMesh2D, mtData::MTData,
+                         invParam::InvDataModel, hmcprior::HMCPrior)
+    ctx = getctx(mtMesh, mtData, invParam)
+    ctx.havePrior || setPrior!(ctx, invParam, hmcParamCurrent)
+    intstep = rand(hmcprior.timestep[1]:hmcprior.timestep[2])          # unirandInteger (HMCUtility.jl)
+    n = ctx.nAC
+    m1 = Vector{Float64}(undef, n); p1 = Vector{Float64}(undef, n)
+    pred = Vector{ComplexF64}(undef, ctx.nData)
+    misfit = Ref{Float64}(0.0); mnorm = Ref{Float64}(0.0); nf = Ref{Int32}(0)
+    rc = ccall((:hmcmt_leapfrog, libhmcmt), Cint,
+               (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64, Int32, Float64, Float64, Float64,
+                Ptr{Float64}, Ptr{Float64}, Ptr{ComplexF64}, Ref{Float64}, Ref{Float64}, Ref{Int32}),
+               ctx.ptr, hmcParamCurrent.rhomodel, hmcParamCurrent.momentum, hmcprior.dt, Int32(intstep),
+               hmcprior.regParam, log(hmcprior.sigBounds[1]), log(hmcprior.sigBounds[2]),
+               m1, p1, pred, misfit, mnorm, nf)
+    checkerr(ctx.ptr, rc)
+    hmcprior.nfevals += nf[]
+    invParam.strModel = copy(m1)
+    mtMesh.sigma = invParam.activeCell * exp.(m1) + invParam.bgModel
+    return m1, p1
+end
+
+"""
+    hipStats(ctx) -> HmcmtStats   (iteration counts, error estimate, fallback counter of the last call)
+"""
+function hipStats(ctx::HipContext)
+    st = Ref{HmcmtStats}()
+    rc = ccall((:hmcmt_get_stats, libhmcmt), Cint, (Ptr{Cvoid}, Ref{HmcmtStats}), ctx.ptr, st)
+    checkerr(ctx.ptr, rc)
+    return st[]
 end
 
 end # module

@@ -1,4 +1,5 @@
 """Shared builders for the tests: synthetic problems (BASELINE.json configs) with oracle-made data."""
+import copy
 import os
 import numpy as np
 
@@ -88,3 +89,26 @@ def cfg3_subset_problem(g):
     inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, g["obs"], g["err"])
     inv16 = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, g["obs16"], g["err16"])
     return mesh, data, inv, S.rough_state(len(inv.strModel)), data16, inv16
+
+
+class OracleContext:
+    """Test double with the HipContext compute interface, backed by the oracle."""
+
+    def __init__(self, mesh, data, inv):
+        from oracle import hmcmt_oracle as O
+        self.O, self.mesh, self.data = O, copy.deepcopy(mesh), data
+        self.inv = copy.deepcopy(inv)
+        O.setupTensorMesh2D(self.mesh)
+        self._cache = None
+        self.ngrad = self.nfwd = 0
+
+    def grad(self, m):
+        self.ngrad += 1
+        self.inv.strModel = np.asarray(m).copy()
+        return self.O.compDataGradient(self.mesh, self.data, self.inv, HMCPrior(), False)
+
+    def forward(self, m):
+        self.nfwd += 1
+        s = self.inv.bgModel.copy(); s[self.inv.activeIdx] += np.exp(m); self.mesh.sigma = s
+        p, _ = self.O.MT2DFwdSolver(self.mesh, self.data)
+        return p, self.O.compDataMisfit(p, self.inv)

@@ -79,3 +79,76 @@ def test_mumps_interface_without_a_device_fails_loudly():
     A = sp.csc_matrix(np.array([[2.0, -1.0], [-1.0, 2.0]]))
     with pytest.raises(RuntimeError, match="MUMPS: error"):
         M.factorMUMPS(A, 1)
+
+
+def _build_abi_check(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "abi_check")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi", "abi_check.c"), "-o", exe, "-ldl"])
+    return exe
+
+
+def test_headers_compile_as_c11_and_match_the_ctypes_mirror(tmp_path):
+    """include/hmcmt.h and include/hmcmt_mumps.h through a real C compiler (gcc -std=c11 -Wall -Wextra -Werror):
+    sizeof / offsetof of hmcmt_options and hmcmt_stats must equal the ctypes structs of hmcmt2d_amd/lib.py (and of
+    julia/HMCMTHip.jl, which mirrors the same field order), the constants the Python side hard-codes must agree."""
+    import subprocess
+    out = subprocess.check_output([_build_abi_check(tmp_path)], text=True)
+    sizes, offs, consts = {}, {}, {}
+    for line in out.splitlines():
+        t = line.split()
+        if t[0] == "sizeof":
+            sizes[t[1]] = int(t[2])
+        elif t[0] == "offsetof":
+            offs[t[1]] = int(t[2])
+        elif t[0] == "const":
+            consts[t[1]] = int(t[2])
+    assert "mumps prototypes" in out
+    for cname, cls in (("hmcmt_options", L.Options), ("hmcmt_stats", L.Stats)):
+        assert sizes[cname] == ctypes.sizeof(cls)
+        fields = [f for f, _ in cls._fields_]
+        assert sorted(k.split(".")[1] for k in offs if k.startswith(cname + ".")) == sorted(f for f in fields if f != "reserved_")
+        for f in fields:
+            if f != "reserved_":
+                assert offs[f"{cname}.{f}"] == getattr(cls, f).offset, f
+    assert consts["HMCMT_NCAT"] == L.HMCMT_NCAT == len(L.CATEGORIES)
+    assert consts["HMCMT_ENOCONV"] == -10 and consts["HMCMT_EBREAKDOWN"] == -11 and consts["HMCMT_ENODEV"] == -2
+    assert L.ERRORS[consts["HMCMT_ENOCONV"]] == "ENOCONV" and L.PRECOND["fdmj"] == consts["HMCMT_PRECOND_FDM_JACOBI"]
+
+
+def test_julia_binding_mirrors_the_struct_layout():
+    """julia/HMCMTHip.jl cannot be executed here (no julia binary): at least its struct field lists must be the
+    header's, in order, and it must bind every hot-path entry point."""
+    src = open(os.path.join(ROOT, "julia", "HMCMTHip.jl")).read()
+    def fields(name):
+        body = re.search(r"struct %s\b(.*?)\nend" % name, src, flags=re.S).group(1)
+        return re.findall(r"^\s*([a-z_]+)::", body, flags=re.M)
+    assert fields("HmcmtOptions") == [f for f, _ in L.Options._fields_]
+    assert fields("HmcmtStats") == [f for f, _ in L.Stats._fields_]
+    assert "using LinearAlgebra" in src
+    for sym in ("hmcmt_create", "hmcmt_grad", "hmcmt_forward", "hmcmt_destroy", "hmcmt_set_prior", "hmcmt_leapfrog",
+                "hmcmt_get_stats", "hmcmt_last_error"):
+        assert f":{sym}" in src, sym
+
+
+@pytest.mark.gpu
+def test_compiled_c_consumer_runs_the_hot_path(tmp_path):
+    """The same C program dlopen()s libhmcmt_hip.so and runs hmcmt_create / hmcmt_grad / hmcmt_get_stats /
+    hmcmt_destroy on the tiny config from a binary dump: no Python, no ctypes between the header and the library."""
+    import subprocess
+    import numpy as np
+    from tests.c_abi.dump import write_dump
+    from tests.helpers import make_problem, oracle_eval, relmax
+    exe = _build_abi_check(tmp_path)
+    mesh, data, inv, m = make_problem("tiny")
+    dump = str(tmp_path / "tiny.bin")
+    a = write_dump(dump, mesh, data, inv, m)
+    out = subprocess.check_output([exe, "run", L.SO_PATH, dump], text=True)
+    kv = {ln.split()[0]: ln.split()[1:] for ln in out.splitlines()}
+    assert kv["status"] == ["0"] and kv["destroy"] == ["0"] and int(kv["nsystems"][0]) == 2 * a.nFreq
+    raw = np.fromfile(dump + ".out")
+    pred = raw[:2 * a.nData].view(np.complex128); grad = raw[2 * a.nData:]
+    po, mo, go = oracle_eval(mesh, data, inv, m)
+    assert relmax(pred, po) < 1e-9 and relmax(grad, go) < 1e-7 and abs(float(kv["misfit"][0]) - mo) / mo < 1e-9
+    assert float(kv["true_res"][0]) < 1e-9 and int(kv["iters"][0]) > 0

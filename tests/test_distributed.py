@@ -43,6 +43,67 @@ def _worker(rank, world, port, nchains, q):
     dist.destroy_process_group()
 
 
+def _worker_real(rank, world, port, nchains, q):
+    """The real runHMCSampler on every rank (host leapfrog loop, accept/reject, packing), the compute interface
+    served by the oracle-backed stand-in of tests/helpers.py -- so the all-gather carries real chain output."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import copy
+    import torch.distributed as dist
+    from hmcmt2d_amd import sampler
+    from hmcmt2d_amd.structs import HMCPrior
+    from tests.helpers import make_problem, OracleContext
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mesh, data, inv, m = make_problem("tiny")
+    prior = HMCPrior(totalsamples=2, burninsamples=0, dt=0.02, timestep=[1, 2], sigBounds=[1e-4, 1.0])
+    devices = []
+
+    def factory(mesh_c, data_c, inv_c, dev):
+        devices.append(dev)
+        return OracleContext(mesh_c, data_c, inv_c)
+
+    hm, hs, hd = sampler.parallelHMCSampler(mesh, data, inv, prior, nchains=nchains, seed=11, context_factory=factory)
+    exp = []
+    for c in range(nchains):        # the same chains, one after another in this process
+        mdl, st, dat = sampler.runHMCSampler(copy.deepcopy(mesh), data, copy.deepcopy(inv), copy.deepcopy(prior),
+                                             np.random.default_rng([11, c]), ctx=OracleContext(mesh, data, inv))
+        exp.append((mdl, st.hmstats, st.acceptstats, dat))
+    ok = all(np.array_equal(hm[c], exp[c][0]) and np.array_equal(hs[c].hmstats, exp[c][1])
+             and np.array_equal(hs[c].acceptstats, exp[c][2]) and np.array_equal(hd[c], exp[c][3]) for c in range(nchains))
+    q.put((rank, ok, devices, [float(np.abs(x).sum()) for x in hm]))
+    dist.destroy_process_group()
+
+
+def test_real_sampler_chains_allgathered_with_per_rank_device():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    nchains = 3
+    procs = [ctx.Process(target=_worker_real, args=(r, 2, port, nchains, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, ok0, dev0, s0), (r1, ok1, dev1, s1) = out
+    assert ok0 and ok1, "gathered chains must equal the same chains run one after another"
+    assert s0 == s1 and all(x > 0 for x in s0)
+    assert dev0 == [0, 0] and dev1 == [1]            # rank r builds its contexts on device LOCAL_RANK = r (chains 0, 2 | 1)
+
+
+def test_default_device_follows_local_rank(monkeypatch):
+    from hmcmt2d_amd import sampler
+    monkeypatch.delenv("LOCAL_RANK", raising=False); monkeypatch.delenv("HMCMT_DEVICE", raising=False)
+    assert sampler.default_device() == 0
+    monkeypatch.setenv("HMCMT_DEVICE", "3")
+    assert sampler.default_device() == 3
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert sampler.default_device() == 5
+
+
 @pytest.mark.parametrize("nchains", [2, 3])
 def test_chains_shard_and_allgather(nchains):
     import torch.multiprocessing as mp

@@ -520,3 +520,39 @@ def test_fused_solve_start_matches_separate_kernels(monkeypatch):
         assert abs(fa - fb) <= 1e-9 * abs(fb)
         assert np.abs(ga - gb).max() <= 1e-7 * np.abs(gb).max()
     assert sa["status"] == 0 and sb["status"] == 0
+
+
+def test_sampler_context_lands_on_the_ranks_device(monkeypatch):
+    """parallelHMCSampler / runHMCSampler / get_context take the GPU from LOCAL_RANK (one process per GPU,
+    parallelHMC.jl:23-40): the context is created there, the process's current HIP device is that device afterwards,
+    and a LOCAL_RANK beyond the box's GPUs fails loudly instead of silently landing on device 0."""
+    import ctypes
+    from hmcmt2d_amd import sampler
+    hip = ctypes.CDLL("libamdhip64.so")
+    n = ctypes.c_int(0); hip.hipGetDeviceCount(ctypes.byref(n))
+    mesh, data, inv, m = make_problem("tiny")
+    last = n.value - 1
+    monkeypatch.setenv("LOCAL_RANK", str(last))
+    ctx = sampler.get_context(mesh, data, inv)
+    assert ctx.device_id == last
+    cur = ctypes.c_int(-1); hip.hipGetDevice(ctypes.byref(cur))
+    assert cur.value == last
+    ctx.grad(m)
+    hip.hipGetDevice(ctypes.byref(cur))
+    assert cur.value == last
+    assert sampler.get_context(mesh, data, inv) is ctx                   # cached per (problem, device)
+    sampler.release_context(inv)
+    monkeypatch.setenv("LOCAL_RANK", str(n.value))                        # one past the last GPU of this box
+    with pytest.raises(HmcmtError) as e:
+        sampler.get_context(mesh, data, inv)
+    assert e.value.code == -2
+    # a context dies with its InvDataModel: a recycled id() cannot return a stale one
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    import copy, gc
+    inv2 = copy.deepcopy(inv)
+    c2 = sampler.get_context(mesh, data, inv2)
+    key = (id(inv2), 0)
+    assert key in sampler._contexts
+    del inv2, c2
+    gc.collect()
+    assert key not in sampler._contexts

@@ -1,0 +1,127 @@
+"""Robustness of the HIP path on the GPU: models far rougher than the bench state, models pinned at
+the sampler's bounds (rho in [1, 1e4] Ohm-m, examples/dprism3d/startupfile:5), the fp64 restart of the mixed-precision
+solver, recovery after a failed evaluation, and a trajectory with the step clamp of HMCSampler.jl:234-243 active."""
+import copy
+import os
+import numpy as np
+import pytest
+
+from hmcmt2d_amd.lib import HipContext, HmcmtError
+from hmcmt2d_amd.structs import HMCPrior, initHMCParameter
+from tests.helpers import make_problem, oracle_eval, relmax, gerr_split
+
+pytestmark = pytest.mark.gpu
+LO, HI = np.log(1e-4), np.log(1.0)
+
+
+def _models(n, ny=50):
+    rng = np.random.default_rng(2)
+    out = {f"std{std}": np.clip(np.log(0.01) + std * rng.standard_normal(n), LO, HI) for std in (1.0, 1.5)}
+    cell = np.arange(n)
+    blk = np.full(n, LO)
+    blk[(cell % ny > 15) & (cell % ny < 35) & (cell // ny < 12)] = HI          # 1 Ohm-m block in 1e4 Ohm-m: both bounds
+    out["block at the bounds"] = blk
+    return out
+
+
+@pytest.mark.parametrize("case", ["std1.0", "std1.5", "block at the bounds"])
+def test_rough_models_and_models_at_the_bounds(case):
+    """cfg2 with ln(sigma) ~ N(ln 0.01, 1.0 / 1.5) clipped to the bounds, and a 1 Ohm-m block in a 1e4 Ohm-m host (every
+    cell AT a bound, contrast 1e4): the solves converge (true residual < 1e-9), predicted data agree with the oracle,
+    and beyond 60 mixed-precision iterations the stragglers are restarted with the fp64 preconditioner
+    (hmcmt_stats.fallback_solves).  Gradient bar: on white-noise models this rough the reference formula's own
+    gradient moves by up to 1e-3 of max|g| under a 1e-14 relative perturbation of the model (its 1-D boundary
+    sensitivities) -- the bar is 1e-8 + 10 x that self-noise, measured here with the oracle; on the
+    block model the formula is well conditioned and the plain 1e-8 holds."""
+    mesh, data, inv, m = make_problem("cfg2")
+    mm = _models(m.size)[case]
+    ctx = HipContext(mesh, data, inv, verify=True)
+    pred, misfit, grad = ctx.grad(mm)
+    st = ctx.stats()
+    assert st["status"] == 0 and st["true_res_max"] < 1e-9, st
+    if case == "std1.0":
+        assert st["iters_fwd_max"] < 60 and st["fallback_solves"] == 0
+    else:
+        assert st["iters_fwd_max"] > 60 and st["fallback_solves"] == 2, st       # the fp64 restart ran in both solves
+    po, mo, go = oracle_eval(mesh, data, inv, mm)
+    assert relmax(pred, po) < 1e-8 and abs(misfit - mo) / mo < 1e-8
+    noise = (0.0, 0.0)
+    if case != "block at the bounds":
+        for eps in (1e-14, -1e-14, 1e-13):
+            _, _, g1 = oracle_eval(mesh, data, inv, mm * (1 + eps))
+            noise = tuple(max(a, b) for a, b in zip(noise, gerr_split(g1, go, inv, mesh)))
+    shallow, deep = gerr_split(grad, go, inv, mesh)
+    assert shallow < 1e-8 + 10 * noise[0] and deep < 5e-7 + 10 * noise[1], (shallow, deep, noise)
+    # the same model through the default path (warm start from the previous fields): same answer
+    ctx.set_options(verify=0)
+    ctx.grad(mm + 1e-3)
+    p2, f2, g2 = ctx.grad(mm)
+    assert relmax(p2, pred) < 1e-8 and gerr_split(g2, grad, inv, mesh)[0] < 1e-6 + 10 * noise[0]
+    ctx.close()
+
+
+def test_context_recovers_after_a_failed_device_evaluation():
+    """A failed evaluation (non-finite model handed over on the DEVICE, where the host-side check cannot see it; an
+    iteration cap) must not poison the next one: its fields and extrapolation history may hold Inf/NaN, so the next
+    call starts cold and succeeds (EBREAKDOWN used to persist until hmcmt_set_options)."""
+    import torch
+    mesh, data, inv, m = make_problem("tiny")
+    dev = torch.device("cuda", 0)
+    ctx = HipContext(mesh, data, inv)
+    good = torch.from_numpy(np.stack([m, m + 0.01, m + 0.02])).to(dev)
+    bad = good[1].clone(); bad[5] = float("nan")
+    d_pred = torch.zeros(2 * ctx.nData, dtype=torch.float64, device=dev)
+    d_mis = torch.zeros(1, dtype=torch.float64, device=dev)
+    d_g = torch.zeros(ctx.nAC, dtype=torch.float64, device=dev)
+    ctx.grad_device(good[0].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr(), d_g.data_ptr())
+    with pytest.raises(HmcmtError) as e:
+        ctx.grad_device(bad.data_ptr(), d_pred.data_ptr(), d_mis.data_ptr(), d_g.data_ptr())
+    assert e.value.code == -11
+    ctx.grad_device(good[2].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr(), d_g.data_ptr())     # no set_options in between
+    st = ctx.stats()
+    assert st["status"] == 0 and st["iters_fwd_max"] > 0
+    po, mo, go = oracle_eval(mesh, data, inv, m + 0.02)
+    assert relmax(d_pred.cpu().numpy().view(np.complex128), po) < 1e-9 and relmax(d_g.cpu().numpy(), go) < 1e-7
+    # iteration cap: ENOCONV, then a normal call with the cap lifted
+    ctx.set_options(maxit=2)
+    with pytest.raises(HmcmtError) as e:
+        ctx.grad(m + 0.05)
+    assert e.value.code == -10
+    ctx.opts.maxit = 2000
+    ctx.lib.hmcmt_set_options(ctx.h, ctx.opts)
+    p, f, g = ctx.grad(m + 0.02)
+    assert relmax(p, po) < 1e-9
+    ctx.close()
+
+
+def test_device_trajectory_with_the_step_clamp_active():
+    """proposeLeapfrog scales a position step whose largest component exceeds maxStepSize = 3.0 (HMCSampler.jl:234-243):
+    a momentum of ~200 per cell makes dt*p ~ 6 > 3 in every step.  hmcmt_leapfrog (device) against the host loop over
+    the same context and against the oracle's proposeLeapfrog; bounds wide enough to see the clamp alone, then the
+    sampler's own bounds (clamp + reflection together)."""
+    from oracle import hmcmt_oracle as O
+    from hmcmt2d_amd import sampler
+    mesh, data, inv, m = make_problem("tiny")
+    inv.refModel = np.full(len(m), np.log(0.01))
+    rng = np.random.default_rng(4)
+    p0 = 200.0 * np.clip(rng.standard_normal(len(m)), -2.5, 2.5)
+    mesh_o = copy.deepcopy(mesh); O.setupTensorMesh2D(mesh_o)
+    for bounds in ([1e-12, 1e8], [1e-4, 1.0]):
+        prior = HMCPrior(dt=0.03, timestep=[3, 3], sigBounds=bounds, regParam=1.0)
+        assert np.abs(0.03 * p0).max() > 3.0
+        ctx = HipContext(mesh, data, inv, warm_start=False)
+        hp = initHMCParameter(len(m)); hp.invM[:] = 1.0; hp.sqrtM[:] = 1.0
+        hp.rhomodel, hp.momentum = m.copy(), p0.copy()
+        m_host, p_host = sampler.proposeLeapfrog(hp, mesh, data, copy.deepcopy(inv), copy.deepcopy(prior), None, 3, ctx)
+        ctx.set_prior(inv.refModel, inv.Wm, hp.invM)
+        ctx.set_prior(inv.refModel, inv.Wm, hp.invM)               # a repeated registration replaces the first
+        m_dev, p_dev = sampler.proposeLeapfrogDevice(hp, mesh, data, copy.deepcopy(inv), copy.deepcopy(prior), None, 3, ctx)
+        m_or, p_or = O.proposeLeapfrog(m.copy(), p0.copy(), np.ones(len(m)), mesh_o, data, copy.deepcopy(inv), prior, 3, False)
+        # the clamp was active: the first position step moved the model by exactly maxStepSize in its largest component
+        assert np.abs(m_dev - m).max() > 3.0 or bounds[1] < 10
+        # measured: device vs host loop 1e-11 (m), 9e-11 (p); vs the oracle 1e-9 (m), 5e-9 (p)
+        assert relmax(m_dev, m_host) < 1e-10 and relmax(p_dev, p_host) < 1e-9
+        assert relmax(m_dev, m_or) < 1e-8 and relmax(p_dev, p_or) < 5e-8
+        lo, hi = np.log(bounds[0]), np.log(bounds[1])
+        assert m_dev.min() >= lo and m_dev.max() <= hi
+        ctx.close()

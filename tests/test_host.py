@@ -8,30 +8,7 @@ import pytest
 import hmcmt2d_amd as H
 from hmcmt2d_amd import synthetic as S, sampler
 from hmcmt2d_amd.structs import HMCPrior
-from tests.helpers import make_problem, relmax
-
-
-class OracleContext:
-    """Test double with the HipContext compute interface, backed by the oracle."""
-
-    def __init__(self, mesh, data, inv):
-        from oracle import hmcmt_oracle as O
-        self.O, self.mesh, self.data = O, copy.deepcopy(mesh), data
-        self.inv = copy.deepcopy(inv)
-        O.setupTensorMesh2D(self.mesh)
-        self._cache = None
-        self.ngrad = self.nfwd = 0
-
-    def grad(self, m):
-        self.ngrad += 1
-        self.inv.strModel = np.asarray(m).copy()
-        return self.O.compDataGradient(self.mesh, self.data, self.inv, HMCPrior(), False)
-
-    def forward(self, m):
-        self.nfwd += 1
-        s = self.inv.bgModel.copy(); s[self.inv.activeIdx] += np.exp(m); self.mesh.sigma = s
-        p, _ = self.O.MT2DFwdSolver(self.mesh, self.data)
-        return p, self.O.compDataMisfit(p, self.inv)
+from tests.helpers import make_problem, relmax, OracleContext
 
 
 def test_model_and_data_file_round_trip(tmp_path):
