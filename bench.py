@@ -1,14 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: leapfrog steps/s (= forward + gradient evaluations/s) on the 200x100-cell,
-16-frequency synthetic of BASELINE.json, one independent chain per GPU.
+16-frequency synthetic of BASELINE.json, one independent HMC chain per GPU.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3]
 
-A step is one pass of the hot path -- compDataGradient (HMCSampler.jl:277-330) -- at the next model
-of a synthetic leapfrog trajectory m_k = m_0 + k*dt*p; all K models are resident in HBM before the
-timed region and predData / misfit / gradient stay in HBM.  For N > 1 the driver launches this file
-with torch.distributed.run (one rank per GPU, RCCL); ranks are independent chains (weak scaling) and
-the only collective in the timed region is the barrier.  Rank 0 prints ONE JSON line.
+A step is one leapfrog step of a REAL trajectory of the sampler (proposeLeapfrog, HMCSampler.jl:206-269): position
+update with the step clamp and the bound reflection, one pass of the hot path -- compDataGradient (:277-330) -- at
+the new model, prior gradient lambda*Wm*(m - mref), momentum update; trajectories of L = 8 steps (timestep 6..10 in
+examples/dprism3d/startupfile), dt = 0.03, momentum redrawn per trajectory from the clipped N(0,1) of
+getMomentumVector (:441-453), accept / reject on the Hamiltonian (:149-171).  Model, momentum, gradient, predicted
+data stay in HBM (hmcmt_leapfrog_device); per trajectory three scalars come back for the accept test.  The gradient
+at a trajectory's start model is the one of the previous trajectory's end (accepted) or start (rejected) model, so a
+trajectory costs L evaluations; the timed region holds exactly K of them.
+
+  value               chain started at the rough state of SURVEY 8(d): m = ln 0.01 + 0.3 N(0,1) (seed 1) -- the
+                      burn-in regime (misfit 8e5, gradients 1e5: the step clamp and the bounds are active)
+  near_true_state     the same chain started at the synthetic's true model: the regime a converged chain samples in
+  straight_line       round 1's idealised figure: evaluations along m0 + k*dt*p (flatters the initial-guess extrapolation)
+  cold_start          evaluations at the rough state's neighbourhood with zero initial guesses (options.warm_start = 0)
+
+For N > 1 the driver launches this file with torch.distributed.run (one rank per GPU, RCCL); ranks are independent
+chains (weak scaling), the only collective in the timed region is the barrier; after it the ranks all-gather a block
+of samples (what parallelHMCSampler does at the end of a run) and report its bandwidth.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -22,12 +35,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+LTRAJ, DT, LAMBDA = 8, 0.03, 1.0
+RHO_BOUNDS = (1.0, 1e4)           # examples/dprism3d/startupfile:5
 
 
-def build_problem(name, seed):
+def build_problem(name):
     """Synthetic workload of SURVEY §8(d): observed data = GPU forward of the true model + 3 % noise."""
     from hmcmt2d_amd import synthetic as S, invsetup as I
-    from hmcmt2d_amd.lib import HipContext
     mesh, data, sig_true = S.make_config(name)
     ny, nz = mesh.gridSize
     nair = len(mesh.airLayer)
@@ -62,7 +76,7 @@ def _cpu_worker(job):
 def cpu_baseline(name):
     """Oracle (numpy/scipy restatement, SuperLU direct solves, dense dBC) on a bounded sample, using every
     host core: one single-threaded worker process per core, each evaluating compDataGradient on its own
-    frequency (TE + TM) of the config -- the frequency loop is the reference's only parallelisable axis
+    frequencies (TE + TM) of the config -- the frequency loop is the reference's only parallelisable axis
     (MT2DFwdSolver.jl:140-146, compJacTMatVec.jl:202-325).  value = frequencies done / wall time / nFreq.
     Runs BEFORE this process touches the GPU (the workers are spawned, not forked)."""
     import multiprocessing as mp
@@ -78,7 +92,6 @@ def cpu_baseline(name):
         t0 = time.time()
         times = pool.map(_cpu_worker, jobs, chunksize=1)
         wall = time.time() - t0
-    # wall includes each worker's imports and set-up; the rate uses the slowest worker's own timer
     tmax = max(times)
     return {"value": per * len(jobs) / (tmax * nF), "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle compDataGradient (numpy/scipy, SuperLU direct solves, dense dBC as the reference) at "
@@ -87,48 +100,121 @@ def cpu_baseline(name):
                       f"incl. start-up {wall:.1f} s), scaled to {nF} frequencies"}
 
 
-def pmc_traffic(cat):
+def pmc_traffic(config, cat):
     """HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in separate runs of
     this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM'), summarised by scripts/pmc_summary.py into
-    profiles/pmc_traffic.json; None when that file has no entry."""
+    profiles/pmc_traffic.json keyed by config; None when that file has no entry for this config."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)["per_launch_bytes"].get(cat)
-    except (OSError, KeyError, ValueError):
+            return json.load(f).get(config, {}).get("per_launch_bytes", {}).get(cat)
+    except (OSError, ValueError):
         return None
 
 
-def sampler_leg(step, forward, K, W, Ltraj, nsamples=6):
-    """samples/s with the reference's cost structure -- per sample one trajectory of (1 + L)
-    gradient evaluations plus one forward-only solve at the proposal (HMCSampler.jl:136,141) -- on the synthetic
-    trajectories of the timed region (L = Ltraj - 1 = 7 position steps, timestep 6..10 in
-    examples/dprism3d/startupfile).  The proposal's model equals the last gradient's, which the library
-    recognises (the forward-only solve then costs about one iteration)."""
-    import torch
-    first = ((W + Ltraj - 1) // Ltraj) * Ltraj            # trajectories start at multiples of Ltraj
-    n = min(nsamples, (W + K - first) // Ltraj)
-    if n < 1:
-        return None
+from hmcmt2d_amd.lib import HmcmtError  # noqa: E402  (pure ctypes: does not touch the GPU at import)
+
+
+class Chain:
+    """The sampler of HMCSampler.jl:72-196 around hmcmt_leapfrog_device: everything O(nparam) stays on the GPU
+    (torch tensors), the accept test reads three scalars per trajectory."""
+
+    def __init__(self, ctx, torch, dev, m_start, mref, Wm, seed):
+        self.ctx, self.torch, self.dev = ctx, torch, dev
+        n = ctx.nAC
+        self.gen = torch.Generator(device=dev); self.gen.manual_seed(seed)
+        self.host_rng = np.random.default_rng([seed, 99])
+        self.m_cur = torch.from_numpy(np.ascontiguousarray(m_start)).to(dev)
+        self.m_prop = self.m_cur.clone()
+        self.p = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.d_pred = torch.zeros(2 * ctx.nData, dtype=torch.float64, device=dev)
+        self.scal = torch.zeros(2, dtype=torch.float64, device=dev)          # [misfit, mnorm] of the proposal
+        self.lo, self.hi = float(np.log(1.0 / RHO_BOUNDS[1])), float(np.log(1.0 / RHO_BOUNDS[0]))
+        ctx.set_prior(mref, Wm, np.ones(n))
+        # Hamiltonian terms at the start model (getHamiltonian, :358-397)
+        d = m_start - mref
+        self.M0 = 0.5 * LAMBDA * float(d @ (Wm @ d))
+        self.D0 = None
+        self.start_grad = 0
+        self.accepted = self.rejected = self.failed = 0
+        self.last_error = None
+        self.iters = []
+        self.ms_per_step = []
+
+    def trajectory(self, L):
+        torch, ctx = self.torch, self.ctx
+        t_begin = time.perf_counter()
+        self.p.normal_(generator=self.gen).clamp_(-2.5, 2.5)
+        K0 = 0.5 * float((self.p * self.p).sum().item())                     # (also orders torch's stream before the library's)
+        self.m_prop.copy_(self.m_cur)
+        torch.cuda.current_stream().synchronize()
+        try:
+            ctx.leapfrog_device(self.m_prop.data_ptr(), self.p.data_ptr(), DT, L, LAMBDA, self.lo, self.hi, self.start_grad,
+                                self.d_pred.data_ptr(), self.scal.data_ptr(), self.scal.data_ptr() + 8)
+            ctx.wait()
+        except HmcmtError as e:                       # a proposal the solver gave up on is a rejected proposal
+            self.failed += 1
+            self.rejected += 1
+            self.start_grad = 0
+            self.last_error = str(e)
+            return None
+        st = ctx.stats()
+        self.iters.append((st["iters_fwd_max"], st["iters_adj_max"], st["fallback_solves"]))
+        self.ms_per_step.append(1e3 * (time.perf_counter() - t_begin) / L)
+        D1, M1 = (float(x) for x in self.scal.tolist())
+        K1 = 0.5 * float((self.p * self.p).sum().item())
+        if self.D0 is None:                                                   # first trajectory: the start model's misfit is not
+            self.D0 = D1 + 1.0                                                # known on the host; accept (burn-in start)
+            h0 = float("inf")
+        else:
+            h0 = self.D0 + self.M0 + K0
+        hdif = h0 - (D1 + M1 + K1)
+        if hdif > 0 or self.host_rng.random() < np.exp(hdif):
+            self.m_cur, self.m_prop = self.m_prop, self.m_cur
+            self.D0, self.M0 = D1, M1
+            self.start_grad = 1
+            self.accepted += 1
+        else:
+            self.start_grad = 2
+            self.rejected += 1
+        return D1
+
+    def run(self, nsteps):
+        """exactly nsteps leapfrog steps (the last trajectory is shorter if need be)"""
+        left = nsteps
+        while left > 0:
+            L = min(LTRAJ, left)
+            self.trajectory(L)
+            left -= L
+
+    def summary(self):
+        it = np.array(self.iters) if self.iters else np.zeros((1, 3))
+        return {"trajectories": len(self.iters), "accepted": self.accepted, "rejected": self.rejected,
+                "iters_fwd_max_last_step_mean": float(it[:, 0].mean()), "iters_adj_max_last_step_mean": float(it[:, 1].mean()),
+                "fp64_restarts": int(it[:, 2].sum()), "misfit_last": self.D0, "failed_trajectories": self.failed,
+                "ms_per_step_by_trajectory": [round(x, 3) for x in self.ms_per_step[-len(self.iters):]],
+                "last_error": self.last_error}
+
+
+def timed(torch, dist, fn):
+    if dist is not None:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(n):
-        k0 = first + i * Ltraj
-        for j in range(Ltraj):
-            step(k0 + j)                         # gradient at the start model and after each of the L position steps
-        forward(k0 + Ltraj - 1)                  # getHamiltonian's forward-only solve at the proposal
+    fn()
+    if dist is not None:
+        dist.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"samples_per_s": n / dt, "samples": n, "evals_per_sample": f"{Ltraj} gradients + 1 forward-only"}
+    return time.perf_counter() - t0
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sampler", action="store_true", help="skip the untimed samples/s leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed-region legs (near_true_state, straight_line, cold_start)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -153,7 +239,7 @@ def main():
     from hmcmt2d_amd import synthetic as S, invsetup as I
     from hmcmt2d_amd.lib import HipContext
     name = args.config
-    mesh, data, inv0, sig_true = build_problem(name, rank)
+    mesh, data, inv0, sig_true = build_problem(name)
     # observed data from the GPU forward of the true model (+ seeded noise), then the real context
     ctx0 = HipContext(mesh, data, inv0, device_id=local)
     m_true = np.log(sig_true[inv0.activeIdx])
@@ -163,83 +249,93 @@ def main():
     inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, obs, err)
     ctx = HipContext(mesh, data, inv, device_id=local)
     nAC, nData = ctx.nAC, ctx.nData
-
-    K, W = args.steps, args.warmup
-    # synthetic leapfrog trajectories: position steps dm = dt*p with dt = 0.03 (examples/dprism3d/startupfile:5),
-    # momentum redrawn every L = 8 steps (timestep 6..10) from the clipped N(0,1) of getMomentumVector
-    rng = np.random.default_rng([20250114, 7, rank])
-    m0 = S.rough_state(nAC, seed=1 + rank)
-    Ltraj, dt = 8, 0.03
-    traj = np.empty((K + W, nAC))
-    for k in range(K + W):
-        if k % Ltraj == 0:
-            p = np.clip(rng.standard_normal(nAC), -2.5, 2.5)
-        traj[k] = m0 + dt * (k % Ltraj) * p
     dev = torch.device("cuda", local)
-    d_m = torch.from_numpy(traj).to(dev)
-    d_pred = torch.zeros(2 * nData, dtype=torch.float64, device=dev)
-    d_mis = torch.zeros(1, dtype=torch.float64, device=dev)
-    d_grad = torch.zeros(nAC, dtype=torch.float64, device=dev)
+    mref = np.full(nAC, np.log(0.01))            # homogeneous 100 Ohm-m reference / start model (HMCSampler.jl:100-109)
+    K, W = args.steps, args.warmup
 
-    # hmcmt_grad_device_async: as a device-resident leapfrog would call it (the next model comes from this gradient on
-    # the device); the step's two convergence polls still block, its gradient tail overlaps the next step's launches
-    def step(k):
-        ctx.grad_device_async(d_m[k].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr(), d_grad.data_ptr())
-
-    for k in range(W):
-        step(k)
-    ctx.wait()
+    # ---- headline: real trajectories from the rough state -------------------------------------------------------
+    chain = Chain(ctx, torch, dev, S.rough_state(nAC, seed=1 + rank), mref, inv.Wm, seed=20250114 + rank)
+    chain.run(W)
+    chain.iters.clear(); acc0, rej0 = chain.accepted, chain.rejected
     if not os.environ.get("HMCMT_BENCH_NOPROF"):
-        # HIP events around the two heaviest kernel families, in every 6th step of the timed region
+        # HIP events around every launch of the iteration kernels, in every 6th evaluation of the timed region
         # (bracketing every launch of every step costs ~20 % of the throughput)
         ctx.profile(["fdm_transform", "tridiagonal", "spmv", "vector_ops", "post_smoother"], every=6)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(W, W + K):
-        step(k)
-    ctx.wait()                                           # (status of the last step; every earlier one was checked by its successor)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(torch, dist, lambda: chain.run(K))
     prof = ctx.profile_read()
+    cnt = ctx.profile_counters()
     ctx.profile(False)
     st = ctx.stats()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    misfit = float(d_mis.item())
-    gnorm = float(torch.linalg.vector_norm(d_grad).item())
-    def forward(k):
-        ctx.forward_device(d_m[k].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr())
+    head = chain.summary()
+    head["accepted"] -= acc0; head["rejected"] -= rej0
 
-    samples = None
-    structured = None
-    if world == 1 and not args.no_sampler:            # (single-GPU runs only: keeps the ranks of an N-GPU run symmetric)
-        samples = sampler_leg(step, forward, K, W, Ltraj)
-        # Secondary, untimed-region figure: the same trajectories laid around the TRUE model (2 layers + a 10x
-        # conductive block) instead of the homogeneous reference model of SURVEY 8(d).  Lateral structure is what
-        # the laterally averaged FDM background cannot see, so this state needs 2-3x the iterations; it is the
-        # regime a converged chain samples in.
-        nst = min(K + W, 24)
-        d_ms = torch.from_numpy(traj[:nst] - m0 + m_true).to(dev)
-        for k in range(min(8, nst)):
-            ctx.grad_device_async(d_ms[k].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr(), d_grad.data_ptr())
-        ctx.wait()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for k in range(8, nst):
-            ctx.grad_device_async(d_ms[k].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr(), d_grad.data_ptr())
-        ctx.wait()
-        torch.cuda.synchronize()
-        sst = ctx.stats()
-        if nst > 8:
-            structured = {"steps_per_s": (nst - 8) / (time.perf_counter() - t1), "steps": nst - 8,
-                          "iters_fwd_max": sst["iters_fwd_max"], "iters_adj_max": sst["iters_adj_max"],
-                          "state": "true model (100 over 10 ohm-m + 10 ohm-m block) + the same dt*j*p trajectories"}
+    # one evaluation of the timed chain's last model again with the true-residual check on (cold start, verify):
+    # the numbers the timed region produced are solutions of the systems it claims to have solved
+    ctx.set_options(verify=1)
+    d_g = torch.zeros(nAC, dtype=torch.float64, device=dev)
+    d_mis = torch.zeros(1, dtype=torch.float64, device=dev)
+    ctx.grad_device(chain.m_cur.data_ptr(), chain.d_pred.data_ptr(), d_mis.data_ptr(), d_g.data_ptr())
+    stv = ctx.stats()
+    check = {"true_res_max_at_last_model": stv["true_res_max"], "misfit_at_last_model": float(d_mis.item()),
+             "chain_misfit": head["misfit_last"], "solver_status": stv["status"],
+             "grad_l2_at_last_model": float(torch.linalg.vector_norm(d_g).item())}
+    ctx.set_options(verify=0)
+
+    # ---- RCCL all-gather of a sample block (what parallelHMCSampler does with the chains' samples, parallelHMC.jl:23-45)
+    gather = None
+    if dist is not None:
+        ks = 64                                                   # samples per rank in the block
+        send = torch.randn(ks * nAC, dtype=torch.float64, device=dev)
+        recv = torch.empty(world * ks * nAC, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(recv, send)                   # warm-up (communicator set-up)
+        tg = timed(torch, dist, lambda: dist.all_gather_into_tensor(recv, send))
+        ok = bool(torch.equal(recv[rank * ks * nAC:(rank + 1) * ks * nAC], send))
+        gather = {"samples_per_rank": ks, "bytes_per_rank": ks * nAC * 8, "seconds": tg,
+                  "algbw_GBps": world * ks * nAC * 8 / tg / 1e9, "own_block_intact": ok,
+                  "note": "all_gather_into_tensor of k x nparam float64 sample blocks over RCCL, outside the timed region"}
+
+    extras = {}
+    if world == 1 and not args.no_extras:            # (single-GPU runs only: keeps the ranks of an N-GPU run symmetric)
+        Ke = min(K, 48)
+        # (ii) the same sampler started at the true model
+        c2 = Chain(ctx, torch, dev, m_true, mref, inv.Wm, seed=7)
+        c2.run(max(W, LTRAJ)); c2.iters.clear(); a0, r0 = c2.accepted, c2.rejected
+        t2 = timed(torch, None, lambda: c2.run(Ke))
+        s2 = c2.summary(); s2["accepted"] -= a0; s2["rejected"] -= r0
+        extras["near_true_state"] = dict(s2, steps_per_s=Ke / t2, steps=Ke,
+                                         state="chain started at the true model (100 over 10 ohm-m + 10 ohm-m block)")
+        # (iii) round 1's idealised straight-line trajectories
+        rng = np.random.default_rng([20250114, 7, rank])
+        m0 = S.rough_state(nAC, seed=1 + rank)
+        traj = np.empty((Ke + W, nAC))
+        for k in range(Ke + W):
+            if k % LTRAJ == 0:
+                p = np.clip(rng.standard_normal(nAC), -2.5, 2.5)
+            traj[k] = m0 + DT * (k % LTRAJ) * p
+        d_m = torch.from_numpy(traj).to(dev)
+
+        def line(k0, k1):
+            for k in range(k0, k1):
+                ctx.grad_device_async(d_m[k].data_ptr(), chain.d_pred.data_ptr(), d_mis.data_ptr(), d_g.data_ptr())
+            ctx.wait()
+        line(0, W)
+        t3 = timed(torch, None, lambda: line(W, W + Ke))
+        s3 = ctx.stats()
+        extras["straight_line"] = {"steps_per_s": Ke / t3, "steps": Ke, "iters_fwd_max": s3["iters_fwd_max"],
+                                   "iters_adj_max": s3["iters_adj_max"],
+                                   "state": "m0 + k*dt*p around the rough state, momentum redrawn every 8 steps (round 1's headline)"}
+        # (iv) cold start: zero initial guesses
+        ctx.set_options(warm_start=0)
+        line(0, 2)
+        t4 = timed(torch, None, lambda: line(W, W + min(Ke, 16)))
+        s4 = ctx.stats()
+        extras["cold_start"] = {"steps_per_s": min(Ke, 16) / t4, "steps": min(Ke, 16), "iters_fwd_max": s4["iters_fwd_max"],
+                                "iters_adj_max": s4["iters_adj_max"], "state": "the straight-line models, options.warm_start = 0"}
+        ctx.set_options(warm_start=2)
 
     if rank == 0:
         # Algorithmic bytes per launch: U = S*(nz-1)*(ny-1) interior unknowns, complex128 = 16 B,
@@ -251,72 +347,83 @@ def main():
         #                  (separate: k_transform_lp<2> 56 U with z written, k_post: read r, z, dinv (48), write t (16) = 64 U)
         #   k_spmv_fused   p = z + beta p, q = A p, p'q: read z, p (32), write p, q (32)                             = 64 U
         #   k_update_fused x, r updates + Jacobi pre-smoothing: read p, q, r, x, dinv (80), write x, r (32), t (8)   = 120 U
+        # A launch works on the systems still active; U_launch = U * (active systems / S), the active count from the
+        # device counter of hmcmt_profile_counters over the SAME sampled launches the HIP events time (every launch of
+        # every 6th evaluation of the timed region, the empty ones behind a convergence poll included).
         nyi, nzi = ctx.ny - 1, ctx.nz - 1
-        U = ctx.S * nzi * nyi
+        Usys = nzi * nyi
+        U = ctx.S * Usys
         back_fused = prof["post_smoother"][1] == 0
         fwd_fused = ctx.NYP <= 256                      # the library's own rule (launch_fdm_fwd): wide meshes run the separate kernels
+        it_sys = cnt["active_iter_systems"]             # sum over sampled iterations of active systems
+        pre_sys = cnt["start_systems"]                  # + one preconditioner application per solve before the first iteration
         fams = {("k_fdm_fwd (split-bf16 MFMA eigen-transform + LDS-resident complex64 tridiagonal sweeps, one launch)" if fwd_fused else
-                 "k_thomas32 (batched complex64 tridiagonal solve of the FDM stage)"): ("tridiagonal", 24.0 * U, 1),
+                 "k_thomas32 (batched complex64 tridiagonal solve of the FDM stage)"): ("tridiagonal", 24.0, 1, it_sys + pre_sys),
                 ("k_back_post (split-bf16 MFMA back transform + both Jacobi halves of the post-smoother + dot products)" if back_fused else
                  "k_transform_lp<2> (split-bf16 MFMA back transform fused with the first Jacobi half)" if fwd_fused else
                  "k_transform_lp<0>,<2> (split-bf16 MFMA forward and back transforms: 16 U and 56 U)"):
-                    ("fdm_transform", 56.0 * U if fwd_fused else 36.0 * U, 1 if fwd_fused else 2),
-                "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 64.0 * U, 1),
-                "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 120.0 * U, 1)}
+                    ("fdm_transform", 56.0 if fwd_fused else 36.0, 1 if fwd_fused else 2, (it_sys + pre_sys) * (1 if fwd_fused else 2)),
+                "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 64.0, 1, it_sys),
+                "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 120.0, 1, it_sys)}
         if not back_fused:
-            fams["k_post (second Jacobi half: 5-point stencil + dot products)"] = ("post_smoother", 64.0 * U, 1)
+            fams["k_post (second Jacobi half: 5-point stencil + dot products)"] = ("post_smoother", 64.0, 1, it_sys + pre_sys)
         roofs = []
-        it_bytes = it_us = 0.0
-        for kname, (cat, nbytes, per_it) in fams.items():
+        it_bytes = it_us = step_bytes = 0.0
+        nev = max(cnt["evaluations"], 1)
+        for kname, (cat, bpu, per_it, sys_launches) in fams.items():
             ms_c, n_c = prof[cat]
             avg_us = 1e3 * ms_c / max(n_c, 1)
+            act = sys_launches / max(n_c, 1)                       # active systems per launch, averaged over the timed launches
+            nbytes = bpu * Usys * act
             ach = nbytes / (avg_us * 1e-6) / 1e9 if n_c else 0.0
             it_bytes += per_it * nbytes
             it_us += per_it * avg_us
+            step_bytes += bpu * Usys * sys_launches / nev
             entry = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(cat), "avg_launch_us": avg_us,
+                     "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(name, cat), "avg_launch_us": avg_us,
                      "launches_timed": n_c, "launches_per_iteration": per_it, "bytes_per_launch": nbytes,
-                     "ms_timed": ms_c}
+                     "bytes_per_launch_all_systems_active": bpu * U, "active_systems_per_launch": act, "ms_timed": ms_c,
+                     "population": "every launch of this kernel in every 6th evaluation of the timed region (HIP events on "
+                                   "the library's stream), launches that found all systems converged included"}
             if cat in ("tridiagonal", "fdm_transform") and n_c:
                 # the two MFMA kernels, for reference: three bf16 products (hi*hi, hi*lo, lo*hi) of a
                 # [2*S*NZP real rows] x [NYP] x [K = NYP padded to 32] real matrix product
                 kpad = 32 * ((ctx.NYP + 31) // 32)
-                flops = 3 * 2.0 * (2 * ctx.S * ctx.NZP) * ctx.NYP * kpad
+                flops = 3 * 2.0 * (2 * act * ctx.NZP) * ctx.NYP * kpad
                 entry["mfma"] = {"flops_per_launch": flops, "achieved_tflops": flops / (avg_us * 1e-6) / 1e12,
                                  "peak_tflops_bf16_dense": 2500.0}
             roofs.append(entry)
         iteration = {"kernels": len(fams), "bytes": it_bytes, "us": it_us,
                      "achieved": it_bytes / (it_us * 1e-6) / 1e9 if it_us else 0.0, "unit": "GB/s",
                      "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS if it_us else 0.0,
-                     "note": "one preconditioned COCG iteration of all systems = %d launches;" % len(fams) + " the working set "
+                     "note": "one preconditioned COCG iteration of the systems still active = %d launches;" % len(fams) + " the working set "
                              "(~15 vectors) fits the 256 MB Infinity Cache at cfg3, so launches are latency- not HBM-bound"}
-        roofs.sort(key=lambda r: -r["ms_timed"])
-        # The four kernels of an iteration take 10-17 us each and two of them (k_update_fused, k_fdm_fwd, the latter with
-        # one launch more per solve) are within a few per cent of each other in total time, so "the dominant kernel"
-        # would flip from run to run: among kernels within 5 % of the largest total, name the one that moves the most
-        # bytes (the HBM-bound one); the others follow in roofline_other, the whole iteration in roofline_iteration.
-        top = [r for r in roofs if r["ms_timed"] >= 0.95 * roofs[0]["ms_timed"]]
-        if len(top) > 1:
-            lead = max(top, key=lambda r: r["bytes_per_launch"])
-            roofs.remove(lead)
-            roofs.insert(0, lead)
-            lead["note"] = "total time within 5 % of: " + ", ".join(r["kernel"].split(" ")[0] for r in top if r is not lead)
+        ms_step = 1e3 * elapsed / K
+        step = {"bytes_per_step": step_bytes, "ms_per_step": ms_step, "achieved": step_bytes / (ms_step * 1e-3) / 1e9,
+                "unit": "GB/s", "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "algorithmic bytes of the iteration kernels per leapfrog step (sampled evaluations) / wall time per step / 8 TB/s"}
+        roofs.sort(key=lambda r: -r["ms_timed"])             # strict arg-max of the measured total time, no tie-break
         out = {
             "metric": "leapfrog steps/sec (= fwd+grad evals/sec), 200x100 mesh x 16 freq",
             "value": world * K / elapsed, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{name}: {mesh.gridSize[0]}x{mesh.gridSize[1] - len(mesh.airLayer)}-cell mesh "
                                    f"(+{len(mesh.airLayer)} air rows), {len(data.freqs)} freq, TE+TM, "
-                                   f"{data.rxLoc.shape[0]} receivers, 1 independent chain per GPU",
+                                   f"{data.rxLoc.shape[0]} receivers, 1 independent chain per GPU; real leapfrog trajectories "
+                                   f"(L = {LTRAJ}, dt = {DT}, prior lambda = {LAMBDA}, bounds rho in [1, 1e4] ohm-m, accept/reject) "
+                                   f"started at the rough state m = ln 0.01 + 0.3 N(0,1)",
                        "systems_per_step": ctx.S, "unknowns_per_system": nyi * nzi, "nparam": nAC,
                        "solver": "batched fp64 COCG, Jacobi/fast-diagonalisation/Jacobi preconditioner (FDM stage in split-bf16/fp32), tol 1e-11 (error estimate), warm start",
                        "iters_fwd_max": st["iters_fwd_max"], "iters_adj_max": st["iters_adj_max"],
                        "parallelism": f"chains x{world}" if world > 1 else "1 chain"},
-            "roofline": roofs[0], "roofline_other": roofs[1:], "roofline_iteration": iteration,
-            "samples": samples, "structured_state": structured,
-            "check": {"misfit_last": misfit, "grad_l2_last": gnorm, "solver_status": st["status"]},
+            "chain": head,
+            "roofline": roofs[0], "roofline_other": roofs[1:], "roofline_iteration": iteration, "roofline_step": step,
+            "check": check,
         }
+        out.update(extras)
+        if gather is not None:
+            out["allgather"] = gather
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -58,6 +58,11 @@ struct Solver {
     int* nactHost;                        // pinned host copy of *nactive (device address): the convergence polls only synchronise
     double *errEst;                       // [S] (zz/xx)
     double tol2;
+    double* errRef;                       // [S] best error estimate so far / 10-fold improvements (stagnation watch of the mixed-precision solve)
+    int* errRefIt;                        // [S] iteration at which errRef was set
+    int stallIt;                          // iterations allowed per 10-fold drop of the error estimate (STALL_IT; HMCMT_STALL_IT)
+    int* stallHost;                       // pinned host flag: a system has not improved its error estimate 10-fold in STALL_IT iterations
+    unsigned long long* cntActive;        // non-null in an evaluation sampled by hmcmt_profile: += systems still active per iteration
 };
 
 // Sum over the 64 lanes of a wave, the total returned in EVERY lane.  Data-parallel-primitive moves inside the rows
@@ -1419,6 +1424,7 @@ __global__ __launch_bounds__(VBLOCK) void k_pre_c64(Solver k) {
 // the staging barrier (11.0 -> 10.3 us; the same treatment of k_update_fused, which moves twice the bytes and sits
 // at 5 TB/s, changed nothing, and neither did computing its dinv from dK, dM instead of loading it).
 constexpr int SB = 4;                  // elements per thread and batch
+constexpr int STALL_IT = 30;           // mixed-precision stagnation watch: iterations allowed per 10-fold drop of the error estimate
 struct StenCo { double dk, dm, cy0, cy1, cz0, cz1; };
 
 __device__ __forceinline__ int div_small(int i, float rcp) { return (int)(((float)i + 0.5f) * rcp); }   // i / n for i < 2^20, rcp = 1/n
@@ -1468,8 +1474,12 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         k.rho2[(long)(it & 1) * k.S + s] = rz;
         k.iters[s] = it - 1;
-        k.errEst[s] = first ? (zz == 0.0 ? 0.0 : 1.0) : sqrt(zz / xx);
+        const double est = first ? (zz == 0.0 ? 0.0 : 1.0) : sqrt(zz / xx);
+        k.errEst[s] = est;
         if (st) k.status[s] = st;
+        // stagnation watch (the host restarts the stragglers with the fp64 preconditioner when it fires)
+        if (first || est < 0.1 * k.errRef[s]) { k.errRef[s] = est; k.errRefIt[s] = it; }
+        else if (on && it - k.errRefIt[s] > k.stallIt) *k.stallHost = 1;
     }
     if (!on) {
         // every block of this system takes the same decision; block 0 records it (a block that starts late and
@@ -1477,6 +1487,7 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
         if (blockIdx.x == 0 && threadIdx.x == 0) { k.active[s] = 0; if (atomicSub(k.nactive, 1) == 1) *k.nactHost = 0; }
         return;
     }
+    if (k.cntActive && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(k.cntActive, 1ull);   // (roofline accounting only)
     for (int i0 = threadIdx.x; i0 < ntot; i0 += SB * VBLOCK) {
         if (i0 != (int)threadIdx.x) ld_stage(i0);
 #pragma unroll
@@ -2212,6 +2223,8 @@ struct hmcmt_ctx {
     cplx* d_fieldsOut = nullptr;
     // pinned host staging
     int* h_nactive = nullptr;
+    int* h_stall = nullptr;               // pinned, mapped: Solver::stallHost
+    hipEvent_t evPoll2[2] = {nullptr, nullptr};   // convergence polls look one iteration back (see solve())
     double* h_rec = nullptr;              // packed per-solve records: [2][S] iters, [2][S] status (int), [2][S] err (double)
     double* h_stage = nullptr;            // m / grad / pred / misfit staging
     size_t stageDoubles = 0;
@@ -2245,12 +2258,17 @@ struct hmcmt_ctx {
     double profOverheadMs = 0.0;      // event-bracket overhead of one launch (null-kernel calibration)
     double profMs[HMCMT_NCAT] = {0};
     long long profN[HMCMT_NCAT] = {0};
+    unsigned long long* d_cnt = nullptr;   // device counter behind Solver::cntActive
+    long long profStartSys = 0, profEvals = 0, profSolves = 0;   // sampled: systems active at the start of a solve (summed), evaluations, solves
+    int nSysOn = 0;
     // leapfrog / prior
     double *d_mref = nullptr, *d_invM = nullptr, *d_wmVal = nullptr, *d_p = nullptr, *d_mcur = nullptr, *d_g = nullptr;
     long long *d_wmRow = nullptr, *d_wmCol = nullptr;
     double *d_lfPart = nullptr, *d_lfScal = nullptr;
     int* d_lfFlag = nullptr;
-    bool havePrior = false;
+    int* h_lfFlag = nullptr;                 // pinned copy of d_lfFlag (read after a synchronisation)
+    double* d_gStart = nullptr;              // data gradient at the start model of the last trajectory (a rejection restarts there)
+    bool havePrior = false, lfHaveGrad = false, lfFlagPending = false;
     // results of the last two host-API evaluations, keyed by the model: a sampler re-evaluates the model it has
     // just evaluated (getHamiltonian at the proposal, HMCSampler.jl:364; the first gradient of the next trajectory,
     // :217) or, after a rejection, the start model of the trajectory before -- those calls cost a memcmp
@@ -2295,6 +2313,7 @@ struct ProfScope {
     hmcmt_ctx* c; int cat; size_t idx;
     ProfScope(hmcmt_ctx* ctx, int cat_) : c(ctx), cat(cat_), idx((size_t)-1) {
         if (!((c->profMask >> cat) & 1u) || (c->evalCount % c->profEvery) != 0) return;
+        if (c->lpFallback) return;          // the fp64 restart of a straggling solve runs other kernels: not part of the sampled population
         if (c->evUsed + 2 > c->evPool.size()) {
             for (int i = 0; i < 512; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c->evPool.push_back(e); c->evCat.push_back(0); }
         }
@@ -2474,13 +2493,14 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     if (!ctx->solveBegun)           // (otherwise done by the residual kernel in front of this solve)
         hipLaunchKernelGGL(k_solve_begin, dim3((S * MAXNB + 255) / 256), dim3(256), 0, ctx->stream, k, ctx->v.sysOn);
     ctx->solveBegun = false;
+    if (k.cntActive) { ++ctx->profSolves; ctx->profStartSys += ctx->nSysOn; }
     int& guess = kind == 0 ? ctx->lastItFwd : ctx->lastItAdj;
     int nextCheck = guess > 2 ? guess : 4;
     const int every = ctx->opt.check_every > 0 ? ctx->opt.check_every : 2;
     int it = 0;
     bool done = false;
     ctx->lpFallback = false;
-    const int lpCap = 60;               // mixed-precision safety net: stragglers continue with the fp64 preconditioner
+    const int lpCap = 60;               // (classic loop only) mixed-precision safety net: stragglers continue with the fp64 preconditioner
     const dim3 tg((k.ny - 1 + 63) / 64, S);
     const bool fused = ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0;
     cplx* const r_entry = k.r;
@@ -2489,16 +2509,20 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
         cplx* pb[2] = {k.p, k.p2};
         cplx* rb[2] = {k.r, k.r2};
         int rcur = 0;
-        while (!done && it < ctx->opt.maxit + 1 && it < lpCap) {
+        // Convergence polls.  The device keeps the number of active systems (and the stagnation flag) in mapped pinned
+        // memory; k_spmv_fused of iteration `it` updates them with the decision on the state after iteration it-1.  From
+        // the iteration count of the previous call on, the host looks at them once per iteration -- but ONE ITERATION BACK:
+        // it waits for the event behind k_spmv_fused(it-1) after queuing all of iteration `it`, so seven launches (~90 us)
+        // are queued when it wakes up and the device never idles at a poll; when the solve is over the launches queued
+        // behind the deciding one find every system inactive and exit at once (~2 us each).
+        *ctx->h_stall = 0;
+        bool stalled = false;
+        while (!done && !stalled && it < ctx->opt.maxit + 1) {
             ++it;
             // decide convergence of the state after iteration it-1, p = z + beta p, q = A p
             { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv_fused, dim3(k.NTR, S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit); }
-            // Convergence poll: the host waits for THIS launch only (an event), with the rest of the iteration already
-            // queued behind it -- if the solve goes on, the device never idles while the host wakes up; if it is over,
-            // the three queued launches exit at once (all systems inactive, ~10 us) inside the host's wake-up time.
-            const bool poll = it - 1 >= nextCheck || it - 1 == ctx->opt.maxit;
-            if (poll) HIPCHK(hipEventRecord(ctx->evPoll, ctx->stream));
-            const size_t evMark = ctx->evUsed;
+            const bool rec = it >= nextCheck || it - 1 == ctx->opt.maxit;
+            if (rec) HIPCHK(hipEventRecord(ctx->evPoll2[it & 1], ctx->stream));
             { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused, dim3(k.NTR, S), vb, (size_t)(2 * k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it); }
             rcur ^= 1;
             k.r = rb[rcur];
@@ -2506,15 +2530,11 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             if ((prc = launch_fdm_fwd(ctx))) return prc;
             if ((prc = launch_back_post(ctx))) return prc;
             std::swap(k.z, k.t);
-            if (poll) {
-                HIPCHK(hipEventSynchronize(ctx->evPoll));
-                if (*(volatile int*)ctx->h_nactive == 0) {
-                    // the three launches behind the event found every system inactive: not samples of the kernels' timing
-                    for (size_t i = evMark; i + 1 < ctx->evUsed; i += 2) ctx->evCat[i] = -1;
-                    done = true;
-                    break;
-                }
-                nextCheck = it - 1 + every;
+            if (it - 1 >= nextCheck || it - 1 == ctx->opt.maxit) {        // the event of iteration it-1 exists
+                const bool last = it - 1 == ctx->opt.maxit;
+                HIPCHK(hipEventSynchronize(ctx->evPoll2[(last ? it : it - 1) & 1]));
+                if (*(volatile int*)ctx->h_nactive == 0) { done = true; break; }
+                if (*(volatile int*)ctx->h_stall) stalled = true;
             }
             if (kind == 0 && it == 2) launch_adjoint_side(ctx);   // (the queue holds two iterations: the host has time for a dozen calls)
         }
@@ -2621,6 +2641,8 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     ctx->stats = hmcmt_stats{};
     ctx->stats.nsystems = S;
     ++ctx->evalCount;
+    ctx->sv.cntActive = (ctx->profMask && ctx->evalCount % ctx->profEvery == 0) ? ctx->d_cnt : nullptr;
+    if (ctx->sv.cntActive) ++ctx->profEvals;
     const int nodes = v.NZP * (v.ny + 1);
     const size_t vecBytes = (size_t)S * v.vstride * sizeof(cplx);
     // initial guesses (options.warm_start): verify checks against the cold right-hand side
@@ -2818,8 +2840,11 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     for (void* p : ctx->allocs) hipFree(p);
     for (hipEvent_t e : ctx->evPool) hipEventDestroy(e);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
+    if (ctx->h_stall) hipHostFree(ctx->h_stall);
+    for (auto& e : ctx->evPoll2) if (e) hipEventDestroy(e);
     if (ctx->h_rec) hipHostFree(ctx->h_rec);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
+    if (ctx->h_lfFlag) hipHostFree(ctx->h_lfFlag);
     if (ctx->evModel) hipEventDestroy(ctx->evModel);
     if (ctx->evSens) hipEventDestroy(ctx->evSens);
     if (ctx->evExtF) hipEventDestroy(ctx->evExtF);
@@ -2943,7 +2968,8 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     DA(v.sensEu, S * 3 * (size_t)(h.nz + 1)) DA(v.sensEd, S * 3 * (size_t)(h.nz + 1)) DA(v.sensMix, S * 12 * (size_t)h.nz)
     DA(v.sensDz1, S * 3 * (size_t)h.nz) DA(v.sensZ1, S * 3) DA(v.sensDead, S * 3)
     DA(v.qPart, S * h.ny) DA(v.gPart, 2 * (size_t)h.nCell) DA(v.gPartG, 2 * GRAD_NG * (size_t)h.nCell) DA(v.grad, h.nAC)
-    DA(ctx->d_m, h.nAC) DA(ctx->d_misfit, 1)
+    DA(ctx->d_m, h.nAC) DA(ctx->d_misfit, 1) DA(ctx->d_cnt, 1)
+    for (int q : h.sysOn) ctx->nSysOn += q;
     for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], (EXT_NP - 1) * S * VS) DA(ctx->d_mHist[kd], EXT_NP * (size_t)h.nAC) DA(ctx->d_ext[kd], EXT_PART + EXT_NS * EXT_NBLK) }
     Solver& k = ctx->sv;
     k.S = h.S; k.NYP = h.NYP; k.NZP = h.NZP; k.ny = h.ny; k.nz = h.nz; k.nFreq = h.nFreq; k.vstride = v.vstride;
@@ -2967,12 +2993,18 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     k.invp32 = ctx->d_invp32;
     DA(k.partA, S * MAXNB) DA(k.partB, S * MAXNB) DA(ctx->d_partZZ, S * MAXNB)
     DA(ctx->d_partRes, S * MAXNB) DA(ctx->d_partBn, S * MAXNB)
-    DA(k.rho, S) DA(k.alphaBeta, S) DA(k.active, S) DA(k.iters, S) DA(k.status, S) DA(k.nactive, 1) DA(k.errEst, S)
+    DA(k.rho, S) DA(k.alphaBeta, S) DA(k.active, S) DA(k.iters, S) DA(k.status, S) DA(k.nactive, 1) DA(k.errEst, S) DA(k.errRef, S) DA(k.errRefIt, S)
     DA(ctx->d_b, S * VS)
     DA(ctx->d_fieldsOut, (size_t)h.nFreq * (h.ny + 1) * (h.nz + 1))
 #undef DA
     HIPCHK(hipHostMalloc((void**)&ctx->h_nactive, sizeof(int), hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void**)&k.nactHost, ctx->h_nactive, 0));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_stall, sizeof(int), hipHostMallocMapped));
+    *ctx->h_stall = 0;
+    HIPCHK(hipHostGetDevicePointer((void**)&k.stallHost, ctx->h_stall, 0));
+    k.stallIt = STALL_IT;
+    if (const char* es = getenv("HMCMT_STALL_IT")) k.stallIt = std::max(1, atoi(es));   // (tests force the fp64 restart with a short window)
+    for (auto& e : ctx->evPoll2) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void**)&ctx->h_rec, sizeof(double) * 4 * h.S, hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void**)&ctx->d_recHost, ctx->h_rec, 0));
     ctx->stageDoubles = (size_t)h.nAC * 4 + (size_t)h.nData * 2 + 16;
@@ -3050,6 +3082,16 @@ int hmcmt_get_iters(const hmcmt_ctx* ctx, int32_t* iters) {
     return 0;
 }
 
+int hmcmt_profile_counters(hmcmt_ctx* ctx, int64_t* out) {
+    if (!ctx || !out) return HMCMT_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    prof_collect(ctx);
+    unsigned long long c = 0;
+    HIPCHK(hipMemcpy(&c, ctx->d_cnt, sizeof c, hipMemcpyDeviceToHost));
+    out[0] = (int64_t)c; out[1] = ctx->profStartSys; out[2] = ctx->profEvals; out[3] = ctx->profSolves;
+    return 0;
+}
+
 int hmcmt_dims(const hmcmt_ctx* ctx, int32_t* o) {
     if (!ctx || !o) return HMCMT_EINVAL;
     o[0] = ctx->v.NYP; o[1] = ctx->v.NZP; o[2] = ctx->v.S; o[3] = ctx->v.ny; o[4] = ctx->v.nz; o[5] = ctx->v.zid; o[6] = ctx->sv.NB;
@@ -3076,13 +3118,16 @@ int hmcmt_grad_device_async(hmcmt_ctx* ctx, const double* d_m, double* d_pred, d
     return 0;
 }
 
+static int leapfrog_flag(hmcmt_ctx* ctx);
+
 int hmcmt_wait(hmcmt_ctx* ctx) {
     if (!ctx) return HMCMT_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     const int rc = collect_pending(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
-    return rc;
+    const int rf = leapfrog_flag(ctx);
+    return rc ? rc : rf;
 }
 
 int hmcmt_forward_device(hmcmt_ctx* ctx, const double* d_m, double* d_pred, double* d_misfit) {
@@ -3204,6 +3249,9 @@ int hmcmt_profile(hmcmt_ctx* ctx, int32_t enable) {
     }
     ctx->profMask = (unsigned)enable;
     for (int i = 0; i < HMCMT_NCAT; ++i) { ctx->profMs[i] = 0; ctx->profN[i] = 0; }
+    ctx->profStartSys = ctx->profEvals = ctx->profSolves = 0;
+    HIPCHK(hipMemsetAsync(ctx->d_cnt, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -3428,9 +3476,91 @@ int hmcmt_set_prior(hmcmt_ctx* ctx, const double* mref, const int64_t* rowptr, c
         if ((rc = dalloc(ctx, &ctx->d_lfPart, (size_t)LFNB))) return rc;
         if ((rc = dalloc(ctx, &ctx->d_lfScal, (size_t)4))) return rc;
         if ((rc = dalloc(ctx, &ctx->d_lfFlag, (size_t)1))) return rc;
+        if ((rc = dalloc(ctx, &ctx->d_gStart, (size_t)n))) return rc;
+        HIPCHK(hipHostMalloc((void**)&ctx->h_lfFlag, sizeof(int), hipHostMallocDefault));
+        *ctx->h_lfFlag = 0;
     }
+    ctx->lfHaveGrad = false;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->havePrior = true;
+    return 0;
+}
+
+// One trajectory on device vectors d_m, d_p (updated in place).  startGrad: 0 evaluate the gradient at the start
+// model, 1 ctx->d_g holds it (the start model is the end model of the previous trajectory), 2 ctx->d_gStart holds it
+// (the start model is the start model of the previous trajectory: a rejected proposal).  Returns with everything
+// enqueued on the context's stream and the solver status of every evaluation collected.
+static int leapfrog_core(hmcmt_ctx* ctx, double* d_m, double* d_p, double dt, int32_t L, double regParam, double lnSigMin,
+                         double lnSigMax, int startGrad, double* d_pred, double* d_misfit, int* evalsOut) {
+    const int n = ctx->v.nAC;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipMemsetAsync(ctx->d_lfFlag, 0, sizeof(int), st));
+    LfView lf{n, ctx->d_mref, ctx->d_invM, ctx->d_wmVal, ctx->d_wmRow, ctx->d_wmCol, d_m, d_p, ctx->d_g,
+              ctx->d_lfPart, ctx->d_lfScal, ctx->d_lfFlag};
+    const dim3 g1((n + 127) / 128), b1(128);
+    int evals = 0;
+    int rc = 0;
+    if (startGrad == 0) {
+        rc = evaluate(ctx, d_m, true, d_pred, d_misfit, ctx->d_g);
+        if (rc) return rc;
+        if ((rc = collect_stats(ctx, true))) return rc;
+        if ((rc = finish_status(ctx))) return rc;
+    } else if (startGrad == 2) {
+        HIPCHK(hipMemcpyAsync(ctx->d_g, ctx->d_gStart, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+    }
+    if (startGrad != 2) HIPCHK(hipMemcpyAsync(ctx->d_gStart, ctx->d_g, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+    ++evals;                                                 // counted as the reference counts it (hmcprior.nfevals, :217)
+    hipLaunchKernelGGL(k_lf_momentum, g1, b1, 0, st, lf, regParam, 0.5 * dt);
+    for (int k = 1; k <= L; ++k) {
+        hipLaunchKernelGGL(k_lf_dmmax, dim3(LFNB), dim3(256), 0, st, lf, dt);
+        hipLaunchKernelGGL(k_lf_step, g1, b1, 0, st, lf, dt, lnSigMin, lnSigMax);
+        rc = evaluate(ctx, d_m, true, d_pred, d_misfit, ctx->d_g);      // (reports a failure of the step before)
+        if (rc) return rc;
+        // asynchronous, as hmcmt_grad_device_async: the next step's launches overlap this step's gradient tail
+        ctx->statsPending = true;
+        ctx->pendingAdj = true;
+        ++evals;
+        hipLaunchKernelGGL(k_lf_momentum, g1, b1, 0, st, lf, regParam, (k < L ? 1.0 : 0.5) * dt);
+    }
+    if ((rc = collect_pending(ctx))) return rc;
+    hipLaunchKernelGGL(k_lf_mnorm, dim3(LFNB), dim3(256), 0, st, lf, regParam);
+    hipLaunchKernelGGL(k_lf_mnorm_final, dim3(1), dim3(1), 0, st, lf, regParam);
+    HIPCHK(hipMemcpyAsync(ctx->h_lfFlag, ctx->d_lfFlag, sizeof(int), hipMemcpyDeviceToHost, st));
+    ctx->lfFlagPending = true;
+    if (evalsOut) *evalsOut = evals;
+    return 0;
+}
+
+// after a synchronisation: did a trajectory meet a non-finite model value?
+static int leapfrog_flag(hmcmt_ctx* ctx) {
+    if (!ctx->lfFlagPending) return 0;
+    ctx->lfFlagPending = false;
+    if (*(volatile int*)ctx->h_lfFlag) {
+        *ctx->h_lfFlag = 0;
+        ctx->haveFwd = ctx->haveAdj = false;
+        ctx->err = "non-finite model value during the trajectory";
+        return HMCMT_EBREAKDOWN;
+    }
+    return 0;
+}
+
+int hmcmt_leapfrog_device(hmcmt_ctx* ctx, double* d_m, double* d_p, double dt, int32_t L, double regParam,
+                          double lnSigMin, double lnSigMax, int32_t start_grad, double* d_pred, double* d_misfit,
+                          double* d_mnorm, int32_t* nfevals) {
+    if (!ctx || !d_m || !d_p) return HMCMT_EINVAL;
+    if (!ctx->havePrior) { ctx->err = "hmcmt_set_prior has not been called"; return HMCMT_EINVAL; }
+    if (L < 1 || !(dt > 0) || !(lnSigMax > lnSigMin)) { ctx->err = "need L >= 1, dt > 0, lnSigMax > lnSigMin"; return HMCMT_EINVAL; }
+    if (start_grad < 0 || start_grad > 2) { ctx->err = "start_grad must be 0, 1 or 2"; return HMCMT_EINVAL; }
+    if (start_grad != 0 && !ctx->lfHaveGrad) { ctx->err = "start_grad != 0 needs a previous trajectory on this context"; return HMCMT_EINVAL; }
+    HIPCHK(hipSetDevice(ctx->device));
+    int evals = 0;
+    ctx->lfHaveGrad = false;
+    int rc = leapfrog_core(ctx, d_m, d_p, dt, L, regParam, lnSigMin, lnSigMax, start_grad, d_pred, d_misfit, &evals);
+    if (rc) return rc;
+    if (d_mnorm) HIPCHK(hipMemcpyAsync(d_mnorm, ctx->d_lfScal, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipGetLastError());
+    ctx->lfHaveGrad = true;
+    if (nfevals) *nfevals = evals;
     return 0;
 }
 
@@ -3449,51 +3579,29 @@ int hmcmt_leapfrog(hmcmt_ctx* ctx, const double* m0, const double* p0, double dt
     std::memcpy(ctx->h_stage + n, p0, sizeof(double) * n);
     HIPCHK(hipMemcpyAsync(ctx->d_mcur, ctx->h_stage, sizeof(double) * n, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->d_p, ctx->h_stage + n, sizeof(double) * n, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(ctx->d_lfFlag, 0, sizeof(int), st));
-    LfView lf{n, ctx->d_mref, ctx->d_invM, ctx->d_wmVal, ctx->d_wmRow, ctx->d_wmCol, ctx->d_mcur, ctx->d_p, ctx->d_g,
-              ctx->d_lfPart, ctx->d_lfScal, ctx->d_lfFlag};
-    const dim3 g1((n + 127) / 128), b1(128);
-    int evals = 0;
-    int rc = 0;
+    int evals = 0, startGrad = 0;
     if (const hmcmt_ctx::Memo* e = ctx->opt.verify ? nullptr : memo_find(ctx, m0, true)) {
         // the gradient at the start model is known (end of the previous trajectory, or its start after a rejection)
         std::memcpy(ctx->h_stage + 2 * n, e->grad.data(), sizeof(double) * n);
         HIPCHK(hipMemcpyAsync(ctx->d_g, ctx->h_stage + 2 * n, sizeof(double) * n, hipMemcpyHostToDevice, st));
         ++ctx->memoHits;
-    } else {
-        rc = evaluate(ctx, ctx->d_mcur, true, nullptr, nullptr, ctx->d_g);
-        if (rc) return rc;
-        if ((rc = collect_stats(ctx, true))) return rc;
-        if ((rc = finish_status(ctx))) return rc;
+        startGrad = 1;
     }
-    ++evals;                                                 // counted as the reference counts it (hmcprior.nfevals, :217)
-    hipLaunchKernelGGL(k_lf_momentum, g1, b1, 0, st, lf, regParam, 0.5 * dt);
-    for (int k = 1; k <= L; ++k) {
-        hipLaunchKernelGGL(k_lf_dmmax, dim3(LFNB), dim3(256), 0, st, lf, dt);
-        hipLaunchKernelGGL(k_lf_step, g1, b1, 0, st, lf, dt, lnSigMin, lnSigMax);
-        rc = evaluate(ctx, ctx->d_mcur, true, nullptr, nullptr, ctx->d_g);      // (reports a failure of the step before)
-        if (rc) return rc;
-        // asynchronous, as hmcmt_grad_device_async: the next step's launches overlap this step's gradient tail
-        ctx->statsPending = true;
-        ctx->pendingAdj = true;
-        ++evals;
-        hipLaunchKernelGGL(k_lf_momentum, g1, b1, 0, st, lf, regParam, (k < L ? 1.0 : 0.5) * dt);
-    }
-    if ((rc = collect_pending(ctx))) return rc;
-    hipLaunchKernelGGL(k_lf_mnorm, dim3(LFNB), dim3(256), 0, st, lf, regParam);
-    hipLaunchKernelGGL(k_lf_mnorm_final, dim3(1), dim3(1), 0, st, lf, regParam);
+    ctx->lfHaveGrad = false;
+    int rc = leapfrog_core(ctx, ctx->d_mcur, ctx->d_p, dt, L, regParam, lnSigMin, lnSigMax, startGrad, nullptr, nullptr, &evals);
+    if (rc) return rc;
     double* hs = ctx->h_stage;
     HIPCHK(hipMemcpyAsync(hs, ctx->d_mcur, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(hs + n, ctx->d_p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(hs + 2 * n, ctx->v.pred, sizeof(cplx) * nData, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(hs + 2 * n + 2 * nData, ctx->d_misfit, sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(hs + 2 * n + 2 * nData + 1, ctx->d_lfScal, sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(ctx->h_nactive, ctx->d_lfFlag, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(hs + 2 * n + 2 * nData + 2, ctx->d_g, sizeof(double) * n, hipMemcpyDeviceToHost, st));   // for the memo
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     prof_collect(ctx);
-    if (*ctx->h_nactive) { ctx->err = "non-finite model value during the trajectory"; return HMCMT_EBREAKDOWN; }
+    if ((rc = leapfrog_flag(ctx))) return rc;
+    ctx->lfHaveGrad = true;
     memo_store(ctx, hs, hs + 2 * n, hs[2 * n + 2 * nData], hs + 2 * n + 2 * nData + 2);   // the end model's data gradient
     std::memcpy(m1, hs, sizeof(double) * n);
     std::memcpy(p1, hs + n, sizeof(double) * n);

@@ -94,10 +94,13 @@ def load_library():
     lib.hmcmt_leapfrog.argtypes = [vp, c_double_p, c_double_p, C.c_double, C.c_int32, C.c_double, C.c_double,
                                    C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                    C.POINTER(C.c_int32)]
+    lib.hmcmt_leapfrog_device.argtypes = [vp, vp, vp, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32,
+                                          vp, vp, vp, C.POINTER(C.c_int32)]
     lib.hmcmt_get_fields.argtypes = [vp, C.c_int32, c_double_p, c_double_p]
     lib.hmcmt_profile.argtypes = [vp, C.c_int32]
     lib.hmcmt_profile_every.argtypes = [vp, C.c_int32]
     lib.hmcmt_profile_read.argtypes = [vp, c_double_p, c_int64_p]
+    lib.hmcmt_profile_counters.argtypes = [vp, c_int64_p]
     lib.hmcmt_dims.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.hmcmt_debug_transform.argtypes = [vp, C.c_int32, c_double_p, c_double_p]
     lib.hmcmt_debug_spmv.argtypes = [vp, c_double_p, c_double_p]
@@ -106,7 +109,7 @@ def load_library():
     lib.hmcmt_debug_back_post.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_double_p]
     for name in ("hmcmt_create", "hmcmt_destroy", "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters",
                  "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async",
-                 "hmcmt_wait", "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read",
+                 "hmcmt_wait", "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters",
                  "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond",
                  "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post"):
         getattr(lib, name).restype = C.c_int
@@ -117,7 +120,7 @@ def load_library():
 EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "hmcmt_last_error",
                     "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters", "hmcmt_grad", "hmcmt_forward",
                     "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async", "hmcmt_wait",
-                    "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_dims",
+                    "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_dims",
                     "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
                     "hmcmt_debug_back_post"]
 
@@ -250,6 +253,15 @@ class HipContext:
                                             C.byref(nf)))
         return m1, p1, pred, mis.value, mnorm.value, nf.value
 
+    def leapfrog_device(self, d_m, d_p, dt, L, regParam, lnSigMin, lnSigMax, start_grad=0, d_pred=None, d_misfit=None,
+                        d_mnorm=None):
+        """hmcmt_leapfrog_device: raw device pointers (ints); d_m, d_p are updated in place; finish with wait().
+        start_grad: 0 evaluate / 1 start = end model of the previous trajectory / 2 start = its start model."""
+        nf = C.c_int32()
+        self._check(self.lib.hmcmt_leapfrog_device(self.h, d_m, d_p, dt, L, regParam, lnSigMin, lnSigMax, start_grad,
+                                                   d_pred, d_misfit, d_mnorm, C.byref(nf)))
+        return nf.value
+
     # -- instrumentation ----------------------------------------------------------------------
     def profile(self, enable=True, every=1):
         """enable: True (all categories), False, or an iterable of category names to time;
@@ -268,6 +280,12 @@ class HipContext:
         n = np.zeros(HMCMT_NCAT, dtype=np.int64)
         self._check(self.lib.hmcmt_profile_read(self.h, _dp(ms), n.ctypes.data_as(c_int64_p)))
         return {c: (float(ms[i]), int(n[i])) for i, c in enumerate(CATEGORIES)}
+
+    def profile_counters(self):
+        """{active_iter_systems, start_systems, evaluations, solves} of the sampled evaluations (hmcmt_profile_counters)."""
+        o = np.zeros(4, dtype=np.int64)
+        self._check(self.lib.hmcmt_profile_counters(self.h, o.ctypes.data_as(c_int64_p)))
+        return dict(zip(("active_iter_systems", "start_systems", "evaluations", "solves"), (int(x) for x in o)))
 
     def _vec(self, a):
         a = np.ascontiguousarray(a, dtype=np.complex128)

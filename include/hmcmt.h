@@ -144,6 +144,20 @@ int hmcmt_leapfrog(hmcmt_ctx* ctx, const double* m0, const double* p0, double dt
                    double* m1, double* p1, double* pred, double* misfit, double* mnorm,
                    int32_t* nfevals);
 
+/* The same trajectory on DEVICE vectors: d_m, d_p [nAC] are updated in place (start model / momentum -> proposal), nothing
+ * crosses PCIe.  start_grad says where the data gradient at the start model comes from:
+ *   0  evaluate it (first trajectory of a chain, or a start model the context has not seen);
+ *   1  the start model is the END model of the previous trajectory on this context (the proposal was accepted,
+ *      HMCSampler.jl:155-163): its gradient is still on the device -- L new evaluations instead of L + 1;
+ *   2  the start model is the START model of the previous trajectory (the proposal was rejected, :164-168).
+ * d_pred complex[nData], d_misfit, d_mnorm (device, each may be NULL) receive the proposal's predicted data, data
+ * misfit and 0.5*lambda*(m-mref)'Wm(m-mref).  Returns when the trajectory is ENQUEUED and the solver status of all its
+ * evaluations but the last has been checked; hmcmt_wait completes it (and reports the last evaluation's status and a
+ * non-finite model met on the way).  nfevals counts as the reference does (L + 1). */
+int hmcmt_leapfrog_device(hmcmt_ctx* ctx, double* d_m, double* d_p, double dt, int32_t L, double regParam,
+                          double lnSigMin, double lnSigMax, int32_t start_grad, double* d_pred, double* d_misfit,
+                          double* d_mnorm, int32_t* nfevals);
+
 /* Solution fields of the last evaluation THAT RAN (a call answered from the stored results runs nothing) in the
  * reference's layout: complex[(ny+1)*(nz+1)*nFreq],
  * node index (iz*(ny+1)+iy) fastest, then frequency (MT2DFwdSolver.jl:111-112).  adjoint=1 returns
@@ -157,6 +171,12 @@ int hmcmt_get_fields(hmcmt_ctx* ctx, int32_t adjoint, double* exTE, double* hxTM
 int hmcmt_profile(hmcmt_ctx* ctx, int32_t category_mask);     /* bit c enables category c; 0 = off; resets the counters */
 int hmcmt_profile_every(hmcmt_ctx* ctx, int32_t n);           /* time only every n-th evaluation (event brackets cost ~20 % when always on) */
 int hmcmt_profile_read(hmcmt_ctx* ctx, double* ms /*[HMCMT_NCAT]*/, int64_t* launches /*[HMCMT_NCAT]*/);
+
+/* What the sampled launches worked on (roofline numerators): out[0] = sum over the sampled iterations of the number of
+ * systems still active (device counter, incremented by k_spmv_fused), out[1] = sum over the sampled solves of the systems
+ * active at their start (the preconditioner is applied once before the first iteration), out[2] = evaluations sampled,
+ * out[3] = solves sampled.  Reset by hmcmt_profile. */
+int hmcmt_profile_counters(hmcmt_ctx* ctx, int64_t* out /*[4]*/);
 
 /* sizes the roofline accounting needs: out = {NYP, NZP, S, ny, nz, zid, nblk} */
 int hmcmt_dims(const hmcmt_ctx* ctx, int32_t* out);

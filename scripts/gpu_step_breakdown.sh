@@ -1,0 +1,37 @@
+#!/bin/bash
+# Where a leapfrog step of a REAL chain goes (kernel trace of scripts/gpu_chain_traj.py): for the steady-state
+# evaluations, wall time per evaluation, main-queue busy time by kernel, idle time and the gaps > GAP_MIN us.
+# usage: gpu_step_breakdown.sh [true|rough]
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/sb
+rocprofv3 --kernel-trace --output-format csv -d /tmp/sb -- python3 $R/scripts/gpu_chain_traj.py ${1:-true} > /tmp/sb.log 2>&1
+tail -3 /tmp/sb.log
+python3 - <<'PY'
+import csv, glob, os, collections
+rows = list(csv.DictReader(open(glob.glob('/tmp/sb/*/*kernel_trace.csv')[0])))
+ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('(anonymous namespace)::','').replace('void ','').split('(')[0].split('<')[0], r['Queue_Id']) for r in rows)
+starts = [i for i, k in enumerate(ks) if k[2] == 'k_sigma']
+gmin = float(os.environ.get("GAP_MIN", "8"))
+n = len(starts)
+evs = range(n - 30, n - 6)            # steady-state evaluations of the last trajectories
+tot = collections.Counter(); cnt = collections.Counter(); wall = busy = 0.0; gaps = collections.Counter(); side = collections.Counter()
+for ev in evs:
+    a, b = starts[ev], starts[ev + 1]
+    seg = ks[a:b]
+    mainq = collections.Counter(k[3] for k in seg).most_common(1)[0][0]
+    m = [k for k in seg if k[3] == mainq]
+    wall += (ks[b][0] - m[0][0]) / 1e3
+    for s, e, nm, q in seg:
+        if q == mainq: tot[nm] += (e - s) / 1e3; cnt[nm] += 1; busy += (e - s) / 1e3
+        else: side[nm] += (e - s) / 1e3
+    for (s0, e0, n0, _), (s1, e1, n1, _) in zip(m[:-1], m[1:] ):
+        g = (s1 - e0) / 1e3
+        if g > gmin: gaps[f"{n0} -> {n1}"] += g
+ne = len(list(evs))
+print(f"per evaluation (mean of {ne}): wall {wall/ne:.1f} us, main-queue kernels {busy/ne:.1f} us, idle {(wall-busy)/ne:.1f} us")
+for nm, t in tot.most_common(): print(f"   main {nm:28s} {t/ne:8.1f} us/eval  {cnt[nm]/ne:6.1f} launches  avg {t/cnt[nm]:6.1f} us")
+for nm, t in side.most_common(8): print(f"   side {nm:28s} {t/ne:8.1f} us/eval")
+print(f"gaps > {gmin} us (us per evaluation):")
+for nm, t in gaps.most_common(12): print(f"   {t/ne:7.1f}  {nm}")
+PY

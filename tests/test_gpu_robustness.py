@@ -24,29 +24,34 @@ def _models(n, ny=50):
     return out
 
 
-@pytest.mark.parametrize("case", ["std1.0", "std1.5", "block at the bounds"])
-def test_rough_models_and_models_at_the_bounds(case):
+@pytest.mark.parametrize("case", ["std1.0", "std1.5", "std1.5 forced restart", "block at the bounds"])
+def test_rough_models_and_models_at_the_bounds(case, monkeypatch):
     """cfg2 with ln(sigma) ~ N(ln 0.01, 1.0 / 1.5) clipped to the bounds, and a 1 Ohm-m block in a 1e4 Ohm-m host (every
-    cell AT a bound, contrast 1e4): the solves converge (true residual < 1e-9), predicted data agree with the oracle,
-    and beyond 60 mixed-precision iterations the stragglers are restarted with the fp64 preconditioner
-    (hmcmt_stats.fallback_solves).  Gradient bar: on white-noise models this rough the reference formula's own
+    cell AT a bound, contrast 1e4): the solves converge (true residual < 1e-9) and predicted data agree with the oracle.
+    The mixed-precision solve is watched for stagnation (no 10-fold drop of the error estimate within 30 iterations):
+    its stragglers are then restarted with the fp64 preconditioner (hmcmt_stats.fallback_solves) -- the block model
+    does that by itself (TM needs 200+ iterations), "forced restart" shortens the window to 3 iterations
+    (HMCMT_STALL_IT) so that the restart path also runs on a model that does not need it.  Gradient bar: on white-noise models this rough the reference formula's own
     gradient moves by up to 1e-3 of max|g| under a 1e-14 relative perturbation of the model (its 1-D boundary
     sensitivities) -- the bar is 1e-8 + 10 x that self-noise, measured here with the oracle; on the
     block model the formula is well conditioned and the plain 1e-8 holds."""
     mesh, data, inv, m = make_problem("cfg2")
-    mm = _models(m.size)[case]
+    mm = _models(m.size)[case.split(" forced")[0]]
+    if "forced" in case:
+        monkeypatch.setenv("HMCMT_STALL_IT", "3")
     ctx = HipContext(mesh, data, inv, verify=True)
     pred, misfit, grad = ctx.grad(mm)
     st = ctx.stats()
     assert st["status"] == 0 and st["true_res_max"] < 1e-9, st
-    if case == "std1.0":
-        assert st["iters_fwd_max"] < 60 and st["fallback_solves"] == 0
+    if case in ("std1.0", "std1.5"):
+        assert st["iters_fwd_max"] < (60 if case == "std1.0" else 120) and st["fallback_solves"] == 0
     else:
-        assert st["iters_fwd_max"] > 60 and st["fallback_solves"] == 2, st       # the fp64 restart ran in both solves
+        assert st["fallback_solves"] == 2, st                                     # the fp64 restart ran in both solves
     po, mo, go = oracle_eval(mesh, data, inv, mm)
     assert relmax(pred, po) < 1e-8 and abs(misfit - mo) / mo < 1e-8
     noise = (0.0, 0.0)
     if case != "block at the bounds":
+        monkeypatch.delenv("HMCMT_STALL_IT", raising=False)
         for eps in (1e-14, -1e-14, 1e-13):
             _, _, g1 = oracle_eval(mesh, data, inv, mm * (1 + eps))
             noise = tuple(max(a, b) for a, b in zip(noise, gerr_split(g1, go, inv, mesh)))
