@@ -128,12 +128,14 @@ class Chain:
         self.p = torch.zeros(n, dtype=torch.float64, device=dev)
         self.d_pred = torch.zeros(2 * ctx.nData, dtype=torch.float64, device=dev)
         self.scal = torch.zeros(2, dtype=torch.float64, device=dev)          # [misfit, mnorm] of the proposal
+        self.ham = torch.zeros(4, dtype=torch.float64, device=dev)           # [K0, K1, D1, M1] read back together
         self.lo, self.hi = float(np.log(1.0 / RHO_BOUNDS[1])), float(np.log(1.0 / RHO_BOUNDS[0]))
         ctx.set_prior(mref, Wm, np.ones(n))
         # Hamiltonian terms at the start model (getHamiltonian, :358-397)
         d = m_start - mref
         self.M0 = 0.5 * LAMBDA * float(d @ (Wm @ d))
-        self.D0 = None
+        ctx.forward_device(self.m_cur.data_ptr(), self.d_pred.data_ptr(), self.scal.data_ptr())
+        self.D0 = float(self.scal[0].item())
         self.start_grad = 0
         self.accepted = self.rejected = self.failed = 0
         self.last_error = None
@@ -144,9 +146,9 @@ class Chain:
         torch, ctx = self.torch, self.ctx
         t_begin = time.perf_counter()
         self.p.normal_(generator=self.gen).clamp_(-2.5, 2.5)
-        K0 = 0.5 * float((self.p * self.p).sum().item())                     # (also orders torch's stream before the library's)
+        self.ham[0] = 0.5 * (self.p * self.p).sum()                          # kinetic energy at the start (stays on the device)
         self.m_prop.copy_(self.m_cur)
-        torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream().synchronize()                            # torch's stream before the library's
         try:
             ctx.leapfrog_device(self.m_prop.data_ptr(), self.p.data_ptr(), DT, L, LAMBDA, self.lo, self.hi, self.start_grad,
                                 self.d_pred.data_ptr(), self.scal.data_ptr(), self.scal.data_ptr() + 8)
@@ -160,14 +162,10 @@ class Chain:
         st = ctx.stats()
         self.iters.append((st["iters_fwd_max"], st["iters_adj_max"], st["fallback_solves"]))
         self.ms_per_step.append(1e3 * (time.perf_counter() - t_begin) / L)
-        D1, M1 = (float(x) for x in self.scal.tolist())
-        K1 = 0.5 * float((self.p * self.p).sum().item())
-        if self.D0 is None:                                                   # first trajectory: the start model's misfit is not
-            self.D0 = D1 + 1.0                                                # known on the host; accept (burn-in start)
-            h0 = float("inf")
-        else:
-            h0 = self.D0 + self.M0 + K0
-        hdif = h0 - (D1 + M1 + K1)
+        self.ham[1] = 0.5 * (self.p * self.p).sum()
+        self.ham[2:4] = self.scal
+        K0, K1, D1, M1 = self.ham.tolist()                                    # the trajectory's one read-back
+        hdif = self.D0 + self.M0 + K0 - (D1 + M1 + K1)
         if hdif > 0 or self.host_rng.random() < np.exp(hdif):
             self.m_cur, self.m_prop = self.m_prop, self.m_cur
             self.D0, self.M0 = D1, M1
@@ -303,7 +301,8 @@ def main():
         Ke = min(K, 48)
         # (ii) the same sampler started at the true model
         c2 = Chain(ctx, torch, dev, m_true, mref, inv.Wm, seed=7)
-        c2.run(max(W, LTRAJ)); c2.iters.clear(); a0, r0 = c2.accepted, c2.rejected
+        c2.run(max(W, 2 * LTRAJ)); c2.iters.clear(); a0, r0 = c2.accepted, c2.rejected     # (two trajectories: the first one starts from
+        #  the headline chain's fields and iteration counts, a transient of the context's history, not of this state)
         t2 = timed(torch, None, lambda: c2.run(Ke))
         s2 = c2.summary(); s2["accepted"] -= a0; s2["rejected"] -= r0
         extras["near_true_state"] = dict(s2, steps_per_s=Ke / t2, steps=Ke,

@@ -2536,7 +2536,9 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
                 if (*(volatile int*)ctx->h_nactive == 0) { done = true; break; }
                 if (*(volatile int*)ctx->h_stall) stalled = true;
             }
-            if (kind == 0 && it == 2) launch_adjoint_side(ctx);   // (the queue holds two iterations: the host has time for a dozen calls)
+            // (a dozen API calls, ~150 us of host time: issued once the queue is five iterations deep -- at two the main
+            // queue ran dry for 86 us of every evaluation)
+            if (kind == 0 && it == 5) launch_adjoint_side(ctx);
         }
         if (!done) {
             // stragglers (or the iteration cap): read the counter once more, then hand over to the classic loop

@@ -35,3 +35,20 @@ for nm, t in side.most_common(8): print(f"   side {nm:28s} {t/ne:8.1f} us/eval")
 print(f"gaps > {gmin} us (us per evaluation):")
 for nm, t in gaps.most_common(12): print(f"   {t/ne:7.1f}  {nm}")
 PY
+python3 - <<'PY'
+import csv, glob, collections
+rows = list(csv.DictReader(open(glob.glob('/tmp/sb/*/*kernel_trace.csv')[0])))
+ks = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('(anonymous namespace)::','').replace('void ','').split('(')[0].split('<')[0], r['Queue_Id']) for r in rows)
+starts = [i for i, k in enumerate(ks) if k[2] == 'k_sigma']
+ev = len(starts) - 12
+a, b = starts[ev], starts[ev + 1]
+seg = ks[a:b]
+mainq = collections.Counter(k[3] for k in seg).most_common(1)[0][0]
+m = [k for k in seg if k[3] == mainq]
+t0 = m[0][0]; nit = 0
+print("one evaluation: gaps > 5 us on the main queue (time since k_sigma, iteration count so far)")
+for (s0, e0, n0, _), (s1, e1, n1, _) in zip(m[:-1], m[1:]):
+    if n0 == 'k_spmv_fused': nit += 1
+    g = (s1 - e0) / 1e3
+    if g > 5: print(f"   {(e0 - t0)/1e3:8.1f} us  gap {g:6.1f} us  after {nit:3d} spmv launches  {n0} -> {n1}")
+PY
