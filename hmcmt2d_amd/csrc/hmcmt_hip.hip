@@ -2908,7 +2908,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     UP(yLen, h.yLen) UP(zLen, h.zLen) UP(omega, h.omega) UP(lam, h.lam) UP(sysOn, h.sysOn)
     UP(cell2act, h.cell2act) UP(bg, h.bg) UP(act, h.act)
     UP(rxIdn, h.rxIdn) UP(rxDy1, h.rxDy1) UP(rxDy2, h.rxDy2) UP(rxKL, h.rxKL) UP(rxKR, h.rxKR) UP(rxWL, h.rxWL) UP(rxWR, h.rxWR)
-    UP(predSys, h.predSys) UP(predRx, h.predRx) UP(datSys, h.datSys) UP(datRx, h.datRx)
+    UP(predSys, h.predSys) UP(predRx, h.predRx) UP(datSys, h.datSys) UP(datRx, h.datRx) UP(predKind, h.predKind) UP(datKind, h.datKind)
     UP(obs, h.obs) UP(dataW, h.dataW) UP(srStart, h.srStart) UP(srList, h.srList)
 #undef UP
     {

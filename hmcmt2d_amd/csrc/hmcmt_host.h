@@ -13,10 +13,10 @@ namespace hmcmt {
 
 struct HostProblem {
     int ny = 0, nz = 0, NYP = 0, NZP = 0, nFreq = 0, S = 0, nRx = 0, nData = 0, nAC = 0, nCell = 0, zid = 0;
-    bool compTE = false, compTM = false;
+    bool compTE = false, compTM = false, rhoPhase = false;
     std::vector<double> yLen, zLen, omega, lam, Vpad, Vtpad, bg, dataW;
     std::vector<double> rxDy1, rxDy2, rxWL, rxWR;
-    std::vector<int> cell2act, act, rxIdn, rxKL, rxKR, predSys, predRx, datSys, datRx, srStart, srList, sysOn;
+    std::vector<int> cell2act, act, rxIdn, rxKL, rxKR, predSys, predRx, predKind, datSys, datRx, datKind, srStart, srList, sysOn;
     std::vector<cplx> obs;
     std::string error;
 
@@ -147,26 +147,37 @@ struct HostProblem {
             linearInterp(rxY[r], yNode, rxKL[r], rxKR[r], rxWL[r], rxWR[r]);
         }
         // modes
-        std::vector<int> cmode(nComp);
+        // component codes: 1 ZXY, 2 ZYX (DataType Impedance, complex data); 3 RhoXY, 4 PhsXY, 5 RhoYX, 6 PhsYX
+        // (DataType Rho_Pha, real data: apparent resistivity |Z|^2/(w mu0) and phase in degrees, mt2DTE.jl:253-255)
+        std::vector<int> cmode(nComp), ckind(nComp);
+        bool anyZ = false, anyRP = false;
         for (int c = 0; c < nComp; ++c) {
-            cmode[c] = (int)compMode[c];
-            if (cmode[c] == 1) compTE = true; else if (cmode[c] == 2) compTM = true;
-            else { error = "compMode must be 1 (XY/TE) or 2 (YX/TM)"; return false; }
+            const int code = (int)compMode[c];
+            if (code < 1 || code > 6) { error = "compMode must be 1 ZXY, 2 ZYX, 3 RhoXY, 4 PhsXY, 5 RhoYX or 6 PhsYX"; return false; }
+            cmode[c] = (code == 1 || code == 3 || code == 4) ? 1 : 2;
+            ckind[c] = code <= 2 ? 0 : ((code == 3 || code == 5) ? 1 : 2);
+            if (code <= 2) anyZ = true; else anyRP = true;
+            if (cmode[c] == 1) compTE = true; else compTM = true;
         }
-        // full response table per (freq, rx): [TE][TM] for the modes present (MT2DFwdSolver.jl:175-189)
-        const int per = (compTE ? 1 : 0) + (compTM ? 1 : 0);
+        if (anyZ && anyRP) { error = "impedance and rho/phase components cannot be mixed in one data set"; return false; }
+        rhoPhase = anyRP;
+        // full response table per (freq, rx): Impedance [Z_TE][Z_TM], Rho_Pha [rho_TE, phs_TE][rho_TM, phs_TM], for the
+        // modes present (MT2DFwdSolver.jl:175-205)
+        const int per = ((compTE ? 1 : 0) + (compTM ? 1 : 0)) * (rhoPhase ? 2 : 1);
         const int64_t nMask = (int64_t)nComp * nRx * nFreq;
         if ((int64_t)per * nRx * nFreq != nMask) { error = "dataID length does not match the response table"; return false; }
-        predSys.clear(); predRx.clear();
+        predSys.clear(); predRx.clear(); predKind.clear();
         for (int64_t q = 0; q < nMask; ++q) {
             if (!dataID[q]) continue;
             int c = (int)(q % per), r = (int)((q / per) % nRx), f = (int)(q / ((int64_t)per * nRx));
-            bool tm = compTE ? (c == 1) : true;
+            const int cm = rhoPhase ? c / 2 : c;                       // which of the modes present
+            bool tm = compTE ? (cm == 1) : true;
             predSys.push_back((tm ? nFreq : 0) + f);
             predRx.push_back(r);
+            predKind.push_back(rhoPhase ? 1 + (c & 1) : 0);
         }
         if ((int)predSys.size() != nData) { error = "dataID selects a different number of entries than nData"; return false; }
-        datSys.resize(nData); datRx.resize(nData);
+        datSys.resize(nData); datRx.resize(nData); datKind.resize(nData);
         obs.resize(nData); dataW.assign(dataW_, dataW_ + nData);
         std::vector<std::vector<int>> lists((size_t)S * nRx);
         for (int p = 0; p < nData; ++p) {
@@ -174,6 +185,7 @@ struct HostProblem {
             if (f < 0 || f >= nFreq || r < 0 || r >= nRx || c < 0 || c >= nComp) { error = "data index out of range"; return false; }
             datSys[p] = (cmode[c] == 2 ? nFreq : 0) + f;
             datRx[p] = r;
+            datKind[p] = ckind[c];
             obs[p] = cplx{obs_[2 * p], obs_[2 * p + 1]};
             lists[(size_t)datSys[p] * nRx + r].push_back(p);
         }

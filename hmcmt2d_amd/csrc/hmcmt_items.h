@@ -66,6 +66,8 @@ struct View {
     const int* predRx;             // [nData] receiver of it
     const int* datSys;             // [nData] system addressed by (freqID, dtID) of datum p
     const int* datRx;              // [nData] rxID-1
+    const int* predKind;           // [nData] what the p-th masked table entry is: 0 impedance, 1 apparent resistivity, 2 phase (degrees)
+    const int* datKind;            // [nData] the same for the component dtID of datum p addresses
     const cplx* obs;               // [nData]
     const double* dataW;           // [nData]
     cplx* pred;                    // [nData]
@@ -326,12 +328,30 @@ HD void item_rx(const View& v, int s, int r, bool wantDeriv) {
 }
 
 // --- residual, misfit terms and conj(W'W r) per datum (HMCSampler.jl:298-304, compJacTMatVec.jl:160)
+//     DataType Rho_Pha: the data are rho_a = |Z|^2/(w mu0) and phi = atan2(Im Z, Re Z) in degrees (compMTRespTE,
+//     mt2DTE.jl:253-255; compMTRespTM, mt2DTM.jl:236-238), real.  Their sensitivities are the impedance's times
+//     2 conj(Z)/(w mu0) and -i (180/pi) conj(Z)/|Z|^2 (dataFuncSens.jl:137-141, :307-311); the residual weights being
+//     real, the whole adjoint machinery stays the impedance one with vbar = weight x that factor.
 HD void item_resid(const View& v, int p) {
-    cplx z = v.Zrx[(long)v.predSys[p] * v.nRx + v.predRx[p]];
-    v.pred[p] = z;
-    cplx res = v.dataW[p] * (z - v.obs[p]);
+    const int sp = v.predSys[p];
+    const cplx z = v.Zrx[(long)sp * v.nRx + v.predRx[p]];
+    const int kind = v.predKind[p];
+    cplx val = z;
+    if (kind == 1) val = cplx{cabs2(z) / (v.omega[sp] * MU0), 0.0};
+    else if (kind == 2) val = cplx{atan2(z.im, z.re) * (180.0 / 3.14159265358979323846), 0.0};
+    v.pred[p] = val;
+    const cplx res = v.dataW[p] * (val - v.obs[p]);
     v.misfitPart[p] = 0.5 * cabs2(res);
-    v.vbar[p] = conj(v.dataW[p] * res);
+    const cplx wr = v.dataW[p] * res;
+    const int dk = v.datKind[p];
+    if (dk == 0) { v.vbar[p] = conj(wr); return; }
+    const int sd = v.datSys[p];
+    const cplx zs = v.Zrx[(long)sd * v.nRx + v.datRx[p]];
+    if (dk == 1) v.vbar[p] = (wr.re * 2.0 / (v.omega[sd] * MU0)) * conj(zs);
+    else {
+        const cplx c = conj(zs);                                   // -i conj(Z) = (Im conj Z, -Re conj Z)
+        v.vbar[p] = (wr.re * (180.0 / 3.14159265358979323846) / cabs2(zs)) * cplx{c.im, -c.re};
+    }
 }
 
 // --- per (s, rx): sum of vbar over the data addressing that receiver of that system

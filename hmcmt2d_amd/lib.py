@@ -197,7 +197,7 @@ class HipContext:
         grad = np.empty(self.nAC)
         mis = C.c_double()
         self._check(self.lib.hmcmt_grad(self.h, _dp(m), _dp(pred), C.byref(mis), _dp(grad)))
-        return pred, mis.value, grad
+        return (pred.real.copy() if self.args.real_data else pred), mis.value, grad
 
     def forward(self, m):
         """MT2DFwdSolver + compDataMisfit: m -> (predData, dataMisfit)."""
@@ -207,7 +207,7 @@ class HipContext:
         pred = np.empty(self.nData, dtype=np.complex128)
         mis = C.c_double()
         self._check(self.lib.hmcmt_forward(self.h, _dp(m), _dp(pred), C.byref(mis)))
-        return pred, mis.value
+        return (pred.real.copy() if self.args.real_data else pred), mis.value
 
     def grad_device(self, d_m, d_pred, d_misfit, d_grad):
         """Raw device pointers (ints), e.g. torch tensors' data_ptr()."""

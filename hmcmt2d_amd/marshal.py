@@ -22,17 +22,22 @@ def _i64(a):
     return np.ascontiguousarray(a, dtype=np.int64)
 
 
-def comp_modes(dataComp):
-    """1 for a component containing "XY" (TE), 2 for "YX" (TM) -- the substring test the
-    reference uses (readMT2DData.jl:150-161, compJacTMatVec.jl:166-177)."""
+COMPONENT_CODES = {"ZXY": 1, "ZYX": 2, "RhoXY": 3, "PhsXY": 4, "RhoYX": 5, "PhsYX": 6}
+
+
+def comp_modes(dataComp, dataType="Impedance"):
+    """Component codes of include/hmcmt.h: ZXY 1, ZYX 2 (DataType Impedance); RhoXY 3, PhsXY 4, RhoYX 5, PhsYX 6
+    (DataType Rho_Pha: the names compJacTMatVec.jl:106-113 looks for).  `log10Rho*` is refused: the reference's
+    forward returns the linear apparent resistivity for it while its sensitivity branch switches to log10
+    (mt2DTE.jl:253 vs dataFuncSens.jl:154-160)."""
     out = []
     for c in dataComp:
-        if "XY" in c:
-            out.append(1)
-        elif "YX" in c:
-            out.append(2)
-        else:
-            raise ValueError(f"unsupported data component {c!r} (only ZXY / ZYX impedances)")
+        if c not in COMPONENT_CODES:
+            raise ValueError(f"unsupported data component {c!r} (supported: {', '.join(COMPONENT_CODES)})")
+        code = COMPONENT_CODES[c]
+        if (code <= 2) != ("Impedance" in dataType):
+            raise ValueError(f"data component {c!r} does not belong to DataType {dataType!r}")
+        out.append(code)
     return np.asarray(out, dtype=np.int64)
 
 
@@ -40,9 +45,9 @@ class CreateArgs:
     """Keeps the numpy buffers alive and exposes them as a ctypes argument tuple."""
 
     def __init__(self, mtMesh, mtData, invParam):
-        if "Impedance" not in mtData.dataType:
-            raise ValueError("only DataType Impedance is supported (the reference's Rho_Pha branch is "
-                             "unreachable, SURVEY App. B.1)")
+        if "Impedance" not in mtData.dataType and "Rho_Pha" not in mtData.dataType and "Rho_Phs" not in mtData.dataType:
+            raise ValueError(f"unsupported DataType {mtData.dataType!r} (Impedance or Rho_Pha)")
+        self.real_data = "Impedance" not in mtData.dataType
         ny, nz = int(mtMesh.gridSize[0]), int(mtMesh.gridSize[1])
         self.ny, self.nz = ny, nz
         self.yLen = _f64(mtMesh.yLen)
@@ -52,7 +57,7 @@ class CreateArgs:
         rx = _f64(mtData.rxLoc)
         self.rxY = _f64(rx[:, 0])
         self.rxZ = _f64(rx[:, 1])
-        self.compMode = comp_modes(mtData.dataComp)
+        self.compMode = comp_modes(mtData.dataComp, mtData.dataType)
         self.freqID = _i64(mtData.freqID)
         self.rxID = _i64(mtData.rxID)
         self.dtID = _i64(mtData.dtID)

@@ -53,6 +53,19 @@ def make_data_layout(freqs, rx_y, rx_z=0.0) -> MTData:
                   np.ones(2 * nR * nF, dtype=bool), True, True)
 
 
+def make_rhophase_layout(freqs, rx_y, rx_z=0.0) -> MTData:
+    """The same survey as apparent resistivity + phase (DataType Rho_Pha, components RhoXY PhsXY RhoYX PhsYX in the
+    order MT2DFwdSolver.jl:191-205 stacks them), data sorted (freq, rx, comp)."""
+    freqs = np.asarray(freqs, dtype=np.float64)
+    rx_y = np.asarray(rx_y, dtype=np.float64)
+    nF, nR = len(freqs), len(rx_y)
+    rxLoc = np.stack([rx_y, np.full(nR, rx_z)], axis=1)
+    f, r, d = np.meshgrid(np.arange(1, nF + 1), np.arange(1, nR + 1), np.arange(1, 5), indexing="ij")
+    return MTData(rxLoc, freqs, "Rho_Pha", ["RhoXY", "PhsXY", "RhoYX", "PhsYX"], r.reshape(-1).astype(np.int64),
+                  f.reshape(-1).astype(np.int64), d.reshape(-1).astype(np.int64),
+                  np.ones(4 * nR * nF, dtype=bool), True, True)
+
+
 def log_freqs(n, fmax=100.0, fmin=0.01):
     return np.logspace(np.log10(fmax), np.log10(fmin), n)
 

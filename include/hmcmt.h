@@ -83,7 +83,10 @@ void hmcmt_default_options(hmcmt_options* opts);
  *   ny, nz            cells in y / z (nz INCLUDES the air layers, TensorMesh2D.gridSize)
  *   yLen[ny], zLen[nz], origin[2]      TensorMesh2D fields (HMCFileIO.jl:45-60)
  *   freqs[nFreq]; rxY[nRx], rxZ[nRx]   MTData.freqs, columns of MTData.rxLoc
- *   compMode[nComp]   1 for a data component containing "XY" (TE), 2 for "YX" (TM)
+ *   compMode[nComp]   component code per entry of MTData.dataComp: 1 ZXY, 2 ZYX (DataType Impedance, complex data);
+ *                     3 RhoXY, 4 PhsXY, 5 RhoYX, 6 PhsYX (DataType Rho_Pha: apparent resistivity |Z|^2/(w mu0) in Ohm-m and
+ *                     phase in degrees, mt2DTE.jl:253-255 -- real data: obs / pred keep the complex layout with zero
+ *                     imaginary parts).  The two families cannot be mixed
  *   freqID/rxID/dtID[nData]  1-based, MTData fields; dataID[nComp*nRx*nFreq] mask, dt fastest
  *   obs[nData] complex, dataW[nData] = diag of InvDataModel.dataW
  *   activeIdx[nAC]    1-based cell id of each active cell (= activeCell.rowval), bgModel[ny*nz]

@@ -537,6 +537,28 @@ def _edge_dup(M):
     return sp.vstack([M[0], M, M[-1]], format="csr")
 
 
+
+def _rho_phase_rows(omega, Z, dZ, dZ_dsig):
+    """The "Rho_Phs" branch of dataFuncSens.jl:130-159 (TE) / :300-330 (TM): rows of L and Q for apparent
+    resistivity (first nRx rows) and phase in degrees (next nRx rows).  The reference tests the data type against
+    "Rho_Phs" here while its reader and forward solver say "Rho_Pha" (readMT2DData.jl:87, MT2DFwdSolver.jl:191), so
+    the branch is unreachable there; this restatement accepts either spelling -- a deliberate fix,
+    not a reproduction.  `log10Rho` components (:154-160) are not restated: the reference's forward returns the
+    linear apparent resistivity for them (mt2DTE.jl:253)."""
+    omu = omega * MU0
+    dZ = sp.csr_matrix(dZ)
+    dZs = sp.csr_matrix(dZ_dsig)
+    dAppRho = (2.0 / omu) * (sdiag(np.conj(Z)) @ dZ)
+    dPhase = (sdiag(1.0 / np.abs(Z) ** 2) @ ((-1j) * (sdiag(np.conj(Z)) @ dZ))) * (180.0 / np.pi)
+    dAppRho_dsig = (2.0 / omu) * (sdiag(Z.real) @ dZs.real + sdiag(Z.imag) @ dZs.imag)
+    dPhase_dsig = (sdiag(1.0 / np.abs(Z) ** 2) @ (sdiag(Z.real) @ dZs.imag - sdiag(Z.imag) @ dZs.real)) * (180.0 / np.pi)
+    return sp.vstack([dAppRho, dPhase]).tocsr(), sp.vstack([dAppRho_dsig, dPhase_dsig]).tocsr()
+
+
+def _is_rho_phase(dataType):
+    return "Rho_Pha" in dataType or "Rho_Phs" in dataType
+
+
 def getDataFuncSensTE(omega, rx: PreRxSens, Ex01, dataType):
     """Impedance branch of dataFuncSens.jl:21-176."""
     dEx0, dEx1, sigma1, dsigma1 = rx.dFn0, rx.dFn1, rx.sigma1, rx.dsigma1
@@ -570,8 +592,10 @@ def getDataFuncSensTE(omega, rx: PreRxSens, Ex01, dataType):
     dHyr_dsig = linRxMap.T @ dHy0_dsig
     dZ = sdiag(1.0 / Hyr) @ dExr - sdiag(Exr / Hyr ** 2) @ dHyr
     dZ_dsig = -sdiag(Exr / Hyr ** 2) @ dHyr_dsig
+    if _is_rho_phase(dataType):
+        return _rho_phase_rows(omega, Exr / Hyr, dZ, dZ_dsig)
     if "Impedance" not in dataType:
-        raise NotImplementedError("only DataType Impedance works end-to-end in the reference (SURVEY App. B.1)")
+        raise NotImplementedError(dataType)
     return sp.csr_matrix(dZ), sp.csr_matrix(dZ_dsig)
 
 
@@ -613,8 +637,10 @@ def getDataFuncSensTM(omega, rx: PreRxSens, Hx01, dataType):
     dEyr_dsig = linRxMap.T @ dEy0_dsig
     dZ = sdiag(1.0 / Hxr) @ dEyr - sdiag(Eyr / Hxr ** 2) @ dHxr
     dZ_dsig = sdiag(1.0 / Hxr) @ dEyr_dsig
+    if _is_rho_phase(dataType):
+        return _rho_phase_rows(omega, Eyr / Hxr, dZ, dZ_dsig)
     if "Impedance" not in dataType:
-        raise NotImplementedError("only DataType Impedance works end-to-end in the reference (SURVEY App. B.1)")
+        raise NotImplementedError(dataType)
     return sp.csr_matrix(dZ), sp.csr_matrix(dZ_dsig)
 
 
@@ -855,14 +881,39 @@ def compJacTMatVec(exTE, hxTM, datVec, mesh, mtData, activeIdx, AinvTE, AinvTM,
         Gradio = Grad[:, io]
         dMsigF = (AveCF @ F @ sdiag(-1.0 / sigma ** 2) @ activeCell).tocsr()
 
-    if "Impedance" not in dataType:
-        raise NotImplementedError("Rho_Phs sensitivity is unreachable in the reference (SURVEY App. B.1)")
-    iZXY = iZYX = 0
+    rhoPhase = _is_rho_phase(dataType)                 # compJacTMatVec.jl:104-130 (see _rho_phase_rows for the spelling)
+    if not rhoPhase and "Impedance" not in dataType:
+        raise NotImplementedError(dataType)
+    iZXY = iZYX = iRhoXY = iPhsXY = iRhoYX = iPhsYX = 0
+    nRx = rxLoc.shape[0]
     for j, c in enumerate(dataComp):
         if c == "ZXY":
             iZXY = j + 1
         elif c == "ZYX":
             iZYX = j + 1
+        elif "log10Rho" in c:
+            raise NotImplementedError("log10Rho components: the reference's forward and sensitivity disagree on them")
+        elif "RhoXY" in c:
+            iRhoXY = j + 1
+        elif c == "PhsXY":
+            iPhsXY = j + 1
+        elif "RhoYX" in c:
+            iRhoYX = j + 1
+        elif c == "PhsYX":
+            iPhsYX = j + 1
+
+    def pick(L, Q, i1, i2):
+        """sVec and Q^T v of one system: impedance rows (i2 = 0) or rho rows + phase rows (:189-199, :260-270)"""
+        idd1 = np.nonzero(subDcID == i1)[0]
+        idr1 = subRxID[idd1] - 1
+        sv = L[idr1, :].T @ datTmp[idd1]
+        qv = Q[idr1, :].T @ datTmp[idd1]
+        if i2:
+            idd2 = np.nonzero(subDcID == i2)[0]
+            idr2 = subRxID[idd2] - 1 + nRx
+            sv = sv + L[idr2, :].T @ datTmp[idd2]
+            qv = qv + Q[idr2, :].T @ datTmp[idd2]
+        return sv, activeCell.T @ qv
 
     rxSens = preSetRxFieldSens(rxLoc, yNode, zNode, sigma)
     zid = rxSens.zid
@@ -886,10 +937,7 @@ def compJacTMatVec(exTE, hxTM, datVec, mesh, mtData, activeIdx, AinvTE, AinvTM,
         if calTE:
             Ex01 = np.stack([exTE[id0, iFreq], exTE[id1, iFreq]], axis=1)
             L, Q = getDataFuncSensTE(omega, rxSens, Ex01, dataType)
-            idd1 = np.nonzero(subDcID == iZXY)[0]
-            idr1 = subRxID[idd1] - 1
-            sVec = L[idr1, :].T @ datTmp[idd1]
-            qt = activeCell.T @ (Q[idr1, :].T @ datTmp[idd1])
+            sVec, qt = pick(L, Q, iRhoXY, iPhsXY) if rhoPhase else pick(L, Q, iZXY, 0)
             QTv = QTv + qt
             AioTE = (rAioTE + 1j * omega * iAioTE).tocsr()
             eVal = AinvTE[iFreq].solve(sVec[ii])
@@ -911,10 +959,7 @@ def compJacTMatVec(exTE, hxTM, datVec, mesh, mtData, activeIdx, AinvTE, AinvTM,
         if calTM:
             Hx01 = np.stack([hxTM[id0, iFreq], hxTM[id1, iFreq]], axis=1)
             L, Q = getDataFuncSensTM(omega, rxSens, Hx01, dataType)
-            idd1 = np.nonzero(subDcID == iZYX)[0]
-            idr1 = subRxID[idd1] - 1
-            sVec = L[idr1, :].T @ datTmp[idd1]
-            qt = activeCell.T @ (Q[idr1, :].T @ datTmp[idd1])
+            sVec, qt = pick(L, Q, iRhoYX, iPhsYX) if rhoPhase else pick(L, Q, iZYX, 0)
             QTv = QTv + qt
             AioTM = (rAioTM + 1j * omega * iAioTM).tocsr()
             eVal = AinvTM[iFreq].solve(sVec[ii])

@@ -52,7 +52,7 @@ struct Emul {
         v.rxIdn = h.rxIdn.data(); v.rxDy1 = h.rxDy1.data(); v.rxDy2 = h.rxDy2.data();
         v.rxKL = h.rxKL.data(); v.rxKR = h.rxKR.data(); v.rxWL = h.rxWL.data(); v.rxWR = h.rxWR.data();
         v.Zrx = Zrx.data(); v.rxN0 = rxN0.data(); v.rxD = rxD.data(); v.rxCoef = rxCoef.data();
-        v.predSys = h.predSys.data(); v.predRx = h.predRx.data(); v.datSys = h.datSys.data(); v.datRx = h.datRx.data();
+        v.predSys = h.predSys.data(); v.predRx = h.predRx.data(); v.datSys = h.datSys.data(); v.datRx = h.datRx.data(); v.predKind = h.predKind.data(); v.datKind = h.datKind.data();
         v.obs = h.obs.data(); v.dataW = h.dataW.data(); v.pred = pred.data(); v.vbar = vbar.data();
         v.misfitPart = misfitPart.data(); v.srStart = h.srStart.data(); v.srList = h.srList.data();
         v.srcB = srcB.data(); v.wL = wL.data(); v.wR = wR.data(); v.colw = colw.data();

@@ -1,5 +1,5 @@
 """Generates the golden vectors tests/golden/*.npz with the oracle (run in the build
-container: `python tests/golden/make_golden.py [names...]`; names: tiny cfg2 cfg1 cfg3s dprism3d coprod2).  Inputs: BASELINE.json-style synthetic configs
+container: `python tests/golden/make_golden.py [names...]`; names: tiny cfg2 cfg1 cfg3s dprism3d coprod2 rhophase).  Inputs: BASELINE.json-style synthetic configs
 (hmcmt2d_amd/synthetic.py), observed data = oracle forward of the true model + 3 % seeded noise,
 evaluation state m = ln(0.01) + 0.3 N(0,1) (seed 1).  Outputs: predData, misfit, gradient, the
 receiver-row fields and (tiny only) every intermediate term of J^T v.
@@ -98,6 +98,32 @@ def make_cfg3_subset():
     print("cfg3s misfit", misfit, misfit2, "file kB", os.path.getsize(os.path.join(HERE, "cfg3s.npz")) // 1024)
 
 
+def make_rho_phase():
+    """tiny config with DataType Rho_Pha (apparent resistivity + phase of both polarisations, a tenth of the data
+    masked out): observations = oracle response of the true model + 5 % / 1.5 degree noise."""
+    mesh, dz, sig_true = S.make_config("tiny")
+    data = S.make_rhophase_layout(dz.freqs, dz.rxLoc[:, 0])
+    O.setupTensorMesh2D(mesh)
+    mesh.sigma = sig_true.copy()
+    full, _ = O.MT2DFwdSolver(mesh, data)
+    rng = np.random.default_rng(20250114)
+    keep = rng.random(len(full)) > 0.1
+    data.dataID = keep.copy()
+    data.rxID, data.freqID, data.dtID = data.rxID[keep], data.freqID[keep], data.dtID[keep]
+    isrho = (data.dtID % 2) == 1
+    err = np.where(isrho, 0.05 * np.abs(full[keep]), 1.5)
+    obs = full[keep] + err * rng.standard_normal(keep.sum())
+    ny, nz = mesh.gridSize
+    nair = len(mesh.airLayer)
+    mesh.sigma = np.concatenate([np.full(ny * nair, S.SIG_AIR), np.full(ny * (nz - nair), 0.01)])
+    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, obs, err)
+    m = S.rough_state(len(inv.strModel))
+    inv.strModel = m.copy()
+    pred, misfit, grad = O.compDataGradient(mesh, data, inv, HMCPrior(), True)
+    np.savez_compressed(os.path.join(HERE, "tiny_rhophase.npz"), keep=keep, obs=obs, err=err, m=m, pred=pred, misfit=misfit, grad=grad)
+    print("tiny_rhophase nData", len(obs), "misfit", misfit, "|grad|max", np.abs(grad).max())
+
+
 def make_example(name):
     """The reference's own example directory (data files copied as fixtures to tests/golden/examples/<name>/:
     startupfile, model file, data file -- inputs only): oracle compDataGradient at the file's start model and at a
@@ -134,7 +160,7 @@ def make_example(name):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or ["tiny", "cfg2", "cfg1", "cfg3s", "dprism3d", "coprod2"]
+    names = sys.argv[1:] or ["tiny", "cfg2", "cfg1", "cfg3s", "dprism3d", "coprod2", "rhophase"]
     for nm in names:
         if nm == "tiny":
             make("tiny", True)
@@ -142,5 +168,7 @@ if __name__ == "__main__":
             make(nm, False)
         elif nm == "cfg3s":
             make_cfg3_subset()
+        elif nm == "rhophase":
+            make_rho_phase()
         else:
             make_example(nm)

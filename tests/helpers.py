@@ -112,3 +112,17 @@ class OracleContext:
         s = self.inv.bgModel.copy(); s[self.inv.activeIdx] += np.exp(m); self.mesh.sigma = s
         p, _ = self.O.MT2DFwdSolver(self.mesh, self.data)
         return p, self.O.compDataMisfit(p, self.inv)
+
+
+def rhophase_problem():
+    """tiny config with DataType Rho_Pha and the masked data set of tests/golden/tiny_rhophase.npz.
+    Returns (mesh, data, inv, m, golden)."""
+    g = np.load(os.path.join(GOLDEN, "tiny_rhophase.npz"))
+    mesh, dz, _ = S.make_config("tiny")
+    data = S.make_rhophase_layout(dz.freqs, dz.rxLoc[:, 0])
+    keep = g["keep"]
+    data.dataID = keep.copy()
+    data.rxID, data.freqID, data.dtID = data.rxID[keep], data.freqID[keep], data.dtID[keep]
+    mesh.sigma = start_sigma(mesh)
+    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, g["obs"], g["err"])
+    return mesh, data, inv, S.rough_state(len(inv.strModel)), g

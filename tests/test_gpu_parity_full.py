@@ -158,3 +158,31 @@ def test_full_fields_adjoint_fields_and_per_system_terms():
             ref = em * tot.real
             shallow, deep = gerr_split(g1, ref, inv, mesh, 3)
             assert shallow < GRAD_TOL and deep < GRAD_DEEP_TOL, (md, f, shallow, deep)
+
+
+def test_rho_phase_data_type():
+    """DataType Rho_Pha (apparent resistivity + phase in degrees, both polarisations, a tenth of the data masked out;
+    SURVEY 8(f)4): predicted data, misfit and gradient against the oracle and its golden; then the TE-only subset
+    (RhoXY + PhsXY), for which the TM systems must not iterate."""
+    from tests.helpers import rhophase_problem
+    mesh, data, inv, m, g = rhophase_problem()
+    ctx = HipContext(mesh, data, inv, verify=True)
+    pred, misfit, grad = _check(ctx, m, g["pred"], float(g["misfit"]), g["grad"], inv, mesh, deep_rows=3)
+    assert pred.dtype == np.float64 and pred.shape == g["obs"].shape
+    po, mo, go = oracle_eval(mesh, data, inv, m)
+    _check(ctx, m, po, mo, go, inv, mesh, deep_rows=3)
+    pf, mf = ctx.forward(m + 0.01)
+    assert pf.dtype == np.float64 and mf > 0
+    ctx.close()
+    te = data.dtID <= 2
+    nF, nR = len(data.freqs), data.rxLoc.shape[0]
+    dataID = np.zeros((nF, nR, 2), bool)
+    dataID[data.freqID[te] - 1, data.rxID[te] - 1, data.dtID[te] - 1] = True
+    d2 = MTData(data.rxLoc, data.freqs, "Rho_Pha", ["RhoXY", "PhsXY"], data.rxID[te], data.freqID[te], data.dtID[te],
+                dataID.reshape(-1), True, False)
+    inv2 = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0, 0, inv.obsData[te], (1.0 / inv.dataW)[te])
+    c2 = HipContext(mesh, d2, inv2, verify=True)
+    po, mo, go = oracle_eval(mesh, d2, inv2, m)
+    _check(c2, m, po, mo, go, inv2, mesh, deep_rows=3)
+    assert c2.iters()[:, nF:].max() == 0
+    c2.close()

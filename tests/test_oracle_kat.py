@@ -141,3 +141,49 @@ def test_reference_gradient_is_ill_conditioned_in_the_deepest_rows():
     assert deep[worst].all()
     assert d[deep].max() / np.abs(g0).max() > 1e-8 and d[deep].max() > 10 * d[~deep].max()
     assert (d[worst] / np.abs(g0[worst])).max() > 1e-4          # third to fourth digit of the entries themselves
+
+
+def test_rho_phase_sensitivity_equals_the_impedance_adjoint_with_chain_rule_weights():
+    """DataType Rho_Pha (mt2DTE.jl:253-255, dataFuncSens.jl:130-159, :300-330, compJacTMatVec.jl:104-130,
+    :189-199, :260-270).  Known answer: rho = |Z|^2/(w mu0) and phi = atan2(Im Z, Re Z) are functions of the impedance,
+    so J_rhophi^T v must equal the IMPEDANCE adjoint applied to conj(c), c = v_rho 2 conj(Z)/(w mu0) +
+    v_phi (-i)(180/pi) conj(Z)/|Z|^2 -- an identity between two independently restated branches (rounding level).
+    Also the forward values against their definitions and an interior finite difference of the misfit."""
+    from hmcmt2d_amd import synthetic as S
+    from tests.helpers import make_problem, rhophase_problem
+    mesh, data, inv, m = make_problem("tiny")
+    O.setupTensorMesh2D(mesh)
+    nF, nR = len(data.freqs), data.rxLoc.shape[0]
+    drp = S.make_rhophase_layout(data.freqs, data.rxLoc[:, 0])
+    sig = inv.bgModel.copy(); sig[inv.activeIdx] += np.exp(m); mesh.sigma = sig
+    pz, fwd = O.MT2DFwdSolver(mesh, data)
+    prp, _ = O.MT2DFwdSolver(mesh, drp)
+    Z = pz.reshape(nF, nR, 2); R = prp.reshape(nF, nR, 4)
+    om = 2 * np.pi * data.freqs[:, None]
+    for md in range(2):
+        assert np.allclose(R[:, :, 2 * md], np.abs(Z[:, :, md]) ** 2 / (om * O.MU0), rtol=1e-13)
+        assert np.allclose(R[:, :, 2 * md + 1], np.degrees(np.angle(Z[:, :, md])), rtol=1e-13)
+    v = np.random.default_rng(0).standard_normal(len(prp))
+    g_rp = O.compJacTMatVec(fwd.exTE, fwd.hxTM, v, mesh, drp, inv.activeIdx, fwd.AinvTE, fwd.AinvTM, False)
+    V = v.reshape(nF, nR, 4)
+    c = np.zeros((nF, nR, 2), complex)
+    for md in range(2):
+        z = Z[:, :, md]
+        c[:, :, md] = V[:, :, 2 * md] * (2 / (om * O.MU0)) * np.conj(z) + V[:, :, 2 * md + 1] * (-1j) * (180 / np.pi) * np.conj(z) / np.abs(z) ** 2
+    g_z = O.compJacTMatVec(fwd.exTE, fwd.hxTM, np.conj(c).reshape(-1), mesh, data, inv.activeIdx, fwd.AinvTE, fwd.AinvTM, False)
+    assert np.abs(g_rp - g_z).max() < 1e-12 * np.abs(g_z).max()
+    # the committed golden (masked data set) and an interior finite difference
+    mesh, drp, invr, m, g = rhophase_problem()
+    O.setupTensorMesh2D(mesh)
+    invr.strModel = m.copy()
+    pred, misfit, grad = O.compDataGradient(mesh, drp, invr, HMCPrior(), False)
+    assert np.allclose(pred, g["pred"], rtol=1e-12) and abs(misfit - float(g["misfit"])) < 1e-10 * misfit
+    assert np.abs(grad - g["grad"]).max() < 1e-10 * np.abs(grad).max()
+
+    def phi(mm):
+        s = invr.bgModel.copy(); s[invr.activeIdx] += np.exp(mm); mesh.sigma = s
+        return O.compDataMisfit(O.MT2DFwdSolver(mesh, drp)[0], invr)
+    c = 2 * mesh.gridSize[0] + 6
+    mp, mm_ = m.copy(), m.copy(); mp[c] += 1e-5; mm_[c] -= 1e-5
+    fd = (phi(mp) - phi(mm_)) / 2e-5
+    assert abs(fd - grad[c]) < 3e-2 * abs(fd)
