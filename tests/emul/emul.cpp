@@ -73,7 +73,7 @@ struct Emul {
         const int NYP = v.NYP, nz = v.nz;
         if (kind == 2) {
             const int mode = s >= v.nFreq;
-            const double wJ = 0.7;
+            const double wJ = 0.8;
             std::vector<cplx> z0((size_t)v.vstride, cplx{0, 0}), t((size_t)v.vstride, cplx{0, 0}), z1((size_t)v.vstride, cplx{0, 0});
             auto dinv = [&](int iy, int iz) { long mo = (long)mode * v.vstride + nidx(v, iy, iz); return wJ / cplx{v.dK[mo], v.omega[s] * v.dM[mo]}; };
             for (int iz = 1; iz <= nz - 1; ++iz) for (int iy = 1; iy <= v.ny - 1; ++iy) z0[nidx(v, iy, iz)] = dinv(iy, iz) * r[nidx(v, iy, iz)];

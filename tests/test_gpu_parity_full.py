@@ -30,13 +30,13 @@ pytestmark = pytest.mark.gpu
 PRED_TOL, GRAD_TOL, GRAD_DEEP_TOL, RES_TOL = 1e-9, 1e-8, 5e-7, 1e-9
 
 
-def _check(ctx, m, pred_ref, misfit_ref, grad_refs, inv, mesh, deep_rows=5, grad_tol=GRAD_TOL):
+def _check(ctx, m, pred_ref, misfit_ref, grad_refs, inv, mesh, deep_rows=5, grad_tol=GRAD_TOL, misfit_tol=PRED_TOL, pred_tol=PRED_TOL):
     """grad_refs: one reference gradient, or several rounding-equivalent evaluations of the reference formula (the
     gradient must agree with one of them, see tests/golden/make_golden.py::make_example)."""
     pred, misfit, grad = ctx.grad(m)
     st = ctx.stats()
     assert st["status"] == 0 and st["true_res_max"] < RES_TOL, st
-    assert relmax(pred, pred_ref) < PRED_TOL and abs(misfit - misfit_ref) / misfit_ref < PRED_TOL
+    assert relmax(pred, pred_ref) < pred_tol and abs(misfit - misfit_ref) / misfit_ref < misfit_tol
     refs = grad_refs if isinstance(grad_refs, (list, tuple)) else [grad_refs]
     errs = [gerr_split(grad, r, inv, mesh, deep_rows) for r in refs]
     shallow, deep = min(errs)
@@ -77,7 +77,12 @@ def test_cfg3_mesh_frequency_subset_parity_and_full_run_agreement():
     ea, ha = ctx.fields(adjoint=True)
     _, sig_true = S.make_config("cfg3")[1:]
     m_true = np.log(sig_true[inv.activeIdx])
-    _check(ctx, m_true, g["pred_true"], float(g["misfit_true"]), g["grad_true"], inv, mesh, grad_tol=5e-8)
+    # (at the true model the residuals are the 3 % noise, so the misfit's relative error is ~30x the predicted data's:
+    #  measured 3e-10 .. 2e-9 for predicted data good to 3e-10 .. 8e-10)
+    #  The gradient there is 1000x smaller than at the rough state (the residuals it is built from are noise) with the
+    #  same absolute error: 3e-7 of its own maximum (measured 2e-8 .. 1e-7), i.e. 1e-10 of the rough state's.
+    _, _, g_true = _check(ctx, m_true, g["pred_true"], float(g["misfit_true"]), g["grad_true"], inv, mesh, grad_tol=3e-7, misfit_tol=2e-8)
+    assert np.abs(g_true - g["grad_true"]).max() < 1e-9 * np.abs(g["grad"]).max()
     ctx.close()
     # full headline problem: 16 frequencies, the subset's observations at the subset's frequencies
     ctx16 = HipContext(mesh, data16, inv16, verify=True)
@@ -167,10 +172,12 @@ def test_rho_phase_data_type():
     from tests.helpers import rhophase_problem
     mesh, data, inv, m, g = rhophase_problem()
     ctx = HipContext(mesh, data, inv, verify=True)
-    pred, misfit, grad = _check(ctx, m, g["pred"], float(g["misfit"]), g["grad"], inv, mesh, deep_rows=3)
+    # (rho_a = |Z|^2/(w mu0) doubles the impedance's relative error: 3e-9, measured 1e-9)
+    rp = dict(deep_rows=3, pred_tol=3e-9, misfit_tol=3e-9)
+    pred, misfit, grad = _check(ctx, m, g["pred"], float(g["misfit"]), g["grad"], inv, mesh, **rp)
     assert pred.dtype == np.float64 and pred.shape == g["obs"].shape
     po, mo, go = oracle_eval(mesh, data, inv, m)
-    _check(ctx, m, po, mo, go, inv, mesh, deep_rows=3)
+    _check(ctx, m, po, mo, go, inv, mesh, **rp)
     pf, mf = ctx.forward(m + 0.01)
     assert pf.dtype == np.float64 and mf > 0
     ctx.close()
@@ -183,6 +190,6 @@ def test_rho_phase_data_type():
     inv2 = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0, 0, inv.obsData[te], (1.0 / inv.dataW)[te])
     c2 = HipContext(mesh, d2, inv2, verify=True)
     po, mo, go = oracle_eval(mesh, d2, inv2, m)
-    _check(c2, m, po, mo, go, inv2, mesh, deep_rows=3)
+    _check(c2, m, po, mo, go, inv2, mesh, **rp)
     assert c2.iters()[:, nF:].max() == 0
     c2.close()

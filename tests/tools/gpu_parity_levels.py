@@ -18,7 +18,7 @@ def level(tag, ctx, m, pred_ref, mis_ref, grad_ref, inv, mesh):
 
 
 def main():
-    for tol in (1e-11, 1e-12):
+    for tol in (1e-11, 3e-12):
         print("tol", tol)
         for name in ("tiny", "cfg2", "cfg1"):
             g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
