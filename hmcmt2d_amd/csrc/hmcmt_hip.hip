@@ -1,16 +1,19 @@
 // libhmcmt_hip.so -- gfx950 (MI355X) implementation of the HMCMT2D hot path behind include/hmcmt.h.
 //
-// Structure:
-//   * "item" kernels: one thread per node / cell / receiver / boundary column, bodies in
-//     hmcmt_items.h (assembly from sigma, 1-D boundary fields, receiver functionals, adjoint
-//     sources, J^T accumulation).
-//   * batched COCG over all S = 2*nFreq complex-symmetric 5-point systems at once, with
-//       - stencil SpMV on the padded nodal grid (real K shared by all frequencies of a mode,
-//         i*omega*D formed on the fly),
-//       - fast-diagonalisation preconditioner: two FP64-MFMA transforms with the mesh's y-eigenbasis
-//         (v_mfma_f64_16x16x4_f64) around a batched tridiagonal solve in z,
-//       - deterministic two-stage reductions (wave shuffles + fixed partial arrays).
-//   * no host compute path: every entry point needs a HIP device.
+// One translation unit in five files:
+//   hmcmt_hip.hip     this file: the context, the host orchestration of an evaluation (evaluate / solve), the C ABI
+//   kernels_cocg.h    Solver state, deterministic reductions (DPP wave sums), classic COCG kernels (Jacobi / plain FDM
+//                     preconditioners; the fp64 restart of a stagnating mixed-precision solve)
+//   kernels_fdm.h     fast-diagonalisation stage: y-eigenbasis transforms on the matrix cores (split-bf16
+//                     v_mfma_f32_16x16x32_bf16 by default, v_mfma_f64_16x16x4_f64 for fdm_precision = 1) around batched
+//                     tridiagonal solves in z; k_fdm_fwd / k_back_post are the two fused kernels of the default path
+//   kernels_fused.h   the fused COCG iteration (k_spmv_fused, k_update_fused), solve start / end, initial guesses
+//   kernels_path.h    "item" kernels, one thread per node / cell / receiver / boundary column with bodies in
+//                     hmcmt_items.h (assembly from sigma, 1-D boundary fields and sensitivities, receiver functionals,
+//                     adjoint sources, J^T v accumulation), and the leapfrog vector kernels
+// The systems are never stored as CSR: real 5-point stencil coefficients shared by all frequencies of a polarisation,
+// i*omega*D formed on the fly; every reduction is a fixed-order two-stage sum (bitwise repeatable).
+// There is no host compute path: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -29,2168 +32,10 @@ namespace {
 constexpr int MAXNB = 64;          // max partial-sum blocks per system (<= 64: one wave sums them, total_part)
 constexpr int VBLOCK = 256;        // threads of the vector kernels
 
-// ----------------------------------------------------------------------------------------------
-// solver state shared by the COCG kernels
-// ----------------------------------------------------------------------------------------------
-struct Solver {
-    int S, NB, NYP, NZP, ny, nz, nFreq;
-    long vstride, chunk;
-    const double* omega;
-    const double *cY, *cZ, *dK, *dM;      // [2][vstride]
-    const double* ofz;                    // [2][NZP]
-    const cplx* invp;                     // [S][vstride]
-    cplx *x, *r, *p, *q, *z, *y, *t;      // [S][vstride]
-    cplx *dinv;                           // [S][vstride] omegaJ / diag(A) on interior nodes, 0 elsewhere
-    // mixed-precision FDM stage (options.fdm_precision == 0): bf16 transform operands, fp32 tridiagonal
-    float2* t32;                          // [S][vstride] complex64 transform input (or its pre-split bf16 form, see store_t32)
-    int splitT;                           // 1: t32 / y32 hold bf16 hi/lo planes instead of complex64
-    int twist;                            // = View.twist: the inverse pivots are those of the twisted factorisation
-    float2* y32;                          // [S][vstride] complex64
-    const float2* invp32;                 // [S][vstride]
-    cplx *p2, *r2;                        // second buffers of p and r for the fused kernels
-    int RT, NTR;                          // rows per tile / row tiles per system of the fused kernels (NTR <= MAXNB)
-    cplx *partPQ;                         // [S][MAXNB]  p'q of the fused path
-    cplx *rho2;                           // [2][S] rho by iteration parity (fused path)
-    cplx *partA;                          // [S][MAXNB]  p'q   | r'z
-    double *partB;                        // [S][MAXNB]  |x|^2 | |z|^2
-    cplx *rho, *alphaBeta;                // [S]
-    int *active, *iters, *status, *nactive;
-    int* nactHost;                        // pinned host copy of *nactive (device address): the convergence polls only synchronise
-    double *errEst;                       // [S] (zz/xx)
-    double tol2;
-    double* errRef;                       // [S] best error estimate so far / 10-fold improvements (stagnation watch of the mixed-precision solve)
-    int* errRefIt;                        // [S] iteration at which errRef was set
-    int stallIt;                          // iterations allowed per 10-fold drop of the error estimate (STALL_IT; HMCMT_STALL_IT)
-    int* stallHost;                       // pinned host flag: a system has not improved its error estimate 10-fold in STALL_IT iterations
-    unsigned long long* cntActive;        // non-null in an evaluation sampled by hmcmt_profile: += systems still active per iteration
-};
-
-// Sum over the 64 lanes of a wave, the total returned in EVERY lane.  Data-parallel-primitive moves inside the rows
-// of 16 lanes (quad_perm xor 1, xor 2, row_ror 4, row_ror 8: ~4 cycles each) and one v_readlane per row instead of a
-// butterfly of 6 ds_bpermute round trips per 32-bit half (~1 us for the three sums at the end of k_back_post).
-// The order of the additions is fixed, and the final value is formed from lanes 0/16/32/48 only, so it is the same
-// bit pattern in every lane and in every workgroup that reduces the same numbers.
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-__device__ __forceinline__ double wave_sum(double v) {
-    v += dpp_mov_f64<0xB1>(v);          // quad_perm [1,0,3,2]
-    v += dpp_mov_f64<0x4E>(v);          // quad_perm [2,3,0,1]
-    v += dpp_mov_f64<0x124>(v);         // row_ror:4
-    v += dpp_mov_f64<0x128>(v);         // row_ror:8  -> the sum of the lane's row of 16
-    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
-}
-
-// block-wide deterministic sum of up to 2 doubles; result valid in thread 0
-__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh /* [2*4] */) {
-    a = wave_sum(a);
-    b = wave_sum(b);
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if (l == 0) { sh[w] = a; sh[4 + w] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int nw = (blockDim.x + 63) >> 6;
-        double sa = 0, sb = 0;
-        for (int i = 0; i < nw; ++i) { sa += sh[i]; sb += sh[4 + i]; }
-        a = sa; b = sb;
-    }
-}
-
-// the same for workgroups of up to 8 waves (sh: [2*8])
-__device__ __forceinline__ void block_sum2_8(double& a, double& b, double* sh) {
-    a = wave_sum(a);
-    b = wave_sum(b);
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if (l == 0) { sh[w] = a; sh[8 + w] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int nw = (blockDim.x + 63) >> 6;
-        double sa = 0, sb = 0;
-        for (int i = 0; i < nw; ++i) { sa += sh[i]; sb += sh[8 + i]; }
-        a = sa; b = sb;
-    }
-}
-
-__device__ __forceinline__ void block_sum3_8(double& a, double& b, double& c, double* sh, int nw) {
-    a = wave_sum(a);
-    b = wave_sum(b);
-    c = wave_sum(c);
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if (l == 0) { sh[w] = a; sh[8 + w] = b; sh[16 + w] = c; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double sa = 0, sb = 0, sc = 0;
-        for (int i = 0; i < nw; ++i) { sa += sh[i]; sb += sh[8 + i]; sc += sh[16 + i]; }
-        a = sa; b = sb; c = sc;
-    }
-}
-
-// sum of n <= 64 per-block partials by one wave: lane b fetches partial b (one memory latency instead of n in a
-// row), a fixed sequence of lane exchanges (wave_sum) adds them up, every lane gets the total -- the same value in every wave
-// of every block, so all blocks of a system still agree on alpha / beta / convergence
-__device__ __forceinline__ double wave_total(double v) { return wave_sum(v); }
-__device__ __forceinline__ double total_part(const double* part, int n) {
-    const int l = threadIdx.x & 63;
-    return wave_total(l < n ? part[l] : 0.0);
-}
-__device__ __forceinline__ cplx total_part(const cplx* part, int n) {
-    const int l = threadIdx.x & 63;
-    const cplx v = l < n ? part[l] : cplx{0, 0};
-    return cplx{wave_total(v.re), wave_total(v.im)};
-}
-
-__device__ __forceinline__ cplx sum_partA(const Solver& k, int s) {
-    cplx t = cplx{0, 0};
-    for (int b = 0; b < k.NB; ++b) t += k.partA[(long)s * MAXNB + b];
-    return t;
-}
-
-// q = A p (interior nodes), partA = p'q (unconjugated)
-__global__ __launch_bounds__(VBLOCK) void k_spmv(Solver k) {
-    const int s = blockIdx.y;
-    if (!k.active[s]) return;
-    __shared__ double sh[8];
-    const int mode = s >= k.nFreq;
-    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
-    const double w = k.omega[s];
-    const cplx* p = k.p + so;
-    cplx* q = k.q + so;
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    double ar = 0, ai = 0;
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
-        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
-        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
-            const cplx c = p[e];
-            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
-            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
-            acc += k.cY[mo + e] * p[e + 1];
-            acc += k.cY[mo + e - 1] * p[e - 1];
-            acc += k.cZ[mo + e] * p[e + k.NYP];
-            acc += k.cZ[mo + e - k.NYP] * p[e - k.NYP];
-            q[e] = acc;
-            ar += c.re * acc.re - c.im * acc.im;
-            ai += c.re * acc.im + c.im * acc.re;
-        }
-    }
-    block_sum2(ar, ai, sh);
-    if (threadIdx.x == 0) k.partA[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
-}
-
-// alpha = rho / p'q ; x += alpha p ; r -= alpha q ; partB = |x|^2 over interior nodes
-__global__ __launch_bounds__(VBLOCK) void k_update(Solver k) {
-    const int s = blockIdx.y;
-    if (!k.active[s]) return;
-    __shared__ double sh[8];
-    const long so = (long)s * k.vstride;
-    const cplx al = k.rho[s] / sum_partA(k, s);
-    const cplx *p = k.p + so, *q = k.q + so;
-    cplx *x = k.x + so, *r = k.r + so;
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    double xx = 0, dummy = 0;
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
-        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
-        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
-            cplx xv = x[e] + al * p[e];
-            x[e] = xv;
-            r[e] -= al * q[e];
-            xx += cabs2(xv);
-        }
-    }
-    block_sum2(xx, dummy, sh);
-    if (threadIdx.x == 0) {
-        k.partB[(long)s * MAXNB + blockIdx.x] = xx;
-        if (blockIdx.x == 0) k.alphaBeta[s] = al;
-    }
-}
-
-// partA = r'z (unconjugated), partB2 = |z|^2
-__global__ __launch_bounds__(VBLOCK) void k_dots(Solver k, double* partZZ) {
-    const int s = blockIdx.y;
-    if (!k.active[s]) return;
-    __shared__ double sh[8];
-    __shared__ double sh2[8];
-    const long so = (long)s * k.vstride;
-    const cplx *r = k.r + so, *z = k.z + so;
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    double ar = 0, ai = 0, zz = 0, dummy = 0;
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
-        const cplx a = r[e], b = z[e];
-        ar += a.re * b.re - a.im * b.im;
-        ai += a.re * b.im + a.im * b.re;
-        zz += cabs2(b);
-    }
-    block_sum2(ar, ai, sh);
-    block_sum2(zz, dummy, sh2);
-    if (threadIdx.x == 0) {
-        k.partA[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
-        partZZ[(long)s * MAXNB + blockIdx.x] = zz;
-    }
-}
-
-// per-system scalar bookkeeping: convergence test on the error estimate ||z|| <= tol ||x||,
-// beta = rho_new / rho_old.  first != 0: initialise (rho = r'z, beta = 0).
-__global__ void k_check(Solver k, const double* partZZ, int first, int maxit) {
-    __shared__ int cnt;
-    if (threadIdx.x == 0) cnt = 0;
-    __syncthreads();
-    for (int s = threadIdx.x; s < k.S; s += blockDim.x) {
-        if (!k.active[s]) continue;
-        cplx rz = cplx{0, 0};
-        double zz = 0, xx = 0;
-        for (int b = 0; b < k.NB; ++b) {
-            rz += k.partA[(long)s * MAXNB + b];
-            zz += partZZ[(long)s * MAXNB + b];
-            if (!first) xx += k.partB[(long)s * MAXNB + b];
-        }
-        bool on = true;
-        if (first == 2) {                                                // restart with a different preconditioner
-            k.rho[s] = rz;
-            k.alphaBeta[s] = cplx{0, 0};
-        } else if (first) {
-            k.rho[s] = rz;
-            k.alphaBeta[s] = cplx{0, 0};
-            k.errEst[s] = 1.0;
-            if (zz == 0.0) { on = false; k.errEst[s] = 0.0; }          // zero right-hand side
-        } else {
-            k.iters[s] += 1;
-            k.errEst[s] = sqrt(zz / xx);
-            if (zz <= k.tol2 * xx) on = false;
-            else {
-                k.alphaBeta[s] = rz / k.rho[s];
-                k.rho[s] = rz;
-                if (k.iters[s] >= maxit) { on = false; k.status[s] = HMCMT_ENOCONV; }
-            }
-        }
-        if (!(isfinite(rz.re) && isfinite(rz.im) && isfinite(zz) && isfinite(xx))) {
-            on = false; k.status[s] = HMCMT_EBREAKDOWN;
-        }
-        if (!on) k.active[s] = 0;
-        else atomicAdd(&cnt, 1);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { *k.nactive = cnt; *k.nactHost = cnt; }
-}
-
-// p = z + beta p   (first: p = z)
-__global__ __launch_bounds__(VBLOCK) void k_pupdate(Solver k, int first) {
-    const int s = blockIdx.y;
-    if (!k.active[s]) return;
-    const long so = (long)s * k.vstride;
-    const cplx be = k.alphaBeta[s];
-    const cplx* z = k.z + so;
-    cplx* p = k.p + so;
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) p[e] = first ? z[e] : z[e] + be * p[e];
-}
-
-// z = r / diag(A)  (Jacobi)
-__global__ __launch_bounds__(VBLOCK) void k_jacobi(Solver k) {
-    const int s = blockIdx.y;
-    if (!k.active[s]) return;
-    const int mode = s >= k.nFreq;
-    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
-    const double w = k.omega[s];
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
-        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
-        cplx zv = cplx{0, 0};
-        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1)
-            zv = k.r[so + e] / cplx{k.dK[mo + e], w * k.dM[mo + e]};
-        k.z[so + e] = zv;
-    }
-}
-
-// ----------------------------------------------------------------------------------------------
-// FDM transform: C[m][n] = sum_k A[m][k] * B[k][n],  A, C complex [M][NYP], B real [NYP][NYP].
-//
-// One wave = 8 complex rows x NTW column tiles of 16.  The 16-row MFMA tile stacks the rows' real
-// parts (tile rows 0-7) and imaginary parts (8-15), so one B fragment feeds both.
-// v_mfma_f64_16x16x4_f64 layout (measured, scripts/probe/mfma_f64_layout.hip):
-//   A[i = lane%16][k = lane/16], B[k = lane/16][j = lane%16], D[i = 4*r + lane/16][j = lane%16].
-// The reduction index is processed 16 at a time with the permutation k = 16*kg + 4*(lane/16) + i
-// for MFMA step i = 0..3, so each lane reads 4 consecutive complex of its A row (64 B) and the
-// constant B operand is pre-swizzled on the host into fragment order
-//   Bsw[((kg*NT + t)*64 + lane)*4 + i] = B[16*kg + 4*(lane/16) + i][16*t + lane%16]
-// (two 16-byte loads per tile per 4 MFMAs).  Operands of group kg+1 are fetched into registers
-// while group kg is multiplied; there is no LDS and no barrier.
-// ----------------------------------------------------------------------------------------------
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-template <int NTW>
-__device__ __forceinline__ void transform_body(const cplx* __restrict__ A, const double* __restrict__ Bsw,
-                                               cplx* __restrict__ C, int M, int NYP, int m0, int t0, int lane) {
-    const int NT = NYP >> 4, KG = NYP >> 4;
-    // Every workgroup streams the same B; starting each at a different k-group keeps the CUs of an
-    // XCD on different L2 channels instead of all requesting the same lines at once.
-    const int kg0 = (m0 >> 3) % KG;
-    const int li = lane & 15, lk = lane >> 4;
-    const bool im = (li >> 3) != 0;
-    const int arow = min(m0 + (li & 7), M - 1);
-    const d4* Ap = reinterpret_cast<const d4*>(A + (long)arow * NYP + 4 * lk);
-    const d4* Bp = reinterpret_cast<const d4*>(Bsw) + (long)t0 * 64 + lane;
-    const long bstride = (long)NT * 64;                // d4 per k-group
-    d4 acc[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) acc[t] = d4{0, 0, 0, 0};
-    d4 a0 = Ap[kg0 * 8], a1 = Ap[kg0 * 8 + 1];
-    d4 b[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) b[t] = Bp[kg0 * bstride + t * 64];
-    for (int it = 0; it < KG; ++it) {
-        int kn = kg0 + it + 1;                          // next k-group (wraps; last one re-reads, harmless)
-        if (kn >= KG) kn -= KG;
-        const d4 na0 = Ap[kn * 8], na1 = Ap[kn * 8 + 1];
-        d4 nb[NTW];
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) nb[t] = Bp[kn * bstride + t * 64];
-        // Pin the software pipeline.  Left alone, LLVM folds the phi of loads back into a load at the
-        // top of the iteration and the scheduler emits load -> wait -> MFMA with no overlap.  The two
-        // scheduling barriers keep "issue next loads | multiply current | wait for next" in this order.
-        __builtin_amdgcn_sched_barrier(0);
-        const double av[4] = {im ? a0[1] : a0[0], im ? a0[3] : a0[2], im ? a1[1] : a1[0], im ? a1[3] : a1[2]};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], b[t][i], acc[t], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        a0 = na0; a1 = na1;
-        asm volatile("" : "+v"(a0), "+v"(a1));
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) { b[t] = nb[t]; asm volatile("" : "+v"(b[t])); }
-    }
-    // r = 0,1: real parts of complex rows lk, 4+lk; r = 2,3: their imaginary parts -> every lane owns two
-    // complete complex results; 16 lanes write 256 contiguous bytes.
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-        const long col = (long)(t0 + t) * 16 + li;
-        if (m0 + lk < M) C[(long)(m0 + lk) * NYP + col] = cplx{acc[t][0], acc[t][2]};
-        if (m0 + 4 + lk < M) C[(long)(m0 + 4 + lk) * NYP + col] = cplx{acc[t][1], acc[t][3]};
-    }
-}
-
-// Workgroup = RG row groups (8 complex rows each) x NW column splits, RG*NW <= 4 waves, so that a
-// CU holding one workgroup runs one wave per SIMD (two 2-wave workgroups on a CU land on the same
-// SIMD pair and halve the MFMA rate -- measured, scripts/probe/transform_bench.hip).  Column tiles
-// are dealt to the NW waves as evenly as possible (first `extra` waves get one more).
-__global__ __launch_bounds__(256) void k_transform(const cplx* __restrict__ A, const double* __restrict__ Bsw,
-                                                    cplx* __restrict__ C, int M, int NYP, int rowsPerSys,
-                                                    const int* __restrict__ active, int NW, int RG) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rg = wave / NW, nw = wave - rg * NW;
-    const int m0 = (blockIdx.x * RG + rg) * 8;
-    if (m0 >= M) return;
-    if (active) {
-        const int s0 = m0 / rowsPerSys, s1 = min(m0 + 7, M - 1) / rowsPerSys;
-        if (!active[s0] && !active[s1]) return;
-    }
-    const int NT = NYP >> 4;
-    const int base = NT / NW, extra = NT % NW;
-    const int ntl = base + (nw < extra ? 1 : 0);
-    const int t0 = nw * base + min(nw, extra);
-    switch (ntl) {
-        case 1: transform_body<1>(A, Bsw, C, M, NYP, m0, t0, lane); break;
-        case 2: transform_body<2>(A, Bsw, C, M, NYP, m0, t0, lane); break;
-        case 3: transform_body<3>(A, Bsw, C, M, NYP, m0, t0, lane); break;
-        case 4: transform_body<4>(A, Bsw, C, M, NYP, m0, t0, lane); break;
-        case 5: transform_body<5>(A, Bsw, C, M, NYP, m0, t0, lane); break;
-        case 6: transform_body<6>(A, Bsw, C, M, NYP, m0, t0, lane); break;
-        case 7: transform_body<7>(A, Bsw, C, M, NYP, m0, t0, lane); break;
-        default: break;
-    }
-}
-
-// batched tridiagonal solve in z for every (system, eigenmode j), in place on y[s][iz][j]; lanes =
-// consecutive j (coalesced rows).  About 75 ns per row at one wave per CU; neither deeper prefetch, more
-// waves nor shorter chains change that (all measured).
-// With HMCMT_TWIST the twisted factorisation of item_pivot is used (rows 1..mid swept top-down, rows
-// n..mid+1 bottom-up as two interleaved chains joined by one 2x2 solve); it measured SLOWER (20 vs 16 us):
-// the kernel is bound by instruction issue of its ~100 lone waves, not by dependency latency, so the
-// default is the classic sweep (mid = n, bottom chain compiled out).
-// Operands of the next block of rows are in flight while the current block is processed.
-constexpr int TB = 8;
-constexpr int MAXNZP = 1024;
-
-struct alignas(8) c32 { float re, im; };
-__device__ __forceinline__ c32 operator*(c32 a, c32 b) { return c32{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
-__device__ __forceinline__ c32 operator*(float a, c32 b) { return c32{a * b.re, a * b.im}; }
-__device__ __forceinline__ c32 operator-(c32 a, c32 b) { return c32{a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ void pin(cplx& a) { asm volatile("" : "+v"(a.re), "+v"(a.im)); }
-__device__ __forceinline__ void pin(c32& a) { asm volatile("" : "+v"(a.re), "+v"(a.im)); }
-// a - b*x with four single (unpacked) FMAs, dependent depth two: the serial tridiagonal sweeps are latency
-// chains, and the packed v_pk_* forms hipcc's SLP pass would pick are slower per dependent step
-__device__ __forceinline__ c32 cmsub(c32 a, c32 b, c32 x) {
-    float re, im;
-    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(re) : "v"(b.re), "v"(x.re), "v"(a.re));
-    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(im) : "v"(b.re), "v"(x.im), "v"(a.im));
-    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(re) : "v"(b.im), "v"(x.im), "v"(re));
-    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(im) : "v"(b.im), "v"(x.re), "v"(im));
-    return c32{re, im};
-}
-
-template <class CT, class RT, bool TW>                   // TW = false: classic sweep, the bottom/down chain code is compiled out
-__device__ __forceinline__ void thomas_twisted(CT* __restrict__ y, const CT* __restrict__ ip, const RT* sof, int n, long NYP) {
-    const int mid = twist_mid(n, TW ? 1 : 0), nt = mid, nb = n - mid;
-    CT pt = CT{0, 0}, pb = CT{0, 0};
-    CT yt[TB], it[TB], yb[TB], ib[TB];
-    // ---- phase 1: normalised elimination, top chain rows 1..mid, bottom chain rows n..mid+1
-    auto load1 = [&](int k0, CT* a, CT* b, CT* c, CT* d) {
-#pragma unroll
-        for (int t = 0; t < TB; ++t) {
-            const int kt = min(k0 + t, nt - 1), kb = min(k0 + t, max(nb - 1, 0));
-            a[t] = y[(long)(1 + kt) * NYP]; b[t] = ip[(long)(1 + kt) * NYP];
-            if (TW) { c[t] = y[(long)(n - kb) * NYP]; d[t] = ip[(long)(n - kb) * NYP]; }
-        }
-    };
-    load1(0, yt, it, yb, ib);
-    for (int k0 = 0; k0 < nt; k0 += TB) {
-        CT nyt[TB], nit[TB], nyb[TB], nib[TB];
-        load1(min(k0 + TB, max(nt - 1, 0)), nyt, nit, nyb, nib);
-        RT ot[TB], ob[TB];
-#pragma unroll
-        for (int t = 0; t < TB; ++t) { ot[t] = sof[min(k0 + t, nt - 1)]; ob[t] = TW ? sof[n - min(k0 + t, max(nb - 1, 0))] : RT(0); }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < TB; ++t) {
-            const int k = k0 + t;
-            if (k < nt) { pt = (yt[t] - ot[t] * pt) * it[t]; y[(long)(1 + k) * NYP] = pt; }
-            if (TW && k < nb) { pb = (yb[t] - ob[t] * pb) * ib[t]; y[(long)(n - k) * NYP] = pb; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < TB; ++t) {
-            yt[t] = nyt[t]; it[t] = nit[t]; pin(yt[t]); pin(it[t]);
-            if (TW) { yb[t] = nyb[t]; ib[t] = nib[t]; pin(yb[t]); pin(ib[t]); }
-        }
-    }
-    // ---- join: x_mid + c x_{mid+1} = y'_mid ; x_{mid+1} + c' x_mid = y''_{mid+1} ; ip[0] = 1/(1 - c c')
-    if (TW && nb > 0) {
-        const RT o = sof[mid];
-        const CT c = o * ip[(long)mid * NYP], c2 = o * ip[(long)(mid + 1) * NYP];
-        pt = (pt - c * pb) * ip[0];
-        pb = pb - c2 * pt;
-        y[(long)mid * NYP] = pt; y[(long)(mid + 1) * NYP] = pb;
-    }
-    // ---- phase 2: substitution outwards, up chain rows mid-1..1, down chain rows mid+2..n
-    const int nu = nt - 1, nd = nb - 1;
-    if (nu <= 0 && nd <= 0) return;
-    auto load2 = [&](int k0, CT* a, CT* b, CT* c, CT* d) {
-#pragma unroll
-        for (int t = 0; t < TB; ++t) {
-            const int ku = min(k0 + t, max(nu - 1, 0)), kd = min(k0 + t, max(nd - 1, 0));
-            const int ru = max(mid - 1 - ku, 1), rd = min(mid + 2 + kd, n);
-            a[t] = y[(long)ru * NYP]; b[t] = ip[(long)ru * NYP];
-            if (TW) { c[t] = y[(long)rd * NYP]; d[t] = ip[(long)rd * NYP]; }
-        }
-    };
-    load2(0, yt, it, yb, ib);
-    const int nmax = max(nu, nd);
-    for (int k0 = 0; k0 < nmax; k0 += TB) {
-        CT nyt[TB], nit[TB], nyb[TB], nib[TB];
-        load2(min(k0 + TB, max(nmax - 1, 0)), nyt, nit, nyb, nib);
-        RT ou[TB], od[TB];
-#pragma unroll
-        for (int t = 0; t < TB; ++t) {
-            const int ru = max(mid - 1 - min(k0 + t, max(nu - 1, 0)), 1), rd = min(mid + 2 + min(k0 + t, max(nd - 1, 0)), n);
-            ou[t] = sof[ru]; od[t] = TW ? sof[rd - 1] : RT(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < TB; ++t) {
-            const int k = k0 + t;
-            if (k < nu) { pt = yt[t] - (ou[t] * it[t]) * pt; y[(long)(mid - 1 - k) * NYP] = pt; }
-            if (TW && k < nd) { pb = yb[t] - (od[t] * ib[t]) * pb; y[(long)(mid + 2 + k) * NYP] = pb; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < TB; ++t) {
-            yt[t] = nyt[t]; it[t] = nit[t]; pin(yt[t]); pin(it[t]);
-            if (TW) { yb[t] = nyb[t]; ib[t] = nib[t]; pin(yb[t]); pin(ib[t]); }
-        }
-    }
-}
-
-__global__ __launch_bounds__(64) void k_thomas(Solver k) {
-    const int s = blockIdx.y;
-    if (!k.active[s]) return;
-    __shared__ double sof[MAXNZP];
-    const int mode = s >= k.nFreq;
-    for (int i = threadIdx.x; i < k.NZP; i += 64) sof[i] = k.ofz[(long)mode * k.NZP + i];
-    __syncthreads();
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    if (j >= k.ny - 1) return;
-    if (k.twist) thomas_twisted<cplx, double, true>(k.y + (long)s * k.vstride + j, k.invp + (long)s * k.vstride + j, sof, k.nz - 1, k.NYP);
-    else thomas_twisted<cplx, double, false>(k.y + (long)s * k.vstride + j, k.invp + (long)s * k.vstride + j, sof, k.nz - 1, k.NYP);
-}
-
-__global__ __launch_bounds__(64) void k_thomas32(Solver k) {
-    const int s = blockIdx.y;
-    if (!k.active[s]) return;
-    __shared__ float sof[MAXNZP];
-    const int mode = s >= k.nFreq;
-    for (int i = threadIdx.x; i < k.NZP; i += 64) sof[i] = (float)k.ofz[(long)mode * k.NZP + i];
-    __syncthreads();
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    if (j >= k.ny - 1) return;
-    if (k.twist) thomas_twisted<c32, float, true>(reinterpret_cast<c32*>(k.y32) + (long)s * k.vstride + j,
-                                                   reinterpret_cast<const c32*>(k.invp32) + (long)s * k.vstride + j, sof, k.nz - 1, k.NYP);
-    else thomas_twisted<c32, float, false>(reinterpret_cast<c32*>(k.y32) + (long)s * k.vstride + j,
-                                            reinterpret_cast<const c32*>(k.invp32) + (long)s * k.vstride + j, sof, k.nz - 1, k.NYP);
-}
-
-// ---- symmetric Jacobi / FDM / Jacobi combination (default preconditioner):
-//   z0 = wJ D^-1 r ; z1 = z0 + F (r - A z0) ; z = z1 + wJ D^-1 (r - A z1)
-// point Jacobi removes the cell-scale coefficient contrast the laterally averaged FDM background
-// cannot see; both factors are complex symmetric, so the product form above is too (COCG needs that).
-__device__ __forceinline__ cplx stencil_at(const Solver& k, const cplx* u, long mo, long e, double w) {
-    const cplx c = u[e];
-    const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
-    cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
-    acc += k.cY[mo + e] * u[e + 1];
-    acc += k.cY[mo + e - 1] * u[e - 1];
-    acc += k.cZ[mo + e] * u[e + k.NYP];
-    acc += k.cZ[mo + e - k.NYP] * u[e - k.NYP];
-    return acc;
-}
-
-__global__ __launch_bounds__(VBLOCK) void k_dinv(Solver k, double wJ) {
-    const int s = blockIdx.y;
-    const int mode = s >= k.nFreq;
-    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
-    const double w = k.omega[s];
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
-        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
-        cplx d = cplx{0, 0};
-        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) d = wJ / cplx{k.dK[mo + e], w * k.dM[mo + e]};
-        k.dinv[so + e] = d;
-    }
-}
-
-// t = r - A (dinv .* r)
-__global__ __launch_bounds__(VBLOCK) void k_pre(Solver k) {
-    const int s = blockIdx.y;
-    if (!k.active[s]) return;
-    const int mode = s >= k.nFreq;
-    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
-    const double w = k.omega[s];
-    const cplx *r = k.r + so, *di = k.dinv + so;
-    cplx* t = k.t + so;
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
-        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
-        cplx out = cplx{0, 0};
-        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
-            const cplx c = di[e] * r[e];
-            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
-            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
-            acc += k.cY[mo + e] * (di[e + 1] * r[e + 1]);
-            acc += k.cY[mo + e - 1] * (di[e - 1] * r[e - 1]);
-            acc += k.cZ[mo + e] * (di[e + k.NYP] * r[e + k.NYP]);
-            acc += k.cZ[mo + e - k.NYP] * (di[e - k.NYP] * r[e - k.NYP]);
-            out = r[e] - acc;
-        }
-        t[e] = out;
-    }
-}
-
-// z += dinv .* r
-__global__ __launch_bounds__(VBLOCK) void k_mid(Solver k) {
-    const int s = blockIdx.y;
-    if (!k.active[s]) return;
-    const long so = (long)s * k.vstride;
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) k.z[so + e] += k.dinv[so + e] * k.r[so + e];
-}
-
-// t = z + dinv .* (r - A z) ; partA = r't ; partZZ = |t|^2     (t becomes the preconditioned residual)
-__global__ __launch_bounds__(VBLOCK) void k_post(Solver k, double* partZZ) {
-    const int s = blockIdx.y;
-    if (!k.active[s]) return;
-    __shared__ double sh[8];
-    __shared__ double sh2[8];
-    const int mode = s >= k.nFreq;
-    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
-    const double w = k.omega[s];
-    const cplx *r = k.r + so, *z = k.z + so, *di = k.dinv + so;
-    cplx* t = k.t + so;
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    double ar = 0, ai = 0, zz = 0, dummy = 0;
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
-        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
-        cplx out = cplx{0, 0};
-        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
-            const cplx rv = r[e];
-            out = z[e] + di[e] * (rv - stencil_at(k, z, mo, e, w));
-            ar += rv.re * out.re - rv.im * out.im;
-            ai += rv.re * out.im + rv.im * out.re;
-            zz += cabs2(out);
-        }
-        t[e] = out;
-    }
-    block_sum2(ar, ai, sh);
-    block_sum2(zz, dummy, sh2);
-    if (threadIdx.x == 0) {
-        k.partA[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
-        partZZ[(long)s * MAXNB + blockIdx.x] = zz;
-    }
-}
-
-// ----------------------------------------------------------------------------------------------
-// Mixed-precision FDM stage.  COCG keeps x, r, p and every inner product in fp64; the preconditioner
-// only proposes search directions, and running its separable part with bf16 transform operands
-// (fp32 accumulation) and a complex64 tridiagonal solve leaves the iteration counts unchanged
-// (measured: identical to within +-1 iteration, same final error).  It moves the transforms from the
-// 78 TF FP64 matrix pipe to the 2.5 PF BF16 pipe and shrinks the stage's traffic 2-4x.
-//
-// v_mfma_f32_16x16x32_bf16 (gfx950; 16 cycles per instruction vs 32 for the older 16x16x16 form) layout:
-//   A[i = lane%16][k = 8*(lane/16) + t], B[k = 8*(lane/16) + t][j = lane%16], D[i = 4*(lane/16) + r][j = lane%16]
-// (D and the 16x16x16 operand layout measured with scripts/probe/mfma_bf16_layout.hip).
-// Tile row 2c+part = part (re/im) of complex row c, so a lane's four results are two complete complex
-// numbers.  K is consumed 32 at a time, k = 32*kg + 8*(lane/16) + i, i.e. 8 contiguous complex per lane;
-// V is pre-swizzled to
-//   Bsw[((kg*NT + t)*64 + lane)*8 + i] = bf16(V[32*kg + 8*(lane/16) + i][16*t + lane%16]), zero for k >= NYP.
-// ----------------------------------------------------------------------------------------------
-typedef short s4v __attribute__((ext_vector_type(4)));
-typedef float f4v __attribute__((ext_vector_type(4)));
-typedef unsigned u4v __attribute__((ext_vector_type(4)));
-typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ unsigned bf16_rn(float x) {           // round-to-nearest-even, finite inputs
-    const unsigned u = __float_as_uint(x);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ unsigned pack_bf16(double re, double im) {
-    return bf16_rn((float)re) | (bf16_rn((float)im) << 16);
-}
-
-constexpr int KCH = 7;             // k-groups (of 32) whose operands are requested together (all of K up to NYP = 224)
-constexpr int LP_NTW = 2;          // column tiles per wave of the mixed-precision transform: many light waves hide latency
-
-__device__ __forceinline__ float bf16_to_f32(unsigned h) { return __uint_as_float(h << 16); }
-
-// A: complex64 rows.  Every value is split in registers into hi = bf16(x), lo = bf16(x - hi) and the
-// product is accumulated as Ah*Bh + Ah*Bl + Al*Bh (fp32 accumulators): ~16 mantissa bits, i.e. fp32-class
-// accuracy from the bf16 pipe.  (Plain bf16 operands stalled one low-frequency TE system in 32.)
-// B: Bhi/Blo fragment arrays.  OUT: 0 = complex64, 1 = fp64 complex, 2 = fp64 complex + dinv*r (fused
-// first half of the post-smoother).
-constexpr int LP_NRG = 2;          // row groups (of 8 complex rows) a workgroup transforms per pass
-constexpr int LP_KC = 4;           // k-groups requested together
-
-// A-operand fragments of LP_NRG row groups starting at row m0, staged in LDS by the whole workgroup in fragment order:
-//   ast[((rg*KG + kg)*2 + hl)*64 + lane] = the 8 bf16 (hi or lo) lane `lane` feeds the MFMA for row group rg, k-group kg.
-// Every wave of the workgroup multiplies the same rows with its own column tiles, so the rows are fetched (and, for
-// complex64 input, split into bf16 hi/lo) once per workgroup instead of once per wave.
-template <int FMT>       // FMT 0: A is complex64 (split here); 1: A is pre-split (store_t32)
-__device__ __forceinline__ void stage_lp_fragments(u4v* __restrict__ ast, const float2* __restrict__ Ain, int M, int NYP, int m0) {
-    const int KG = (NYP + 31) >> 5;
-    for (int i = threadIdx.x; i < LP_NRG * KG * 64; i += blockDim.x) {
-        const int l = i & 63, kg = (i >> 6) % KG, rg = (i >> 6) / KG;
-        const int lj = l & 15, g = l >> 4, part = lj & 1;
-        const int arow = min(m0 + 8 * rg + (lj >> 1), M - 1);
-        u4v ahu, alu;
-        if (FMT) {
-            const u4v* hp = reinterpret_cast<const u4v*>(reinterpret_cast<const unsigned short*>(Ain) +
-                                                         (long)arow * 4 * NYP + part * NYP + 32 * kg + 8 * g);
-            ahu = hp[0]; alu = hp[NYP / 4];                  // the lo planes start 2*NYP bf16 = NYP/4 x 16 B later
-        } else {
-            const f4v* ap = reinterpret_cast<const f4v*>(Ain + (long)arow * NYP + 32 * kg + 8 * g);   // 8 complex = 64 B
-            unsigned hh[8], ll[8];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f4v v = ap[q];
-                const float x0 = part ? v[1] : v[0], x1 = part ? v[3] : v[2];
-                hh[2 * q] = bf16_rn(x0); ll[2 * q] = bf16_rn(x0 - bf16_to_f32(hh[2 * q]));
-                hh[2 * q + 1] = bf16_rn(x1); ll[2 * q + 1] = bf16_rn(x1 - bf16_to_f32(hh[2 * q + 1]));
-            }
-            ahu = u4v{hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16)};
-            alu = u4v{ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16)};
-        }
-        ast[((rg * KG + kg) * 2 + 0) * 64 + l] = ahu;
-        ast[((rg * KG + kg) * 2 + 1) * 64 + l] = alu;
-    }
-}
-
-template <int NTW, int OUT>
-__device__ __forceinline__ void transform_lp_body(const u4v* __restrict__ ast, const u4v* __restrict__ Bhi,
-                                                  const u4v* __restrict__ Blo, void* __restrict__ Cout,
-                                                  const cplx* __restrict__ dinv, const cplx* __restrict__ rvec,
-                                                  int M, int NYP, int m0, int t0, int lane) {
-    const int NT = NYP >> 4, KG = (NYP + 31) >> 5;
-    const int lj = lane & 15, g = lane >> 4;
-    f4v acc[LP_NRG][NTW];
-#pragma unroll
-    for (int rg = 0; rg < LP_NRG; ++rg)
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
-    for (int kc = 0; kc < KG; kc += LP_KC) {
-        u4v ahs[LP_NRG][LP_KC], als[LP_NRG][LP_KC];
-        u4v bh[LP_KC][NTW], bl[LP_KC][NTW];
-#pragma unroll
-        for (int q = 0; q < LP_KC; ++q) {
-            const int kg = min(kc + q, KG - 1);
-#pragma unroll
-            for (int rg = 0; rg < LP_NRG; ++rg) {
-                ahs[rg][q] = ast[((rg * KG + kg) * 2 + 0) * 64 + lane]; als[rg][q] = ast[((rg * KG + kg) * 2 + 1) * 64 + lane];
-            }
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-                const long bi = ((long)kg * NT + t0 + t) * 64 + lane;
-                bh[q][t] = Bhi[bi]; bl[q][t] = Blo[bi];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < LP_KC; ++q) {
-            if (kc + q < KG) {
-                // v_mfma_f32_16x16x32_bf16: A[i = lane%16][k = 8*(lane/16) + t], t = 0..7 -- exactly a lane's 8 staged values
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) {
-                    const bf8v bhf = __builtin_bit_cast(bf8v, bh[q][t]), blf = __builtin_bit_cast(bf8v, bl[q][t]);
-#pragma unroll
-                    for (int rg = 0; rg < LP_NRG; ++rg) {
-                        const bf8v ah = __builtin_bit_cast(bf8v, ahs[rg][q]), al = __builtin_bit_cast(bf8v, als[rg][q]);
-                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
-                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blf, acc[rg][t], 0, 0, 0);
-                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    }
-    // D rows 4g+r: (re, im) of complex rows 2g and 2g+1 of a group, column 16*(t0+t) + lj
-#pragma unroll
-    for (int rg = 0; rg < LP_NRG; ++rg)
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const long col = (long)(t0 + t) * 16 + lj;
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const int row = m0 + 8 * rg + 2 * g + h2;
-                if (row < M) {
-                    const long e = (long)row * NYP + col;
-                    const float re = acc[rg][t][2 * h2], im = acc[rg][t][2 * h2 + 1];
-                    if (OUT == 0) reinterpret_cast<float2*>(Cout)[e] = float2{re, im};
-                    else if (OUT == 1) reinterpret_cast<cplx*>(Cout)[e] = cplx{(double)re, (double)im};
-                    else reinterpret_cast<cplx*>(Cout)[e] = cplx{(double)re, (double)im} + dinv[e] * rvec[e];
-                }
-            }
-        }
-}
-
-template <int OUT, int FMT>
-__global__ __launch_bounds__(512) void k_transform_lp(const float2* __restrict__ A, const u4v* __restrict__ Bhi,
-                                                       const u4v* __restrict__ Blo, void* __restrict__ C,
-                                                       const cplx* __restrict__ dinv, const cplx* __restrict__ rvec,
-                                                       int M, int NYP, int rowsPerSys, const int* __restrict__ active, int NW) {
-    extern __shared__ __attribute__((aligned(16))) char smem_lp[];
-    u4v* ast = reinterpret_cast<u4v*>(smem_lp);
-    const int lane = threadIdx.x & 63, nw = threadIdx.x >> 6;
-    const int m0 = blockIdx.x * 8 * LP_NRG;                 // one set of LP_NRG row groups per workgroup, all waves on it
-    if (m0 >= M) return;
-    if (active) {
-        const int s0 = m0 / rowsPerSys, s1 = min(m0 + 8 * LP_NRG - 1, M - 1) / rowsPerSys;
-        bool any = false;
-        for (int sy = s0; sy <= s1; ++sy) any = any || active[sy];
-        if (!any) return;
-    }
-    stage_lp_fragments<FMT>(ast, A, M, NYP, m0);
-    __syncthreads();
-    const int NT = NYP >> 4;
-    const int base = NT / NW, extra = NT % NW;
-    const int ntl = base + (nw < extra ? 1 : 0);
-    const int t0 = nw * base + min(nw, extra);
-    // two column tiles at a time (a wave owns more than two only on meshes wider than 256 nodes)
-    for (int tt = 0; tt < ntl; tt += 2) {
-        if (ntl - tt >= 2) transform_lp_body<2, OUT>(ast, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0 + tt, lane);
-        else transform_lp_body<1, OUT>(ast, Bhi, Blo, C, dinv, rvec, M, NYP, m0, t0 + tt, lane);
-    }
-}
-
-// ---- pre-split transform operands (fused forward path).  The bf16 hi/lo split of a transform input is the
-// same for every workgroup that reads the row (7 slab workgroups in k_fdm_fwd, 7 waves in k_transform_lp), so
-// the producing kernel does it once: a row of NYP complex64 values (8 B each) is stored instead as four
-// planes of NYP bf16 -- hi(re), hi(im), lo(re), lo(im) -- in the same 8 NYP bytes.  A lane's MFMA A-operand
-// (8 consecutive k of one part) is then one 16-byte load per hi / lo, with no conversion work.
-__device__ __forceinline__ void store_t32(const Solver& k, float2* tsys, int row, int iy, float re, float im) {
-    if (!k.splitT) { tsys[(long)row * k.NYP + iy] = float2{re, im}; return; }
-    unsigned short* b = reinterpret_cast<unsigned short*>(tsys) + (long)row * 4 * k.NYP + iy;
-    const unsigned hr = bf16_rn(re), hi = bf16_rn(im);
-    b[0] = (unsigned short)hr; b[k.NYP] = (unsigned short)hi;
-    b[2 * k.NYP] = (unsigned short)bf16_rn(re - bf16_to_f32(hr));
-    b[3 * k.NYP] = (unsigned short)bf16_rn(im - bf16_to_f32(hi));
-}
-
-// ----------------------------------------------------------------------------------------------
-// Forward half of the mixed-precision FDM stage in ONE kernel: Y = T V for a slab of 16 eigen-modes of one
-// system (all rows; split-bf16 MFMA as above), then the complex64 tridiagonal solves of those 16 modes with
-// the slab resident in LDS, then the coalesced write of the solved slab.  Replaces k_transform_lp<0> +
-// k_thomas32 (one launch, no round trip of Y through global memory, and the serial sweeps read LDS).
-// The recurrences are pre-multiplied off the serial chain by the MFMA waves:
-//   a = y*ip, b = sof[row-1]*ip, c = sof[row]*ip   (ip = inverse pivot, sof = z off-diagonal)
-//   down: x_row = a_row - b_row x_{row-1}  (rows 1..n);  up: x_row = x_row - c_row x_{row+1}  (rows n-1..1)
-// so each serial step is one complex multiply-subtract (two dependent FMAs).
-// LDS: sof[NZP] floats (padded to 128 B) + 3 slabs [NZP][16] complex64.
-// ----------------------------------------------------------------------------------------------
-constexpr int FW_TB = 8;           // rows requested ahead of the serial chain
-constexpr int FW_PRE = 8;          // inverse pivots per thread requested at kernel entry
-#ifndef HMCMT_FW_NTW
-#define HMCMT_FW_NTW 2
-#endif
-constexpr int FW_NTW = HMCMT_FW_NTW; // column tiles per slab: 2 -> 32 modes, ceil(NT/2)*S workgroups (224 at cfg3: one round on 256 CUs)
-
-template <int NTW>                 // column tiles (of 16 modes) per slab
-__global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restrict__ A, const u4v* __restrict__ Bhi,
-                                                 const u4v* __restrict__ Blo, const float2* __restrict__ ip32,
-                                                 float2* __restrict__ Y, long long* stamps = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // 1-D grid of nslab*S workgroups.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has
-    // its own L2: all slabs of a system are placed on ONE XCD so that system's rows are fetched into one L2 once
-    const int nslab = ((k.NYP >> 4) + NTW - 1) / NTW;
-    int s, slab;
-    if ((k.S & 7) == 0) { const int q = blockIdx.x >> 3; s = (q / nslab) * 8 + (blockIdx.x & 7); slab = q % nslab; }
-    else { s = blockIdx.x / nslab; slab = blockIdx.x % nslab; }
-    if (!k.active[s]) return;
-    const int NYP = k.NYP, NZP = k.NZP, n = k.nz - 1;
-    constexpr int SW = 16 * NTW;
-#define FW_STAMP(i) if (stamps && threadIdx.x == 0) stamps[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();
-    FW_STAMP(0)
-    // LDS: sof[NZP] (padded to 128 B), the join factors sj[SW], then three slabs sa / sb / sc.  A slab consists of
-    // one region (classic sweep) or two (twisted factorisation, k.twist): region 0 holds matrix rows 0..mid in
-    // order, region 1 holds rows n+1, n, .., mid+1 -- MIRRORED, so that both halves of the factorisation walk
-    // their region in the same direction and one instruction stream serves the top chain (lanes 0..SW-1) and the
-    // bottom chain (lanes SW..2SW-1) of the sweeping wave.  Every region has 2 FW_TB padding rows in front and
-    // behind (the inner FW_TB initialised): the sweeps run whole blocks of FW_TB rows without conditionals.
-    const int tw = k.twist, mid = twist_mid(n, tw);
-    const int RCAP = tw ? mid + 1 : NZP, RL = RCAP + 4 * FW_TB, nreg = tw ? 2 : 1;
-    float* sof = reinterpret_cast<float*>(smem);
-    c32* sj = reinterpret_cast<c32*>(smem + (((long)NZP * 4 + 127) & ~127L));
-    c32* sa = sj + SW + 2 * FW_TB * SW;                  // -> region 0, row 0
-    c32* sb = sa + (long)nreg * RL * SW;
-    c32* sc = sb + (long)nreg * RL * SW;
-    auto lidx = [&](int row) { return (tw && row > mid) ? RL + (n + 1 - row) : row; };   // slab row of a matrix row
-    const int mode = s >= k.nFreq;
-    for (int i = threadIdx.x; i < NZP; i += blockDim.x) sof[i] = (float)k.ofz[(long)mode * NZP + i];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    const int NT = NYP >> 4, KG = (NYP + 31) >> 5;
-    const int t0 = slab * NTW;                         // first column tile of this slab
-    // The slab's V fragments (hi and lo, all k-groups) are needed by every wave: staged once in LDS (in the space of
-    // sb / sc, which are not written before the transform is over) instead of 7 times through the vector L1.
-    // vst[((kg*NTW + t)*2 + hl)*64 + lane]
-    u4v* vst = reinterpret_cast<u4v*>(sb - 2 * FW_TB * SW);
-    const bool stageV = (size_t)KG * NTW * 2 * 64 * sizeof(u4v) <= (size_t)2 * nreg * RL * SW * sizeof(c32);
-    if (stageV)
-        for (int i = threadIdx.x; i < KG * NTW * 2 * 64; i += blockDim.x) {
-            const int l = i & 63, hl = (i >> 6) & 1, t = (i >> 7) % NTW, kg = (i >> 7) / NTW;
-            const long bi = ((long)kg * NT + min(t0 + t, NT - 1)) * 64 + l;
-            vst[i] = hl ? Blo[bi] : Bhi[bi];
-        }
-    __syncthreads();
-    const int lj = lane & 15, g = lane >> 4, part = lj & 1;
-    const long so = (long)s * k.vstride;
-    const float2* As = A + so;
-    // this thread's inverse pivots of the pre-multiplication pass, requested now so that their latency hides
-    // behind the transform
-    float2 ipv[FW_PRE];
-#pragma unroll
-    for (int e = 0; e < FW_PRE; ++e) {
-        const int idx = threadIdx.x + e * blockDim.x;
-        const int row = idx / SW, c = t0 * 16 + (idx % SW);
-        ipv[e] = (idx < NZP * SW && row >= 1 && row <= n && c < k.ny - 1) ? ip32[so + (long)row * NYP + c] : float2{0.f, 0.f};
-    }
-    // Two row groups per pass (this wave's group and the one nwave groups further down): the V fragments of a
-    // k-group are loaded once for both, and the four accumulator chains keep the MFMA pipe busier than two.
-    constexpr int KC = 4;                                  // k-groups requested together
-    for (int m0 = wave * 8; m0 < NZP; m0 += 2 * nwave * 8) {
-        const int m1 = m0 + nwave * 8;                     // second row group (may lie beyond the last row: clamped, not stored)
-        const int arow[2] = {min(m0 + (lj >> 1), NZP - 1), min(m1 + (lj >> 1), NZP - 1)};
-        f4v acc[2][NTW];
-#pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
-        for (int kc = 0; kc < KG; kc += KC) {
-            u4v ahs[2][KC], als[2][KC];                // pre-split input (store_t32): one 16-byte load per hi / lo
-            u4v bh[KC][NTW], bl[KC][NTW];
-#pragma unroll
-            for (int q = 0; q < KC; ++q) {
-                const int kg = min(kc + q, KG - 1);
-#pragma unroll
-                for (int rg = 0; rg < 2; ++rg) {
-                    const u4v* hp = reinterpret_cast<const u4v*>(reinterpret_cast<const unsigned short*>(As) +
-                                                                 (long)arow[rg] * 4 * NYP + part * NYP + 32 * kg + 8 * g);
-                    ahs[rg][q] = hp[0]; als[rg][q] = hp[NYP / 4];
-                }
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) {
-                    if (stageV) {
-                        bh[q][t] = vst[((kg * NTW + t) * 2 + 0) * 64 + lane]; bl[q][t] = vst[((kg * NTW + t) * 2 + 1) * 64 + lane];
-                    } else {
-                        const long bi = ((long)kg * NT + min(t0 + t, NT - 1)) * 64 + lane;
-                        bh[q][t] = Bhi[bi]; bl[q][t] = Blo[bi];
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < KC; ++q) {
-                if (kc + q < KG) {
-#pragma unroll
-                    for (int t = 0; t < NTW; ++t) {
-                        const bf8v bhf = __builtin_bit_cast(bf8v, bh[q][t]), blf = __builtin_bit_cast(bf8v, bl[q][t]);
-#pragma unroll
-                        for (int rg = 0; rg < 2; ++rg) {
-                            const bf8v ah = __builtin_bit_cast(bf8v, ahs[rg][q]), al = __builtin_bit_cast(bf8v, als[rg][q]);
-                            acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
-                            acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blf, acc[rg][t], 0, 0, 0);
-                            acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        }
-        // D rows 4g+r: (re, im) of complex rows 2g and 2g+1 of a group, column 16 t + lj of the slab
-#pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-            for (int t = 0; t < NTW; ++t)
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    const int row = (rg ? m1 : m0) + 2 * g + h2;
-                    if (row < NZP) sa[lidx(row) * SW + t * 16 + lj] = c32{acc[rg][t][2 * h2], acc[rg][t][2 * h2 + 1]};
-                }
-    }
-    __syncthreads();
-    FW_STAMP(1)
-    // Pre-multiply the recurrences (kept apart from the MFMA waves' epilogue on purpose: computing these products
-    // right behind the last MFMA gave sporadically wrong values on gfx950).  With ip the inverse
-    // pivot and o_r the off-diagonal between rows r and r+1:  a = y*ip, and the coefficient of the elimination
-    // sweep p1 / of the substitution sweep p2 is  o_{r-1}*ip / o_r*ip  for a top row (swept downwards, then
-    // upwards) and  o_r*ip / o_{r-1}*ip  for a bottom row (swept upwards, then downwards).
-    auto premul = [&](int idx, float2 ipf) {
-        const int row = idx / SW, j = idx % SW, c = t0 * 16 + j;
-        const int l = lidx(row) * SW + j;
-        c32 p1 = c32{0, 0}, p2 = c32{0, 0};
-        if (row >= 1 && row <= n && c < k.ny - 1) {
-            const c32 ip = c32{ipf.x, ipf.y};
-            const c32 bb = sof[row - 1] * ip, cc = sof[row] * ip;
-            sa[l] = sa[l] * ip;
-            const bool bottom = tw && row > mid;
-            p1 = bottom ? cc : bb; p2 = bottom ? bb : cc;
-        }
-        sb[l] = p1; sc[l] = p2;
-    };
-#pragma unroll
-    for (int e = 0; e < FW_PRE; ++e) {
-        const int idx = threadIdx.x + e * blockDim.x;
-        if (idx < NZP * SW) premul(idx, ipv[e]);
-    }
-    for (int idx = threadIdx.x + FW_PRE * blockDim.x; idx < NZP * SW; idx += blockDim.x) {
-        const int row = idx / SW, c = t0 * 16 + (idx % SW);
-        premul(idx, (row >= 1 && row <= n && c < k.ny - 1) ? ip32[so + (long)row * NYP + c] : float2{0.f, 0.f});
-    }
-    // padding rows: in front of a region zeros (the substitution sweep runs into them: 0 - 0*x = 0); behind a
-    // region identity rows for the elimination sweep (a = 0, p1 = -1: x stays), zero p2
-    for (int idx = threadIdx.x; idx < nreg * FW_TB * SW; idx += blockDim.x) {
-        const int reg = idx / (FW_TB * SW), o = idx % (FW_TB * SW);
-        const c32 z = c32{0, 0};
-        const long front = (long)reg * RL * SW - (long)FW_TB * SW + o;
-        const int last = tw ? (reg == 0 ? mid : n + 1 - (mid + 1)) : NZP - 1;          // last initialised row of the region
-        const long back = ((long)reg * RL + last + 1) * SW + o;
-        sa[front] = z; sb[front] = z; sc[front] = z;
-        sa[back] = z; sb[back] = c32{-1.f, 0.f}; sc[back] = z;
-    }
-    if (threadIdx.x < SW) {                                 // join factor 1 / (1 - c c') of the two halves (item_pivot)
-        const int c = t0 * 16 + threadIdx.x;
-        const float2 jf = (tw && c < k.ny - 1) ? ip32[so + c] : float2{1.f, 0.f};
-        sj[threadIdx.x] = c32{jf.x, jf.y};
-    }
-    __syncthreads();
-    FW_STAMP(2)
-    if (wave == 0 && lane < nreg * SW && t0 * 16 + (lane % SW) < k.ny - 1) {
-        // rows are addressed from one moving base with compile-time offsets (no clamps: the padding rows absorb the
-        // blocks' overhang), so a step is 4 FMAs + 2 LDS reads + 1 LDS write
-        const int half = lane / SW, col = lane % SW;
-        const int last = tw ? (half == 0 ? mid : n - mid) : n;      // rows 1..last of this lane's region are real
-        const int steps = tw ? mid : n;                             // both halves run the longer count (identity rows)
-        c32* ra = sa + (long)half * RL * SW + col;
-        const c32* rb = sb + (long)half * RL * SW + col;
-        const c32* rc = sc + (long)half * RL * SW + col;
-        c32 pt = c32{0, 0};
-        // ---- elimination, region rows 1..steps.  Blocks of FW_TB rows, two register sets used alternately: while one
-        // block is swept, the next one is on its way from LDS (no register copies between blocks; the prefetch of the
-        // block behind the last one reads padding rows)
-        {
-            c32* pa = ra + SW;
-            const c32* pb = rb + SW;
-            c32 a0[FW_TB], b0[FW_TB], a1[FW_TB], b1[FW_TB];
-            const int nblk = (steps + FW_TB - 1) / FW_TB;
-#pragma unroll
-            for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[t * SW]; b0[t] = pb[t * SW]; }
-            int bk = 0;
-            for (; bk + 1 < nblk; bk += 2) {
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { a1[t] = pa[(FW_TB + t) * SW]; b1[t] = pb[(FW_TB + t) * SW]; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a0[t], b0[t], pt); pa[t * SW] = pt; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[(2 * FW_TB + t) * SW]; b0[t] = pb[(2 * FW_TB + t) * SW]; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a1[t], b1[t], pt); pa[(FW_TB + t) * SW] = pt; }
-                __builtin_amdgcn_sched_barrier(0);
-                pa += 2 * FW_TB * SW; pb += 2 * FW_TB * SW;
-            }
-            if (bk < nblk) {
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a0[t], b0[t], pt); pa[t * SW] = pt; }
-            }
-        }
-        // ---- join of the two halves: x_mid = (y'_mid - c y''_{mid+1}) J ;  x_{mid+1} = y''_{mid+1} - c' x_mid
-        pt = ra[last * SW];                                   // (the identity rows left it unchanged)
-        if (tw) {
-            const c32 p2last = rc[last * SW];
-            const float pre = pt.re, pim = pt.im;               // (plain floats: shuffling struct members kept pt in scratch)
-            const float ore = __shfl_xor(pre, SW), oim = __shfl_xor(pim, SW);
-            const c32 xmid = (c32{pre, pim} - p2last * c32{ore, oim}) * sj[col];       // meaningful in the top half
-            const float xre = xmid.re, xim = xmid.im;
-            const float mre = __shfl_xor(xre, SW), mim = __shfl_xor(xim, SW);
-            const c32 xbot = c32{pre, pim} - p2last * c32{mre, mim};
-            pt = half == 0 ? c32{xre, xim} : xbot;
-            ra[last * SW] = pt;
-        }
-        // ---- substitution, region rows last-1 .. 1 (rows in front of 1: zeros in, zeros out), same scheme downwards
-        {
-            c32* pa = ra + (long)(last - 1) * SW;
-            const c32* pc = rc + (long)(last - 1) * SW;
-            c32 a0[FW_TB], b0[FW_TB], a1[FW_TB], b1[FW_TB];
-            const int nblk = (steps - 1 + FW_TB - 1) / FW_TB;
-#pragma unroll
-            for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[-t * SW]; b0[t] = pc[-t * SW]; }
-            int bk = 0;
-            for (; bk + 1 < nblk; bk += 2) {
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { a1[t] = pa[-(FW_TB + t) * SW]; b1[t] = pc[-(FW_TB + t) * SW]; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a0[t], b0[t], pt); pa[-t * SW] = pt; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[-(2 * FW_TB + t) * SW]; b0[t] = pc[-(2 * FW_TB + t) * SW]; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a1[t], b1[t], pt); pa[-(FW_TB + t) * SW] = pt; }
-                __builtin_amdgcn_sched_barrier(0);
-                pa -= 2 * FW_TB * SW; pc -= 2 * FW_TB * SW;
-            }
-            if (bk < nblk) {
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a0[t], b0[t], pt); pa[-t * SW] = pt; }
-            }
-        }
-    }
-    FW_STAMP(3)
-    __syncthreads();
-    // solved slab -> Y, pre-split for the back transform (store_t32's format).  A thread converts 8 consecutive modes
-    // of a row and writes each of the four bf16 planes with one 16-byte store instead of 32 two-byte stores
-    // (16.0 -> 15.0 us per launch; the same idea in k_update_fused, through an LDS image of its tile: no gain).
-    if (k.splitT) {
-        constexpr int NG = SW / 8;
-        unsigned short* yb = reinterpret_cast<unsigned short*>(Y + so);
-        for (int idx = threadIdx.x; idx < NZP * NG; idx += blockDim.x) {
-            const int row = idx / NG, j0 = (idx % NG) * 8, c0 = t0 * 16 + j0;
-            if (c0 >= NYP) continue;
-            const c32* src = sa + lidx(row) * SW + j0;
-            u4v pl[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const c32 v0 = src[2 * q], v1 = src[2 * q + 1];
-                const unsigned r0 = bf16_rn(v0.re), i0 = bf16_rn(v0.im), r1 = bf16_rn(v1.re), i1 = bf16_rn(v1.im);
-                pl[0][q] = r0 | (r1 << 16);
-                pl[1][q] = i0 | (i1 << 16);
-                pl[2][q] = bf16_rn(v0.re - bf16_to_f32(r0)) | (bf16_rn(v1.re - bf16_to_f32(r1)) << 16);
-                pl[3][q] = bf16_rn(v0.im - bf16_to_f32(i0)) | (bf16_rn(v1.im - bf16_to_f32(i1)) << 16);
-            }
-            unsigned short* b = yb + (long)row * 4 * NYP + c0;
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) *reinterpret_cast<u4v*>(b + pp * NYP) = pl[pp];
-        }
-    } else {
-        for (int idx = threadIdx.x; idx < NZP * SW; idx += blockDim.x) {
-            const int row = idx / SW, j = idx % SW, c = t0 * 16 + j;
-            if (c < NYP) { const c32 v = sa[lidx(row) * SW + j]; store_t32(k, Y + so, row, c, v.re, v.im); }
-        }
-    }
-    FW_STAMP(4)
-}
-
-// ----------------------------------------------------------------------------------------------
-// Back half of the mixed-precision FDM stage fused with BOTH Jacobi halves of the post-smoother:
-//   z = V y + dinv .* r   (split-bf16 MFMA, as k_transform_lp<2>)      on a tile of 16 rows kept in LDS
-//   t = z + dinv .* (r - A z), partial r't and |t|^2                   on the tile's 14 inner rows
-// One workgroup = 14 consecutive interior rows of one system plus one halo row on each side (two MFMA row
-// groups); the halo rows are transformed twice (by the neighbouring workgroups too: +14 % transform work) in
-// exchange for one launch less per iteration and no round trip of z through global memory.
-// Replaces k_transform_lp<2> + k_post on the fused path.
-// ----------------------------------------------------------------------------------------------
-constexpr int BP_OWN = 14;         // interior rows owned by a workgroup (tile = BP_OWN + 2 = two 8-row MFMA groups)
-
-template <int FMT>
-__global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __restrict__ Y, const u4v* __restrict__ Bhi,
-                                                   const u4v* __restrict__ Blo, double* partZZ, int NW, long long* stamps) {
-    extern __shared__ __attribute__((aligned(16))) char smem_[];
-    const int s = blockIdx.y, bx = blockIdx.x, nwg = gridDim.x;
-    const int act = k.active[s];       // tested below, after the first loads are on their way
-#define BP_STAMP(i) if (stamps && threadIdx.x == 0) stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime();
-    BP_STAMP(0)
-    const int bd = NW << 6;            // = blockDim.x, from the kernel argument (a scalar; the implicit-argument load is a vector load here)
-    __shared__ double sh[24];
-    cplx* zt = reinterpret_cast<cplx*>(smem_);             // [16][NYP]
-    const int NYP = k.NYP, NZP = k.NZP;
-    const int iz0 = 1 + bx * BP_OWN, iz1 = min(iz0 + BP_OWN - 1, k.nz - 1), rbase = iz0 - 1;
-    const int mode = s >= k.nFreq;
-    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
-    const double w = k.omega[s];
-    const cplx *r = k.r + so, *di = k.dinv + so;
-    cplx* t = k.t + so;
-    const int nown = (iz1 - iz0 + 1) * NYP;
-    // Every phase below is a short dependent chain (global load -> LDS -> barrier -> MFMA -> LDS -> barrier -> stencil),
-    // so loads are issued as early as their addresses are known and unconditionally (clamped indices): inside
-    // `if (row < NZP)` / `if (interior)` the compiler keeps each load next to its use and the phase costs one
-    // memory round trip per element instead of one per batch (s_memtime stamps: epilogue 3.5 -> us, stencil 4.7 -> us).
-    constexpr int SU = 4;               // stencil elements per thread and batch
-    struct Sten { double dk, dm, cy0, cy1, cz0, cz1; cplx rv, dv; int e, iy; };
-    // (uniform base + 32-bit lane offset: one address register per element instead of two per load)
-    const double *dKm = k.dK + mo, *dMm = k.dM + mo, *cYm = k.cY + mo, *cZm = k.cZ + mo, *cZu = k.cZ + mo - NYP;
-    const float rNYP = 1.0f / (float)NYP;
-    auto ld_st = [&](int i, Sten& q) {
-        const int ic = min(i, nown - 1), lr = (int)(((float)ic + 0.5f) * rNYP);      // ic / NYP (exact: ic < 4096)
-        q.iy = ic - lr * NYP;
-        q.e = (iz0 + lr) * NYP + q.iy;
-        const unsigned e = (unsigned)q.e;
-        q.dk = dKm[e]; q.dm = dMm[e];
-        q.cy0 = cYm[e]; q.cy1 = cYm[e - 1u];
-        q.cz0 = cZm[e]; q.cz1 = cZu[e];
-        q.rv = r[e]; q.dv = di[e];
-    };
-    Sten st[SU], st2[SU];           // 14 NYP <= 8 x blockDim elements: two batches per thread
-    {
-        // both row groups of the tile in one pass over k: a wave's V fragments are loaded once for the two groups
-        const int lane = threadIdx.x & 63, nw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: tile ranges uniform
-        const int NT = NYP >> 4, KG = (NYP + 31) >> 5;
-        const int base = NT == 2 * NW ? 2 : 1, extra = NT - base * NW;      // NW = ceil(NT / 2) waves: no division
-        const int ntl = base + (nw < extra ? 1 : 0);
-        const int t0 = nw * base + min(nw, extra);
-        const int lj = lane & 15, g = lane >> 4;
-        const float2* Ys = Y + so;
-        constexpr int KC = 8;
-        // epilogue operands dinv, r of the wave's 2 x 2 x 2 accumulator elements per lane
-        cplx dv[2][2][2], rv[2][2][2];
-        auto ld_dr = [&]() {
-#pragma unroll
-            for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    // row = rbase + 8 rg + h2 (uniform) + 2 g (lane), clamped to the mesh (those elements are zeroed below)
-                    const int ru = min(rbase + 8 * rg + h2, NZP - 1);
-                    const unsigned lo = (unsigned)(min(2 * g, NZP - 1 - ru) * NYP + lj);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const long ub = (long)ru * NYP + min(t0 + t, NT - 1) * 16;
-                        dv[rg][t][h2] = (di + ub)[lo]; rv[rg][t][h2] = (r + ub)[lo];
-                    }
-                }
-        };
-        // The tile's 16 rows of y are the A-operand of every wave: staged once in LDS in fragment order
-        // (ast[((rg*KG + kg)*2 + hl)*64 + lane] = what lane `lane` feeds the MFMA for row group rg, k-group kg)
-        // instead of 7 times through the vector L1.  nast = 256 KG <= 4 x blockDim elements: one batch of 4 per thread.
-        // Wave kg stages k-group kg (the launcher starts NW = KG waves): its 4 fragments (row group, hi/lo).
-        u4v* ast = reinterpret_cast<u4v*>(zt + (long)16 * NYP);
-        constexpr int SG = 4;
-        u4v tmp[SG];
-        {
-            const int llj = lane & 15, lg = lane >> 4;
-            const char* yb = reinterpret_cast<const char*>(Ys) + (long)(32 * nw) * 2;       // uniform part (k-group)
-#pragma unroll
-            for (int u = 0; u < SG; ++u) {
-                const int rg = u >> 1, hl = u & 1;
-                const int arow = min(rbase + 8 * rg + (llj >> 1), NZP - 1);
-                const unsigned off = (unsigned)(((arow * 4 + (llj & 1) + 2 * hl) * NYP + 8 * lg) * 2);   // bytes (bf16 planes re, im, re_lo, im_lo)
-                tmp[u] = *reinterpret_cast<const u4v*>(yb + off);
-            }
-        }
-        // all V fragments of the wave's (at most) two column tiles: KG <= KC k-groups (NYP <= 256, checked by the
-        // launcher).  Issued behind the staging loads and in k order: the staging barrier does not wait for them and
-        // the MFMAs of k-group q start when fragment q has arrived.
-        // Order matters twice.  (1) The vector memory path of a CU serves the requests of all its waves in order, so
-        // one wave's V loads would sit in front of another wave's staging loads and the staging barrier would wait for
-        // (nearly) all of V: a barrier makes sure every wave has issued its staging loads first.  (2) Every workgroup
-        // streams the same V; the 32 workgroups of an XCD (one tile index, 32 systems) start at different k-groups so
-        // that they are on different L2 channels instead of all asking for the same lines at once.
-        __syncthreads();
-        u4v bh[KC][2], bl[KC][2];
-        const int rot = s % KG;
-        {
-            const unsigned loff = (unsigned)lane * 16u;
-            const int tl0 = min(t0, NT - 1), tl1 = min(t0 + 1, NT - 1);
-            const char* ph = reinterpret_cast<const char*>(Bhi + (long)tl0 * 64) + loff;
-            const char* pl = reinterpret_cast<const char*>(Blo + (long)tl0 * 64) + loff;
-            const long d1 = (long)(tl1 - tl0) * 1024, stride = (long)NT * 1024;   // bytes: second tile, next k-group
-#pragma unroll
-            for (int q = 0; q < KC; ++q) {
-                if (q < KG) {
-                    const int kg = rot + q - (rot + q >= KG ? KG : 0);
-                    const char *qh = ph + kg * stride, *ql = pl + kg * stride;
-                    bh[q][0] = *reinterpret_cast<const u4v*>(qh); bh[q][1] = *reinterpret_cast<const u4v*>(qh + d1);
-                    bl[q][0] = *reinterpret_cast<const u4v*>(ql); bl[q][1] = *reinterpret_cast<const u4v*>(ql + d1);
-                }
-            }
-        }
-        BP_STAMP(7)
-        if (!act) return;                                  // (uniform; nothing has been stored yet)
-#pragma unroll
-        for (int u = 0; u < SG; ++u) ast[(((u >> 1) * KG + nw) * 2 + (u & 1)) * 64 + lane] = tmp[u];
-        __syncthreads();
-        BP_STAMP(1)
-        ld_dr();                                             // in flight during the MFMA loop
-        f4v acc[2][2];
-#pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < KC; ++q) {
-            if (q < KG) {
-                const int kg = rot + q - (rot + q >= KG ? KG : 0);
-                bf8v ah[2], al[2];
-#pragma unroll
-                for (int rg = 0; rg < 2; ++rg) {
-                    ah[rg] = __builtin_bit_cast(bf8v, ast[((rg * KG + kg) * 2 + 0) * 64 + lane]);
-                    al[rg] = __builtin_bit_cast(bf8v, ast[((rg * KG + kg) * 2 + 1) * 64 + lane]);
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const bf8v bhf = __builtin_bit_cast(bf8v, bh[q][t]), blf = __builtin_bit_cast(bf8v, bl[q][t]);
-#pragma unroll
-                    for (int rg = 0; rg < 2; ++rg) {
-                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rg], bhf, acc[rg][t], 0, 0, 0);
-                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rg], blf, acc[rg][t], 0, 0, 0);
-                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rg], bhf, acc[rg][t], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        BP_STAMP(2)
-        // coefficients of the first stencil batch: in flight during the epilogue and the barrier
-#pragma unroll
-        for (int u = 0; u < SU; ++u) ld_st(threadIdx.x + u * bd, st[u]);
-        // z = V y + dinv .* r into the tile (rows beyond the mesh: zero)
-#pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (t < ntl) {
-                    const int col = (t0 + t) * 16 + lj;
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const int lr = 8 * rg + 2 * g + h2;
-                        cplx val = cplx{(double)acc[rg][t][2 * h2], (double)acc[rg][t][2 * h2 + 1]} + dv[rg][t][h2] * rv[rg][t][h2];
-                        if (rbase + lr >= NZP) val = cplx{0.0, 0.0};
-                        zt[(long)lr * NYP + col] = val;
-                    }
-                }
-            }
-#pragma unroll
-        for (int u = 0; u < SU; ++u) ld_st(threadIdx.x + (SU + u) * bd, st2[u]);
-    }
-    BP_STAMP(3)
-    __syncthreads();
-    BP_STAMP(4)
-    double ar = 0, ai = 0, zz = 0;
-    auto stencil = [&](int i, const Sten& q) {
-        if (i < nown) {
-            const int l = q.e - (rbase * NYP);                 // tile-local index: tile row 0 = mesh row rbase
-            const cplx c = zt[l];
-            cplx acc = cplx{q.dk * c.re - w * q.dm * c.im, q.dk * c.im + w * q.dm * c.re};
-            acc += q.cy0 * zt[l + 1];
-            acc += q.cy1 * zt[l - 1];
-            acc += q.cz0 * zt[l + NYP];
-            acc += q.cz1 * zt[l - NYP];
-            cplx out = c + q.dv * (q.rv - acc);
-            if (q.iy < 1 || q.iy > k.ny - 1) out = cplx{0, 0};
-            ar += q.rv.re * out.re - q.rv.im * out.im;
-            ai += q.rv.re * out.im + q.rv.im * out.re;
-            zz += cabs2(out);
-            t[q.e] = out;
-        }
-    };
-#pragma unroll
-    for (int u = 0; u < SU; ++u) stencil(threadIdx.x + u * bd, st[u]);
-#pragma unroll
-    for (int u = 0; u < SU; ++u) stencil(threadIdx.x + (SU + u) * bd, st2[u]);
-    // the two boundary rows of t stay zero (the stencil kernels read them as halo rows)
-    if (bx == 0) for (int i = threadIdx.x; i < NYP; i += bd) t[i] = cplx{0, 0};
-    if (iz1 == k.nz - 1) for (int i = threadIdx.x; i < NYP; i += bd) t[(long)k.nz * NYP + i] = cplx{0, 0};
-    BP_STAMP(5)
-    block_sum3_8(ar, ai, zz, sh, NW);
-    if (threadIdx.x == 0) {
-        k.partA[(long)s * MAXNB + bx] = cplx{ar, ai};
-        partZZ[(long)s * MAXNB + bx] = zz;
-    }
-    // the consumers add up k.NB partial sums per system: clear the slots this launch does not use
-    if (bx == 0)
-        for (int b = nwg + threadIdx.x; b < k.NB; b += bd) {
-            k.partA[(long)s * MAXNB + b] = cplx{0, 0};
-            partZZ[(long)s * MAXNB + b] = 0.0;
-        }
-    BP_STAMP(6)
-}
-
-// pre-split planes -> complex64 (hi + lo), tests only
-__global__ void k_unsplit(Solver k, const float2* __restrict__ src, float2* __restrict__ dst) {
-    const long n = (long)k.S * k.vstride;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const long row = e / k.NYP;
-        const int iy = (int)(e - row * k.NYP);
-        const unsigned short* b = reinterpret_cast<const unsigned short*>(src) + row * 4 * k.NYP + iy;
-        dst[e] = float2{bf16_to_f32(b[0]) + bf16_to_f32(b[2 * k.NYP]), bf16_to_f32(b[k.NYP]) + bf16_to_f32(b[3 * k.NYP])};
-    }
-}
-
-// complex64 copy of a vector (plain FDM: the transform input is r itself)
-__global__ __launch_bounds__(VBLOCK) void k_to_c64(Solver k, const cplx* src) {
-    const int s = blockIdx.y;
-    if (!k.active[s]) return;
-    const long so = (long)s * k.vstride;
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
-        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
-        store_t32(k, k.t32 + so, iz, iy, (float)src[so + e].re, (float)src[so + e].im);
-    }
-}
-
-// t = r - A (dinv .* r), written as complex64 for the mixed-precision transform
-__global__ __launch_bounds__(VBLOCK) void k_pre_c64(Solver k) {
-    const int s = blockIdx.y;
-    if (!k.active[s]) return;
-    const int mode = s >= k.nFreq;
-    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
-    const double w = k.omega[s];
-    const cplx *r = k.r + so, *di = k.dinv + so;
-    float2* t = k.t32 + so;
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
-        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
-        cplx out = cplx{0, 0};
-        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
-            const cplx c = di[e] * r[e];
-            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
-            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
-            acc += k.cY[mo + e] * (di[e + 1] * r[e + 1]);
-            acc += k.cY[mo + e - 1] * (di[e - 1] * r[e - 1]);
-            acc += k.cZ[mo + e] * (di[e + k.NYP] * r[e + k.NYP]);
-            acc += k.cZ[mo + e - k.NYP] * (di[e - k.NYP] * r[e - k.NYP]);
-            out = r[e] - acc;
-        }
-        store_t32(k, t, iz, iy, (float)out.re, (float)out.im);
-    }
-}
-
-
-// ----------------------------------------------------------------------------------------------
-// Fused COCG iteration of the default path (Jacobi/FDM/Jacobi preconditioner, mixed precision):
-//   k_spmv_fused   : scalar bookkeeping (convergence test on the error estimate, beta), p = z + beta p
-//                    recomputed on each node's 5-point halo, q = A p, partial p'q
-//   k_update_fused : alpha, x += alpha p, r' = r - alpha q recomputed on the halo, Jacobi pre-smoothing
-//                    t = r' - A (dinv .* r') written as complex64 for the transform, partial |x|^2
-// Every block of a system reduces that system's partial sums itself (same order -> same value), so no
-// separate scalar kernel and no grid synchronisation is needed; p and r are double-buffered because
-// blocks read their neighbours' old values while writing new ones.  Block 0 of each system owns the
-// per-system records (rho by parity, iteration count, error estimate, active flag, active counter).
-// ----------------------------------------------------------------------------------------------
-// Both kernels work on tiles of RT interior rows of one system: the tile plus one halo row above and below
-// is staged in LDS (dynamic, (RT+2)*NYP complex [+ RT*NYP]), so every global value is read once.
-//
-// k_spmv_fused is a chain of short phases (scalars -> stage tile -> barrier -> stencil -> reduce), each a memory round
-// trip long: its loads are issued as early as their addresses are known, in batches of SB elements per thread,
-// unconditionally (clamped indices) and apart from their use -- the per-system partial sums, rho and the first staging
-// batch go out together before the active flag is even tested, the stencil coefficients of the first batch before
-// the staging barrier (11.0 -> 10.3 us; the same treatment of k_update_fused, which moves twice the bytes and sits
-// at 5 TB/s, changed nothing, and neither did computing its dinv from dK, dM instead of loading it).
-constexpr int SB = 4;                  // elements per thread and batch
-constexpr int STALL_IT = 30;           // mixed-precision stagnation watch: iterations allowed per 10-fold drop of the error estimate
-struct StenCo { double dk, dm, cy0, cy1, cz0, cz1; };
-
-__device__ __forceinline__ int div_small(int i, float rcp) { return (int)(((float)i + 0.5f) * rcp); }   // i / n for i < 2^20, rcp = 1/n
-
-__global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* partZZ, const cplx* pin_, cplx* pout, int it, int maxit) {
-    const int s = blockIdx.y;
-    extern __shared__ __attribute__((aligned(16))) char smem_[];
-    cplx* pn = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]
-    __shared__ double sh[8];
-    const bool first = it == 1;
-    const int act = k.active[s];
-    const int ln = threadIdx.x & 63;
-    // the system's partial sums (lane b fetches partial b), rho of the previous iteration
-    const cplx paL = ln < k.NB ? k.partA[(long)s * MAXNB + ln] : cplx{0, 0};
-    const double pzL = ln < k.NB ? partZZ[(long)s * MAXNB + ln] : 0.0;
-    const double pbL = ln < k.NTR ? k.partB[(long)s * MAXNB + ln] : 0.0;
-    const cplx rhoPrev = k.rho2[(long)((it - 1) & 1) * k.S + s];
-    const int mode = s >= k.nFreq;
-    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
-    const double w = k.omega[s];
-    const cplx *z = k.z + so, *pi = pin_ + so;
-    cplx *po = pout + so, *q = k.q + so;
-    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);   // own rows iz0..iz1
-    const float rNYP = 1.0f / (float)NYP;
-    // rows iz0-1 .. iz1+1 of the new direction (z, p vanish on boundary / pad nodes: no masking needed)
-    const int nrows = iz1 - iz0 + 3, ntot = nrows * NYP, ebase = (iz0 - 1) * NYP;
-    cplx zv[SB], pv[SB];
-    auto ld_stage = [&](int i0) {
-#pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            const unsigned e = (unsigned)(ebase + min(i0 + u * VBLOCK, ntot - 1));
-            zv[u] = z[e];
-            pv[u] = first ? cplx{0, 0} : pi[e];
-        }
-    };
-    ld_stage(threadIdx.x);
-    if (!act) return;
-    const cplx rz = cplx{wave_sum(paL.re), wave_sum(paL.im)};
-    const double zz = wave_sum(pzL), xx = wave_sum(pbL);
-    bool on = true;
-    int st = 0;
-    if (first) { if (zz == 0.0) on = false; }
-    else if (zz <= k.tol2 * xx) on = false;
-    else if (it - 1 >= maxit) { on = false; st = HMCMT_ENOCONV; }
-    if (!(isfinite(rz.re) && isfinite(rz.im) && isfinite(zz) && isfinite(xx))) { on = false; st = HMCMT_EBREAKDOWN; }
-    const cplx be = first ? cplx{0, 0} : rz / rhoPrev;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        k.rho2[(long)(it & 1) * k.S + s] = rz;
-        k.iters[s] = it - 1;
-        const double est = first ? (zz == 0.0 ? 0.0 : 1.0) : sqrt(zz / xx);
-        k.errEst[s] = est;
-        if (st) k.status[s] = st;
-        // stagnation watch (the host restarts the stragglers with the fp64 preconditioner when it fires)
-        if (first || est < 0.1 * k.errRef[s]) { k.errRef[s] = est; k.errRefIt[s] = it; }
-        else if (on && it - k.errRefIt[s] > k.stallIt) *k.stallHost = 1;
-    }
-    if (!on) {
-        // every block of this system takes the same decision; block 0 records it (a block that starts late and
-        // already sees the cleared flag returns just the same)
-        if (blockIdx.x == 0 && threadIdx.x == 0) { k.active[s] = 0; if (atomicSub(k.nactive, 1) == 1) *k.nactHost = 0; }
-        return;
-    }
-    if (k.cntActive && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(k.cntActive, 1ull);   // (roofline accounting only)
-    for (int i0 = threadIdx.x; i0 < ntot; i0 += SB * VBLOCK) {
-        if (i0 != (int)threadIdx.x) ld_stage(i0);
-#pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            const int i = i0 + u * VBLOCK;
-            if (i < ntot) {
-                const cplx v = first ? zv[u] : zv[u] + be * pv[u];
-                pn[i] = v;
-                if (i >= NYP && i < ntot - NYP) po[ebase + i] = v;
-            }
-        }
-    }
-    const int nown = (iz1 - iz0 + 1) * NYP, obase = iz0 * NYP;
-    const double *dKm = k.dK + mo, *dMm = k.dM + mo, *cYm = k.cY + mo, *cZm = k.cZ + mo, *cZu = k.cZ + mo - NYP;
-    StenCo co[SB];
-    auto ld_co = [&](int i0) {
-#pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            const unsigned e = (unsigned)(obase + min(i0 + u * VBLOCK, nown - 1));
-            co[u].dk = dKm[e]; co[u].dm = dMm[e];
-            co[u].cy0 = cYm[e]; co[u].cy1 = cYm[e - 1u];
-            co[u].cz0 = cZm[e]; co[u].cz1 = cZu[e];
-        }
-    };
-    ld_co(threadIdx.x);
-    __syncthreads();
-    double ar = 0, ai = 0;
-    for (int i0 = threadIdx.x; i0 < nown; i0 += SB * VBLOCK) {
-        if (i0 != (int)threadIdx.x) ld_co(i0);
-#pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            const int i = i0 + u * VBLOCK;
-            const int iy = i - div_small(i, rNYP) * NYP;
-            if (i < nown && iy >= 1 && iy <= k.ny - 1) {
-                const int l = i + NYP;
-                const cplx pc = pn[l];
-                const double dm = w * co[u].dm;
-                cplx acc = cplx{co[u].dk * pc.re - dm * pc.im, co[u].dk * pc.im + dm * pc.re};
-                acc += co[u].cy0 * pn[l + 1];
-                acc += co[u].cy1 * pn[l - 1];
-                acc += co[u].cz0 * pn[l + NYP];
-                acc += co[u].cz1 * pn[l - NYP];
-                q[obase + i] = acc;
-                ar += pc.re * acc.re - pc.im * acc.im;
-                ai += pc.re * acc.im + pc.im * acc.re;
-            }
-        }
-    }
-    block_sum2(ar, ai, sh);
-    if (threadIdx.x == 0) k.partPQ[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
-}
-
-__global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const cplx* pcur, const cplx* rin, cplx* rout, int it) {
-    const int s = blockIdx.y;
-    if (!k.active[s]) return;
-    extern __shared__ __attribute__((aligned(16))) char smem_[];
-    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);
-    const int nrows = iz1 - iz0 + 3;
-    cplx* cs = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]  dinv .* r'
-    cplx* rs = cs + (long)(k.RT + 2) * NYP;               // [RT][NYP]      r' of the own rows
-    __shared__ double sh[8];
-    const cplx pq = total_part(k.partPQ + (long)s * MAXNB, k.NTR);
-    const cplx al = k.rho2[(long)(it & 1) * k.S + s] / pq;
-    const int mode = s >= k.nFreq;
-    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
-    const double w = k.omega[s];
-    const cplx *p = pcur + so, *q = k.q + so, *ri = rin + so, *di = k.dinv + so;
-    cplx *x = k.x + so, *ro = rout + so;
-    float2* t = k.t32 + so;
-    double xx = 0, dummy = 0;
-    // r' = r - alpha q and dinv .* r' on rows iz0-1 .. iz1+1 (r, q, dinv vanish outside the interior: no masking)
-    for (int i = threadIdx.x; i < nrows * NYP; i += VBLOCK) {
-        const int lr = i / NYP, iy = i - lr * NYP;
-        const long e = (long)(iz0 - 1 + lr) * NYP + iy;
-        const cplx rn = ri[e] - al * q[e];
-        cs[i] = di[e] * rn;
-        if (lr >= 1 && lr <= nrows - 2) {
-            rs[i - NYP] = rn;
-            ro[e] = rn;
-            const cplx xv = x[e] + al * p[e];             // p vanishes outside the interior
-            x[e] = xv;
-            xx += cabs2(xv);
-        }
-    }
-    __syncthreads();
-    const int nown = (iz1 - iz0 + 1) * NYP;
-    for (int i = threadIdx.x; i < nown; i += VBLOCK) {
-        const int lr = i / NYP, iy = i - lr * NYP;
-        const long e = (long)(iz0 + lr) * NYP + iy;
-        cplx out = cplx{0, 0};
-        if (iy >= 1 && iy <= k.ny - 1) {
-            const int l = (lr + 1) * NYP + iy;
-            const cplx c = cs[l];
-            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
-            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
-            acc += k.cY[mo + e] * cs[l + 1];
-            acc += k.cY[mo + e - 1] * cs[l - 1];
-            acc += k.cZ[mo + e] * cs[l + NYP];
-            acc += k.cZ[mo + e - NYP] * cs[l - NYP];
-            out = rs[i] - acc;
-        }
-        store_t32(k, t, iz0 + lr, iy, (float)out.re, (float)out.im);
-    }
-    block_sum2(xx, dummy, sh);
-    if (threadIdx.x == 0) {
-        k.partB[(long)s * MAXNB + blockIdx.x] = xx;
-        if (blockIdx.x == 0) k.alphaBeta[s] = al;
-    }
-}
-
-// warm start: r <- r - A x over interior nodes, x including whatever sits on its boundary nodes
-// (forward: Dirichlet values, so with r = 0 on entry this is the reference's rhs -Aio*bc minus Aii*x0)
-// sysOn != nullptr: workgroup (0,0) also does k_solve_begin's bookkeeping for the solve that follows (one launch less
-// on the critical path in front of each solve)
-__global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r, const int* __restrict__ sysOn) {
-    const int s = blockIdx.y;
-    if (sysOn && blockIdx.x == 0 && blockIdx.y == 0) {
-        for (int t = threadIdx.x; t < k.S * MAXNB; t += VBLOCK) k.partB[t] = 0.0;
-        for (int t = threadIdx.x; t < k.S; t += VBLOCK) { k.active[t] = sysOn[t]; k.iters[t] = 0; k.status[t] = 0; }
-        if (threadIdx.x == 0) {
-            int n = 0;
-            for (int q = 0; q < k.S; ++q) n += sysOn[q];
-            *k.nactive = n;
-            *k.nactHost = n;
-        }
-    }
-    const int mode = s >= k.nFreq;
-    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
-    const double w = k.omega[s];
-    const cplx* u = x + so;
-    cplx* r = k.r + so;
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
-        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
-        cplx out = cplx{0, 0};
-        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1)
-            out = (zero_r ? cplx{0, 0} : r[e]) - stencil_at(k, u, mo, e, w);
-        r[e] = out;
-    }
-}
-
-// k_resid0 + k_pre_c64 in one launch (the start of a solve on the default path): on a tile of RT rows
-//   r = b - A x0        on the tile's rows and one halo row on each side (x0 staged with two halo rows)
-//   t = r - A (dinv r)  on the tile's rows, written in the transform's input format
-// so the residual is not re-read by a second kernel and one launch disappears in front of each solve.  The residual is
-// written to a SECOND buffer (rout): the halo rows' b are read from rin while the neighbouring workgroups write theirs.
-// Workgroup (0,0) also does k_solve_begin's bookkeeping.
-__global__ __launch_bounds__(VBLOCK) void k_resid_pre(Solver k, const cplx* x, const cplx* rin, cplx* rout, int zero_r,
-                                                      const int* __restrict__ sysOn) {
-    const int s = blockIdx.y;
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
-        for (int t = threadIdx.x; t < k.S * MAXNB; t += VBLOCK) k.partB[t] = 0.0;
-        for (int t = threadIdx.x; t < k.S; t += VBLOCK) { k.active[t] = sysOn[t]; k.iters[t] = 0; k.status[t] = 0; }
-        if (threadIdx.x == 0) {
-            int n = 0;
-            for (int q = 0; q < k.S; ++q) n += sysOn[q];
-            *k.nactive = n;
-            *k.nactHost = n;
-        }
-    }
-    extern __shared__ __attribute__((aligned(16))) char smem_[];
-    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1), nown = iz1 - iz0 + 1;
-    cplx* xs = reinterpret_cast<cplx*>(smem_);            // [(RT+4)][NYP]  x0 rows iz0-2 .. iz1+2; later dinv .* r (rows iz0-1 ..)
-    cplx* rs = xs + (long)(k.RT + 4) * NYP;               // [(RT+2)][NYP]  r rows iz0-1 .. iz1+1
-    const int mode = s >= k.nFreq;
-    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
-    const double w = k.omega[s];
-    const float rNYP = 1.0f / (float)NYP;
-    const cplx* u = x + so;
-    for (int i = threadIdx.x; i < (nown + 4) * NYP; i += VBLOCK) {
-        const int lr = div_small(i, rNYP), g = iz0 - 2 + lr;
-        xs[i] = (g >= 0 && g <= k.nz) ? u[(long)g * NYP + (i - lr * NYP)] : cplx{0, 0};
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < (nown + 2) * NYP; i += VBLOCK) {
-        const int lr = div_small(i, rNYP), iy = i - lr * NYP, g = iz0 - 1 + lr;
-        const long e = (long)g * NYP + iy;
-        cplx out = cplx{0, 0};
-        if (g >= 1 && g <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
-            const int l = i + NYP;                         // the same node in xs (one more halo row in front)
-            const cplx c = xs[l];
-            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
-            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
-            acc += k.cY[mo + e] * xs[l + 1];
-            acc += k.cY[mo + e - 1] * xs[l - 1];
-            acc += k.cZ[mo + e] * xs[l + NYP];
-            acc += k.cZ[mo + e - NYP] * xs[l - NYP];
-            out = (zero_r ? cplx{0, 0} : rin[so + e]) - acc;
-        }
-        rs[i] = out;
-        if (lr >= 1 && lr <= nown) rout[so + e] = out;
-    }
-    // the two boundary rows of r and of t (zeros)
-    if (blockIdx.x == 0 || iz1 == k.nz - 1) {
-        const int row = blockIdx.x == 0 ? 0 : k.nz;
-        for (int iy = threadIdx.x; iy < NYP; iy += VBLOCK) {
-            rout[so + (long)row * NYP + iy] = cplx{0, 0};
-            store_t32(k, k.t32 + so, row, iy, 0.f, 0.f);
-        }
-        if (blockIdx.x == 0 && iz1 == k.nz - 1)            // (a single tile: both rows)
-            for (int iy = threadIdx.x; iy < NYP; iy += VBLOCK) {
-                rout[so + (long)k.nz * NYP + iy] = cplx{0, 0};
-                store_t32(k, k.t32 + so, k.nz, iy, 0.f, 0.f);
-            }
-    }
-    __syncthreads();
-    const cplx* di = k.dinv + so;
-    for (int i = threadIdx.x; i < (nown + 2) * NYP; i += VBLOCK) xs[i] = di[(long)(iz0 - 1) * NYP + i] * rs[i];
-    __syncthreads();
-    for (int i = threadIdx.x; i < nown * NYP; i += VBLOCK) {
-        const int lr = div_small(i, rNYP), iy = i - lr * NYP;
-        const long e = (long)(iz0 + lr) * NYP + iy;
-        cplx out = cplx{0, 0};
-        if (iy >= 1 && iy <= k.ny - 1) {
-            const int l = i + NYP;
-            const cplx c = xs[l];
-            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
-            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
-            acc += k.cY[mo + e] * xs[l + 1];
-            acc += k.cY[mo + e - 1] * xs[l - 1];
-            acc += k.cZ[mo + e] * xs[l + NYP];
-            acc += k.cZ[mo + e - NYP] * xs[l - NYP];
-            out = rs[l] - acc;
-        }
-        store_t32(k, k.t32 + so, iz0 + lr, iy, (float)out.re, (float)out.im);
-    }
-}
-
-// start of a solve: every requested system active, records cleared (one launch instead of five copies/memsets)
-__global__ void k_solve_begin(Solver k, const int* __restrict__ sysOn) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < k.S * MAXNB) k.partB[t] = 0.0;
-    if (t < k.S) { k.active[t] = sysOn[t]; k.iters[t] = 0; k.status[t] = 0; }
-    if (t == 0) {
-        int n = 0;
-        for (int s = 0; s < k.S; ++s) n += sysOn[s];
-        *k.nactive = n;
-        *k.nactHost = n;
-    }
-}
-
-// end of a solve: per-system records of this solve kind into the packed read-back buffer
-// rec = [2 kinds][S] iters (int) | [2][S] status (int) | [2][S] error estimate (double)
-__global__ void k_solve_end(Solver k, int kind, int* __restrict__ recI, double* __restrict__ recE) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= k.S) return;
-    recI[kind * k.S + s] = k.iters[s];
-    recI[(2 + kind) * k.S + s] = k.status[s];
-    recE[kind * k.S + s] = k.errEst[s];
-}
-
-// ---- initial guess extrapolated along the model path (options.warm_start == 2) ----
-// The fields are smooth functions of the model, and a leapfrog trajectory moves the model along an almost
-// straight line at almost constant speed.  With the last three models on that line at "times"
-// tau = -1-gamma, -1, 0 (unit = the last step; gamma, alpha = projections of the previous / the new step on
-// the last one) the guess is the Lagrange extrapolation of the last three fields to tau = alpha:
-//     x0 = w2 x_k + w1 x_{k-1} + w0 x_{k-2}      (uniform steps: 3, -3, 1)
-// when the three steps are nearly collinear, else the linear one  x0 = x_k + alpha (x_k - x_{k-1})
-// (e.g. across a momentum refresh).  State per solve kind, all on the device (no host round trip):
-// hist = [m_k | m_{k-1} | ... | m_{k-NP+1}], ext = {w_k, ..., w_{k-NP+1}, keep, count}; every further step that is
-// nearly collinear with the last one and of comparable length adds a point (and an order) to the Lagrange
-// extrapolation, up to EXT_NP fields.  A repeated model (getHamiltonian after the last leapfrog step) keeps the
-// history untouched.
-constexpr int EXT_NP = 6;          // fields kept per solve kind: the current one + EXT_NP-1 earlier ones (Lagrange order <= EXT_NP-1)
-constexpr int EXT_NBLK = 32;       // blocks of the partial-sum pass
-constexpr int EXT_NS = 2 * EXT_NP; // partial sums per block: <d_j,d1> (j = 0..NP-1), <d_j,d_j> (j = 0, 2..NP-1), <m_k,m_k>
-constexpr int EXT_KEEP = EXT_NP, EXT_COUNT = EXT_NP + 1, EXT_PART = EXT_NP + 2;   // ext = {w_0..w_{NP-1}, keep, count, partial sums...}
-
-// pass 1: per-block partial sums over the model history hist = [m_k | m_{k-1} | ... | m_{k-NP+1}]: steps
-// d0 = m_new - m_k, d_j = m_{k-j+1} - m_{k-j};  a[j] = <d_j,d1> (j < NP), a[NP] = <d0,d0>, a[NP+j-1] = <d_j,d_j>
-// (j = 2..NP-1), a[2NP-1] = <m_k,m_k>   ->  part[block][EXT_NS]
-__global__ __launch_bounds__(256) void k_extrap_sums(const double* __restrict__ mNew, const double* __restrict__ hist, int nAC,
-                                                      double* __restrict__ part) {
-    __shared__ double sh[EXT_NS][4];
-    double a[EXT_NS];
-#pragma unroll
-    for (int q = 0; q < EXT_NS; ++q) a[q] = 0.0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nAC; i += EXT_NBLK * 256) {
-        double m[EXT_NP], d[EXT_NP];
-#pragma unroll
-        for (int j = 0; j < EXT_NP; ++j) m[j] = hist[(long)j * nAC + i];
-        d[0] = mNew[i] - m[0];
-#pragma unroll
-        for (int j = 1; j < EXT_NP; ++j) d[j] = m[j - 1] - m[j];
-#pragma unroll
-        for (int j = 0; j < EXT_NP; ++j) a[j] += d[j] * d[1];
-        a[EXT_NP] += d[0] * d[0];
-#pragma unroll
-        for (int j = 2; j < EXT_NP; ++j) a[EXT_NP + j - 1] += d[j] * d[j];
-        a[EXT_NS - 1] += m[0] * m[0];
-    }
-    const int w = threadIdx.x >> 6;
-#pragma unroll
-    for (int q = 0; q < EXT_NS; ++q) {
-        a[q] = wave_sum(a[q]);
-        if ((threadIdx.x & 63) == 0) sh[q][w] = a[q];
-    }
-    __syncthreads();
-    if (threadIdx.x < EXT_NS) part[blockIdx.x * EXT_NS + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
-}
-
-// pass 2 (one wave): the extrapolation weights from the partial sums
-__global__ __launch_bounds__(64) void k_extrap_weights(const double* __restrict__ part, double* ext, int maxNp) {
-    double a[EXT_NS];
-#pragma unroll
-    for (int q = 0; q < EXT_NS; ++q) a[q] = wave_sum(threadIdx.x < EXT_NBLK ? part[threadIdx.x * EXT_NS + q] : 0.0);
-    if (threadIdx.x != 0) return;
-    const int count = (int)ext[EXT_COUNT];
-    const double d1d1 = a[1], d0d0 = a[EXT_NP], mkmk = a[EXT_NS - 1];
-    const bool keep = count >= 1 && d0d0 <= 1e-28 * mkmk;
-    double wts[EXT_NP];                                       // weights of x_k, x_{k-1}, ...
-    for (int i = 0; i < EXT_NP; ++i) wts[i] = i == 0 ? 1.0 : 0.0;
-    if (!keep && count >= 2 && d1d1 > 0) {
-        const double alpha = fmin(2.0, fmax(-1.0, a[0] / d1d1));
-        wts[0] = 1.0 + alpha; wts[1] = -alpha;
-        // "times" of the models on the line through the last step: 0, -1, -1-g2, -1-g2-g3, ...; a further point is used
-        // while its step is nearly collinear with the last one and of comparable length
-        double tau[EXT_NP];
-        tau[0] = 0.0; tau[1] = -1.0;
-        int np = 2;
-        if (d0d0 > 0 && a[0] / sqrt(d0d0 * d1d1) > 0.95 && alpha > 0.5 && alpha < 2.0) {
-            for (int j = 2; j < EXT_NP; ++j) {
-                const double djdj = a[EXT_NP + j - 1], g = a[j] / d1d1;
-                if (!(count >= j + 1 && djdj > 0 && a[j] / sqrt(djdj * d1d1) > 0.95 && g > 0.5 && g < 2.0)) break;
-                tau[j] = tau[j - 1] - g;
-                np = j + 1;
-            }
-        }
-        np = min(maxNp, np);
-        if (np > 2) {
-            for (int i = 0; i < EXT_NP; ++i) {
-                double l = i < np ? 1.0 : 0.0;
-                for (int j = 0; j < np; ++j)
-                    if (j != i && i < np) l *= (alpha - tau[j]) / (tau[i] - tau[j]);
-                wts[i] = l;
-            }
-        }
-    }
-    for (int i = 0; i < EXT_NP; ++i) ext[i] = wts[i];
-    ext[EXT_KEEP] = keep ? 1.0 : 0.0;
-    if (!keep) ext[EXT_COUNT] = (double)min(count + 1, EXT_NP);
-}
-
-// pass 3: the model history moves on (unless the model is a repeat)
-__global__ __launch_bounds__(256) void k_extrap_shift(const double* __restrict__ mNew, double* hist, int nAC, const double* __restrict__ ext) {
-    if (ext[EXT_KEEP] != 0.0) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nAC) {
-#pragma unroll
-        for (int j = EXT_NP - 1; j >= 1; --j) hist[(long)j * nAC + i] = hist[(long)(j - 1) * nAC + i];
-        hist[i] = mNew[i];
-    }
-}
-
-// x <- sum_j w_j x_{k-j}, history shifted (... <- xp1 <- xp0 <- old x), on interior nodes (runs beside
-// k_bc_forward, which writes X's boundary nodes); xp = [EXT_NP-1][S*vstride]
-__global__ __launch_bounds__(VBLOCK) void k_extrap(Solver k, cplx* x, cplx* xp, const double* __restrict__ ext) {
-    if (ext[EXT_KEEP] != 0.0) return;
-    double w[EXT_NP];
-#pragma unroll
-    for (int j = 0; j < EXT_NP; ++j) w[j] = ext[j];
-    const long so = (long)blockIdx.y * k.vstride, hs = (long)k.S * k.vstride;
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
-        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
-        if (iz < 1 || iz > k.nz - 1 || iy < 1 || iy > k.ny - 1) continue;
-        cplx q[EXT_NP];
-        q[0] = x[so + e];
-#pragma unroll
-        for (int j = 1; j < EXT_NP; ++j) q[j] = xp[(long)(j - 1) * hs + so + e];
-        cplx acc = w[0] * q[0];
-#pragma unroll
-        for (int j = 1; j < EXT_NP; ++j) acc += w[j] * q[j];
-#pragma unroll
-        for (int j = EXT_NP - 1; j >= 1; --j) xp[(long)(j - 1) * hs + so + e] = q[j - 1];
-        x[so + e] = acc;
-    }
-}
-
-// true residual norm check: partB = |b - A x|^2 with b passed separately (verify option)
-__global__ __launch_bounds__(VBLOCK) void k_trueres(Solver k, const cplx* b, const cplx* x, double* partRes, double* partBn) {
-    const int s = blockIdx.y;
-    __shared__ double sh[8];
-    const int mode = s >= k.nFreq;
-    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
-    const double w = k.omega[s];
-    const cplx* p = x + so;
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    double rr = 0, bb = 0;
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
-        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
-        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
-            const cplx c = p[e];
-            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
-            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
-            // boundary entries of x hold Dirichlet values: they belong to the right-hand side
-            if (iy + 1 <= k.ny - 1) acc += k.cY[mo + e] * p[e + 1];
-            if (iy - 1 >= 1) acc += k.cY[mo + e - 1] * p[e - 1];
-            if (iz + 1 <= k.nz - 1) acc += k.cZ[mo + e] * p[e + k.NYP];
-            if (iz - 1 >= 1) acc += k.cZ[mo + e - k.NYP] * p[e - k.NYP];
-            rr += cabs2(b[so + e] - acc);
-            bb += cabs2(b[so + e]);
-        }
-    }
-    block_sum2(rr, bb, sh);
-    if (threadIdx.x == 0) { partRes[(long)s * MAXNB + blockIdx.x] = rr; partBn[(long)s * MAXNB + blockIdx.x] = bb; }
-}
-
-// ----------------------------------------------------------------------------------------------
-// item kernels
-// ----------------------------------------------------------------------------------------------
-#define TID1 (blockIdx.x * blockDim.x + threadIdx.x)
-
-__global__ void k_null() {}
-__global__ void k_sigma(View v) { int c = TID1; if (c < v.nCell) item_sigma(v, c); }
-// lateral means of one cell row per wave (deterministic shuffle reduction)
-__global__ __launch_bounds__(64) void k_rowmean(View v) {
-    const int kz = blockIdx.x;
-    double sa = 0.0, sl = 0.0;
-    for (int ky = threadIdx.x; ky < v.ny; ky += 64) {
-        const double s = v.sigma[(long)kz * v.ny + ky];
-        sa += s; sl += log(s);
-    }
-    sa = wave_sum(sa); sl = wave_sum(sl);
-    if (threadIdx.x == 0) { v.sigMeanA[kz] = sa / v.ny; v.sigMeanG[kz] = exp(sl / v.ny); }
-}
-__global__ void k_coef(View v, int te_doK, int te_doM, int tm_doK, int tm_doM) {
-    int e = TID1;
-    if (e >= v.NZP * (v.ny + 1)) return;
-    int iz = e / (v.ny + 1), iy = e % (v.ny + 1);
-    if (te_doK || te_doM) item_coef(v, 0, iy, iz, te_doK, te_doM);
-    if (tm_doK || tm_doM) item_coef(v, 1, iy, iz, tm_doK, tm_doM);
-}
-__global__ void k_fdm_z(View v) { int e = TID1; if (e < 2 * v.NZP) item_fdm_z(v, e / v.NZP, e % v.NZP); }
-// Inverse pivots of the FDM tridiagonals, with what used to be two more launches in front of and behind it: every
-// workgroup computes its mode's four z-coefficient rows (item_fdm_z: a hundred values) straight into LDS -- the
-// serial loop reads them from there, not from global memory -- and the first workgroup of each mode also stores
-// them for the solver's kernels; the complex64 copy of the pivots (ip32 != nullptr) is written along.
-__global__ __launch_bounds__(64) void k_pivot(View v, float2* ip32) {
-    extern __shared__ __attribute__((aligned(16))) char smem_pv[];
-    double* tab = reinterpret_cast<double*>(smem_pv);
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y, mode = s >= v.nFreq;
-    const bool store = blockIdx.x == 0 && s == mode * v.nFreq;
-    for (int i = threadIdx.x; i < v.NZP; i += blockDim.x) {
-        double a, b, c, d;
-        fdm_z_values(v, mode, i, a, b, c, d);
-        tab[i] = a; tab[v.NZP + i] = b; tab[2 * v.NZP + i] = c; tab[3 * v.NZP + i] = d;
-        if (store) {
-            const long o = (long)mode * v.NZP + i;
-            v.mzq[o] = a; v.dgz[o] = b; v.ofz[o] = c; v.mzs[o] = d;
-        }
-    }
-    __syncthreads();
-    if (j < v.ny - 1)
-        item_pivot_tab(v, s, j, tab, tab + v.NZP, tab + 2 * v.NZP, tab + 3 * v.NZP,
-                       ip32 ? reinterpret_cast<float*>(ip32 + (long)s * v.vstride + j) : nullptr);
-}
-__global__ __launch_bounds__(64) void k_bc_layers(View v) {       // grid z: frequencies
-    int col = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, f = blockIdx.z;
-    if (col <= v.ny) item_bc_layers_f(v, f, j, col);
-}
-// One thread per boundary column.  The two edge columns need the whole 1-D field (left / right boundary values):
-// their lane writes it to LDS inside the recurrence (same code path as every other lane) and the wave copies it
-// out afterwards.
-// One lane = one boundary column of one FREQUENCY: the layered-earth recurrences are the same for the two
-// polarisations, so one pass yields both systems' values.  Only the two edge columns need the fields under every layer;
-// their lanes store the amplitudes per layer in LDS and the workgroup evaluates the outputs afterwards in parallel
-// (fwd_outputs: ~30 fp64 instructions per layer that would otherwise sit in every wave's serial loop).
-__global__ __launch_bounds__(64) void k_bc_forward(View v) {
-    extern __shared__ __attribute__((aligned(16))) char smem_bc[];
-    cplx* amp = reinterpret_cast<cplx*>(smem_bc);         // [slot 0: column 0, slot 1: column ny][nz][eu, ed]
-    __shared__ FwdTop top[2];
-    __shared__ int deadAt[2];
-    const int col0 = blockIdx.x * blockDim.x, col = col0 + threadIdx.x, f = blockIdx.y;
-    const bool onE = v.sysOn[f] != 0, onH = v.sysOn[v.nFreq + f] != 0;
-    if (!onE && !onH) return;
-    cplx* XE = v.X + (long)f * v.vstride;
-    cplx* XH = v.X + (long)(v.nFreq + f) * v.vstride;
-    const long ls = v.ny + 1, qs = (long)v.nz * ls;
-    const bool has0 = col0 == 0, hasN = col0 <= v.ny && v.ny < col0 + (int)blockDim.x;
-    if (col <= v.ny) {
-        if (onE) XE[nidx(v, col, 0)] = cplx{1.0, 0.0};    // top row incl. corners
-        if (onH) XH[nidx(v, col, 0)] = cplx{1.0, 0.0};
-        const cplx* T = v.fwdTab + (long)f * FWD_NQ * qs + col;
-        // ONE instantiation of the recurrence for every lane (a separate call for the edge lanes would make their
-        // wave run the whole chain twice, once per divergent path: that was the kernel's critical path)
-        const bool isEdge = col == 0 || col == v.ny;
-        const int slot = col == 0 ? 0 : 1;
-        cplx* ea = amp + (long)slot * 2 * v.nz;
-        int dAt = v.nz;                                   // first layer behind the overflow cut-off
-        FwdTop tp;
-        cplx lastE, lastH;
-        bc1d_forward_core(v.omega[f], v.nz, T, qs, ls, [&](int i, cplx eu, cplx ed, cplx, bool dead) {
-            if (isEdge) { ea[2 * i] = eu; ea[2 * i + 1] = ed; if (dead && dAt > i) dAt = i; }
-        }, tp, lastE, lastH);
-        if (isEdge) { top[slot] = tp; deadAt[slot] = dAt; }
-        else {
-            if (onE) XE[nidx(v, col, v.nz)] = lastE;
-            if (onH) XH[nidx(v, col, v.nz)] = lastH;
-        }
-    }
-    if (has0 || hasN) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < v.nz; i += blockDim.x) {
-#pragma unroll
-            for (int slot = 0; slot < 2; ++slot) {
-                if (slot == 0 ? !has0 : !hasN) continue;
-                const int ecol = slot == 0 ? 0 : v.ny;
-                const cplx* T = v.fwdTab + (long)f * FWD_NQ * qs + ecol;
-                const cplx kj = T[(long)(i + 1 < v.nz ? i + 1 : v.nz - 1) * ls];      // k of the layer below (the last layer: its own)
-                cplx oE, oH;
-                fwd_outputs(top[slot], amp[((long)slot * v.nz + i) * 2], amp[((long)slot * v.nz + i) * 2 + 1], kj, i >= deadAt[slot], oE, oH);
-                if (onE) XE[nidx(v, ecol, 1 + i)] = oE;
-                if (onH) XH[nidx(v, ecol, 1 + i)] = oH;
-            }
-        }
-    }
-}
-__global__ __launch_bounds__(64) void k_sens_layers(View v) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
-    if (j <= v.nz) item_sens_layers(v, s, prof, j);
-}
-__global__ __launch_bounds__(64) void k_sens_profile(View v) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < 3 * v.S) item_sens_profile(v, e / 3, e % 3);
-}
-__global__ void k_rhs(View v) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
-    if (e >= v.NZP * (v.ny + 1)) return;
-    item_rhs(v, s, e % (v.ny + 1), e / (v.ny + 1));
-}
-__global__ __launch_bounds__(64) void k_rx(View v, int wantDeriv) {
-    int e = TID1;
-    if (e < v.S * v.nRx) item_rx(v, e / v.nRx, e % v.nRx, wantDeriv != 0);
-}
-__global__ void k_resid(View v) { int p = TID1; if (p < v.nData) item_resid(v, p); }
-__global__ void k_misfit(View v, double* out) {
-    __shared__ double sh[8];
-    double a = 0, b = 0;
-    for (int p = threadIdx.x; p < v.nData; p += blockDim.x) a += v.misfitPart[p];
-    block_sum2(a, b, sh);
-    if (threadIdx.x == 0) *out = a;
-}
-// Between the two solves: per (system, receiver) the impedance (+ its derivatives), then the residual / misfit terms of
-// the data that address this receiver and their sum of conj(W'W r) -- one launch instead of three in a row on the
-// critical path (a datum belongs to exactly one (system, receiver), so there is no cross-thread dependency; the
-// misfit itself, a reduction over all data, is not needed by the adjoint half and is summed after the sources).
-__global__ __launch_bounds__(64) void k_rxall(View v, int wantGrad) {        // (64: registers instead of 200 B of spills)
-    const int e = TID1;
-    if (e >= v.S * v.nRx) return;
-    const int s = e / v.nRx, r = e % v.nRx;
-    item_rx(v, s, r, wantGrad != 0);
-    cplx c = cplx{0, 0};
-    for (int t = v.srStart[e]; t < v.srStart[e + 1]; ++t) {
-        const int p = v.srList[t];
-        item_resid(v, p);
-        c += v.vbar[p];
-    }
-    if (wantGrad) v.rxCoef[e] = c;
-}
-__global__ void k_rxcoef(View v) { int e = TID1; if (e < v.S * v.nRx) item_rxcoef(v, e / v.nRx, e % v.nRx); }
-// adjoint sources; workgroup (0,0) also adds up the misfit terms (a reduction nothing on the device waits for: no
-// launch of its own on the critical path between the solves)
-__global__ __launch_bounds__(128) void k_src(View v, double* misfitOut, int nsrc) {
-    // blocks x < nsrc: the sources; the blocks behind them: the receiver-layer Q-terms of the gradient (item_qterm
-    // needs nothing from the adjoint solve: here they cost no launch in the gradient tail)
-    const int s = blockIdx.y;
-    if ((int)blockIdx.x >= nsrc) {
-        const int ky = (blockIdx.x - nsrc) * blockDim.x + threadIdx.x;
-        if (ky < v.ny) item_qterm(v, s, ky);
-        return;
-    }
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < 2 * (v.ny + 1)) item_src(v, s, e / (v.ny + 1), e % (v.ny + 1));
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
-        __shared__ double sh[2];
-        double a = 0;
-        for (int p = threadIdx.x; p < v.nData; p += 128) a += v.misfitPart[p];
-        a = wave_sum(a);
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
-        __syncthreads();
-        if (threadIdx.x == 0) *misfitOut = sh[0] + sh[1];
-    }
-}
-__global__ void k_wb(View v) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
-    if (e < v.nz) item_wside(v, s, e + 1);
-    else if (e < v.nz + v.ny) item_colw(v, s, e - v.nz);
-}
-__global__ __launch_bounds__(64) void k_bcsens_pre(View v) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
-    if (c < v.nz) item_bcsens_pre(v, s, prof, c);
-}
-__global__ void k_bcsens_contract(View v) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
-    if (c < v.nz) item_bcsens_contract(v, s, prof, c);
-}
-__global__ void k_gradcell(View v) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x, mode = blockIdx.y, grp = blockIdx.z;
-    if (c < v.nCell) item_gradcell_group(v, mode, grp, c);
-}
-__global__ __launch_bounds__(64) void k_qterm(View v) {
-    int ky = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
-    if (ky < v.ny) item_qterm(v, s, ky);
-}
-// final assembly with four lanes per active cell (a latency-bound loop over the systems: 4x the threads), each
-// taking every fourth system / partial sum; the four partial sums are added in lane order
-__global__ void k_gradfinal(View v) {
-    const int t = TID1, a = t >> 2, l = t & 3;
-    double g = 0.0;
-    if (a < v.nAC) {
-        const int cell = v.act[a];
-        const int ky = cell % v.ny, kz = cell / v.ny;
-        for (int q = l; q < 2 * GRAD_NG; q += 4) g += v.gPartG[(long)q * v.nCell + cell];
-#pragma unroll 4
-        for (int s = l; s < v.S; s += 4) g += gradfinal_sys(v, s, ky, kz);
-        if (kz == v.zid)
-            for (int s = l; s < v.S; s += 4) g += v.qPart[(long)s * v.ny + ky];
-    }
-    // lanes 4a .. 4a+3 are neighbours in a wave (the grid is a multiple of 64 threads)
-    const double g1 = __shfl_down(g, 1, 4), g2 = __shfl_down(g, 2, 4), g3 = __shfl_down(g, 3, 4);
-    if (a < v.nAC && l == 0) v.grad[a] = exp(v.m[a]) * (((g + g1) + g2) + g3);
-}
-
-// copy padded nodal layout -> reference layout [(ny+1)*(nz+1)] per frequency
-__global__ void k_unpad(View v, const cplx* src, cplx* dst, int s0) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
-    const int nn = (v.ny + 1) * (v.nz + 1);
-    if (e >= nn) return;
-    int iz = e / (v.ny + 1), iy = e % (v.ny + 1);
-    dst[(long)f * nn + e] = src[(long)(s0 + f) * v.vstride + nidx(v, iy, iz)];
-}
-
-// ----------------------------------------------------------------------------------------------
-// leapfrog vector kernels (proposeLeapfrog, HMCSampler.jl:206-269; diagonal mass)
-// ----------------------------------------------------------------------------------------------
-struct LfView {
-    int n;
-    const double *mref, *invM, *wmVal;
-    const long long *wmRow, *wmCol;
-    double *m, *p, *g;            // model, momentum, data gradient (in) / total gradient (out)
-    double *part;                 // [LFNB] partial maxima / sums
-    double *scal;                 // [0] mnorm
-    int* flag;                    // non-zero: non-finite value met
-};
-constexpr int LFNB = 64;
-
-// g <- g + lambda*Wm*(m - mref) ; p <- p - c*dt*g      (HMCSampler.jl:223-228, 255-263)
-__global__ void k_lf_momentum(LfView L, double lambda, double cdt) {
-    const int a = TID1;
-    if (a >= L.n) return;
-    double acc = 0.0;
-    for (long long t = L.wmRow[a]; t < L.wmRow[a + 1]; ++t) {
-        const long long j = L.wmCol[t];
-        acc += L.wmVal[t] * (L.m[j] - L.mref[j]);
-    }
-    const double g = L.g[a] + lambda * acc;       // L.g stays the data gradient (hmcmt_leapfrog memoises it)
-    L.p[a] -= cdt * g;
-}
-// partial max |dt*invM*p|   (HMCSampler.jl:237-240)
-__global__ __launch_bounds__(256) void k_lf_dmmax(LfView L, double dt) {
-    __shared__ double sh[4];
-    double mx = 0.0;
-    for (int a = blockIdx.x * 256 + threadIdx.x; a < L.n; a += 256 * LFNB) mx = fmax(mx, fabs(dt * L.invM[a] * L.p[a]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) L.part[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
-}
-// m += dm (clamped to max |dm| = 3), reflect at the ln-sigma bounds, flip momentum (:241-247, :515-559)
-__global__ void k_lf_step(LfView L, double dt, double lo, double hi) {
-    const int a = TID1;
-    if (a >= L.n) return;
-    double mx = 0.0;
-    for (int b = 0; b < LFNB; ++b) mx = fmax(mx, L.part[b]);
-    double dm = dt * L.invM[a] * L.p[a];
-    if (mx > 3.0) dm = dm / mx * 3.0;
-    double m = L.m[a] + dm, p = L.p[a];
-    if (!isfinite(m)) { atomicExch(L.flag, 1); return; }
-    for (int it = 0; it < 500 && !(m <= hi && m >= lo); ++it) {
-        if (m < lo) { m = 2.0 * lo - m; p = -p; }
-        if (m > hi) { m = 2.0 * hi - m; p = -p; }
-    }
-    L.m[a] = m; L.p[a] = p;
-}
-// mnorm = 0.5*lambda*(m-mref)' Wm (m-mref)   (HMCSampler.jl:389-391): partial sums, then block 0 finishes
-__global__ __launch_bounds__(256) void k_lf_mnorm(LfView L, double lambda) {
-    __shared__ double sh[8];
-    double acc = 0.0, dummy = 0.0;
-    for (int a = blockIdx.x * 256 + threadIdx.x; a < L.n; a += 256 * LFNB) {
-        double row = 0.0;
-        for (long long t = L.wmRow[a]; t < L.wmRow[a + 1]; ++t) { const long long j = L.wmCol[t]; row += L.wmVal[t] * (L.m[j] - L.mref[j]); }
-        acc += (L.m[a] - L.mref[a]) * row;
-    }
-    block_sum2(acc, dummy, sh);
-    if (threadIdx.x == 0) L.part[blockIdx.x] = acc;
-}
-__global__ void k_lf_mnorm_final(LfView L, double lambda) {
-    double acc = 0.0;
-    for (int b = 0; b < LFNB; ++b) acc += L.part[b];
-    L.scal[0] = 0.5 * lambda * acc;
-}
+#include "kernels_cocg.h"
+#include "kernels_fdm.h"
+#include "kernels_fused.h"
+#include "kernels_path.h"
 
 }  // namespace
 
@@ -2235,8 +80,8 @@ struct hmcmt_ctx {
     bool haveModel = false;
     bool haveFwd = false, haveAdj = false;   // previous fields usable as initial guesses
     cplx* d_prevField[2] = {nullptr, nullptr};   // the two previous solutions (warm_start == 2), per solve kind: [2][S*vstride]
-    double* d_mHist[2] = {nullptr, nullptr};     // [3][nAC] model history per solve kind
-    double* d_ext[2] = {nullptr, nullptr};       // {w0, w1, w2, keep, count}
+    double* d_mHist[2] = {nullptr, nullptr};     // [EXT_NP][nAC] model history per solve kind (newest first)
+    double* d_ext[2] = {nullptr, nullptr};       // {w_0..w_{EXT_NP-1}, keep, count, partial sums} (kernels_fused.h)
     double jacobiW = 0.8;                    // damping of the point-Jacobi halves (HMCMT_JACOBI_W; 0.7 in round 1: 0.8 saves 3-8 % of the iterations on structured models, costs 6-25 % on white-noise models of std >= 1)
     int extrapNp = EXT_NP;                   // fields used by the initial-guess extrapolation (HMCMT_EXTRAP_POINTS = 2..EXT_NP)
     bool fusedFwd = true;                    // forward transform + tridiagonal solve in one kernel (HMCMT_FUSED_FWD=0: separate)

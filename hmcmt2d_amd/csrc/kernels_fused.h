@@ -1,0 +1,497 @@
+// kernels_fused.h -- part of libhmcmt_hip.so; included by hmcmt_hip.hip INSIDE its anonymous namespace (one translation unit).
+// The fused COCG iteration of the default path (k_spmv_fused, k_update_fused), the solve start (k_resid0, k_resid_pre),
+// per-solve bookkeeping, the initial-guess extrapolation along the model path, and the true-residual check.
+#pragma once
+
+// ----------------------------------------------------------------------------------------------
+// Fused COCG iteration of the default path (Jacobi/FDM/Jacobi preconditioner, mixed precision):
+//   k_spmv_fused   : scalar bookkeeping (convergence test on the error estimate, beta), p = z + beta p
+//                    recomputed on each node's 5-point halo, q = A p, partial p'q
+//   k_update_fused : alpha, x += alpha p, r' = r - alpha q recomputed on the halo, Jacobi pre-smoothing
+//                    t = r' - A (dinv .* r') written as complex64 for the transform, partial |x|^2
+// Every block of a system reduces that system's partial sums itself (same order -> same value), so no
+// separate scalar kernel and no grid synchronisation is needed; p and r are double-buffered because
+// blocks read their neighbours' old values while writing new ones.  Block 0 of each system owns the
+// per-system records (rho by parity, iteration count, error estimate, active flag, active counter).
+// ----------------------------------------------------------------------------------------------
+// Both kernels work on tiles of RT interior rows of one system: the tile plus one halo row above and below
+// is staged in LDS (dynamic, (RT+2)*NYP complex [+ RT*NYP]), so every global value is read once.
+//
+// k_spmv_fused is a chain of short phases (scalars -> stage tile -> barrier -> stencil -> reduce), each a memory round
+// trip long: its loads are issued as early as their addresses are known, in batches of SB elements per thread,
+// unconditionally (clamped indices) and apart from their use -- the per-system partial sums, rho and the first staging
+// batch go out together before the active flag is even tested, the stencil coefficients of the first batch before
+// the staging barrier (11.0 -> 10.3 us; the same treatment of k_update_fused, which moves twice the bytes and sits
+// at 5 TB/s, changed nothing, and neither did computing its dinv from dK, dM instead of loading it).
+constexpr int SB = 4;                  // elements per thread and batch
+constexpr int STALL_IT = 30;           // mixed-precision stagnation watch: iterations allowed per 10-fold drop of the error estimate
+struct StenCo { double dk, dm, cy0, cy1, cz0, cz1; };
+
+__device__ __forceinline__ int div_small(int i, float rcp) { return (int)(((float)i + 0.5f) * rcp); }   // i / n for i < 2^20, rcp = 1/n
+
+__global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* partZZ, const cplx* pin_, cplx* pout, int it, int maxit) {
+    const int s = blockIdx.y;
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    cplx* pn = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]
+    __shared__ double sh[8];
+    const bool first = it == 1;
+    const int act = k.active[s];
+    const int ln = threadIdx.x & 63;
+    // the system's partial sums (lane b fetches partial b), rho of the previous iteration
+    const cplx paL = ln < k.NB ? k.partA[(long)s * MAXNB + ln] : cplx{0, 0};
+    const double pzL = ln < k.NB ? partZZ[(long)s * MAXNB + ln] : 0.0;
+    const double pbL = ln < k.NTR ? k.partB[(long)s * MAXNB + ln] : 0.0;
+    const cplx rhoPrev = k.rho2[(long)((it - 1) & 1) * k.S + s];
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx *z = k.z + so, *pi = pin_ + so;
+    cplx *po = pout + so, *q = k.q + so;
+    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);   // own rows iz0..iz1
+    const float rNYP = 1.0f / (float)NYP;
+    // rows iz0-1 .. iz1+1 of the new direction (z, p vanish on boundary / pad nodes: no masking needed)
+    const int nrows = iz1 - iz0 + 3, ntot = nrows * NYP, ebase = (iz0 - 1) * NYP;
+    cplx zv[SB], pv[SB];
+    auto ld_stage = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const unsigned e = (unsigned)(ebase + min(i0 + u * VBLOCK, ntot - 1));
+            zv[u] = z[e];
+            pv[u] = first ? cplx{0, 0} : pi[e];
+        }
+    };
+    ld_stage(threadIdx.x);
+    if (!act) return;
+    const cplx rz = cplx{wave_sum(paL.re), wave_sum(paL.im)};
+    const double zz = wave_sum(pzL), xx = wave_sum(pbL);
+    bool on = true;
+    int st = 0;
+    if (first) { if (zz == 0.0) on = false; }
+    else if (zz <= k.tol2 * xx) on = false;
+    else if (it - 1 >= maxit) { on = false; st = HMCMT_ENOCONV; }
+    if (!(isfinite(rz.re) && isfinite(rz.im) && isfinite(zz) && isfinite(xx))) { on = false; st = HMCMT_EBREAKDOWN; }
+    const cplx be = first ? cplx{0, 0} : rz / rhoPrev;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        k.rho2[(long)(it & 1) * k.S + s] = rz;
+        k.iters[s] = it - 1;
+        const double est = first ? (zz == 0.0 ? 0.0 : 1.0) : sqrt(zz / xx);
+        k.errEst[s] = est;
+        if (st) k.status[s] = st;
+        // stagnation watch (the host restarts the stragglers with the fp64 preconditioner when it fires)
+        if (first || est < 0.1 * k.errRef[s]) { k.errRef[s] = est; k.errRefIt[s] = it; }
+        else if (on && it - k.errRefIt[s] > k.stallIt) *k.stallHost = 1;
+    }
+    if (!on) {
+        // every block of this system takes the same decision; block 0 records it (a block that starts late and
+        // already sees the cleared flag returns just the same)
+        if (blockIdx.x == 0 && threadIdx.x == 0) { k.active[s] = 0; if (atomicSub(k.nactive, 1) == 1) *k.nactHost = 0; }
+        return;
+    }
+    if (k.cntActive && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(k.cntActive, 1ull);   // (roofline accounting only)
+    for (int i0 = threadIdx.x; i0 < ntot; i0 += SB * VBLOCK) {
+        if (i0 != (int)threadIdx.x) ld_stage(i0);
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int i = i0 + u * VBLOCK;
+            if (i < ntot) {
+                const cplx v = first ? zv[u] : zv[u] + be * pv[u];
+                pn[i] = v;
+                if (i >= NYP && i < ntot - NYP) po[ebase + i] = v;
+            }
+        }
+    }
+    const int nown = (iz1 - iz0 + 1) * NYP, obase = iz0 * NYP;
+    const double *dKm = k.dK + mo, *dMm = k.dM + mo, *cYm = k.cY + mo, *cZm = k.cZ + mo, *cZu = k.cZ + mo - NYP;
+    StenCo co[SB];
+    auto ld_co = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const unsigned e = (unsigned)(obase + min(i0 + u * VBLOCK, nown - 1));
+            co[u].dk = dKm[e]; co[u].dm = dMm[e];
+            co[u].cy0 = cYm[e]; co[u].cy1 = cYm[e - 1u];
+            co[u].cz0 = cZm[e]; co[u].cz1 = cZu[e];
+        }
+    };
+    ld_co(threadIdx.x);
+    __syncthreads();
+    double ar = 0, ai = 0;
+    for (int i0 = threadIdx.x; i0 < nown; i0 += SB * VBLOCK) {
+        if (i0 != (int)threadIdx.x) ld_co(i0);
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int i = i0 + u * VBLOCK;
+            const int iy = i - div_small(i, rNYP) * NYP;
+            if (i < nown && iy >= 1 && iy <= k.ny - 1) {
+                const int l = i + NYP;
+                const cplx pc = pn[l];
+                const double dm = w * co[u].dm;
+                cplx acc = cplx{co[u].dk * pc.re - dm * pc.im, co[u].dk * pc.im + dm * pc.re};
+                acc += co[u].cy0 * pn[l + 1];
+                acc += co[u].cy1 * pn[l - 1];
+                acc += co[u].cz0 * pn[l + NYP];
+                acc += co[u].cz1 * pn[l - NYP];
+                q[obase + i] = acc;
+                ar += pc.re * acc.re - pc.im * acc.im;
+                ai += pc.re * acc.im + pc.im * acc.re;
+            }
+        }
+    }
+    block_sum2(ar, ai, sh);
+    if (threadIdx.x == 0) k.partPQ[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
+}
+
+__global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const cplx* pcur, const cplx* rin, cplx* rout, int it) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);
+    const int nrows = iz1 - iz0 + 3;
+    cplx* cs = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]  dinv .* r'
+    cplx* rs = cs + (long)(k.RT + 2) * NYP;               // [RT][NYP]      r' of the own rows
+    __shared__ double sh[8];
+    const cplx pq = total_part(k.partPQ + (long)s * MAXNB, k.NTR);
+    const cplx al = k.rho2[(long)(it & 1) * k.S + s] / pq;
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx *p = pcur + so, *q = k.q + so, *ri = rin + so, *di = k.dinv + so;
+    cplx *x = k.x + so, *ro = rout + so;
+    float2* t = k.t32 + so;
+    double xx = 0, dummy = 0;
+    // r' = r - alpha q and dinv .* r' on rows iz0-1 .. iz1+1 (r, q, dinv vanish outside the interior: no masking)
+    for (int i = threadIdx.x; i < nrows * NYP; i += VBLOCK) {
+        const int lr = i / NYP, iy = i - lr * NYP;
+        const long e = (long)(iz0 - 1 + lr) * NYP + iy;
+        const cplx rn = ri[e] - al * q[e];
+        cs[i] = di[e] * rn;
+        if (lr >= 1 && lr <= nrows - 2) {
+            rs[i - NYP] = rn;
+            ro[e] = rn;
+            const cplx xv = x[e] + al * p[e];             // p vanishes outside the interior
+            x[e] = xv;
+            xx += cabs2(xv);
+        }
+    }
+    __syncthreads();
+    const int nown = (iz1 - iz0 + 1) * NYP;
+    for (int i = threadIdx.x; i < nown; i += VBLOCK) {
+        const int lr = i / NYP, iy = i - lr * NYP;
+        const long e = (long)(iz0 + lr) * NYP + iy;
+        cplx out = cplx{0, 0};
+        if (iy >= 1 && iy <= k.ny - 1) {
+            const int l = (lr + 1) * NYP + iy;
+            const cplx c = cs[l];
+            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+            acc += k.cY[mo + e] * cs[l + 1];
+            acc += k.cY[mo + e - 1] * cs[l - 1];
+            acc += k.cZ[mo + e] * cs[l + NYP];
+            acc += k.cZ[mo + e - NYP] * cs[l - NYP];
+            out = rs[i] - acc;
+        }
+        store_t32(k, t, iz0 + lr, iy, (float)out.re, (float)out.im);
+    }
+    block_sum2(xx, dummy, sh);
+    if (threadIdx.x == 0) {
+        k.partB[(long)s * MAXNB + blockIdx.x] = xx;
+        if (blockIdx.x == 0) k.alphaBeta[s] = al;
+    }
+}
+
+// warm start: r <- r - A x over interior nodes, x including whatever sits on its boundary nodes
+// (forward: Dirichlet values, so with r = 0 on entry this is the reference's rhs -Aio*bc minus Aii*x0)
+// sysOn != nullptr: workgroup (0,0) also does k_solve_begin's bookkeeping for the solve that follows (one launch less
+// on the critical path in front of each solve)
+__global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r, const int* __restrict__ sysOn) {
+    const int s = blockIdx.y;
+    if (sysOn && blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int t = threadIdx.x; t < k.S * MAXNB; t += VBLOCK) k.partB[t] = 0.0;
+        for (int t = threadIdx.x; t < k.S; t += VBLOCK) { k.active[t] = sysOn[t]; k.iters[t] = 0; k.status[t] = 0; }
+        if (threadIdx.x == 0) {
+            int n = 0;
+            for (int q = 0; q < k.S; ++q) n += sysOn[q];
+            *k.nactive = n;
+            *k.nactHost = n;
+        }
+    }
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx* u = x + so;
+    cplx* r = k.r + so;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        cplx out = cplx{0, 0};
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1)
+            out = (zero_r ? cplx{0, 0} : r[e]) - stencil_at(k, u, mo, e, w);
+        r[e] = out;
+    }
+}
+
+// k_resid0 + k_pre_c64 in one launch (the start of a solve on the default path): on a tile of RT rows
+//   r = b - A x0        on the tile's rows and one halo row on each side (x0 staged with two halo rows)
+//   t = r - A (dinv r)  on the tile's rows, written in the transform's input format
+// so the residual is not re-read by a second kernel and one launch disappears in front of each solve.  The residual is
+// written to a SECOND buffer (rout): the halo rows' b are read from rin while the neighbouring workgroups write theirs.
+// Workgroup (0,0) also does k_solve_begin's bookkeeping.
+__global__ __launch_bounds__(VBLOCK) void k_resid_pre(Solver k, const cplx* x, const cplx* rin, cplx* rout, int zero_r,
+                                                      const int* __restrict__ sysOn) {
+    const int s = blockIdx.y;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        for (int t = threadIdx.x; t < k.S * MAXNB; t += VBLOCK) k.partB[t] = 0.0;
+        for (int t = threadIdx.x; t < k.S; t += VBLOCK) { k.active[t] = sysOn[t]; k.iters[t] = 0; k.status[t] = 0; }
+        if (threadIdx.x == 0) {
+            int n = 0;
+            for (int q = 0; q < k.S; ++q) n += sysOn[q];
+            *k.nactive = n;
+            *k.nactHost = n;
+        }
+    }
+    extern __shared__ __attribute__((aligned(16))) char smem_[];
+    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1), nown = iz1 - iz0 + 1;
+    cplx* xs = reinterpret_cast<cplx*>(smem_);            // [(RT+4)][NYP]  x0 rows iz0-2 .. iz1+2; later dinv .* r (rows iz0-1 ..)
+    cplx* rs = xs + (long)(k.RT + 4) * NYP;               // [(RT+2)][NYP]  r rows iz0-1 .. iz1+1
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const float rNYP = 1.0f / (float)NYP;
+    const cplx* u = x + so;
+    for (int i = threadIdx.x; i < (nown + 4) * NYP; i += VBLOCK) {
+        const int lr = div_small(i, rNYP), g = iz0 - 2 + lr;
+        xs[i] = (g >= 0 && g <= k.nz) ? u[(long)g * NYP + (i - lr * NYP)] : cplx{0, 0};
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (nown + 2) * NYP; i += VBLOCK) {
+        const int lr = div_small(i, rNYP), iy = i - lr * NYP, g = iz0 - 1 + lr;
+        const long e = (long)g * NYP + iy;
+        cplx out = cplx{0, 0};
+        if (g >= 1 && g <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+            const int l = i + NYP;                         // the same node in xs (one more halo row in front)
+            const cplx c = xs[l];
+            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+            acc += k.cY[mo + e] * xs[l + 1];
+            acc += k.cY[mo + e - 1] * xs[l - 1];
+            acc += k.cZ[mo + e] * xs[l + NYP];
+            acc += k.cZ[mo + e - NYP] * xs[l - NYP];
+            out = (zero_r ? cplx{0, 0} : rin[so + e]) - acc;
+        }
+        rs[i] = out;
+        if (lr >= 1 && lr <= nown) rout[so + e] = out;
+    }
+    // the two boundary rows of r and of t (zeros)
+    if (blockIdx.x == 0 || iz1 == k.nz - 1) {
+        const int row = blockIdx.x == 0 ? 0 : k.nz;
+        for (int iy = threadIdx.x; iy < NYP; iy += VBLOCK) {
+            rout[so + (long)row * NYP + iy] = cplx{0, 0};
+            store_t32(k, k.t32 + so, row, iy, 0.f, 0.f);
+        }
+        if (blockIdx.x == 0 && iz1 == k.nz - 1)            // (a single tile: both rows)
+            for (int iy = threadIdx.x; iy < NYP; iy += VBLOCK) {
+                rout[so + (long)k.nz * NYP + iy] = cplx{0, 0};
+                store_t32(k, k.t32 + so, k.nz, iy, 0.f, 0.f);
+            }
+    }
+    __syncthreads();
+    const cplx* di = k.dinv + so;
+    for (int i = threadIdx.x; i < (nown + 2) * NYP; i += VBLOCK) xs[i] = di[(long)(iz0 - 1) * NYP + i] * rs[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < nown * NYP; i += VBLOCK) {
+        const int lr = div_small(i, rNYP), iy = i - lr * NYP;
+        const long e = (long)(iz0 + lr) * NYP + iy;
+        cplx out = cplx{0, 0};
+        if (iy >= 1 && iy <= k.ny - 1) {
+            const int l = i + NYP;
+            const cplx c = xs[l];
+            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+            acc += k.cY[mo + e] * xs[l + 1];
+            acc += k.cY[mo + e - 1] * xs[l - 1];
+            acc += k.cZ[mo + e] * xs[l + NYP];
+            acc += k.cZ[mo + e - NYP] * xs[l - NYP];
+            out = rs[l] - acc;
+        }
+        store_t32(k, k.t32 + so, iz0 + lr, iy, (float)out.re, (float)out.im);
+    }
+}
+
+// start of a solve: every requested system active, records cleared (one launch instead of five copies/memsets)
+__global__ void k_solve_begin(Solver k, const int* __restrict__ sysOn) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < k.S * MAXNB) k.partB[t] = 0.0;
+    if (t < k.S) { k.active[t] = sysOn[t]; k.iters[t] = 0; k.status[t] = 0; }
+    if (t == 0) {
+        int n = 0;
+        for (int s = 0; s < k.S; ++s) n += sysOn[s];
+        *k.nactive = n;
+        *k.nactHost = n;
+    }
+}
+
+// end of a solve: per-system records of this solve kind into the packed read-back buffer
+// rec = [2 kinds][S] iters (int) | [2][S] status (int) | [2][S] error estimate (double)
+__global__ void k_solve_end(Solver k, int kind, int* __restrict__ recI, double* __restrict__ recE) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= k.S) return;
+    recI[kind * k.S + s] = k.iters[s];
+    recI[(2 + kind) * k.S + s] = k.status[s];
+    recE[kind * k.S + s] = k.errEst[s];
+}
+
+// ---- initial guess extrapolated along the model path (options.warm_start == 2) ----
+// The fields are smooth functions of the model, and a leapfrog trajectory moves the model along an almost
+// straight line at almost constant speed.  With the last three models on that line at "times"
+// tau = -1-gamma, -1, 0 (unit = the last step; gamma, alpha = projections of the previous / the new step on
+// the last one) the guess is the Lagrange extrapolation of the last three fields to tau = alpha:
+//     x0 = w2 x_k + w1 x_{k-1} + w0 x_{k-2}      (uniform steps: 3, -3, 1)
+// when the three steps are nearly collinear, else the linear one  x0 = x_k + alpha (x_k - x_{k-1})
+// (e.g. across a momentum refresh).  State per solve kind, all on the device (no host round trip):
+// hist = [m_k | m_{k-1} | ... | m_{k-NP+1}], ext = {w_k, ..., w_{k-NP+1}, keep, count}; every further step that is
+// nearly collinear with the last one and of comparable length adds a point (and an order) to the Lagrange
+// extrapolation, up to EXT_NP fields.  A repeated model (getHamiltonian after the last leapfrog step) keeps the
+// history untouched.
+constexpr int EXT_NP = 6;          // fields kept per solve kind: the current one + EXT_NP-1 earlier ones (Lagrange order <= EXT_NP-1)
+constexpr int EXT_NBLK = 32;       // blocks of the partial-sum pass
+constexpr int EXT_NS = 2 * EXT_NP; // partial sums per block: <d_j,d1> (j = 0..NP-1), <d_j,d_j> (j = 0, 2..NP-1), <m_k,m_k>
+constexpr int EXT_KEEP = EXT_NP, EXT_COUNT = EXT_NP + 1, EXT_PART = EXT_NP + 2;   // ext = {w_0..w_{NP-1}, keep, count, partial sums...}
+
+// pass 1: per-block partial sums over the model history hist = [m_k | m_{k-1} | ... | m_{k-NP+1}]: steps
+// d0 = m_new - m_k, d_j = m_{k-j+1} - m_{k-j};  a[j] = <d_j,d1> (j < NP), a[NP] = <d0,d0>, a[NP+j-1] = <d_j,d_j>
+// (j = 2..NP-1), a[2NP-1] = <m_k,m_k>   ->  part[block][EXT_NS]
+__global__ __launch_bounds__(256) void k_extrap_sums(const double* __restrict__ mNew, const double* __restrict__ hist, int nAC,
+                                                      double* __restrict__ part) {
+    __shared__ double sh[EXT_NS][4];
+    double a[EXT_NS];
+#pragma unroll
+    for (int q = 0; q < EXT_NS; ++q) a[q] = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nAC; i += EXT_NBLK * 256) {
+        double m[EXT_NP], d[EXT_NP];
+#pragma unroll
+        for (int j = 0; j < EXT_NP; ++j) m[j] = hist[(long)j * nAC + i];
+        d[0] = mNew[i] - m[0];
+#pragma unroll
+        for (int j = 1; j < EXT_NP; ++j) d[j] = m[j - 1] - m[j];
+#pragma unroll
+        for (int j = 0; j < EXT_NP; ++j) a[j] += d[j] * d[1];
+        a[EXT_NP] += d[0] * d[0];
+#pragma unroll
+        for (int j = 2; j < EXT_NP; ++j) a[EXT_NP + j - 1] += d[j] * d[j];
+        a[EXT_NS - 1] += m[0] * m[0];
+    }
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < EXT_NS; ++q) {
+        a[q] = wave_sum(a[q]);
+        if ((threadIdx.x & 63) == 0) sh[q][w] = a[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < EXT_NS) part[blockIdx.x * EXT_NS + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+
+// pass 2 (one wave): the extrapolation weights from the partial sums
+__global__ __launch_bounds__(64) void k_extrap_weights(const double* __restrict__ part, double* ext, int maxNp) {
+    double a[EXT_NS];
+#pragma unroll
+    for (int q = 0; q < EXT_NS; ++q) a[q] = wave_sum(threadIdx.x < EXT_NBLK ? part[threadIdx.x * EXT_NS + q] : 0.0);
+    if (threadIdx.x != 0) return;
+    const int count = (int)ext[EXT_COUNT];
+    const double d1d1 = a[1], d0d0 = a[EXT_NP], mkmk = a[EXT_NS - 1];
+    const bool keep = count >= 1 && d0d0 <= 1e-28 * mkmk;
+    double wts[EXT_NP];                                       // weights of x_k, x_{k-1}, ...
+    for (int i = 0; i < EXT_NP; ++i) wts[i] = i == 0 ? 1.0 : 0.0;
+    if (!keep && count >= 2 && d1d1 > 0) {
+        const double alpha = fmin(2.0, fmax(-1.0, a[0] / d1d1));
+        wts[0] = 1.0 + alpha; wts[1] = -alpha;
+        // "times" of the models on the line through the last step: 0, -1, -1-g2, -1-g2-g3, ...; a further point is used
+        // while its step is nearly collinear with the last one and of comparable length
+        double tau[EXT_NP];
+        tau[0] = 0.0; tau[1] = -1.0;
+        int np = 2;
+        if (d0d0 > 0 && a[0] / sqrt(d0d0 * d1d1) > 0.95 && alpha > 0.5 && alpha < 2.0) {
+            for (int j = 2; j < EXT_NP; ++j) {
+                const double djdj = a[EXT_NP + j - 1], g = a[j] / d1d1;
+                if (!(count >= j + 1 && djdj > 0 && a[j] / sqrt(djdj * d1d1) > 0.95 && g > 0.5 && g < 2.0)) break;
+                tau[j] = tau[j - 1] - g;
+                np = j + 1;
+            }
+        }
+        np = min(maxNp, np);
+        if (np > 2) {
+            for (int i = 0; i < EXT_NP; ++i) {
+                double l = i < np ? 1.0 : 0.0;
+                for (int j = 0; j < np; ++j)
+                    if (j != i && i < np) l *= (alpha - tau[j]) / (tau[i] - tau[j]);
+                wts[i] = l;
+            }
+        }
+    }
+    for (int i = 0; i < EXT_NP; ++i) ext[i] = wts[i];
+    ext[EXT_KEEP] = keep ? 1.0 : 0.0;
+    if (!keep) ext[EXT_COUNT] = (double)min(count + 1, EXT_NP);
+}
+
+// pass 3: the model history moves on (unless the model is a repeat)
+__global__ __launch_bounds__(256) void k_extrap_shift(const double* __restrict__ mNew, double* hist, int nAC, const double* __restrict__ ext) {
+    if (ext[EXT_KEEP] != 0.0) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nAC) {
+#pragma unroll
+        for (int j = EXT_NP - 1; j >= 1; --j) hist[(long)j * nAC + i] = hist[(long)(j - 1) * nAC + i];
+        hist[i] = mNew[i];
+    }
+}
+
+// x <- sum_j w_j x_{k-j}, history shifted (... <- xp1 <- xp0 <- old x), on interior nodes (runs beside
+// k_bc_forward, which writes X's boundary nodes); xp = [EXT_NP-1][S*vstride]
+__global__ __launch_bounds__(VBLOCK) void k_extrap(Solver k, cplx* x, cplx* xp, const double* __restrict__ ext) {
+    if (ext[EXT_KEEP] != 0.0) return;
+    double w[EXT_NP];
+#pragma unroll
+    for (int j = 0; j < EXT_NP; ++j) w[j] = ext[j];
+    const long so = (long)blockIdx.y * k.vstride, hs = (long)k.S * k.vstride;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        if (iz < 1 || iz > k.nz - 1 || iy < 1 || iy > k.ny - 1) continue;
+        cplx q[EXT_NP];
+        q[0] = x[so + e];
+#pragma unroll
+        for (int j = 1; j < EXT_NP; ++j) q[j] = xp[(long)(j - 1) * hs + so + e];
+        cplx acc = w[0] * q[0];
+#pragma unroll
+        for (int j = 1; j < EXT_NP; ++j) acc += w[j] * q[j];
+#pragma unroll
+        for (int j = EXT_NP - 1; j >= 1; --j) xp[(long)(j - 1) * hs + so + e] = q[j - 1];
+        x[so + e] = acc;
+    }
+}
+
+// true residual norm check: partB = |b - A x|^2 with b passed separately (verify option)
+__global__ __launch_bounds__(VBLOCK) void k_trueres(Solver k, const cplx* b, const cplx* x, double* partRes, double* partBn) {
+    const int s = blockIdx.y;
+    __shared__ double sh[8];
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx* p = x + so;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    double rr = 0, bb = 0;
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+            const cplx c = p[e];
+            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+            // boundary entries of x hold Dirichlet values: they belong to the right-hand side
+            if (iy + 1 <= k.ny - 1) acc += k.cY[mo + e] * p[e + 1];
+            if (iy - 1 >= 1) acc += k.cY[mo + e - 1] * p[e - 1];
+            if (iz + 1 <= k.nz - 1) acc += k.cZ[mo + e] * p[e + k.NYP];
+            if (iz - 1 >= 1) acc += k.cZ[mo + e - k.NYP] * p[e - k.NYP];
+            rr += cabs2(b[so + e] - acc);
+            bb += cabs2(b[so + e]);
+        }
+    }
+    block_sum2(rr, bb, sh);
+    if (threadIdx.x == 0) { partRes[(long)s * MAXNB + blockIdx.x] = rr; partBn[(long)s * MAXNB + blockIdx.x] = bb; }
+}

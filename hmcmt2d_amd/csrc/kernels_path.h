@@ -1,0 +1,300 @@
+// kernels_path.h -- part of libhmcmt_hip.so; included by hmcmt_hip.hip INSIDE its anonymous namespace (one translation unit).
+// The kernels around the solves: assembly from sigma, 1-D boundary fields and their sensitivities, receiver
+// functionals and adjoint sources, J^T v accumulation (bodies in hmcmt_items.h), and the leapfrog vector kernels.
+#pragma once
+
+// ----------------------------------------------------------------------------------------------
+// item kernels
+// ----------------------------------------------------------------------------------------------
+#define TID1 (blockIdx.x * blockDim.x + threadIdx.x)
+
+__global__ void k_null() {}
+__global__ void k_sigma(View v) { int c = TID1; if (c < v.nCell) item_sigma(v, c); }
+// lateral means of one cell row per wave (deterministic shuffle reduction)
+__global__ __launch_bounds__(64) void k_rowmean(View v) {
+    const int kz = blockIdx.x;
+    double sa = 0.0, sl = 0.0;
+    for (int ky = threadIdx.x; ky < v.ny; ky += 64) {
+        const double s = v.sigma[(long)kz * v.ny + ky];
+        sa += s; sl += log(s);
+    }
+    sa = wave_sum(sa); sl = wave_sum(sl);
+    if (threadIdx.x == 0) { v.sigMeanA[kz] = sa / v.ny; v.sigMeanG[kz] = exp(sl / v.ny); }
+}
+__global__ void k_coef(View v, int te_doK, int te_doM, int tm_doK, int tm_doM) {
+    int e = TID1;
+    if (e >= v.NZP * (v.ny + 1)) return;
+    int iz = e / (v.ny + 1), iy = e % (v.ny + 1);
+    if (te_doK || te_doM) item_coef(v, 0, iy, iz, te_doK, te_doM);
+    if (tm_doK || tm_doM) item_coef(v, 1, iy, iz, tm_doK, tm_doM);
+}
+__global__ void k_fdm_z(View v) { int e = TID1; if (e < 2 * v.NZP) item_fdm_z(v, e / v.NZP, e % v.NZP); }
+// Inverse pivots of the FDM tridiagonals, with what used to be two more launches in front of and behind it: every
+// workgroup computes its mode's four z-coefficient rows (item_fdm_z: a hundred values) straight into LDS -- the
+// serial loop reads them from there, not from global memory -- and the first workgroup of each mode also stores
+// them for the solver's kernels; the complex64 copy of the pivots (ip32 != nullptr) is written along.
+__global__ __launch_bounds__(64) void k_pivot(View v, float2* ip32) {
+    extern __shared__ __attribute__((aligned(16))) char smem_pv[];
+    double* tab = reinterpret_cast<double*>(smem_pv);
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y, mode = s >= v.nFreq;
+    const bool store = blockIdx.x == 0 && s == mode * v.nFreq;
+    for (int i = threadIdx.x; i < v.NZP; i += blockDim.x) {
+        double a, b, c, d;
+        fdm_z_values(v, mode, i, a, b, c, d);
+        tab[i] = a; tab[v.NZP + i] = b; tab[2 * v.NZP + i] = c; tab[3 * v.NZP + i] = d;
+        if (store) {
+            const long o = (long)mode * v.NZP + i;
+            v.mzq[o] = a; v.dgz[o] = b; v.ofz[o] = c; v.mzs[o] = d;
+        }
+    }
+    __syncthreads();
+    if (j < v.ny - 1)
+        item_pivot_tab(v, s, j, tab, tab + v.NZP, tab + 2 * v.NZP, tab + 3 * v.NZP,
+                       ip32 ? reinterpret_cast<float*>(ip32 + (long)s * v.vstride + j) : nullptr);
+}
+__global__ __launch_bounds__(64) void k_bc_layers(View v) {       // grid z: frequencies
+    int col = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, f = blockIdx.z;
+    if (col <= v.ny) item_bc_layers_f(v, f, j, col);
+}
+// One thread per boundary column.  The two edge columns need the whole 1-D field (left / right boundary values):
+// their lane writes it to LDS inside the recurrence (same code path as every other lane) and the wave copies it
+// out afterwards.
+// One lane = one boundary column of one FREQUENCY: the layered-earth recurrences are the same for the two
+// polarisations, so one pass yields both systems' values.  Only the two edge columns need the fields under every layer;
+// their lanes store the amplitudes per layer in LDS and the workgroup evaluates the outputs afterwards in parallel
+// (fwd_outputs: ~30 fp64 instructions per layer that would otherwise sit in every wave's serial loop).
+__global__ __launch_bounds__(64) void k_bc_forward(View v) {
+    extern __shared__ __attribute__((aligned(16))) char smem_bc[];
+    cplx* amp = reinterpret_cast<cplx*>(smem_bc);         // [slot 0: column 0, slot 1: column ny][nz][eu, ed]
+    __shared__ FwdTop top[2];
+    __shared__ int deadAt[2];
+    const int col0 = blockIdx.x * blockDim.x, col = col0 + threadIdx.x, f = blockIdx.y;
+    const bool onE = v.sysOn[f] != 0, onH = v.sysOn[v.nFreq + f] != 0;
+    if (!onE && !onH) return;
+    cplx* XE = v.X + (long)f * v.vstride;
+    cplx* XH = v.X + (long)(v.nFreq + f) * v.vstride;
+    const long ls = v.ny + 1, qs = (long)v.nz * ls;
+    const bool has0 = col0 == 0, hasN = col0 <= v.ny && v.ny < col0 + (int)blockDim.x;
+    if (col <= v.ny) {
+        if (onE) XE[nidx(v, col, 0)] = cplx{1.0, 0.0};    // top row incl. corners
+        if (onH) XH[nidx(v, col, 0)] = cplx{1.0, 0.0};
+        const cplx* T = v.fwdTab + (long)f * FWD_NQ * qs + col;
+        // ONE instantiation of the recurrence for every lane (a separate call for the edge lanes would make their
+        // wave run the whole chain twice, once per divergent path: that was the kernel's critical path)
+        const bool isEdge = col == 0 || col == v.ny;
+        const int slot = col == 0 ? 0 : 1;
+        cplx* ea = amp + (long)slot * 2 * v.nz;
+        int dAt = v.nz;                                   // first layer behind the overflow cut-off
+        FwdTop tp;
+        cplx lastE, lastH;
+        bc1d_forward_core(v.omega[f], v.nz, T, qs, ls, [&](int i, cplx eu, cplx ed, cplx, bool dead) {
+            if (isEdge) { ea[2 * i] = eu; ea[2 * i + 1] = ed; if (dead && dAt > i) dAt = i; }
+        }, tp, lastE, lastH);
+        if (isEdge) { top[slot] = tp; deadAt[slot] = dAt; }
+        else {
+            if (onE) XE[nidx(v, col, v.nz)] = lastE;
+            if (onH) XH[nidx(v, col, v.nz)] = lastH;
+        }
+    }
+    if (has0 || hasN) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < v.nz; i += blockDim.x) {
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+                if (slot == 0 ? !has0 : !hasN) continue;
+                const int ecol = slot == 0 ? 0 : v.ny;
+                const cplx* T = v.fwdTab + (long)f * FWD_NQ * qs + ecol;
+                const cplx kj = T[(long)(i + 1 < v.nz ? i + 1 : v.nz - 1) * ls];      // k of the layer below (the last layer: its own)
+                cplx oE, oH;
+                fwd_outputs(top[slot], amp[((long)slot * v.nz + i) * 2], amp[((long)slot * v.nz + i) * 2 + 1], kj, i >= deadAt[slot], oE, oH);
+                if (onE) XE[nidx(v, ecol, 1 + i)] = oE;
+                if (onH) XH[nidx(v, ecol, 1 + i)] = oH;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(64) void k_sens_layers(View v) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
+    if (j <= v.nz) item_sens_layers(v, s, prof, j);
+}
+__global__ __launch_bounds__(64) void k_sens_profile(View v) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 3 * v.S) item_sens_profile(v, e / 3, e % 3);
+}
+__global__ void k_rhs(View v) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (e >= v.NZP * (v.ny + 1)) return;
+    item_rhs(v, s, e % (v.ny + 1), e / (v.ny + 1));
+}
+__global__ __launch_bounds__(64) void k_rx(View v, int wantDeriv) {
+    int e = TID1;
+    if (e < v.S * v.nRx) item_rx(v, e / v.nRx, e % v.nRx, wantDeriv != 0);
+}
+__global__ void k_resid(View v) { int p = TID1; if (p < v.nData) item_resid(v, p); }
+__global__ void k_misfit(View v, double* out) {
+    __shared__ double sh[8];
+    double a = 0, b = 0;
+    for (int p = threadIdx.x; p < v.nData; p += blockDim.x) a += v.misfitPart[p];
+    block_sum2(a, b, sh);
+    if (threadIdx.x == 0) *out = a;
+}
+// Between the two solves: per (system, receiver) the impedance (+ its derivatives), then the residual / misfit terms of
+// the data that address this receiver and their sum of conj(W'W r) -- one launch instead of three in a row on the
+// critical path (a datum belongs to exactly one (system, receiver), so there is no cross-thread dependency; the
+// misfit itself, a reduction over all data, is not needed by the adjoint half and is summed after the sources).
+__global__ __launch_bounds__(64) void k_rxall(View v, int wantGrad) {        // (64: registers instead of 200 B of spills)
+    const int e = TID1;
+    if (e >= v.S * v.nRx) return;
+    const int s = e / v.nRx, r = e % v.nRx;
+    item_rx(v, s, r, wantGrad != 0);
+    cplx c = cplx{0, 0};
+    for (int t = v.srStart[e]; t < v.srStart[e + 1]; ++t) {
+        const int p = v.srList[t];
+        item_resid(v, p);
+        c += v.vbar[p];
+    }
+    if (wantGrad) v.rxCoef[e] = c;
+}
+__global__ void k_rxcoef(View v) { int e = TID1; if (e < v.S * v.nRx) item_rxcoef(v, e / v.nRx, e % v.nRx); }
+// adjoint sources; workgroup (0,0) also adds up the misfit terms (a reduction nothing on the device waits for: no
+// launch of its own on the critical path between the solves)
+__global__ __launch_bounds__(128) void k_src(View v, double* misfitOut, int nsrc) {
+    // blocks x < nsrc: the sources; the blocks behind them: the receiver-layer Q-terms of the gradient (item_qterm
+    // needs nothing from the adjoint solve: here they cost no launch in the gradient tail)
+    const int s = blockIdx.y;
+    if ((int)blockIdx.x >= nsrc) {
+        const int ky = (blockIdx.x - nsrc) * blockDim.x + threadIdx.x;
+        if (ky < v.ny) item_qterm(v, s, ky);
+        return;
+    }
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 2 * (v.ny + 1)) item_src(v, s, e / (v.ny + 1), e % (v.ny + 1));
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        __shared__ double sh[2];
+        double a = 0;
+        for (int p = threadIdx.x; p < v.nData; p += 128) a += v.misfitPart[p];
+        a = wave_sum(a);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) *misfitOut = sh[0] + sh[1];
+    }
+}
+__global__ void k_wb(View v) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (e < v.nz) item_wside(v, s, e + 1);
+    else if (e < v.nz + v.ny) item_colw(v, s, e - v.nz);
+}
+__global__ __launch_bounds__(64) void k_bcsens_pre(View v) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
+    if (c < v.nz) item_bcsens_pre(v, s, prof, c);
+}
+__global__ void k_bcsens_contract(View v) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
+    if (c < v.nz) item_bcsens_contract(v, s, prof, c);
+}
+__global__ void k_gradcell(View v) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x, mode = blockIdx.y, grp = blockIdx.z;
+    if (c < v.nCell) item_gradcell_group(v, mode, grp, c);
+}
+__global__ __launch_bounds__(64) void k_qterm(View v) {
+    int ky = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (ky < v.ny) item_qterm(v, s, ky);
+}
+// final assembly with four lanes per active cell (a latency-bound loop over the systems: 4x the threads), each
+// taking every fourth system / partial sum; the four partial sums are added in lane order
+__global__ void k_gradfinal(View v) {
+    const int t = TID1, a = t >> 2, l = t & 3;
+    double g = 0.0;
+    if (a < v.nAC) {
+        const int cell = v.act[a];
+        const int ky = cell % v.ny, kz = cell / v.ny;
+        for (int q = l; q < 2 * GRAD_NG; q += 4) g += v.gPartG[(long)q * v.nCell + cell];
+#pragma unroll 4
+        for (int s = l; s < v.S; s += 4) g += gradfinal_sys(v, s, ky, kz);
+        if (kz == v.zid)
+            for (int s = l; s < v.S; s += 4) g += v.qPart[(long)s * v.ny + ky];
+    }
+    // lanes 4a .. 4a+3 are neighbours in a wave (the grid is a multiple of 64 threads)
+    const double g1 = __shfl_down(g, 1, 4), g2 = __shfl_down(g, 2, 4), g3 = __shfl_down(g, 3, 4);
+    if (a < v.nAC && l == 0) v.grad[a] = exp(v.m[a]) * (((g + g1) + g2) + g3);
+}
+
+// copy padded nodal layout -> reference layout [(ny+1)*(nz+1)] per frequency
+__global__ void k_unpad(View v, const cplx* src, cplx* dst, int s0) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    const int nn = (v.ny + 1) * (v.nz + 1);
+    if (e >= nn) return;
+    int iz = e / (v.ny + 1), iy = e % (v.ny + 1);
+    dst[(long)f * nn + e] = src[(long)(s0 + f) * v.vstride + nidx(v, iy, iz)];
+}
+
+// ----------------------------------------------------------------------------------------------
+// leapfrog vector kernels (proposeLeapfrog, HMCSampler.jl:206-269; diagonal mass)
+// ----------------------------------------------------------------------------------------------
+struct LfView {
+    int n;
+    const double *mref, *invM, *wmVal;
+    const long long *wmRow, *wmCol;
+    double *m, *p, *g;            // model, momentum, data gradient (in) / total gradient (out)
+    double *part;                 // [LFNB] partial maxima / sums
+    double *scal;                 // [0] mnorm
+    int* flag;                    // non-zero: non-finite value met
+};
+constexpr int LFNB = 64;
+
+// g <- g + lambda*Wm*(m - mref) ; p <- p - c*dt*g      (HMCSampler.jl:223-228, 255-263)
+__global__ void k_lf_momentum(LfView L, double lambda, double cdt) {
+    const int a = TID1;
+    if (a >= L.n) return;
+    double acc = 0.0;
+    for (long long t = L.wmRow[a]; t < L.wmRow[a + 1]; ++t) {
+        const long long j = L.wmCol[t];
+        acc += L.wmVal[t] * (L.m[j] - L.mref[j]);
+    }
+    const double g = L.g[a] + lambda * acc;       // L.g stays the data gradient (hmcmt_leapfrog memoises it)
+    L.p[a] -= cdt * g;
+}
+// partial max |dt*invM*p|   (HMCSampler.jl:237-240)
+__global__ __launch_bounds__(256) void k_lf_dmmax(LfView L, double dt) {
+    __shared__ double sh[4];
+    double mx = 0.0;
+    for (int a = blockIdx.x * 256 + threadIdx.x; a < L.n; a += 256 * LFNB) mx = fmax(mx, fabs(dt * L.invM[a] * L.p[a]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) L.part[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+// m += dm (clamped to max |dm| = 3), reflect at the ln-sigma bounds, flip momentum (:241-247, :515-559)
+__global__ void k_lf_step(LfView L, double dt, double lo, double hi) {
+    const int a = TID1;
+    if (a >= L.n) return;
+    double mx = 0.0;
+    for (int b = 0; b < LFNB; ++b) mx = fmax(mx, L.part[b]);
+    double dm = dt * L.invM[a] * L.p[a];
+    if (mx > 3.0) dm = dm / mx * 3.0;
+    double m = L.m[a] + dm, p = L.p[a];
+    if (!isfinite(m)) { atomicExch(L.flag, 1); return; }
+    for (int it = 0; it < 500 && !(m <= hi && m >= lo); ++it) {
+        if (m < lo) { m = 2.0 * lo - m; p = -p; }
+        if (m > hi) { m = 2.0 * hi - m; p = -p; }
+    }
+    L.m[a] = m; L.p[a] = p;
+}
+// mnorm = 0.5*lambda*(m-mref)' Wm (m-mref)   (HMCSampler.jl:389-391): partial sums, then block 0 finishes
+__global__ __launch_bounds__(256) void k_lf_mnorm(LfView L, double lambda) {
+    __shared__ double sh[8];
+    double acc = 0.0, dummy = 0.0;
+    for (int a = blockIdx.x * 256 + threadIdx.x; a < L.n; a += 256 * LFNB) {
+        double row = 0.0;
+        for (long long t = L.wmRow[a]; t < L.wmRow[a + 1]; ++t) { const long long j = L.wmCol[t]; row += L.wmVal[t] * (L.m[j] - L.mref[j]); }
+        acc += (L.m[a] - L.mref[a]) * row;
+    }
+    block_sum2(acc, dummy, sh);
+    if (threadIdx.x == 0) L.part[blockIdx.x] = acc;
+}
+__global__ void k_lf_mnorm_final(LfView L, double lambda) {
+    double acc = 0.0;
+    for (int b = 0; b < LFNB; ++b) acc += L.part[b];
+    L.scal[0] = 0.5 * lambda * acc;
+}

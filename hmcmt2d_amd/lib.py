@@ -16,7 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("HMCMT_LIB_PATH") or os.path.join(HERE, "libhmcmt_hip.so")   # (override: A/B runs of two builds)
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = [os.path.join(CSRC, "hmcmt_hip.hip"), os.path.join(CSRC, "mumps_shim.hip")]
-HEADERS = [os.path.join(CSRC, h) for h in ("hmcmt_math.h", "hmcmt_items.h", "hmcmt_host.h")] + \
+HEADERS = [os.path.join(CSRC, h) for h in ("hmcmt_math.h", "hmcmt_items.h", "hmcmt_host.h", "kernels_cocg.h", "kernels_fdm.h",
+                                            "kernels_fused.h", "kernels_path.h")] + \
           [os.path.join(HERE, "..", "include", "hmcmt.h"), os.path.join(HERE, "..", "include", "hmcmt_mumps.h")]
 
 HMCMT_NCAT = 8
