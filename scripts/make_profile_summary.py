@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy the judged artefacts of a scripts/gpu_profile_all.sh run into profiles/ and write the round summary.
 
-    python scripts/make_profile_summary.py gpurun_out/<run dir> [round tag, default r01]
+    python scripts/make_profile_summary.py gpurun_out/<run dir> [round tag, default r02] [config, default cfg3]
 """
 import csv
 import glob
@@ -11,75 +11,76 @@ import shutil
 import sys
 
 O = sys.argv[1]
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+cfg = sys.argv[3] if len(sys.argv) > 3 else "cfg3"
 P = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
-shutil.copy(glob.glob(os.path.join(O, "stats", "*", "*kernel_stats.csv"))[0], os.path.join(P, f"{tag}_bench_cfg3_kernel_stats.csv"))
-shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, f"{tag}_bench_cfg3.json"))
-shutil.copy(os.path.join(O, "pmc_traffic.json"), os.path.join(P, f"{tag}_pmc_traffic.json"))
-shutil.copy(os.path.join(O, "pmc_traffic.json"), os.path.join(P, "pmc_traffic.json"))
-rows = list(csv.DictReader(open(os.path.join(P, f"{tag}_bench_cfg3_kernel_stats.csv"))))
-d = json.load(open(os.path.join(P, f"{tag}_bench_cfg3.json")))
-pm = json.load(open(os.path.join(P, "pmc_traffic.json")))
-ne = 56
-out = [f"# Round {tag} — rocprofv3 summary of `bench.py` at cfg3 (200x100 cells, 16 freq, 1 chain, 1 MI355X)\n",
+stats_csv = os.path.join(P, f"{tag}_bench_{cfg}_kernel_stats.csv")
+shutil.copy(glob.glob(os.path.join(O, "stats", "*", "*kernel_stats.csv"))[0], stats_csv)
+shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, f"{tag}_bench_{cfg}.json"))
+# PMC bytes: merge this config's entry into the tracked file bench.py reads
+run_pm = json.load(open(os.path.join(O, "pmc_traffic.json")))
+tracked = os.path.join(P, "pmc_traffic.json")
+allc = json.load(open(tracked)) if os.path.exists(tracked) else {}
+if "per_launch_bytes" in allc:
+    allc = {"cfg3": allc}
+allc[cfg] = run_pm[cfg]
+json.dump(allc, open(tracked, "w"), indent=1)
+rows = list(csv.DictReader(open(stats_csv)))
+d = json.load(open(os.path.join(P, f"{tag}_bench_{cfg}.json")))
+pm = allc[cfg]
+out = [f"# Round {tag} — rocprofv3 summary of `bench.py --config {cfg}` (1 chain, 1 MI355X)\n",
        "Commands (on the GPU box, `scripts/gpu_profile_all.sh`; this file: `scripts/make_profile_summary.py`):\n",
-       "```\npython3 bench.py                                    -> %s_bench_cfg3.json (HIP-event sampling on, CPU leg on)\n"
-       "HMCMT_BENCH_NOPROF=1 rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 48 --warmup 8 --no-cpu-baseline --no-sampler\n"
-       "                                                    -> %s_bench_cfg3_kernel_stats.csv\n"
+       f"```\npython3 bench.py --config {cfg}                     -> {tag}_bench_{cfg}.json (HIP-event sampling on, CPU leg on, extras on)\n"
+       f"HMCMT_BENCH_NOPROF=1 rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 48 --warmup 8 --config {cfg} --no-cpu-baseline --no-extras\n"
+       f"                                                    -> {tag}_bench_{cfg}_kernel_stats.csv\n"
        "HMCMT_BENCH_NOPROF=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace ... (same command)  \\\n"
-       "HMCMT_BENCH_NOPROF=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace ... (same command)  /  -> scripts/pmc_summary.py -> %s_pmc_traffic.json\n"
-       "                                                                                      (= pmc_traffic.json, read by bench.py)\n```\n" % (tag, tag, tag)]
+       "HMCMT_BENCH_NOPROF=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace ... (same command)  /  -> scripts/pmc_summary.py -> pmc_traffic.json\n"
+       f"                                                                                      (entry \"{cfg}\", read by bench.py)\n```\n"]
 cb = d.get("cpu_baseline") or {}
-ss = d.get("structured_state") or {}
-out.append(f"Bench line: **{d['value']:.1f} steps/s** ({d['ms_per_step']:.3f} ms/step), iterations fwd/adj max "
-           f"{d['config']['iters_fwd_max']}/{d['config']['iters_adj_max']}; samples/s (reference cost structure) "
-           f"{(d.get('samples') or {}).get('samples_per_s', float('nan')):.1f}; structured-model state "
-           f"{ss.get('steps_per_s', float('nan')):.0f} steps/s (iterations {ss.get('iters_fwd_max')}/{ss.get('iters_adj_max')}); "
+nt = d.get("near_true_state") or {}
+sl = d.get("straight_line") or {}
+cs = d.get("cold_start") or {}
+ch = d.get("chain") or {}
+out.append(f"Bench line: **{d['value']:.1f} leapfrog steps/s** ({d['ms_per_step']:.3f} ms/step) on real trajectories of the chain started at "
+           f"the rough state (accepted {ch.get('accepted')} / rejected {ch.get('rejected')} in the timed region, iterations of the last step of a "
+           f"trajectory {ch.get('iters_fwd_max_last_step_mean', float('nan')):.0f} forward / {ch.get('iters_adj_max_last_step_mean', float('nan')):.0f} adjoint); "
+           f"chain started at the true model {nt.get('steps_per_s', float('nan')):.0f} steps/s "
+           f"({nt.get('iters_fwd_max_last_step_mean', float('nan')):.0f}/{nt.get('iters_adj_max_last_step_mean', float('nan')):.0f} iterations); idealised straight-line "
+           f"trajectories (round 1's headline) {sl.get('steps_per_s', float('nan')):.0f}; cold starts {cs.get('steps_per_s', float('nan')):.0f}; "
            f"CPU baseline (oracle, {cb.get('cores')} cores) {cb.get('value', float('nan')):.3f} steps/s.\n")
-out.append("The rocprofv3 run covers 56 evaluations (8 warm-up + 48 timed; the first warm-up evaluations are cold starts "
-           "with more iterations, so calls/eval is above the steady state).\n")
-out.append("`avg µs, working launches`: the convergence polls wait on an event behind `k_spmv_fused` with the rest of the iteration "
-           "already queued, so every solve ends with three launches that find all systems inactive and exit at once (~3 µs), and "
-           "late iterations run with part of the systems converged; the column averages the launches of the kernel trace that last "
-           "longer than 40 % of the kernel's median — the population bench.py's HIP events sample (it drops the launches the host "
-           "knows to be empty).\n")
-out.append("| kernel | calls/eval | avg µs, all launches (rocprofv3 --stats) | avg µs, working launches (kernel trace) | µs/eval | % | HIP-event avg µs in bench.py | PMC bytes/launch (MB) | algorithmic bytes/launch (MB) |")
+ri, rs = d["roofline_iteration"], d["roofline_step"]
+out.append(f"Roofline (HIP events, every launch of every 6th evaluation of the timed region; numerators scaled by the device-counted number "
+           f"of active systems): dominant kernel `{d['roofline']['kernel'].split(' ')[0]}` {d['roofline']['achieved']:.0f} GB/s algorithmic = "
+           f"**{d['roofline']['frac']:.3f}** of the 8 TB/s HBM peak at {d['roofline']['active_systems_per_launch']:.1f} active systems per launch; one COCG iteration "
+           f"({ri['kernels']} launches) {ri['us']:.1f} us = {ri['frac']:.3f}; whole step (iteration kernels' bytes / wall time) {rs['frac']:.3f}.\n")
+nev = None
+for r in rows:
+    if "k_sigma" in r["Name"]:
+        nev = int(r["Calls"])
+nev = nev or 1
+out.append(f"The rocprofv3 run covers {nev} evaluations (chain set-up, 8 warm-up steps, 48 timed steps, the verify evaluation).\n")
+out.append("| kernel | calls/eval | avg us, all launches (rocprofv3 --stats) | us/eval | % | HIP-event avg us in bench.py (same population: all launches, sampled evaluations of the timed region) | active systems / launch | PMC bytes/launch (MB) | algorithmic bytes/launch (MB) |")
 out.append("|---|---|---|---|---|---|---|---|---|")
-import statistics
-durs = {}
-tr = glob.glob(os.path.join(O, "stats", "*", "*kernel_trace.csv"))
-if tr:
-    for r in csv.DictReader(open(tr[0])):
-        n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-        durs.setdefault(n, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-def working_avg(n):
-    v = durs.get(n)
-    if not v:
-        return ""
-    med = statistics.median(v)
-    w = [x for x in v if x > 0.4 * med]
-    return f"{sum(w) / len(w):.1f}"
 ev = {}
 for r in [d["roofline"]] + d["roofline_other"]:
-    ev[r["kernel"].split(" ")[0].split("<")[0]] = (r["avg_launch_us"], r["bytes_per_launch"])
-tot = sum(float(r["TotalDurationNs"]) for r in rows) / ne / 1e3
+    ev[r["kernel"].split(" ")[0].split("<")[0]] = r
+tot = sum(float(r["TotalDurationNs"]) for r in rows) / nev / 1e3
 for r in rows:
-    t = float(r["TotalDurationNs"]) / ne / 1e3
+    t = float(r["TotalDurationNs"]) / nev / 1e3
     if t < 3:
         continue
     nm = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     e = ev.get(nm.split("<")[0])
     pk = pm["kernels"].get(nm)
-    cells = [f"`{nm}`", f"{int(r['Calls']) / ne:.1f}", f"{float(r['AverageNs']) / 1e3:.1f}", working_avg(nm), f"{t:.1f}", f"{100 * t / tot:.1f}",
-             f"{e[0]:.1f}" if e else "", f"{pk['bytes_per_launch'] / 1e6:.1f}" if pk else "", f"{e[1] / 1e6:.1f}" if e else ""]
+    cells = [f"`{nm}`", f"{int(r['Calls']) / nev:.1f}", f"{float(r['AverageNs']) / 1e3:.1f}", f"{t:.1f}", f"{100 * t / tot:.1f}",
+             f"{e['avg_launch_us']:.1f}" if e else "", f"{e['active_systems_per_launch']:.1f}" if e else "",
+             f"{pk['bytes_per_launch'] / 1e6:.1f}" if pk else "", f"{e['bytes_per_launch'] / 1e6:.1f}" if e else ""]
     out.append("| " + " | ".join(cells) + " |")
-out.append(f"\nSum of kernel time per evaluation: {tot:.0f} µs (k_sens_profile and the extrapolation kernels run on the side stream "
-           "under the forward solve).\n")
-out.append("PMC bytes are `(2*FETCH_SIZE + WRITE_SIZE)*1024` averaged over ALL launches of the run, including the late iterations in "
-           "which most systems have converged and their workgroups exit at once — hence below the algorithmic bytes of a full launch. "
-           "FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads; 2- and 8-byte-per-lane accesses are "
-           "uncalibrated, so treat the complex64 / bf16 rows as ±2x on the read side. Only `k_fdm_fwd` moves more than its algorithmic "
-           "bytes (each of a system's 7 slab workgroups reads that system's rows; they share one XCD's L2). The launches are "
-           "latency-bound: the ~160 MB working set of one solve sits in the 256 MB Infinity Cache.\n")
-open(os.path.join(P, f"{tag}_bench_cfg3_summary.md"), "w").write("\n".join(out))
-print("\n".join(out)[:3600])
+out.append(f"\nSum of kernel time per evaluation: {tot:.0f} us (k_sens_profile, k_bcsens_pre, k_pivot and the extrapolation kernels run on the side "
+           "streams beside the solves).\n")
+out.append("PMC bytes are `(2*FETCH_SIZE + WRITE_SIZE)*1024` averaged over ALL launches of the run (late iterations with most systems "
+           "converged included). FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads; 2- and 8-byte-per-lane "
+           "accesses are uncalibrated, so treat the complex64 / bf16 rows as +-2x on the read side. The launches are latency-bound: the "
+           "~160 MB working set of one solve sits in the 256 MB Infinity Cache.\n")
+open(os.path.join(P, f"{tag}_bench_{cfg}_summary.md"), "w").write("\n".join(out))
+print("\n".join(out)[:4000])

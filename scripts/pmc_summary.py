@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 PMC passes of bench.py into profiles/pmc_traffic.json.
 
-    python scripts/pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [out.json]
+    python scripts/pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [out.json] [config]
+
+The output file is keyed by bench.py's --config (cfg3, cfg5, ...): an existing file keeps its other configs.
 
 Each pass is `rocprofv3 --pmc <COUNTER> --kernel-trace --output-format csv -d <dir> -- python3 bench.py ...`
 (separate runs: FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950).  Units and corrections follow
@@ -52,10 +54,20 @@ def main():
                 b += v["bytes_per_launch"] * v["launches"]
                 n += v["launches"]
         cats[c] = b / n if n else None
+    config = sys.argv[4] if len(sys.argv) > 4 else "cfg3"
+    allc = {}
+    if os.path.exists(out):
+        try:
+            allc = json.load(open(out))
+            if "per_launch_bytes" in allc:          # round-1 layout (not keyed by config): it was cfg3
+                allc = {"cfg3": allc}
+        except ValueError:
+            allc = {}
+    allc[config] = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --config %s; "
+                              "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch, averaged over all launches of the run" % config,
+                    "per_launch_bytes": cats, "kernels": {k: v for k, v in kernels.items() if k.startswith("k_")}}
     with open(out, "w") as f:
-        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py; "
-                             "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch",
-                   "per_launch_bytes": cats, "kernels": kernels}, f, indent=1)
+        json.dump(allc, f, indent=1)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["bytes_per_launch"] * kv[1]["launches"])[:16]:
         print(f"{k:40s} n={v['launches']:6d} fetch(raw KiB)={v['fetch_kib_raw']:10.1f} write(KiB)={v['write_kib']:10.1f} "
               f"bytes/launch={v['bytes_per_launch'] / 1e6:8.2f} MB")
