@@ -367,6 +367,7 @@ def main():
         if not back_fused:
             fams["k_post (second Jacobi half: 5-point stencil + dot products)"] = ("post_smoother", 64.0, 1, it_sys + pre_sys)
         roofs = []
+        ws_mb = 15 * ctx.S * ctx.NZP * ctx.NYP * 16 / 1e6
         it_bytes = it_us = step_bytes = 0.0
         nev = max(cnt["evaluations"], 1)
         for kname, (cat, bpu, per_it, sys_launches) in fams.items():
@@ -395,8 +396,10 @@ def main():
         iteration = {"kernels": len(fams), "bytes": it_bytes, "us": it_us,
                      "achieved": it_bytes / (it_us * 1e-6) / 1e9 if it_us else 0.0, "unit": "GB/s",
                      "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS if it_us else 0.0,
-                     "note": "one preconditioned COCG iteration of the systems still active = %d launches;" % len(fams) + " the working set "
-                             "(~15 vectors) fits the 256 MB Infinity Cache at cfg3, so launches are latency- not HBM-bound"}
+                     "note": "one preconditioned COCG iteration of the systems still active = %d launches; " % len(fams) +
+                             ("the working set of a solve (~15 vectors = %.0f MB) fits the 256 MB Infinity Cache, so launches are "
+                              "latency- not HBM-bound" if ws_mb <= 256 else
+                              "the working set of a solve (~15 vectors = %.0f MB) is beyond the 256 MB Infinity Cache: HBM-bound") % ws_mb}
         ms_step = 1e3 * elapsed / K
         step = {"bytes_per_step": step_bytes, "ms_per_step": ms_step, "achieved": step_bytes / (ms_step * 1e-3) / 1e9,
                 "unit": "GB/s", "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
