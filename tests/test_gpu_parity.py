@@ -556,3 +556,52 @@ def test_sampler_context_lands_on_the_ranks_device(monkeypatch):
     del inv2, c2
     gc.collect()
     assert key not in sampler._contexts
+
+
+def test_device_resident_trajectories_match_the_host_entry_point():
+    """hmcmt_leapfrog_device (model and momentum stay in HBM, updated in place; what bench.py times) against
+    hmcmt_leapfrog (host buffers) on the same trajectories, for the three sources of the start gradient: evaluated
+    (0), kept from the END of the previous trajectory (1: the proposal was accepted) and kept from its START (2: it was
+    rejected).  Same kernels, same order of operations: model, momentum, predicted data, misfit and the prior term
+    agree to rounding of the warm-started solves."""
+    import torch
+    mesh, data, inv, m = make_problem("cfg2")
+    n = len(m)
+    inv.refModel = np.full(n, np.log(0.01))
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(8)
+    p = [np.clip(rng.standard_normal(n), -2.5, 2.5) for _ in range(3)]
+    lo, hi = float(np.log(1e-4)), 0.0
+    args = (0.03, 4, 1.0, lo, hi)
+
+    host = HipContext(mesh, data, inv)
+    host.set_prior(inv.refModel, inv.Wm, np.ones(n))
+    h1 = host.leapfrog(m, p[0], *args)                    # trajectory 1 from m
+    h2 = host.leapfrog(h1[0], p[1], *args)                # accepted: trajectory 2 from the end model of 1
+    h3 = host.leapfrog(h1[0], p[2], *args)                # rejected: trajectory 3 from the start model of 2
+    host.close()
+
+    ctx = HipContext(mesh, data, inv)
+    ctx.set_prior(inv.refModel, inv.Wm, np.ones(n))
+    d_pred = torch.zeros(2 * ctx.nData, dtype=torch.float64, device=dev)
+    d_sc = torch.zeros(2, dtype=torch.float64, device=dev)
+
+    def traj(m_start, p0, start_grad):
+        d_m = torch.from_numpy(np.ascontiguousarray(m_start)).to(dev)
+        d_p = torch.from_numpy(np.ascontiguousarray(p0)).to(dev)
+        torch.cuda.synchronize()
+        nf = ctx.leapfrog_device(d_m.data_ptr(), d_p.data_ptr(), *args, start_grad, d_pred.data_ptr(), d_sc.data_ptr(),
+                                 d_sc.data_ptr() + 8)
+        ctx.wait()
+        return d_m.cpu().numpy(), d_p.cpu().numpy(), d_pred.cpu().numpy().view(np.complex128), float(d_sc[0]), float(d_sc[1]), nf
+
+    with pytest.raises(HmcmtError):                        # nothing to reuse yet
+        traj(m, p[0], 1)
+    for dres, hres in ((traj(m, p[0], 0), h1), (None, h2), (None, h3)):
+        if dres is None:
+            dres = traj(h1[0], p[1], 1) if hres is h2 else traj(h1[0], p[2], 2)
+        assert dres[5] == hres[5] == 5                     # counted as the reference counts: L + 1
+        assert relmax(dres[0], hres[0]) < 1e-10 and relmax(dres[1], hres[1]) < 1e-8
+        assert relmax(dres[2], hres[2]) < 1e-8 and abs(dres[3] - hres[3]) < 1e-8 * hres[3]
+        assert abs(dres[4] - hres[4]) <= 1e-9 * max(hres[4], 1e-30)
+    ctx.close()
