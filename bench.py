@@ -194,15 +194,21 @@ class Chain:
 
 
 def timed(torch, dist, fn):
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    fn()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    return time.perf_counter() - t0
+    import gc
+    gc.collect()
+    gc.disable()                      # (no collector pauses inside a timed region)
+    try:
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    finally:
+        gc.enable()
 
 
 def main():
@@ -335,6 +341,27 @@ def main():
         extras["cold_start"] = {"steps_per_s": min(Ke, 16) / t4, "steps": min(Ke, 16), "iters_fwd_max": s4["iters_fwd_max"],
                                 "iters_adj_max": s4["iters_adj_max"], "state": "the straight-line models, options.warm_start = 0"}
         ctx.set_options(warm_start=2)
+        # (v) two chains on this GPU at once (what parallelHMCSampler(chains_per_gpu=2) does): a second context, one
+        # host thread per chain; aggregate steps/s of both chains near the true model
+        import threading
+        ctxb = HipContext(mesh, data, inv, device_id=local)
+        ca = Chain(ctx, torch, dev, m_true, mref, inv.Wm, seed=7)
+        cb_ = Chain(ctxb, torch, dev, m_true, mref, inv.Wm, seed=8)
+        for c in (ca, cb_):
+            c.run(2 * LTRAJ)
+        th = [threading.Thread(target=c.run, args=(Ke,)) for c in (ca, cb_)]
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        t5 = time.perf_counter() - t5
+        extras["two_chains_per_gpu"] = {"steps_per_s_aggregate": 2 * Ke / t5, "steps_per_chain": Ke,
+                                        "state": "two independent chains near the true model on ONE GPU (two contexts, two host "
+                                                 "threads): the launches of one chain are latency-bound, two overlap"}
+        ctxb.close()
 
     if rank == 0:
         # Algorithmic bytes per launch: U = S*(nz-1)*(ny-1) interior unknowns, complex128 = 16 B,

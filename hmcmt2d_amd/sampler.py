@@ -268,7 +268,7 @@ def runHMCSampler(mtMesh, mtData, invParam, hmcprior, rng=None, rhoref=None, ctx
 
 # --------------------------------------------------------------------------------------------
 def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, outdir=None, nchains=None,
-                       run_chain=None, device_id=None, context_factory=None, **sampler_kw):
+                       run_chain=None, device_id=None, context_factory=None, chains_per_gpu=1, **sampler_kw):
     """Independent chains, one process per GPU (parallelHMC.jl:10-49).
 
     With `torch.distributed` initialised (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
@@ -279,6 +279,10 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
     after another.  `pids` is kept for signature parity: its length is the number of chains (default:
     world size).  `context_factory(mesh, data, inv, device_id)` replaces `get_context` (the CPU tests run
     the real sampler on an oracle-backed stand-in); `run_chain(chain_index, rng)` replaces the sampler.
+    `chains_per_gpu` > 1 runs that many of the rank's chains CONCURRENTLY on its GPU, one context and one host
+    thread each: a single chain's launches are latency-bound at the headline size, and two chains overlap to
+    1.34x the throughput of one (measured, scripts/gpu_two_chains.py); the chains and their results are the same as
+    run one after another (independent contexts, per-chain RNG streams).
     Further keyword arguments go to runHMCSampler (e.g. device_leapfrog=True).
     Returns (hmcmodel[list], hmcstats[list], hmcdata[list]) indexed by chain.
     """
@@ -298,7 +302,8 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
         nchains = len(pids) if pids is not None else world
     mine = list(range(rank, nchains, world))
     results = {}
-    for c in mine:
+
+    def one_chain(c):
         rng = np.random.default_rng([seed, c])
         t0 = time.time()
         if run_chain is not None:
@@ -310,6 +315,14 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
             model, stats, data = runHMCSampler(mesh_c, mtData, inv_c, prior_c, rng, ctx=ctx_c, **sampler_kw)
             release_context(inv_c)
         results[c] = (model, stats, data, time.time() - t0)
+
+    if chains_per_gpu > 1 and len(mine) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=int(chains_per_gpu)) as pool:      # (the library calls release the GIL)
+            list(pool.map(one_chain, mine))
+    else:
+        for c in mine:
+            one_chain(c)
 
     nparam, nsamples = next(iter(results.values()))[0].shape if results else (len(invParam.strModel), hmcprior.totalsamples)
     ndata = len(invParam.obsData)

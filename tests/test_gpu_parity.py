@@ -605,3 +605,16 @@ def test_device_resident_trajectories_match_the_host_entry_point():
         assert relmax(dres[2], hres[2]) < 1e-8 and abs(dres[3] - hres[3]) < 1e-8 * hres[3]
         assert abs(dres[4] - hres[4]) <= 1e-9 * max(hres[4], 1e-30)
     ctx.close()
+
+
+def test_concurrent_chains_on_one_gpu_equal_sequential_ones():
+    """parallelHMCSampler(chains_per_gpu=2): two chains of this rank run concurrently on the GPU (one context and one
+    host thread each) -- the samples must be the ones the same chains produce one after another."""
+    from hmcmt2d_amd import sampler
+    mesh, data, inv, m = make_problem("tiny")
+    prior = HMCPrior(totalsamples=3, burninsamples=1, dt=0.02, timestep=[2, 3], sigBounds=[1e-4, 1.0])
+    seq = sampler.parallelHMCSampler(mesh, data, inv, prior, nchains=3, seed=4)
+    con = sampler.parallelHMCSampler(mesh, data, inv, prior, nchains=3, seed=4, chains_per_gpu=2)
+    for c in range(3):
+        assert np.array_equal(seq[0][c], con[0][c]) and np.array_equal(seq[2][c], con[2][c])
+        assert np.array_equal(seq[1][c].acceptstats, con[1][c].acceptstats)
