@@ -186,7 +186,11 @@ class Chain:
 
     def summary(self):
         it = np.array(self.iters) if self.iters else np.zeros((1, 3))
+        ms = self.ms_per_step[-len(self.iters):] if self.iters else []
         return {"trajectories": len(self.iters), "accepted": self.accepted, "rejected": self.rejected,
+                # samples/s = trajectories/s (a sample costs L new evaluations here; the reference pays
+                # L + 1 gradients and one more forward solve for the same sample, HMCSampler.jl:136,141)
+                "samples_per_s": (1e3 / (LTRAJ * float(np.mean(ms)))) if ms else None,
                 "iters_fwd_max_last_step_mean": float(it[:, 0].mean()), "iters_adj_max_last_step_mean": float(it[:, 1].mean()),
                 "fp64_restarts": int(it[:, 2].sum()), "misfit_last": self.D0, "failed_trajectories": self.failed,
                 "ms_per_step_by_trajectory": [round(x, 3) for x in self.ms_per_step[-len(self.iters):]],

@@ -193,3 +193,33 @@ def test_rho_phase_data_type():
     _check(c2, m, po, mo, go, inv2, mesh, **rp)
     assert c2.iters()[:, nF:].max() == 0
     c2.close()
+
+
+def test_example_directory_short_chain_matches_the_oracle_chain():
+    """HMCMT/examples/dprism3d run as the reference's runHMCscript.jl runs it -- readstartupFile, runHMCSampler,
+    outputHMCSamples, getPosteriorModel -- but two samples long with two leapfrog steps each: the HIP chain (host
+    leapfrog loop and device trajectory) against the oracle's chain under the same random stream."""
+    import copy
+    from oracle import hmcmt_oracle as O
+    from hmcmt2d_amd import sampler, fileio
+    mesh, data, inv, prior = readstartupFile(os.path.join(GOLDEN, "examples", "dprism3d", "startupfile"))
+    prior.totalsamples, prior.burninsamples, prior.timestep = 2, 0, [2, 2]
+    mesh_o, inv_o, prior_o = copy.deepcopy(mesh), copy.deepcopy(inv), copy.deepcopy(prior)
+    O.setupTensorMesh2D(mesh_o)
+    mo, so, do = O.runHMCSampler(mesh_o, data, inv_o, prior_o, np.random.default_rng(21), dense_dbc=False)
+    for dev in (False, True):
+        inv_p, prior_p = copy.deepcopy(inv), copy.deepcopy(prior)
+        mp, sp_, dp = sampler.runHMCSampler(copy.deepcopy(mesh), data, inv_p, prior_p, np.random.default_rng(21),
+                                            device_leapfrog=dev)
+        sampler.release_context(inv_p)
+        assert np.array_equal(sp_.acceptstats, so["acceptstats"]) and prior_p.nfevals == prior_o.nfevals
+        assert relmax(mp, mo) < 1e-7 and relmax(dp, do) < 1e-7 and relmax(sp_.hmstats, so["hmstats"]) < 1e-7
+    # the reference's writers on the result (byte-compatible formats, SURVEY App. D)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        fileio.outputHMCSamples(mp, sp_, dp, ichain=1, cputime=1.0, outdir=td)
+        mean, std = fileio.getPosteriorModel(mp, copy.deepcopy(mesh), inv, prior, outdir=td)
+        assert sorted(os.listdir(td)) == ["hmcsamples_id1.data", "hmcsamples_id1.model", "hmcstatistics_id1.log",
+                                          "meanModel.model", "stdModel.model"]
+        back = fileio.readEMModel2D(os.path.join(td, "meanModel.model"))
+        assert back.gridSize == mesh.gridSize and np.allclose(np.log(back.sigma[inv.activeIdx]), mean, atol=6e-3)
