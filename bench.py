@@ -373,10 +373,10 @@ def main():
         # counted).  One preconditioned COCG iteration = these four launches on the fused path (five when the back
         # transform and the post-smoother run as separate kernels: wide meshes, HMCMT_FUSED_BACK=0):
         #   k_fdm_fwd      forward eigen-transform + tridiagonal solves: read t (8) + inverse pivots (8), write y (8) = 24 U
-        #   k_back_post    back transform + both Jacobi halves + dots: read y (8), dinv (16), r (16), write t (16)   = 56 U
-        #                  (separate: k_transform_lp<2> 56 U with z written, k_post: read r, z, dinv (48), write t (16) = 64 U)
-        #   k_spmv_fused   p = z + beta p, q = A p, p'q: read z, p (32), write p, q (32)                             = 64 U
-        #   k_update_fused x, r updates + Jacobi pre-smoothing: read p, q, r, x, dinv (80), write x, r (32), t (8)   = 120 U
+        #   k_back_post    back transform + both Jacobi halves + dots: read y (8), dinv (16), r (16), write z (8)   = 48 U
+        #                  (separate: k_transform_lp<2> 56 U with z1 written, k_post: read r, z1, dinv (48), write z (8) = 56 U)
+        #   k_spmv_fused   p = z + beta p, q = A p, p'q: read z, p (8 + 8: complex64), write p (8), q (16)          = 40 U
+        #   k_update_fused x, r updates + Jacobi pre-smoothing: read p (8), q, r, x, dinv (64), write x, r (32), t (8) = 112 U
         # A launch works on the systems still active; U_launch = U * (active systems / S), the active count from the
         # device counter of hmcmt_profile_counters over the SAME sampled launches the HIP events time (every launch of
         # every 6th evaluation of the timed region, the empty ones behind a convergence poll included).
@@ -392,11 +392,11 @@ def main():
                 ("k_back_post (split-bf16 MFMA back transform + both Jacobi halves of the post-smoother + dot products)" if back_fused else
                  "k_transform_lp<2> (split-bf16 MFMA back transform fused with the first Jacobi half)" if fwd_fused else
                  "k_transform_lp<0>,<2> (split-bf16 MFMA forward and back transforms: 16 U and 56 U)"):
-                    ("fdm_transform", 56.0 if fwd_fused else 36.0, 1 if fwd_fused else 2, (it_sys + pre_sys) * (1 if fwd_fused else 2)),
-                "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 64.0, 1, it_sys),
-                "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 120.0, 1, it_sys)}
+                    ("fdm_transform", (48.0 if back_fused else 56.0) if fwd_fused else 36.0, 1 if fwd_fused else 2, (it_sys + pre_sys) * (1 if fwd_fused else 2)),
+                "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 40.0, 1, it_sys),
+                "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 112.0, 1, it_sys)}
         if not back_fused:
-            fams["k_post (second Jacobi half: 5-point stencil + dot products)"] = ("post_smoother", 64.0, 1, it_sys + pre_sys)
+            fams["k_post (second Jacobi half: 5-point stencil + dot products)"] = ("post_smoother", 56.0, 1, it_sys + pre_sys)
         roofs = []
         ws_mb = 15 * ctx.S * ctx.NZP * ctx.NYP * 16 / 1e6
         it_bytes = it_us = step_bytes = 0.0

@@ -235,7 +235,7 @@ int launch_back_post(hmcmt_ctx* ctx) {
     }
     int rc;
     if ((rc = launch_transform_lp<2>(ctx, k.y32, true, k.z, k.active))) return rc;   // z = F t + dinv r
-    { ProfScope ps(ctx, 7); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+    { ProfScope ps(ctx, 7); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ, k.z32); }
     return 0;
 }
 
@@ -313,7 +313,7 @@ int apply_precond(hmcmt_ctx* ctx) {
     if ((rc = launch_transform(ctx, k.y, ctx->d_Vt, k.z, k.active))) return rc;
     if (smooth) {
         { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_mid, vg, vb, 0, ctx->stream, k); }
-        { ProfScope ps(ctx, 7); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+        { ProfScope ps(ctx, 7); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ, (float2*)nullptr); }
         std::swap(k.z, k.t);                            // the smoothed result is the preconditioned residual
     } else {
         ProfScope ps(ctx, 3);
@@ -352,7 +352,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     cplx* const r_entry = k.r;
     if (fused) {
         { int prc = apply_precond(ctx); if (prc) return prc; }          // z = P^-1 r and the partial sums of r'z, |z|^2
-        cplx* pb[2] = {k.p, k.p2};
+        float2* pb[2] = {k.p32a, k.p32b};
         cplx* rb[2] = {k.r, k.r2};
         int rcur = 0;
         // Convergence polls.  The device keeps the number of active systems (and the stagnation flag) in mapped pinned
@@ -391,8 +391,6 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             HIPCHK(hipStreamSynchronize(ctx->stream));
             if (*(volatile int*)ctx->h_nactive == 0) done = true;
         }
-        k.p = pb[it & 1];                // current search direction (only needed by the classic restart below)
-        k.p2 = pb[(it - 1) & 1];
         if (done) it = std::max(0, it - 1);
     }
     if (!done) {
@@ -838,6 +836,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     k.r = v.R;
     DA(k.p, S * VS) DA(k.q, S * VS) DA(k.z, S * VS) DA(k.y, S * VS) DA(k.t, S * VS) DA(k.dinv, S * VS)
     DA(k.t32, S * VS + 64) DA(k.y32, S * VS + 64) DA(ctx->d_invp32, S * VS)
+    DA(k.z32, S * VS) DA(k.p32a, S * VS) DA(k.p32b, S * VS)
     DA(k.p2, S * VS) DA(k.r2, S * VS) DA(k.partPQ, S * MAXNB) DA(k.rho2, 2 * S)
     k.invp32 = ctx->d_invp32;
     DA(k.partA, S * MAXNB) DA(k.partB, S * MAXNB) DA(ctx->d_partZZ, S * MAXNB)
@@ -1169,6 +1168,14 @@ int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z) {
     if (rc) return rc;
     apply_precond(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0) {
+        // the default path leaves its result as complex64 (Solver::z32): widen it for the caller
+        const size_t n = (size_t)ctx->v.S * ctx->v.vstride;
+        std::vector<float2> h(n);
+        HIPCHK(hipMemcpy(h.data(), ctx->sv.z32, n * sizeof(float2), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) { z[2 * i] = h[i].x; z[2 * i + 1] = h[i].y; }
+        return 0;
+    }
     HIPCHK(hipMemcpy(z, ctx->sv.z, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1252,7 +1259,7 @@ int hmcmt_debug_back_post(hmcmt_ctx* ctx, const double* y, const double* r, doub
         hipLaunchKernelGGL(k_to_c64, dim3(k.NB, k.S), dim3(VBLOCK), 0, ctx->stream, k, k.r);
         HIPCHK(hipMemcpyAsync(k.y32, k.t32, n * sizeof(float2), hipMemcpyDeviceToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(k.r, r, n * sizeof(cplx), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemsetAsync(k.t, 0xff, n * sizeof(cplx), ctx->stream));
+        HIPCHK(hipMemsetAsync(k.z32, 0xff, n * sizeof(float2), ctx->stream));
         ctx->fusedBack = pass == 0;
         rc = launch_back_post(ctx);
         if (!rc && pass == 0 && getenv("HMCMT_BACK_STAMPS")) {
@@ -1279,10 +1286,12 @@ int hmcmt_debug_back_post(hmcmt_ctx* ctx, const double* y, const double* r, doub
         }
         ctx->fusedBack = keep;
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(out + 2 * pass * n, k.t, n * sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<float2> hz(n);                              // both paths leave the result as complex64 in z32
+        HIPCHK(hipMemcpyAsync(hz.data(), k.z32, n * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipMemcpyAsync(pa.data(), k.partA, pa.size() * sizeof(cplx), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipMemcpyAsync(pz.data(), ctx->d_partZZ, pz.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < n; ++i) { out[2 * (pass * n + i)] = hz[i].x; out[2 * (pass * n + i) + 1] = hz[i].y; }
         double are = 0, aim = 0, zz = 0;
         for (int s = 0; s < k.S; ++s)
             for (int b = 0; b < k.NB; ++b) { are += pa[(size_t)s * MAXNB + b].re; aim += pa[(size_t)s * MAXNB + b].im; zz += pz[(size_t)s * MAXNB + b]; }

@@ -22,6 +22,8 @@ struct Solver {
     float2* y32;                          // [S][vstride] complex64
     const float2* invp32;                 // [S][vstride]
     cplx *p2, *r2;                        // second buffers of p and r for the fused kernels
+    float2 *z32, *p32a, *p32b;            // fused path: preconditioned residual and the two search-direction buffers as complex64
+                                          // (x, r, q and every inner product stay fp64; see k_spmv_fused)
     int RT, NTR;                          // rows per tile / row tiles per system of the fused kernels (NTR <= MAXNB)
     cplx *partPQ;                         // [S][MAXNB]  p'q of the fused path
     cplx *rho2;                           // [2][S] rho by iteration parity (fused path)

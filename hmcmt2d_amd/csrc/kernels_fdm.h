@@ -308,7 +308,9 @@ __global__ __launch_bounds__(VBLOCK) void k_mid(Solver k) {
 }
 
 // t = z + dinv .* (r - A z) ; partA = r't ; partZZ = |t|^2     (t becomes the preconditioned residual)
-__global__ __launch_bounds__(VBLOCK) void k_post(Solver k, double* partZZ) {
+// z32out != nullptr (the fused COCG loop on meshes too wide for k_back_post): the result is stored as complex64 there
+// instead of k.t, and the partial sums are those of the stored (rounded) values.
+__global__ __launch_bounds__(VBLOCK) void k_post(Solver k, double* partZZ, float2* z32out) {
     const int s = blockIdx.y;
     if (!k.active[s]) return;
     __shared__ double sh[8];
@@ -326,11 +328,13 @@ __global__ __launch_bounds__(VBLOCK) void k_post(Solver k, double* partZZ) {
         if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
             const cplx rv = r[e];
             out = z[e] + di[e] * (rv - stencil_at(k, z, mo, e, w));
+            if (z32out) out = cplx{(double)(float)out.re, (double)(float)out.im};
             ar += rv.re * out.re - rv.im * out.im;
             ai += rv.re * out.im + rv.im * out.re;
             zz += cabs2(out);
         }
-        t[e] = out;
+        if (z32out) z32out[so + e] = float2{(float)out.re, (float)out.im};
+        else t[e] = out;
     }
     block_sum2(ar, ai, sh);
     block_sum2(zz, dummy, sh2);
@@ -856,7 +860,7 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
     const double w = k.omega[s];
     const cplx *r = k.r + so, *di = k.dinv + so;
-    cplx* t = k.t + so;
+    float2* t = k.z32 + so;            // the preconditioned residual leaves as complex64 (the FDM stage is fp32-class anyway)
     const int nown = (iz1 - iz0 + 1) * NYP;
     // Every phase below is a short dependent chain (global load -> LDS -> barrier -> MFMA -> LDS -> barrier -> stencil),
     // so loads are issued as early as their addresses are known and unconditionally (clamped indices): inside
@@ -1022,10 +1026,12 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
             acc += q.cz1 * zt[l - NYP];
             cplx out = c + q.dv * (q.rv - acc);
             if (q.iy < 1 || q.iy > k.ny - 1) out = cplx{0, 0};
+            const float2 of = float2{(float)out.re, (float)out.im};
+            out = cplx{(double)of.x, (double)of.y};            // the sums are those of the value that is stored
             ar += q.rv.re * out.re - q.rv.im * out.im;
             ai += q.rv.re * out.im + q.rv.im * out.re;
             zz += cabs2(out);
-            t[q.e] = out;
+            t[q.e] = of;
         }
     };
 #pragma unroll
@@ -1033,8 +1039,8 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
 #pragma unroll
     for (int u = 0; u < SU; ++u) stencil(threadIdx.x + (SU + u) * bd, st2[u]);
     // the two boundary rows of t stay zero (the stencil kernels read them as halo rows)
-    if (bx == 0) for (int i = threadIdx.x; i < NYP; i += bd) t[i] = cplx{0, 0};
-    if (iz1 == k.nz - 1) for (int i = threadIdx.x; i < NYP; i += bd) t[(long)k.nz * NYP + i] = cplx{0, 0};
+    if (bx == 0) for (int i = threadIdx.x; i < NYP; i += bd) t[i] = float2{0.f, 0.f};
+    if (iz1 == k.nz - 1) for (int i = threadIdx.x; i < NYP; i += bd) t[(long)k.nz * NYP + i] = float2{0.f, 0.f};
     BP_STAMP(5)
     block_sum3_8(ar, ai, zz, sh, NW);
     if (threadIdx.x == 0) {

@@ -29,7 +29,12 @@ struct StenCo { double dk, dm, cy0, cy1, cz0, cz1; };
 
 __device__ __forceinline__ int div_small(int i, float rcp) { return (int)(((float)i + 0.5f) * rcp); }   // i / n for i < 2^20, rcp = 1/n
 
-__global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* partZZ, const cplx* pin_, cplx* pout, int it, int maxit) {
+// z and p are STORED as complex64 (8 B instead of 16 per value on the two busiest streams of the iteration): z is the
+// output of a preconditioner whose FDM stage is fp32-class already, and a search direction rounded to fp32 is still a
+// valid direction as long as x += alpha p, q = A p and r -= alpha q all use the SAME rounded p -- they do: p is rounded
+// here before the stencil, the update kernel reads the stored value.  x, r, q and all inner products stay fp64.
+// (CPU prototype on the headline systems: iteration counts +-2, final error 1e-12 either way.)
+__global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* partZZ, const float2* pin_, float2* pout, int it, int maxit) {
     const int s = blockIdx.y;
     extern __shared__ __attribute__((aligned(16))) char smem_[];
     cplx* pn = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]
@@ -45,19 +50,20 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
     const int mode = s >= k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
     const double w = k.omega[s];
-    const cplx *z = k.z + so, *pi = pin_ + so;
-    cplx *po = pout + so, *q = k.q + so;
+    const float2 *z = k.z32 + so, *pi = pin_ + so;
+    float2* po = pout + so;
+    cplx* q = k.q + so;
     const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);   // own rows iz0..iz1
     const float rNYP = 1.0f / (float)NYP;
     // rows iz0-1 .. iz1+1 of the new direction (z, p vanish on boundary / pad nodes: no masking needed)
     const int nrows = iz1 - iz0 + 3, ntot = nrows * NYP, ebase = (iz0 - 1) * NYP;
-    cplx zv[SB], pv[SB];
+    float2 zv[SB], pv[SB];
     auto ld_stage = [&](int i0) {
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
             const unsigned e = (unsigned)(ebase + min(i0 + u * VBLOCK, ntot - 1));
             zv[u] = z[e];
-            pv[u] = first ? cplx{0, 0} : pi[e];
+            pv[u] = first ? float2{0.f, 0.f} : pi[e];
         }
     };
     ld_stage(threadIdx.x);
@@ -94,9 +100,11 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
         for (int u = 0; u < SB; ++u) {
             const int i = i0 + u * VBLOCK;
             if (i < ntot) {
-                const cplx v = first ? zv[u] : zv[u] + be * pv[u];
-                pn[i] = v;
-                if (i >= NYP && i < ntot - NYP) po[ebase + i] = v;
+                const cplx zc = cplx{(double)zv[u].x, (double)zv[u].y};
+                const cplx v = first ? zc : zc + be * cplx{(double)pv[u].x, (double)pv[u].y};
+                const float2 vf = float2{(float)v.re, (float)v.im};
+                pn[i] = cplx{(double)vf.x, (double)vf.y};          // the stencil sees the value that is stored
+                if (i >= NYP && i < ntot - NYP) po[ebase + i] = vf;
             }
         }
     }
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
     if (threadIdx.x == 0) k.partPQ[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
 }
 
-__global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const cplx* pcur, const cplx* rin, cplx* rout, int it) {
+__global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2* pcur, const cplx* rin, cplx* rout, int it) {
     const int s = blockIdx.y;
     if (!k.active[s]) return;
     extern __shared__ __attribute__((aligned(16))) char smem_[];
@@ -154,7 +162,8 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const cplx* p
     const int mode = s >= k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
     const double w = k.omega[s];
-    const cplx *p = pcur + so, *q = k.q + so, *ri = rin + so, *di = k.dinv + so;
+    const float2* p = pcur + so;
+    const cplx *q = k.q + so, *ri = rin + so, *di = k.dinv + so;
     cplx *x = k.x + so, *ro = rout + so;
     float2* t = k.t32 + so;
     double xx = 0, dummy = 0;
@@ -167,7 +176,8 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const cplx* p
         if (lr >= 1 && lr <= nrows - 2) {
             rs[i - NYP] = rn;
             ro[e] = rn;
-            const cplx xv = x[e] + al * p[e];             // p vanishes outside the interior
+            const float2 pf = p[e];
+            const cplx xv = x[e] + al * cplx{(double)pf.x, (double)pf.y};     // p vanishes outside the interior
             x[e] = xv;
             xx += cabs2(xv);
         }
