@@ -228,6 +228,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE line, the JSON: whatever libraries print there (RCCL's version banner under
+    # NCCL_DEBUG=VERSION goes to the C stdout) is sent to stderr for the life of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.config)          # before this process touches the GPU: the workers are spawned
@@ -239,9 +244,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("HMCMT_BENCH_FORCE_PG"):      # (FORCE_PG: exercise the RCCL calls with a single rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from hmcmt2d_amd import synthetic as S, invsetup as I
@@ -459,7 +465,7 @@ def main():
             out["allgather"] = gather
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
