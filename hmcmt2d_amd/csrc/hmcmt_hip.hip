@@ -52,7 +52,7 @@ struct hmcmt_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;       // sigma-only sensitivity tables run beside the forward solve
     hipStream_t side2 = nullptr;      // inverse pivots of the FDM tridiagonals run beside the boundary-value kernels
-    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evPiv = nullptr, evPoll = nullptr, evRec = nullptr;
+    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evPiv = nullptr, evRec = nullptr;
     bool solveBegun = false;                 // k_resid0 / k_resid_pre has done k_solve_begin's work for the next solve
     bool preDone = false;                    // k_resid_pre has done the first pre-smoothing pass of the next solve
     bool statsPending = false, pendingAdj = false;   // records of an asynchronous evaluation not read yet
@@ -69,7 +69,7 @@ struct hmcmt_ctx {
     // pinned host staging
     int* h_nactive = nullptr;
     int* h_stall = nullptr;               // pinned, mapped: Solver::stallHost
-    hipEvent_t evPoll2[2] = {nullptr, nullptr};   // convergence polls look one iteration back (see solve())
+    int* h_prog = nullptr;                // pinned, mapped: Solver::progHost
     double* h_rec = nullptr;              // packed per-solve records: [2][S] iters, [2][S] status (int), [2][S] err (double)
     double* h_stage = nullptr;            // m / grad / pred / misfit staging
     size_t stageDoubles = 0;
@@ -355,20 +355,23 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
         float2* pb[2] = {k.p32a, k.p32b};
         cplx* rb[2] = {k.r, k.r2};
         int rcur = 0;
-        // Convergence polls.  The device keeps the number of active systems (and the stagnation flag) in mapped pinned
-        // memory; k_spmv_fused of iteration `it` updates them with the decision on the state after iteration it-1.  From
-        // the iteration count of the previous call on, the host looks at them once per iteration -- but ONE ITERATION BACK:
-        // it waits for the event behind k_spmv_fused(it-1) after queuing all of iteration `it`, so seven launches (~90 us)
-        // are queued when it wakes up and the device never idles at a poll; when the solve is over the launches queued
-        // behind the deciding one find every system inactive and exit at once (~2 us each).
-        *ctx->h_stall = 0;
+        // Convergence polls without events.  The device keeps three words in mapped pinned memory: the number of active
+        // systems and the stagnation flag (k_spmv_fused of iteration `it` updates them with its decision on the state
+        // after iteration it-1) and a progress word (the first thread of k_spmv_fused(it) stores `it` when it STARTS,
+        // i.e. when everything of iteration it-1 has completed).  From the iteration count of the previous call on, the
+        // host queues all of iteration `it`, then spins until the progress word says k_spmv_fused(it) has started --
+        // three launches (~40 us) are still queued behind it at that moment and a spin on host memory wakes within a
+        // microsecond, so the queue never drains -- and reads the counter.  (An event per polled iteration put a 6 us
+        // bubble behind every polled k_spmv_fused and its hipEventSynchronize took 50-100 us to wake; round 1 lost
+        // ~90 us per evaluation there.)  The launches queued behind a finished solve find every system inactive and
+        // exit at once.
+        *(volatile int*)ctx->h_stall = 0;
+        *(volatile int*)ctx->h_prog = 0;
         bool stalled = false;
         while (!done && !stalled && it < ctx->opt.maxit + 1) {
             ++it;
             // decide convergence of the state after iteration it-1, p = z + beta p, q = A p
             { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv_fused, dim3(k.NTR, S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit); }
-            const bool rec = it >= nextCheck || it - 1 == ctx->opt.maxit;
-            if (rec) HIPCHK(hipEventRecord(ctx->evPoll2[it & 1], ctx->stream));
             { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused, dim3(k.NTR, S), vb, (size_t)(2 * k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it); }
             rcur ^= 1;
             k.r = rb[rcur];
@@ -376,9 +379,13 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             if ((prc = launch_fdm_fwd(ctx))) return prc;
             if ((prc = launch_back_post(ctx))) return prc;
             std::swap(k.z, k.t);
-            if (it - 1 >= nextCheck || it - 1 == ctx->opt.maxit) {        // the event of iteration it-1 exists
-                const bool last = it - 1 == ctx->opt.maxit;
-                HIPCHK(hipEventSynchronize(ctx->evPoll2[(last ? it : it - 1) & 1]));
+            if (it >= nextCheck || it - 1 == ctx->opt.maxit) {
+                long spins = 0;
+                while (*(volatile int*)ctx->h_prog < it) {
+                    if ((++spins & 0xfffff) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;   // (device error / all done)
+                }
+                if (*(volatile int*)ctx->h_prog < it) HIPCHK(hipStreamSynchronize(ctx->stream));   // reports the error, if any
+                if (it - 1 == ctx->opt.maxit) HIPCHK(hipStreamSynchronize(ctx->stream));          // (k_spmv_fused(it) itself decides the cap)
                 if (*(volatile int*)ctx->h_nactive == 0) { done = true; break; }
                 if (*(volatile int*)ctx->h_stall) stalled = true;
             }
@@ -687,7 +694,8 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     for (hipEvent_t e : ctx->evPool) hipEventDestroy(e);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
     if (ctx->h_stall) hipHostFree(ctx->h_stall);
-    for (auto& e : ctx->evPoll2) if (e) hipEventDestroy(e);
+    if (ctx->h_prog) hipHostFree(ctx->h_prog);
+
     if (ctx->h_rec) hipHostFree(ctx->h_rec);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
     if (ctx->h_lfFlag) hipHostFree(ctx->h_lfFlag);
@@ -695,7 +703,6 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (ctx->evSens) hipEventDestroy(ctx->evSens);
     if (ctx->evExtF) hipEventDestroy(ctx->evExtF);
     if (ctx->evPiv) hipEventDestroy(ctx->evPiv);
-    if (ctx->evPoll) hipEventDestroy(ctx->evPoll);
     if (ctx->evRec) hipEventDestroy(ctx->evRec);
     if (ctx->side2) hipStreamDestroy(ctx->side2);
     if (ctx->evExtA) hipEventDestroy(ctx->evExtA);
@@ -718,7 +725,6 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     HIPCHK(hipEventCreateWithFlags(&ctx->evSens, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evExtF, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evPiv, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ctx->evPoll, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evRec, hipEventDisableTiming));
     HIPCHK(hipStreamCreate(&ctx->side2));
     {
@@ -852,7 +858,9 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     HIPCHK(hipHostGetDevicePointer((void**)&k.stallHost, ctx->h_stall, 0));
     k.stallIt = STALL_IT;
     if (const char* es = getenv("HMCMT_STALL_IT")) k.stallIt = std::max(1, atoi(es));   // (tests force the fp64 restart with a short window)
-    for (auto& e : ctx->evPoll2) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_prog, sizeof(int), hipHostMallocMapped));
+    *ctx->h_prog = 0;
+    HIPCHK(hipHostGetDevicePointer((void**)&k.progHost, ctx->h_prog, 0));
     HIPCHK(hipHostMalloc((void**)&ctx->h_rec, sizeof(double) * 4 * h.S, hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void**)&ctx->d_recHost, ctx->h_rec, 0));
     ctx->stageDoubles = (size_t)h.nAC * 4 + (size_t)h.nData * 2 + 16;

@@ -37,6 +37,7 @@ struct Solver {
     double* errRef;                       // [S] best error estimate so far / 10-fold improvements (stagnation watch of the mixed-precision solve)
     int* errRefIt;                        // [S] iteration at which errRef was set
     int stallIt;                          // iterations allowed per 10-fold drop of the error estimate (STALL_IT; HMCMT_STALL_IT)
+    int* progHost;                        // pinned host word: the iteration whose k_spmv_fused has STARTED (host throttle, see solve())
     int* stallHost;                       // pinned host flag: a system has not improved its error estimate 10-fold in STALL_IT iterations
     unsigned long long* cntActive;        // non-null in an evaluation sampled by hmcmt_profile: += systems still active per iteration
 };

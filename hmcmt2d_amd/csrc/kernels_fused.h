@@ -39,6 +39,7 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
     extern __shared__ __attribute__((aligned(16))) char smem_[];
     cplx* pn = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]
     __shared__ double sh[8];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *(volatile int*)k.progHost = it;   // "iteration it-1 is complete"
     const bool first = it == 1;
     const int act = k.active[s];
     const int ln = threadIdx.x & 63;
