@@ -124,7 +124,7 @@ struct hmcmt_ctx {
     long long memoHits = 0;
 };
 
-static std::string g_createError;
+static thread_local std::string g_createError;      // (per thread: contexts of different chains are created from different threads)
 
 #define HIPCHK(call)                                                                                   \
     do {                                                                                               \
