@@ -56,7 +56,8 @@ typedef struct hmcmt_options {
     int32_t precond;      /* HMCMT_PRECOND_* ; default FDM_JACOBI */
     int32_t maxit;        /* iteration cap per solve; default 2000 (FDM) */
     double  tol;          /* stop when ||P^-1 r|| <= tol*||x|| (error estimate); default 1e-11 */
-    int32_t check_every;  /* host convergence poll interval in iterations; default 2 */
+    int32_t check_every;  /* host convergence poll interval in iterations of the classic (non-default) solver loops; default 2.
+                             The default path looks at a mapped counter once per iteration without waiting */
     int32_t verify;       /* 1: also compute true relative residuals ||b-Ax||/||b|| after each solve */
     int32_t warm_start;   /* initial guess of both solves: 0 zero, 1 the previous evaluation's fields, 2 (default) those
                              fields extrapolated along the model path from the last two or three evaluations (leapfrog
