@@ -27,6 +27,13 @@
 
 using namespace hmcmt;
 
+#ifndef HMCMT_LP_NRG
+#define HMCMT_LP_NRG 2
+#endif
+#ifndef HMCMT_LP_KC
+#define HMCMT_LP_KC 4
+#endif
+
 namespace {
 
 constexpr int MAXNB = 64;          // max partial-sum blocks per system (<= 64: one wave sums them, total_part)
@@ -743,6 +750,11 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
             ctx->maxLds = 160 * 1024;
         else (void)hipGetLastError();
+        // (the separate transform kernel stages LP_NRG row groups: beyond 64 KB on wide meshes with LP_NRG > 2)
+        for (const void* f : {reinterpret_cast<const void*>(k_transform_lp<0, 0>), reinterpret_cast<const void*>(k_transform_lp<0, 1>),
+                              reinterpret_cast<const void*>(k_transform_lp<1, 0>), reinterpret_cast<const void*>(k_transform_lp<1, 1>),
+                              reinterpret_cast<const void*>(k_transform_lp<2, 0>), reinterpret_cast<const void*>(k_transform_lp<2, 1>)})
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
         // the stencil kernels' tiles can pass 64 KB on wide meshes
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();

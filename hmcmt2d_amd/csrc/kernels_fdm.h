@@ -382,8 +382,8 @@ __device__ __forceinline__ float bf16_to_f32(unsigned h) { return __uint_as_floa
 // accuracy from the bf16 pipe.  (Plain bf16 operands stalled one low-frequency TE system in 32.)
 // B: Bhi/Blo fragment arrays.  OUT: 0 = complex64, 1 = fp64 complex, 2 = fp64 complex + dinv*r (fused
 // first half of the post-smoother).
-constexpr int LP_NRG = 2;          // row groups (of 8 complex rows) a workgroup transforms per pass
-constexpr int LP_KC = 4;           // k-groups requested together
+constexpr int LP_NRG = HMCMT_LP_NRG;   // row groups (of 8 complex rows) a workgroup transforms per pass
+constexpr int LP_KC = HMCMT_LP_KC;     // k-groups requested together
 
 // A-operand fragments of LP_NRG row groups starting at row m0, staged in LDS by the whole workgroup in fragment order:
 //   ast[((rg*KG + kg)*2 + hl)*64 + lane] = the 8 bf16 (hi or lo) lane `lane` feeds the MFMA for row group rg, k-group kg.
