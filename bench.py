@@ -351,6 +351,19 @@ def main():
         extras["cold_start"] = {"steps_per_s": min(Ke, 16) / t4, "steps": min(Ke, 16), "iters_fwd_max": s4["iters_fwd_max"],
                                 "iters_adj_max": s4["iters_adj_max"], "state": "the straight-line models, options.warm_start = 0"}
         ctx.set_options(warm_start=2)
+        # (iv-b) the iteration kernels with EVERY system active in every launch: cold solves that cannot converge
+        # (tolerance 1e-200) cut off after 12 iterations -- the per-launch cost at full batch, beside the timed region's
+        # figures at the real chains' 60-65 % activity
+        ctx.set_options(warm_start=0, tol=1e-200, maxit=12)
+        ctx.profile(["fdm_transform", "tridiagonal", "spmv", "vector_ops", "post_smoother"], every=1)
+        for k in range(4):
+            try:
+                ctx.grad_device(d_m[k].data_ptr(), chain.d_pred.data_ptr(), d_mis.data_ptr(), d_g.data_ptr())
+            except HmcmtError:
+                pass                                     # (ENOCONV by construction)
+        full_prof, full_cnt = ctx.profile_read(), ctx.profile_counters()
+        ctx.profile(False)
+        ctx.set_options(warm_start=2, tol=1e-11, maxit=2000)
         # (v) two chains on this GPU at once (what parallelHMCSampler(chains_per_gpu=2) does): a second context, one
         # host thread per chain; aggregate steps/s of both chains near the true model
         import threading
@@ -389,59 +402,65 @@ def main():
         nyi, nzi = ctx.ny - 1, ctx.nz - 1
         Usys = nzi * nyi
         U = ctx.S * Usys
-        back_fused = prof["post_smoother"][1] == 0
-        fwd_fused = ctx.NYP <= 256                      # the library's own rule (launch_fdm_fwd): wide meshes run the separate kernels
-        it_sys = cnt["active_iter_systems"]             # sum over sampled iterations of active systems
-        pre_sys = cnt["start_systems"]                  # + one preconditioner application per solve before the first iteration
-        fams = {("k_fdm_fwd (split-bf16 MFMA eigen-transform + LDS-resident complex64 tridiagonal sweeps, one launch)" if fwd_fused else
-                 "k_thomas32 (batched complex64 tridiagonal solve of the FDM stage)"): ("tridiagonal", 24.0, 1, it_sys + pre_sys),
-                ("k_back_post (split-bf16 MFMA back transform + both Jacobi halves of the post-smoother + dot products)" if back_fused else
-                 "k_transform_lp<2> (split-bf16 MFMA back transform fused with the first Jacobi half)" if fwd_fused else
-                 "k_transform_lp<0>,<2> (split-bf16 MFMA forward and back transforms: 16 U and 56 U)"):
-                    ("fdm_transform", (48.0 if back_fused else 56.0) if fwd_fused else 36.0, 1 if fwd_fused else 2, (it_sys + pre_sys) * (1 if fwd_fused else 2)),
-                "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 40.0, 1, it_sys),
-                "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 112.0, 1, it_sys)}
-        if not back_fused:
-            fams["k_post (second Jacobi half: 5-point stencil + dot products)"] = ("post_smoother", 56.0, 1, it_sys + pre_sys)
-        roofs = []
         ws_mb = 15 * ctx.S * ctx.NZP * ctx.NYP * 16 / 1e6
-        it_bytes = it_us = step_bytes = 0.0
-        nev = max(cnt["evaluations"], 1)
-        for kname, (cat, bpu, per_it, sys_launches) in fams.items():
-            ms_c, n_c = prof[cat]
-            avg_us = 1e3 * ms_c / max(n_c, 1)
-            act = sys_launches / max(n_c, 1)                       # active systems per launch, averaged over the timed launches
-            nbytes = bpu * Usys * act
-            ach = nbytes / (avg_us * 1e-6) / 1e9 if n_c else 0.0
-            it_bytes += per_it * nbytes
-            it_us += per_it * avg_us
-            step_bytes += bpu * Usys * sys_launches / nev
-            entry = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(name, cat), "avg_launch_us": avg_us,
-                     "launches_timed": n_c, "launches_per_iteration": per_it, "bytes_per_launch": nbytes,
-                     "bytes_per_launch_all_systems_active": bpu * U, "active_systems_per_launch": act, "ms_timed": ms_c,
-                     "population": "every launch of this kernel in every 6th evaluation of the timed region (HIP events on "
-                                   "the library's stream), launches that found all systems converged included"}
-            if cat in ("tridiagonal", "fdm_transform") and n_c:
-                # the two MFMA kernels, for reference: three bf16 products (hi*hi, hi*lo, lo*hi) of a
-                # [2*S*NZP real rows] x [NYP] x [K = NYP padded to 32] real matrix product
-                kpad = 32 * ((ctx.NYP + 31) // 32)
-                flops = 3 * 2.0 * (2 * act * ctx.NZP) * ctx.NYP * kpad
-                entry["mfma"] = {"flops_per_launch": flops, "achieved_tflops": flops / (avg_us * 1e-6) / 1e12,
-                                 "peak_tflops_bf16_dense": 2500.0}
-            roofs.append(entry)
-        iteration = {"kernels": len(fams), "bytes": it_bytes, "us": it_us,
-                     "achieved": it_bytes / (it_us * 1e-6) / 1e9 if it_us else 0.0, "unit": "GB/s",
-                     "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS if it_us else 0.0,
-                     "note": "one preconditioned COCG iteration of the systems still active = %d launches; " % len(fams) +
-                             ("the working set of a solve (~15 vectors = %.0f MB) fits the 256 MB Infinity Cache, so launches are "
-                              "latency- not HBM-bound" if ws_mb <= 256 else
-                              "the working set of a solve (~15 vectors = %.0f MB) is beyond the 256 MB Infinity Cache: HBM-bound") % ws_mb}
+
+        def build_roofline(prof, cnt, population):
+            back_fused = prof["post_smoother"][1] == 0
+            fwd_fused = ctx.NYP <= 256                      # the library's own rule (launch_fdm_fwd): wide meshes run the separate kernels
+            it_sys = cnt["active_iter_systems"]             # sum over sampled iterations of active systems
+            pre_sys = cnt["start_systems"]                  # + one preconditioner application per solve before the first iteration
+            fams = {("k_fdm_fwd (split-bf16 MFMA eigen-transform + LDS-resident complex64 tridiagonal sweeps, one launch)" if fwd_fused else
+                     "k_thomas32 (batched complex64 tridiagonal solve of the FDM stage)"): ("tridiagonal", 24.0, 1, it_sys + pre_sys),
+                    ("k_back_post (split-bf16 MFMA back transform + both Jacobi halves of the post-smoother + dot products)" if back_fused else
+                     "k_transform_lp<2> (split-bf16 MFMA back transform fused with the first Jacobi half)" if fwd_fused else
+                     "k_transform_lp<0>,<2> (split-bf16 MFMA forward and back transforms: 16 U and 56 U)"):
+                        ("fdm_transform", (48.0 if back_fused else 56.0) if fwd_fused else 36.0, 1 if fwd_fused else 2, (it_sys + pre_sys) * (1 if fwd_fused else 2)),
+                    "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 40.0, 1, it_sys),
+                    "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 112.0, 1, it_sys)}
+            if not back_fused:
+                fams["k_post (second Jacobi half: 5-point stencil + dot products)"] = ("post_smoother", 56.0, 1, it_sys + pre_sys)
+            roofs = []
+            it_bytes = it_us = step_bytes = 0.0
+            nev = max(cnt["evaluations"], 1)
+            for kname, (cat, bpu, per_it, sys_launches) in fams.items():
+                ms_c, n_c = prof[cat]
+                avg_us = 1e3 * ms_c / max(n_c, 1)
+                act = sys_launches / max(n_c, 1)                       # active systems per launch, averaged over the timed launches
+                nbytes = bpu * Usys * act
+                ach = nbytes / (avg_us * 1e-6) / 1e9 if n_c else 0.0
+                it_bytes += per_it * nbytes
+                it_us += per_it * avg_us
+                step_bytes += bpu * Usys * sys_launches / nev
+                entry = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(name, cat), "avg_launch_us": avg_us,
+                         "launches_timed": n_c, "launches_per_iteration": per_it, "bytes_per_launch": nbytes,
+                         "bytes_per_launch_all_systems_active": bpu * U, "active_systems_per_launch": act, "ms_timed": ms_c,
+                         "population": population}
+                if cat in ("tridiagonal", "fdm_transform") and n_c:
+                    # the two MFMA kernels, for reference: three bf16 products (hi*hi, hi*lo, lo*hi) of a
+                    # [2*S*NZP real rows] x [NYP] x [K = NYP padded to 32] real matrix product
+                    kpad = 32 * ((ctx.NYP + 31) // 32)
+                    flops = 3 * 2.0 * (2 * act * ctx.NZP) * ctx.NYP * kpad
+                    entry["mfma"] = {"flops_per_launch": flops, "achieved_tflops": flops / (avg_us * 1e-6) / 1e12,
+                                     "peak_tflops_bf16_dense": 2500.0}
+                roofs.append(entry)
+            iteration = {"kernels": len(fams), "bytes": it_bytes, "us": it_us,
+                         "achieved": it_bytes / (it_us * 1e-6) / 1e9 if it_us else 0.0, "unit": "GB/s",
+                         "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS if it_us else 0.0,
+                         "note": "one preconditioned COCG iteration of the systems still active = %d launches; " % len(fams) +
+                                 ("the working set of a solve (~15 vectors = %.0f MB) fits the 256 MB Infinity Cache, so launches are "
+                                  "latency- not HBM-bound" if ws_mb <= 256 else
+                                  "the working set of a solve (~15 vectors = %.0f MB) is beyond the 256 MB Infinity Cache: HBM-bound") % ws_mb}
+            roofs.sort(key=lambda r: -r["ms_timed"])             # strict arg-max of the measured total time, no tie-break
+            return roofs, iteration, step_bytes
+
+        roofs, iteration, step_bytes = build_roofline(
+            prof, cnt, "every launch of this kernel in every 6th evaluation of the timed region (HIP events on the library's "
+                       "stream), launches that found all systems converged included")
         ms_step = 1e3 * elapsed / K
         step = {"bytes_per_step": step_bytes, "ms_per_step": ms_step, "achieved": step_bytes / (ms_step * 1e-3) / 1e9,
                 "unit": "GB/s", "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "algorithmic bytes of the iteration kernels per leapfrog step (sampled evaluations) / wall time per step / 8 TB/s"}
-        roofs.sort(key=lambda r: -r["ms_timed"])             # strict arg-max of the measured total time, no tie-break
         out = {
             "metric": "leapfrog steps/sec (= fwd+grad evals/sec), 200x100 mesh x 16 freq",
             "value": world * K / elapsed, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -460,6 +479,10 @@ def main():
             "roofline": roofs[0], "roofline_other": roofs[1:], "roofline_iteration": iteration, "roofline_step": step,
             "check": check,
         }
+        if world == 1 and not args.no_extras:
+            fr, fi, _ = build_roofline(full_prof, full_cnt, "every launch of 4 cold evaluations whose solves are cut off after 12 "
+                                                           "iterations with all systems still active (tolerance 1e-200)")
+            extras["roofline_all_systems_active"] = {"kernels": fr, "iteration": fi}
         out.update(extras)
         if gather is not None:
             out["allgather"] = gather
