@@ -462,7 +462,7 @@ void launch_extrap_weights(hmcmt_ctx* ctx, const double* d_m, int kd) {
     const int nAC = ctx->v.nAC;
     double* part = ctx->d_ext[kd] + EXT_PART;
     hipLaunchKernelGGL(k_extrap_sums, dim3(EXT_NBLK), dim3(256), 0, ctx->side, d_m, ctx->d_mHist[kd], nAC, part);
-    hipLaunchKernelGGL(k_extrap_weights, dim3(1), dim3(64), 0, ctx->side, part, ctx->d_ext[kd], ctx->extrapNp);
+    hipLaunchKernelGGL(k_extrap_weights, dim3(1), dim3(64), 0, ctx->side, part, ctx->d_ext[kd], ctx->extrapNp, kd == 1 ? 1 : 0);
     hipLaunchKernelGGL(k_extrap_shift, dim3((nAC + 255) / 256), dim3(256), 0, ctx->side, d_m, ctx->d_mHist[kd], nAC, ctx->d_ext[kd]);
 }
 

@@ -401,7 +401,11 @@ __global__ __launch_bounds__(256) void k_extrap_sums(const double* __restrict__ 
 }
 
 // pass 2 (one wave): the extrapolation weights from the partial sums
-__global__ __launch_bounds__(64) void k_extrap_weights(const double* __restrict__ part, double* ext, int maxNp) {
+// coldUnlessSmooth (the adjoint solve): without at least three collinear points the weights are all zero -- the adjoint's
+// right-hand side is the weighted residual, which changes by O(1) from step to step, so its previous solution is no
+// better a guess than zero (measured on the sampler's trajectories: 0-4 iterations WORSE than a cold start) unless the
+// model path is smooth enough for the extrapolation proper.
+__global__ __launch_bounds__(64) void k_extrap_weights(const double* __restrict__ part, double* ext, int maxNp, int coldUnlessSmooth) {
     double a[EXT_NS];
 #pragma unroll
     for (int q = 0; q < EXT_NS; ++q) a[q] = wave_sum(threadIdx.x < EXT_NBLK ? part[threadIdx.x * EXT_NS + q] : 0.0);
@@ -411,6 +415,7 @@ __global__ __launch_bounds__(64) void k_extrap_weights(const double* __restrict_
     const bool keep = count >= 1 && d0d0 <= 1e-28 * mkmk;
     double wts[EXT_NP];                                       // weights of x_k, x_{k-1}, ...
     for (int i = 0; i < EXT_NP; ++i) wts[i] = i == 0 ? 1.0 : 0.0;
+    if (coldUnlessSmooth && !keep) wts[0] = 0.0;
     if (!keep && count >= 2 && d1d1 > 0) {
         const double alpha = fmin(2.0, fmax(-1.0, a[0] / d1d1));
         wts[0] = 1.0 + alpha; wts[1] = -alpha;
@@ -428,6 +433,7 @@ __global__ __launch_bounds__(64) void k_extrap_weights(const double* __restrict_
             }
         }
         np = min(maxNp, np);
+        if (coldUnlessSmooth && np <= 2) wts[0] = wts[1] = 0.0;
         if (np > 2) {
             for (int i = 0; i < EXT_NP; ++i) {
                 double l = i < np ? 1.0 : 0.0;
