@@ -32,3 +32,7 @@ if len(sys.argv) > 2:
         c2.trajectory(8)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(f"traj {t}: {dt*1e3:.1f} ms ({dt*1e3/8:.2f} ms/step) {'accepted' if c2.accepted > a0 else 'rejected'} last-step iters {c2.iters[-1]} misfit {c2.D0:.1f}", flush=True)
+it = ctx.iters()
+print("per-system iterations of the last evaluation (forward | adjoint), systems = TE f0..f15, TM f0..f15:")
+print(" fwd", it[0].tolist())
+print(" adj", it[1].tolist())
