@@ -15,7 +15,8 @@ inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, obs, err)
 ctx = HipContext(mesh, data, inv, warm_start=os.environ.get("WS", "extrapolate"))
 dev = torch.device("cuda", 0)
 n = ctx.nAC
-c = B.Chain(ctx, torch, dev, m_true if state == "true" else S.rough_state(n), np.full(n, np.log(0.01)), inv.Wm, seed=7)
+start = {"true": m_true, "rough": S.rough_state(n), "homog": np.full(n, np.log(0.01))}[state]
+c = B.Chain(ctx, torch, dev, start, np.full(n, np.log(0.01)), inv.Wm, seed=7)
 for t in range(int(os.environ.get('NTRAJ', '10'))):
     a0 = c.accepted
     torch.cuda.synchronize(); t0 = time.perf_counter()
