@@ -59,7 +59,7 @@ struct hmcmt_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;       // sigma-only sensitivity tables run beside the forward solve
     hipStream_t side2 = nullptr;      // inverse pivots of the FDM tridiagonals run beside the boundary-value kernels
-    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evPiv = nullptr, evRec = nullptr;
+    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evPiv = nullptr, evRec = nullptr, evCoef = nullptr;
     bool solveBegun = false;                 // k_resid0 / k_resid_pre has done k_solve_begin's work for the next solve
     bool preDone = false;                    // k_resid_pre has done the first pre-smoothing pass of the next solve
     bool statsPending = false, pendingAdj = false;   // records of an asynchronous evaluation not read yet
@@ -86,9 +86,9 @@ struct hmcmt_ctx {
     int lastItFwd = 0, lastItAdj = 0;
     bool haveModel = false;
     bool haveFwd = false, haveAdj = false;   // previous fields usable as initial guesses
-    cplx* d_prevField[2] = {nullptr, nullptr};   // the two previous solutions (warm_start == 2), per solve kind: [2][S*vstride]
-    double* d_mHist[2] = {nullptr, nullptr};     // [EXT_NP][nAC] model history per solve kind (newest first)
-    double* d_ext[2] = {nullptr, nullptr};       // {w_0..w_{EXT_NP-1}, keep, count, partial sums} (kernels_fused.h)
+    cplx* d_prevField[2] = {nullptr, nullptr};   // the EXT_NP-1 previous solutions (warm_start == 2), per solve kind: a ring [EXT_NP-1][S*vstride]
+    double* d_mHist[2] = {nullptr, nullptr};     // [EXT_NP][nAC] model history per solve kind (a ring: kernels_fused.h)
+    double* d_ext[2] = {nullptr, nullptr};       // {w_0..w_{EXT_NP-1}, keep, count, ring heads, partial sums, ticket} (kernels_fused.h)
     double jacobiW = 0.8;                    // damping of the point-Jacobi halves (HMCMT_JACOBI_W; 0.7 in round 1: 0.8 saves 3-8 % of the iterations on structured models, costs 6-25 % on white-noise models of std >= 1)
     int extrapNp = EXT_NP;                   // fields used by the initial-guess extrapolation (HMCMT_EXTRAP_POINTS = 2..EXT_NP)
     bool fusedFwd = true;                    // forward transform + tridiagonal solve in one kernel (HMCMT_FUSED_FWD=0: separate)
@@ -375,6 +375,8 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
         *(volatile int*)ctx->h_stall = 0;
         *(volatile int*)ctx->h_prog = 0;
         bool stalled = false;
+        static const int sideItEnv = getenv("HMCMT_SIDE_IT") ? atoi(getenv("HMCMT_SIDE_IT")) : 12;
+        const int sideIt = sideItEnv > 0 ? sideItEnv : std::max(2, nextCheck + sideItEnv);
         while (!done && !stalled && it < ctx->opt.maxit + 1) {
             ++it;
             // decide convergence of the state after iteration it-1, p = z + beta p, q = A p
@@ -396,9 +398,10 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
                 if (*(volatile int*)ctx->h_nactive == 0) { done = true; break; }
                 if (*(volatile int*)ctx->h_stall) stalled = true;
             }
-            // (a dozen API calls, ~150 us of host time: issued once the queue is five iterations deep -- at two the main
-            // queue ran dry for 86 us of every evaluation)
-            if (kind == 0 && it == 5) launch_adjoint_side(ctx);
+            // (a dozen API calls, ~150 us of host time: issued once the queue is a dozen iterations deep -- or after the
+            // solve, if it is shorter than that.  Without a tracer attached 2..12 measure the same within 1 %; under
+            // rocprofv3, whose launches cost twice as much, the early settings drain the main queue.)
+            if (kind == 0 && it == sideIt) launch_adjoint_side(ctx);
         }
         if (!done) {
             // stragglers (or the iteration cap): read the counter once more, then hand over to the classic loop
@@ -459,11 +462,8 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
 
 // weights of the initial-guess extrapolation for solve kind kd (side stream): partial sums, weights, history shift
 void launch_extrap_weights(hmcmt_ctx* ctx, const double* d_m, int kd) {
-    const int nAC = ctx->v.nAC;
-    double* part = ctx->d_ext[kd] + EXT_PART;
-    hipLaunchKernelGGL(k_extrap_sums, dim3(EXT_NBLK), dim3(256), 0, ctx->side, d_m, ctx->d_mHist[kd], nAC, part);
-    hipLaunchKernelGGL(k_extrap_weights, dim3(1), dim3(64), 0, ctx->side, part, ctx->d_ext[kd], ctx->extrapNp, kd == 1 ? 1 : 0);
-    hipLaunchKernelGGL(k_extrap_shift, dim3((nAC + 255) / 256), dim3(256), 0, ctx->side, d_m, ctx->d_mHist[kd], nAC, ctx->d_ext[kd]);
+    hipLaunchKernelGGL(k_extrap_prepare, dim3(EXT_NBLK), dim3(256), 0, ctx->side, d_m, ctx->d_mHist[kd], ctx->v.nAC, ctx->d_ext[kd],
+                       ctx->extrapNp, kd == 1 ? 1 : 0);
 }
 
 // side stream, beside the forward solve: the adjoint initial guess and the sigma-only sensitivity tables (joined
@@ -527,15 +527,27 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         }
         HIPCHK(hipEventRecord(ctx->evModel, st));
         // Three chains start from sigma and meet at the forward residual:
-        //   main    boundary-value tables and the serial 1-D recurrences (0.1 ms: the critical one)
-        //   side2   lateral means -> FDM background -> inverse pivots of its tridiagonals (serial, 60-85 us)
-        //   side    stencil coefficients, Jacobi diagonal, the extrapolated forward guess
+        //   main    boundary-value tables and the serial 1-D recurrences (60 us: the critical one)
+        //   side    the extrapolated forward guess (weights from the model history, then one pass over the fields: 45 us)
+        //   side2   stencil coefficients, Jacobi diagonal (15 us, the residual waits for them), then lateral means ->
+        //           FDM background -> inverse pivots of its tridiagonals (serial, 35-85 us; the preconditioner waits)
         // The host issues them in this order (after the previous evaluation's synchronisation the order of the API
         // calls is the schedule); the side-stream work of the adjoint half follows from inside the forward solve.
         hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, v.nFreq), dim3(64), 0, st, v);
         hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, v.nFreq), dim3(64), 4 * (size_t)v.nz * sizeof(cplx), st, v);
         const bool pivots = ctx->opt.precond != HMCMT_PRECOND_JACOBI;
+        if (extrap) {
+            // (interior nodes only -- k_bc_forward owns the boundary nodes of X)
+            HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evModel, 0));
+            launch_extrap_weights(ctx, d_m, 0);
+            hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
+            HIPCHK(hipEventRecord(ctx->evExtF, ctx->side));
+        }
         HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->evModel, 0));
+        hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, ctx->side2, v, 0, 1, 1, 0);
+        if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI)
+            hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side2, ctx->sv, ctx->jacobiW);
+        HIPCHK(hipEventRecord(ctx->evCoef, ctx->side2));
         hipLaunchKernelGGL(k_rowmean, dim3(v.nz), dim3(64), 0, ctx->side2, v);
         if (pivots)
             hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 4 * (size_t)v.NZP * sizeof(double), ctx->side2, v,
@@ -543,17 +555,8 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         else
             hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, ctx->side2, v);
         HIPCHK(hipEventRecord(ctx->evPiv, ctx->side2));
-        HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evModel, 0));
-        hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, ctx->side, v, 0, 1, 1, 0);
-        if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI)
-            hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, ctx->jacobiW);
-        if (extrap) {
-            // (interior nodes only -- k_bc_forward owns the boundary nodes of X)
-            launch_extrap_weights(ctx, d_m, 0);
-            hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
-        }
-        HIPCHK(hipEventRecord(ctx->evExtF, ctx->side));
-        HIPCHK(hipStreamWaitEvent(st, ctx->evExtF, 0));
+        if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtF, 0));
+        HIPCHK(hipStreamWaitEvent(st, ctx->evCoef, 0));
         // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X
         if (fusedStart) {
             hipLaunchKernelGGL(k_resid_pre, dim3(ctx->sv.NTR, S), dim3(VBLOCK), startLds, st, ctx->sv, v.X, ctx->sv.r, ctx->sv.r2, 1, ctx->v.sysOn);
@@ -709,6 +712,7 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (ctx->evModel) hipEventDestroy(ctx->evModel);
     if (ctx->evSens) hipEventDestroy(ctx->evSens);
     if (ctx->evExtF) hipEventDestroy(ctx->evExtF);
+    if (ctx->evCoef) hipEventDestroy(ctx->evCoef);
     if (ctx->evPiv) hipEventDestroy(ctx->evPiv);
     if (ctx->evRec) hipEventDestroy(ctx->evRec);
     if (ctx->side2) hipStreamDestroy(ctx->side2);
@@ -731,6 +735,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     HIPCHK(hipEventCreateWithFlags(&ctx->evModel, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evSens, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evExtF, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evCoef, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evPiv, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->evRec, hipEventDisableTiming));
     HIPCHK(hipStreamCreate(&ctx->side2));
@@ -835,7 +840,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     DA(v.qPart, S * h.ny) DA(v.gPart, 2 * (size_t)h.nCell) DA(v.gPartG, 2 * GRAD_NG * (size_t)h.nCell) DA(v.grad, h.nAC)
     DA(ctx->d_m, h.nAC) DA(ctx->d_misfit, 1) DA(ctx->d_cnt, 1)
     for (int q : h.sysOn) ctx->nSysOn += q;
-    for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], (EXT_NP - 1) * S * VS) DA(ctx->d_mHist[kd], EXT_NP * (size_t)h.nAC) DA(ctx->d_ext[kd], EXT_PART + EXT_NS * EXT_NBLK) }
+    for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], (EXT_NP - 1) * S * VS) DA(ctx->d_mHist[kd], EXT_NP * (size_t)h.nAC) DA(ctx->d_ext[kd], EXT_LEN) }
     Solver& k = ctx->sv;
     k.S = h.S; k.NYP = h.NYP; k.NZP = h.NZP; k.ny = h.ny; k.nz = h.nz; k.nFreq = h.nFreq; k.vstride = v.vstride;
     k.NB = std::max(1, std::min(32, (1024 + h.S - 1) / h.S));

@@ -358,58 +358,23 @@ __global__ void k_solve_end(Solver k, int kind, int* __restrict__ recI, double* 
 //     x0 = w2 x_k + w1 x_{k-1} + w0 x_{k-2}      (uniform steps: 3, -3, 1)
 // when the three steps are nearly collinear, else the linear one  x0 = x_k + alpha (x_k - x_{k-1})
 // (e.g. across a momentum refresh).  State per solve kind, all on the device (no host round trip):
-// hist = [m_k | m_{k-1} | ... | m_{k-NP+1}], ext = {w_k, ..., w_{k-NP+1}, keep, count}; every further step that is
+// hist = the last NP models (a ring), ext = {w_k, ..., w_{k-NP+1}, keep, count, ring heads}; every further step that is
 // nearly collinear with the last one and of comparable length adds a point (and an order) to the Lagrange
 // extrapolation, up to EXT_NP fields.  A repeated model (getHamiltonian after the last leapfrog step) keeps the
 // history untouched.
 constexpr int EXT_NP = 6;          // fields kept per solve kind: the current one + EXT_NP-1 earlier ones (Lagrange order <= EXT_NP-1)
 constexpr int EXT_NBLK = 32;       // blocks of the partial-sum pass
 constexpr int EXT_NS = 2 * EXT_NP; // partial sums per block: <d_j,d1> (j = 0..NP-1), <d_j,d_j> (j = 0, 2..NP-1), <m_k,m_k>
-constexpr int EXT_KEEP = EXT_NP, EXT_COUNT = EXT_NP + 1, EXT_PART = EXT_NP + 2;   // ext = {w_0..w_{NP-1}, keep, count, partial sums...}
+constexpr int EXT_KEEP = EXT_NP, EXT_COUNT = EXT_NP + 1, EXT_HEAD = EXT_NP + 2, EXT_MHEAD = EXT_NP + 3, EXT_PART = EXT_NP + 4;
+// ext = {w_0..w_{NP-1}, keep, count, head of the field ring, head of the model ring, partial sums [NBLK][NS], ticket}
+constexpr int EXT_TICKET = EXT_PART + EXT_NS * EXT_NBLK, EXT_LEN = EXT_TICKET + 1;
 
-// pass 1: per-block partial sums over the model history hist = [m_k | m_{k-1} | ... | m_{k-NP+1}]: steps
-// d0 = m_new - m_k, d_j = m_{k-j+1} - m_{k-j};  a[j] = <d_j,d1> (j < NP), a[NP] = <d0,d0>, a[NP+j-1] = <d_j,d_j>
-// (j = 2..NP-1), a[2NP-1] = <m_k,m_k>   ->  part[block][EXT_NS]
-__global__ __launch_bounds__(256) void k_extrap_sums(const double* __restrict__ mNew, const double* __restrict__ hist, int nAC,
-                                                      double* __restrict__ part) {
-    __shared__ double sh[EXT_NS][4];
-    double a[EXT_NS];
-#pragma unroll
-    for (int q = 0; q < EXT_NS; ++q) a[q] = 0.0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nAC; i += EXT_NBLK * 256) {
-        double m[EXT_NP], d[EXT_NP];
-#pragma unroll
-        for (int j = 0; j < EXT_NP; ++j) m[j] = hist[(long)j * nAC + i];
-        d[0] = mNew[i] - m[0];
-#pragma unroll
-        for (int j = 1; j < EXT_NP; ++j) d[j] = m[j - 1] - m[j];
-#pragma unroll
-        for (int j = 0; j < EXT_NP; ++j) a[j] += d[j] * d[1];
-        a[EXT_NP] += d[0] * d[0];
-#pragma unroll
-        for (int j = 2; j < EXT_NP; ++j) a[EXT_NP + j - 1] += d[j] * d[j];
-        a[EXT_NS - 1] += m[0] * m[0];
-    }
-    const int w = threadIdx.x >> 6;
-#pragma unroll
-    for (int q = 0; q < EXT_NS; ++q) {
-        a[q] = wave_sum(a[q]);
-        if ((threadIdx.x & 63) == 0) sh[q][w] = a[q];
-    }
-    __syncthreads();
-    if (threadIdx.x < EXT_NS) part[blockIdx.x * EXT_NS + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
-}
-
-// pass 2 (one wave): the extrapolation weights from the partial sums
+// The weights from the summed partials (one thread).
 // coldUnlessSmooth (the adjoint solve): without at least three collinear points the weights are all zero -- the adjoint's
 // right-hand side is the weighted residual, which changes by O(1) from step to step, so its previous solution is no
 // better a guess than zero (measured on the sampler's trajectories: 0-4 iterations WORSE than a cold start) unless the
-// model path is smooth enough for the extrapolation proper.
-__global__ __launch_bounds__(64) void k_extrap_weights(const double* __restrict__ part, double* ext, int maxNp, int coldUnlessSmooth) {
-    double a[EXT_NS];
-#pragma unroll
-    for (int q = 0; q < EXT_NS; ++q) a[q] = wave_sum(threadIdx.x < EXT_NBLK ? part[threadIdx.x * EXT_NS + q] : 0.0);
-    if (threadIdx.x != 0) return;
+// model path is smooth enough for the extrapolation proper.  Returns keep (the model is a repeat: nothing moves).
+__device__ bool extrap_weights(const double* a, double* ext, int maxNp, int coldUnlessSmooth) {
     const int count = (int)ext[EXT_COUNT];
     const double d1d1 = a[1], d0d0 = a[EXT_NP], mkmk = a[EXT_NS - 1];
     const bool keep = count >= 1 && d0d0 <= 1e-28 * mkmk;
@@ -445,41 +410,99 @@ __global__ __launch_bounds__(64) void k_extrap_weights(const double* __restrict_
     }
     for (int i = 0; i < EXT_NP; ++i) ext[i] = wts[i];
     ext[EXT_KEEP] = keep ? 1.0 : 0.0;
-    if (!keep) ext[EXT_COUNT] = (double)min(count + 1, EXT_NP);
-}
-
-// pass 3: the model history moves on (unless the model is a repeat)
-__global__ __launch_bounds__(256) void k_extrap_shift(const double* __restrict__ mNew, double* hist, int nAC, const double* __restrict__ ext) {
-    if (ext[EXT_KEEP] != 0.0) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nAC) {
-#pragma unroll
-        for (int j = EXT_NP - 1; j >= 1; --j) hist[(long)j * nAC + i] = hist[(long)(j - 1) * nAC + i];
-        hist[i] = mNew[i];
+    if (!keep) {
+        ext[EXT_COUNT] = (double)min(count + 1, EXT_NP);
+        // both histories are rings: the heads move back by one; the slot a head lands on (the oldest entry) receives the
+        // new model (below) / the solution that is about to be replaced by the new guess (k_extrap)
+        ext[EXT_HEAD] = (double)(((int)ext[EXT_HEAD] + EXT_NP - 2) % (EXT_NP - 1));
+        ext[EXT_MHEAD] = (double)(((int)ext[EXT_MHEAD] + EXT_NP - 1) % EXT_NP);
     }
+    return keep;
 }
 
-// x <- sum_j w_j x_{k-j}, history shifted (... <- xp1 <- xp0 <- old x), on interior nodes (runs beside
-// k_bc_forward, which writes X's boundary nodes); xp = [EXT_NP-1][S*vstride]
+// One launch (round 1: three in a row in front of every k_extrap -- 45 us of serial side-stream time that the forward
+// residual waited for): per-block partial sums over the model history -- a ring hist[slot][nAC], the model j evaluations
+// back in slot (head + j) mod NP -- of the steps d0 = m_new - m_k, d_j = m_{k-j+1} - m_{k-j}:
+//     a[j] = <d_j,d1> (j < NP), a[NP] = <d0,d0>, a[NP+j-1] = <d_j,d_j> (j = 2..NP-1), a[2NP-1] = <m_k,m_k>;
+// the block that takes the last ticket adds them up, derives the weights and stores the new model in the ring (every
+// other block has finished reading the history by then).
+__global__ __launch_bounds__(256) void k_extrap_prepare(const double* __restrict__ mNew, double* hist, int nAC, double* ext,
+                                                         int maxNp, int coldUnlessSmooth) {
+    __shared__ double sh[EXT_NS][4];
+    __shared__ int lastFlag, keepFlag;
+    const int hm = (int)ext[EXT_MHEAD];
+    double a[EXT_NS];
+#pragma unroll
+    for (int q = 0; q < EXT_NS; ++q) a[q] = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nAC; i += EXT_NBLK * 256) {
+        double m[EXT_NP], d[EXT_NP];
+#pragma unroll
+        for (int j = 0; j < EXT_NP; ++j) m[j] = hist[(long)((hm + j) % EXT_NP) * nAC + i];
+        d[0] = mNew[i] - m[0];
+#pragma unroll
+        for (int j = 1; j < EXT_NP; ++j) d[j] = m[j - 1] - m[j];
+#pragma unroll
+        for (int j = 0; j < EXT_NP; ++j) a[j] += d[j] * d[1];
+        a[EXT_NP] += d[0] * d[0];
+#pragma unroll
+        for (int j = 2; j < EXT_NP; ++j) a[EXT_NP + j - 1] += d[j] * d[j];
+        a[EXT_NS - 1] += m[0] * m[0];
+    }
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < EXT_NS; ++q) {
+        a[q] = wave_sum(a[q]);
+        if ((threadIdx.x & 63) == 0) sh[q][w] = a[q];
+    }
+    __syncthreads();
+    double* part = ext + EXT_PART;
+    if (threadIdx.x < EXT_NS) part[blockIdx.x * EXT_NS + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* ticket = reinterpret_cast<unsigned*>(ext + EXT_TICKET);
+        const unsigned t = atomicAdd(ticket, 1u);
+        lastFlag = t == EXT_NBLK - 1;
+        if (lastFlag) *ticket = 0;
+    }
+    __syncthreads();
+    if (!lastFlag) return;
+    __threadfence();
+    if (threadIdx.x < 64) {
+        const volatile double* vp = part;
+#pragma unroll
+        for (int q = 0; q < EXT_NS; ++q) a[q] = wave_sum(threadIdx.x < EXT_NBLK ? vp[threadIdx.x * EXT_NS + q] : 0.0);
+        if (threadIdx.x == 0) keepFlag = extrap_weights(a, ext, maxNp, coldUnlessSmooth) ? 1 : 0;
+    }
+    __syncthreads();
+    if (keepFlag) return;
+    double* slot = hist + (long)((hm + EXT_NP - 1) % EXT_NP) * nAC;
+    for (int i = threadIdx.x; i < nAC; i += 256) slot[i] = mNew[i];
+}
+
+// x <- sum_j w_j x_{k-j} on interior nodes (runs beside k_bc_forward, which writes X's boundary nodes).  The previous
+// solutions live in a RING of EXT_NP-1 slots xp[slot][S*vstride]: with the head h already moved by k_extrap_weights, the
+// solution j evaluations back (j = 1..NP-1, before this call) is slot (h + j) mod (NP-1), and the current solution goes
+// to slot h -- the oldest one, read (if its weight is non-zero) before it is overwritten by the same thread.  Only the
+// fields with a non-zero weight are read: 2 on a path that is not smooth, none for a cold adjoint start (round 1
+// shifted the whole history through memory: 12 vector passes of 11.5 MB per call instead of 2-8).
 __global__ __launch_bounds__(VBLOCK) void k_extrap(Solver k, cplx* x, cplx* xp, const double* __restrict__ ext) {
     if (ext[EXT_KEEP] != 0.0) return;
     double w[EXT_NP];
 #pragma unroll
     for (int j = 0; j < EXT_NP; ++j) w[j] = ext[j];
+    const int h = (int)ext[EXT_HEAD];
     const long so = (long)blockIdx.y * k.vstride, hs = (long)k.S * k.vstride;
     const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
     for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
         const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
         if (iz < 1 || iz > k.nz - 1 || iy < 1 || iy > k.ny - 1) continue;
-        cplx q[EXT_NP];
-        q[0] = x[so + e];
+        const cplx q0 = x[so + e];
+        cplx acc = w[0] * q0;
 #pragma unroll
-        for (int j = 1; j < EXT_NP; ++j) q[j] = xp[(long)(j - 1) * hs + so + e];
-        cplx acc = w[0] * q[0];
-#pragma unroll
-        for (int j = 1; j < EXT_NP; ++j) acc += w[j] * q[j];
-#pragma unroll
-        for (int j = EXT_NP - 1; j >= 1; --j) xp[(long)(j - 1) * hs + so + e] = q[j - 1];
+        for (int j = 1; j < EXT_NP; ++j)
+            if (w[j] != 0.0) acc += w[j] * xp[(long)((h + j) % (EXT_NP - 1)) * hs + so + e];
+        xp[(long)h * hs + so + e] = q0;
         x[so + e] = acc;
     }
 }

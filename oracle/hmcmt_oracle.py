@@ -7,13 +7,25 @@ it.  It is the checker the GPU path is compared against.  Only `tests/`,
 `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it; the
 product (`hmcmt2d_amd/`) never does.
 
-PARITY UNPINNED: the reference is Julia (no `julia` in this image), its native
-solver binary (MUMPS) is stripped from the snapshot, and HMCMT ships no tests or
-golden vectors for this path.  The restatement is therefore
-pinned only by (i) the MUMPS wrapper's residual bar (MUMPS/test/testDivGrad.jl:19),
-(ii) analytic 1-D impedances, (iii) adjoint-vs-explicit-J identities from
-MTSensitivity/compJacMat.jl:206-314 and (iv) interior finite differences; see
-tests/test_oracle_*.py.
+PARITY -- the reference cannot be run here (Julia: no `julia` in this image; its
+native solver binary, MUMPS, is stripped from the snapshot) and HMCMT ships no tests
+or golden vectors for this path.  What pins this file:
+
+* FORWARD HALF (m -> predData): PINNED against the reference's own example data.
+  HMCMT/examples/dprism3d/dprism2dobs.dat is synthetic output of its authors'
+  forward code with noise in the real parts only; for the model the file was
+  generated from (two prisms, recovered by oracle/pin/recover_dprism.py) this
+  restatement reproduces all 902 imaginary parts to the last of their seven printed
+  digits -- TE and TM, 11 frequencies, 41 receivers, 10/100/1000 Ohm-m -- and the
+  error column as 5 % of its |Z| (tests/test_oracle_kat.py, first test; the HIP
+  path is held to the same file in tests/test_gpu_parity_full.py).
+* ADJOINT / GRADIENT HALF (-> dataGrad): PARITY UNPINNED by reference outputs (none
+  exist).  It is pinned by identities only: the adjoint against the explicit
+  Jacobian built as MTSensitivity/compJacMat.jl:206-314 specifies it, interior
+  finite differences of the (pinned) forward map, the Rho/phase chain rule, and
+  the MUMPS wrapper's residual bar (MUMPS/test/testDivGrad.jl:19) for the solver;
+  the reference's boundary-derivative approximations are
+  restated from the source and not observable in any output it ships.
 
 The sparse direct solve of the reference (UMFPACK `lu` via SuiteSparse_jll 7.2.1,
 mt2DTE.jl:48 / MUMPS `sym=1`, mt2DTE.jl:51-53) is a third-party dependency that is

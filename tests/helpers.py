@@ -126,3 +126,41 @@ def rhophase_problem():
     mesh.sigma = start_sigma(mesh)
     inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, g["obs"], g["err"])
     return mesh, data, inv, S.rough_state(len(inv.strModel)), g
+
+
+# ---- the reference example whose data pin the forward half (oracle/pin/recover_dprism.py) ----
+DPRISM_TRUE = [(4000.0, 8000.0, 1000.0, 2000.0, 10.0), (8000.0, 12000.0, 1000.0, 2000.0, 1000.0)]   # y0, y1, z0, z1 (m), Ohm-m
+
+
+def dprism_generating_problem():
+    """(mesh, data, obs, err) of examples/dprism3d with the model its data were generated from -- a 10 Ohm-m and a
+    1000 Ohm-m prism in 100 Ohm-m, recovered from the file's noise-free imaginary parts -- and the generator's
+    frequencies (the logarithmic grid rounded to six digits; the file prints five)."""
+    from hmcmt2d_amd import fileio
+    ex = os.path.join(GOLDEN, "examples", "dprism3d")
+    mesh = fileio.readEMModel2D(os.path.join(ex, "dprism2d_G96x49.mod"))
+    data, obs, err = fileio.readMT2DData(os.path.join(ex, "dprism2dobs.dat"))
+    data.freqs = np.array([float("%.6g" % f) for f in 10.0 ** np.linspace(2, -2, len(data.freqs))])
+    ny, nz = mesh.gridSize
+    nair = len(mesh.airLayer)
+    yN = np.concatenate([[0.0], np.cumsum(mesh.yLen)]) - mesh.origin[0]
+    zN = np.concatenate([[0.0], np.cumsum(mesh.zLen)]) - mesh.origin[1]
+    sig = np.full((nz, ny), 0.01)
+    sig[:nair] = S.SIG_AIR
+    for y0, y1, z0, z1, rho in DPRISM_TRUE:
+        sig[np.searchsorted(zN, z0 - 1):np.searchsorted(zN, z1 - 1), np.searchsorted(yN, y0 - 1):np.searchsorted(yN, y1 - 1)] = 1.0 / rho
+    mesh.sigma = sig.reshape(-1)
+    return mesh, data, obs, err
+
+
+def assert_reproduces_dprism_file(pred, obs, err, slack=0.0):
+    """The 902 data of dprism2dobs.dat against a forward response of the generating model: every imaginary part
+    (noise-free in the file) equal to the last of its seven printed digits, the error column = 5 % of |Z|, the
+    real parts (5 % noise, clipped at two standard deviations by the generator) statistically consistent."""
+    digit = lambda x: 10.0 ** (np.floor(np.log10(np.abs(x))) - 6)
+    u = (pred - obs).imag / digit(obs.imag)
+    assert np.abs(u).max() <= 0.5 + slack, np.abs(u).max()                 # i.e. '%.6e' % pred.imag == the file's text
+    assert 0.27 < np.sqrt(np.mean(u * u)) < 0.31                           # rounding alone: 1/sqrt(12) = 0.289
+    assert np.abs(0.05 * np.abs(pred) / err - 1).max() < 1e-6              # (pins |Z|, i.e. the real parts too)
+    z = (obs - pred).real / err
+    assert abs(z.mean()) < 0.1 and 0.9 < z.std() < 1.0 and np.abs(z).max() < 2.0 + 1e-4

@@ -23,7 +23,8 @@ from hmcmt2d_amd import synthetic as S, invsetup as I
 from hmcmt2d_amd.fileio import readstartupFile
 from hmcmt2d_amd.lib import HipContext
 from hmcmt2d_amd.structs import MTData
-from tests.helpers import GOLDEN, make_problem, oracle_eval, relmax, cfg3_subset_problem, gerr_split
+from tests.helpers import (GOLDEN, make_problem, oracle_eval, relmax, cfg3_subset_problem, gerr_split,
+                           dprism_generating_problem, assert_reproduces_dprism_file)
 
 pytestmark = pytest.mark.gpu
 
@@ -114,6 +115,24 @@ def test_reference_example_directories(name):
     ny = mesh.gridSize[0]; zid = len(mesh.airLayer)
     rows = slice(zid * (ny + 1), (zid + 2) * (ny + 1))
     assert relmax(ex[rows], g["exTE_rx"]) < 1e-9 and relmax(hx[rows], g["hxTM_rx"]) < 1e-9
+    ctx.close()
+
+
+def test_hip_forward_reproduces_the_reference_example_data_to_the_last_printed_digit():
+    """The HIP path against output of the reference authors' own forward code, no oracle in between: the noise-free
+    imaginary parts and the error column of examples/dprism3d/dprism2dobs.dat for the model the file was generated
+    from (tests/test_oracle_kat.py, oracle/pin/recover_dprism.py).  1e-3 of a digit of slack for the iterative
+    solver's 1e-10."""
+    mesh, data, obs, err = dprism_generating_problem()
+    sig = mesh.sigma.copy()
+    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, obs, err)
+    ctx = HipContext(mesh, data, inv, verify=True)
+    pred, misfit = ctx.forward(np.log(sig[inv.activeIdx]))
+    assert ctx.stats()["status"] == 0 and ctx.stats()["true_res_max"] < RES_TOL
+    assert_reproduces_dprism_file(pred, obs, err, slack=1e-3)
+    # the misfit at the generating model is the noise alone: chi^2 / N close to 1 on the 902 real parts
+    z = (obs - pred).real / err
+    assert abs(2 * misfit - np.sum(z * z)) < 1e-3 and 0.8 < 2 * misfit / len(z) < 1.0
     ctx.close()
 
 

@@ -1,4 +1,5 @@
-"""Known-answer tests that pin the oracle (the reference ships no tests for this path)."""
+"""Known-answer tests that pin the oracle: the reference ships no tests for this path, but its example data
+file turned out to hold noise-free output of its authors' forward code -- the first test below."""
 import numpy as np
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
@@ -7,7 +8,28 @@ import pytest
 from oracle import hmcmt_oracle as O
 from hmcmt2d_amd import synthetic as S, invsetup as I
 from hmcmt2d_amd.structs import HMCPrior
-from tests.helpers import make_problem, oracle_eval
+from tests.helpers import make_problem, oracle_eval, dprism_generating_problem, assert_reproduces_dprism_file
+
+
+def test_forward_reproduces_the_reference_example_data_to_the_last_printed_digit():
+    """THE PIN of the forward half (predData).  HMCMT/examples/dprism3d/dprism2dobs.dat is synthetic data its authors
+    generated on the mesh of dprism2d_G96x49.mod; noise went into the real parts only.  For the generating model
+    (two prisms, recovered by oracle/pin/recover_dprism.py) the oracle's response equals the file's 902 imaginary
+    parts digit for digit -- both polarisations, 11 frequencies, 41 receivers, across a 10 / 100 / 1000 Ohm-m
+    contrast -- and 5 % of its |Z| equals the error column.  (For scale: the discretisation error this reproduces
+    is 3e-5 of |Z| at the far receivers, 100x the file's resolution.)"""
+    mesh, data, obs, err = dprism_generating_problem()
+    O.setupTensorMesh2D(mesh)
+    pred, _ = O.MT2DFwdSolver(mesh, data)
+    assert_reproduces_dprism_file(pred, obs, err)
+    # the analytic half-space value is NOT what the file holds at the far receivers: the match is with the scheme
+    an = np.sqrt(2 * np.pi * 100.0 * O.MU0 * 100.0 / 2)
+    assert abs(obs[0].imag - an) > 2.5e-5 and abs(obs[0].imag - pred[0].imag) < 5e-8
+    # and a wrong model / the 5-digit frequencies printed in the file do not pass
+    data.freqs = np.array([float("%.5g" % f) for f in data.freqs])
+    pred5, _ = O.MT2DFwdSolver(mesh, data)
+    with pytest.raises(AssertionError):
+        assert_reproduces_dprism_file(pred5, obs, err)
 
 
 def divgrad(n1, n2, n3):
