@@ -29,3 +29,20 @@ with tempfile.TemporaryDirectory() as td:
     H.outputHMCSamples(model, stats, preds, ichain=1, cputime=dt, outdir=td)
     print("wrote", sorted(os.listdir(td)))
 print(f"posterior ln(sigma) after burn-in: mean in [{mean.min():.2f}, {mean.max():.2f}], std in [{std.min():.3f}, {std.max():.3f}]")
+if name == "dprism3d":
+    # the model the example's data were generated from (oracle/pin/recover_dprism.py): where does the
+    # posterior put it?
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tests.helpers import dprism_generating_problem
+    tmesh = dprism_generating_problem()[0]
+    truth = np.log(tmesh.sigma[inv.activeIdx])
+    ny, nz = mesh.gridSize; nair = len(mesh.airLayer)
+    T = truth.reshape(nz - nair, ny); M = np.asarray(mean).reshape(nz - nair, ny); Sd = np.asarray(std).reshape(nz - nair, ny)
+    core = np.zeros_like(T, dtype=bool); core[:30, 8:88] = True          # under the receiver line, top 3 km
+    l10 = lambda x: -x / np.log(10.0)                                    # ln sigma -> log10 rho
+    for label, sel in (("conductive prism (10 ohm-m)", (T > np.log(0.05)) & core), ("resistive prism (1000 ohm-m)", (T < np.log(0.005)) & core),
+                       ("background (100 ohm-m), top 3 km under the line", (np.abs(T - np.log(0.01)) < 1e-9) & core)):
+        z = (M[sel] - T[sel]) / Sd[sel]
+        print(f"  {label}: {sel.sum()} cells, true log10 rho {l10(T[sel]).mean():.2f}, posterior mean {l10(M[sel]).mean():.2f} "
+              f"(cell range {l10(M[sel]).min():.2f} .. {l10(M[sel]).max():.2f}), mean posterior std {Sd[sel].mean() / np.log(10):.2f} decades, "
+              f"truth within 2 std in {100 * np.mean(np.abs(z) < 2):.0f} % of the cells")
