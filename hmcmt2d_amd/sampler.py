@@ -202,10 +202,46 @@ def proposeLeapfrogDevice(hmcParamCurrent: HMCParameter, mtMesh, mtData, invPara
     return m1, p1
 
 
+def _save_checkpoint(path, it, hmcmodel, hmcdata, stats, cur, start, rng, invParam, hmcprior):
+    """Everything the loop of runHMCSampler carries from one sample to the next, written atomically."""
+    import json
+    import os
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
+        np.savez(f, it=it, hmcmodel=hmcmodel[:, :it], hmcdata=hmcdata[:, :it + 1], hmstats=stats.hmstats[:, :it + 1],
+                 acceptstats=stats.acceptstats[:it], counts=np.array([stats.nAccept, stats.nReject, hmcprior.nfevals]),
+                 rhomodel=cur.rhomodel, momentum=cur.momentum, start=np.array(start), refModel=invParam.refModel,
+                 shape=np.array(hmcmodel.shape), rng=np.array(json.dumps(rng.bit_generator.state)))
+    os.replace(tmp, path)
+
+
+def _load_checkpoint(path, hmcmodel, hmcdata, stats, cur, rng, invParam, hmcprior):
+    import json
+    with np.load(path) as g:
+        if tuple(g["shape"]) != hmcmodel.shape or not np.array_equal(g["refModel"], invParam.refModel):
+            raise ValueError(f"{path}: checkpoint of a different run (sizes or reference model differ)")
+        it = int(g["it"])
+        hmcmodel[:, :it] = g["hmcmodel"]
+        hmcdata[:, :it + 1] = g["hmcdata"]
+        stats.hmstats[:, :it + 1] = g["hmstats"]
+        stats.acceptstats[:it] = g["acceptstats"]
+        stats.nAccept, stats.nReject, hmcprior.nfevals = (int(c) for c in g["counts"])
+        cur.rhomodel, cur.momentum = g["rhomodel"].copy(), g["momentum"].copy()
+        rng.bit_generator.state = json.loads(str(g["rng"]))
+        return it, tuple(float(x) for x in g["start"])
+
+
 def runHMCSampler(mtMesh, mtData, invParam, hmcprior, rng=None, rhoref=None, ctx: HipContext | None = None,
-                  verbose=False, reuse_forward=True, device_leapfrog=False, device_id=None):
+                  verbose=False, reuse_forward=True, device_leapfrog=False, device_id=None,
+                  checkpoint=None, checkpoint_every=0):
     """Returns (hmcmodel[nparam, nsamples], hmcstats, hmcdata[ndata, nsamples+1]).  The chain runs on GPU `device_id`
-    (default: `default_device()`, i.e. LOCAL_RANK) unless a context is passed in."""
+    (default: `default_device()`, i.e. LOCAL_RANK) unless a context is passed in.
+
+    `checkpoint` (a file path) with `checkpoint_every` = k > 0: the chain's state -- samples so far, statistics, current
+    model and momentum, the RNG state -- is flushed every k samples; if the file exists when the sampler starts, the
+    chain RESUMES behind its last flushed sample and draws the same random numbers an uninterrupted run would have
+    (the reference keeps every sample in memory until the chain ends, HMCSampler.jl:785-828: a crash loses the run;
+    SURVEY section 5 lists this as the one piece of fault tolerance worth adding)."""
     _check_solver(hmcprior)
     rng = rng or np.random.default_rng()
     ctx = ctx or get_context(mtMesh, mtData, invParam, device_id=device_id)
@@ -237,7 +273,16 @@ def runHMCSampler(mtMesh, mtData, invParam, hmcprior, rng=None, rhoref=None, ctx
     stats: HMCStatus = initHMCStatus(nsamples)
     stats.hmstats[:, 0] = [startD, startM, startK, startH]
     hmcdata[:, 0] = predData
-    for it in range(1, nsamples + 1):
+    first = 1
+    if checkpoint:
+        import os
+        if os.path.exists(checkpoint):
+            done, (startD, startM, startK, startH) = _load_checkpoint(checkpoint, hmcmodel, hmcdata, stats, cur, rng,
+                                                                      invParam, hmcprior)
+            first = done + 1
+            if verbose:
+                print(f"resuming behind sample {done} of {nsamples} ({checkpoint})")
+    for it in range(first, nsamples + 1):
         propose = proposeLeapfrogDevice if device_leapfrog else proposeLeapfrog
         propModel, propMomentum = propose(cur, mtMesh, mtData, invParam, hmcprior, rng, None, ctx)
         prop.rhomodel, prop.momentum = propModel.copy(), propMomentum.copy()
@@ -263,6 +308,9 @@ def runHMCSampler(mtMesh, mtData, invParam, hmcprior, rng=None, rhoref=None, ctx
         startH = startD + startM + startK
         stats.hmstats[:, it] = [startD, startM, startK, startH]
         hmcmodel[:, it - 1] = cur.rhomodel
+        if checkpoint and checkpoint_every > 0 and (it % checkpoint_every == 0 or it == nsamples):
+            _save_checkpoint(checkpoint, it, hmcmodel, hmcdata, stats, cur, (startD, startM, startK, startH), rng,
+                             invParam, hmcprior)
     return hmcmodel, stats, hmcdata
 
 
@@ -283,7 +331,8 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
     thread each: a single chain's launches are latency-bound at the headline size, and two chains overlap to
     1.34x the throughput of one (measured, scripts/gpu_two_chains.py); the chains and their results are the same as
     run one after another (independent contexts, per-chain RNG streams).
-    Further keyword arguments go to runHMCSampler (e.g. device_leapfrog=True).
+    Further keyword arguments go to runHMCSampler (e.g. device_leapfrog=True; `checkpoint=path` becomes
+    `path.chain<k>` per chain).
     Returns (hmcmodel[list], hmcstats[list], hmcdata[list]) indexed by chain.
     """
     import copy
@@ -312,7 +361,10 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
             inv_c, prior_c, mesh_c = copy.deepcopy(invParam), copy.deepcopy(hmcprior), copy.deepcopy(mtMesh)
             ctx_c = context_factory(mesh_c, mtData, inv_c, dev_id) if context_factory is not None else \
                 get_context(mesh_c, mtData, inv_c, device_id=dev_id)
-            model, stats, data = runHMCSampler(mesh_c, mtData, inv_c, prior_c, rng, ctx=ctx_c, **sampler_kw)
+            kw = dict(sampler_kw)
+            if kw.get("checkpoint"):                        # one checkpoint file per chain
+                kw["checkpoint"] = f"{kw['checkpoint']}.chain{c + 1}"
+            model, stats, data = runHMCSampler(mesh_c, mtData, inv_c, prior_c, rng, ctx=ctx_c, **kw)
             release_context(inv_c)
         results[c] = (model, stats, data, time.time() - t0)
 

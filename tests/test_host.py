@@ -83,6 +83,44 @@ def test_sampler_mirror_equals_oracle_chain():
     assert ctx.nfwd == 1 and ctx.ngrad == prior_p.nfevals
 
 
+def test_checkpointed_chain_resumes_bit_for_bit(tmp_path):
+    """checkpoint / resume (not in the reference, which loses the run on a crash: SURVEY section 5): a chain killed in
+    the middle of a sample and restarted with the same seed continues behind its last flushed sample and ends with
+    exactly the samples, statistics and evaluation count of an uninterrupted run."""
+    mesh, data, inv, m = make_problem("tiny")
+    prior = HMCPrior(totalsamples=5, burninsamples=1, dt=0.02, timestep=[2, 3], sigBounds=[1e-4, 1.0], regParam=1.0)
+    full = sampler.runHMCSampler(copy.deepcopy(mesh), data, copy.deepcopy(inv), copy.deepcopy(prior), np.random.default_rng(5),
+                                 ctx=OracleContext(mesh, data, inv))
+
+    class Crash(Exception):
+        pass
+
+    class Dying(OracleContext):
+        def grad(self, m):
+            if self.ngrad >= 9:                    # somewhere inside the fourth trajectory
+                raise Crash()
+            return super().grad(m)
+
+    ck = str(tmp_path / "chain.ckpt")
+    with pytest.raises(Crash):
+        sampler.runHMCSampler(copy.deepcopy(mesh), data, copy.deepcopy(inv), copy.deepcopy(prior), np.random.default_rng(5),
+                              ctx=Dying(mesh, data, inv), checkpoint=ck, checkpoint_every=2)
+    assert os.path.exists(ck) and int(np.load(ck)["it"]) == 2
+    prior2 = copy.deepcopy(prior)
+    ctx2 = OracleContext(mesh, data, inv)
+    res = sampler.runHMCSampler(copy.deepcopy(mesh), data, copy.deepcopy(inv), prior2, np.random.default_rng(5), ctx=ctx2,
+                                checkpoint=ck, checkpoint_every=2)
+    assert np.array_equal(res[0], full[0]) and np.array_equal(res[2], full[2])
+    assert np.array_equal(res[1].hmstats, full[1].hmstats) and np.array_equal(res[1].acceptstats, full[1].acceptstats)
+    assert (res[1].nAccept, res[1].nReject) == (full[1].nAccept, full[1].nReject)
+    assert ctx2.ngrad < prior2.nfevals                     # (the resumed process did only the remaining trajectories)
+    assert int(np.load(ck)["it"]) == 5
+    # a checkpoint of another run is refused
+    with pytest.raises(ValueError):
+        sampler.runHMCSampler(copy.deepcopy(mesh), data, copy.deepcopy(inv), copy.deepcopy(prior), np.random.default_rng(6),
+                              ctx=OracleContext(mesh, data, inv), checkpoint=ck, checkpoint_every=2)
+
+
 def test_get_hamiltonian_without_reuse_repeats_forward():
     mesh, data, inv, m = make_problem("tiny")
     ctx = OracleContext(mesh, data, inv)
