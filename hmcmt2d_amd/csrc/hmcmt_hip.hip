@@ -87,7 +87,7 @@ struct hmcmt_ctx {
     bool haveModel = false;
     bool haveFwd = false, haveAdj = false;   // previous fields usable as initial guesses
     cplx* d_prevField[2] = {nullptr, nullptr};   // the EXT_NP-1 previous solutions (warm_start == 2), per solve kind: a ring [EXT_NP-1][S*vstride]
-    double* d_mHist[2] = {nullptr, nullptr};     // [EXT_NP][nAC] model history per solve kind (a ring: kernels_fused.h)
+    double* d_mHist[2] = {nullptr, nullptr};     // [EXT_NP+1][nAC] model history per solve kind (a ring: kernels_fused.h)
     double* d_ext[2] = {nullptr, nullptr};       // {w_0..w_{EXT_NP-1}, keep, count, ring heads, partial sums, ticket} (kernels_fused.h)
     double jacobiW = 0.8;                    // damping of the point-Jacobi halves (HMCMT_JACOBI_W; 0.7 in round 1: 0.8 saves 3-8 % of the iterations on structured models, costs 6-25 % on white-noise models of std >= 1)
     int extrapNp = EXT_NP;                   // fields used by the initial-guess extrapolation (HMCMT_EXTRAP_POINTS = 2..EXT_NP)
@@ -840,7 +840,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     DA(v.qPart, S * h.ny) DA(v.gPart, 2 * (size_t)h.nCell) DA(v.gPartG, 2 * GRAD_NG * (size_t)h.nCell) DA(v.grad, h.nAC)
     DA(ctx->d_m, h.nAC) DA(ctx->d_misfit, 1) DA(ctx->d_cnt, 1)
     for (int q : h.sysOn) ctx->nSysOn += q;
-    for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], (EXT_NP - 1) * S * VS) DA(ctx->d_mHist[kd], EXT_NP * (size_t)h.nAC) DA(ctx->d_ext[kd], EXT_LEN) }
+    for (int kd = 0; kd < 2; ++kd) { DA(ctx->d_prevField[kd], (EXT_NP - 1) * S * VS) DA(ctx->d_mHist[kd], (EXT_NP + 1) * (size_t)h.nAC) DA(ctx->d_ext[kd], EXT_LEN) }
     Solver& k = ctx->sv;
     k.S = h.S; k.NYP = h.NYP; k.NZP = h.NZP; k.ny = h.ny; k.nz = h.nz; k.nFreq = h.nFreq; k.vstride = v.vstride;
     k.NB = std::max(1, std::min(32, (1024 + h.S - 1) / h.S));

@@ -412,33 +412,38 @@ __device__ bool extrap_weights(const double* a, double* ext, int maxNp, int cold
     ext[EXT_KEEP] = keep ? 1.0 : 0.0;
     if (!keep) {
         ext[EXT_COUNT] = (double)min(count + 1, EXT_NP);
-        // both histories are rings: the heads move back by one; the slot a head lands on (the oldest entry) receives the
-        // new model (below) / the solution that is about to be replaced by the new guess (k_extrap)
+        // both histories are rings: the heads move back by one, the model ring's onto the slot k_extrap_prepare has just
+        // filled with the new model, the field ring's onto its oldest entry, which receives the solution that is about to
+        // be replaced by the new guess (k_extrap)
         ext[EXT_HEAD] = (double)(((int)ext[EXT_HEAD] + EXT_NP - 2) % (EXT_NP - 1));
-        ext[EXT_MHEAD] = (double)(((int)ext[EXT_MHEAD] + EXT_NP - 1) % EXT_NP);
+        ext[EXT_MHEAD] = (double)(((int)ext[EXT_MHEAD] + EXT_NP) % (EXT_NP + 1));
     }
     return keep;
 }
 
 // One launch (round 1: three in a row in front of every k_extrap -- 45 us of serial side-stream time that the forward
-// residual waited for): per-block partial sums over the model history -- a ring hist[slot][nAC], the model j evaluations
-// back in slot (head + j) mod NP -- of the steps d0 = m_new - m_k, d_j = m_{k-j+1} - m_{k-j}:
+// residual waited for): per-block partial sums over the model history -- a ring hist[slot][nAC] of NP+1 slots, the model
+// j evaluations back in slot (head + j) mod (NP+1) -- of the steps d0 = m_new - m_k, d_j = m_{k-j+1} - m_{k-j}:
 //     a[j] = <d_j,d1> (j < NP), a[NP] = <d0,d0>, a[NP+j-1] = <d_j,d_j> (j = 2..NP-1), a[2NP-1] = <m_k,m_k>;
-// the block that takes the last ticket adds them up, derives the weights and stores the new model in the ring (every
-// other block has finished reading the history by then).
+// every block also stores its part of the new model in the one slot nobody reads, the slot in front of the head; the
+// block that takes the last ticket adds the partial sums up, derives the weights and -- unless the model is a repeat --
+// moves the head onto that slot.
 __global__ __launch_bounds__(256) void k_extrap_prepare(const double* __restrict__ mNew, double* hist, int nAC, double* ext,
                                                          int maxNp, int coldUnlessSmooth) {
     __shared__ double sh[EXT_NS][4];
-    __shared__ int lastFlag, keepFlag;
+    __shared__ int lastFlag;
     const int hm = (int)ext[EXT_MHEAD];
+    double* fresh = hist + (long)((hm + EXT_NP) % (EXT_NP + 1)) * nAC;
     double a[EXT_NS];
 #pragma unroll
     for (int q = 0; q < EXT_NS; ++q) a[q] = 0.0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nAC; i += EXT_NBLK * 256) {
         double m[EXT_NP], d[EXT_NP];
 #pragma unroll
-        for (int j = 0; j < EXT_NP; ++j) m[j] = hist[(long)((hm + j) % EXT_NP) * nAC + i];
-        d[0] = mNew[i] - m[0];
+        for (int j = 0; j < EXT_NP; ++j) m[j] = hist[(long)((hm + j) % (EXT_NP + 1)) * nAC + i];
+        const double mn = mNew[i];
+        fresh[i] = mn;
+        d[0] = mn - m[0];
 #pragma unroll
         for (int j = 1; j < EXT_NP; ++j) d[j] = m[j - 1] - m[j];
 #pragma unroll
@@ -466,18 +471,12 @@ __global__ __launch_bounds__(256) void k_extrap_prepare(const double* __restrict
         if (lastFlag) *ticket = 0;
     }
     __syncthreads();
-    if (!lastFlag) return;
+    if (!lastFlag || threadIdx.x >= 64) return;
     __threadfence();
-    if (threadIdx.x < 64) {
-        const volatile double* vp = part;
+    const volatile double* vp = part;
 #pragma unroll
-        for (int q = 0; q < EXT_NS; ++q) a[q] = wave_sum(threadIdx.x < EXT_NBLK ? vp[threadIdx.x * EXT_NS + q] : 0.0);
-        if (threadIdx.x == 0) keepFlag = extrap_weights(a, ext, maxNp, coldUnlessSmooth) ? 1 : 0;
-    }
-    __syncthreads();
-    if (keepFlag) return;
-    double* slot = hist + (long)((hm + EXT_NP - 1) % EXT_NP) * nAC;
-    for (int i = threadIdx.x; i < nAC; i += 256) slot[i] = mNew[i];
+    for (int q = 0; q < EXT_NS; ++q) a[q] = wave_sum(threadIdx.x < EXT_NBLK ? vp[threadIdx.x * EXT_NS + q] : 0.0);
+    if (threadIdx.x == 0) extrap_weights(a, ext, maxNp, coldUnlessSmooth);
 }
 
 // x <- sum_j w_j x_{k-j} on interior nodes (runs beside k_bc_forward, which writes X's boundary nodes).  The previous
