@@ -473,9 +473,12 @@ __global__ __launch_bounds__(256) void k_extrap_prepare(const double* __restrict
     __syncthreads();
     if (!lastFlag || threadIdx.x >= 64) return;
     __threadfence();
-    const volatile double* vp = part;
+    const volatile double* vp = part + (threadIdx.x < EXT_NBLK ? threadIdx.x : 0) * EXT_NS;
+    double v[EXT_NS];
 #pragma unroll
-    for (int q = 0; q < EXT_NS; ++q) a[q] = wave_sum(threadIdx.x < EXT_NBLK ? vp[threadIdx.x * EXT_NS + q] : 0.0);
+    for (int q = 0; q < EXT_NS; ++q) v[q] = vp[q];                    // (all twelve requested before the first is used)
+#pragma unroll
+    for (int q = 0; q < EXT_NS; ++q) a[q] = wave_sum(threadIdx.x < EXT_NBLK ? v[q] : 0.0);
     if (threadIdx.x == 0) extrap_weights(a, ext, maxNp, coldUnlessSmooth);
 }
 
