@@ -15,7 +15,7 @@ tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 cfg = sys.argv[3] if len(sys.argv) > 3 else "cfg3"
 P = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 stats_csv = os.path.join(P, f"{tag}_bench_{cfg}_kernel_stats.csv")
-shutil.copy(glob.glob(os.path.join(O, "stats", "*", "*kernel_stats.csv"))[0], stats_csv)
+shutil.copy(max(glob.glob(os.path.join(O, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime), stats_csv)   # (the newest, if the run dir was reused)
 shutil.copy(os.path.join(O, "bench.json"), os.path.join(P, f"{tag}_bench_{cfg}.json"))
 # PMC bytes: merge this config's entry into the tracked file bench.py reads
 run_pm = json.load(open(os.path.join(O, "pmc_traffic.json")))
