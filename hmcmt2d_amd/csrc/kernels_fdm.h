@@ -378,10 +378,21 @@ constexpr int LP_NTW = 2;          // column tiles per wave of the mixed-precisi
 __device__ __forceinline__ float bf16_to_f32(unsigned h) { return __uint_as_float(h << 16); }
 
 // A: complex64 rows.  Every value is split in registers into hi = bf16(x), lo = bf16(x - hi) and the
-// product is accumulated as Ah*Bh + Ah*Bl + Al*Bh (fp32 accumulators): ~16 mantissa bits, i.e. fp32-class
-// accuracy from the bf16 pipe.  (Plain bf16 operands stalled one low-frequency TE system in 32.)
+// product is accumulated as Ah*Bh + Al*Bh [+ Ah*Bl with HMCMT_VLO] (fp32 accumulators): the input to ~16 mantissa
+// bits from the bf16 pipe.  (Plain bf16 operands stalled one low-frequency TE system in 32.)
 // B: Bhi/Blo fragment arrays.  OUT: 0 = complex64, 1 = fp64 complex, 2 = fp64 complex + dinv*r (fused
 // first half of the post-smoother).
+// The eigenvector matrix V is used in PLAIN bf16 (HMCMT_VLO = 0, the default): the term Ah*Bl and the lo fragments of V
+// are dropped.  Rounding V is not rounding the data: M = V_hi T^-1 V_hi' is still a fixed, linear, complex-symmetric
+// operator -- exactly what COCG needs -- and V_hi = V (I + F) with |F| ~ 2^-9 moves the preconditioned spectrum by
+// a per cent while the layered FDM background itself is off by the lateral contrast.  Measured: the same iteration
+// counts on every trajectory of the bench (18/25 near the true model, 39/46 from the rough state), a third of the
+// MFMAs and half of the V stream gone.  The INPUT rows keep their hi/lo split: rounding them is a nonlinearity of
+// 2^-9 per application, which is what stalled a system when both operands were plain bf16.
+#ifndef HMCMT_VLO
+#define HMCMT_VLO 0
+#endif
+constexpr bool V_LO = HMCMT_VLO != 0;
 constexpr int LP_NRG = HMCMT_LP_NRG;   // row groups (of 8 complex rows) a workgroup transforms per pass
 constexpr int LP_KC = HMCMT_LP_KC;     // k-groups requested together
 
@@ -444,7 +455,8 @@ __device__ __forceinline__ void transform_lp_body(const u4v* __restrict__ ast, c
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
                 const long bi = ((long)kg * NT + t0 + t) * 64 + lane;
-                bh[q][t] = Bhi[bi]; bl[q][t] = Blo[bi];
+                bh[q][t] = Bhi[bi];
+                if (V_LO) bl[q][t] = Blo[bi];
             }
         }
 #pragma unroll
@@ -458,7 +470,7 @@ __device__ __forceinline__ void transform_lp_body(const u4v* __restrict__ ast, c
                     for (int rg = 0; rg < LP_NRG; ++rg) {
                         const bf8v ah = __builtin_bit_cast(bf8v, ahs[rg][q]), al = __builtin_bit_cast(bf8v, als[rg][q]);
                         acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
-                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blf, acc[rg][t], 0, 0, 0);
+                        if (V_LO) acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blf, acc[rg][t], 0, 0, 0);
                         acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
                     }
                 }
@@ -587,10 +599,10 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
     u4v* vst = reinterpret_cast<u4v*>(sb - 2 * FW_TB * SW);
     const bool stageV = (size_t)KG * NTW * 2 * 64 * sizeof(u4v) <= (size_t)2 * nreg * RL * SW * sizeof(c32);
     if (stageV)
-        for (int i = threadIdx.x; i < KG * NTW * 2 * 64; i += blockDim.x) {
-            const int l = i & 63, hl = (i >> 6) & 1, t = (i >> 7) % NTW, kg = (i >> 7) / NTW;
+        for (int i = threadIdx.x; i < KG * NTW * (V_LO ? 2 : 1) * 64; i += blockDim.x) {
+            const int l = i & 63, hl = V_LO ? (i >> 6) & 1 : 0, tk = V_LO ? i >> 7 : i >> 6, t = tk % NTW, kg = tk / NTW;
             const long bi = ((long)kg * NT + min(t0 + t, NT - 1)) * 64 + l;
-            vst[i] = hl ? Blo[bi] : Bhi[bi];
+            vst[((kg * NTW + t) * 2 + hl) * 64 + l] = hl ? Blo[bi] : Bhi[bi];
         }
     __syncthreads();
     const int lj = lane & 15, g = lane >> 4, part = lj & 1;
@@ -631,10 +643,12 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) {
                     if (stageV) {
-                        bh[q][t] = vst[((kg * NTW + t) * 2 + 0) * 64 + lane]; bl[q][t] = vst[((kg * NTW + t) * 2 + 1) * 64 + lane];
+                        bh[q][t] = vst[((kg * NTW + t) * 2 + 0) * 64 + lane];
+                        if (V_LO) bl[q][t] = vst[((kg * NTW + t) * 2 + 1) * 64 + lane];
                     } else {
                         const long bi = ((long)kg * NT + min(t0 + t, NT - 1)) * 64 + lane;
-                        bh[q][t] = Bhi[bi]; bl[q][t] = Blo[bi];
+                        bh[q][t] = Bhi[bi];
+                        if (V_LO) bl[q][t] = Blo[bi];
                     }
                 }
             }
@@ -648,7 +662,7 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
                         for (int rg = 0; rg < 2; ++rg) {
                             const bf8v ah = __builtin_bit_cast(bf8v, ahs[rg][q]), al = __builtin_bit_cast(bf8v, als[rg][q]);
                             acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
-                            acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blf, acc[rg][t], 0, 0, 0);
+                            if (V_LO) acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blf, acc[rg][t], 0, 0, 0);
                             acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
                         }
                     }
@@ -950,7 +964,7 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
                     const int kg = rot + q - (rot + q >= KG ? KG : 0);
                     const char *qh = ph + kg * stride, *ql = pl + kg * stride;
                     bh[q][0] = *reinterpret_cast<const u4v*>(qh); bh[q][1] = *reinterpret_cast<const u4v*>(qh + d1);
-                    bl[q][0] = *reinterpret_cast<const u4v*>(ql); bl[q][1] = *reinterpret_cast<const u4v*>(ql + d1);
+                    if (V_LO) { bl[q][0] = *reinterpret_cast<const u4v*>(ql); bl[q][1] = *reinterpret_cast<const u4v*>(ql + d1); }
                 }
             }
         }
@@ -982,7 +996,7 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
 #pragma unroll
                     for (int rg = 0; rg < 2; ++rg) {
                         acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rg], bhf, acc[rg][t], 0, 0, 0);
-                        acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rg], blf, acc[rg][t], 0, 0, 0);
+                        if (V_LO) acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rg], blf, acc[rg][t], 0, 0, 0);
                         acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rg], bhf, acc[rg][t], 0, 0, 0);
                     }
                 }

@@ -103,13 +103,19 @@ def test_kernels_against_host_instantiation():
     assert relmax(ctx.debug_precond(P), E.apply("fdmj", P)) < 1e-11
     ctx.set_options(precond="fdm"); ctx.grad(m)
     assert relmax(ctx.debug_precond(P), E.apply("fdm", P)) < 1e-11
-    # mixed precision: split-bf16 operands (hi + lo), fp32 accumulation -> fp32-class accuracy
+    # mixed precision: the input rows as split bf16 (hi + lo, ~16 bits), the eigenvectors as plain bf16 (the library's
+    # default, HMCMT_VLO = 0: a rounded V is still one fixed linear symmetric operator, kernels_fdm.h), fp32 accumulation
+    def bf16(x):
+        u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+        return ((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).view(np.float32).astype(np.float64)
     A32 = A.astype(np.complex64).astype(np.complex128)
-    assert relmax(ctx.debug_transform(2, A).reshape(shape), A32 @ V) < 5e-5
-    assert relmax(ctx.debug_transform(3, A).reshape(shape), A32 @ V.T) < 5e-5
+    Vb = bf16(V)
+    assert relmax(ctx.debug_transform(2, A).reshape(shape), A32 @ Vb) < 5e-5
+    assert relmax(ctx.debug_transform(3, A).reshape(shape), A32 @ Vb.T) < 5e-5
+    assert 1e-4 < relmax(A32 @ Vb, A32 @ V) < 1e-2          # (what the rounding of V amounts to)
     ctx.set_options(precond="fdmj", fdm_precision="mixed"); ctx.grad(m)
     z_mixed = ctx.debug_precond(P)
-    assert relmax(z_mixed, E.apply("fdmj", P)) < 1e-3       # a preconditioner: fp32-class agreement is plenty
+    assert relmax(z_mixed, E.apply("fdmj", P)) < 2e-2       # a preconditioner: per-cent agreement with the fp64 one is plenty
     ctx.close()
 
 

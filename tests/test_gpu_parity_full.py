@@ -11,7 +11,7 @@ log in profiles/r02_parity_levels.log) x 3-5:
                           the reference's own rounding floor, tests/test_oracle_kat.py::test_reference_gradient_is_ill_
                           conditioned_in_the_deepest_rows
   nodal fields            1e-9 of max|field| (measured 1e-11); adjoint fields 1e-8 (measured 2e-9)
-  true residual           1e-9 (measured 1e-11 .. 3e-10; was 1e-8 in round 1.  The reference's own bar, 1e-14 in
+  true residual           1e-9 (measured 1e-11 .. 3e-10; 1.4e-8 at the half-space start model of dprism3d, see there; was 1e-8 in round 1.  The reference's own bar, 1e-14 in
                           MUMPS/test/testDivGrad.jl:19, is for a direct solver; with options.tol = 1e-12 the iterative
                           solves reach 3e-12 .. 6e-12 at one more iteration)
 """
@@ -31,12 +31,13 @@ pytestmark = pytest.mark.gpu
 PRED_TOL, GRAD_TOL, GRAD_DEEP_TOL, RES_TOL = 1e-9, 1e-8, 5e-7, 1e-9
 
 
-def _check(ctx, m, pred_ref, misfit_ref, grad_refs, inv, mesh, deep_rows=5, grad_tol=GRAD_TOL, misfit_tol=PRED_TOL, pred_tol=PRED_TOL):
+def _check(ctx, m, pred_ref, misfit_ref, grad_refs, inv, mesh, deep_rows=5, grad_tol=GRAD_TOL, misfit_tol=PRED_TOL, pred_tol=PRED_TOL,
+           res_tol=RES_TOL):
     """grad_refs: one reference gradient, or several rounding-equivalent evaluations of the reference formula (the
     gradient must agree with one of them, see tests/golden/make_golden.py::make_example)."""
     pred, misfit, grad = ctx.grad(m)
     st = ctx.stats()
-    assert st["status"] == 0 and st["true_res_max"] < RES_TOL, st
+    assert st["status"] == 0 and st["true_res_max"] < res_tol, st
     assert relmax(pred, pred_ref) < pred_tol and abs(misfit - misfit_ref) / misfit_ref < misfit_tol
     refs = grad_refs if isinstance(grad_refs, (list, tuple)) else [grad_refs]
     errs = [gerr_split(grad, r, inv, mesh, deep_rows) for r in refs]
@@ -109,7 +110,11 @@ def test_reference_example_directories(name):
     assert np.array_equal(inv.strModel, g["m0"])
     ctx = HipContext(mesh, data, inv, verify=True)
     # (the homogeneous start model: the reference formula's gradient is rounding-dependent there, see make_example)
-    _check(ctx, g["m0"], g["pred0"], float(g["misfit0"]), [g["grad0"], g["grad0_alt"][0], g["grad0_alt"][1]], inv, mesh)
+    # (... and the one model where the residual norm says little: for a half-space the FDM background IS the operator, the
+    # solve ends after a handful of iterations on the ERROR estimate -- predData within 5e-12 of the oracle's --
+    # while the 2^-9 rounding of the eigenvectors leaves 1e-8 of residual in short-wavelength modes that carry no error)
+    _check(ctx, g["m0"], g["pred0"], float(g["misfit0"]), [g["grad0"], g["grad0_alt"][0], g["grad0_alt"][1]], inv, mesh,
+           pred_tol=1e-10, res_tol=5e-8 if name == "dprism3d" else RES_TOL)
     _check(ctx, g["m1"], g["pred1"], float(g["misfit1"]), g["grad1"], inv, mesh)
     ex, hx = ctx.fields()
     ny = mesh.gridSize[0]; zid = len(mesh.airLayer)
