@@ -325,6 +325,34 @@ def test_initial_guess_modes_agree_and_extrapolation_saves_iterations():
     assert its["extrapolate"] < its["previous"] < its["cold"]
 
 
+def test_extrapolation_history_rings_wrap_and_survive_kinks_and_repeats():
+    """The field and model histories of the extrapolated initial guess are rings (5 field slots, 7 model slots per
+    solve kind): a path three times as long as the rings, with a repeated model in the middle and a change of direction,
+    (a) gives the cold-start answers at every model, (b) gets cheaper along each straight stretch until the six-point
+    order is reached and stays there while the rings wrap, (c) falls back to the low order at the kink and recovers."""
+    mesh, data, inv, m = make_problem("cfg2")
+    rng = np.random.default_rng(11)
+    d1, d2 = 0.02 * rng.standard_normal(m.size), 0.02 * rng.standard_normal(m.size)
+    path = [m + j * d1 for j in range(10)]
+    path.insert(5, path[4].copy())                                     # a repeat (getHamiltonian's re-evaluation)
+    path += [path[-1] + j * d2 for j in range(1, 9)]                   # the kink, then a second straight stretch
+    cold = HipContext(mesh, data, inv, warm_start="cold")
+    ext = HipContext(mesh, data, inv, warm_start="extrapolate")
+    its_c, its_e = [], []
+    for mj in path:
+        pc, fc, gc = cold.grad(mj); its_c.append(cold.stats()["iters_fwd_sum"] + cold.stats()["iters_adj_sum"])
+        pe, fe, ge = ext.grad(mj); its_e.append(ext.stats()["iters_fwd_sum"] + ext.stats()["iters_adj_sum"])
+        assert ext.stats()["status"] == 0
+        assert relmax(pe, pc) < 1e-9 and abs(fe - fc) / fc < 1e-9 and relmax(ge, gc) < 1e-7
+    its_c, its_e = np.array(its_c), np.array(its_e)
+    assert its_e[5] <= 0.2 * its_c[5]                                   # the repeat costs (next to) nothing
+    first, second = its_e[6:11], its_e[14:19]                          # deep inside the two straight stretches
+    assert first.max() <= 0.7 * its_c[6:11].min() and second.max() <= 0.7 * its_c[14:19].min(), (its_e, its_c)
+    assert its_e[11] > first.max() and its_e[11] <= 1.05 * its_c[11]   # the kink: no better than a warm start, no worse than cold
+    assert abs(int(first[-1]) - int(second[-1])) <= 0.15 * first[-1]   # the second stretch recovers the first one's level
+    cold.close(); ext.close()
+
+
 def test_fused_forward_fdm_kernel_matches_separate_kernels():
     """k_fdm_fwd (eigen-transform + tridiagonal solves of a 16-mode slab in one kernel, slab in LDS) against
     k_transform_lp<0> + k_thomas32 on the same input at the headline size: same arithmetic up to the
