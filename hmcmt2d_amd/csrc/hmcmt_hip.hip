@@ -375,8 +375,9 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
         *(volatile int*)ctx->h_stall = 0;
         *(volatile int*)ctx->h_prog = 0;
         bool stalled = false;
-        static const int sideItEnv = getenv("HMCMT_SIDE_IT") ? atoi(getenv("HMCMT_SIDE_IT")) : 12;
-        const int sideIt = sideItEnv > 0 ? sideItEnv : std::max(2, nextCheck + sideItEnv);
+        // (HMCMT_SIDE_IT = n > 0: at iteration n; default: half-way through the expected solve, between 2 and 12)
+        static const int sideItEnv = getenv("HMCMT_SIDE_IT") ? atoi(getenv("HMCMT_SIDE_IT")) : 0;
+        const int sideIt = sideItEnv > 0 ? sideItEnv : std::max(2, std::min(12, nextCheck / 2));
         while (!done && !stalled && it < ctx->opt.maxit + 1) {
             ++it;
             // decide convergence of the state after iteration it-1, p = z + beta p, q = A p
@@ -398,8 +399,9 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
                 if (*(volatile int*)ctx->h_nactive == 0) { done = true; break; }
                 if (*(volatile int*)ctx->h_stall) stalled = true;
             }
-            // (a dozen API calls, ~150 us of host time: issued once the queue is a dozen iterations deep -- or after the
-            // solve, if it is shorter than that.  Without a tracer attached 2..12 measure the same within 1 %; under
+            // (a dozen API calls, ~150 us of host time: issued half-way through the expected solve, at most a dozen
+            // iterations deep -- short solves, 5-6 iterations on smooth paths, would otherwise get them behind the solve and
+            // wait for the adjoint guess.  Without a tracer attached 2..12 measure the same within 1 %; under
             // rocprofv3, whose launches cost twice as much, the early settings drain the main queue.)
             if (kind == 0 && it == sideIt) launch_adjoint_side(ctx);
         }
