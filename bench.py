@@ -405,8 +405,13 @@ def main():
         ws_mb = 15 * ctx.S * ctx.NZP * ctx.NYP * 16 / 1e6
 
         def build_roofline(prof, cnt, population):
-            back_fused = prof["post_smoother"][1] == 0
             fwd_fused = ctx.NYP <= 256                      # the library's own rule (launch_fdm_fwd): wide meshes run the separate kernels
+            back_fused = fwd_fused                          # ... and k_back_post goes with it (launch_back_post)
+            # two damped Jacobi sweeps per side of the FDM stage (chosen per solve by the library, hmcmt_stats.smoother_sweeps):
+            # a fifth launch, k_post2 (category post_smoother on the fused path), and 8 B/unknown more in two others.  f2 = the
+            # fraction of the sampled preconditioner applications that ran it
+            n0, n7 = prof["fdm_transform"][1], prof["post_smoother"][1]
+            f2 = min(1.0, n7 / n0) if (back_fused and n0) else 0.0
             it_sys = cnt["active_iter_systems"]             # sum over sampled iterations of active systems
             pre_sys = cnt["start_systems"]                  # + one preconditioner application per solve before the first iteration
             fams = {("k_fdm_fwd (split-bf16 MFMA eigen-transform + LDS-resident complex64 tridiagonal sweeps, one launch)" if fwd_fused else
@@ -414,11 +419,16 @@ def main():
                     ("k_back_post (split-bf16 MFMA back transform + both Jacobi halves of the post-smoother + dot products)" if back_fused else
                      "k_transform_lp<2> (split-bf16 MFMA back transform fused with the first Jacobi half)" if fwd_fused else
                      "k_transform_lp<0>,<2> (split-bf16 MFMA forward and back transforms: 16 U and 56 U)"):
-                        ("fdm_transform", (48.0 if back_fused else 56.0) if fwd_fused else 36.0, 1 if fwd_fused else 2, (it_sys + pre_sys) * (1 if fwd_fused else 2)),
+                        ("fdm_transform", ((48.0 + 8.0 * f2) if back_fused else 56.0) if fwd_fused else 36.0, 1 if fwd_fused else 2, (it_sys + pre_sys) * (1 if fwd_fused else 2)),
                     "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 40.0, 1, it_sys),
-                    "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 112.0, 1, it_sys)}
+                    "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 112.0 + 8.0 * f2, 1, it_sys)}
             if not back_fused:
                 fams["k_post (second Jacobi half: 5-point stencil + dot products)"] = ("post_smoother", 56.0, 1, it_sys + pre_sys)
+            elif n7:
+                # read z4 (8), r (16), dinv (16), write z (8); the other two-sweep kernels: k_update_fused<2> also writes the
+                # pre-smoothed iterate z2 (8), k_back_post<.,2> reads it (8) on top of dinv, r for its own sweep
+                fams["k_post2 (second post-sweep of the two-sweep smoother: 5-point stencil + dot products)"] = \
+                    ("post_smoother", 48.0, f2, (it_sys + pre_sys) * f2)
             roofs = []
             it_bytes = it_us = step_bytes = 0.0
             nev = max(cnt["evaluations"], 1)
@@ -437,17 +447,18 @@ def main():
                          "bytes_per_launch_all_systems_active": bpu * U, "active_systems_per_launch": act, "ms_timed": ms_c,
                          "population": population}
                 if cat in ("tridiagonal", "fdm_transform") and n_c:
-                    # the two MFMA kernels, for reference: three bf16 products (hi*hi, hi*lo, lo*hi) of a
-                    # [2*S*NZP real rows] x [NYP] x [K = NYP padded to 32] real matrix product
+                    # the two MFMA kernels, for reference: two bf16 products (input hi and lo parts x the bf16 eigenvectors) of
+                    # a [2*S*NZP real rows] x [NYP] x [K = NYP padded to 32] real matrix product
                     kpad = 32 * ((ctx.NYP + 31) // 32)
-                    flops = 3 * 2.0 * (2 * act * ctx.NZP) * ctx.NYP * kpad
+                    flops = 2 * 2.0 * (2 * act * ctx.NZP) * ctx.NYP * kpad
                     entry["mfma"] = {"flops_per_launch": flops, "achieved_tflops": flops / (avg_us * 1e-6) / 1e12,
                                      "peak_tflops_bf16_dense": 2500.0}
                 roofs.append(entry)
-            iteration = {"kernels": len(fams), "bytes": it_bytes, "us": it_us,
+            iteration = {"kernels": len(fams), "two_sweep_fraction": f2, "bytes": it_bytes, "us": it_us,
                          "achieved": it_bytes / (it_us * 1e-6) / 1e9 if it_us else 0.0, "unit": "GB/s",
                          "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS if it_us else 0.0,
-                         "note": "one preconditioned COCG iteration of the systems still active = %d launches; " % len(fams) +
+                         "note": "one preconditioned COCG iteration of the systems still active = %d launches%s; " % (
+                                     len(fams), " (two smoothing sweeps per side in %.0f %% of the sampled solves: 5 launches, else 4)" % (100 * f2) if n7 and back_fused else "") +
                                  ("the working set of a solve (~15 vectors = %.0f MB) fits the 256 MB Infinity Cache, so launches are "
                                   "latency- not HBM-bound" if ws_mb <= 256 else
                                   "the working set of a solve (~15 vectors = %.0f MB) is beyond the 256 MB Infinity Cache: HBM-bound") % ws_mb}
@@ -472,8 +483,9 @@ def main():
                                    f"(L = {LTRAJ}, dt = {DT}, prior lambda = {LAMBDA}, bounds rho in [1, 1e4] ohm-m, accept/reject) "
                                    f"started at the rough state m = ln 0.01 + 0.3 N(0,1)",
                        "systems_per_step": ctx.S, "unknowns_per_system": nyi * nzi, "nparam": nAC,
-                       "solver": "batched fp64 COCG, Jacobi/fast-diagonalisation/Jacobi preconditioner (FDM stage in split-bf16/fp32), tol 1e-11 (error estimate), warm start",
+                       "solver": "batched fp64 COCG, Jacobi/fast-diagonalisation/Jacobi preconditioner (FDM stage in bf16/fp32; one or two Jacobi sweeps per side, chosen per solve), tol 1e-11 (error estimate), warm start",
                        "iters_fwd_max": st["iters_fwd_max"], "iters_adj_max": st["iters_adj_max"],
+                       "smoother_sweeps_last_evaluation": st["smoother_sweeps"],
                        "parallelism": f"chains x{world}" if world > 1 else "1 chain"},
             "chain": head,
             "roofline": roofs[0], "roofline_other": roofs[1:], "roofline_iteration": iteration, "roofline_step": step,

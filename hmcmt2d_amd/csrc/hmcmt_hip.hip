@@ -95,6 +95,14 @@ struct hmcmt_ctx {
     View sideView; const double* sideM = nullptr;   // deferred side-stream launches of the adjoint half (launch_adjoint_side)
     bool sidePending = false, sideExtrap = false, sideSens = false;
     bool fusedBack = true;                   // back transform + post-smoother in one kernel (HMCMT_FUSED_BACK=0: separate)
+    cplx* d_sw = nullptr;                    // fp64 path with two sweeps per side: spare vector
+    int sweepsMode = 0;                      // HMCMT_SWEEPS: 1 / 2 damped Jacobi sweeps on each side of the FDM stage, 0 (default) = per solve
+    int sweepsKind[2] = {1, 1};              // ... what the forward / adjoint solve uses next (auto: from its last iteration count)
+    int sweepsUsed[2] = {1, 1};              // ... what the last evaluation's solves used
+    int sweepsCount2[2] = {0, 0}, sweepsSince[2] = {0, 0};   // ... iterations of the last two-sweep solve, solves since the last probe
+    bool sweepsProbe[2] = {false, false};    // ... the solve at hand is a one-sweep probe out of the two-sweep mode
+    int sweepsUp = 30, sweepsDown = 6;       // auto: one sweep -> two above sweepsUp iterations, two -> one below sweepsDown (12: the first,
+                                             // cheap steps of every clamped burn-in trajectory switched back and the next ones up again)
     long long* backStamps = nullptr;         // HMCMT_BACK_STAMPS: per-block s_memtime stamps of k_back_post (debug entry only)
     size_t maxLdsBack = 64 * 1024;
     bool twistOn = true;                     // HMCMT_TWIST=0: classic one-sided sweeps in the fused kernel as well
@@ -226,6 +234,20 @@ int launch_transform_lp(hmcmt_ctx* ctx, const float2* A, bool transposed, void* 
     return 0;
 }
 
+// the fused back transform + post-smoother is available for this problem (pre-split operands, 16-row tile in LDS)
+bool fused_back_ok(const hmcmt_ctx* ctx) {
+    const Solver& k = ctx->sv;
+    const size_t lds = (size_t)16 * k.NYP * sizeof(cplx) + (size_t)2 * ((k.NYP + 31) / 32) * 2 * 64 * 16;
+    return k.splitT && ctx->fusedBack && lds <= ctx->maxLdsBack && k.NYP <= 256;
+}
+size_t update2_lds(const Solver& k) { return (size_t)(3 * k.RT + 8) * k.NYP * sizeof(float2); }
+// two sweeps per side exist on the fused mixed-precision path (and on the fp64 path of the restarts)
+bool sweeps2_ok(const hmcmt_ctx* ctx) {
+    const Solver& k = ctx->sv;
+    return ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI &&
+           (ctx->opt.fdm_precision != 0 || (fused_back_ok(ctx) && k.NTR <= k.NB && update2_lds(k) <= (size_t)150 * 1024));
+}
+
 // forward half of the mixed-precision FDM stage: y32 = tridiag^-1 (t32 V); fused kernel when its LDS slabs fit
 // back half of the FDM stage + post-smoother: fused kernel on the pre-split path when its 16-row tile fits LDS
 int launch_back_post(hmcmt_ctx* ctx) {
@@ -235,8 +257,16 @@ int launch_back_post(hmcmt_ctx* ctx) {
     dim3 vg(k.NB, k.S), vb(VBLOCK);
     if (k.splitT && ctx->fusedBack && lds <= ctx->maxLdsBack && k.NYP <= 256) {      // the kernel holds all of a wave's V fragments: 8 k-groups, 2 tiles
         const int nwg = (k.nz - 1 + BP_OWN - 1) / BP_OWN;
+        if (k.sweeps == 2) {
+            { ProfScope ps(ctx, 0);
+              hipLaunchKernelGGL((k_back_post<1, 2>), dim3(nwg, k.S), dim3(64 * NW), lds, ctx->stream, k, k.y32, ctx->d_Vtb, ctx->d_Vtbl,
+                                 ctx->d_partZZ, NW, ctx->backStamps); }
+            ProfScope ps(ctx, 7);
+            hipLaunchKernelGGL(k_post2, dim3(k.NTR, k.S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(float2), ctx->stream, k, ctx->d_partZZ);
+            return 0;
+        }
         ProfScope ps(ctx, 0);
-        hipLaunchKernelGGL(k_back_post<1>, dim3(nwg, k.S), dim3(64 * NW), lds, ctx->stream, k, k.y32, ctx->d_Vtb, ctx->d_Vtbl,
+        hipLaunchKernelGGL((k_back_post<1, 1>), dim3(nwg, k.S), dim3(64 * NW), lds, ctx->stream, k, k.y32, ctx->d_Vtb, ctx->d_Vtbl,
                            ctx->d_partZZ, NW, ctx->backStamps);
         return 0;
     }
@@ -301,6 +331,10 @@ int apply_precond(hmcmt_ctx* ctx) {
     if (ctx->opt.fdm_precision == 0 && !ctx->lpFallback) {
         // mixed precision: split-bf16 operands / fp32 accumulation in the transforms, complex64 tridiagonal
         if (smooth && ctx->preDone) ctx->preDone = false;                        // (k_resid_pre has written t)
+        else if (smooth && k.sweeps == 2) {                                       // both pre-sweeps of the residual at hand
+            ProfScope ps(ctx, 3);
+            hipLaunchKernelGGL(k_update_fused<2>, dim3(k.NTR, k.S), vb, update2_lds(k), ctx->stream, k, k.p32a, k.r, k.r, 0, 1);
+        }
         else if (smooth) { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_pre_c64, vg, vb, 0, ctx->stream, k); }
         else { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_to_c64, vg, vb, 0, ctx->stream, k, k.r); }
         if ((rc = launch_fdm_fwd(ctx))) return rc;
@@ -312,6 +346,21 @@ int apply_precond(hmcmt_ctx* ctx) {
             ProfScope ps(ctx, 3);
             hipLaunchKernelGGL(k_dots, vg, vb, 0, ctx->stream, k, ctx->d_partZZ);
         }
+        return 0;
+    }
+    if (smooth && k.sweeps == 2) {                  // two sweeps per side, fp64 (fdm_precision = 1, and the restart of a stagnating solve)
+        if (!ctx->d_sw) { int rc2 = dalloc(ctx, &ctx->d_sw, (size_t)k.S * k.vstride); if (rc2) return rc2; }
+        hipLaunchKernelGGL(k_pre, vg, vb, 0, ctx->stream, k);                                        // t1 = r - A D r
+        hipLaunchKernelGGL(k_sweep_exp, vg, vb, 0, ctx->stream, k, k.t, ctx->d_sw, 0);               // z2 = D (r + t1)
+        hipLaunchKernelGGL(k_sweep_exp, vg, vb, 0, ctx->stream, k, ctx->d_sw, k.t, 1);               // t2 = r - A z2
+        if ((rc = launch_transform(ctx, k.t, ctx->d_V, k.y, k.active))) return rc;
+        hipLaunchKernelGGL(k_thomas, tg, dim3(64), 0, ctx->stream, k);
+        if ((rc = launch_transform(ctx, k.y, ctx->d_Vt, k.z, k.active))) return rc;
+        hipLaunchKernelGGL(k_sweep_exp, vg, vb, 0, ctx->stream, k, ctx->d_sw, k.z, 3);               // z3 = F t2 + z2
+        hipLaunchKernelGGL(k_sweep_exp, vg, vb, 0, ctx->stream, k, k.z, ctx->d_sw, 2);               // z4 = z3 + D (r - A z3)
+        Solver k2 = k; k2.z = ctx->d_sw;
+        hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k2, ctx->d_partZZ, (float2*)nullptr);     // t = z4 + D (r - A z4), dots
+        std::swap(k.z, k.t);
         return 0;
     }
     if (smooth) { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_pre, vg, vb, 0, ctx->stream, k); }
@@ -331,6 +380,18 @@ int apply_precond(hmcmt_ctx* ctx) {
 
 void launch_adjoint_side(hmcmt_ctx* ctx);
 int collect_pending(hmcmt_ctx* ctx);
+
+constexpr double SWEEPS2_COST = 1.28;       // time of a two-sweep iteration / time of a one-sweep iteration (5 launches, 64 us / 4 launches, 50 us)
+constexpr int SWEEPS_PROBE_EVERY = 40;      // in two-sweep mode: every so many solves of a kind one solve runs one sweep, to compare
+// damped Jacobi sweeps on each side of the FDM stage for the next solve of this kind.  Two sweeps cut the iterations by
+// 20 % (smooth models) to 35 % (high-contrast ones) and cost a fifth launch and ~30 % more time per iteration: by
+// default a solve kind switches to two when its last solve needed more than sweepsUp iterations, back to one below
+// sweepsDown, and -- since the gain depends on the model, not on the count -- tries one sweep once every
+// SWEEPS_PROBE_EVERY solves and keeps whichever is cheaper (parse_stats).
+int pick_sweeps(const hmcmt_ctx* ctx, int kind) {
+    if (ctx->sweepsMode == 1 || !sweeps2_ok(ctx)) return 1;
+    return ctx->sweepsMode == 2 ? 2 : ctx->sweepsKind[kind];
+}
 
 // Solves A x = r for all systems (x zero on interior on entry; r destroyed).  kind 0 forward, 1 adjoint.
 int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
@@ -382,7 +443,8 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             ++it;
             // decide convergence of the state after iteration it-1, p = z + beta p, q = A p
             { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv_fused, dim3(k.NTR, S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit); }
-            { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused, dim3(k.NTR, S), vb, (size_t)(2 * k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it); }
+            if (k.sweeps == 2) { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused<2>, dim3(k.NTR, S), vb, update2_lds(k), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it, 0); }
+            else { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused<1>, dim3(k.NTR, S), vb, (size_t)(2 * k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it, 0); }
             rcur ^= 1;
             k.r = rb[rcur];
             int prc;
@@ -443,6 +505,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     // the fused loop ping-pongs r between the caller's buffer and r2: leave the struct as it was found
     if (k.r != r_entry) { k.r2 = k.r; k.r = r_entry; }
     guess = it;        // (launched iterations; collect_stats replaces it with the iterations actually needed)
+
     ctx->solveDone[kind] = done;
     // iteration counts / status / error estimates stay on the device; evaluate() reads both solves back at once
     hipLaunchKernelGGL(k_solve_end, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, k, kind, (int*)ctx->d_recHost, ctx->d_recHost + 2 * S);
@@ -513,8 +576,13 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     const bool extrap = ctx->opt.warm_start == 2 && !ctx->opt.verify;
     // start of a solve on the default path: residual and first pre-smoothing pass in one launch (k_resid_pre)
     const size_t startLds = (size_t)(2 * ctx->sv.RT + 6) * v.NYP * sizeof(cplx);
-    const bool fusedStart = ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0 && !ctx->opt.verify &&
-                            startLds <= (size_t)150 * 1024 && !getenv("HMCMT_NO_FUSED_START");
+    const bool fusedStartOk = ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0 && !ctx->opt.verify &&
+                              startLds <= (size_t)150 * 1024 && !getenv("HMCMT_NO_FUSED_START");
+    const int sweepsF = pick_sweeps(ctx, 0), sweepsA = pick_sweeps(ctx, 1);
+    bool fusedStart = fusedStartOk && sweepsF == 1;      // (k_resid_pre does ONE pre-sweep; two go through k_resid0 + the solve's own start)
+    ctx->sv.sweeps = sweepsF;
+    ctx->stats.smoother_sweeps = 10 * sweepsF + (wantGrad ? sweepsA : 0);
+    ctx->sweepsUsed[0] = sweepsF; if (wantGrad) ctx->sweepsUsed[1] = sweepsA;
     {
         ProfScope ps(ctx, 4);
         hipLaunchKernelGGL(k_sigma, grid1(v.nCell, 256), dim3(256), 0, st, v);
@@ -547,8 +615,10 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         }
         HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->evModel, 0));
         hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, ctx->side2, v, 0, 1, 1, 0);
-        if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI)
+        if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI) {
             hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side2, ctx->sv, ctx->jacobiW);
+            hipLaunchKernelGGL(k_coef32, dim3(ctx->sv.NB, 2), dim3(VBLOCK), 0, ctx->side2, ctx->sv, const_cast<float4*>(ctx->sv.cf32));
+        }
         HIPCHK(hipEventRecord(ctx->evCoef, ctx->side2));
         hipLaunchKernelGGL(k_rowmean, dim3(v.nz), dim3(64), 0, ctx->side2, v);
         if (pivots)
@@ -576,6 +646,8 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     }
     int rc = solve(ctx, v.X, 0);
     if (fusedStart) std::swap(ctx->sv.r, ctx->sv.r2);
+    fusedStart = fusedStartOk && sweepsA == 1;
+    ctx->sv.sweeps = sweepsA;
     if (!wantGrad) HIPCHK(hipEventRecord(ctx->evRec, st));          // behind the last k_solve_end
     launch_adjoint_side(ctx);            // (no-op when the solve has already done it)
     ctx->haveFwd = (rc == 0 && ctx->solveDone[0]);
@@ -638,6 +710,22 @@ void parse_stats(hmcmt_ctx* ctx, bool withAdjoint) {
         // first convergence poll of the next evaluation: where this one actually finished (the loop itself only
         // knows how many iterations it launched, which includes the empty ones behind the last poll)
         if (ctx->solveDone[kind] && mx > 0) (kind == 0 ? ctx->lastItFwd : ctx->lastItAdj) = mx;
+        // ... and the smoother of the next solve of this kind (pick_sweeps): two sweeps per side when this one was long
+        if (ctx->sweepsMode == 0 && ctx->solveDone[kind] && mx > 0) {
+            int& next = ctx->sweepsKind[kind];
+            if (ctx->sweepsUsed[kind] == 1) {
+                if (ctx->sweepsProbe[kind]) {                 // a probe with one sweep: keep it if it is the cheaper one
+                    ctx->sweepsProbe[kind] = false;
+                    next = (double)mx <= SWEEPS2_COST * ctx->sweepsCount2[kind] ? 1 : 2;
+                } else if (mx > ctx->sweepsUp) next = 2;
+            } else {
+                ctx->sweepsCount2[kind] = mx;
+                if (mx < ctx->sweepsDown) next = 1;
+                else if (++ctx->sweepsSince[kind] >= SWEEPS_PROBE_EVERY && mx < ctx->sweepsUp) {
+                    ctx->sweepsSince[kind] = 0; ctx->sweepsProbe[kind] = true; next = 1;
+                }
+            }
+        }
         if (!ctx->solveDone[kind] && ctx->stats.status == 0) ctx->stats.status = HMCMT_ENOCONV;
     }
     if (ctx->stats.status != 0) {
@@ -748,10 +836,13 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         if (const char* et = getenv("HMCMT_TWIST")) ctx->twistOn = et[0] != '0';
         if (const char* eb = getenv("HMCMT_FUSED_BACK")) ctx->fusedBack = eb[0] != '0';
         // (this kernel also has a few hundred bytes of static LDS: ask for less than the full 160 KB)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_back_post<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) == hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_back_post<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) == hipSuccess)
             ctx->maxLdsBack = 152 * 1024;
         else (void)hipGetLastError();
         if (const char* ew = getenv("HMCMT_JACOBI_W")) ctx->jacobiW = std::min(1.2, std::max(0.1, atof(ew)));
+        if (const char* es = getenv("HMCMT_SWEEPS")) ctx->sweepsMode = std::max(0, std::min(2, atoi(es)));     // 0 / "auto": per solve
+        if (const char* es = getenv("HMCMT_SWEEPS_UP")) ctx->sweepsUp = std::max(1, atoi(es));
+        if (const char* es = getenv("HMCMT_SWEEPS_DOWN")) ctx->sweepsDown = std::max(0, atoi(es));
         if (const char* ep = getenv("HMCMT_EXTRAP_POINTS")) ctx->extrapNp = std::max(2, std::min(EXT_NP, atoi(ep)));
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<FW_NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
@@ -763,7 +854,10 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
                               reinterpret_cast<const void*>(k_transform_lp<2, 0>), reinterpret_cast<const void*>(k_transform_lp<2, 1>)})
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
         // the stencil kernels' tiles can pass 64 KB on wide meshes
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_fused<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_fused<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_post2), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_back_post<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_resid_pre), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
     }
@@ -857,11 +951,13 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         k.RT = std::max(e ? atoi(e) : want, (h.nz - 1 + MAXNB - 1) / MAXNB);
     }
     k.NTR = (h.nz - 1 + k.RT - 1) / k.RT;
+    k.sweeps = 1;
     k.omega = v.omega; k.cY = v.cY; k.cZ = v.cZ; k.dK = v.dK; k.dM = v.dM; k.ofz = v.ofz; k.invp = v.invp;
+    { float4* cf = nullptr; if ((rc = dalloc(ctx, &cf, 2 * 2 * VS))) return rc; k.cf32 = cf; }
     k.r = v.R;
     DA(k.p, S * VS) DA(k.q, S * VS) DA(k.z, S * VS) DA(k.y, S * VS) DA(k.t, S * VS) DA(k.dinv, S * VS)
     DA(k.t32, S * VS + 64) DA(k.y32, S * VS + 64) DA(ctx->d_invp32, S * VS)
-    DA(k.z32, S * VS) DA(k.p32a, S * VS) DA(k.p32b, S * VS)
+    DA(k.z32, S * VS) DA(k.p32a, S * VS) DA(k.p32b, S * VS) DA(k.zs32, S * VS) DA(k.z4_32, S * VS)
     DA(k.p2, S * VS) DA(k.r2, S * VS) DA(k.partPQ, S * MAXNB) DA(k.rho2, 2 * S)
     k.invp32 = ctx->d_invp32;
     DA(k.partA, S * MAXNB) DA(k.partB, S * MAXNB) DA(ctx->d_partZZ, S * MAXNB)

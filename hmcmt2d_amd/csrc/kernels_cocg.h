@@ -11,6 +11,8 @@ struct Solver {
     long vstride, chunk;
     const double* omega;
     const double *cY, *cZ, *dK, *dM;      // [2][vstride]
+    const float4* cf32;                   // [2][vstride][2] the same six stencil coefficients of a node as floats: {dK, dM, cY[e], cY[e-1]}, {cZ[e], cZ[e-NYP], 0, 0}
+                                          // (two 16-byte loads instead of six 8-byte ones, for the preconditioner's own stencils; interior nodes, else 0)
     const double* ofz;                    // [2][NZP]
     const cplx* invp;                     // [S][vstride]
     cplx *x, *r, *p, *q, *z, *y, *t;      // [S][vstride]
@@ -22,6 +24,9 @@ struct Solver {
     float2* y32;                          // [S][vstride] complex64
     const float2* invp32;                 // [S][vstride]
     cplx *p2, *r2;                        // second buffers of p and r for the fused kernels
+    float2 *zs32, *z4_32;                 // two smoothing sweeps per side (sweeps == 2): the pre-smoothed iterate z2 and the iterate
+                                          // after the first post-sweep z4, complex64 (k_update_fused<2> -> k_back_post<.,2> -> k_post2)
+    int sweeps;                           // damped Jacobi sweeps on each side of the FDM stage in the solve at hand (1 or 2)
     float2 *z32, *p32a, *p32b;            // fused path: preconditioned residual and the two search-direction buffers as complex64
                                           // (x, r, q and every inner product stay fp64; see k_spmv_fused)
     int RT, NTR;                          // rows per tile / row tiles per system of the fused kernels (NTR <= MAXNB)

@@ -257,6 +257,22 @@ __device__ __forceinline__ cplx stencil_at(const Solver& k, const cplx* u, long 
     return acc;
 }
 
+// float copies of the stencil coefficients, packed per node (Solver::cf32); grid (NB, 2 modes)
+__global__ __launch_bounds__(VBLOCK) void k_coef32(Solver k, float4* __restrict__ out) {
+    const int mode = blockIdx.y;
+    const long mo = (long)mode * k.vstride;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        float4 a = float4{0.f, 0.f, 0.f, 0.f}, b = a;
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+            a = float4{(float)k.dK[mo + e], (float)k.dM[mo + e], (float)k.cY[mo + e], (float)k.cY[mo + e - 1]};
+            b = float4{(float)k.cZ[mo + e], (float)k.cZ[mo + e - k.NYP], 0.f, 0.f};
+        }
+        out[2 * (mo + e)] = a; out[2 * (mo + e) + 1] = b;
+    }
+}
+
 __global__ __launch_bounds__(VBLOCK) void k_dinv(Solver k, double wJ) {
     const int s = blockIdx.y;
     const int mode = s >= k.nFreq;
@@ -295,6 +311,33 @@ __global__ __launch_bounds__(VBLOCK) void k_pre(Solver k) {
             out = r[e] - acc;
         }
         t[e] = out;
+    }
+}
+
+// ---- EXPERIMENT (HMCMT_SWEEPS=2, fp64 classic path only): two damped Jacobi sweeps on each side of the FDM stage
+// mode 0: out = dinv .* (r + a)            (second pre-sweep from the first one's residual a = r - A dinv r)
+// mode 1: out = r - A a                    (residual of the pre-smoothed iterate)
+// mode 2: out = a + dinv .* (r - A a)      (one post-sweep)
+// mode 3: out += a
+__global__ __launch_bounds__(VBLOCK) void k_sweep_exp(Solver k, const cplx* ain, cplx* outv, int mode) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    const int md = s >= k.nFreq;
+    const long mo = (long)md * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx *r = k.r + so, *di = k.dinv + so, *a = ain + so;
+    cplx* o = outv + so;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        cplx out = cplx{0, 0};
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+            if (mode == 0) out = di[e] * (r[e] + a[e]);
+            else if (mode == 1) out = r[e] - stencil_at(k, a, mo, e, w);
+            else if (mode == 2) out = a[e] + di[e] * (r[e] - stencil_at(k, a, mo, e, w));
+            else out = o[e] + a[e];
+        }
+        o[e] = out;
     }
 }
 
@@ -857,7 +900,10 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
 // ----------------------------------------------------------------------------------------------
 constexpr int BP_OWN = 14;         // interior rows owned by a workgroup (tile = BP_OWN + 2 = two 8-row MFMA groups)
 
-template <int FMT>
+// SW = 2 (two sweeps per side): the first term added to the FDM correction is the pre-smoothed iterate z2 that
+// k_update_fused<2> stored (instead of dinv .* r), and the result -- the iterate after the FIRST post-sweep -- goes to
+// z4_32; k_post2 does the second post-sweep and the dot products.
+template <int FMT, int SW = 1>
 __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __restrict__ Y, const u4v* __restrict__ Bhi,
                                                    const u4v* __restrict__ Blo, double* partZZ, int NW, long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
@@ -874,7 +920,8 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
     const double w = k.omega[s];
     const cplx *r = k.r + so, *di = k.dinv + so;
-    float2* t = k.z32 + so;            // the preconditioned residual leaves as complex64 (the FDM stage is fp32-class anyway)
+    float2* t = (SW == 2 ? k.z4_32 : k.z32) + so;   // the preconditioned residual leaves as complex64 (the FDM stage is fp32-class anyway)
+    const float2* z2i = k.zs32 + so;
     const int nown = (iz1 - iz0 + 1) * NYP;
     // Every phase below is a short dependent chain (global load -> LDS -> barrier -> MFMA -> LDS -> barrier -> stencil),
     // so loads are issued as early as their addresses are known and unconditionally (clamped indices): inside
@@ -908,6 +955,7 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
         constexpr int KC = 8;
         // epilogue operands dinv, r of the wave's 2 x 2 x 2 accumulator elements per lane
         cplx dv[2][2][2], rv[2][2][2];
+        float2 zq[2][2][2];
         auto ld_dr = [&]() {
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg)
@@ -919,7 +967,8 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const long ub = (long)ru * NYP + min(t0 + t, NT - 1) * 16;
-                        dv[rg][t][h2] = (di + ub)[lo]; rv[rg][t][h2] = (r + ub)[lo];
+                        if (SW == 2) zq[rg][t][h2] = (z2i + ub)[lo];
+                        else { dv[rg][t][h2] = (di + ub)[lo]; rv[rg][t][h2] = (r + ub)[lo]; }
                     }
                 }
         };
@@ -1016,7 +1065,9 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
 #pragma unroll
                     for (int h2 = 0; h2 < 2; ++h2) {
                         const int lr = 8 * rg + 2 * g + h2;
-                        cplx val = cplx{(double)acc[rg][t][2 * h2], (double)acc[rg][t][2 * h2 + 1]} + dv[rg][t][h2] * rv[rg][t][h2];
+                        cplx val = cplx{(double)acc[rg][t][2 * h2], (double)acc[rg][t][2 * h2 + 1]};
+                        if (SW == 2) val += cplx{(double)zq[rg][t][h2].x, (double)zq[rg][t][h2].y};
+                        else val += dv[rg][t][h2] * rv[rg][t][h2];
                         if (rbase + lr >= NZP) val = cplx{0.0, 0.0};
                         zt[(long)lr * NYP + col] = val;
                     }
@@ -1068,6 +1119,72 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
             partZZ[(long)s * MAXNB + b] = 0.0;
         }
     BP_STAMP(6)
+}
+
+// ----------------------------------------------------------------------------------------------
+// Second post-sweep of the two-sweep smoother (k.sweeps == 2):  z = z4 + dinv .* (r - A z4)  on tiles of RT rows
+// with one halo row of z4 staged in LDS, the result stored as complex64 where k_spmv_fused reads it, and the
+// partial sums r'z, |z|^2 of the stored values (those k_back_post<., 1> produces on the one-sweep path).
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(VBLOCK) void k_post2(Solver k, double* partZZ) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    extern __shared__ __attribute__((aligned(16))) char smem_p2[];
+    c32* zs = reinterpret_cast<c32*>(smem_p2);            // [(RT+2)][NYP]
+    __shared__ double sh[8];
+    __shared__ double sh2[8];
+    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);
+    const int nrows = iz1 - iz0 + 3;
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const float wf = (float)k.omega[s];
+    const float2* z4 = k.z4_32 + so;
+    const cplx *r = k.r + so, *di = k.dinv + so;
+    float2* zo = k.z32 + so;
+    for (int i = threadIdx.x; i < nrows * NYP; i += VBLOCK) {
+        const float2 v = z4[(long)(iz0 - 1) * NYP + i];      // (rows 0 and nz of z4 are zero: k_back_post keeps them so)
+        zs[i] = c32{v.x, v.y};
+    }
+    __syncthreads();
+    double ar = 0, ai = 0, zz = 0, dummy = 0;
+    const int nown = (iz1 - iz0 + 1) * NYP;
+    for (int i = threadIdx.x; i < nown; i += VBLOCK) {
+        const int lr = i / NYP, iy = i - lr * NYP;
+        const long e = (long)(iz0 + lr) * NYP + iy;
+        const int l = i + NYP;
+        float2 of = float2{0.f, 0.f};
+        if (iy >= 1 && iy <= k.ny - 1) {
+            const float4 ca = k.cf32[2 * (mo + e)], cb = k.cf32[2 * (mo + e) + 1];
+            const c32 cc = zs[l];
+            const float dm = wf * ca.y;
+            const c32 af = c32{ca.x * cc.re - dm * cc.im + ca.z * zs[l + 1].re + ca.w * zs[l - 1].re + cb.x * zs[l + NYP].re + cb.y * zs[l - NYP].re,
+                               ca.x * cc.im + dm * cc.re + ca.z * zs[l + 1].im + ca.w * zs[l - 1].im + cb.x * zs[l + NYP].im + cb.y * zs[l - NYP].im};
+            const cplx c = cplx{(double)cc.re, (double)cc.im}, acc = cplx{(double)af.re, (double)af.im};
+            const cplx rv = r[e];
+            const cplx out = c + di[e] * (rv - acc);
+            of = float2{(float)out.re, (float)out.im};
+            const cplx o = cplx{(double)of.x, (double)of.y};     // the sums are those of the value that is stored
+            ar += rv.re * o.re - rv.im * o.im;
+            ai += rv.re * o.im + rv.im * o.re;
+            zz += cabs2(o);
+        }
+        zo[e] = of;
+    }
+    // the two boundary rows of z stay zero (k_spmv_fused reads them as halo rows)
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < NYP; i += VBLOCK) zo[i] = float2{0.f, 0.f};
+    if (iz1 == k.nz - 1) for (int i = threadIdx.x; i < NYP; i += VBLOCK) zo[(long)k.nz * NYP + i] = float2{0.f, 0.f};
+    block_sum2(ar, ai, sh);
+    block_sum2(zz, dummy, sh2);
+    if (threadIdx.x == 0) {
+        k.partA[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
+        partZZ[(long)s * MAXNB + blockIdx.x] = zz;
+    }
+    // the consumers add up k.NB partial sums per system: clear the slots this launch does not use
+    if (blockIdx.x == 0)
+        for (int b = gridDim.x + threadIdx.x; b < k.NB; b += VBLOCK) {
+            k.partA[(long)s * MAXNB + b] = cplx{0, 0};
+            partZZ[(long)s * MAXNB + b] = 0.0;
+        }
 }
 
 // pre-split planes -> complex64 (hi + lo), tests only

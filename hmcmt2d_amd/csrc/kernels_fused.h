@@ -149,12 +149,101 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
     if (threadIdx.x == 0) k.partPQ[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
 }
 
-__global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2* pcur, const cplx* rin, cplx* rout, int it) {
+// SW = 2 (two damped Jacobi sweeps on each side of the FDM stage, k.sweeps == 2): the pre-smoother becomes
+//   z1 = D r', t1 = r' - A z1, z2 = z1 + D t1 (= D (r' + t1)), t = r' - A z2      (D = dinv)
+// on the tile's rows, with r' and z1 recomputed on TWO halo rows on each side and z2 on one; z2 is also written out
+// (complex64): the back transform adds it to the FDM correction (k_back_post<., 2>).  The tile's intermediate
+// values live in LDS as complex64 -- they are internals of the preconditioner, whose output t goes to 16-bit planes
+// anyway -- so the three arrays of (RT + 4), (RT + 2), (RT + 2) rows fit where the two fp64 arrays of SW = 1 do.
+// startOnly (SW = 2): the pre-smoothing of the residual of a solve's first preconditioner application -- alpha = 0,
+// x and r stay untouched (k_resid_pre does this for one sweep).
+template <int SW>
+__global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2* pcur, const cplx* rin, cplx* rout, int it, int startOnly = 0) {
     const int s = blockIdx.y;
     if (!k.active[s]) return;
     extern __shared__ __attribute__((aligned(16))) char smem_[];
     const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);
     const int nrows = iz1 - iz0 + 3;
+    if constexpr (SW == 2) {
+        c32* z1s = reinterpret_cast<c32*>(smem_);             // [(RT+4)][NYP]  z1 = dinv .* r'   rows iz0-2 .. iz1+2
+        c32* rs = z1s + (long)(k.RT + 4) * NYP;               // [(RT+2)][NYP]  r'                rows iz0-1 .. iz1+1
+        c32* z2s = rs + (long)(k.RT + 2) * NYP;               // [(RT+2)][NYP]  z2                rows iz0-1 .. iz1+1
+        __shared__ double sh2[8];
+        cplx al = cplx{0, 0};
+        if (!startOnly) {
+            const cplx pq = total_part(k.partPQ + (long)s * MAXNB, k.NTR);
+            al = k.rho2[(long)(it & 1) * k.S + s] / pq;
+        }
+        const int mode = s >= k.nFreq;
+        const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+        const float w = (float)k.omega[s];
+        const float2* p = pcur + so;
+        const cplx *q = k.q + so, *ri = rin + so, *di = k.dinv + so;
+        cplx *x = k.x + so, *ro = rout + so;
+        float2 *t = k.t32 + so, *z2o = k.zs32 + so;
+        double xx = 0, dummy = 0;
+        // phase A: r' and z1 on rows iz0-2 .. iz1+2 (rows outside the mesh: zero)
+        for (int i = threadIdx.x; i < (nrows + 2) * NYP; i += VBLOCK) {
+            const int lr = i / NYP, iy = i - lr * NYP, row = iz0 - 2 + lr;
+            cplx rn = cplx{0, 0}, z1 = cplx{0, 0};
+            const long e = (long)row * NYP + iy;
+            if (row >= 0 && row <= k.nz) {
+                rn = startOnly ? ri[e] : ri[e] - al * q[e];
+                z1 = di[e] * rn;
+            }
+            z1s[i] = c32{(float)z1.re, (float)z1.im};
+            if (lr >= 1 && lr <= nrows) rs[i - NYP] = c32{(float)rn.re, (float)rn.im};
+            if (!startOnly && lr >= 2 && lr <= nrows - 1) {
+                ro[e] = rn;
+                const float2 pf = p[e];
+                const cplx xv = x[e] + al * cplx{(double)pf.x, (double)pf.y};
+                x[e] = xv;
+                xx += cabs2(xv);
+            }
+        }
+        __syncthreads();
+        auto sten = [&](const c32* u, int l, long e) -> c32 {       // (A u)(e), u a tile array with the same row pitch
+            const float4 ca = k.cf32[2 * (mo + e)], cb = k.cf32[2 * (mo + e) + 1];
+            const c32 c = u[l];
+            const float dm = w * ca.y;
+            return c32{ca.x * c.re - dm * c.im + ca.z * u[l + 1].re + ca.w * u[l - 1].re + cb.x * u[l + NYP].re + cb.y * u[l - NYP].re,
+                       ca.x * c.im + dm * c.re + ca.z * u[l + 1].im + ca.w * u[l - 1].im + cb.x * u[l + NYP].im + cb.y * u[l - NYP].im};
+        };
+        // phase B: z2 = z1 + D (r' - A z1) on rows iz0-1 .. iz1+1
+        for (int i = threadIdx.x; i < nrows * NYP; i += VBLOCK) {
+            const int lr = i / NYP, iy = i - lr * NYP, row = iz0 - 1 + lr;
+            c32 z2 = c32{0.f, 0.f};
+            if (row >= 1 && row <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+                const long e = (long)row * NYP + iy;
+                const int l = i + NYP;                                 // the same node in z1s
+                const c32 t1 = rs[i] - sten(z1s, l, e);
+                const cplx d = di[e];
+                const c32 df = c32{(float)d.re, (float)d.im};
+                const c32 dt = df * t1;
+                z2 = c32{z1s[l].re + dt.re, z1s[l].im + dt.im};
+            }
+            z2s[i] = z2;
+        }
+        __syncthreads();
+        // phase C: t = r' - A z2 on the own rows; z2 of the own rows goes out too
+        const int nown = (iz1 - iz0 + 1) * NYP;
+        for (int i = threadIdx.x; i < nown; i += VBLOCK) {
+            const int lr = i / NYP, iy = i - lr * NYP;
+            const long e = (long)(iz0 + lr) * NYP + iy;
+            const int l = i + NYP;                                     // the same node in rs / z2s
+            c32 out = c32{0.f, 0.f};
+            if (iy >= 1 && iy <= k.ny - 1) out = rs[l] - sten(z2s, l, e);
+            store_t32(k, t, iz0 + lr, iy, out.re, out.im);
+            z2o[e] = float2{z2s[l].re, z2s[l].im};
+        }
+        if (startOnly) return;
+        block_sum2(xx, dummy, sh2);
+        if (threadIdx.x == 0) {
+            k.partB[(long)s * MAXNB + blockIdx.x] = xx;
+            if (blockIdx.x == 0) k.alphaBeta[s] = al;
+        }
+        return;
+    }
     cplx* cs = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]  dinv .* r'
     cplx* rs = cs + (long)(k.RT + 2) * NYP;               // [RT][NYP]      r' of the own rows
     __shared__ double sh[8];

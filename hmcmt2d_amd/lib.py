@@ -48,7 +48,7 @@ class Stats(C.Structure):
     _fields_ = [("iters_fwd_max", C.c_int32), ("iters_adj_max", C.c_int32),
                 ("iters_fwd_sum", C.c_int32), ("iters_adj_sum", C.c_int32),
                 ("err_est_max", C.c_double), ("true_res_max", C.c_double),
-                ("status", C.c_int32), ("nsystems", C.c_int32), ("fallback_solves", C.c_int32), ("reserved_", C.c_int32)]
+                ("status", C.c_int32), ("nsystems", C.c_int32), ("fallback_solves", C.c_int32), ("smoother_sweeps", C.c_int32)]
 
 
 def build_library(force=False, verbose=False):

@@ -75,7 +75,9 @@ typedef struct hmcmt_stats {
     int32_t nsystems;                       /* 2*nFreq */
     int32_t fallback_solves;                /* solves of the last call (0..2) whose stragglers were restarted with the fp64
                                                preconditioner after 60 mixed-precision iterations */
-    int32_t reserved_;                      /* keeps sizeof a multiple of 8 on every ABI */
+    int32_t smoother_sweeps;                /* damped Jacobi sweeps on each side of the FDM stage in the last call: 10 * (forward
+                                               solve) + (adjoint solve), e.g. 11 or 22; chosen per solve unless HMCMT_SWEEPS is
+                                               set (was `reserved_`: same offset, same size) */
 } hmcmt_stats;
 
 void hmcmt_default_options(hmcmt_options* opts);

@@ -51,7 +51,7 @@ struct HmcmtStats
     status::Int32
     nsystems::Int32
     fallback_solves::Int32
-    reserved_::Int32
+    smoother_sweeps::Int32
 end
 
 mutable struct HipContext

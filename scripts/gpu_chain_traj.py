@@ -12,7 +12,7 @@ m_true = np.log(sig_true[inv0.activeIdx])
 pred_true, _ = ctx0.forward(m_true); ctx0.close()
 obs, err = S.noisy_observations(pred_true)
 inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, obs, err)
-ctx = HipContext(mesh, data, inv, warm_start=os.environ.get("WS", "extrapolate"))
+ctx = HipContext(mesh, data, inv, warm_start=os.environ.get("WS", "extrapolate"), fdm_precision=os.environ.get("FDMP", "mixed"))
 dev = torch.device("cuda", 0)
 n = ctx.nAC
 start = {"true": m_true, "rough": S.rough_state(n), "homog": np.full(n, np.log(0.01))}[state]

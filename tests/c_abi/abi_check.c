@@ -29,7 +29,7 @@ static int print_layout(void) {
     printf("sizeof hmcmt_stats %zu\n", sizeof(hmcmt_stats));
     FIELD(hmcmt_stats, iters_fwd_max); FIELD(hmcmt_stats, iters_adj_max); FIELD(hmcmt_stats, iters_fwd_sum);
     FIELD(hmcmt_stats, iters_adj_sum); FIELD(hmcmt_stats, err_est_max); FIELD(hmcmt_stats, true_res_max);
-    FIELD(hmcmt_stats, status); FIELD(hmcmt_stats, nsystems); FIELD(hmcmt_stats, fallback_solves);
+    FIELD(hmcmt_stats, status); FIELD(hmcmt_stats, nsystems); FIELD(hmcmt_stats, fallback_solves); FIELD(hmcmt_stats, smoother_sweeps);
     printf("const HMCMT_NCAT %d\n", HMCMT_NCAT);
     printf("const HMCMT_ENOCONV %d\n", HMCMT_ENOCONV);
     printf("const HMCMT_EBREAKDOWN %d\n", HMCMT_EBREAKDOWN);

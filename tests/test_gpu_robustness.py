@@ -124,8 +124,11 @@ def test_device_trajectory_with_the_step_clamp_active():
         m_or, p_or = O.proposeLeapfrog(m.copy(), p0.copy(), np.ones(len(m)), mesh_o, data, copy.deepcopy(inv), prior, 3, False)
         # the clamp was active: the first position step moved the model by exactly maxStepSize in its largest component
         assert np.abs(m_dev - m).max() > 3.0 or bounds[1] < 10
-        # measured: device vs host loop 1e-11 (m), 9e-11 (p); vs the oracle 1e-9 (m), 5e-9 (p)
-        assert relmax(m_dev, m_host) < 1e-10 and relmax(p_dev, p_host) < 1e-9
+        # measured: device vs host loop 1e-11 (m), 9e-11 (p) with the same smoother in both runs; the second run on this
+        # context may start with two sweeps per side where the first started with one (the choice follows the last
+        # iteration counts, and these clamped models are rough): 4e-10, the level of the solver tolerance;
+        # vs the oracle 1e-9 (m), 5e-9 (p)
+        assert relmax(m_dev, m_host) < 1e-9 and relmax(p_dev, p_host) < 5e-9
         assert relmax(m_dev, m_or) < 1e-8 and relmax(p_dev, p_or) < 5e-8
         lo, hi = np.log(bounds[0]), np.log(bounds[1])
         assert m_dev.min() >= lo and m_dev.max() <= hi

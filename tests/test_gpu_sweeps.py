@@ -1,0 +1,116 @@
+"""Two damped Jacobi sweeps on each side of the FDM stage (k_update_fused<2>, k_back_post<.,2>, k_post2):
+same answers as one sweep and as the oracle, fewer iterations on high-contrast models, a preconditioner that is still
+linear and complex symmetric, and the per-solve choice between one and two sweeps."""
+import numpy as np
+import pytest
+
+from hmcmt2d_amd.lib import HipContext
+from tests.helpers import make_problem, oracle_eval, relmax, gerr_split
+
+pytestmark = pytest.mark.gpu
+LO, HI = np.log(1e-4), np.log(1.0)
+
+
+def _rough(n, std, seed=2):
+    return np.clip(np.log(0.01) + std * np.random.default_rng(seed).standard_normal(n), LO, HI)
+
+
+def test_two_sweeps_give_the_one_sweep_answers_in_fewer_iterations(monkeypatch):
+    """cfg2, ln(sigma) ~ N(ln 0.01, 1.0) clipped to the sampler's bounds (the regime of clamped burn-in trajectories): the
+    forced two-sweep path agrees with the oracle and with the one-sweep path at the levels of the robustness tests and
+    needs clearly fewer iterations (measured: 0.73 of the forward, 0.78 of the adjoint ones); hmcmt_stats.smoother_sweeps reports what ran."""
+    mesh, data, inv, m = make_problem("cfg2")
+    mm = _rough(m.size, 1.0)
+    res = {}
+    for sw in (1, 2):
+        monkeypatch.setenv("HMCMT_SWEEPS", str(sw))
+        ctx = HipContext(mesh, data, inv, verify=True)
+        res[sw] = ctx.grad(mm) + (ctx.stats(),)
+        ctx.close()
+    (p1, f1, g1, s1), (p2, f2, g2, s2) = res[1], res[2]
+    assert s1["smoother_sweeps"] == 11 and s2["smoother_sweeps"] == 22
+    assert s1["status"] == 0 and s2["status"] == 0 and s2["true_res_max"] < 1e-9 and s2["fallback_solves"] == 0
+    po, mo, go = oracle_eval(mesh, data, inv, mm)
+    assert relmax(p2, po) < 1e-8 and abs(f2 - mo) / mo < 1e-8 and relmax(p2, p1) < 1e-8
+    noise = (0.0, 0.0)                                    # the reference formula's own rounding noise on a model this rough
+    for eps in (1e-14, -1e-14, 1e-13):
+        _, _, gn = oracle_eval(mesh, data, inv, mm * (1 + eps))
+        noise = tuple(max(a, b) for a, b in zip(noise, gerr_split(gn, go, inv, mesh)))
+    shallow, deep = gerr_split(g2, go, inv, mesh)
+    assert shallow < 1e-8 + 10 * noise[0] and deep < 5e-7 + 10 * noise[1], (shallow, deep, noise)
+    assert s2["iters_fwd_sum"] <= 0.85 * s1["iters_fwd_sum"] and s2["iters_adj_sum"] <= 0.85 * s1["iters_adj_sum"], (s1, s2)
+    assert s2["iters_fwd_max"] <= 0.8 * s1["iters_fwd_max"] and s2["iters_adj_max"] <= 0.8 * s1["iters_adj_max"], (s1, s2)
+
+
+def test_two_sweep_preconditioner_is_linear_symmetric_and_close_to_its_fp64_form(monkeypatch):
+    """What COCG needs of the preconditioner holds for the two-sweep one as well (x'My = y'Mx unconjugated, linearity),
+    to the accuracy of its mixed-precision stages; and it is the operator the fp64 path applies (k_sweep_exp around the
+    fp64 transforms) to per-cent accuracy."""
+    monkeypatch.setenv("HMCMT_SWEEPS", "2")
+    mesh, data, inv, m = make_problem("cfg3")
+    ctx = HipContext(mesh, data, inv)
+    ctx.forward(m)
+    assert ctx.stats()["smoother_sweeps"] == 20
+    shape = (ctx.S, ctx.NZP, ctx.NYP)
+    rng = np.random.default_rng(1)
+
+    def rand():
+        v = np.zeros(shape, complex)
+        v[:, 1:ctx.nz, 1:ctx.ny] = rng.standard_normal((ctx.S, ctx.nz - 1, ctx.ny - 1)) + 1j * rng.standard_normal((ctx.S, ctx.nz - 1, ctx.ny - 1))
+        return v
+
+    x, y = rand(), rand()
+    Mx, My = ctx.debug_precond(x).reshape(shape), ctx.debug_precond(y).reshape(shape)
+    a, b = np.sum(y * Mx, axis=(1, 2)), np.sum(x * My, axis=(1, 2))
+    assert np.max(np.abs(a - b) / np.abs(a)) < 2e-3
+    assert relmax(ctx.debug_precond(2.0 * x + (0.5 - 1j) * y).reshape(shape), 2.0 * Mx + (0.5 - 1j) * My) < 1e-4
+    ctx.set_options(fdm_precision="fp64"); ctx.forward(m)
+    M64 = ctx.debug_precond(x).reshape(shape)
+    assert relmax(Mx, M64) < 2e-2
+    a64 = np.sum(y * M64, axis=(1, 2)); b64 = np.sum(x * ctx.debug_precond(y).reshape(shape), axis=(1, 2))
+    assert np.max(np.abs(a64 - b64) / np.abs(a64)) < 1e-9
+    ctx.close()
+    # ... and it is NOT the one-sweep operator
+    monkeypatch.setenv("HMCMT_SWEEPS", "1")
+    c1 = HipContext(mesh, data, inv)
+    c1.forward(m)
+    assert relmax(c1.debug_precond(x).reshape(shape), Mx) > 1e-3
+    c1.close()
+
+
+def test_sweeps_are_chosen_per_solve(monkeypatch):
+    """Default (HMCMT_SWEEPS unset): a solve kind goes to two sweeps when its last solve needed more than 30 iterations,
+    back to one below HMCMT_SWEEPS_DOWN (default 6; 12 here), and -- every 40th solve in two-sweep mode -- runs one sweep once and keeps the cheaper of the
+    two (iterations x 1.28 for two sweeps).  Rough model: the first evaluation runs one sweep and is long, the next ones
+    run two and are shorter; a homogeneous model (the FDM background exact: a handful of iterations) brings both kinds
+    back to one sweep; a moderately rough model stays in two-sweep mode until the probe finds one sweep cheaper."""
+    monkeypatch.delenv("HMCMT_SWEEPS", raising=False)
+    monkeypatch.setenv("HMCMT_SWEEPS_DOWN", "12")
+    mesh, data, inv, m = make_problem("cfg2")
+    rough = _rough(m.size, 1.0)
+    ctx = HipContext(mesh, data, inv, warm_start="cold")
+    ctx.grad(rough); s0 = ctx.stats()
+    assert s0["smoother_sweeps"] == 11 and s0["iters_fwd_max"] > 30 and s0["iters_adj_max"] > 30, s0
+    ctx.grad(rough + 1e-3); s1 = ctx.stats()
+    assert s1["smoother_sweeps"] == 22 and s1["iters_fwd_max"] <= 0.8 * s0["iters_fwd_max"], (s0, s1)
+    smooth = np.full(m.size, np.log(0.01))
+    ctx.grad(smooth); s2 = ctx.stats()
+    assert s2["smoother_sweeps"] == 22 and s2["iters_fwd_max"] < 12
+    ctx.grad(smooth + 1e-3); s3 = ctx.stats()
+    assert s3["smoother_sweeps"] == 11, s3
+    p_auto, f_auto, g_auto = ctx.grad(rough)                           # (one sweep again, then the rule flips it back)
+    # the probe: a model of the bench's rough state (std 0.3: ~12 iterations with either smoother) in two-sweep mode
+    mild = m.copy()
+    ctx.grad(rough + 2e-3)
+    assert ctx.stats()["smoother_sweeps"] == 22
+    seen = []
+    for j in range(45):
+        ctx.grad(mild + 1e-4 * j)
+        seen.append(ctx.stats()["smoother_sweeps"])
+    assert seen[0] == 22 and seen[-1] == 11 and 22 in seen[:39], seen      # 40 solves with two sweeps, the probe, then one
+    ctx.close()
+    monkeypatch.setenv("HMCMT_SWEEPS", "1")
+    c1 = HipContext(mesh, data, inv, warm_start="cold")
+    p1, f1, g1 = c1.grad(rough)
+    c1.close()
+    assert relmax(p_auto, p1) < 1e-9
