@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(VBLOCK) void k_post2(Solver k, double* partZZ) {
     const int nrows = iz1 - iz0 + 3;
     const int mode = s >= k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
-    const float wf = (float)k.omega[s];
+    const float wf = (float)k.omega[s], rNYP = 1.0f / (float)NYP;
     const float2* z4 = k.z4_32 + so;
     const cplx *r = k.r + so, *di = k.dinv + so;
     float2* zo = k.z32 + so;
@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(VBLOCK) void k_post2(Solver k, double* partZZ) {
     double ar = 0, ai = 0, zz = 0, dummy = 0;
     const int nown = (iz1 - iz0 + 1) * NYP;
     for (int i = threadIdx.x; i < nown; i += VBLOCK) {
-        const int lr = i / NYP, iy = i - lr * NYP;
+        const int lr = (int)(((float)i + 0.5f) * rNYP), iy = i - lr * NYP;      // i / NYP (exact: i < 2^20)
         const long e = (long)(iz0 + lr) * NYP + iy;
         const int l = i + NYP;
         float2 of = float2{0.f, 0.f};

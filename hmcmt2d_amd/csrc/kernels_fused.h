@@ -177,6 +177,7 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
         const int mode = s >= k.nFreq;
         const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
         const float w = (float)k.omega[s];
+        const float rNYP = 1.0f / (float)NYP;
         const float2* p = pcur + so;
         const cplx *q = k.q + so, *ri = rin + so, *di = k.dinv + so;
         cplx *x = k.x + so, *ro = rout + so;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
         double xx = 0, dummy = 0;
         // phase A: r' and z1 on rows iz0-2 .. iz1+2 (rows outside the mesh: zero)
         for (int i = threadIdx.x; i < (nrows + 2) * NYP; i += VBLOCK) {
-            const int lr = i / NYP, iy = i - lr * NYP, row = iz0 - 2 + lr;
+            const int lr = div_small(i, rNYP), iy = i - lr * NYP, row = iz0 - 2 + lr;
             cplx rn = cplx{0, 0}, z1 = cplx{0, 0};
             const long e = (long)row * NYP + iy;
             if (row >= 0 && row <= k.nz) {
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
         };
         // phase B: z2 = z1 + D (r' - A z1) on rows iz0-1 .. iz1+1
         for (int i = threadIdx.x; i < nrows * NYP; i += VBLOCK) {
-            const int lr = i / NYP, iy = i - lr * NYP, row = iz0 - 1 + lr;
+            const int lr = div_small(i, rNYP), iy = i - lr * NYP, row = iz0 - 1 + lr;
             c32 z2 = c32{0.f, 0.f};
             if (row >= 1 && row <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
                 const long e = (long)row * NYP + iy;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
         // phase C: t = r' - A z2 on the own rows; z2 of the own rows goes out too
         const int nown = (iz1 - iz0 + 1) * NYP;
         for (int i = threadIdx.x; i < nown; i += VBLOCK) {
-            const int lr = i / NYP, iy = i - lr * NYP;
+            const int lr = div_small(i, rNYP), iy = i - lr * NYP;
             const long e = (long)(iz0 + lr) * NYP + iy;
             const int l = i + NYP;                                     // the same node in rs / z2s
             c32 out = c32{0.f, 0.f};
