@@ -183,59 +183,122 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
         cplx *x = k.x + so, *ro = rout + so;
         float2 *t = k.t32 + so, *z2o = k.zs32 + so;
         double xx = 0, dummy = 0;
+        // Every phase is a short chain (loads -> arithmetic -> LDS -> barrier): the loads of a batch of UB elements per
+        // thread are issued together, unconditionally (clamped addresses), apart from their use -- inside `if (valid)` the
+        // compiler keeps each load next to its use and a phase costs one memory round trip per element (48 VGPRs,
+        // 20.6 us) instead of one per batch.
+        constexpr int UB = 6;
+        const int nA = (nrows + 2) * NYP, nB = nrows * NYP, nown = (iz1 - iz0 + 1) * NYP;
         // phase A: r' and z1 on rows iz0-2 .. iz1+2 (rows outside the mesh: zero)
-        for (int i = threadIdx.x; i < (nrows + 2) * NYP; i += VBLOCK) {
-            const int lr = div_small(i, rNYP), iy = i - lr * NYP, row = iz0 - 2 + lr;
-            cplx rn = cplx{0, 0}, z1 = cplx{0, 0};
-            const long e = (long)row * NYP + iy;
-            if (row >= 0 && row <= k.nz) {
-                rn = startOnly ? ri[e] : ri[e] - al * q[e];
-                z1 = di[e] * rn;
+        for (int i0 = threadIdx.x; i0 < nA; i0 += UB * VBLOCK) {
+            cplx rv[UB], qv[UB], dv[UB], xv[UB];
+            float2 pv[UB];
+            long ee[UB];
+            int lrs[UB];
+            bool ok[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int i = min(i0 + u * VBLOCK, nA - 1);
+                const int lr = div_small(i, rNYP), iy = i - lr * NYP, row = iz0 - 2 + lr;
+                ok[u] = i0 + u * VBLOCK < nA && row >= 0 && row <= k.nz;
+                lrs[u] = lr;
+                ee[u] = (long)min(max(row, 0), k.nz) * NYP + iy;
+                rv[u] = ri[ee[u]]; dv[u] = di[ee[u]];
+                if (!startOnly) {
+                    qv[u] = q[ee[u]];
+                    if (lr >= 2 && lr <= nrows - 1) { xv[u] = x[ee[u]]; pv[u] = p[ee[u]]; }     // (own rows only: a predicated load)
+                }
             }
-            z1s[i] = c32{(float)z1.re, (float)z1.im};
-            if (lr >= 1 && lr <= nrows) rs[i - NYP] = c32{(float)rn.re, (float)rn.im};
-            if (!startOnly && lr >= 2 && lr <= nrows - 1) {
-                ro[e] = rn;
-                const float2 pf = p[e];
-                const cplx xv = x[e] + al * cplx{(double)pf.x, (double)pf.y};
-                x[e] = xv;
-                xx += cabs2(xv);
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int i = i0 + u * VBLOCK;
+                if (i < nA) {
+                    cplx rn = cplx{0, 0}, z1 = cplx{0, 0};
+                    if (ok[u]) {
+                        rn = startOnly ? rv[u] : rv[u] - al * qv[u];
+                        z1 = dv[u] * rn;
+                    }
+                    z1s[i] = c32{(float)z1.re, (float)z1.im};
+                    const int lr = lrs[u];
+                    if (lr >= 1 && lr <= nrows) rs[i - NYP] = c32{(float)rn.re, (float)rn.im};
+                    if (!startOnly && lr >= 2 && lr <= nrows - 1) {
+                        ro[ee[u]] = rn;
+                        const cplx xn = xv[u] + al * cplx{(double)pv[u].x, (double)pv[u].y};
+                        x[ee[u]] = xn;
+                        xx += cabs2(xn);
+                    }
+                }
             }
         }
-        __syncthreads();
-        auto sten = [&](const c32* u, int l, long e) -> c32 {       // (A u)(e), u a tile array with the same row pitch
-            const float4 ca = k.cf32[2 * (mo + e)], cb = k.cf32[2 * (mo + e) + 1];
+        auto sten = [&](const c32* u, int l, const float4& ca, const float4& cb) -> c32 {   // (A u) at tile index l
             const c32 c = u[l];
             const float dm = w * ca.y;
             return c32{ca.x * c.re - dm * c.im + ca.z * u[l + 1].re + ca.w * u[l - 1].re + cb.x * u[l + NYP].re + cb.y * u[l - NYP].re,
                        ca.x * c.im + dm * c.re + ca.z * u[l + 1].im + ca.w * u[l - 1].im + cb.x * u[l + NYP].im + cb.y * u[l - NYP].im};
         };
-        // phase B: z2 = z1 + D (r' - A z1) on rows iz0-1 .. iz1+1
-        for (int i = threadIdx.x; i < nrows * NYP; i += VBLOCK) {
-            const int lr = div_small(i, rNYP), iy = i - lr * NYP, row = iz0 - 1 + lr;
-            c32 z2 = c32{0.f, 0.f};
-            if (row >= 1 && row <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
-                const long e = (long)row * NYP + iy;
-                const int l = i + NYP;                                 // the same node in z1s
-                const c32 t1 = rs[i] - sten(z1s, l, e);
-                const cplx d = di[e];
-                const c32 df = c32{(float)d.re, (float)d.im};
-                const c32 dt = df * t1;
-                z2 = c32{z1s[l].re + dt.re, z1s[l].im + dt.im};
+        // phase B: z2 = z1 + D (r' - A z1) on rows iz0-1 .. iz1+1; the first batch's coefficients are requested before the barrier
+        const float4* cf = k.cf32 + 2 * mo;
+        {
+            float4 ca[UB], cb[UB];
+            cplx dv[UB];
+            bool in[UB];
+            auto ldB = [&](int i0) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int i = min(i0 + u * VBLOCK, nB - 1);
+                    const int lr = div_small(i, rNYP), iy = i - lr * NYP, row = iz0 - 1 + lr;
+                    in[u] = i0 + u * VBLOCK < nB && row >= 1 && row <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1;
+                    const long e = (long)row * NYP + iy;
+                    ca[u] = cf[2 * e]; cb[u] = cf[2 * e + 1]; dv[u] = di[e];
+                }
+            };
+            ldB(threadIdx.x);
+            __syncthreads();                                         // z1s, rs complete
+            for (int i0 = threadIdx.x; i0 < nB; i0 += UB * VBLOCK) {
+                if (i0 != (int)threadIdx.x) ldB(i0);
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int i = i0 + u * VBLOCK;
+                    if (i < nB) {
+                        c32 z2 = c32{0.f, 0.f};
+                        if (in[u]) {
+                            const int l = i + NYP;                       // the same node in z1s
+                            const c32 t1 = rs[i] - sten(z1s, l, ca[u], cb[u]);
+                            const c32 dt = c32{(float)dv[u].re, (float)dv[u].im} * t1;
+                            z2 = c32{z1s[l].re + dt.re, z1s[l].im + dt.im};
+                        }
+                        z2s[i] = z2;
+                    }
+                }
             }
-            z2s[i] = z2;
         }
-        __syncthreads();
         // phase C: t = r' - A z2 on the own rows; z2 of the own rows goes out too
-        const int nown = (iz1 - iz0 + 1) * NYP;
-        for (int i = threadIdx.x; i < nown; i += VBLOCK) {
-            const int lr = div_small(i, rNYP), iy = i - lr * NYP;
-            const long e = (long)(iz0 + lr) * NYP + iy;
-            const int l = i + NYP;                                     // the same node in rs / z2s
-            c32 out = c32{0.f, 0.f};
-            if (iy >= 1 && iy <= k.ny - 1) out = rs[l] - sten(z2s, l, e);
-            store_t32(k, t, iz0 + lr, iy, out.re, out.im);
-            z2o[e] = float2{z2s[l].re, z2s[l].im};
+        {
+            float4 ca[UB], cb[UB];
+            auto ldC = [&](int i0) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const long e = (long)iz0 * NYP + min(i0 + u * VBLOCK, nown - 1);
+                    ca[u] = cf[2 * e]; cb[u] = cf[2 * e + 1];
+                }
+            };
+            ldC(threadIdx.x);
+            __syncthreads();                                         // z2s complete
+            for (int i0 = threadIdx.x; i0 < nown; i0 += UB * VBLOCK) {
+                if (i0 != (int)threadIdx.x) ldC(i0);
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int i = i0 + u * VBLOCK;
+                    if (i < nown) {
+                        const int lr = div_small(i, rNYP), iy = i - lr * NYP;
+                        const int l = i + NYP;                         // the same node in rs / z2s
+                        c32 out = c32{0.f, 0.f};
+                        if (iy >= 1 && iy <= k.ny - 1) out = rs[l] - sten(z2s, l, ca[u], cb[u]);
+                        store_t32(k, t, iz0 + lr, iy, out.re, out.im);
+                        z2o[(long)iz0 * NYP + i] = float2{z2s[l].re, z2s[l].im};
+                    }
+                }
+            }
         }
         if (startOnly) return;
         block_sum2(xx, dummy, sh2);
