@@ -381,7 +381,7 @@ int apply_precond(hmcmt_ctx* ctx) {
 void launch_adjoint_side(hmcmt_ctx* ctx);
 int collect_pending(hmcmt_ctx* ctx);
 
-constexpr double SWEEPS2_COST = 1.28;       // time of a two-sweep iteration / time of a one-sweep iteration (5 launches, 64 us / 4 launches, 50 us)
+constexpr double SWEEPS2_COST = 1.20;       // time of a two-sweep iteration / time of a one-sweep iteration (5 launches, 59-60 us / 4 launches, 50 us)
 constexpr int SWEEPS_PROBE_EVERY = 40;      // in two-sweep mode: every so many solves of a kind one solve runs one sweep, to compare
 // damped Jacobi sweeps on each side of the FDM stage for the next solve of this kind.  Two sweeps cut the iterations by
 // 20 % (smooth models) to 35 % (high-contrast ones) and cost a fifth launch and ~30 % more time per iteration: by

@@ -81,7 +81,7 @@ def test_two_sweep_preconditioner_is_linear_symmetric_and_close_to_its_fp64_form
 def test_sweeps_are_chosen_per_solve(monkeypatch):
     """Default (HMCMT_SWEEPS unset): a solve kind goes to two sweeps when its last solve needed more than 30 iterations,
     back to one below HMCMT_SWEEPS_DOWN (default 6; 12 here), and -- every 40th solve in two-sweep mode -- runs one sweep once and keeps the cheaper of the
-    two (iterations x 1.28 for two sweeps).  Rough model: the first evaluation runs one sweep and is long, the next ones
+    two (iterations x 1.2 for two sweeps).  Rough model: the first evaluation runs one sweep and is long, the next ones
     run two and are shorter; a homogeneous model (the FDM background exact: a handful of iterations) brings both kinds
     back to one sweep; a moderately rough model stays in two-sweep mode until the probe finds one sweep cheaper."""
     monkeypatch.delenv("HMCMT_SWEEPS", raising=False)
