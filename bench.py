@@ -410,8 +410,9 @@ def main():
             # two damped Jacobi sweeps per side of the FDM stage (chosen per solve by the library, hmcmt_stats.smoother_sweeps):
             # a fifth launch, k_post2 (category post_smoother on the fused path), and 8 B/unknown more in two others.  f2 = the
             # fraction of the sampled preconditioner applications that ran it
-            n0, n7 = prof["fdm_transform"][1], prof["post_smoother"][1]
-            f2 = min(1.0, n7 / n0) if (back_fused and n0) else 0.0
+            n7 = prof["post_smoother"][1]
+            f2 = cnt.get("solves_two_sweeps", 0) / max(cnt["solves"], 1) if back_fused else 0.0
+            merged = f2 > 0 and n7 == 0                     # the second post-sweep inside k_spmv_fused<2> (default) or as k_post2 (HMCMT_POST2=1)
             it_sys = cnt["active_iter_systems"]             # sum over sampled iterations of active systems
             pre_sys = cnt["start_systems"]                  # + one preconditioner application per solve before the first iteration
             fams = {("k_fdm_fwd (split-bf16 MFMA eigen-transform + LDS-resident complex64 tridiagonal sweeps, one launch)" if fwd_fused else
@@ -419,14 +420,16 @@ def main():
                     ("k_back_post (split-bf16 MFMA back transform + both Jacobi halves of the post-smoother + dot products)" if back_fused else
                      "k_transform_lp<2> (split-bf16 MFMA back transform fused with the first Jacobi half)" if fwd_fused else
                      "k_transform_lp<0>,<2> (split-bf16 MFMA forward and back transforms: 16 U and 56 U)"):
-                        ("fdm_transform", ((48.0 + 8.0 * f2) if back_fused else 56.0) if fwd_fused else 36.0, 1 if fwd_fused else 2, (it_sys + pre_sys) * (1 if fwd_fused else 2)),
-                    "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 40.0, 1, it_sys),
-                    "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 112.0 + 8.0 * f2, 1, it_sys)}
+                        ("fdm_transform", ((48.0 + (16.0 if merged else 8.0) * f2) if back_fused else 56.0) if fwd_fused else 36.0, 1 if fwd_fused else 2, (it_sys + pre_sys) * (1 if fwd_fused else 2)),
+                    "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 40.0 + (32.0 * f2 if merged else 0.0), 1, it_sys),
+                    "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 112.0 + (16.0 if merged else 8.0) * f2, 1, it_sys)}
+            # two sweeps, bytes per unknown: k_update_fused<2> also writes the pre-smoothed iterate z2 and the smoothed residual t
+            # as complex64 (+16), k_back_post<.,2> reads both on top of dinv, r (+16), k_spmv_fused<2> reads z4, r, dinv instead of
+            # z (+32) for the second post-sweep it does itself
             if not back_fused:
                 fams["k_post (second Jacobi half: 5-point stencil + dot products)"] = ("post_smoother", 56.0, 1, it_sys + pre_sys)
             elif n7:
-                # read z4 (8), r (16), dinv (16), write z (8); the other two-sweep kernels: k_update_fused<2> also writes the
-                # pre-smoothed iterate z2 (8), k_back_post<.,2> reads it (8) on top of dinv, r for its own sweep
+                # HMCMT_POST2=1: read z4 (8), r (16), dinv (16), write z (8)
                 fams["k_post2 (second post-sweep of the two-sweep smoother: 5-point stencil + dot products)"] = \
                     ("post_smoother", 48.0, f2, (it_sys + pre_sys) * f2)
             roofs = []
@@ -458,7 +461,7 @@ def main():
                          "achieved": it_bytes / (it_us * 1e-6) / 1e9 if it_us else 0.0, "unit": "GB/s",
                          "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS if it_us else 0.0,
                          "note": "one preconditioned COCG iteration of the systems still active = %d launches%s; " % (
-                                     len(fams), " (two smoothing sweeps per side in %.0f %% of the sampled solves: 5 launches, else 4)" % (100 * f2) if n7 and back_fused else "") +
+                                     len(fams), " (two smoothing sweeps per side in %.0f %% of the sampled solves)" % (100 * f2) if f2 > 0 else "") +
                                  ("the working set of a solve (~15 vectors = %.0f MB) fits the 256 MB Infinity Cache, so launches are "
                                   "latency- not HBM-bound" if ws_mb <= 256 else
                                   "the working set of a solve (~15 vectors = %.0f MB) is beyond the 256 MB Infinity Cache: HBM-bound") % ws_mb}

@@ -120,7 +120,7 @@ struct hmcmt_ctx {
     double profMs[HMCMT_NCAT] = {0};
     long long profN[HMCMT_NCAT] = {0};
     unsigned long long* d_cnt = nullptr;   // device counter behind Solver::cntActive
-    long long profStartSys = 0, profEvals = 0, profSolves = 0;   // sampled: systems active at the start of a solve (summed), evaluations, solves
+    long long profStartSys = 0, profEvals = 0, profSolves = 0, profSolves2 = 0;   // sampled: systems active at the start of a solve (summed), evaluations, solves, solves with two sweeps
     int nSysOn = 0;
     // leapfrog / prior
     double *d_mref = nullptr, *d_invM = nullptr, *d_wmVal = nullptr, *d_p = nullptr, *d_mcur = nullptr, *d_g = nullptr;
@@ -261,6 +261,7 @@ int launch_back_post(hmcmt_ctx* ctx) {
             { ProfScope ps(ctx, 0);
               hipLaunchKernelGGL((k_back_post<1, 2>), dim3(nwg, k.S), dim3(64 * NW), lds, ctx->stream, k, k.y32, ctx->d_Vtb, ctx->d_Vtbl,
                                  ctx->d_partZZ, NW, ctx->backStamps); }
+            if (k.merged2) return 0;                  // (the second post-sweep runs inside k_spmv_fused<2>)
             ProfScope ps(ctx, 7);
             hipLaunchKernelGGL(k_post2, dim3(k.NTR, k.S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(float2), ctx->stream, k, ctx->d_partZZ);
             return 0;
@@ -381,10 +382,10 @@ int apply_precond(hmcmt_ctx* ctx) {
 void launch_adjoint_side(hmcmt_ctx* ctx);
 int collect_pending(hmcmt_ctx* ctx);
 
-constexpr double SWEEPS2_COST = 1.20;       // time of a two-sweep iteration / time of a one-sweep iteration (5 launches, 59-60 us / 4 launches, 50 us)
+constexpr double SWEEPS2_COST = 1.20;       // time of a two-sweep iteration / time of a one-sweep iteration (59-60 us / 50 us at the headline size)
 constexpr int SWEEPS_PROBE_EVERY = 40;      // in two-sweep mode: every so many solves of a kind one solve runs one sweep, to compare
 // damped Jacobi sweeps on each side of the FDM stage for the next solve of this kind.  Two sweeps cut the iterations by
-// 20 % (smooth models) to 35 % (high-contrast ones) and cost a fifth launch and ~30 % more time per iteration: by
+// 20 % (smooth models) to 35 % (high-contrast ones) and cost ~20 % more time per iteration: by
 // default a solve kind switches to two when its last solve needed more than sweepsUp iterations, back to one below
 // sweepsDown, and -- since the gain depends on the model, not on the count -- tries one sweep once every
 // SWEEPS_PROBE_EVERY solves and keeps whichever is cheaper (parse_stats).
@@ -407,7 +408,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     if (!ctx->solveBegun)           // (otherwise done by the residual kernel in front of this solve)
         hipLaunchKernelGGL(k_solve_begin, dim3((S * MAXNB + 255) / 256), dim3(256), 0, ctx->stream, k, ctx->v.sysOn);
     ctx->solveBegun = false;
-    if (k.cntActive) { ++ctx->profSolves; ctx->profStartSys += ctx->nSysOn; }
+    if (k.cntActive) { ++ctx->profSolves; ctx->profStartSys += ctx->nSysOn; if (k.sweeps == 2) ++ctx->profSolves2; }
     int& guess = kind == 0 ? ctx->lastItFwd : ctx->lastItAdj;
     int nextCheck = guess > 2 ? guess : 4;
     const int every = ctx->opt.check_every > 0 ? ctx->opt.check_every : 2;
@@ -442,7 +443,11 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
         while (!done && !stalled && it < ctx->opt.maxit + 1) {
             ++it;
             // decide convergence of the state after iteration it-1, p = z + beta p, q = A p
-            { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv_fused, dim3(k.NTR, S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit); }
+            if (k.sweeps == 2 && k.merged2) {
+                ProfScope ps(ctx, 2);
+                hipLaunchKernelGGL(k_spmv_fused<2>, dim3(k.NTR, S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx) + (size_t)(k.RT + 4) * k.NYP * sizeof(float2),
+                                   ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit);
+            } else { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv_fused<1>, dim3(k.NTR, S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit); }
             if (k.sweeps == 2) { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused<2>, dim3(k.NTR, S), vb, update2_lds(k), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it, 0); }
             else { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused<1>, dim3(k.NTR, S), vb, (size_t)(2 * k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it, 0); }
             rcur ^= 1;
@@ -858,7 +863,8 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_fused<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_post2), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_back_post<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_fused<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_fused<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_resid_pre), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
     }
     HIPCHK(hipEventCreateWithFlags(&ctx->evExtA, hipEventDisableTiming));
@@ -952,12 +958,13 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     }
     k.NTR = (h.nz - 1 + k.RT - 1) / k.RT;
     k.sweeps = 1;
+    k.merged2 = getenv("HMCMT_POST2") && atoi(getenv("HMCMT_POST2")) == 1 ? 0 : 1;
     k.omega = v.omega; k.cY = v.cY; k.cZ = v.cZ; k.dK = v.dK; k.dM = v.dM; k.ofz = v.ofz; k.invp = v.invp;
     { float4* cf = nullptr; if ((rc = dalloc(ctx, &cf, 2 * 2 * VS))) return rc; k.cf32 = cf; }
     k.r = v.R;
     DA(k.p, S * VS) DA(k.q, S * VS) DA(k.z, S * VS) DA(k.y, S * VS) DA(k.t, S * VS) DA(k.dinv, S * VS)
     DA(k.t32, S * VS + 64) DA(k.y32, S * VS + 64) DA(ctx->d_invp32, S * VS)
-    DA(k.z32, S * VS) DA(k.p32a, S * VS) DA(k.p32b, S * VS) DA(k.zs32, S * VS) DA(k.z4_32, S * VS)
+    DA(k.z32, S * VS) DA(k.p32a, S * VS) DA(k.p32b, S * VS) DA(k.zs32, S * VS) DA(k.z4_32, S * VS) DA(k.t2_32, S * VS) DA(k.partR, S * MAXNB)
     DA(k.p2, S * VS) DA(k.r2, S * VS) DA(k.partPQ, S * MAXNB) DA(k.rho2, 2 * S)
     k.invp32 = ctx->d_invp32;
     DA(k.partA, S * MAXNB) DA(k.partB, S * MAXNB) DA(ctx->d_partZZ, S * MAXNB)
@@ -1059,7 +1066,7 @@ int hmcmt_profile_counters(hmcmt_ctx* ctx, int64_t* out) {
     prof_collect(ctx);
     unsigned long long c = 0;
     HIPCHK(hipMemcpy(&c, ctx->d_cnt, sizeof c, hipMemcpyDeviceToHost));
-    out[0] = (int64_t)c; out[1] = ctx->profStartSys; out[2] = ctx->profEvals; out[3] = ctx->profSolves;
+    out[0] = (int64_t)c; out[1] = ctx->profStartSys; out[2] = ctx->profEvals; out[3] = ctx->profSolves; out[4] = ctx->profSolves2;
     return 0;
 }
 
@@ -1220,7 +1227,7 @@ int hmcmt_profile(hmcmt_ctx* ctx, int32_t enable) {
     }
     ctx->profMask = (unsigned)enable;
     for (int i = 0; i < HMCMT_NCAT; ++i) { ctx->profMs[i] = 0; ctx->profN[i] = 0; }
-    ctx->profStartSys = ctx->profEvals = ctx->profSolves = 0;
+    ctx->profStartSys = ctx->profEvals = ctx->profSolves = ctx->profSolves2 = 0;
     HIPCHK(hipMemsetAsync(ctx->d_cnt, 0, sizeof(unsigned long long), ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -1289,7 +1296,10 @@ int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z) {
     HIPCHK(hipMemcpy(ctx->sv.r, r, bytes, hipMemcpyHostToDevice));
     int rc = set_all_active(ctx);
     if (rc) return rc;
+    const int merged = ctx->sv.merged2;
+    ctx->sv.merged2 = 0;                 // (two sweeps: the last one as a launch of its own, so that z exists in memory)
     apply_precond(ctx);
+    ctx->sv.merged2 = merged;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0) {
         // the default path leaves its result as complex64 (Solver::z32): widen it for the caller

@@ -26,6 +26,12 @@ struct Solver {
     cplx *p2, *r2;                        // second buffers of p and r for the fused kernels
     float2 *zs32, *z4_32;                 // two smoothing sweeps per side (sweeps == 2): the pre-smoothed iterate z2 and the iterate
                                           // after the first post-sweep z4, complex64 (k_update_fused<2> -> k_back_post<.,2> -> k_post2)
+    float2 *t2_32;                        // ... the smoothed residual t the FDM stage was given, as complex64 (for the rho identity below)
+    cplx *partR;                          // [S][MAXNB] two sweeps: sum over a tile of (r + t) .* z2 -- with k_back_post<.,2>'s sum of t .* (V y) it
+                                          // makes rho = r'z WITHOUT the second post-sweep: r'z5 = t'z3 + r'z2 (z3 = z2 + F t), an identity of the
+                                          // symmetric construction (G'^2 r = t for the smoother's iteration matrix G) -- so that sweep can run
+                                          // inside k_spmv_fused<2>, after the reduction that needs rho
+    int merged2;                          // two sweeps: 1 = second post-sweep inside k_spmv_fused<2> (default), 0 = k_post2 launch (HMCMT_POST2=1)
     int sweeps;                           // damped Jacobi sweeps on each side of the FDM stage in the solve at hand (1 or 2)
     float2 *z32, *p32a, *p32b;            // fused path: preconditioned residual and the two search-direction buffers as complex64
                                           // (x, r, q and every inner product stay fp64; see k_spmv_fused)

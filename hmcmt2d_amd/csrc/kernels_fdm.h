@@ -921,7 +921,8 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
     const double w = k.omega[s];
     const cplx *r = k.r + so, *di = k.dinv + so;
     float2* t = (SW == 2 ? k.z4_32 : k.z32) + so;   // the preconditioned residual leaves as complex64 (the FDM stage is fp32-class anyway)
-    const float2* z2i = k.zs32 + so;
+    const float2 *z2i = k.zs32 + so, *t2i = k.t2_32 + so;
+    double p2r = 0, p2i = 0;           // SW = 2: sum over the own rows of t .* (V y), the second part of the rho identity (Solver::partR)
     const int nown = (iz1 - iz0 + 1) * NYP;
     // Every phase below is a short dependent chain (global load -> LDS -> barrier -> MFMA -> LDS -> barrier -> stencil),
     // so loads are issued as early as their addresses are known and unconditionally (clamped indices): inside
@@ -955,7 +956,7 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
         constexpr int KC = 8;
         // epilogue operands dinv, r of the wave's 2 x 2 x 2 accumulator elements per lane
         cplx dv[2][2][2], rv[2][2][2];
-        float2 zq[2][2][2];
+        float2 zq[2][2][2], tq[2][2][2];
         auto ld_dr = [&]() {
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg)
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const long ub = (long)ru * NYP + min(t0 + t, NT - 1) * 16;
-                        if (SW == 2) zq[rg][t][h2] = (z2i + ub)[lo];
+                        if (SW == 2) { zq[rg][t][h2] = (z2i + ub)[lo]; tq[rg][t][h2] = (t2i + ub)[lo]; }
                         else { dv[rg][t][h2] = (di + ub)[lo]; rv[rg][t][h2] = (r + ub)[lo]; }
                     }
                 }
@@ -1066,7 +1067,13 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
                     for (int h2 = 0; h2 < 2; ++h2) {
                         const int lr = 8 * rg + 2 * g + h2;
                         cplx val = cplx{(double)acc[rg][t][2 * h2], (double)acc[rg][t][2 * h2 + 1]};
-                        if (SW == 2) val += cplx{(double)zq[rg][t][h2].x, (double)zq[rg][t][h2].y};
+                        if (SW == 2) {
+                            if (lr >= 1 && rbase + lr <= iz1 && col >= 1 && col <= k.ny - 1) {         // own rows, interior columns
+                                const double tr = tq[rg][t][h2].x, ti = tq[rg][t][h2].y;
+                                p2r += tr * val.re - ti * val.im; p2i += tr * val.im + ti * val.re;
+                            }
+                            val += cplx{(double)zq[rg][t][h2].x, (double)zq[rg][t][h2].y};
+                        }
                         else val += dv[rg][t][h2] * rv[rg][t][h2];
                         if (rbase + lr >= NZP) val = cplx{0.0, 0.0};
                         zt[(long)lr * NYP + col] = val;
@@ -1107,6 +1114,7 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
     if (bx == 0) for (int i = threadIdx.x; i < NYP; i += bd) t[i] = float2{0.f, 0.f};
     if (iz1 == k.nz - 1) for (int i = threadIdx.x; i < NYP; i += bd) t[(long)k.nz * NYP + i] = float2{0.f, 0.f};
     BP_STAMP(5)
+    if (SW == 2) { ar = p2r; ai = p2i; }       // (rho comes from the identity; zz stays |z4|^2, the error estimate of the two-sweep path)
     block_sum3_8(ar, ai, zz, sh, NW);
     if (threadIdx.x == 0) {
         k.partA[(long)s * MAXNB + bx] = cplx{ar, ai};

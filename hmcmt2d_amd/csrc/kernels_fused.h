@@ -34,6 +34,11 @@ __device__ __forceinline__ int div_small(int i, float rcp) { return (int)(((floa
 // valid direction as long as x += alpha p, q = A p and r -= alpha q all use the SAME rounded p -- they do: p is rounded
 // here before the stencil, the update kernel reads the stored value.  x, r, q and all inner products stay fp64.
 // (CPU prototype on the headline systems: iteration counts +-2, final error 1e-12 either way.)
+// SW = 2 (two sweeps per side, Solver::merged2): the preconditioned residual arrives as z4, the iterate after the FIRST
+// post-sweep (k_back_post<., 2>), with rho = r'z already known from the identity of Solver::partR and |z4|^2 as the
+// error estimate; the second post-sweep  z = z4 + dinv .* (r - A z4)  is done here, on the tile's rows and one halo row
+// on each side (z4 staged with two), in fp32 like the rest of the smoother -- no launch of its own (k_post2: 8 us).
+template <int SW>
 __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* partZZ, const float2* pin_, float2* pout, int it, int maxit) {
     const int s = blockIdx.y;
     extern __shared__ __attribute__((aligned(16))) char smem_[];
@@ -44,14 +49,15 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
     const int act = k.active[s];
     const int ln = threadIdx.x & 63;
     // the system's partial sums (lane b fetches partial b), rho of the previous iteration
-    const cplx paL = ln < k.NB ? k.partA[(long)s * MAXNB + ln] : cplx{0, 0};
+    cplx paL = ln < k.NB ? k.partA[(long)s * MAXNB + ln] : cplx{0, 0};
+    if (SW == 2 && ln < k.NTR) paL += k.partR[(long)s * MAXNB + ln];
     const double pzL = ln < k.NB ? partZZ[(long)s * MAXNB + ln] : 0.0;
     const double pbL = ln < k.NTR ? k.partB[(long)s * MAXNB + ln] : 0.0;
     const cplx rhoPrev = k.rho2[(long)((it - 1) & 1) * k.S + s];
     const int mode = s >= k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
     const double w = k.omega[s];
-    const float2 *z = k.z32 + so, *pi = pin_ + so;
+    const float2 *z = (SW == 2 ? k.z4_32 : k.z32) + so, *pi = pin_ + so;
     float2* po = pout + so;
     cplx* q = k.q + so;
     const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);   // own rows iz0..iz1
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
             pv[u] = first ? float2{0.f, 0.f} : pi[e];
         }
     };
-    ld_stage(threadIdx.x);
+    if (SW == 1) ld_stage(threadIdx.x);
     if (!act) return;
     const cplx rz = cplx{wave_sum(paL.re), wave_sum(paL.im)};
     const double zz = wave_sum(pzL), xx = wave_sum(pbL);
@@ -95,6 +101,61 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
         return;
     }
     if (k.cntActive && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(k.cntActive, 1ull);   // (roofline accounting only)
+    if constexpr (SW == 2) {
+        // z4 on rows iz0-2 .. iz1+2 (outside the mesh: zero) -> LDS, then z = z4 + dinv .* (r - A z4) on rows iz0-1 .. iz1+1
+        c32* z4s = reinterpret_cast<c32*>(pn + (long)(k.RT + 2) * NYP);      // [(RT+4)][NYP]
+        const int nz4 = (nrows + 2) * NYP;
+        for (int i = threadIdx.x; i < nz4; i += VBLOCK) {
+            const int lr = div_small(i, rNYP), row = iz0 - 2 + lr;
+            float2 v = float2{0.f, 0.f};
+            if (row >= 0 && row <= k.nz) v = z[(long)row * NYP + (i - lr * NYP)];
+            z4s[i] = c32{v.x, v.y};
+        }
+        const cplx *rr = k.r + so, *di = k.dinv + so;
+        const float4* cf = k.cf32 + 2 * mo;
+        const float wf = (float)w;
+        constexpr int UB2 = 4;
+        float4 ca[UB2], cb[UB2];
+        cplx rv[UB2], dv[UB2];
+        float2 pv2[UB2];
+        bool in[UB2];
+        auto ld2 = [&](int i0) {
+#pragma unroll
+            for (int u = 0; u < UB2; ++u) {
+                const int i = min(i0 + u * VBLOCK, ntot - 1);
+                const int lr = div_small(i, rNYP), iy = i - lr * NYP, row = iz0 - 1 + lr;
+                in[u] = row >= 1 && row <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1;
+                const long e = (long)row * NYP + iy;
+                ca[u] = cf[2 * e]; cb[u] = cf[2 * e + 1]; rv[u] = rr[e]; dv[u] = di[e];
+                pv2[u] = first ? float2{0.f, 0.f} : pi[e];
+            }
+        };
+        ld2(threadIdx.x);
+        __syncthreads();                                         // z4s complete
+        for (int i0 = threadIdx.x; i0 < ntot; i0 += UB2 * VBLOCK) {
+            if (i0 != (int)threadIdx.x) ld2(i0);
+#pragma unroll
+            for (int u = 0; u < UB2; ++u) {
+                const int i = i0 + u * VBLOCK;
+                if (i < ntot) {
+                    cplx zc = cplx{0, 0};
+                    if (in[u]) {
+                        const int l = i + NYP;                        // the same node in z4s
+                        const c32 c = z4s[l];
+                        const float dm = wf * ca[u].y;
+                        const c32 az = c32{ca[u].x * c.re - dm * c.im + ca[u].z * z4s[l + 1].re + ca[u].w * z4s[l - 1].re + cb[u].x * z4s[l + NYP].re + cb[u].y * z4s[l - NYP].re,
+                                           ca[u].x * c.im + dm * c.re + ca[u].z * z4s[l + 1].im + ca[u].w * z4s[l - 1].im + cb[u].x * z4s[l + NYP].im + cb[u].y * z4s[l - NYP].im};
+                        const cplx res = cplx{rv[u].re - (double)az.re, rv[u].im - (double)az.im};
+                        zc = cplx{(double)c.re, (double)c.im} + dv[u] * res;
+                    }
+                    const cplx v = first ? zc : zc + be * cplx{(double)pv2[u].x, (double)pv2[u].y};
+                    const float2 vf = float2{(float)v.re, (float)v.im};
+                    pn[i] = cplx{(double)vf.x, (double)vf.y};          // the stencil sees the value that is stored
+                    if (i >= NYP && i < ntot - NYP) po[ebase + i] = vf;
+                }
+            }
+        }
+    } else
     for (int i0 = threadIdx.x; i0 < ntot; i0 += SB * VBLOCK) {
         if (i0 != (int)threadIdx.x) ld_stage(i0);
 #pragma unroll
@@ -181,8 +242,8 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
         const float2* p = pcur + so;
         const cplx *q = k.q + so, *ri = rin + so, *di = k.dinv + so;
         cplx *x = k.x + so, *ro = rout + so;
-        float2 *t = k.t32 + so, *z2o = k.zs32 + so;
-        double xx = 0, dummy = 0;
+        float2 *t = k.t32 + so, *z2o = k.zs32 + so, *t2o = k.t2_32 + so;
+        double xx = 0, dummy = 0, p1r = 0, p1i = 0;
         // Every phase is a short chain (loads -> arithmetic -> LDS -> barrier): the loads of a batch of UB elements per
         // thread are issued together, unconditionally (clamped addresses), apart from their use -- inside `if (valid)` the
         // compiler keeps each load next to its use and a phase costs one memory round trip per element (48 VGPRs,
@@ -295,11 +356,18 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
                         c32 out = c32{0.f, 0.f};
                         if (iy >= 1 && iy <= k.ny - 1) out = rs[l] - sten(z2s, l, ca[u], cb[u]);
                         store_t32(k, t, iz0 + lr, iy, out.re, out.im);
-                        z2o[(long)iz0 * NYP + i] = float2{z2s[l].re, z2s[l].im};
+                        const c32 z2v = z2s[l];
+                        z2o[(long)iz0 * NYP + i] = float2{z2v.re, z2v.im};
+                        t2o[(long)iz0 * NYP + i] = float2{out.re, out.im};
+                        const double sr = (double)rs[l].re + (double)out.re, si = (double)rs[l].im + (double)out.im;     // (r' + t) .* z2
+                        p1r += sr * z2v.re - si * z2v.im; p1i += sr * z2v.im + si * z2v.re;
                     }
                 }
             }
         }
+        __shared__ double sh3[8];
+        block_sum2(p1r, p1i, sh3);
+        if (threadIdx.x == 0) k.partR[(long)s * MAXNB + blockIdx.x] = cplx{p1r, p1i};
         if (startOnly) return;
         block_sum2(xx, dummy, sh2);
         if (threadIdx.x == 0) {

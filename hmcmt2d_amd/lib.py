@@ -283,10 +283,11 @@ class HipContext:
         return {c: (float(ms[i]), int(n[i])) for i, c in enumerate(CATEGORIES)}
 
     def profile_counters(self):
-        """{active_iter_systems, start_systems, evaluations, solves} of the sampled evaluations (hmcmt_profile_counters)."""
-        o = np.zeros(4, dtype=np.int64)
+        """{active_iter_systems, start_systems, evaluations, solves, solves_two_sweeps} of the sampled evaluations
+        (hmcmt_profile_counters)."""
+        o = np.zeros(5, dtype=np.int64)
         self._check(self.lib.hmcmt_profile_counters(self.h, o.ctypes.data_as(c_int64_p)))
-        return dict(zip(("active_iter_systems", "start_systems", "evaluations", "solves"), (int(x) for x in o)))
+        return dict(zip(("active_iter_systems", "start_systems", "evaluations", "solves", "solves_two_sweeps"), (int(x) for x in o)))
 
     def _vec(self, a):
         a = np.ascontiguousarray(a, dtype=np.complex128)

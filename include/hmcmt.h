@@ -181,8 +181,9 @@ int hmcmt_profile_read(hmcmt_ctx* ctx, double* ms /*[HMCMT_NCAT]*/, int64_t* lau
 /* What the sampled launches worked on (roofline numerators): out[0] = sum over the sampled iterations of the number of
  * systems still active (device counter, incremented by k_spmv_fused), out[1] = sum over the sampled solves of the systems
  * active at their start (the preconditioner is applied once before the first iteration), out[2] = evaluations sampled,
- * out[3] = solves sampled.  Reset by hmcmt_profile. */
-int hmcmt_profile_counters(hmcmt_ctx* ctx, int64_t* out /*[4]*/);
+ * out[3] = solves sampled, out[4] = those of them that ran two smoothing sweeps per side (hmcmt_stats.smoother_sweeps).
+ * Reset by hmcmt_profile. */
+int hmcmt_profile_counters(hmcmt_ctx* ctx, int64_t* out /*[5]*/);
 
 /* sizes the roofline accounting needs: out = {NYP, NZP, S, ny, nz, zid, nblk} */
 int hmcmt_dims(const hmcmt_ctx* ctx, int32_t* out);

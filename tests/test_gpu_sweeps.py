@@ -1,4 +1,4 @@
-"""Two damped Jacobi sweeps on each side of the FDM stage (k_update_fused<2>, k_back_post<.,2>, k_post2):
+"""Two damped Jacobi sweeps on each side of the FDM stage (k_update_fused<2>, k_back_post<.,2>, k_spmv_fused<2>):
 same answers as one sweep and as the oracle, fewer iterations on high-contrast models, a preconditioner that is still
 linear and complex symmetric, and the per-solve choice between one and two sweeps."""
 import numpy as np
