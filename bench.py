@@ -420,12 +420,12 @@ def main():
                     ("k_back_post (split-bf16 MFMA back transform + both Jacobi halves of the post-smoother + dot products)" if back_fused else
                      "k_transform_lp<2> (split-bf16 MFMA back transform fused with the first Jacobi half)" if fwd_fused else
                      "k_transform_lp<0>,<2> (split-bf16 MFMA forward and back transforms: 16 U and 56 U)"):
-                        ("fdm_transform", ((48.0 + (16.0 if merged else 8.0) * f2) if back_fused else 56.0) if fwd_fused else 36.0, 1 if fwd_fused else 2, (it_sys + pre_sys) * (1 if fwd_fused else 2)),
-                    "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 40.0 + (32.0 * f2 if merged else 0.0), 1, it_sys),
-                    "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 112.0 + (16.0 if merged else 8.0) * f2, 1, it_sys)}
-            # two sweeps, bytes per unknown: k_update_fused<2> also writes the pre-smoothed iterate z2 and the smoothed residual t
-            # as complex64 (+16), k_back_post<.,2> reads both on top of dinv, r (+16), k_spmv_fused<2> reads z4, r, dinv instead of
-            # z (+32) for the second post-sweep it does itself
+                        ("fdm_transform", ((48.0 + 8.0 * f2) if back_fused else 56.0) if fwd_fused else 36.0, 1 if fwd_fused else 2, (it_sys + pre_sys) * (1 if fwd_fused else 2)),
+                    "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 40.0 + (24.0 * f2 if merged else 0.0), 1, it_sys),
+                    "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 112.0 + 8.0 * f2, 1, it_sys)}
+            # two sweeps, bytes per unknown (the Jacobi diagonal is complex64 there, -8 per read): k_update_fused<2> also writes
+            # the pre-smoothed iterate z2 and the smoothed residual t as complex64 (+16 - 8), k_back_post<.,2> reads both on top
+            # of dinv, r (+16 - 8), k_spmv_fused<2> reads z4, r, dinv instead of z (+24) for the second post-sweep it does itself
             if not back_fused:
                 fams["k_post (second Jacobi half: 5-point stencil + dot products)"] = ("post_smoother", 56.0, 1, it_sys + pre_sys)
             elif n7:

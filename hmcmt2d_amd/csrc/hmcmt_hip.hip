@@ -964,7 +964,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     k.r = v.R;
     DA(k.p, S * VS) DA(k.q, S * VS) DA(k.z, S * VS) DA(k.y, S * VS) DA(k.t, S * VS) DA(k.dinv, S * VS)
     DA(k.t32, S * VS + 64) DA(k.y32, S * VS + 64) DA(ctx->d_invp32, S * VS)
-    DA(k.z32, S * VS) DA(k.p32a, S * VS) DA(k.p32b, S * VS) DA(k.zs32, S * VS) DA(k.z4_32, S * VS) DA(k.t2_32, S * VS) DA(k.partR, S * MAXNB)
+    DA(k.z32, S * VS) DA(k.p32a, S * VS) DA(k.p32b, S * VS) DA(k.zs32, S * VS) DA(k.z4_32, S * VS) DA(k.t2_32, S * VS) DA(k.partR, S * MAXNB) DA(k.dinv32, S * VS)
     DA(k.p2, S * VS) DA(k.r2, S * VS) DA(k.partPQ, S * MAXNB) DA(k.rho2, 2 * S)
     k.invp32 = ctx->d_invp32;
     DA(k.partA, S * MAXNB) DA(k.partB, S * MAXNB) DA(ctx->d_partZZ, S * MAXNB)

@@ -17,6 +17,7 @@ struct Solver {
     const cplx* invp;                     // [S][vstride]
     cplx *x, *r, *p, *q, *z, *y, *t;      // [S][vstride]
     cplx *dinv;                           // [S][vstride] omegaJ / diag(A) on interior nodes, 0 elsewhere
+    float2 *dinv32;                       // ... the same as complex64, for the two-sweep smoother's kernels (it is read four times per iteration there)
     // mixed-precision FDM stage (options.fdm_precision == 0): bf16 transform operands, fp32 tridiagonal
     float2* t32;                          // [S][vstride] complex64 transform input (or its pre-split bf16 form, see store_t32)
     int splitT;                           // 1: t32 / y32 hold bf16 hi/lo planes instead of complex64

@@ -284,6 +284,7 @@ __global__ __launch_bounds__(VBLOCK) void k_dinv(Solver k, double wJ) {
         cplx d = cplx{0, 0};
         if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) d = wJ / cplx{k.dK[mo + e], w * k.dM[mo + e]};
         k.dinv[so + e] = d;
+        k.dinv32[so + e] = float2{(float)d.re, (float)d.im};
     }
 }
 
@@ -941,7 +942,9 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
         q.dk = dKm[e]; q.dm = dMm[e];
         q.cy0 = cYm[e]; q.cy1 = cYm[e - 1u];
         q.cz0 = cZm[e]; q.cz1 = cZu[e];
-        q.rv = r[e]; q.dv = di[e];
+        q.rv = r[e];
+        if (SW == 2) { const float2 d2 = (k.dinv32 + so)[e]; q.dv = cplx{(double)d2.x, (double)d2.y}; }
+        else q.dv = di[e];
     };
     Sten st[SU], st2[SU];           // 14 NYP <= 8 x blockDim elements: two batches per thread
     {

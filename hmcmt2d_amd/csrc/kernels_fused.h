@@ -111,13 +111,14 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
             if (row >= 0 && row <= k.nz) v = z[(long)row * NYP + (i - lr * NYP)];
             z4s[i] = c32{v.x, v.y};
         }
-        const cplx *rr = k.r + so, *di = k.dinv + so;
+        const cplx* rr = k.r + so;
+        const float2* di = k.dinv32 + so;
         const float4* cf = k.cf32 + 2 * mo;
         const float wf = (float)w;
         constexpr int UB2 = 4;
         float4 ca[UB2], cb[UB2];
-        cplx rv[UB2], dv[UB2];
-        float2 pv2[UB2];
+        cplx rv[UB2];
+        float2 pv2[UB2], dv[UB2];
         bool in[UB2];
         auto ld2 = [&](int i0) {
 #pragma unroll
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
                         const c32 az = c32{ca[u].x * c.re - dm * c.im + ca[u].z * z4s[l + 1].re + ca[u].w * z4s[l - 1].re + cb[u].x * z4s[l + NYP].re + cb[u].y * z4s[l - NYP].re,
                                            ca[u].x * c.im + dm * c.re + ca[u].z * z4s[l + 1].im + ca[u].w * z4s[l - 1].im + cb[u].x * z4s[l + NYP].im + cb[u].y * z4s[l - NYP].im};
                         const cplx res = cplx{rv[u].re - (double)az.re, rv[u].im - (double)az.im};
-                        zc = cplx{(double)c.re, (double)c.im} + dv[u] * res;
+                        zc = cplx{(double)c.re, (double)c.im} + cplx{(double)dv[u].x, (double)dv[u].y} * res;
                     }
                     const cplx v = first ? zc : zc + be * cplx{(double)pv2[u].x, (double)pv2[u].y};
                     const float2 vf = float2{(float)v.re, (float)v.im};
@@ -240,7 +241,8 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
         const float w = (float)k.omega[s];
         const float rNYP = 1.0f / (float)NYP;
         const float2* p = pcur + so;
-        const cplx *q = k.q + so, *ri = rin + so, *di = k.dinv + so;
+        const cplx *q = k.q + so, *ri = rin + so;
+        const float2* di = k.dinv32 + so;
         cplx *x = k.x + so, *ro = rout + so;
         float2 *t = k.t32 + so, *z2o = k.zs32 + so, *t2o = k.t2_32 + so;
         double xx = 0, dummy = 0, p1r = 0, p1i = 0;
@@ -252,8 +254,8 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
         const int nA = (nrows + 2) * NYP, nB = nrows * NYP, nown = (iz1 - iz0 + 1) * NYP;
         // phase A: r' and z1 on rows iz0-2 .. iz1+2 (rows outside the mesh: zero)
         for (int i0 = threadIdx.x; i0 < nA; i0 += UB * VBLOCK) {
-            cplx rv[UB], qv[UB], dv[UB], xv[UB];
-            float2 pv[UB];
+            cplx rv[UB], qv[UB], xv[UB];
+            float2 pv[UB], dv[UB];
             long ee[UB];
             int lrs[UB];
             bool ok[UB];
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
                     cplx rn = cplx{0, 0}, z1 = cplx{0, 0};
                     if (ok[u]) {
                         rn = startOnly ? rv[u] : rv[u] - al * qv[u];
-                        z1 = dv[u] * rn;
+                        z1 = cplx{(double)dv[u].x, (double)dv[u].y} * rn;
                     }
                     z1s[i] = c32{(float)z1.re, (float)z1.im};
                     const int lr = lrs[u];
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
         const float4* cf = k.cf32 + 2 * mo;
         {
             float4 ca[UB], cb[UB];
-            cplx dv[UB];
+            float2 dv[UB];
             bool in[UB];
             auto ldB = [&](int i0) {
 #pragma unroll
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
                         if (in[u]) {
                             const int l = i + NYP;                       // the same node in z1s
                             const c32 t1 = rs[i] - sten(z1s, l, ca[u], cb[u]);
-                            const c32 dt = c32{(float)dv[u].re, (float)dv[u].im} * t1;
+                            const c32 dt = c32{dv[u].x, dv[u].y} * t1;
                             z2 = c32{z1s[l].re + dt.re, z1s[l].im + dt.im};
                         }
                         z2s[i] = z2;
