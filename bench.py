@@ -411,8 +411,9 @@ def main():
             # a fifth launch, k_post2 (category post_smoother on the fused path), and 8 B/unknown more in two others.  f2 = the
             # fraction of the sampled preconditioner applications that ran it
             n7 = prof["post_smoother"][1]
-            f2 = cnt.get("solves_two_sweeps", 0) / max(cnt["solves"], 1) if back_fused else 0.0
-            merged = f2 > 0 and n7 == 0                     # the second post-sweep inside k_spmv_fused<2> (default) or as k_post2 (HMCMT_POST2=1)
+            f2 = cnt.get("solves_two_sweeps", 0) / max(cnt["solves"], 1)
+            # the second post-sweep inside k_spmv_fused<2> (default) or as k_post2 (HMCMT_POST2=1; fused path only)
+            merged = f2 > 0 and (n7 == 0 or not back_fused)
             it_sys = cnt["active_iter_systems"]             # sum over sampled iterations of active systems
             pre_sys = cnt["start_systems"]                  # + one preconditioner application per solve before the first iteration
             fams = {("k_fdm_fwd (split-bf16 MFMA eigen-transform + LDS-resident complex64 tridiagonal sweeps, one launch)" if fwd_fused else
@@ -420,14 +421,16 @@ def main():
                     ("k_back_post (split-bf16 MFMA back transform + both Jacobi halves of the post-smoother + dot products)" if back_fused else
                      "k_transform_lp<2> (split-bf16 MFMA back transform fused with the first Jacobi half)" if fwd_fused else
                      "k_transform_lp<0>,<2> (split-bf16 MFMA forward and back transforms: 16 U and 56 U)"):
-                        ("fdm_transform", ((48.0 + 8.0 * f2) if back_fused else 56.0) if fwd_fused else 36.0, 1 if fwd_fused else 2, (it_sys + pre_sys) * (1 if fwd_fused else 2)),
+                        ("fdm_transform", ((48.0 + 8.0 * f2) if back_fused else 56.0) if fwd_fused else (16.0 + 56.0 * (1 - f2) + 24.0 * f2) / 2, 1 if fwd_fused else 2, (it_sys + pre_sys) * (1 if fwd_fused else 2)),
                     "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 40.0 + (24.0 * f2 if merged else 0.0), 1, it_sys),
                     "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 112.0 + 8.0 * f2, 1, it_sys)}
             # two sweeps, bytes per unknown (the Jacobi diagonal is complex64 there, -8 per read): k_update_fused<2> also writes
             # the pre-smoothed iterate z2 and the smoothed residual t as complex64 (+16 - 8), k_back_post<.,2> reads both on top
             # of dinv, r (+16 - 8), k_spmv_fused<2> reads z4, r, dinv instead of z (+24) for the second post-sweep it does itself
             if not back_fused:
-                fams["k_post (second Jacobi half: 5-point stencil + dot products)"] = ("post_smoother", 56.0, 1, it_sys + pre_sys)
+                # (two sweeps on this path: the back transform writes F t alone, 24 U, and k_post_w2 reads F t, z2, t, r, dinv (56) and
+                # writes z4 (8) = 64 U)
+                fams["k_post / k_post_w2 (post-smoothing sweep: 5-point stencil + dot products)"] = ("post_smoother", 56.0 * (1 - f2) + 64.0 * f2, 1, it_sys + pre_sys)
             elif n7:
                 # HMCMT_POST2=1: read z4 (8), r (16), dinv (16), write z (8)
                 fams["k_post2 (second post-sweep of the two-sweep smoother: 5-point stencil + dot products)"] = \

@@ -244,8 +244,10 @@ size_t update2_lds(const Solver& k) { return (size_t)(3 * k.RT + 8) * k.NYP * si
 // two sweeps per side exist on the fused mixed-precision path (and on the fp64 path of the restarts)
 bool sweeps2_ok(const hmcmt_ctx* ctx) {
     const Solver& k = ctx->sv;
+    const size_t spmv2 = (size_t)(k.RT + 2) * k.NYP * sizeof(cplx) + (size_t)(k.RT + 4) * k.NYP * sizeof(float2);
     return ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI &&
-           (ctx->opt.fdm_precision != 0 || (fused_back_ok(ctx) && k.NTR <= k.NB && update2_lds(k) <= (size_t)150 * 1024));
+           (ctx->opt.fdm_precision != 0 || (update2_lds(k) <= (size_t)150 * 1024 && spmv2 <= (size_t)150 * 1024 &&
+                                            (k.merged2 || (fused_back_ok(ctx) && k.NTR <= k.NB))));
 }
 
 // forward half of the mixed-precision FDM stage: y32 = tridiag^-1 (t32 V); fused kernel when its LDS slabs fit
@@ -272,6 +274,12 @@ int launch_back_post(hmcmt_ctx* ctx) {
         return 0;
     }
     int rc;
+    if (k.sweeps == 2) {                     // wide meshes, two sweeps: F t as fp64, then z4 and the sums of the rho identity
+        if ((rc = launch_transform_lp<1>(ctx, k.y32, true, k.z, k.active))) return rc;
+        { ProfScope ps(ctx, 7); hipLaunchKernelGGL(k_post_w2, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
+        if (!k.merged2) hipLaunchKernelGGL(k_post2, dim3(k.NTR, k.S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(float2), ctx->stream, k, ctx->d_partZZ);
+        return 0;
+    }
     if ((rc = launch_transform_lp<2>(ctx, k.y32, true, k.z, k.active))) return rc;   // z = F t + dinv r
     { ProfScope ps(ctx, 7); hipLaunchKernelGGL(k_post, vg, vb, 0, ctx->stream, k, ctx->d_partZZ, k.z32); }
     return 0;

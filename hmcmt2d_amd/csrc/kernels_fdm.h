@@ -1132,6 +1132,52 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
     BP_STAMP(6)
 }
 
+// Back half of the two-sweep smoother on meshes too wide for k_back_post (separate back transform k_transform_lp<1>):
+//   z3 = F t + z2 (F t = k.z from the transform, z2 from k_update_fused<2>),  z4 = z3 + dinv .* (r - A z3)  -> z4_32,
+// with the partial sums of t .* (F t) (second part of the rho identity, Solver::partR) and |z4|^2.  z3 is formed on the
+// fly at the five stencil points.
+__global__ __launch_bounds__(VBLOCK) void k_post_w2(Solver k, double* partZZ) {
+    const int s = blockIdx.y;
+    if (!k.active[s]) return;
+    __shared__ double sh[8];
+    __shared__ double sh2[8];
+    const int mode = s >= k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const cplx *r = k.r + so, *ft = k.z + so;
+    const float2 *z2 = k.zs32 + so, *t2 = k.t2_32 + so, *di = k.dinv32 + so;
+    float2* z4 = k.z4_32 + so;
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    double ar = 0, ai = 0, zz = 0, dummy = 0;
+    auto z3 = [&](long e) { const float2 a = z2[e]; const cplx f = ft[e]; return cplx{f.re + (double)a.x, f.im + (double)a.y}; };
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        float2 of = float2{0.f, 0.f};
+        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+            const cplx c = z3(e), f = ft[e];
+            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
+            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+            acc += k.cY[mo + e] * z3(e + 1);
+            acc += k.cY[mo + e - 1] * z3(e - 1);
+            acc += k.cZ[mo + e] * z3(e + k.NYP);
+            acc += k.cZ[mo + e - k.NYP] * z3(e - k.NYP);
+            const float2 d = di[e], tv = t2[e];
+            const cplx out = c + cplx{(double)d.x, (double)d.y} * (r[e] - acc);
+            of = float2{(float)out.re, (float)out.im};
+            ar += (double)tv.x * f.re - (double)tv.y * f.im;
+            ai += (double)tv.x * f.im + (double)tv.y * f.re;
+            zz += (double)of.x * of.x + (double)of.y * of.y;
+        }
+        z4[e] = of;
+    }
+    block_sum2(ar, ai, sh);
+    block_sum2(zz, dummy, sh2);
+    if (threadIdx.x == 0) {
+        k.partA[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
+        partZZ[(long)s * MAXNB + blockIdx.x] = zz;
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // Second post-sweep of the two-sweep smoother (k.sweeps == 2):  z = z4 + dinv .* (r - A z4)  on tiles of RT rows
 // with one halo row of z4 staged in LDS, the result stored as complex64 where k_spmv_fused reads it, and the

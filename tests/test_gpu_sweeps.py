@@ -114,3 +114,29 @@ def test_sweeps_are_chosen_per_solve(monkeypatch):
     p1, f1, g1 = c1.grad(rough)
     c1.close()
     assert relmax(p_auto, p1) < 1e-9
+
+
+@pytest.mark.parametrize("sweeps", ["1", "2"])
+def test_wide_mesh_path_against_the_oracle(sweeps, monkeypatch):
+    """Meshes wider than 256 nodes run the separate forward / back kernels (k_transform_lp, k_thomas32, k_post); with two
+    sweeps the back half is k_transform_lp<1> + k_post_w2.  A ragged 270-cell-wide problem (NYP = 272), rough model,
+    both smoothers against the oracle."""
+    from tests.helpers import ragged_problem
+    monkeypatch.setenv("HMCMT_SWEEPS", sweeps)
+    mesh, data, inv, m = ragged_problem(270, 14, 2, 4, 4, 3)
+    ny, nt = mesh.gridSize
+    mm = np.clip(m + 0.8 * np.random.default_rng(3).standard_normal(m.size), LO, HI)
+    ctx = HipContext(mesh, data, inv, verify=True)
+    assert ctx.NYP > 256
+    pred, misfit, grad = ctx.grad(mm)
+    st = ctx.stats()
+    assert st["status"] == 0 and st["true_res_max"] < 1e-9 and st["smoother_sweeps"] == 11 * int(sweeps), st
+    po, mo, go = oracle_eval(mesh, data, inv, mm)
+    noise = (0.0, 0.0)
+    for eps in (1e-14, -1e-14, 1e-13):
+        _, _, gn = oracle_eval(mesh, data, inv, mm * (1 + eps))
+        noise = tuple(max(a, b) for a, b in zip(noise, gerr_split(gn, go, inv, mesh)))
+    assert relmax(pred, po) < 1e-8 and abs(misfit - mo) / mo < 1e-8
+    shallow, deep = gerr_split(grad, go, inv, mesh)
+    assert shallow < 1e-8 + 10 * noise[0] and deep < 5e-6 + 10 * noise[1], (shallow, deep, noise)
+    ctx.close()
