@@ -966,6 +966,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     }
     k.NTR = (h.nz - 1 + k.RT - 1) / k.RT;
     k.sweeps = 1;
+    k.w2 = getenv("HMCMT_JACOBI_W2") ? (float)atof(getenv("HMCMT_JACOBI_W2")) : 1.0f;
     k.merged2 = getenv("HMCMT_POST2") && atoi(getenv("HMCMT_POST2")) == 1 ? 0 : 1;
     k.omega = v.omega; k.cY = v.cY; k.cZ = v.cZ; k.dK = v.dK; k.dM = v.dM; k.ofz = v.ofz; k.invp = v.invp;
     { float4* cf = nullptr; if ((rc = dalloc(ctx, &cf, 2 * 2 * VS))) return rc; k.cf32 = cf; }

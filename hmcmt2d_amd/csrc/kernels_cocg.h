@@ -32,6 +32,7 @@ struct Solver {
                                           // makes rho = r'z WITHOUT the second post-sweep: r'z5 = t'z3 + r'z2 (z3 = z2 + F t), an identity of the
                                           // symmetric construction (G'^2 r = t for the smoother's iteration matrix G) -- so that sweep can run
                                           // inside k_spmv_fused<2>, after the reduction that needs rho
+    float w2;                             // two sweeps: damping of the INNER sweeps (second pre-sweep, first post-sweep) relative to the outer ones
     int merged2;                          // two sweeps: 1 = second post-sweep inside k_spmv_fused<2> (default), 0 = k_post2 launch (HMCMT_POST2=1)
     int sweeps;                           // damped Jacobi sweeps on each side of the FDM stage in the solve at hand (1 or 2)
     float2 *z32, *p32a, *p32b;            // fused path: preconditioned residual and the two search-direction buffers as complex64

@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
             acc += q.cy1 * zt[l - 1];
             acc += q.cz0 * zt[l + NYP];
             acc += q.cz1 * zt[l - NYP];
-            cplx out = c + q.dv * (q.rv - acc);
+            cplx out = c + (SW == 2 ? (double)k.w2 : 1.0) * (q.dv * (q.rv - acc));
             if (q.iy < 1 || q.iy > k.ny - 1) out = cplx{0, 0};
             const float2 of = float2{(float)out.re, (float)out.im};
             out = cplx{(double)of.x, (double)of.y};            // the sums are those of the value that is stored
@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(VBLOCK) void k_post_w2(Solver k, double* partZZ) {
             acc += k.cZ[mo + e] * z3(e + k.NYP);
             acc += k.cZ[mo + e - k.NYP] * z3(e - k.NYP);
             const float2 d = di[e], tv = t2[e];
-            const cplx out = c + cplx{(double)d.x, (double)d.y} * (r[e] - acc);
+            const cplx out = c + (double)k.w2 * (cplx{(double)d.x, (double)d.y} * (r[e] - acc));
             of = float2{(float)out.re, (float)out.im};
             ar += (double)tv.x * f.re - (double)tv.y * f.im;
             ai += (double)tv.x * f.im + (double)tv.y * f.re;

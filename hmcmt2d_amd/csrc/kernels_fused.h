@@ -327,7 +327,7 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
                         if (in[u]) {
                             const int l = i + NYP;                       // the same node in z1s
                             const c32 t1 = rs[i] - sten(z1s, l, ca[u], cb[u]);
-                            const c32 dt = c32{dv[u].x, dv[u].y} * t1;
+                            const c32 dt = c32{k.w2 * dv[u].x, k.w2 * dv[u].y} * t1;
                             z2 = c32{z1s[l].re + dt.re, z1s[l].im + dt.im};
                         }
                         z2s[i] = z2;
