@@ -26,7 +26,7 @@ struct Solver {
     const float2* invp32;                 // [S][vstride]
     cplx *p2, *r2;                        // second buffers of p and r for the fused kernels
     float2 *zs32, *z4_32;                 // two smoothing sweeps per side (sweeps == 2): the pre-smoothed iterate z2 and the iterate
-                                          // after the first post-sweep z4, complex64 (k_update_fused<2> -> k_back_post<.,2> -> k_post2)
+                                          // after the first post-sweep z4, complex64 (k_update_fused<2> -> k_back_post<.,2> -> k_spmv_fused<2>)
     float2 *t2_32;                        // ... the smoothed residual t the FDM stage was given, as complex64 (for the rho identity below)
     cplx *partR;                          // [S][MAXNB] two sweeps: sum over a tile of (r + t) .* z2 -- with k_back_post<.,2>'s sum of t .* (V y) it
                                           // makes rho = r'z WITHOUT the second post-sweep: r'z5 = t'z3 + r'z2 (z3 = z2 + F t), an identity of the

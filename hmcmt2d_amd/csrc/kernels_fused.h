@@ -9,6 +9,9 @@
 //                    recomputed on each node's 5-point halo, q = A p, partial p'q
 //   k_update_fused : alpha, x += alpha p, r' = r - alpha q recomputed on the halo, Jacobi pre-smoothing
 //                    t = r' - A (dinv .* r') written as complex64 for the transform, partial |x|^2
+// Both exist in a second form (<2>) for the smoother with TWO damped Jacobi sweeps on each side of the FDM stage
+// (Solver::sweeps, chosen per solve by the host: pick_sweeps): k_update_fused<2> does both pre-sweeps, k_spmv_fused<2>
+// the second post-sweep (the first one is k_back_post<., 2>'s).
 // Every block of a system reduces that system's partial sums itself (same order -> same value), so no
 // separate scalar kernel and no grid synchronisation is needed; p and r are double-buffered because
 // blocks read their neighbours' old values while writing new ones.  Block 0 of each system owns the
