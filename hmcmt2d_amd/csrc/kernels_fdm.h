@@ -903,7 +903,8 @@ constexpr int BP_OWN = 14;         // interior rows owned by a workgroup (tile =
 
 // SW = 2 (two sweeps per side): the first term added to the FDM correction is the pre-smoothed iterate z2 that
 // k_update_fused<2> stored (instead of dinv .* r), and the result -- the iterate after the FIRST post-sweep -- goes to
-// z4_32; k_post2 does the second post-sweep and the dot products.
+// z4_32 together with the second part of the rho identity (Solver::partR) and |z4|^2; the second post-sweep runs inside
+// k_spmv_fused<2> (or, HMCMT_POST2=1 and the test hook, as k_post2).
 template <int FMT, int SW = 1>
 __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __restrict__ Y, const u4v* __restrict__ Bhi,
                                                    const u4v* __restrict__ Blo, double* partZZ, int NW, long long* stamps) {
