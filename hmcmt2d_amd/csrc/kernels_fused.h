@@ -227,12 +227,13 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
     const int s = blockIdx.y;
     if (!k.active[s]) return;
     extern __shared__ __attribute__((aligned(16))) char smem_[];
-    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);
+    const int RTt = SW == 2 ? k.RT2 : k.RT;
+    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * RTt, iz1 = min(iz0 + RTt - 1, k.nz - 1);
     const int nrows = iz1 - iz0 + 3;
     if constexpr (SW == 2) {
         c32* z1s = reinterpret_cast<c32*>(smem_);             // [(RT+4)][NYP]  z1 = dinv .* r'   rows iz0-2 .. iz1+2
-        c32* rs = z1s + (long)(k.RT + 4) * NYP;               // [(RT+2)][NYP]  r'                rows iz0-1 .. iz1+1
-        c32* z2s = rs + (long)(k.RT + 2) * NYP;               // [(RT+2)][NYP]  z2                rows iz0-1 .. iz1+1
+        c32* rs = z1s + (long)(RTt + 4) * NYP;                // [(RT+2)][NYP]  r'                rows iz0-1 .. iz1+1
+        c32* z2s = rs + (long)(RTt + 2) * NYP;               // [(RT+2)][NYP]  z2                rows iz0-1 .. iz1+1
         __shared__ double sh2[8];
         cplx al = cplx{0, 0};
         if (!startOnly) {
@@ -373,6 +374,11 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
         __shared__ double sh3[8];
         block_sum2(p1r, p1i, sh3);
         if (threadIdx.x == 0) k.partR[(long)s * MAXNB + blockIdx.x] = cplx{p1r, p1i};
+        if (blockIdx.x == 0)                                           // (fewer tiles than the k.NTR partial sums the consumers add up)
+            for (int b = gridDim.x + threadIdx.x; b < k.NTR; b += VBLOCK) {
+                k.partR[(long)s * MAXNB + b] = cplx{0, 0};
+                if (!startOnly) k.partB[(long)s * MAXNB + b] = 0.0;
+            }
         if (startOnly) return;
         block_sum2(xx, dummy, sh2);
         if (threadIdx.x == 0) {
