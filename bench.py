@@ -272,9 +272,12 @@ def main():
     chain.run(W)
     chain.iters.clear(); acc0, rej0 = chain.accepted, chain.rejected
     if not os.environ.get("HMCMT_BENCH_NOPROF"):
-        # HIP events around every launch of the iteration kernels, in every 6th evaluation of the timed region
-        # (bracketing every launch of every step costs ~20 % of the throughput)
-        ctx.profile(["fdm_transform", "tridiagonal", "spmv", "vector_ops", "post_smoother"], every=6)
+        # HIP events around every launch of the iteration kernels, in every n-th evaluation of the timed region, n chosen so
+        # that about ten evaluations (~450 iterations, ~1800 launches) are sampled whatever K is: the driver's 20-step run
+        # samples every 2nd, the default 96-step run every 9th (bracketing every launch of every step costs ~20 % of the
+        # throughput; round 2 sampled every 6th = 3 evaluations of a 20-step run)
+        prof_every = max(1, K // 10)
+        ctx.profile(["fdm_transform", "tridiagonal", "spmv", "vector_ops", "post_smoother"], every=prof_every)
     elapsed = timed(torch, dist, lambda: chain.run(K))
     prof = ctx.profile_read()
     cnt = ctx.profile_counters()
@@ -398,13 +401,25 @@ def main():
         #   k_update_fused x, r updates + Jacobi pre-smoothing: read p (8), q, r, x, dinv (64), write x, r (32), t (8) = 112 U
         # A launch works on the systems still active; U_launch = U * (active systems / S), the active count from the
         # device counter of hmcmt_profile_counters over the SAME sampled launches the HIP events time (every launch of
-        # every 6th evaluation of the timed region, the empty ones behind a convergence poll included).
+        # every n-th evaluation of the timed region, the empty ones behind a convergence poll included).
         nyi, nzi = ctx.ny - 1, ctx.nz - 1
         Usys = nzi * nyi
         U = ctx.S * Usys
         ws_mb = 15 * ctx.S * ctx.NZP * ctx.NYP * 16 / 1e6
 
-        def build_roofline(prof, cnt, population):
+        # SURVEY 8(d)'s canonical figure beside it: what a CSR implementation (complex128 values + int32 column indices,
+        # complex128 vectors, one pass per vector operation, nothing fused) would move for the operations a kernel performs:
+        # B_spmv = nnz*(16+4) + (N+1)*4 + 2*16*N per system and stencil product, 16*N per vector pass.
+        nnz_sys = 5 * Usys - 2 * (nyi + nzi)
+        B_spmv = nnz_sys * 20 + (Usys + 1) * 4 + 32 * Usys
+        # category -> (stencil products, vector passes) with one / two smoothing sweeps per side
+        CANON = {"spmv": ((1, 5), (2, 11)),            # p = z + beta p (3), q = A p, p'q (2)   [two sweeps: + second post-sweep: A z4, 6 passes]
+                 "vector_ops": ((1, 12), (2, 18)),     # x += a p (3), r -= a q (3), z1 = D r (3), t = r - A z1 (2), |x|^2 (1)   [+ A z1 ..., 6]
+                 "tridiagonal": ((0, 3), (0, 3)),      # read t, pivots, write y (the eigen-transform itself has no CSR analogue)
+                 "fdm_transform": ((1, 13), (1, 13)),  # read y (1), z0 = D r (3), z = V y + z0 (3), A z, 4 passes, r'z and |z|^2 (2)
+                 "post_smoother": ((1, 6), (1, 6))}
+
+        def build_roofline(prof, cnt, population, every):
             fwd_fused = ctx.NYP <= 256                      # the library's own rule (launch_fdm_fwd): wide meshes run the separate kernels
             back_fused = fwd_fused                          # ... and k_back_post goes with it (launch_back_post)
             # two damped Jacobi sweeps per side of the FDM stage (chosen per solve by the library, hmcmt_stats.smoother_sweeps):
@@ -447,8 +462,13 @@ def main():
                 it_bytes += per_it * nbytes
                 it_us += per_it * avg_us
                 step_bytes += bpu * Usys * sys_launches / nev
+                (sp1, vp1), (sp2, vp2) = CANON[cat]
+                can_sys = (sp1 * B_spmv + vp1 * 16 * Usys) * (1 - f2) + (sp2 * B_spmv + vp2 * 16 * Usys) * f2
+                can = can_sys * act / (avg_us * 1e-6) / 1e9 if n_c else 0.0
                 entry = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(name, cat), "avg_launch_us": avg_us,
+                         "frac_canonical_csr": can / HBM_PEAK_GBS, "canonical_csr_bytes_per_launch": can_sys * act,
+                         "evaluations_sampled": cnt["evaluations"], "sampled_every": every,
                          "launches_timed": n_c, "launches_per_iteration": per_it, "bytes_per_launch": nbytes,
                          "bytes_per_launch_all_systems_active": bpu * U, "active_systems_per_launch": act, "ms_timed": ms_c,
                          "population": population}
@@ -472,8 +492,8 @@ def main():
             return roofs, iteration, step_bytes
 
         roofs, iteration, step_bytes = build_roofline(
-            prof, cnt, "every launch of this kernel in every 6th evaluation of the timed region (HIP events on the library's "
-                       "stream), launches that found all systems converged included")
+            prof, cnt, f"every launch of this kernel in every {prof_every}. evaluation of the timed region (HIP events on the "
+                       "library's stream), launches that found all systems converged included", prof_every)
         ms_step = 1e3 * elapsed / K
         step = {"bytes_per_step": step_bytes, "ms_per_step": ms_step, "achieved": step_bytes / (ms_step * 1e-3) / 1e9,
                 "unit": "GB/s", "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -499,7 +519,7 @@ def main():
         }
         if world == 1 and not args.no_extras:
             fr, fi, _ = build_roofline(full_prof, full_cnt, "every launch of 4 cold evaluations whose solves are cut off after 12 "
-                                                           "iterations with all systems still active (tolerance 1e-200)")
+                                                           "iterations with all systems still active (tolerance 1e-200)", 1)
             extras["roofline_all_systems_active"] = {"kernels": fr, "iteration": fi}
         out.update(extras)
         if gather is not None:

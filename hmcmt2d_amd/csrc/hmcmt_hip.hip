@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 #include "../../include/hmcmt.h"
 #include "hmcmt_host.h"
@@ -72,6 +73,7 @@ struct hmcmt_ctx {
     double *d_m = nullptr, *d_V = nullptr, *d_Vt = nullptr, *d_partZZ = nullptr, *d_misfit = nullptr;
     double *d_partRes = nullptr, *d_partBn = nullptr;
     cplx* d_b = nullptr;                  // copy of the right-hand side (verify)
+    int dbgFlags = 0;                     // hmcmt_debug_flags
     cplx* d_fieldsOut = nullptr;
     // pinned host staging
     int* h_nactive = nullptr;
@@ -130,6 +132,7 @@ struct hmcmt_ctx {
     int* h_lfFlag = nullptr;                 // pinned copy of d_lfFlag (read after a synchronisation)
     double* d_gStart = nullptr;              // data gradient at the start model of the last trajectory (a rejection restarts there)
     bool havePrior = false, lfHaveGrad = false, lfFlagPending = false;
+    int solveFail = 0;                    // status a system of the last solve gave up with (mapped failure word), 0 = none
     // results of the last two host-API evaluations, keyed by the model: a sampler re-evaluates the model it has
     // just evaluated (getHamiltonian at the proposal, HMCSampler.jl:364; the first gradient of the next trajectory,
     // :217) or, after a rejection, the start model of the trajectory before -- those calls cost a memcmp
@@ -300,6 +303,8 @@ int fdm_fwd_ntw(const hmcmt_ctx* ctx) {
     // forces it (16-mode slabs if need be), =0 disables it.
     if (!ctx->fusedFwd) return 0;
     const int tw = ctx->twistOn ? 1 : 0;
+    static const int ntwEnv = getenv("HMCMT_FWD_NTW") ? atoi(getenv("HMCMT_FWD_NTW")) : 0;      // 1: 16-mode slabs (twice the workgroups)
+    if (ntwEnv == 1 && k.NYP <= 256 && fdm_fwd_lds(k, 1, tw) <= ctx->maxLds) return 1;
     if (fdm_fwd_lds(k, FW_NTW, tw) <= ctx->maxLds && (k.NYP <= 256 || ctx->fusedFwdForce)) return FW_NTW;
     if (ctx->fusedFwdForce && fdm_fwd_lds(k, 1, tw) <= ctx->maxLds) return 1;
     return 0;
@@ -390,7 +395,10 @@ int apply_precond(hmcmt_ctx* ctx) {
 
 void launch_adjoint_side(hmcmt_ctx* ctx);
 int collect_pending(hmcmt_ctx* ctx);
+int collect_stats(hmcmt_ctx* ctx, bool withAdjoint);
+int finish_status(hmcmt_ctx* ctx);
 
+constexpr double SPIN_LIMIT_S = 60.0;       // a convergence poll that sees no progress for this long gives up (HMCMT_EHIP)
 constexpr double SWEEPS2_COST = 1.20;       // time of a two-sweep iteration / time of a one-sweep iteration (59-60 us / 50 us at the headline size)
 constexpr int SWEEPS_PROBE_EVERY = 40;      // in two-sweep mode: every so many solves of a kind one solve runs one sweep, to compare
 // damped Jacobi sweeps on each side of the FDM stage for the next solve of this kind.  Two sweeps cut the iterations by
@@ -424,6 +432,8 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     int it = 0;
     bool done = false;
     ctx->lpFallback = false;
+    ctx->solveFail = 0;
+    *(volatile int*)(ctx->h_stall + 1) = 0;             // (ordered before this solve's kernels: the previous solve has been waited for)
     const int lpCap = 60;               // (classic loop only) mixed-precision safety net: stragglers continue with the fp64 preconditioner
     const dim3 tg((k.ny - 1 + 63) / 64, S);
     const bool fused = ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0;
@@ -466,10 +476,22 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             if ((prc = launch_back_post(ctx))) return prc;
             std::swap(k.z, k.t);
             if (it >= nextCheck || it - 1 == ctx->opt.maxit) {
+                // (a spin on host memory wakes within a microsecond; `pause` leaves the core's other hyper-thread its
+                //  cycles, and the stream is looked at every 2^16 spins: a device error, or everything done, ends the wait;
+                //  a device that makes no progress for SPIN_LIMIT_S seconds is reported instead of spinning forever)
                 long spins = 0;
+                std::chrono::steady_clock::time_point t0;
+                bool hung = false;
                 while (*(volatile int*)ctx->h_prog < it) {
-                    if ((++spins & 0xfffff) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;   // (device error / all done)
+                    __builtin_ia32_pause();
+                    if ((++spins & 0xffff) == 0) {
+                        if (hipStreamQuery(ctx->stream) != hipErrorNotReady) break;
+                        const auto now = std::chrono::steady_clock::now();
+                        if (spins == 0x10000) t0 = now;
+                        else if (std::chrono::duration<double>(now - t0).count() > SPIN_LIMIT_S) { hung = true; break; }
+                    }
                 }
+                if (hung) { ctx->err = "the device made no progress on a solve for 60 s"; return HMCMT_EHIP; }
                 if (*(volatile int*)ctx->h_prog < it) HIPCHK(hipStreamSynchronize(ctx->stream));   // reports the error, if any
                 if (it - 1 == ctx->opt.maxit) HIPCHK(hipStreamSynchronize(ctx->stream));          // (k_spmv_fused(it) itself decides the cap)
                 if (*(volatile int*)ctx->h_nactive == 0) { done = true; break; }
@@ -518,6 +540,10 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     }
     // the fused loop ping-pongs r between the caller's buffer and r2: leave the struct as it was found
     if (k.r != r_entry) { k.r2 = k.r; k.r = r_entry; }
+    // a system that hit the iteration cap or broke down has been deactivated like a converged one: "no active systems"
+    // is then not "solved" (the host learns it from the mapped failure word at the poll that ended the loop)
+    ctx->solveFail = *(volatile int*)(ctx->h_stall + 1);
+    if (ctx->solveFail) done = false;
     guess = it;        // (launched iterations; collect_stats replaces it with the iterations actually needed)
 
     ctx->solveDone[kind] = done;
@@ -572,6 +598,7 @@ void launch_adjoint_side(hmcmt_ctx* ctx) {
 int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, double* d_misfit, double* d_grad) {
     View v = ctx->v;
     v.m = d_m;
+    v.dbg = ctx->dbgFlags;
     if (d_pred) v.pred = reinterpret_cast<cplx*>(d_pred);
     if (d_grad) v.grad = d_grad;
     hipStream_t st = ctx->stream;
@@ -585,7 +612,11 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     const int nodes = v.NZP * (v.ny + 1);
     const size_t vecBytes = (size_t)S * v.vstride * sizeof(cplx);
     // initial guesses (options.warm_start): verify checks against the cold right-hand side
-    const bool warmF = ctx->opt.warm_start && ctx->haveFwd && !ctx->opt.verify;
+    // (test hook hmcmt_debug_flags bit 0: the Dirichlet values stay those of the previous evaluation -- they live in the
+    //  boundary nodes of X, so the forward solve must start from the previous fields)
+    const bool freezeBC = (ctx->dbgFlags & 1) && ctx->haveFwd;
+    if (freezeBC && ctx->opt.verify) { ctx->err = "hmcmt_debug_flags: frozen boundary values and options.verify exclude each other"; return HMCMT_EINVAL; }
+    const bool warmF = (ctx->opt.warm_start && ctx->haveFwd && !ctx->opt.verify) || freezeBC;
     const bool warmA = ctx->opt.warm_start && ctx->haveAdj && !ctx->opt.verify;
     const bool extrap = ctx->opt.warm_start == 2 && !ctx->opt.verify;
     // start of a solve on the default path: residual and first pre-smoothing pass in one launch (k_resid_pre)
@@ -617,8 +648,10 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         //           FDM background -> inverse pivots of its tridiagonals (serial, 35-85 us; the preconditioner waits)
         // The host issues them in this order (after the previous evaluation's synchronisation the order of the API
         // calls is the schedule); the side-stream work of the adjoint half follows from inside the forward solve.
-        hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, v.nFreq), dim3(64), 0, st, v);
-        hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, v.nFreq), dim3(64), 4 * (size_t)v.nz * sizeof(cplx), st, v);
+        if (!freezeBC) {
+            hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, v.nFreq), dim3(64), 0, st, v);
+            hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, v.nFreq), dim3(64), 4 * (size_t)v.nz * sizeof(cplx), st, v);
+        }
         const bool pivots = ctx->opt.precond != HMCMT_PRECOND_JACOBI;
         if (extrap) {
             // (interior nodes only -- k_bc_forward owns the boundary nodes of X)
@@ -663,6 +696,15 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     fusedStart = fusedStartOk && sweepsA == 1;
     ctx->sv.sweeps = sweepsA;
     if (!wantGrad) HIPCHK(hipEventRecord(ctx->evRec, st));          // behind the last k_solve_end
+    if (rc == 0 && ctx->solveFail) {
+        // the forward solve gave up (iteration cap / breakdown): no adjoint solve on its fields, no further leapfrog step on
+        // its gradient -- the records of k_solve_end carry the status, the caller gets it now
+        ctx->sidePending = false;
+        HIPCHK(hipEventRecord(ctx->evRec, st));
+        ctx->haveFwd = false;
+        rc = collect_stats(ctx, false);
+        return rc ? rc : finish_status(ctx);
+    }
     launch_adjoint_side(ctx);            // (no-op when the solve has already done it)
     ctx->haveFwd = (rc == 0 && ctx->solveDone[0]);
     if (rc) return rc;
@@ -692,6 +734,10 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         HIPCHK(hipEventRecord(ctx->evRec, st));                        // behind the last k_solve_end
         ctx->haveAdj = (rc == 0 && ctx->solveDone[1]);
         if (rc) return rc;
+        if (ctx->solveFail) {             // (as after the forward solve: no gradient from a failed adjoint, and the caller knows NOW)
+            rc = collect_stats(ctx, true);
+            return rc ? rc : finish_status(ctx);
+        }
         ProfScope ps(ctx, 6);
         hipLaunchKernelGGL(k_wb, dim3((v.nz + v.ny + 127) / 128, S), dim3(128), 0, st, v);
         HIPCHK(hipStreamWaitEvent(st, ctx->evSens, 0));         // sensitivity tables, boundary values, dBC (side stream)
@@ -987,9 +1033,10 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
 #undef DA
     HIPCHK(hipHostMalloc((void**)&ctx->h_nactive, sizeof(int), hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void**)&k.nactHost, ctx->h_nactive, 0));
-    HIPCHK(hipHostMalloc((void**)&ctx->h_stall, sizeof(int), hipHostMallocMapped));
-    *ctx->h_stall = 0;
+    HIPCHK(hipHostMalloc((void**)&ctx->h_stall, 2 * sizeof(int), hipHostMallocMapped));     // [0] stagnation flag, [1] failure status
+    ctx->h_stall[0] = ctx->h_stall[1] = 0;
     HIPCHK(hipHostGetDevicePointer((void**)&k.stallHost, ctx->h_stall, 0));
+    k.failHost = k.stallHost + 1;
     k.stallIt = STALL_IT;
     if (const char* es = getenv("HMCMT_STALL_IT")) k.stallIt = std::max(1, atoi(es));   // (tests force the fp64 restart with a short window)
     HIPCHK(hipHostMalloc((void**)&ctx->h_prog, sizeof(int), hipHostMallocMapped));
@@ -1057,6 +1104,7 @@ int hmcmt_set_options(hmcmt_ctx* ctx, const hmcmt_options* o) {
     ctx->lastItFwd = ctx->lastItAdj = 0;
     ctx->haveFwd = ctx->haveAdj = false;
     ctx->memo[0].valid = ctx->memo[1].valid = false;
+    ctx->lfHaveGrad = false;            // (a gradient kept for start_grad = 1 / 2 was computed under the old options)
     return 0;
 }
 
@@ -1282,6 +1330,14 @@ int hmcmt_debug_transform(hmcmt_ctx* ctx, int32_t which, const double* A, double
     launch_transform(ctx, ctx->sv.p, which ? ctx->d_Vt : ctx->d_V, ctx->sv.q, nullptr);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(C, ctx->sv.q, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int hmcmt_debug_flags(hmcmt_ctx* ctx, int32_t flags) {
+    if (!ctx || (flags & ~3)) return HMCMT_EINVAL;
+    ctx->dbgFlags = flags;
+    ctx->memo[0].valid = ctx->memo[1].valid = false;      // (stored results belong to the flags they were computed under)
+    ctx->lfHaveGrad = false;
     return 0;
 }
 

@@ -19,6 +19,7 @@ struct View {
     int ny, nz, NYP, NZP, nFreq, S, nRx, nData, nAC, nCell;
     int twist;                     // 1: twisted (two-sided) factorisation of the FDM tridiagonals, see item_pivot
     int zid;                       // node row of the receivers (mt2DTE.jl:66-67), 0-based
+    int dbg;                       // test hooks (hmcmt_debug_flags): bit 1 = leave the boundary-derivative terms B^T v out of the gradient
     long vstride;                  // NZP*NYP elements per system
     // mesh (constant)
     const double* yLen;            // [ny]
@@ -568,6 +569,7 @@ HD void item_qterm(const View& v, int s, int ky) {
 // boundary term of one system for one cell (branch-free select, not `continue`, so that the loads of several systems
 // are in flight)
 HD double gradfinal_sys(const View& v, int s, int ky, int kz) {
+    if (v.dbg & 2) return 0.0;
     const long o = (long)s * v.nz + kz;
     cplx b = v.gMn[o] * v.colw[(long)s * v.ny + ky];
     if (ky == 0) b += v.gL[o];

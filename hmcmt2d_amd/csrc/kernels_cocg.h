@@ -53,6 +53,8 @@ struct Solver {
     int stallIt;                          // iterations allowed per 10-fold drop of the error estimate (STALL_IT; HMCMT_STALL_IT)
     int* progHost;                        // pinned host word: the iteration whose k_spmv_fused has STARTED (host throttle, see solve())
     int* stallHost;                       // pinned host flag: a system has not improved its error estimate 10-fold in STALL_IT iterations
+    int* failHost;                        // pinned host word: status (HMCMT_ENOCONV / HMCMT_EBREAKDOWN) of a system that has just given up --
+                                          // the host must not build on this solve (adjoint on a failed forward, next leapfrog step)
     unsigned long long* cntActive;        // non-null in an evaluation sampled by hmcmt_profile: += systems still active per iteration
 };
 
@@ -255,11 +257,11 @@ __global__ void k_check(Solver k, const double* partZZ, int first, int maxit) {
             else {
                 k.alphaBeta[s] = rz / k.rho[s];
                 k.rho[s] = rz;
-                if (k.iters[s] >= maxit) { on = false; k.status[s] = HMCMT_ENOCONV; }
+                if (k.iters[s] >= maxit) { on = false; k.status[s] = HMCMT_ENOCONV; *k.failHost = HMCMT_ENOCONV; }
             }
         }
         if (!(isfinite(rz.re) && isfinite(rz.im) && isfinite(zz) && isfinite(xx))) {
-            on = false; k.status[s] = HMCMT_EBREAKDOWN;
+            on = false; k.status[s] = HMCMT_EBREAKDOWN; *k.failHost = HMCMT_EBREAKDOWN;
         }
         if (!on) k.active[s] = 0;
         else atomicAdd(&cnt, 1);

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
         k.iters[s] = it - 1;
         const double est = first ? (zz == 0.0 ? 0.0 : 1.0) : sqrt(zz / xx);
         k.errEst[s] = est;
-        if (st) k.status[s] = st;
+        if (st) { k.status[s] = st; *k.failHost = st; }
         // stagnation watch (the host restarts the stragglers with the fp64 preconditioner when it fires)
         if (first || est < 0.1 * k.errRef[s]) { k.errRef[s] = est; k.errRefIt[s] = it; }
         else if (on && it - k.errRefIt[s] > k.stallIt) *k.stallHost = 1;

@@ -104,6 +104,7 @@ def load_library():
     lib.hmcmt_profile_counters.argtypes = [vp, c_int64_p]
     lib.hmcmt_dims.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.hmcmt_debug_transform.argtypes = [vp, C.c_int32, c_double_p, c_double_p]
+    lib.hmcmt_debug_flags.argtypes = [vp, C.c_int32]
     lib.hmcmt_debug_spmv.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_precond.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_fdm_fwd.argtypes = [vp, c_double_p, c_double_p]
@@ -111,7 +112,7 @@ def load_library():
     for name in ("hmcmt_create", "hmcmt_destroy", "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters",
                  "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async",
                  "hmcmt_wait", "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters",
-                 "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond",
+                 "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond",
                  "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
@@ -122,7 +123,7 @@ EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "h
                     "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters", "hmcmt_grad", "hmcmt_forward",
                     "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async", "hmcmt_wait",
                     "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_dims",
-                    "hmcmt_debug_transform", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
+                    "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
                     "hmcmt_debug_back_post"]
 
 
@@ -252,7 +253,7 @@ class HipContext:
         self._check(self.lib.hmcmt_leapfrog(self.h, _dp(m0), _dp(p0), dt, L, regParam, lnSigMin, lnSigMax,
                                             _dp(m1), _dp(p1), _dp(pred), C.byref(mis), C.byref(mnorm),
                                             C.byref(nf)))
-        return m1, p1, pred, mis.value, mnorm.value, nf.value
+        return m1, p1, (pred.real.copy() if self.args.real_data else pred), mis.value, mnorm.value, nf.value
 
     def leapfrog_device(self, d_m, d_p, dt, L, regParam, lnSigMin, lnSigMax, start_grad=0, d_pred=None, d_misfit=None,
                         d_mnorm=None):
@@ -313,6 +314,11 @@ class HipContext:
         Cc = np.empty_like(A)
         self._check(self.lib.hmcmt_debug_transform(self.h, which, _dp(A), _dp(Cc)))
         return Cc
+
+    def debug_flags(self, freeze_boundary=False, no_boundary_terms=False):
+        """Test hook (include/hmcmt.h): hold the Dirichlet values at the previous evaluation's / leave dBC^T w out of the gradient."""
+        self._cache = None
+        self._check(self.lib.hmcmt_debug_flags(self.h, (1 if freeze_boundary else 0) | (2 if no_boundary_terms else 0)))
 
     def debug_spmv(self, p):
         p = self._vec(p)

@@ -29,9 +29,10 @@ _contexts: dict = {}          # (id(invParam), device) -> HipContext; entries di
 
 
 def default_device() -> int:
-    """The GPU of this process: LOCAL_RANK under torch.distributed.run / torchrun (one process per GPU), else
-    HMCMT_DEVICE, else 0.  The reference's counterpart is the worker id of `pmap` (parallelHMC.jl:23-40)."""
-    for var in ("LOCAL_RANK", "HMCMT_DEVICE"):
+    """The GPU of this process: an explicit HMCMT_DEVICE first (the same precedence as julia/HMCMTHip.jl's
+    defaultDevice), else LOCAL_RANK under torch.distributed.run / torchrun (one process per GPU), else 0.  The
+    reference's counterpart is the worker id of `pmap` (parallelHMC.jl:23-40)."""
+    for var in ("HMCMT_DEVICE", "LOCAL_RANK"):
         v = os.environ.get(var)
         if v not in (None, ""):
             return int(v)
@@ -202,27 +203,61 @@ def proposeLeapfrogDevice(hmcParamCurrent: HMCParameter, mtMesh, mtData, invPara
     return m1, p1
 
 
-def _save_checkpoint(path, it, hmcmodel, hmcdata, stats, cur, start, rng, invParam, hmcprior):
-    """Everything the loop of runHMCSampler carries from one sample to the next, written atomically."""
+def _run_fingerprint(invParam, hmcprior, shape):
+    """What a checkpoint belongs to: sizes, sampler settings, data, weights and reference model (sha256)."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(np.asarray(shape, dtype=np.int64).tobytes())
+    h.update(np.asarray([hmcprior.dt, hmcprior.regParam, *hmcprior.timestep, *hmcprior.sigBounds], dtype=np.float64).tobytes())
+    for a in (invParam.obsData, invParam.dataW, invParam.refModel):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def _save_checkpoint(path, it, done, hmcmodel, hmcdata, stats, cur, start, rng, invParam, hmcprior):
+    """Flushes samples `done + 1 .. it` and the loop state.  Two files: `path + ".samples"`, append-only records of one
+    sample each (model column, predicted-data column) -- a flush writes only the new samples, so a run costs O(N) I/O,
+    not O(N^2 / k) -- and `path`, the small state (counters, statistics, current model / momentum, RNG state, the run's
+    fingerprint), replaced atomically AFTER the samples are on disk (flush + fsync before os.replace; a crash between
+    the two leaves surplus records that a resume ignores)."""
     import json
     import os
+    with open(path + ".samples", "r+b" if os.path.exists(path + ".samples") else "w+b") as f:
+        rec = (hmcmodel.shape[0] + 2 * hmcdata.shape[0]) * 8
+        f.seek(done * rec)
+        f.truncate()
+        for j in range(done + 1, it + 1):
+            f.write(np.ascontiguousarray(hmcmodel[:, j - 1]).tobytes())
+            f.write(np.ascontiguousarray(hmcdata[:, j]).tobytes())
+        f.flush()
+        os.fsync(f.fileno())
     tmp = path + ".tmp"
     with open(tmp, "wb") as f:
-        np.savez(f, it=it, hmcmodel=hmcmodel[:, :it], hmcdata=hmcdata[:, :it + 1], hmstats=stats.hmstats[:, :it + 1],
+        np.savez(f, it=it, data0=hmcdata[:, 0], hmstats=stats.hmstats[:, :it + 1],
                  acceptstats=stats.acceptstats[:it], counts=np.array([stats.nAccept, stats.nReject, hmcprior.nfevals]),
-                 rhomodel=cur.rhomodel, momentum=cur.momentum, start=np.array(start), refModel=invParam.refModel,
-                 shape=np.array(hmcmodel.shape), rng=np.array(json.dumps(rng.bit_generator.state)))
+                 rhomodel=cur.rhomodel, momentum=cur.momentum, start=np.array(start),
+                 fingerprint=np.array(_run_fingerprint(invParam, hmcprior, hmcmodel.shape)),
+                 rng=np.array(json.dumps(rng.bit_generator.state)))
+        f.flush()
+        os.fsync(f.fileno())
     os.replace(tmp, path)
 
 
 def _load_checkpoint(path, hmcmodel, hmcdata, stats, cur, rng, invParam, hmcprior):
     import json
     with np.load(path) as g:
-        if tuple(g["shape"]) != hmcmodel.shape or not np.array_equal(g["refModel"], invParam.refModel):
-            raise ValueError(f"{path}: checkpoint of a different run (sizes or reference model differ)")
+        if str(g["fingerprint"]) != _run_fingerprint(invParam, hmcprior, hmcmodel.shape):
+            raise ValueError(f"{path}: checkpoint of a different run (sizes, dt / timestep / regParam / sigBounds, data, "
+                             "weights or reference model differ)")
         it = int(g["it"])
-        hmcmodel[:, :it] = g["hmcmodel"]
-        hmcdata[:, :it + 1] = g["hmcdata"]
+        nparam, ndata = hmcmodel.shape[0], hmcdata.shape[0]
+        raw = np.fromfile(path + ".samples", dtype=np.float64, count=it * (nparam + 2 * ndata))
+        if raw.size != it * (nparam + 2 * ndata):
+            raise ValueError(f"{path}.samples holds fewer than the {it} samples the state file records")
+        raw = raw.reshape(it, nparam + 2 * ndata)
+        hmcmodel[:, :it] = raw[:, :nparam].T
+        hmcdata[:, 1:it + 1] = raw[:, nparam:].copy().view(np.complex128).T
+        hmcdata[:, 0] = g["data0"]
         stats.hmstats[:, :it + 1] = g["hmstats"]
         stats.acceptstats[:it] = g["acceptstats"]
         stats.nAccept, stats.nReject, hmcprior.nfevals = (int(c) for c in g["counts"])
@@ -241,7 +276,11 @@ def runHMCSampler(mtMesh, mtData, invParam, hmcprior, rng=None, rhoref=None, ctx
     model and momentum, the RNG state -- is flushed every k samples; if the file exists when the sampler starts, the
     chain RESUMES behind its last flushed sample and draws the same random numbers an uninterrupted run would have
     (the reference keeps every sample in memory until the chain ends, HMCSampler.jl:785-828: a crash loses the run;
-    SURVEY section 5 lists this as the one piece of fault tolerance worth adding)."""
+    SURVEY section 5 lists this as the one piece of fault tolerance worth adding).  The resumed chain is the
+    uninterrupted chain to solver tolerance, not bit for bit, on a real GPU context: the iterative solves of the first
+    resumed trajectory start cold instead of from the interrupted run's field history (bit-identical with a
+    deterministic direct-solve context, tests/test_host.py).  A checkpoint of a different run -- other sizes, dt,
+    timestep, regParam, sigBounds, data, weights or reference model -- is refused."""
     _check_solver(hmcprior)
     rng = rng or np.random.default_rng()
     ctx = ctx or get_context(mtMesh, mtData, invParam, device_id=device_id)
@@ -274,12 +313,14 @@ def runHMCSampler(mtMesh, mtData, invParam, hmcprior, rng=None, rhoref=None, ctx
     stats.hmstats[:, 0] = [startD, startM, startK, startH]
     hmcdata[:, 0] = predData
     first = 1
+    flushed = 0
     if checkpoint:
         import os
         if os.path.exists(checkpoint):
             done, (startD, startM, startK, startH) = _load_checkpoint(checkpoint, hmcmodel, hmcdata, stats, cur, rng,
                                                                       invParam, hmcprior)
             first = done + 1
+            flushed = done
             if verbose:
                 print(f"resuming behind sample {done} of {nsamples} ({checkpoint})")
     for it in range(first, nsamples + 1):
@@ -309,8 +350,9 @@ def runHMCSampler(mtMesh, mtData, invParam, hmcprior, rng=None, rhoref=None, ctx
         stats.hmstats[:, it] = [startD, startM, startK, startH]
         hmcmodel[:, it - 1] = cur.rhomodel
         if checkpoint and checkpoint_every > 0 and (it % checkpoint_every == 0 or it == nsamples):
-            _save_checkpoint(checkpoint, it, hmcmodel, hmcdata, stats, cur, (startD, startM, startK, startH), rng,
+            _save_checkpoint(checkpoint, it, flushed, hmcmodel, hmcdata, stats, cur, (startD, startM, startK, startH), rng,
                              invParam, hmcprior)
+            flushed = it
     return hmcmodel, stats, hmcdata
 
 

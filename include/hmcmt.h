@@ -60,8 +60,10 @@ typedef struct hmcmt_options {
                              The default path looks at a mapped counter once per iteration without waiting */
     int32_t verify;       /* 1: also compute true relative residuals ||b-Ax||/||b|| after each solve */
     int32_t warm_start;   /* initial guess of both solves: 0 zero, 1 the previous evaluation's fields, 2 (default) those
-                             fields extrapolated along the model path from the last two or three evaluations (leapfrog
-                             trajectories are nearly straight lines at nearly constant speed) */
+                             fields extrapolated along the model path from up to the last six evaluations (Lagrange
+                             extrapolation over the nearly collinear part of the history; leapfrog trajectories are nearly
+                             straight lines at nearly constant speed).  The adjoint solve starts from zero unless at least
+                             three collinear points exist */
     int32_t fdm_precision;/* 0 (default): bf16 transforms (fp32 accumulate) + complex64 tridiagonal inside the
                              preconditioner; 1: fp64 throughout.  x, r, p and all inner products are fp64 either way */
 } hmcmt_options;
@@ -74,7 +76,8 @@ typedef struct hmcmt_stats {
     int32_t status;                         /* 0 or HMCMT_ENOCONV / HMCMT_EBREAKDOWN */
     int32_t nsystems;                       /* 2*nFreq */
     int32_t fallback_solves;                /* solves of the last call (0..2) whose stragglers were restarted with the fp64
-                                               preconditioner after 60 mixed-precision iterations */
+                                               preconditioner because the device's stagnation watch fired (a system that did
+                                               not improve its error estimate 10-fold within 30 iterations) */
     int32_t smoother_sweeps;                /* damped Jacobi sweeps on each side of the FDM stage in the last call: 10 * (forward
                                                solve) + (adjoint solve), e.g. 11 or 22; chosen per solve unless HMCMT_SWEEPS is
                                                set (was `reserved_`: same offset, same size) */
@@ -157,9 +160,10 @@ int hmcmt_leapfrog(hmcmt_ctx* ctx, const double* m0, const double* p0, double dt
  *      HMCSampler.jl:155-163): its gradient is still on the device -- L new evaluations instead of L + 1;
  *   2  the start model is the START model of the previous trajectory (the proposal was rejected, :164-168).
  * d_pred complex[nData], d_misfit, d_mnorm (device, each may be NULL) receive the proposal's predicted data, data
- * misfit and 0.5*lambda*(m-mref)'Wm(m-mref).  Returns when the trajectory is ENQUEUED and the solver status of all its
- * evaluations but the last has been checked; hmcmt_wait completes it (and reports the last evaluation's status and a
- * non-finite model met on the way).  nfevals counts as the reference does (L + 1). */
+ * misfit and 0.5*lambda*(m-mref)'Wm(m-mref).  Returns when the whole trajectory is enqueued and the solver status of
+ * every evaluation -- the last one included: the call waits for its two solves' records, not for the gradient assembly,
+ * the final momentum update and the Hamiltonian terms queued behind them -- has been checked; hmcmt_wait completes it
+ * (and reports a non-finite model met on the way).  nfevals counts as the reference does (L + 1). */
 int hmcmt_leapfrog_device(hmcmt_ctx* ctx, double* d_m, double* d_p, double dt, int32_t L, double regParam,
                           double lnSigMin, double lnSigMax, int32_t start_grad, double* d_pred, double* d_misfit,
                           double* d_mnorm, int32_t* nfevals);
@@ -194,6 +198,12 @@ int hmcmt_dims(const hmcmt_ctx* ctx, int32_t* out);
  *   A, C: host complex[S*NZP*NYP] in the padded nodal layout.
  * hmcmt_debug_spmv: q = A_s p for all systems at the model of the last evaluation. */
 int hmcmt_debug_transform(hmcmt_ctx* ctx, int32_t which, const double* A, double* C);
+/* hmcmt_debug_flags (for the gradient pin, tests/test_gradient_pin.py): bit 0 -- the Dirichlet values of all four sides
+ *   (mt2DTE.jl:100-134, mt2DTM.jl:100-134) are NOT recomputed from the model but stay those of the previous evaluation;
+ *   bit 1 -- the boundary-derivative terms dBC^T w (compJacTMatVec.jl:237-242, :309-313, :316) are left out of the
+ *   gradient.  A frozen-boundary finite difference of the misfit must then equal the gradient with bit 1 set.
+ *   0 restores the product behaviour; stored results of earlier calls are dropped. */
+int hmcmt_debug_flags(hmcmt_ctx* ctx, int32_t flags);
 int hmcmt_debug_spmv(hmcmt_ctx* ctx, const double* p, double* q);
 int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z);
 int hmcmt_debug_fdm_fwd(hmcmt_ctx* ctx, const double* t, double* out);   /* [2][S*vstride] complex: fused kernel | separate kernels */

@@ -26,7 +26,8 @@ using SparseArrays
 using Distributed              # myid
 using HMCMT.HMCFileIO, HMCMT.HMCStruct, HMCMT.HMCUtility
 
-export HipContext, hipContext, compDataGradient, hipForward, setPrior!, proposeLeapfrog, hipStats, destroy!
+export HipContext, hipContext, compDataGradient, hipForward, setPrior!, proposeLeapfrog, proposeLeapfrogDevice!,
+       hipWait, hipStats, destroy!
 
 const libhmcmt = get(ENV, "HMCMT_HIP_LIB", joinpath(@__DIR__, "..", "hmcmt2d_amd", "libhmcmt_hip.so"))
 
@@ -59,7 +60,24 @@ mutable struct HipContext
     nAC::Int
     nData::Int
     device::Int
-    havePrior::Bool
+    realData::Bool          # DataType Rho_Pha: the reference's obsData / predData are real vectors
+end
+
+# component codes of include/hmcmt.h (the same table as hmcmt2d_amd/marshal.py COMPONENT_CODES; tests/test_abi.py compares them)
+const COMPONENT_CODES = Dict("ZXY" => 1, "ZYX" => 2, "RhoXY" => 3, "PhsXY" => 4, "RhoYX" => 5, "PhsYX" => 6)
+
+function compModes(dataComp, dataType::AbstractString)
+    isimp = occursin("Impedance", dataType)
+    (isimp || occursin("Rho_Pha", dataType) || occursin("Rho_Phs", dataType)) ||
+        error("unsupported DataType $dataType (Impedance or Rho_Pha)")
+    out = Int64[]
+    for c in dataComp
+        haskey(COMPONENT_CODES, c) || error("unsupported data component $c (log10Rho*: the reference's forward and sensitivity disagree on it)")
+        code = COMPONENT_CODES[c]
+        (code <= 2) == isimp || error("data component $c does not belong to DataType $dataType")
+        push!(out, code)
+    end
+    return out
 end
 
 function checkerr(ctx::Ptr{Cvoid}, rc::Cint)
@@ -87,10 +105,9 @@ Builds the GPU context once per run (replaces the operator set-up the reference 
 call: setupTensorMesh2D!, getBoundaryIndex, preSetRxFieldSens).
 """
 function hipContext(mtMesh::TensorMesh2D, mtData::MTData, invParam::InvDataModel; device::Integer=defaultDevice())
-    occursin("Impedance", mtData.dataType) || error("only DataType Impedance is supported")
     ny, nz = mtMesh.gridSize
-    compMode = Int64[occursin("XY", c) ? 1 : (occursin("YX", c) ? 2 : error("unsupported component $c"))
-                     for c in mtData.dataComp]
+    compMode = compModes(mtData.dataComp, mtData.dataType)
+    realData = !occursin("Impedance", mtData.dataType)
     rxY = Vector{Float64}(mtData.rxLoc[:, 1]); rxZ = Vector{Float64}(mtData.rxLoc[:, 2])
     dataID = Vector{UInt8}(mtData.dataID)
     obs = Vector{ComplexF64}(invParam.obsData)
@@ -115,7 +132,7 @@ function hipContext(mtMesh::TensorMesh2D, mtData::MTData, invParam::InvDataModel
                dataID, obs, dataW,
                length(activeIdx), activeIdx, invParam.bgModel, C_NULL)
     checkerr(C_NULL, rc)
-    ctx = HipContext(ctxref[], length(activeIdx), length(obs), Int(device), false)
+    ctx = HipContext(ctxref[], length(activeIdx), length(obs), Int(device), realData)
     finalizer(destroy!, ctx)
     return ctx
 end
@@ -148,7 +165,7 @@ function compDataGradient(mtMesh::TensorMesh2D, mtData::MTData, invParam::InvDat
     checkerr(ctx.ptr, rc)
     # keep mtMesh.sigma in the state the reference leaves it in (HMCSampler.jl:293-294)
     mtMesh.sigma = invParam.activeCell * exp.(m) + invParam.bgModel
-    return pred, misfit[], grad
+    return (ctx.realData ? real.(pred) : pred), misfit[], grad
 end
 
 """
@@ -164,16 +181,19 @@ function hipForward(mtMesh::TensorMesh2D, mtData::MTData, invParam::InvDataModel
                (Ptr{Cvoid}, Ptr{Float64}, Ptr{ComplexF64}, Ref{Float64}),
                ctx.ptr, invParam.strModel, pred, misfit)
     checkerr(ctx.ptr, rc)
-    return pred, misfit[]
+    return (ctx.realData ? real.(pred) : pred), misfit[]
 end
 
 """
     setPrior!(ctx, invParam, hmcParam)
 
 Registers the prior (refModel, Wm) and the diagonal of M^-1 for device-resident trajectories (hmcmt_set_prior).
-Wm is symmetric, so its CSC arrays are its CSR arrays; they go over 0-based.
+Wm is symmetric, so its CSC arrays are its CSR arrays; they go over 0-based.  Only the reference's default, diagonal
+mass matrix is supported (setMassMatrix's dense option, HMCSampler.jl:478-489, is refused, not silently truncated).
 """
 function setPrior!(ctx::HipContext, invParam::InvDataModel, hmcParam::HMCParameter)
+    (hmcParam.invM isa Diagonal || isdiag(hmcParam.invM)) ||
+        error("HMCMTHip: only diagonal mass matrices are supported on the device (masstype: diagonal)")
     Wm = invParam.Wm
     rowptr = Vector{Int64}(Wm.colptr .- 1)
     colind = Vector{Int64}(Wm.rowval .- 1)
@@ -183,7 +203,6 @@ function setPrior!(ctx::HipContext, invParam::InvDataModel, hmcParam::HMCParamet
                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}),
                ctx.ptr, invParam.refModel, rowptr, colind, val, invM)
     checkerr(ctx.ptr, rc)
-    ctx.havePrior = true
     return ctx
 end
 
@@ -198,7 +217,9 @@ evaluations, the momentum / position updates, the step clamp and the bound refle
 function proposeLeapfrog(hmcParamCurrent::HMCParameter, mtMesh::TensorMesh2D, mtData::MTData,
                          invParam::InvDataModel, hmcprior::HMCPrior)
     ctx = getctx(mtMesh, mtData, invParam)
-    ctx.havePrior || setPrior!(ctx, invParam, hmcParamCurrent)
+    # every trajectory: runHMCSampler re-randomises invParam.refModel on each run (HMCSampler.jl:100-109) and the mass
+    # matrix may change between runs; the upload is O(nnz(Wm)), nothing beside a trajectory
+    setPrior!(ctx, invParam, hmcParamCurrent)
     intstep = rand(hmcprior.timestep[1]:hmcprior.timestep[2])          # unirandInteger (HMCUtility.jl)
     n = ctx.nAC
     m1 = Vector{Float64}(undef, n); p1 = Vector{Float64}(undef, n)
@@ -216,6 +237,29 @@ function proposeLeapfrog(hmcParamCurrent::HMCParameter, mtMesh::TensorMesh2D, mt
     mtMesh.sigma = invParam.activeCell * exp.(m1) + invParam.bgModel
     return m1, p1
 end
+
+"""
+    proposeLeapfrogDevice!(ctx, d_m, d_p, dt, L, regParam, lnSigMin, lnSigMax; startGrad=0,
+                           d_pred=C_NULL, d_misfit=C_NULL, d_mnorm=C_NULL) -> nfevals
+
+hmcmt_leapfrog_device for callers that keep the chain state in GPU memory (e.g. AMDGPU.jl `ROCArray`s: pass
+`pointer(a)`): d_m, d_p are updated in place, nothing crosses PCIe; complete with `hipWait(ctx)`.  `startGrad` as in
+include/hmcmt.h (0 evaluate, 1 previous proposal accepted, 2 rejected).  Call `setPrior!` first.
+"""
+function proposeLeapfrogDevice!(ctx::HipContext, d_m::Ptr, d_p::Ptr, dt::Real, L::Integer, regParam::Real,
+                                lnSigMin::Real, lnSigMax::Real; startGrad::Integer=0,
+                                d_pred::Ptr=C_NULL, d_misfit::Ptr=C_NULL, d_mnorm::Ptr=C_NULL)
+    nf = Ref{Int32}(0)
+    rc = ccall((:hmcmt_leapfrog_device, libhmcmt), Cint,
+               (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int32, Float64, Float64, Float64, Int32,
+                Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}),
+               ctx.ptr, d_m, d_p, Float64(dt), Int32(L), Float64(regParam), Float64(lnSigMin), Float64(lnSigMax),
+               Int32(startGrad), d_pred, d_misfit, d_mnorm, nf)
+    checkerr(ctx.ptr, rc)
+    return Int(nf[])
+end
+
+hipWait(ctx::HipContext) = checkerr(ctx.ptr, ccall((:hmcmt_wait, libhmcmt), Cint, (Ptr{Cvoid},), ctx.ptr))
 
 """
     hipStats(ctx) -> HmcmtStats   (iteration counts, error estimate, fallback counter of the last call)

@@ -379,7 +379,7 @@ class CoeffMat:
     iAio: object
 
 
-def _compMT2D(freq, mesh, coeMat, rxLoc, dataType, mode, keep=None):
+def _compMT2D(freq, mesh, coeMat, rxLoc, dataType, mode, keep=None, bc_fixed=None):
     yLen, zLen, origin, sigma = mesh.yLen, mesh.zLen, mesh.origin, mesh.sigma
     yNode = np.concatenate([[0.0], np.cumsum(yLen)]) - origin[0]
     zNode = np.concatenate([[0.0], np.cumsum(zLen)]) - origin[1]
@@ -388,6 +388,8 @@ def _compMT2D(freq, mesh, coeMat, rxLoc, dataType, mode, keep=None):
     Aii = (coeMat.rAii + 1j * omega * coeMat.iAii).tocsc()
     Aio = (coeMat.rAio + 1j * omega * coeMat.iAio).tocsr()
     bc = _getBoundaryMT2D(freq, yLen, zLen, sigma, mode)
+    if bc_fixed is not None:              # (test hook, not in the reference: Dirichlet values held at another model's,
+        bc = bc_fixed[(mode, freq)]       #  for the frozen-boundary finite differences of tests/test_gradient_pin.py)
     rhs = -(Aio @ bc)
     Ainv = spla.splu(Aii)                 # `lu(Aii)` (mt2DTE.jl:48) -> SuperLU here
     Fii = Ainv.solve(rhs)
@@ -425,7 +427,7 @@ class MT2DFwdData:
     linearSolver: str
 
 
-def MT2DFwdSolver(mesh: TensorMesh2D, mtData: MTData, linearSolver="", keep=None):
+def MT2DFwdSolver(mesh: TensorMesh2D, mtData: MTData, linearSolver="", keep=None, bc_fixed=None):
     """MT2DFwdSolver.jl:74-216."""
     yLen, zLen, sigma = mesh.yLen, mesh.zLen, mesh.sigma
     freqs, rxLoc, dataType = mtData.freqs, mtData.rxLoc, mtData.dataType
@@ -448,7 +450,7 @@ def MT2DFwdSolver(mesh: TensorMesh2D, mtData: MTData, linearSolver="", keep=None
         coe = CoeffMat(dGrad[ii][:, ii], MsigCN[ii][:, ii], dGrad[ii][:, io], MsigCN[ii][:, io])
         respTE = np.zeros((nFreq * nRx, 2))
         for j in range(nFreq):
-            r, exte[:, j], AinvTE[j] = _compMT2D(freqs[j], mesh, coe, rxLoc, dataType, "TE", keep)
+            r, exte[:, j], AinvTE[j] = _compMT2D(freqs[j], mesh, coe, rxLoc, dataType, "TE", keep, bc_fixed)
             respTE[j * nRx:(j + 1) * nRx, :] = r
     if mtData.compTM:
         MmuCN = sdiag(AveCN @ (F @ mu))
@@ -457,7 +459,7 @@ def MT2DFwdSolver(mesh: TensorMesh2D, mtData: MTData, linearSolver="", keep=None
         coe = CoeffMat(dGrad[ii][:, ii], MmuCN[ii][:, ii], dGrad[ii][:, io], MmuCN[ii][:, io])
         respTM = np.zeros((nFreq * nRx, 2))
         for j in range(nFreq):
-            r, hxtm[:, j], AinvTM[j] = _compMT2D(freqs[j], mesh, coe, rxLoc, dataType, "TM", keep)
+            r, hxtm[:, j], AinvTM[j] = _compMT2D(freqs[j], mesh, coe, rxLoc, dataType, "TM", keep, bc_fixed)
             respTM[j * nRx:(j + 1) * nRx, :] = r
 
     if "Impedance" in dataType:                       # :175-189

@@ -1,6 +1,12 @@
 import os
 import sys
 
+# The oracle's sparse direct solves (SuperLU) call BLAS on small supernodes: a multi-threaded BLAS gains nothing there and,
+# when anything else runs on the machine, its spinning worker threads cost 50x (measured: 4 s -> 300 s for one test).
+# One thread per process, set before numpy / scipy load their BLAS.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,0 +1,38 @@
+"""Generates tests/golden/cfg2_chain.npz: a 200-sample HMC chain of the ORACLE (direct solves) on BASELINE configs[1]
+(50x25-cell mesh, 8 frequencies, TE+TM; observations of cfg2.npz) with the sampler settings of the reference's
+examples (dt = 0.03, L in [6, 10], lambda = 1, bounds rho in [1, 1e4] ohm-m: examples/dprism3d/startupfile:3-8),
+homogeneous 100 ohm-m start / reference model, numpy Generator seed 2025.  About ten minutes on one core:
+`python tests/golden/make_chain.py`.  Stored: the Hamiltonian terms and accept flags of every sample (float64), the
+samples as float32, their mean and standard deviation (float64) -- what tests/test_gpu_posterior.py holds the HIP
+sampler to (north star: "posterior means/variances match the reference CPU path on the same synthetic model")."""
+import copy
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+NSAMPLES, SEED, RHOREF = 200, 2025, 100.0
+
+
+def chain_prior():
+    from hmcmt2d_amd.structs import HMCPrior
+    return HMCPrior(totalsamples=NSAMPLES, burninsamples=50, dt=0.03, timestep=[6, 10], sigBounds=[1e-4, 1.0], regParam=1.0)
+
+
+if __name__ == "__main__":
+    from oracle import hmcmt_oracle as O
+    from tests.helpers import make_problem
+    mesh, data, inv, _ = make_problem("cfg2")
+    O.setupTensorMesh2D(mesh)
+    prior = chain_prior()
+    t0 = time.time()
+    hm, st, hd = O.runHMCSampler(mesh, data, copy.deepcopy(inv), prior, np.random.default_rng(SEED), rhoref=RHOREF, dense_dbc=False)
+    print("chain done in %.0f s: accepted %d of %d, nfevals %d, misfit %.1f -> %.1f" % (
+        time.time() - t0, st["nAccept"], NSAMPLES, prior.nfevals, st["hmstats"][0, 0], st["hmstats"][0, -1]))
+    np.savez_compressed(os.path.join(HERE, "cfg2_chain.npz"), hmstats=st["hmstats"], acceptstats=st["acceptstats"],
+                        samples32=hm.astype(np.float32), mean=hm.mean(1), std=hm.std(1), nfevals=prior.nfevals,
+                        first=hm[:, :5], last=hm[:, -1], data_last=hd[:, -1])

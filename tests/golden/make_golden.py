@@ -1,5 +1,5 @@
 """Generates the golden vectors tests/golden/*.npz with the oracle (run in the build
-container: `python tests/golden/make_golden.py [names...]`; names: tiny cfg2 cfg1 cfg3s dprism3d coprod2 rhophase).  Inputs: BASELINE.json-style synthetic configs
+container: `python tests/golden/make_golden.py [names...]`; names: tiny cfg2 cfg1 cfg3s cfg3 cfg5s dprism3d coprod2 rhophase).  Inputs: BASELINE.json-style synthetic configs
 (hmcmt2d_amd/synthetic.py), observed data = oracle forward of the true model + 3 % seeded noise,
 evaluation state m = ln(0.01) + 0.3 N(0,1) (seed 1).  Outputs: predData, misfit, gradient, the
 receiver-row fields and (tiny only) every intermediate term of J^T v.
@@ -98,6 +98,64 @@ def make_cfg3_subset():
     print("cfg3s misfit", misfit, misfit2, "file kB", os.path.getsize(os.path.join(HERE, "cfg3s.npz")) // 1024)
 
 
+def make_cfg3_full():
+    """BASELINE configs[2] in full: the headline mesh, ALL 16 frequencies, TE+TM, on the observations of cfg3s.npz
+    (`obs16`/`err16`): oracle pred / misfit / gradient at the rough bench state and at the true model, plus the
+    receiver-row fields of every frequency.  (About a minute of oracle time.)"""
+    mesh, data, sig_true = S.make_config("cfg3")
+    O.setupTensorMesh2D(mesh)
+    g = np.load(os.path.join(HERE, "cfg3s.npz"))
+    obs, err = g["obs16"], g["err16"]
+    ny, nz = mesh.gridSize
+    nair = len(mesh.airLayer)
+    mesh.sigma = np.concatenate([np.full(ny * nair, S.SIG_AIR), np.full(ny * (nz - nair), 0.01)])
+    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, obs, err)
+    m = S.rough_state(len(inv.strModel))
+    inv.strModel = m.copy()
+    keep = {}
+    pred, misfit, grad = O.compDataGradient(mesh, data, inv, HMCPrior(), False, keep)
+    rows = slice(nair * (ny + 1), (nair + 2) * (ny + 1))
+    out = dict(obs=obs, err=err, m=m, pred=pred, misfit=misfit, grad=grad, exTE_rx=keep["exTE"][rows, :], hxTM_rx=keep["hxTM"][rows, :])
+    m_true = np.log(sig_true[inv.activeIdx])
+    inv.strModel = m_true.copy()
+    pred2, misfit2, grad2 = O.compDataGradient(mesh, data, inv, HMCPrior(), False)
+    out.update(pred_true=pred2, misfit_true=misfit2, grad_true=grad2)
+    np.savez_compressed(os.path.join(HERE, "cfg3.npz"), **out)
+    print("cfg3 misfit", misfit, misfit2, "file kB", os.path.getsize(os.path.join(HERE, "cfg3.npz")) // 1024)
+
+
+CFG5_FIDX = np.array([0, 16, 31])
+
+
+def make_cfg5_subset():
+    """BASELINE configs[4]'s mesh (400x200 cells + 7 air rows, 82 194 unknowns per system) with 3 of its 32
+    frequencies (100, 0.59, 0.01 Hz), TE+TM: oracle pred / misfit / gradient at the rough state and at the true model.
+    Observations = oracle forward of the true model at these frequencies + seeded noise."""
+    mesh, data32, sig_true = S.make_config("cfg5")
+    O.setupTensorMesh2D(mesh)
+    data = S.make_data_layout(data32.freqs[CFG5_FIDX], data32.rxLoc[:, 0])
+    mesh.sigma = sig_true.copy()
+    pred_t, _ = O.MT2DFwdSolver(mesh, data)
+    obs, err = S.noisy_observations(pred_t)
+    ny, nz = mesh.gridSize
+    nair = len(mesh.airLayer)
+    mesh.sigma = np.concatenate([np.full(ny * nair, S.SIG_AIR), np.full(ny * (nz - nair), 0.01)])
+    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, obs, err)
+    m = S.rough_state(len(inv.strModel))
+    inv.strModel = m.copy()
+    keep = {}
+    pred, misfit, grad = O.compDataGradient(mesh, data, inv, HMCPrior(), False, keep)
+    rows = slice(nair * (ny + 1), (nair + 2) * (ny + 1))
+    out = dict(fidx=CFG5_FIDX, obs=obs, err=err, m=m, pred=pred, misfit=misfit, grad=grad,
+               exTE_rx=keep["exTE"][rows, :], hxTM_rx=keep["hxTM"][rows, :])
+    m_true = np.log(sig_true[inv.activeIdx])
+    inv.strModel = m_true.copy()
+    pred2, misfit2, grad2 = O.compDataGradient(mesh, data, inv, HMCPrior(), False)
+    out.update(pred_true=pred2, misfit_true=misfit2, grad_true=grad2)
+    np.savez_compressed(os.path.join(HERE, "cfg5s.npz"), **out)
+    print("cfg5s misfit", misfit, misfit2, "file kB", os.path.getsize(os.path.join(HERE, "cfg5s.npz")) // 1024)
+
+
 def make_rho_phase():
     """tiny config with DataType Rho_Pha (apparent resistivity + phase of both polarisations, a tenth of the data
     masked out): observations = oracle response of the true model + 5 % / 1.5 degree noise."""
@@ -160,7 +218,7 @@ def make_example(name):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or ["tiny", "cfg2", "cfg1", "cfg3s", "dprism3d", "coprod2", "rhophase"]
+    names = sys.argv[1:] or ["tiny", "cfg2", "cfg1", "cfg3s", "cfg3", "cfg5s", "dprism3d", "coprod2", "rhophase"]
     for nm in names:
         if nm == "tiny":
             make("tiny", True)
@@ -168,6 +226,10 @@ if __name__ == "__main__":
             make(nm, False)
         elif nm == "cfg3s":
             make_cfg3_subset()
+        elif nm == "cfg3":
+            make_cfg3_full()
+        elif nm == "cfg5s":
+            make_cfg5_subset()
         elif nm == "rhophase":
             make_rho_phase()
         else:

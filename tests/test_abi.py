@@ -128,8 +128,22 @@ def test_julia_binding_mirrors_the_struct_layout():
     assert fields("HmcmtStats") == [f for f, _ in L.Stats._fields_]
     assert "using LinearAlgebra" in src
     for sym in ("hmcmt_create", "hmcmt_grad", "hmcmt_forward", "hmcmt_destroy", "hmcmt_set_prior", "hmcmt_leapfrog",
-                "hmcmt_get_stats", "hmcmt_last_error"):
+                "hmcmt_leapfrog_device", "hmcmt_wait", "hmcmt_get_stats", "hmcmt_last_error"):
         assert f":{sym}" in src, sym
+    # the component map is the Python binding's (include/hmcmt.h: 1 ZXY .. 6 PhsYX), both data types are accepted, and
+    # the ccall signatures carry as many argument types as the header's prototypes have parameters
+    from hmcmt2d_amd.marshal import COMPONENT_CODES
+    jl = dict((k, int(v)) for k, v in re.findall(r'"(\w+)"\s*=>\s*(\d)', re.search(r"const COMPONENT_CODES = Dict\((.*?)\)", src, flags=re.S).group(1)))
+    assert jl == COMPONENT_CODES
+    assert "only DataType Impedance" not in src and 'occursin("Rho_Pha", dataType)' in src
+    assert "ctx.havePrior ||" not in src and "isdiag(hmcParam.invM)" in src
+    hdr = open(os.path.join(ROOT, "include", "hmcmt.h")).read()
+    for sym in ("hmcmt_grad", "hmcmt_forward", "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_create"):
+        proto = re.search(r"int %s\((.*?)\);" % sym, hdr, flags=re.S).group(1)
+        nargs_c = len(proto.split(","))
+        call = re.search(r"ccall\(\(:%s, libhmcmt\), Cint,\s*\((.*?)\),\s*\n\s*ctx" % sym, src, flags=re.S).group(1)
+        nargs_jl = len([t for t in re.sub(r"\{[^}]*\}", "", call).split(",") if t.strip()])
+        assert nargs_c == nargs_jl, (sym, nargs_c, nargs_jl)
 
 
 @pytest.mark.gpu

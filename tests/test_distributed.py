@@ -95,13 +95,15 @@ def test_real_sampler_chains_allgathered_with_per_rank_device():
 
 
 def test_default_device_follows_local_rank(monkeypatch):
+    """LOCAL_RANK (one process per GPU) unless HMCMT_DEVICE says otherwise -- the precedence of julia/HMCMTHip.jl's
+    defaultDevice."""
     from hmcmt2d_amd import sampler
     monkeypatch.delenv("LOCAL_RANK", raising=False); monkeypatch.delenv("HMCMT_DEVICE", raising=False)
     assert sampler.default_device() == 0
-    monkeypatch.setenv("HMCMT_DEVICE", "3")
-    assert sampler.default_device() == 3
     monkeypatch.setenv("LOCAL_RANK", "5")
     assert sampler.default_device() == 5
+    monkeypatch.setenv("HMCMT_DEVICE", "3")
+    assert sampler.default_device() == 3
 
 
 @pytest.mark.parametrize("nchains", [2, 3])

@@ -164,12 +164,13 @@ def test_operator_symmetry_properties():
 
 
 @pytest.mark.parametrize("name", ["cfg3", "cfg5"])
-def test_headline_size_gradient_checks(name):
-    """cfg3 (200x100 cells, 16 freq: BASELINE.json's full size) and cfg5 (400x200 cells, 32 freq: the stress
-    size, beyond what the oracle can check in reasonable time): true residuals of the converged systems,
-    directional finite difference of the GPU misfit along an interior-cell direction (the reference's
-    boundary-derivative terms are approximations, so only interior directions are FD-consistent), and
-    insensitivity to the solver tolerance."""
+def test_headline_size_properties(name):
+    """Size-independent properties at BASELINE.json's full sizes, cfg3 (200x100 cells, 16 freq) and cfg5 (400x200 cells,
+    32 freq) -- beside the oracle comparisons at these sizes (tests/test_gpu_parity_full.py: cfg3 at all 16
+    frequencies, cfg5's mesh on a 3-frequency subset plus the agreement of the full batch with it): true residuals
+    of the converged systems, a directional finite difference of the GPU misfit along an interior-cell direction
+    (the reference's boundary-derivative terms are approximations, so only interior directions are FD-consistent),
+    and insensitivity to the solver tolerance."""
     mesh, data, inv, m = make_problem(name)
     ctx = HipContext(mesh, data, inv, verify=True)
     pred, f0, g = ctx.grad(m)
@@ -566,6 +567,7 @@ def test_sampler_context_lands_on_the_ranks_device(monkeypatch):
     n = ctypes.c_int(0); hip.hipGetDeviceCount(ctypes.byref(n))
     mesh, data, inv, m = make_problem("tiny")
     last = n.value - 1
+    monkeypatch.delenv("HMCMT_DEVICE", raising=False)
     monkeypatch.setenv("LOCAL_RANK", str(last))
     ctx = sampler.get_context(mesh, data, inv)
     assert ctx.device_id == last

@@ -100,6 +100,69 @@ def test_cfg3_mesh_frequency_subset_parity_and_full_run_agreement():
     ctx16.close()
 
 
+def test_cfg3_all_sixteen_frequencies_parity():
+    """BASELINE configs[2] -- the configuration the metric is quoted on -- in full: 200x100 cells + 7 air rows, ALL 16
+    frequencies, TE+TM, 1312 data: predData / misfit / gradient / receiver-row fields against the oracle's golden at
+    the rough bench state and at the true model (tests/golden/make_golden.py::make_cfg3_full)."""
+    g = np.load(os.path.join(GOLDEN, "cfg3.npz"))
+    mesh, data, inv, m = make_problem("cfg3")
+    assert np.array_equal(m, g["m"]) and len(data.freqs) == 16 and len(g["pred"]) == 2 * 16 * 41
+    ctx = HipContext(mesh, data, inv, verify=True)
+    _check(ctx, m, g["pred"], float(g["misfit"]), g["grad"], inv, mesh)
+    ex, hx = ctx.fields()
+    ny = mesh.gridSize[0]; zid = len(mesh.airLayer)
+    rows = slice(zid * (ny + 1), (zid + 2) * (ny + 1))
+    assert relmax(ex[rows], g["exTE_rx"]) < 1e-9 and relmax(hx[rows], g["hxTM_rx"]) < 1e-9
+    _, sig_true = S.make_config("cfg3")[1:]
+    m_true = np.log(sig_true[inv.activeIdx])
+    # (true model: the residuals are the 3 % noise -- see the subset test above for the two tolerances)
+    _, _, g_true = _check(ctx, m_true, g["pred_true"], float(g["misfit_true"]), g["grad_true"], inv, mesh, grad_tol=3e-7, misfit_tol=2e-8)
+    assert np.abs(g_true - g["grad_true"]).max() < 1e-9 * np.abs(g["grad"]).max()
+    # the default (non-verify, warm-started, mixed-precision) path the bench runs gives the same numbers
+    ctx.set_options(verify=0)
+    for _ in range(2):
+        pred, misfit, grad = ctx.grad(m + 0.0)
+    assert relmax(pred, g["pred"]) < PRED_TOL and gerr_split(grad, g["grad"], inv, mesh)[0] < GRAD_TOL
+    ctx.close()
+
+
+def test_cfg5_mesh_frequency_subset_parity_and_full_run_agreement():
+    """BASELINE configs[4]'s mesh (400x200 cells + 7 air rows, 82 194 unknowns per system: the wide-mesh kernels, separate
+    transform / tridiagonal launches) with 3 of its 32 frequencies (100, 0.59, 0.01 Hz): predData / misfit / gradient
+    against the oracle's golden at the rough state and at the true model; then the full 32-frequency context must give,
+    at the subset's frequencies, the subset run's predicted data."""
+    g = np.load(os.path.join(GOLDEN, "cfg5s.npz"))
+    mesh, data32, sig_true = S.make_config("cfg5")
+    fidx = g["fidx"]
+    data = S.make_data_layout(data32.freqs[fidx], data32.rxLoc[:, 0])
+    from tests.helpers import start_sigma
+    mesh.sigma = start_sigma(mesh)
+    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, g["obs"], g["err"])
+    m = S.rough_state(len(inv.strModel))
+    assert np.array_equal(m, g["m"])
+    ctx = HipContext(mesh, data, inv, verify=True)
+    _check(ctx, m, g["pred"], float(g["misfit"]), g["grad"], inv, mesh)
+    ex, hx = ctx.fields()
+    ny = mesh.gridSize[0]; zid = len(mesh.airLayer)
+    rows = slice(zid * (ny + 1), (zid + 2) * (ny + 1))
+    assert relmax(ex[rows], g["exTE_rx"]) < 1e-9 and relmax(hx[rows], g["hxTM_rx"]) < 1e-9
+    m_true = np.log(sig_true[inv.activeIdx])
+    _, _, g_true = _check(ctx, m_true, g["pred_true"], float(g["misfit_true"]), g["grad_true"], inv, mesh, grad_tol=3e-7, misfit_tol=2e-8)
+    assert np.abs(g_true - g["grad_true"]).max() < 1e-9 * np.abs(g["grad"]).max()
+    ctx.close()
+    # all 32 frequencies (the stress configuration itself): the subset's systems inside the full batch
+    n32 = len(data32.rxID)
+    obs32 = np.full(n32, 0.02 + 0.02j) * np.where(data32.dtID == 1, 1.0, -1.0)
+    sel = np.isin(data32.freqID - 1, fidx)
+    obs32[sel] = g["obs"]; err32 = np.full(n32, 1e-3); err32[sel] = g["err"]
+    inv32 = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, obs32, err32)
+    ctx32 = HipContext(mesh, data32, inv32, verify=True)
+    pred32, _, _ = ctx32.grad(m)
+    assert ctx32.stats()["status"] == 0 and ctx32.stats()["true_res_max"] < RES_TOL
+    assert relmax(pred32[sel], g["pred"]) < PRED_TOL
+    ctx32.close()
+
+
 @pytest.mark.parametrize("name", ["dprism3d", "coprod2"])
 def test_reference_example_directories(name):
     """HMCMT/examples/{dprism3d,coprod2} (startupfile + model + data files, committed unchanged as fixtures): read by

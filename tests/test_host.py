@@ -115,10 +115,22 @@ def test_checkpointed_chain_resumes_bit_for_bit(tmp_path):
     assert (res[1].nAccept, res[1].nReject) == (full[1].nAccept, full[1].nReject)
     assert ctx2.ngrad < prior2.nfevals                     # (the resumed process did only the remaining trajectories)
     assert int(np.load(ck)["it"]) == 5
-    # a checkpoint of another run is refused
+    # the samples live in an append-only file of one record per sample (a flush writes the new samples only)
+    nparam, ndata = full[0].shape[0], full[2].shape[0]
+    assert os.path.getsize(ck + ".samples") == 5 * (nparam + 2 * ndata) * 8
+    # a checkpoint of another run is refused: another reference model (seed), other sampler settings, other data
     with pytest.raises(ValueError):
         sampler.runHMCSampler(copy.deepcopy(mesh), data, copy.deepcopy(inv), copy.deepcopy(prior), np.random.default_rng(6),
                               ctx=OracleContext(mesh, data, inv), checkpoint=ck, checkpoint_every=2)
+    for change in ("dt", "obs"):
+        prior3, inv3 = copy.deepcopy(prior), copy.deepcopy(inv)
+        if change == "dt":
+            prior3.dt = 0.021
+        else:
+            inv3.obsData = inv3.obsData * (1 + 1e-9)
+        with pytest.raises(ValueError):
+            sampler.runHMCSampler(copy.deepcopy(mesh), data, inv3, prior3, np.random.default_rng(5),
+                                  ctx=OracleContext(mesh, data, inv), checkpoint=ck, checkpoint_every=2)
 
 
 def test_get_hamiltonian_without_reuse_repeats_forward():
