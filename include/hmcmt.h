@@ -130,9 +130,10 @@ int hmcmt_forward_device(hmcmt_ctx* ctx, const double* d_m, double* d_pred, doub
 /* Asynchronous variant for a device-resident caller (a leapfrog loop whose next model is computed on the device from
  * this gradient, bench.py): returns when the evaluation is ENQUEUED; the outputs are ordered on the context's stream.
  * The call still blocks at its two convergence polls, but not on the gradient assembly behind the adjoint solve, so
- * the host issues the next evaluation's boundary-value stage while the device finishes this one.  Solver status and
- * statistics of an asynchronous evaluation are collected -- and an error of it is returned -- by the next evaluation
- * on the context or by hmcmt_wait; between hmcmt_grad_device_async and hmcmt_wait only further
+ * the host issues the next evaluation's boundary-value stage while the device finishes this one.  A solve that gives
+ * up (iteration cap, breakdown) is seen at its poll and returned by the call itself -- nothing is built on it: no
+ * adjoint solve on a failed forward solve, no gradient from a failed adjoint solve; the statistics of a successful
+ * asynchronous evaluation are collected by the next evaluation on the context or by hmcmt_wait; between hmcmt_grad_device_async and hmcmt_wait only further
  * hmcmt_grad_device_async calls are allowed on the context. */
 int hmcmt_grad_device_async(hmcmt_ctx* ctx, const double* d_m, double* d_pred, double* d_misfit, double* d_grad);
 /* waits for everything enqueued on the context; returns the status of the last asynchronous evaluation */

@@ -517,14 +517,21 @@ def test_asynchronous_device_evaluations_match_synchronous_ones():
     assert np.array_equal(gs, ga) and np.array_equal(ps, pa) and fs == fa        # same kernels, same order: bit-identical
     assert sa["iters_fwd_max"] == ss["iters_fwd_max"] and sa["iters_adj_max"] == ss["iters_adj_max"] and sa["status"] == 0
 
-    # an evaluation that cannot converge (maxit 2): reported by the next call, not silently dropped
+    # an evaluation that cannot converge (maxit 2) is reported, not silently dropped -- by the call itself since round 3
+    # (the device raises a mapped failure word the host reads at its convergence poll: no adjoint solve on a failed
+    # forward solve, no further leapfrog step), at the latest by hmcmt_wait; and the context recovers
     ctx = HipContext(mesh, data, inv, maxit=2)
     d_pred = torch.zeros(2 * ctx.nData, dtype=torch.float64, device=dev)
     d_mis = torch.zeros(1, dtype=torch.float64, device=dev)
     d_g = torch.zeros(ctx.nAC, dtype=torch.float64, device=dev)
-    ctx.grad_device_async(d_ms[0].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr(), d_g.data_ptr())
-    with pytest.raises(RuntimeError):
+    with pytest.raises(HmcmtError) as e:
+        ctx.grad_device_async(d_ms[0].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr(), d_g.data_ptr())
         ctx.wait()
+    assert e.value.code == -10 and ctx.iters()[1].max() == 0          # (the adjoint solve was never started)
+    ctx.set_options(maxit=2000)
+    ctx.grad_device_async(d_ms[0].data_ptr(), d_pred.data_ptr(), d_mis.data_ptr(), d_g.data_ptr())
+    ctx.wait()
+    assert ctx.stats()["status"] == 0 and np.array_equal(d_g.cpu().numpy(), gs[0])
     ctx.close()
 
 

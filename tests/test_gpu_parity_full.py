@@ -141,13 +141,16 @@ def test_cfg5_mesh_frequency_subset_parity_and_full_run_agreement():
     m = S.rough_state(len(inv.strModel))
     assert np.array_equal(m, g["m"])
     ctx = HipContext(mesh, data, inv, verify=True)
-    _check(ctx, m, g["pred"], float(g["misfit"]), g["grad"], inv, mesh)
+    # (the solves stop on the ERROR estimate; the true residual that leaves is 4e-9 on this mesh -- its norm is
+    #  dominated by the 1e8-weighted air rows of the TM systems, four times as many unknowns as at cfg3 -- for predicted
+    #  data and gradients at the usual levels)
+    _check(ctx, m, g["pred"], float(g["misfit"]), g["grad"], inv, mesh, res_tol=2e-8)
     ex, hx = ctx.fields()
     ny = mesh.gridSize[0]; zid = len(mesh.airLayer)
     rows = slice(zid * (ny + 1), (zid + 2) * (ny + 1))
     assert relmax(ex[rows], g["exTE_rx"]) < 1e-9 and relmax(hx[rows], g["hxTM_rx"]) < 1e-9
     m_true = np.log(sig_true[inv.activeIdx])
-    _, _, g_true = _check(ctx, m_true, g["pred_true"], float(g["misfit_true"]), g["grad_true"], inv, mesh, grad_tol=3e-7, misfit_tol=2e-8)
+    _, _, g_true = _check(ctx, m_true, g["pred_true"], float(g["misfit_true"]), g["grad_true"], inv, mesh, grad_tol=3e-7, misfit_tol=2e-8, res_tol=2e-8)
     assert np.abs(g_true - g["grad_true"]).max() < 1e-9 * np.abs(g["grad"]).max()
     ctx.close()
     # all 32 frequencies (the stress configuration itself): the subset's systems inside the full batch
@@ -158,7 +161,7 @@ def test_cfg5_mesh_frequency_subset_parity_and_full_run_agreement():
     inv32 = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, obs32, err32)
     ctx32 = HipContext(mesh, data32, inv32, verify=True)
     pred32, _, _ = ctx32.grad(m)
-    assert ctx32.stats()["status"] == 0 and ctx32.stats()["true_res_max"] < RES_TOL
+    assert ctx32.stats()["status"] == 0 and ctx32.stats()["true_res_max"] < 2e-8
     assert relmax(pred32[sel], g["pred"]) < PRED_TOL
     ctx32.close()
 
