@@ -278,6 +278,7 @@ def main():
         # throughput; round 2 sampled every 6th = 3 evaluations of a 20-step run)
         prof_every = max(1, K // 10)
         ctx.profile(["fdm_transform", "tridiagonal", "spmv", "vector_ops", "post_smoother"], every=prof_every)
+    prof_overhead_us = ctx.profile_overhead_us()
     elapsed = timed(torch, dist, lambda: chain.run(K))
     prof = ctx.profile_read()
     cnt = ctx.profile_counters()
@@ -469,6 +470,7 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(name, cat), "avg_launch_us": avg_us,
                          "frac_canonical_csr": can / HBM_PEAK_GBS, "canonical_csr_bytes_per_launch": can_sys * act,
                          "evaluations_sampled": cnt["evaluations"], "sampled_every": every,
+                         "event_bracket_overhead_us_subtracted": prof_overhead_us,
                          "launches_timed": n_c, "launches_per_iteration": per_it, "bytes_per_launch": nbytes,
                          "bytes_per_launch_all_systems_active": bpu * U, "active_systems_per_launch": act, "ms_timed": ms_c,
                          "population": population}

@@ -38,7 +38,10 @@ using namespace hmcmt;
 namespace {
 
 constexpr int MAXNB = 64;          // max partial-sum blocks per system (<= 64: one wave sums them, total_part)
-constexpr int VBLOCK = 256;        // threads of the vector kernels
+#ifndef HMCMT_VBLOCK
+#define HMCMT_VBLOCK 256
+#endif
+constexpr int VBLOCK = HMCMT_VBLOCK;        // threads of the vector kernels (build-time knob for A/B runs: 512 measured in round 3)
 
 #include "kernels_cocg.h"
 #include "kernels_fdm.h"
@@ -118,7 +121,7 @@ struct hmcmt_ctx {
     std::vector<hipEvent_t> evPool;
     std::vector<int> evCat;
     size_t evUsed = 0;
-    double profOverheadMs = 0.0;      // event-bracket overhead of one launch (null-kernel calibration)
+    double profOverheadMs = 0.0;      // event-bracket overhead of one launch (spin-kernel calibration, hmcmt_profile)
     double profMs[HMCMT_NCAT] = {0};
     long long profN[HMCMT_NCAT] = {0};
     unsigned long long* d_cnt = nullptr;   // device counter behind Solver::cntActive
@@ -243,6 +246,8 @@ bool fused_back_ok(const hmcmt_ctx* ctx) {
     const size_t lds = (size_t)16 * k.NYP * sizeof(cplx) + (size_t)2 * ((k.NYP + 31) / 32) * 2 * 64 * 16;
     return k.splitT && ctx->fusedBack && lds <= ctx->maxLdsBack && k.NYP <= 256;
 }
+// grid of the fused stencil kernels for `ntiles` row tiles per system (tile_map, kernels_fused.h)
+dim3 tile_grid(const Solver& k, int ntiles) { return k.xmap ? dim3(8 * ((k.S + 7) / 8) * ntiles) : dim3(ntiles, k.S); }
 size_t update2_lds(const Solver& k) { return (size_t)(3 * k.RT2 + 8) * k.NYP * sizeof(float2); }
 int update2_tiles(const Solver& k) { return (k.nz - 1 + k.RT2 - 1) / k.RT2; }
 // two sweeps per side exist on the fused mixed-precision path (and on the fp64 path of the restarts)
@@ -348,7 +353,7 @@ int apply_precond(hmcmt_ctx* ctx) {
         if (smooth && ctx->preDone) ctx->preDone = false;                        // (k_resid_pre has written t)
         else if (smooth && k.sweeps == 2) {                                       // both pre-sweeps of the residual at hand
             ProfScope ps(ctx, 3);
-            hipLaunchKernelGGL(k_update_fused<2>, dim3(update2_tiles(k), k.S), vb, update2_lds(k), ctx->stream, k, k.p32a, k.r, k.r, 0, 1);
+            hipLaunchKernelGGL(k_update_fused<2>, tile_grid(k, update2_tiles(k)), vb, update2_lds(k), ctx->stream, k, k.p32a, k.r, k.r, 0, 1);
         }
         else if (smooth) { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_pre_c64, vg, vb, 0, ctx->stream, k); }
         else { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_to_c64, vg, vb, 0, ctx->stream, k, k.r); }
@@ -464,11 +469,11 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             // decide convergence of the state after iteration it-1, p = z + beta p, q = A p
             if (k.sweeps == 2 && k.merged2) {
                 ProfScope ps(ctx, 2);
-                hipLaunchKernelGGL(k_spmv_fused<2>, dim3(k.NTR, S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx) + (size_t)(k.RT + 4) * k.NYP * sizeof(float2),
+                hipLaunchKernelGGL(k_spmv_fused<2>, tile_grid(k, k.NTR), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx) + (size_t)(k.RT + 4) * k.NYP * sizeof(float2),
                                    ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit);
-            } else { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv_fused<1>, dim3(k.NTR, S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit); }
-            if (k.sweeps == 2) { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused<2>, dim3(update2_tiles(k), S), vb, update2_lds(k), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it, 0); }
-            else { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused<1>, dim3(k.NTR, S), vb, (size_t)(2 * k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it, 0); }
+            } else { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv_fused<1>, tile_grid(k, k.NTR), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit); }
+            if (k.sweeps == 2) { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused<2>, tile_grid(k, update2_tiles(k)), vb, update2_lds(k), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it, 0); }
+            else { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused<1>, tile_grid(k, k.NTR), vb, (size_t)(2 * k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it, 0); }
             rcur ^= 1;
             k.r = rb[rcur];
             int prc;
@@ -1015,6 +1020,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     k.sweeps = 1;
     k.RT2 = getenv("HMCMT_RT2") ? std::max(k.RT, atoi(getenv("HMCMT_RT2"))) : k.RT;    // (>= RT: its partial sums fill the first slots of the k.NTR the consumers read;
                                                                                      //  measured at the headline size: 7 (= RT) 21.8 / 26.0 ms per trajectory, 8: 22.6 / 26.2, 10: 23.4 / 27.0, 14: 23.4 / 27.2)
+    k.xmap = getenv("HMCMT_XMAP") ? atoi(getenv("HMCMT_XMAP")) : 0;     // (XCD-aware tile placement: measured neutral, kernels_fused.h tile_map)
     k.w2 = getenv("HMCMT_JACOBI_W2") ? (float)atof(getenv("HMCMT_JACOBI_W2")) : 1.0f;
     k.merged2 = getenv("HMCMT_POST2") && atoi(getenv("HMCMT_POST2")) == 1 ? 0 : 1;
     k.omega = v.omega; k.cY = v.cY; k.cZ = v.cZ; k.dK = v.dK; k.dM = v.dM; k.ofz = v.ofz; k.invp = v.invp;
@@ -1262,27 +1268,34 @@ int hmcmt_profile(hmcmt_ctx* ctx, int32_t enable) {
     ctx->evUsed = 0;
     ctx->profOverheadMs = 0.0;
     if (enable) {
-        // An event pair around a launch also times the dispatch latency of that launch.  Calibrate it
-        // with a null kernel on the same stream (median of 33) and subtract it from every sample.
+        // An event pair around a launch also times what the command processor does between the two markers beside
+        // running the kernel (the marker packets themselves, dispatch latency).  Calibrated on the device's own clock:
+        // a one-workgroup kernel that spins for a KNOWN time (SPIN_US on the constant-rate wall clock) is bracketed the
+        // same way, back to back, long enough that the queue never runs dry (the host needs ~5 us per launch + record);
+        // the bracket overhead is the median period minus the duration rocprofv3 reports for that kernel (spin time +
+        // SPIN_EDGE_US of dispatch / completion edges: 12.39 us for a 12.00 us spin, scripts/gpu_spin_calib.sh).  It comes
+        // out at 2.57 us run after run.  (Rounds 1-2 calibrated with an EMPTY kernel, whose period is the HOST's launch
+        // rate, times a fitted factor: the subtracted value followed the host's speed, 0.3 .. 3.8 us from run to run.
+        // A 512-workgroup spin kernel is no better a yardstick: its workgroups start over 6 us.)
         HIPCHK(hipSetDevice(ctx->device));
-        // steady state of a busy queue: N null launches with an event after each, one sync at the end
+        int wallKHz = 100000;
+        if (hipDeviceGetAttribute(&wallKHz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || wallKHz <= 0) wallKHz = 100000;
+        constexpr double SPIN_US = 12.0, SPIN_EDGE_US = 0.39;
+        const long long ticks = (long long)(SPIN_US * 1e-3 * wallKHz);
         const int N = 48;
-        std::vector<hipEvent_t> ev(N + 1);
+        std::vector<hipEvent_t> ev(2 * N);
         for (auto& e : ev) HIPCHK(hipEventCreate(&e));
-        hipLaunchKernelGGL(k_null, dim3(1), dim3(64), 0, ctx->stream);
-        HIPCHK(hipEventRecord(ev[0], ctx->stream));
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, ctx->stream, ticks);
         for (int i = 0; i < N; ++i) {
-            hipLaunchKernelGGL(k_null, dim3(1), dim3(64), 0, ctx->stream);
-            HIPCHK(hipEventRecord(ev[i + 1], ctx->stream));
+            HIPCHK(hipEventRecord(ev[2 * i], ctx->stream));
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, ctx->stream, ticks);
+            HIPCHK(hipEventRecord(ev[2 * i + 1], ctx->stream));
         }
         HIPCHK(hipStreamSynchronize(ctx->stream));
         std::vector<float> t;
-        for (int i = 0; i < N; ++i) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); t.push_back(ms); }
+        for (int i = 0; i < N; ++i) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); t.push_back(ms); }
         std::sort(t.begin(), t.end());
-        // The null kernel itself runs ~1.5 us (rocprofv3).  Of the remaining launch+event period about 60 %
-        // also precedes a LONG kernel inside its bracket (the rest overlaps its execution): factor fitted
-        // once against the rocprofv3 average of k_transform (profiles/r01_bench_cfg3_kernel_stats.csv).
-        ctx->profOverheadMs = std::max(0.0, 0.6 * ((double)t[t.size() / 2] - 0.0015));
+        ctx->profOverheadMs = std::max(0.0, (double)t[t.size() / 2] - (SPIN_US + SPIN_EDGE_US) * 1e-3);
         for (auto& e : ev) hipEventDestroy(e);
     }
     ctx->profMask = (unsigned)enable;
@@ -1290,6 +1303,12 @@ int hmcmt_profile(hmcmt_ctx* ctx, int32_t enable) {
     ctx->profStartSys = ctx->profEvals = ctx->profSolves = ctx->profSolves2 = 0;
     HIPCHK(hipMemsetAsync(ctx->d_cnt, 0, sizeof(unsigned long long), ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int hmcmt_profile_overhead(const hmcmt_ctx* ctx, double* us) {
+    if (!ctx || !us) return HMCMT_EINVAL;
+    *us = 1e3 * ctx->profOverheadMs;
     return 0;
 }
 

@@ -38,6 +38,7 @@ struct Solver {
     float2 *z32, *p32a, *p32b;            // fused path: preconditioned residual and the two search-direction buffers as complex64
                                           // (x, r, q and every inner product stay fp64; see k_spmv_fused)
     int RT, NTR;                          // rows per tile / row tiles per system of the fused kernels (NTR <= MAXNB)
+    int xmap;                             // 1: XCD-aware 1-D grids of the fused stencil kernels (tile_map, kernels_fused.h)
     int RT2;                              // rows per tile of k_update_fused<2> (its two halo rows per side cost less on taller tiles)
     cplx *partPQ;                         // [S][MAXNB]  p'q of the fused path
     cplx *rho2;                           // [2][S] rho by iteration parity (fused path)
@@ -81,16 +82,16 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // block-wide deterministic sum of up to 2 doubles; result valid in thread 0
-__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh /* [2*4] */) {
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh /* [2*8]: workgroups of up to 8 waves */) {
     a = wave_sum(a);
     b = wave_sum(b);
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if (l == 0) { sh[w] = a; sh[4 + w] = b; }
+    if (l == 0) { sh[w] = a; sh[8 + w] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const int nw = (blockDim.x + 63) >> 6;
         double sa = 0, sb = 0;
-        for (int i = 0; i < nw; ++i) { sa += sh[i]; sb += sh[4 + i]; }
+        for (int i = 0; i < nw; ++i) { sa += sh[i]; sb += sh[8 + i]; }
         a = sa; b = sb;
     }
 }
@@ -148,7 +149,7 @@ __device__ __forceinline__ cplx sum_partA(const Solver& k, int s) {
 __global__ __launch_bounds__(VBLOCK) void k_spmv(Solver k) {
     const int s = blockIdx.y;
     if (!k.active[s]) return;
-    __shared__ double sh[8];
+    __shared__ double sh[16];
     const int mode = s >= k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
     const double w = k.omega[s];
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv(Solver k) {
 __global__ __launch_bounds__(VBLOCK) void k_update(Solver k) {
     const int s = blockIdx.y;
     if (!k.active[s]) return;
-    __shared__ double sh[8];
+    __shared__ double sh[16];
     const long so = (long)s * k.vstride;
     const cplx al = k.rho[s] / sum_partA(k, s);
     const cplx *p = k.p + so, *q = k.q + so;
@@ -206,8 +207,8 @@ __global__ __launch_bounds__(VBLOCK) void k_update(Solver k) {
 __global__ __launch_bounds__(VBLOCK) void k_dots(Solver k, double* partZZ) {
     const int s = blockIdx.y;
     if (!k.active[s]) return;
-    __shared__ double sh[8];
-    __shared__ double sh2[8];
+    __shared__ double sh[16];
+    __shared__ double sh2[16];
     const long so = (long)s * k.vstride;
     const cplx *r = k.r + so, *z = k.z + so;
     const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);

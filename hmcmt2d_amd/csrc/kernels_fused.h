@@ -41,13 +41,36 @@ __device__ __forceinline__ int div_small(int i, float rcp) { return (int)(((floa
 // post-sweep (k_back_post<., 2>), with rho = r'z already known from the identity of Solver::partR and |z4|^2 as the
 // error estimate; the second post-sweep  z = z4 + dinv .* (r - A z4)  is done here, on the tile's rows and one halo row
 // on each side (z4 staged with two), in fp32 like the rest of the smoother -- no launch of its own (k_post2: 8 us).
+// Workgroup -> (row tile, system) of the two stencil kernels of the iteration.  Workgroups are dealt to the 8 XCDs
+// round-robin by linear id (checked on the box: scripts/probe/xcc_map.hip, XCD(b) == XCD(b % 8) for every workgroup of
+// 1-D and 2-D grids) and each XCD has its own 4 MB L2: with the plain 2-D grid (tile = blockIdx.x) the row tiles above
+// and below a tile -- whose edge rows it reads as halo -- and the same tile of the mode's other frequencies -- whose
+// stencil coefficients it shares -- all sit on OTHER XCDs.  k.xmap = 1 (HMCMT_XMAP=1; NOT the default) is the
+// experiment that tested whether that matters: a 1-D grid of 8 * ceil(S / 8) * ntiles workgroups, XCD x owning ALL tiles
+// of the systems x, x + 8, x + 16, .. (every XCD gets TE and TM systems of several frequencies: a first version with
+// contiguous system ranges per XCD emptied whole XCDs when the TE systems converged, -3 % at cfg3, -9 % at cfg5) and
+// walking them system by system, tile by tile.  Measured (round 3, profiles/r03_xmap.md): the same time within noise at cfg3
+// (286.6 vs 286.6-290.6 steps/s), 2 % slower at cfg5 (49.3 vs 50.3), and the PMC bytes per launch did NOT fall
+// (k_update_fused<2> at cfg5: 640.6 vs 645.8 MB, k_spmv_fused<2> 459.9 vs 406.1 MB): co-locating a tile's neighbours
+// does not make the XCD's L2 share their rows -- the workgroups in flight on an XCD stream ~20 MB through a 4 MB L2 --
+// so the fabric reads of the halo rows are served by the Infinity Cache either way.  Placement only: any mapping gives
+// the same numbers.
+__device__ __forceinline__ bool tile_map(const Solver& k, int ntiles, int& tile, int& s) {
+    if (!k.xmap) { tile = blockIdx.x; s = blockIdx.y; return true; }
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, q = j / ntiles;
+    tile = j - q * ntiles;
+    s = x + 8 * q;
+    return s < k.S;
+}
+
 template <int SW>
 __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* partZZ, const float2* pin_, float2* pout, int it, int maxit) {
-    const int s = blockIdx.y;
     extern __shared__ __attribute__((aligned(16))) char smem_[];
     cplx* pn = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]
-    __shared__ double sh[8];
+    __shared__ double sh[16];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *(volatile int*)k.progHost = it;   // "iteration it-1 is complete"
+    int tile, s;
+    if (!tile_map(k, k.NTR, tile, s)) return;
     const bool first = it == 1;
     const int act = k.active[s];
     const int ln = threadIdx.x & 63;
@@ -63,7 +86,7 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
     const float2 *z = (SW == 2 ? k.z4_32 : k.z32) + so, *pi = pin_ + so;
     float2* po = pout + so;
     cplx* q = k.q + so;
-    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);   // own rows iz0..iz1
+    const int NYP = k.NYP, iz0 = 1 + tile * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);   // own rows iz0..iz1
     const float rNYP = 1.0f / (float)NYP;
     // rows iz0-1 .. iz1+1 of the new direction (z, p vanish on boundary / pad nodes: no masking needed)
     const int nrows = iz1 - iz0 + 3, ntot = nrows * NYP, ebase = (iz0 - 1) * NYP;
@@ -87,7 +110,7 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
     else if (it - 1 >= maxit) { on = false; st = HMCMT_ENOCONV; }
     if (!(isfinite(rz.re) && isfinite(rz.im) && isfinite(zz) && isfinite(xx))) { on = false; st = HMCMT_EBREAKDOWN; }
     const cplx be = first ? cplx{0, 0} : rz / rhoPrev;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (tile == 0 && threadIdx.x == 0) {
         k.rho2[(long)(it & 1) * k.S + s] = rz;
         k.iters[s] = it - 1;
         const double est = first ? (zz == 0.0 ? 0.0 : 1.0) : sqrt(zz / xx);
@@ -100,10 +123,10 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
     if (!on) {
         // every block of this system takes the same decision; block 0 records it (a block that starts late and
         // already sees the cleared flag returns just the same)
-        if (blockIdx.x == 0 && threadIdx.x == 0) { k.active[s] = 0; if (atomicSub(k.nactive, 1) == 1) *k.nactHost = 0; }
+        if (tile == 0 && threadIdx.x == 0) { k.active[s] = 0; if (atomicSub(k.nactive, 1) == 1) *k.nactHost = 0; }
         return;
     }
-    if (k.cntActive && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(k.cntActive, 1ull);   // (roofline accounting only)
+    if (k.cntActive && tile == 0 && threadIdx.x == 0) atomicAdd(k.cntActive, 1ull);   // (roofline accounting only)
     if constexpr (SW == 2) {
         // z4 on rows iz0-2 .. iz1+2 (outside the mesh: zero) -> LDS, then z = z4 + dinv .* (r - A z4) on rows iz0-1 .. iz1+1
         c32* z4s = reinterpret_cast<c32*>(pn + (long)(k.RT + 2) * NYP);      // [(RT+4)][NYP]
@@ -211,7 +234,7 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
         }
     }
     block_sum2(ar, ai, sh);
-    if (threadIdx.x == 0) k.partPQ[(long)s * MAXNB + blockIdx.x] = cplx{ar, ai};
+    if (threadIdx.x == 0) k.partPQ[(long)s * MAXNB + tile] = cplx{ar, ai};
 }
 
 // SW = 2 (two damped Jacobi sweeps on each side of the FDM stage, k.sweeps == 2): the pre-smoother becomes
@@ -224,17 +247,19 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
 // x and r stay untouched (k_resid_pre does this for one sweep).
 template <int SW>
 __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2* pcur, const cplx* rin, cplx* rout, int it, int startOnly = 0) {
-    const int s = blockIdx.y;
+    const int RTt = SW == 2 ? k.RT2 : k.RT;
+    const int ntiles = (k.nz - 1 + RTt - 1) / RTt;
+    int tile, s;
+    if (!tile_map(k, ntiles, tile, s)) return;
     if (!k.active[s]) return;
     extern __shared__ __attribute__((aligned(16))) char smem_[];
-    const int RTt = SW == 2 ? k.RT2 : k.RT;
-    const int NYP = k.NYP, iz0 = 1 + blockIdx.x * RTt, iz1 = min(iz0 + RTt - 1, k.nz - 1);
+    const int NYP = k.NYP, iz0 = 1 + tile * RTt, iz1 = min(iz0 + RTt - 1, k.nz - 1);
     const int nrows = iz1 - iz0 + 3;
     if constexpr (SW == 2) {
         c32* z1s = reinterpret_cast<c32*>(smem_);             // [(RT+4)][NYP]  z1 = dinv .* r'   rows iz0-2 .. iz1+2
         c32* rs = z1s + (long)(RTt + 4) * NYP;                // [(RT+2)][NYP]  r'                rows iz0-1 .. iz1+1
         c32* z2s = rs + (long)(RTt + 2) * NYP;               // [(RT+2)][NYP]  z2                rows iz0-1 .. iz1+1
-        __shared__ double sh2[8];
+        __shared__ double sh2[16];
         cplx al = cplx{0, 0};
         if (!startOnly) {
             const cplx pq = total_part(k.partPQ + (long)s * MAXNB, k.NTR);
@@ -371,25 +396,25 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
                 }
             }
         }
-        __shared__ double sh3[8];
+        __shared__ double sh3[16];
         block_sum2(p1r, p1i, sh3);
-        if (threadIdx.x == 0) k.partR[(long)s * MAXNB + blockIdx.x] = cplx{p1r, p1i};
-        if (blockIdx.x == 0)                                           // (fewer tiles than the k.NTR partial sums the consumers add up)
-            for (int b = gridDim.x + threadIdx.x; b < k.NTR; b += VBLOCK) {
+        if (threadIdx.x == 0) k.partR[(long)s * MAXNB + tile] = cplx{p1r, p1i};
+        if (tile == 0)                                                 // (fewer tiles than the k.NTR partial sums the consumers add up)
+            for (int b = ntiles + threadIdx.x; b < k.NTR; b += VBLOCK) {
                 k.partR[(long)s * MAXNB + b] = cplx{0, 0};
                 if (!startOnly) k.partB[(long)s * MAXNB + b] = 0.0;
             }
         if (startOnly) return;
         block_sum2(xx, dummy, sh2);
         if (threadIdx.x == 0) {
-            k.partB[(long)s * MAXNB + blockIdx.x] = xx;
-            if (blockIdx.x == 0) k.alphaBeta[s] = al;
+            k.partB[(long)s * MAXNB + tile] = xx;
+            if (tile == 0) k.alphaBeta[s] = al;
         }
         return;
     }
     cplx* cs = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]  dinv .* r'
     cplx* rs = cs + (long)(k.RT + 2) * NYP;               // [RT][NYP]      r' of the own rows
-    __shared__ double sh[8];
+    __shared__ double sh[16];
     const cplx pq = total_part(k.partPQ + (long)s * MAXNB, k.NTR);
     const cplx al = k.rho2[(long)(it & 1) * k.S + s] / pq;
     const int mode = s >= k.nFreq;
@@ -436,8 +461,8 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
     }
     block_sum2(xx, dummy, sh);
     if (threadIdx.x == 0) {
-        k.partB[(long)s * MAXNB + blockIdx.x] = xx;
-        if (blockIdx.x == 0) k.alphaBeta[s] = al;
+        k.partB[(long)s * MAXNB + tile] = xx;
+        if (tile == 0) k.alphaBeta[s] = al;
     }
 }
 
@@ -744,7 +769,7 @@ __global__ __launch_bounds__(VBLOCK) void k_extrap(Solver k, cplx* x, cplx* xp, 
 // true residual norm check: partB = |b - A x|^2 with b passed separately (verify option)
 __global__ __launch_bounds__(VBLOCK) void k_trueres(Solver k, const cplx* b, const cplx* x, double* partRes, double* partBn) {
     const int s = blockIdx.y;
-    __shared__ double sh[8];
+    __shared__ double sh[16];
     const int mode = s >= k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
     const double w = k.omega[s];

@@ -9,6 +9,12 @@
 #define TID1 (blockIdx.x * blockDim.x + threadIdx.x)
 
 __global__ void k_null() {}
+// spins for `ticks` of the constant-rate wall clock (hipDeviceAttributeWallClockRate): the known-duration kernel the
+// event-bracket overhead is calibrated with (hmcmt_profile)
+__global__ void k_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(1);
+}
 __global__ void k_sigma(View v) { int c = TID1; if (c < v.nCell) item_sigma(v, c); }
 // lateral means of one cell row per wave (deterministic shuffle reduction)
 __global__ __launch_bounds__(64) void k_rowmean(View v) {
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(64) void k_rx(View v, int wantDeriv) {
 }
 __global__ void k_resid(View v) { int p = TID1; if (p < v.nData) item_resid(v, p); }
 __global__ void k_misfit(View v, double* out) {
-    __shared__ double sh[8];
+    __shared__ double sh[16];
     double a = 0, b = 0;
     for (int p = threadIdx.x; p < v.nData; p += blockDim.x) a += v.misfitPart[p];
     block_sum2(a, b, sh);
@@ -283,7 +289,7 @@ __global__ void k_lf_step(LfView L, double dt, double lo, double hi) {
 }
 // mnorm = 0.5*lambda*(m-mref)' Wm (m-mref)   (HMCSampler.jl:389-391): partial sums, then block 0 finishes
 __global__ __launch_bounds__(256) void k_lf_mnorm(LfView L, double lambda) {
-    __shared__ double sh[8];
+    __shared__ double sh[16];
     double acc = 0.0, dummy = 0.0;
     for (int a = blockIdx.x * 256 + threadIdx.x; a < L.n; a += 256 * LFNB) {
         double row = 0.0;

@@ -102,6 +102,7 @@ def load_library():
     lib.hmcmt_profile_every.argtypes = [vp, C.c_int32]
     lib.hmcmt_profile_read.argtypes = [vp, c_double_p, c_int64_p]
     lib.hmcmt_profile_counters.argtypes = [vp, c_int64_p]
+    lib.hmcmt_profile_overhead.argtypes = [vp, C.POINTER(C.c_double)]
     lib.hmcmt_dims.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.hmcmt_debug_transform.argtypes = [vp, C.c_int32, c_double_p, c_double_p]
     lib.hmcmt_debug_flags.argtypes = [vp, C.c_int32]
@@ -111,7 +112,7 @@ def load_library():
     lib.hmcmt_debug_back_post.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_double_p]
     for name in ("hmcmt_create", "hmcmt_destroy", "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters",
                  "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async",
-                 "hmcmt_wait", "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters",
+                 "hmcmt_wait", "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead",
                  "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond",
                  "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post"):
         getattr(lib, name).restype = C.c_int
@@ -122,7 +123,7 @@ def load_library():
 EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "hmcmt_last_error",
                     "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters", "hmcmt_grad", "hmcmt_forward",
                     "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async", "hmcmt_wait",
-                    "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_dims",
+                    "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead", "hmcmt_dims",
                     "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
                     "hmcmt_debug_back_post"]
 
@@ -282,6 +283,11 @@ class HipContext:
         n = np.zeros(HMCMT_NCAT, dtype=np.int64)
         self._check(self.lib.hmcmt_profile_read(self.h, _dp(ms), n.ctypes.data_as(c_int64_p)))
         return {c: (float(ms[i]), int(n[i])) for i, c in enumerate(CATEGORIES)}
+
+    def profile_overhead_us(self):
+        us = C.c_double()
+        self._check(self.lib.hmcmt_profile_overhead(self.h, C.byref(us)))
+        return us.value
 
     def profile_counters(self):
         """{active_iter_systems, start_systems, evaluations, solves, solves_two_sweeps} of the sampled evaluations

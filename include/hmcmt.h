@@ -182,6 +182,9 @@ int hmcmt_get_fields(hmcmt_ctx* ctx, int32_t adjoint, double* exTE, double* hxTM
 int hmcmt_profile(hmcmt_ctx* ctx, int32_t category_mask);     /* bit c enables category c; 0 = off; resets the counters */
 int hmcmt_profile_every(hmcmt_ctx* ctx, int32_t n);           /* time only every n-th evaluation (event brackets cost ~20 % when always on) */
 int hmcmt_profile_read(hmcmt_ctx* ctx, double* ms /*[HMCMT_NCAT]*/, int64_t* launches /*[HMCMT_NCAT]*/);
+/* the per-launch bracket overhead (microseconds) hmcmt_profile calibrated -- a kernel that spins for a known time on the
+ * device's wall clock, bracketed back to back -- and subtracts from every sampled launch */
+int hmcmt_profile_overhead(const hmcmt_ctx* ctx, double* us);
 
 /* What the sampled launches worked on (roofline numerators): out[0] = sum over the sampled iterations of the number of
  * systems still active (device counter, incremented by k_spmv_fused), out[1] = sum over the sampled solves of the systems

@@ -1,7 +1,11 @@
 """Generates tests/golden/cfg2_chain.npz: a 200-sample HMC chain of the ORACLE (direct solves) on BASELINE configs[1]
 (50x25-cell mesh, 8 frequencies, TE+TM; observations of cfg2.npz) with the sampler settings of the reference's
-examples (dt = 0.03, L in [6, 10], lambda = 1, bounds rho in [1, 1e4] ohm-m: examples/dprism3d/startupfile:3-8),
-homogeneous 100 ohm-m start / reference model, numpy Generator seed 2025.  About ten minutes on one core:
+examples (L in [6, 10], lambda = 1, bounds rho in [1, 1e4] ohm-m: examples/dprism3d/startupfile:3-8; dt = 0.015, half
+the example's: from the homogeneous start model with the example's dt this data set -- 3 % errors, misfit 3.5e5 -- rejects
+all of its first 200 proposals, which compares nothing), homogeneous 100 ohm-m reference model, the chain state started
+at the synthetic's true model (`start_model`; the reference keeps the file's start model as the chain state and takes
+the start Hamiltonian at the homogeneous model, HMCSampler.jl:88 vs :100-109, so the first proposal is accepted and the
+chain then samples the posterior region), numpy Generator seed 2025.  About twenty minutes on one core:
 `python tests/golden/make_chain.py`.  Stored: the Hamiltonian terms and accept flags of every sample (float64), the
 samples as float32, their mean and standard deviation (float64) -- what tests/test_gpu_posterior.py holds the HIP
 sampler to (north star: "posterior means/variances match the reference CPU path on the same synthetic model")."""
@@ -20,7 +24,13 @@ NSAMPLES, SEED, RHOREF = 200, 2025, 100.0
 
 def chain_prior():
     from hmcmt2d_amd.structs import HMCPrior
-    return HMCPrior(totalsamples=NSAMPLES, burninsamples=50, dt=0.03, timestep=[6, 10], sigBounds=[1e-4, 1.0], regParam=1.0)
+    return HMCPrior(totalsamples=NSAMPLES, burninsamples=50, dt=0.015, timestep=[6, 10], sigBounds=[1e-4, 1.0], regParam=1.0)
+
+
+def start_model(mesh, inv):
+    """ln sigma of the synthetic's true model (100 over 10 ohm-m + block) on the active cells"""
+    from hmcmt2d_amd import synthetic as S
+    return np.log(S.true_model_sigma(mesh)[inv.activeIdx])
 
 
 if __name__ == "__main__":
@@ -29,6 +39,7 @@ if __name__ == "__main__":
     mesh, data, inv, _ = make_problem("cfg2")
     O.setupTensorMesh2D(mesh)
     prior = chain_prior()
+    inv.strModel = start_model(mesh, inv)
     t0 = time.time()
     hm, st, hd = O.runHMCSampler(mesh, data, copy.deepcopy(inv), prior, np.random.default_rng(SEED), rhoref=RHOREF, dense_dbc=False)
     print("chain done in %.0f s: accepted %d of %d, nfevals %d, misfit %.1f -> %.1f" % (
