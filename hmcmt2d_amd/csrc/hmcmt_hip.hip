@@ -111,6 +111,9 @@ struct hmcmt_ctx {
     long long* backStamps = nullptr;         // HMCMT_BACK_STAMPS: per-block s_memtime stamps of k_back_post (debug entry only)
     size_t maxLdsBack = 64 * 1024;
     bool twistOn = true;                     // HMCMT_TWIST=0: classic one-sided sweeps in the fused kernel as well
+    int upd2Threads = 256, upd2Batch = 6;    // launch shape of k_update_fused<2> (launch_update2; HMCMT_UPD2)
+    int spmvThreads = 256;                   // launch shape of k_spmv_fused (launch_spmv; HMCMT_SPMV)
+    int upd1Threads = 256;                   // ... of k_update_fused<1> (HMCMT_UPD1)
     bool fusedFwdForce = false;              // HMCMT_FUSED_FWD=2: also where the heuristic prefers the separate kernels
     size_t maxLds = 64 * 1024;               // dynamic LDS the fused kernels may request
     bool lpFallback = false;                 // this solve has switched its stragglers to the fp64 preconditioner
@@ -250,6 +253,32 @@ bool fused_back_ok(const hmcmt_ctx* ctx) {
 dim3 tile_grid(const Solver& k, int ntiles) { return k.xmap ? dim3(8 * ((k.S + 7) / 8) * ntiles) : dim3(ntiles, k.S); }
 size_t update2_lds(const Solver& k) { return (size_t)(3 * k.RT2 + 8) * k.NYP * sizeof(float2); }
 int update2_tiles(const Solver& k) { return (k.nz - 1 + k.RT2 - 1) / k.RT2; }
+// The two stencil kernels of the iteration are launched with a thread count / batch size / tile height chosen per
+// problem (round 3): at the headline size their first phase runs at the bandwidth of the fabric (Infinity Cache) -- 88 MB
+// in 10 us with all systems active, in-kernel stamps HMCMT_STAMPS=upd -- so what counts is the bytes a tile loads, i.e.
+// the share of halo rows: taller tiles with proportionally more threads (same work per thread, same phase structure).
+// HMCMT_UPD2="threads,batch,rows" / HMCMT_SPMV="threads" override the choice.
+void launch_update2(hmcmt_ctx* ctx, const float2* pcur, const cplx* rin, cplx* rout, int it, int startOnly) {
+    const Solver& k = ctx->sv;
+    const dim3 grid = tile_grid(k, update2_tiles(k));
+    const size_t lds = update2_lds(k);
+#define UPD2(NT, UB) hipLaunchKernelGGL((k_update_fused<2, NT, UB>), grid, dim3(NT), lds, ctx->stream, k, pcur, rin, rout, it, startOnly)
+    const int nt = ctx->upd2Threads, ub = ctx->upd2Batch;
+    if (nt == 1024) UPD2(1024, 4);
+    else if (nt == 512 && ub <= 4) UPD2(512, 4);
+    else if (nt == 512 && ub <= 6) UPD2(512, 6);
+    else if (nt == 512) UPD2(512, 8);
+    else UPD2(256, 6);
+#undef UPD2
+}
+template <int SW>
+void launch_spmv(hmcmt_ctx* ctx, size_t lds, const float2* pin, float2* pout, int it) {
+    const Solver& k = ctx->sv;
+    const dim3 grid = tile_grid(k, k.NTR);
+    if (ctx->spmvThreads == 512) hipLaunchKernelGGL((k_spmv_fused<SW, 512>), grid, dim3(512), lds, ctx->stream, k, ctx->d_partZZ, pin, pout, it, ctx->opt.maxit);
+    else if (ctx->spmvThreads == 1024) hipLaunchKernelGGL((k_spmv_fused<SW, 1024>), grid, dim3(1024), lds, ctx->stream, k, ctx->d_partZZ, pin, pout, it, ctx->opt.maxit);
+    else hipLaunchKernelGGL((k_spmv_fused<SW, 256>), grid, dim3(256), lds, ctx->stream, k, ctx->d_partZZ, pin, pout, it, ctx->opt.maxit);
+}
 // two sweeps per side exist on the fused mixed-precision path (and on the fp64 path of the restarts)
 bool sweeps2_ok(const hmcmt_ctx* ctx) {
     const Solver& k = ctx->sv;
@@ -353,7 +382,7 @@ int apply_precond(hmcmt_ctx* ctx) {
         if (smooth && ctx->preDone) ctx->preDone = false;                        // (k_resid_pre has written t)
         else if (smooth && k.sweeps == 2) {                                       // both pre-sweeps of the residual at hand
             ProfScope ps(ctx, 3);
-            hipLaunchKernelGGL(k_update_fused<2>, tile_grid(k, update2_tiles(k)), vb, update2_lds(k), ctx->stream, k, k.p32a, k.r, k.r, 0, 1);
+            launch_update2(ctx, k.p32a, k.r, k.r, 0, 1);
         }
         else if (smooth) { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_pre_c64, vg, vb, 0, ctx->stream, k); }
         else { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_to_c64, vg, vb, 0, ctx->stream, k, k.r); }
@@ -469,11 +498,11 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
             // decide convergence of the state after iteration it-1, p = z + beta p, q = A p
             if (k.sweeps == 2 && k.merged2) {
                 ProfScope ps(ctx, 2);
-                hipLaunchKernelGGL(k_spmv_fused<2>, tile_grid(k, k.NTR), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx) + (size_t)(k.RT + 4) * k.NYP * sizeof(float2),
-                                   ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit);
-            } else { ProfScope ps(ctx, 2); hipLaunchKernelGGL(k_spmv_fused<1>, tile_grid(k, k.NTR), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, ctx->d_partZZ, pb[(it - 1) & 1], pb[it & 1], it, ctx->opt.maxit); }
-            if (k.sweeps == 2) { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused<2>, tile_grid(k, update2_tiles(k)), vb, update2_lds(k), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it, 0); }
-            else { ProfScope ps(ctx, 3); hipLaunchKernelGGL(k_update_fused<1>, tile_grid(k, k.NTR), vb, (size_t)(2 * k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it, 0); }
+                launch_spmv<2>(ctx, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx) + (size_t)(k.RT + 4) * k.NYP * sizeof(float2), pb[(it - 1) & 1], pb[it & 1], it);
+            } else { ProfScope ps(ctx, 2); launch_spmv<1>(ctx, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx), pb[(it - 1) & 1], pb[it & 1], it); }
+            if (k.sweeps == 2) { ProfScope ps(ctx, 3); launch_update2(ctx, pb[it & 1], rb[rcur], rb[rcur ^ 1], it, 0); }
+            else { ProfScope ps(ctx, 3); if (ctx->upd1Threads == 512) hipLaunchKernelGGL((k_update_fused<1, 512, 6>), tile_grid(k, k.NTR), dim3(512), (size_t)(2 * k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it, 0);
+                   else hipLaunchKernelGGL((k_update_fused<1, 256, 6>), tile_grid(k, k.NTR), dim3(256), (size_t)(2 * k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it, 0); }
             rcur ^= 1;
             k.r = rb[rcur];
             int prc;
@@ -854,6 +883,24 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->side) hipStreamSynchronize(ctx->side);      // (side-stream work of an evaluation nobody waited for)
+    if (ctx->sv.stamps) {                                // HMCMT_STAMPS: phase stamps of the last launch that wrote them
+        std::vector<long long> st(8 * 4096);
+        hipMemcpy(st.data(), ctx->sv.stamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        double acc[8] = {0}; long n = 0; long long t0min = 0x7fffffffffffffffLL, tend = 0;
+        for (int b = 0; b < 4096; ++b) {
+            const long long* p = &st[8 * b];
+            if (!p[0] || !p[6]) continue;
+            ++n;
+            for (int i = 1; i < 7; ++i) acc[i] += (double)(p[i] - p[i - 1]);
+            t0min = std::min(t0min, p[0]); tend = std::max(tend, p[6]);
+        }
+        if (n) {
+            fprintf(stderr, "HMCMT_STAMPS kernel %d: %ld workgroups; mean ticks per phase:", ctx->sv.stampKernel, n);
+            for (int i = 1; i < 7; ++i) fprintf(stderr, " %.0f", acc[i] / n);
+            fprintf(stderr, " | first entry -> last exit %lld ticks\n", tend - t0min);
+        }
+        hipFree(ctx->sv.stamps);
+    }
     if (ctx->side2) hipStreamSynchronize(ctx->side2);
     for (void* p : ctx->allocs) hipFree(p);
     for (hipEvent_t e : ctx->evPool) hipEventDestroy(e);
@@ -898,6 +945,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         const char* e = getenv("HMCMT_FUSED_FWD");
         ctx->fusedFwd = !(e && e[0] == '0');
         ctx->fusedFwdForce = e && e[0] == '2';
+
         if (const char* et = getenv("HMCMT_TWIST")) ctx->twistOn = et[0] != '0';
         if (const char* eb = getenv("HMCMT_FUSED_BACK")) ctx->fusedBack = eb[0] != '0';
         // (this kernel also has a few hundred bytes of static LDS: ask for less than the full 160 KB)
@@ -919,12 +967,15 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
                               reinterpret_cast<const void*>(k_transform_lp<2, 0>), reinterpret_cast<const void*>(k_transform_lp<2, 1>)})
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
         // the stencil kernels' tiles can pass 64 KB on wide meshes
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_fused<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_fused<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
+        for (const void* f : {reinterpret_cast<const void*>(k_update_fused<1, 256, 6>), reinterpret_cast<const void*>(k_update_fused<1, 512, 6>), reinterpret_cast<const void*>(k_update_fused<2, 256, 6>),
+                              reinterpret_cast<const void*>(k_update_fused<2, 512, 4>), reinterpret_cast<const void*>(k_update_fused<2, 512, 6>),
+                              reinterpret_cast<const void*>(k_update_fused<2, 512, 8>), reinterpret_cast<const void*>(k_update_fused<2, 1024, 4>)})
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_post2), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_back_post<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_fused<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_fused<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
+        for (const void* f : {reinterpret_cast<const void*>(k_spmv_fused<1, 256>), reinterpret_cast<const void*>(k_spmv_fused<1, 512>), reinterpret_cast<const void*>(k_spmv_fused<1, 1024>),
+                              reinterpret_cast<const void*>(k_spmv_fused<2, 256>), reinterpret_cast<const void*>(k_spmv_fused<2, 512>), reinterpret_cast<const void*>(k_spmv_fused<2, 1024>)})
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_resid_pre), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
     }
     HIPCHK(hipEventCreateWithFlags(&ctx->evExtA, hipEventDisableTiming));
@@ -1018,8 +1069,33 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     }
     k.NTR = (h.nz - 1 + k.RT - 1) / k.RT;
     k.sweeps = 1;
-    k.RT2 = getenv("HMCMT_RT2") ? std::max(k.RT, atoi(getenv("HMCMT_RT2"))) : k.RT;    // (>= RT: its partial sums fill the first slots of the k.NTR the consumers read;
-                                                                                     //  measured at the headline size: 7 (= RT) 21.8 / 26.0 ms per trajectory, 8: 22.6 / 26.2, 10: 23.4 / 27.0, 14: 23.4 / 27.2)
+    k.RT2 = k.RT;      // rows per tile of k_update_fused<2> (>= RT: its partial sums fill the first slots of the k.NTR the consumers read); set with the launch shapes below
+    // launch shapes of the two stencil kernels (launch_update2, launch_spmv).  Measured at the headline size, bench.py, steps/s
+    // (round 3, profiles/r03_launch_shapes.md): k_spmv_fused 256 / 512 / 1024 threads 290 / 294 / 275; k_update_fused<2>
+    // threads,batch,rows 256,6,7 (round 2) 294 | 512,8,14 304 | 512,6,14 301 | 512,4,14 297 | 1024,4,14 305 | 512,8,18 298 |
+    // 512,8,21 279 | 512,8,12 281 | 256,6,14 277: twice the rows with twice the threads -- the same work per thread, 4 halo
+    // rows per 14 instead of per 7.
+    ctx->spmvThreads = 512;
+    ctx->upd1Threads = 512;                 // (k_update_fused<1>: 367 -> 376 steps/s near the true model, 779 -> 794 on straight lines)
+    ctx->upd2Threads = 512; ctx->upd2Batch = 8;
+    if ((size_t)(3 * 2 * k.RT + 8) * k.NYP * sizeof(float2) <= (size_t)150 * 1024) k.RT2 = 2 * k.RT;
+    else { ctx->upd2Threads = 256; ctx->upd2Batch = 6; }
+    if (k.NYP > 256) { ctx->upd2Threads = 256; ctx->upd2Batch = 6; k.RT2 = k.RT; }      // (cfg5: 52.7 vs 51.8 steps/s with the taller tiles)
+    if (const char* e2 = getenv("HMCMT_RT2")) k.RT2 = std::max(k.RT, atoi(e2));
+    if (const char* eu = getenv("HMCMT_UPD2")) {              // "threads,batch,rows"
+        int a = 0, b = 0, c = 0;
+        const int n = sscanf(eu, "%d,%d,%d", &a, &b, &c);
+        if (n >= 1 && (a == 256 || a == 512 || a == 1024)) ctx->upd2Threads = a;
+        if (n >= 2 && b > 0) ctx->upd2Batch = b;
+        if (n >= 3 && c >= k.RT) k.RT2 = c;
+    }
+    if (const char* eu = getenv("HMCMT_UPD1")) { const int a = atoi(eu); if (a == 256 || a == 512) ctx->upd1Threads = a; }
+    if (const char* eu = getenv("HMCMT_SPMV")) { const int a = atoi(eu); if (a == 256 || a == 512 || a == 1024) ctx->spmvThreads = a; }
+    k.stamps = nullptr; k.stampKernel = 0;
+    if (const char* es = getenv("HMCMT_STAMPS")) {
+        k.stampKernel = !strcmp(es, "upd") ? 1 : (!strcmp(es, "spmv") ? 2 : 0);
+        if (k.stampKernel) { HIPCHK(hipMalloc((void**)&k.stamps, sizeof(long long) * 8 * 4096)); HIPCHK(hipMemset(k.stamps, 0, sizeof(long long) * 8 * 4096)); }
+    }
     k.xmap = getenv("HMCMT_XMAP") ? atoi(getenv("HMCMT_XMAP")) : 0;     // (XCD-aware tile placement: measured neutral, kernels_fused.h tile_map)
     k.w2 = getenv("HMCMT_JACOBI_W2") ? (float)atof(getenv("HMCMT_JACOBI_W2")) : 1.0f;
     k.merged2 = getenv("HMCMT_POST2") && atoi(getenv("HMCMT_POST2")) == 1 ? 0 : 1;

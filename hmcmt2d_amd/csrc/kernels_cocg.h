@@ -56,6 +56,8 @@ struct Solver {
     int* stallHost;                       // pinned host flag: a system has not improved its error estimate 10-fold in STALL_IT iterations
     int* failHost;                        // pinned host word: status (HMCMT_ENOCONV / HMCMT_EBREAKDOWN) of a system that has just given up --
                                           // the host must not build on this solve (adjoint on a failed forward, next leapfrog step)
+    long long* stamps;                    // HMCMT_STAMPS=<kernel>: per-workgroup s_memtime stamps of that kernel's phases ([workgroup][8]; printed at hmcmt_destroy)
+    int stampKernel;                      // 1 k_update_fused<2> / k_update2r, 2 k_spmv_fused<2>
     unsigned long long* cntActive;        // non-null in an evaluation sampled by hmcmt_profile: += systems still active per iteration
 };
 
@@ -82,16 +84,16 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // block-wide deterministic sum of up to 2 doubles; result valid in thread 0
-__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh /* [2*8]: workgroups of up to 8 waves */) {
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh /* [2*16]: workgroups of up to 16 waves */) {
     a = wave_sum(a);
     b = wave_sum(b);
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if (l == 0) { sh[w] = a; sh[8 + w] = b; }
+    if (l == 0) { sh[w] = a; sh[16 + w] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const int nw = (blockDim.x + 63) >> 6;
         double sa = 0, sb = 0;
-        for (int i = 0; i < nw; ++i) { sa += sh[i]; sb += sh[8 + i]; }
+        for (int i = 0; i < nw; ++i) { sa += sh[i]; sb += sh[16 + i]; }
         a = sa; b = sb;
     }
 }
@@ -149,7 +151,7 @@ __device__ __forceinline__ cplx sum_partA(const Solver& k, int s) {
 __global__ __launch_bounds__(VBLOCK) void k_spmv(Solver k) {
     const int s = blockIdx.y;
     if (!k.active[s]) return;
-    __shared__ double sh[16];
+    __shared__ double sh[32];
     const int mode = s >= k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
     const double w = k.omega[s];
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv(Solver k) {
 __global__ __launch_bounds__(VBLOCK) void k_update(Solver k) {
     const int s = blockIdx.y;
     if (!k.active[s]) return;
-    __shared__ double sh[16];
+    __shared__ double sh[32];
     const long so = (long)s * k.vstride;
     const cplx al = k.rho[s] / sum_partA(k, s);
     const cplx *p = k.p + so, *q = k.q + so;
@@ -207,8 +209,8 @@ __global__ __launch_bounds__(VBLOCK) void k_update(Solver k) {
 __global__ __launch_bounds__(VBLOCK) void k_dots(Solver k, double* partZZ) {
     const int s = blockIdx.y;
     if (!k.active[s]) return;
-    __shared__ double sh[16];
-    __shared__ double sh2[16];
+    __shared__ double sh[32];
+    __shared__ double sh2[32];
     const long so = (long)s * k.vstride;
     const cplx *r = k.r + so, *z = k.z + so;
     const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);

@@ -357,8 +357,8 @@ __global__ __launch_bounds__(VBLOCK) void k_mid(Solver k) {
 __global__ __launch_bounds__(VBLOCK) void k_post(Solver k, double* partZZ, float2* z32out) {
     const int s = blockIdx.y;
     if (!k.active[s]) return;
-    __shared__ double sh[16];
-    __shared__ double sh2[16];
+    __shared__ double sh[32];
+    __shared__ double sh2[32];
     const int mode = s >= k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
     const double w = k.omega[s];
@@ -1140,8 +1140,8 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
 __global__ __launch_bounds__(VBLOCK) void k_post_w2(Solver k, double* partZZ) {
     const int s = blockIdx.y;
     if (!k.active[s]) return;
-    __shared__ double sh[16];
-    __shared__ double sh2[16];
+    __shared__ double sh[32];
+    __shared__ double sh2[32];
     const int mode = s >= k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
     const double w = k.omega[s];
@@ -1189,8 +1189,8 @@ __global__ __launch_bounds__(VBLOCK) void k_post2(Solver k, double* partZZ) {
     if (!k.active[s]) return;
     extern __shared__ __attribute__((aligned(16))) char smem_p2[];
     c32* zs = reinterpret_cast<c32*>(smem_p2);            // [(RT+2)][NYP]
-    __shared__ double sh[16];
-    __shared__ double sh2[16];
+    __shared__ double sh[32];
+    __shared__ double sh2[32];
     const int NYP = k.NYP, iz0 = 1 + blockIdx.x * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);
     const int nrows = iz1 - iz0 + 3;
     const int mode = s >= k.nFreq;

@@ -26,6 +26,7 @@
 // batch go out together before the active flag is even tested, the stencil coefficients of the first batch before
 // the staging barrier (11.0 -> 10.3 us; the same treatment of k_update_fused, which moves twice the bytes and sits
 // at 5 TB/s, changed nothing, and neither did computing its dinv from dK, dM instead of loading it).
+#define PH_STAMP(kid, i) if (k.stamps && k.stampKernel == (kid) && threadIdx.x == 0) k.stamps[((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 + (i)] = __builtin_amdgcn_s_memtime();
 constexpr int SB = 4;                  // elements per thread and batch
 constexpr int STALL_IT = 30;           // mixed-precision stagnation watch: iterations allowed per 10-fold drop of the error estimate
 struct StenCo { double dk, dm, cy0, cy1, cz0, cz1; };
@@ -63,11 +64,11 @@ __device__ __forceinline__ bool tile_map(const Solver& k, int ntiles, int& tile,
     return s < k.S;
 }
 
-template <int SW>
-__global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* partZZ, const float2* pin_, float2* pout, int it, int maxit) {
+template <int SW, int NT>             // NT: threads per workgroup (chosen by the host: launch_spmv)
+__global__ __launch_bounds__(NT) void k_spmv_fused(Solver k, const double* partZZ, const float2* pin_, float2* pout, int it, int maxit) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
     cplx* pn = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]
-    __shared__ double sh[16];
+    __shared__ double sh[32];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *(volatile int*)k.progHost = it;   // "iteration it-1 is complete"
     int tile, s;
     if (!tile_map(k, k.NTR, tile, s)) return;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
     auto ld_stage = [&](int i0) {
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-            const unsigned e = (unsigned)(ebase + min(i0 + u * VBLOCK, ntot - 1));
+            const unsigned e = (unsigned)(ebase + min(i0 + u * NT, ntot - 1));
             zv[u] = z[e];
             pv[u] = first ? float2{0.f, 0.f} : pi[e];
         }
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
         // z4 on rows iz0-2 .. iz1+2 (outside the mesh: zero) -> LDS, then z = z4 + dinv .* (r - A z4) on rows iz0-1 .. iz1+1
         c32* z4s = reinterpret_cast<c32*>(pn + (long)(k.RT + 2) * NYP);      // [(RT+4)][NYP]
         const int nz4 = (nrows + 2) * NYP;
-        for (int i = threadIdx.x; i < nz4; i += VBLOCK) {
+        for (int i = threadIdx.x; i < nz4; i += NT) {
             const int lr = div_small(i, rNYP), row = iz0 - 2 + lr;
             float2 v = float2{0.f, 0.f};
             if (row >= 0 && row <= k.nz) v = z[(long)row * NYP + (i - lr * NYP)];
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
         auto ld2 = [&](int i0) {
 #pragma unroll
             for (int u = 0; u < UB2; ++u) {
-                const int i = min(i0 + u * VBLOCK, ntot - 1);
+                const int i = min(i0 + u * NT, ntot - 1);
                 const int lr = div_small(i, rNYP), iy = i - lr * NYP, row = iz0 - 1 + lr;
                 in[u] = row >= 1 && row <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1;
                 const long e = (long)row * NYP + iy;
@@ -159,11 +160,11 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
         };
         ld2(threadIdx.x);
         __syncthreads();                                         // z4s complete
-        for (int i0 = threadIdx.x; i0 < ntot; i0 += UB2 * VBLOCK) {
+        for (int i0 = threadIdx.x; i0 < ntot; i0 += UB2 * NT) {
             if (i0 != (int)threadIdx.x) ld2(i0);
 #pragma unroll
             for (int u = 0; u < UB2; ++u) {
-                const int i = i0 + u * VBLOCK;
+                const int i = i0 + u * NT;
                 if (i < ntot) {
                     cplx zc = cplx{0, 0};
                     if (in[u]) {
@@ -183,11 +184,11 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
             }
         }
     } else
-    for (int i0 = threadIdx.x; i0 < ntot; i0 += SB * VBLOCK) {
+    for (int i0 = threadIdx.x; i0 < ntot; i0 += SB * NT) {
         if (i0 != (int)threadIdx.x) ld_stage(i0);
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-            const int i = i0 + u * VBLOCK;
+            const int i = i0 + u * NT;
             if (i < ntot) {
                 const cplx zc = cplx{(double)zv[u].x, (double)zv[u].y};
                 const cplx v = first ? zc : zc + be * cplx{(double)pv[u].x, (double)pv[u].y};
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
     auto ld_co = [&](int i0) {
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-            const unsigned e = (unsigned)(obase + min(i0 + u * VBLOCK, nown - 1));
+            const unsigned e = (unsigned)(obase + min(i0 + u * NT, nown - 1));
             co[u].dk = dKm[e]; co[u].dm = dMm[e];
             co[u].cy0 = cYm[e]; co[u].cy1 = cYm[e - 1u];
             co[u].cz0 = cZm[e]; co[u].cz1 = cZu[e];
@@ -212,11 +213,11 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
     ld_co(threadIdx.x);
     __syncthreads();
     double ar = 0, ai = 0;
-    for (int i0 = threadIdx.x; i0 < nown; i0 += SB * VBLOCK) {
+    for (int i0 = threadIdx.x; i0 < nown; i0 += SB * NT) {
         if (i0 != (int)threadIdx.x) ld_co(i0);
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-            const int i = i0 + u * VBLOCK;
+            const int i = i0 + u * NT;
             const int iy = i - div_small(i, rNYP) * NYP;
             if (i < nown && iy >= 1 && iy <= k.ny - 1) {
                 const int l = i + NYP;
@@ -245,8 +246,8 @@ __global__ __launch_bounds__(VBLOCK) void k_spmv_fused(Solver k, const double* p
 // anyway -- so the three arrays of (RT + 4), (RT + 2), (RT + 2) rows fit where the two fp64 arrays of SW = 1 do.
 // startOnly (SW = 2): the pre-smoothing of the residual of a solve's first preconditioner application -- alpha = 0,
 // x and r stay untouched (k_resid_pre does this for one sweep).
-template <int SW>
-__global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2* pcur, const cplx* rin, cplx* rout, int it, int startOnly = 0) {
+template <int SW, int NT, int UBX>    // NT: threads per workgroup; UBX: elements per thread and batch of the two-sweep form
+__global__ __launch_bounds__(NT) void k_update_fused(Solver k, const float2* pcur, const cplx* rin, cplx* rout, int it, int startOnly) {
     const int RTt = SW == 2 ? k.RT2 : k.RT;
     const int ntiles = (k.nz - 1 + RTt - 1) / RTt;
     int tile, s;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
         c32* z1s = reinterpret_cast<c32*>(smem_);             // [(RT+4)][NYP]  z1 = dinv .* r'   rows iz0-2 .. iz1+2
         c32* rs = z1s + (long)(RTt + 4) * NYP;                // [(RT+2)][NYP]  r'                rows iz0-1 .. iz1+1
         c32* z2s = rs + (long)(RTt + 2) * NYP;               // [(RT+2)][NYP]  z2                rows iz0-1 .. iz1+1
-        __shared__ double sh2[16];
+        __shared__ double sh2[32];
         cplx al = cplx{0, 0};
         if (!startOnly) {
             const cplx pq = total_part(k.partPQ + (long)s * MAXNB, k.NTR);
@@ -275,14 +276,15 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
         cplx *x = k.x + so, *ro = rout + so;
         float2 *t = k.t32 + so, *z2o = k.zs32 + so, *t2o = k.t2_32 + so;
         double xx = 0, dummy = 0, p1r = 0, p1i = 0;
+        PH_STAMP(1, 0)
         // Every phase is a short chain (loads -> arithmetic -> LDS -> barrier): the loads of a batch of UB elements per
         // thread are issued together, unconditionally (clamped addresses), apart from their use -- inside `if (valid)` the
         // compiler keeps each load next to its use and a phase costs one memory round trip per element (48 VGPRs,
         // 20.6 us) instead of one per batch.
-        constexpr int UB = 6;
+        constexpr int UB = UBX;
         const int nA = (nrows + 2) * NYP, nB = nrows * NYP, nown = (iz1 - iz0 + 1) * NYP;
         // phase A: r' and z1 on rows iz0-2 .. iz1+2 (rows outside the mesh: zero)
-        for (int i0 = threadIdx.x; i0 < nA; i0 += UB * VBLOCK) {
+        for (int i0 = threadIdx.x; i0 < nA; i0 += UB * NT) {
             cplx rv[UB], qv[UB], xv[UB];
             float2 pv[UB], dv[UB];
             long ee[UB];
@@ -290,9 +292,9 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
             bool ok[UB];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                const int i = min(i0 + u * VBLOCK, nA - 1);
+                const int i = min(i0 + u * NT, nA - 1);
                 const int lr = div_small(i, rNYP), iy = i - lr * NYP, row = iz0 - 2 + lr;
-                ok[u] = i0 + u * VBLOCK < nA && row >= 0 && row <= k.nz;
+                ok[u] = i0 + u * NT < nA && row >= 0 && row <= k.nz;
                 lrs[u] = lr;
                 ee[u] = (long)min(max(row, 0), k.nz) * NYP + iy;
                 rv[u] = ri[ee[u]]; dv[u] = di[ee[u]];
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                const int i = i0 + u * VBLOCK;
+                const int i = i0 + u * NT;
                 if (i < nA) {
                     cplx rn = cplx{0, 0}, z1 = cplx{0, 0};
                     if (ok[u]) {
@@ -337,20 +339,22 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
             auto ldB = [&](int i0) {
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
-                    const int i = min(i0 + u * VBLOCK, nB - 1);
+                    const int i = min(i0 + u * NT, nB - 1);
                     const int lr = div_small(i, rNYP), iy = i - lr * NYP, row = iz0 - 1 + lr;
-                    in[u] = i0 + u * VBLOCK < nB && row >= 1 && row <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1;
+                    in[u] = i0 + u * NT < nB && row >= 1 && row <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1;
                     const long e = (long)row * NYP + iy;
                     ca[u] = cf[2 * e]; cb[u] = cf[2 * e + 1]; dv[u] = di[e];
                 }
             };
             ldB(threadIdx.x);
+            PH_STAMP(1, 1)
             __syncthreads();                                         // z1s, rs complete
-            for (int i0 = threadIdx.x; i0 < nB; i0 += UB * VBLOCK) {
+            PH_STAMP(1, 2)
+            for (int i0 = threadIdx.x; i0 < nB; i0 += UB * NT) {
                 if (i0 != (int)threadIdx.x) ldB(i0);
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
-                    const int i = i0 + u * VBLOCK;
+                    const int i = i0 + u * NT;
                     if (i < nB) {
                         c32 z2 = c32{0.f, 0.f};
                         if (in[u]) {
@@ -370,17 +374,19 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
             auto ldC = [&](int i0) {
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
-                    const long e = (long)iz0 * NYP + min(i0 + u * VBLOCK, nown - 1);
+                    const long e = (long)iz0 * NYP + min(i0 + u * NT, nown - 1);
                     ca[u] = cf[2 * e]; cb[u] = cf[2 * e + 1];
                 }
             };
             ldC(threadIdx.x);
+            PH_STAMP(1, 3)
             __syncthreads();                                         // z2s complete
-            for (int i0 = threadIdx.x; i0 < nown; i0 += UB * VBLOCK) {
+            PH_STAMP(1, 4)
+            for (int i0 = threadIdx.x; i0 < nown; i0 += UB * NT) {
                 if (i0 != (int)threadIdx.x) ldC(i0);
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
-                    const int i = i0 + u * VBLOCK;
+                    const int i = i0 + u * NT;
                     if (i < nown) {
                         const int lr = div_small(i, rNYP), iy = i - lr * NYP;
                         const int l = i + NYP;                         // the same node in rs / z2s
@@ -396,11 +402,12 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
                 }
             }
         }
-        __shared__ double sh3[16];
+        __shared__ double sh3[32];
+        PH_STAMP(1, 5)
         block_sum2(p1r, p1i, sh3);
         if (threadIdx.x == 0) k.partR[(long)s * MAXNB + tile] = cplx{p1r, p1i};
         if (tile == 0)                                                 // (fewer tiles than the k.NTR partial sums the consumers add up)
-            for (int b = ntiles + threadIdx.x; b < k.NTR; b += VBLOCK) {
+            for (int b = ntiles + threadIdx.x; b < k.NTR; b += NT) {
                 k.partR[(long)s * MAXNB + b] = cplx{0, 0};
                 if (!startOnly) k.partB[(long)s * MAXNB + b] = 0.0;
             }
@@ -410,11 +417,12 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
             k.partB[(long)s * MAXNB + tile] = xx;
             if (tile == 0) k.alphaBeta[s] = al;
         }
+        PH_STAMP(1, 6)
         return;
     }
     cplx* cs = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]  dinv .* r'
     cplx* rs = cs + (long)(k.RT + 2) * NYP;               // [RT][NYP]      r' of the own rows
-    __shared__ double sh[16];
+    __shared__ double sh[32];
     const cplx pq = total_part(k.partPQ + (long)s * MAXNB, k.NTR);
     const cplx al = k.rho2[(long)(it & 1) * k.S + s] / pq;
     const int mode = s >= k.nFreq;
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
     float2* t = k.t32 + so;
     double xx = 0, dummy = 0;
     // r' = r - alpha q and dinv .* r' on rows iz0-1 .. iz1+1 (r, q, dinv vanish outside the interior: no masking)
-    for (int i = threadIdx.x; i < nrows * NYP; i += VBLOCK) {
+    for (int i = threadIdx.x; i < nrows * NYP; i += NT) {
         const int lr = i / NYP, iy = i - lr * NYP;
         const long e = (long)(iz0 - 1 + lr) * NYP + iy;
         const cplx rn = ri[e] - al * q[e];
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(VBLOCK) void k_update_fused(Solver k, const float2*
     }
     __syncthreads();
     const int nown = (iz1 - iz0 + 1) * NYP;
-    for (int i = threadIdx.x; i < nown; i += VBLOCK) {
+    for (int i = threadIdx.x; i < nown; i += NT) {
         const int lr = i / NYP, iy = i - lr * NYP;
         const long e = (long)(iz0 + lr) * NYP + iy;
         cplx out = cplx{0, 0};
@@ -769,7 +777,7 @@ __global__ __launch_bounds__(VBLOCK) void k_extrap(Solver k, cplx* x, cplx* xp, 
 // true residual norm check: partB = |b - A x|^2 with b passed separately (verify option)
 __global__ __launch_bounds__(VBLOCK) void k_trueres(Solver k, const cplx* b, const cplx* x, double* partRes, double* partBn) {
     const int s = blockIdx.y;
-    __shared__ double sh[16];
+    __shared__ double sh[32];
     const int mode = s >= k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
     const double w = k.omega[s];

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) void k_rx(View v, int wantDeriv) {
 }
 __global__ void k_resid(View v) { int p = TID1; if (p < v.nData) item_resid(v, p); }
 __global__ void k_misfit(View v, double* out) {
-    __shared__ double sh[16];
+    __shared__ double sh[32];
     double a = 0, b = 0;
     for (int p = threadIdx.x; p < v.nData; p += blockDim.x) a += v.misfitPart[p];
     block_sum2(a, b, sh);
@@ -289,7 +289,7 @@ __global__ void k_lf_step(LfView L, double dt, double lo, double hi) {
 }
 // mnorm = 0.5*lambda*(m-mref)' Wm (m-mref)   (HMCSampler.jl:389-391): partial sums, then block 0 finishes
 __global__ __launch_bounds__(256) void k_lf_mnorm(LfView L, double lambda) {
-    __shared__ double sh[16];
+    __shared__ double sh[32];
     double acc = 0.0, dummy = 0.0;
     for (int a = blockIdx.x * 256 + threadIdx.x; a < L.n; a += 256 * LFNB) {
         double row = 0.0;
