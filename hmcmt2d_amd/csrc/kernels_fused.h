@@ -72,6 +72,7 @@ __global__ __launch_bounds__(NT) void k_spmv_fused(Solver k, const double* partZ
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *(volatile int*)k.progHost = it;   // "iteration it-1 is complete"
     int tile, s;
     if (!tile_map(k, k.NTR, tile, s)) return;
+    PH_STAMP(2, 0)
     const bool first = it == 1;
     const int act = k.active[s];
     const int ln = threadIdx.x & 63;
@@ -100,8 +101,45 @@ __global__ __launch_bounds__(NT) void k_spmv_fused(Solver k, const double* partZ
             pv[u] = first ? float2{0.f, 0.f} : pi[e];
         }
     };
-    if (SW == 1) ld_stage(threadIdx.x);
+    // SW = 2: the first batch of the z4 rows (iz0-2 .. iz1+2) and of the second post-sweep's operands, requested here as
+    // well -- unconditionally, clamped, apart from their use.  (Until round 3 the z4 staging loop loaded each element
+    // inside `if (row in the mesh)` right in front of its LDS store: one memory round trip per element, 4.5 per thread
+    // in a row -- 11 500 of the kernel's 24 000 ticks, HMCMT_STAMPS=spmv.)
+    constexpr int ZB = 5;                                          // z4 elements per thread and batch
+    constexpr int UB2 = 4;
+    const int nz4 = (nrows + 2) * NYP;
+    float2 zq[ZB];
+    bool zin[ZB];
+    auto ldz = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < ZB; ++u) {
+            const int i = min(i0 + u * NT, nz4 - 1);
+            const int lr = div_small(i, rNYP), row = iz0 - 2 + lr;
+            zin[u] = row >= 0 && row <= k.nz;
+            zq[u] = z[(unsigned)(min(max(row, 0), k.nz) * NYP + (i - lr * NYP))];
+        }
+    };
+    const cplx* rr = k.r + so;
+    const float2* di = k.dinv32 + so;
+    const float4* cf = k.cf32 + 2 * mo;
+    float4 ca[UB2], cb[UB2];
+    cplx rv[UB2];
+    float2 pv2[UB2], dv[UB2];
+    bool in[UB2];
+    auto ld2 = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < UB2; ++u) {
+            const int i = min(i0 + u * NT, ntot - 1);
+            const int lr = div_small(i, rNYP), iy = i - lr * NYP, row = iz0 - 1 + lr;
+            in[u] = row >= 1 && row <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1;
+            const unsigned e = (unsigned)(row * NYP + iy);
+            ca[u] = cf[2u * e]; cb[u] = cf[2u * e + 1u]; rv[u] = rr[e]; dv[u] = di[e];
+            pv2[u] = first ? float2{0.f, 0.f} : pi[e];
+        }
+    };
     if (!act) return;
+    if (SW == 1) ld_stage(threadIdx.x);
+    if (SW == 2) { ldz(threadIdx.x); ld2(threadIdx.x); }        // (behind the test: the workgroups of a converged system must not pull 60 KB each through the fabric)
     const cplx rz = cplx{wave_sum(paL.re), wave_sum(paL.im)};
     const double zz = wave_sum(pzL), xx = wave_sum(pbL);
     bool on = true;
@@ -128,38 +166,22 @@ __global__ __launch_bounds__(NT) void k_spmv_fused(Solver k, const double* partZ
         return;
     }
     if (k.cntActive && tile == 0 && threadIdx.x == 0) atomicAdd(k.cntActive, 1ull);   // (roofline accounting only)
+    PH_STAMP(2, 1)
     if constexpr (SW == 2) {
         // z4 on rows iz0-2 .. iz1+2 (outside the mesh: zero) -> LDS, then z = z4 + dinv .* (r - A z4) on rows iz0-1 .. iz1+1
         c32* z4s = reinterpret_cast<c32*>(pn + (long)(k.RT + 2) * NYP);      // [(RT+4)][NYP]
-        const int nz4 = (nrows + 2) * NYP;
-        for (int i = threadIdx.x; i < nz4; i += NT) {
-            const int lr = div_small(i, rNYP), row = iz0 - 2 + lr;
-            float2 v = float2{0.f, 0.f};
-            if (row >= 0 && row <= k.nz) v = z[(long)row * NYP + (i - lr * NYP)];
-            z4s[i] = c32{v.x, v.y};
-        }
-        const cplx* rr = k.r + so;
-        const float2* di = k.dinv32 + so;
-        const float4* cf = k.cf32 + 2 * mo;
-        const float wf = (float)w;
-        constexpr int UB2 = 4;
-        float4 ca[UB2], cb[UB2];
-        cplx rv[UB2];
-        float2 pv2[UB2], dv[UB2];
-        bool in[UB2];
-        auto ld2 = [&](int i0) {
+        for (int i0 = threadIdx.x; i0 < nz4; i0 += ZB * NT) {
+            if (i0 != (int)threadIdx.x) ldz(i0);
 #pragma unroll
-            for (int u = 0; u < UB2; ++u) {
-                const int i = min(i0 + u * NT, ntot - 1);
-                const int lr = div_small(i, rNYP), iy = i - lr * NYP, row = iz0 - 1 + lr;
-                in[u] = row >= 1 && row <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1;
-                const long e = (long)row * NYP + iy;
-                ca[u] = cf[2 * e]; cb[u] = cf[2 * e + 1]; rv[u] = rr[e]; dv[u] = di[e];
-                pv2[u] = first ? float2{0.f, 0.f} : pi[e];
+            for (int u = 0; u < ZB; ++u) {
+                const int i = i0 + u * NT;
+                if (i < nz4) z4s[i] = zin[u] ? c32{zq[u].x, zq[u].y} : c32{0.f, 0.f};
             }
-        };
-        ld2(threadIdx.x);
+        }
+        const float wf = (float)w;
+        PH_STAMP(2, 2)
         __syncthreads();                                         // z4s complete
+        PH_STAMP(2, 3)
         for (int i0 = threadIdx.x; i0 < ntot; i0 += UB2 * NT) {
             if (i0 != (int)threadIdx.x) ld2(i0);
 #pragma unroll
@@ -211,7 +233,9 @@ __global__ __launch_bounds__(NT) void k_spmv_fused(Solver k, const double* partZ
         }
     };
     ld_co(threadIdx.x);
+    PH_STAMP(2, 4)
     __syncthreads();
+    PH_STAMP(2, 5)
     double ar = 0, ai = 0;
     for (int i0 = threadIdx.x; i0 < nown; i0 += SB * NT) {
         if (i0 != (int)threadIdx.x) ld_co(i0);
@@ -236,6 +260,7 @@ __global__ __launch_bounds__(NT) void k_spmv_fused(Solver k, const double* partZ
     }
     block_sum2(ar, ai, sh);
     if (threadIdx.x == 0) k.partPQ[(long)s * MAXNB + tile] = cplx{ar, ai};
+    PH_STAMP(2, 6)
 }
 
 // SW = 2 (two damped Jacobi sweeps on each side of the FDM stage, k.sweeps == 2): the pre-smoother becomes
