@@ -15,7 +15,7 @@ from .marshal import CreateArgs, CREATE_ARGTYPES, c_double_p, c_int64_p
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("HMCMT_LIB_PATH") or os.path.join(HERE, "libhmcmt_hip.so")   # (override: A/B runs of two builds)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = [os.path.join(CSRC, "hmcmt_hip.hip"), os.path.join(CSRC, "mumps_shim.hip")]
+SOURCES = [os.path.join(CSRC, "hmcmt_hip.hip"), os.path.join(CSRC, "mumps_shim.hip"), os.path.join(CSRC, "comm.hip")]
 HEADERS = [os.path.join(CSRC, h) for h in ("hmcmt_math.h", "hmcmt_items.h", "hmcmt_host.h", "kernels_cocg.h", "kernels_fdm.h",
                                             "kernels_fused.h", "kernels_path.h")] + \
           [os.path.join(HERE, "..", "include", "hmcmt.h"), os.path.join(HERE, "..", "include", "hmcmt_mumps.h")]
@@ -57,7 +57,7 @@ def build_library(force=False, verbose=False):
     if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= newest:
         return SO_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value", "-Wno-pass-failed", "-o", SO_PATH] + SOURCES
+           "-Wno-unused-value", "-Wno-pass-failed", "-o", SO_PATH] + SOURCES + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -105,6 +105,14 @@ def load_library():
     lib.hmcmt_profile_overhead.argtypes = [vp, C.POINTER(C.c_double)]
     lib.hmcmt_dims.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.hmcmt_debug_transform.argtypes = [vp, C.c_int32, c_double_p, c_double_p]
+    lib.hmcmt_comm_id.argtypes = [C.c_char_p]
+    lib.hmcmt_comm_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32, C.c_char_p]
+    lib.hmcmt_allgather_samples.argtypes = [vp, vp, vp, C.c_int64, C.c_int32]
+    lib.hmcmt_comm_destroy.argtypes = [vp]
+    lib.hmcmt_comm_last_error.argtypes = [vp]
+    lib.hmcmt_comm_last_error.restype = C.c_char_p
+    for name in ("hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy"):
+        getattr(lib, name).restype = C.c_int
     lib.hmcmt_debug_flags.argtypes = [vp, C.c_int32]
     lib.hmcmt_debug_spmv.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_precond.argtypes = [vp, c_double_p, c_double_p]
@@ -125,11 +133,55 @@ EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "h
                     "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async", "hmcmt_wait",
                     "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead", "hmcmt_dims",
                     "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
-                    "hmcmt_debug_back_post"]
+                    "hmcmt_debug_back_post", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
+                    "hmcmt_comm_last_error"]
 
 
 def _dp(a):
     return a.ctypes.data_as(c_double_p)
+
+
+class SampleComm:
+    """hmcmt_comm: the RCCL communicator of this process (one process per GPU) for the all-gather of sample blocks."""
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        lib = load_library()
+        buf = C.create_string_buffer(SampleComm.ID_BYTES)
+        rc = lib.hmcmt_comm_id(buf)
+        if rc != 0:
+            raise HmcmtError(rc, (lib.hmcmt_comm_last_error(None) or b"").decode())
+        return buf.raw
+
+    def __init__(self, device_id, nranks, rank, uid):
+        self.lib = load_library()
+        if len(uid) != self.ID_BYTES:
+            raise ValueError("the RCCL unique id has 128 bytes")
+        h = C.c_void_p()
+        rc = self.lib.hmcmt_comm_create(C.byref(h), int(device_id), int(nranks), int(rank), uid)
+        if rc != 0:
+            raise HmcmtError(rc, (self.lib.hmcmt_comm_last_error(None) or b"").decode())
+        self.h, self.nranks, self.rank = h, int(nranks), int(rank)
+
+    def allgather(self, block):
+        """host float64 block of this rank -> [nranks, len(block)] with every rank's block"""
+        send = np.ascontiguousarray(block, dtype=np.float64).reshape(-1)
+        recv = np.empty(self.nranks * send.size)
+        rc = self.lib.hmcmt_allgather_samples(self.h, send.ctypes.data, recv.ctypes.data, send.size, 0)
+        if rc != 0:
+            raise HmcmtError(rc, (self.lib.hmcmt_comm_last_error(self.h) or b"").decode())
+        return recv.reshape(self.nranks, send.size)
+
+    def allgather_device(self, d_send, d_recv, count):
+        rc = self.lib.hmcmt_allgather_samples(self.h, d_send, d_recv, int(count), 1)
+        if rc != 0:
+            raise HmcmtError(rc, (self.lib.hmcmt_comm_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if self.h:
+            self.lib.hmcmt_comm_destroy(self.h)
+            self.h = None
 
 
 class HipContext:

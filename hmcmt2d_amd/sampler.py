@@ -358,7 +358,7 @@ def runHMCSampler(mtMesh, mtData, invParam, hmcprior, rng=None, rhoref=None, ctx
 
 # --------------------------------------------------------------------------------------------
 def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, outdir=None, nchains=None,
-                       run_chain=None, device_id=None, context_factory=None, chains_per_gpu=1, **sampler_kw):
+                       run_chain=None, device_id=None, context_factory=None, chains_per_gpu=1, gather="torch", **sampler_kw):
     """Independent chains, one process per GPU (parallelHMC.jl:10-49).
 
     With `torch.distributed` initialised (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
@@ -373,6 +373,9 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
     thread each: a single chain's launches are latency-bound at the headline size, and two chains overlap to
     1.34x the throughput of one (measured, scripts/gpu_two_chains.py); the chains and their results are the same as
     run one after another (independent contexts, per-chain RNG streams).
+    `gather="library"`: the sample blocks are all-gathered by the library's own RCCL entry point
+    (hmcmt_allgather_samples, include/hmcmt.h -- what a non-Python host would call) instead of torch's; the process
+    group then only carries the 128-byte RCCL id from rank 0 to the others.  Works without a process group too (one rank).
     Further keyword arguments go to runHMCSampler (e.g. device_leapfrog=True; `checkpoint=path` becomes
     `path.chain<k>` per chain).
     Returns (hmcmodel[list], hmcstats[list], hmcdata[list]) indexed by chain.
@@ -437,7 +440,15 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
         return buf
 
     local = np.concatenate([pack(s) for s in range(per)]) if per else np.zeros(0)
-    if have_pg and world > 1:
+    if gather == "library":
+        from .lib import SampleComm
+        uid = [SampleComm.unique_id() if rank == 0 else None]
+        if have_pg and world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        comm = SampleComm(dev_id, world, rank, uid[0])
+        allbuf = comm.allgather(local).reshape(world, per, blk)
+        comm.close()
+    elif have_pg and world > 1:
         dev = torch.device("cuda", dev_id) if use_cuda else torch.device("cpu")
         send = torch.from_numpy(local).to(dev)
         recv = torch.empty(world * local.size, dtype=torch.float64, device=dev)

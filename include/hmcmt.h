@@ -175,6 +175,24 @@ int hmcmt_leapfrog_device(hmcmt_ctx* ctx, double* d_m, double* d_p, double dt, i
  * the adjoint fields instead (interior = eVal of compJacTMatVec.jl:221, boundary 0). */
 int hmcmt_get_fields(hmcmt_ctx* ctx, int32_t adjoint, double* exTE, double* hxTM);
 
+/* All-gather of the chains' sample blocks over RCCL (xGMI inside a node): one process per GPU, one communicator per
+ * process.  Replaces parallelHMCSampler's collection of the workers' results (HMCSampler/parallelHMC.jl:23-45:
+ * remotecall_fetch of hmcmodel / hmcstats / hmcdata per worker) for hosts that hold their chains in this library:
+ *   hmcmt_comm_id        rank 0 obtains the 128-byte RCCL id and hands it to the other ranks by its own means (the Julia
+ *                        host: a remotecall; Python: torch.distributed's store; a file) -- ncclGetUniqueId
+ *   hmcmt_comm_create    every rank, with the same id: ncclCommInitRank on `device_id` (collective)
+ *   hmcmt_allgather_samples   `count` doubles per rank: recv[r*count .. (r+1)*count) = rank r's send -- ncclAllGather on
+ *                        the communicator's stream, complete on return.  on_device = 1: send / recv are device pointers
+ *                        on the communicator's GPU; 0: host buffers, staged through device memory
+ * librccl.so is loaded on first use; without it these calls fail with HMCMT_ENODEV and nothing else is affected. */
+#define HMCMT_COMM_ID_BYTES 128
+typedef struct hmcmt_comm hmcmt_comm;
+int hmcmt_comm_id(void* id /*[HMCMT_COMM_ID_BYTES]*/);
+int hmcmt_comm_create(hmcmt_comm** comm, int32_t device_id, int32_t nranks, int32_t rank, const void* id);
+int hmcmt_allgather_samples(hmcmt_comm* comm, const double* send, double* recv, int64_t count, int32_t on_device);
+int hmcmt_comm_destroy(hmcmt_comm* comm);
+const char* hmcmt_comm_last_error(const hmcmt_comm* comm);   /* comm may be NULL: hmcmt_comm_id / hmcmt_comm_create errors */
+
 /* Kernel-time accounting with HIP events on the context's stream.
  * categories: 0 fdm-transform (MFMA), 1 tridiagonal, 2 stencil SpMV, 3 vector ops,
  *             4 assembly+boundary, 5 receivers+sources, 6 gradient accumulation */

@@ -661,3 +661,34 @@ def test_concurrent_chains_on_one_gpu_equal_sequential_ones():
     for c in range(3):
         assert np.array_equal(seq[0][c], con[0][c]) and np.array_equal(seq[2][c], con[2][c])
         assert np.array_equal(seq[1][c].acceptstats, con[1][c].acceptstats)
+
+
+def test_library_allgather_of_sample_blocks_over_rccl():
+    """hmcmt_comm_id / hmcmt_comm_create / hmcmt_allgather_samples (include/hmcmt.h; parallelHMC.jl:23-45): a one-rank
+    communicator on this box's GPU -- RCCL loaded by the library, ncclAllGather on host blocks (staged) and on device
+    pointers, own block intact -- and parallelHMCSampler(gather="library") returning what the default gather returns.
+    (Two ranks need two GPUs: the driver's multi-GPU runs; the packing / unpacking of the blocks around the collective is
+    covered for world size 2 by tests/test_distributed.py.)"""
+    import torch
+    from hmcmt2d_amd import sampler
+    from hmcmt2d_amd.lib import SampleComm
+    uid = SampleComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = SampleComm(0, 1, 0, uid)
+    blk = np.random.default_rng(0).standard_normal(200_000)
+    out = comm.allgather(blk)
+    assert out.shape == (1, blk.size) and np.array_equal(out[0], blk)
+    d_s = torch.from_numpy(blk).to("cuda:0"); d_r = torch.zeros_like(d_s)
+    torch.cuda.synchronize()
+    comm.allgather_device(d_s.data_ptr(), d_r.data_ptr(), blk.size)
+    assert torch.equal(d_r, d_s)
+    comm.close()
+    with pytest.raises(HmcmtError):
+        SampleComm(0, 2, 5, uid)                           # rank outside the communicator
+    mesh, data, inv, m = make_problem("tiny")
+    prior = HMCPrior(totalsamples=3, burninsamples=1, dt=0.02, timestep=[2, 3], sigBounds=[1e-4, 1.0])
+    a = sampler.parallelHMCSampler(mesh, data, inv, prior, nchains=2, seed=4)
+    b = sampler.parallelHMCSampler(mesh, data, inv, prior, nchains=2, seed=4, gather="library")
+    for c in range(2):
+        assert np.array_equal(a[0][c], b[0][c]) and np.array_equal(a[2][c], b[2][c])
+        assert np.array_equal(a[1][c].hmstats, b[1][c].hmstats)
