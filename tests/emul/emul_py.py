@@ -9,7 +9,10 @@ import numpy as np
 from hmcmt2d_amd.marshal import CreateArgs, CREATE_ARGTYPES, c_double_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "_build", "libhmcmt_emul.so")
+# HMCMT_EMUL_SANITIZE=1: the same source under AddressSanitizer + UndefinedBehaviorSanitizer (CPU only -- SURVEY section 5;
+# the Python process must then run with libasan preloaded: tests/test_kernel_math.py::test_..._under_sanitizers does that)
+SANITIZE = os.environ.get("HMCMT_EMUL_SANITIZE", "") not in ("", "0")
+SO = os.path.join(HERE, "_build", "libhmcmt_emul_asan.so" if SANITIZE else "libhmcmt_emul.so")
 
 
 def build(force=False):
@@ -19,7 +22,8 @@ def build(force=False):
     newest = max(os.path.getmtime(f) for f in [src] + hdrs)
     if force or not os.path.exists(SO) or os.path.getmtime(SO) < newest:
         os.makedirs(os.path.dirname(SO), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", SO])
+        flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"] if SANITIZE else ["-O2"]
+        subprocess.check_call(["g++"] + flags + ["-std=c++17", "-shared", "-fPIC", src, "-o", SO])
     return SO
 
 

@@ -159,3 +159,25 @@ def test_te_only_subset_of_the_data():
     po, fo, go = oracle_eval(mesh, d2, inv2, m)
     assert relmax(pred, po) < 1e-10 and abs(f - fo) / fo < 1e-10 and relmax(g, go) < 1e-8
     assert E.iters[:, nF:].max() == 0
+
+
+def test_kernel_bodies_under_address_and_undefined_behaviour_sanitizers():
+    """SURVEY section 5 (sanitizers on the CPU build; never on the GPU box): the host instantiation of the kernel bodies
+    (hmcmt_items.h / hmcmt_math.h / hmcmt_host.h: the source the HIP kernels inline) compiled with
+    -fsanitize=address,undefined, and this file's tests run against it in a child process with libasan preloaded.
+    Any out-of-bounds access, use after free, signed overflow, misaligned or null access aborts the child."""
+    import subprocess
+    import sys
+    if os.environ.get("HMCMT_EMUL_SANITIZE"):
+        pytest.skip("already inside the sanitized child")
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    if not os.path.isabs(asan):
+        pytest.skip("libasan is not installed")
+    env = dict(os.environ, HMCMT_EMUL_SANITIZE="1", LD_PRELOAD=asan,
+               ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "not sanitizers"], env=env, capture_output=True, text=True, timeout=280,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = r.stdout + r.stderr
+    assert "AddressSanitizer" not in out and "runtime error:" not in out, out[-3000:]
+    assert r.returncode == 0 and " passed" in out, out[-3000:]
