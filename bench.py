@@ -100,6 +100,16 @@ def cpu_baseline(name):
                       f"incl. start-up {wall:.1f} s), scaled to {nF} frequencies"}
 
 
+def rocprof_avg_us(config, cat):
+    """rocprofv3 --stats average duration (us) of the kernels of a category in the committed profile of this config
+    (profiles/pmc_traffic.json `rocprof_avg_us`, written by scripts/make_profile_summary.py); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(config, {}).get("rocprof_avg_us", {}).get(cat)
+    except (OSError, ValueError):
+        return None
+
+
 def pmc_traffic(config, cat):
     """HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in separate runs of
     this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM'), summarised by scripts/pmc_summary.py into
@@ -471,6 +481,7 @@ def main():
                          "frac_canonical_csr": can / HBM_PEAK_GBS, "canonical_csr_bytes_per_launch": can_sys * act,
                          "evaluations_sampled": cnt["evaluations"], "sampled_every": every,
                          "event_bracket_overhead_us_subtracted": prof_overhead_us,
+                         "rocprofv3_avg_launch_us": rocprof_avg_us(name, cat),
                          "launches_timed": n_c, "launches_per_iteration": per_it, "bytes_per_launch": nbytes,
                          "bytes_per_launch_all_systems_active": bpu * U, "active_systems_per_launch": act, "ms_timed": ms_c,
                          "population": population}

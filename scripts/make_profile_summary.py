@@ -11,7 +11,7 @@ import shutil
 import sys
 
 O = sys.argv[1]
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 cfg = sys.argv[3] if len(sys.argv) > 3 else "cfg3"
 P = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 stats_csv = os.path.join(P, f"{tag}_bench_{cfg}_kernel_stats.csv")
@@ -26,6 +26,17 @@ if "per_launch_bytes" in allc:
 allc[cfg] = run_pm[cfg]
 json.dump(allc, open(tracked, "w"), indent=1)
 rows = list(csv.DictReader(open(stats_csv)))
+# launch-weighted rocprofv3 average duration per bench.py category (the cross-check of bench.py's HIP-event averages)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_summary import CATS  # noqa: E402
+rp = {}
+for c, names in CATS.items():
+    tns = sum(float(r["TotalDurationNs"]) for r in rows if any(r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").startswith(nm) for nm in names))
+    ncl = sum(int(r["Calls"]) for r in rows if any(r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").startswith(nm) for nm in names))
+    rp[c] = tns / ncl / 1e3 if ncl else None
+allc[cfg]["rocprof_avg_us"] = rp
+allc[cfg]["rocprof_source"] = f"rocprofv3 --kernel-trace --stats of bench.py --steps 48 --warmup 8 --config {cfg} (profiles/{tag}_bench_{cfg}_kernel_stats.csv), launch-weighted over the kernels of a category"
+json.dump(allc, open(tracked, "w"), indent=1)
 d = json.load(open(os.path.join(P, f"{tag}_bench_{cfg}.json")))
 pm = allc[cfg]
 out = [f"# Round {tag} — rocprofv3 summary of `bench.py --config {cfg}` (1 chain, 1 MI355X)\n",
@@ -49,7 +60,7 @@ out.append(f"Bench line: **{d['value']:.1f} leapfrog steps/s** ({d['ms_per_step'
            f"trajectories (round 1's headline) {sl.get('steps_per_s', float('nan')):.0f}; cold starts {cs.get('steps_per_s', float('nan')):.0f}; "
            f"CPU baseline (oracle, {cb.get('cores')} cores) {cb.get('value', float('nan')):.3f} steps/s.\n")
 ri, rs = d["roofline_iteration"], d["roofline_step"]
-out.append(f"Roofline (HIP events, every launch of every 6th evaluation of the timed region; numerators scaled by the device-counted number "
+out.append(f"Roofline (HIP events, every launch of every n-th evaluation of the timed region (n: `sampled_every` in the JSON); numerators scaled by the device-counted number "
            f"of active systems): dominant kernel `{d['roofline']['kernel'].split(' ')[0]}` {d['roofline']['achieved']:.0f} GB/s algorithmic = "
            f"**{d['roofline']['frac']:.3f}** of the 8 TB/s HBM peak at {d['roofline']['active_systems_per_launch']:.1f} active systems per launch; one COCG iteration "
            f"({ri['kernels']} launches) {ri['us']:.1f} us = {ri['frac']:.3f}; whole step (iteration kernels' bytes / wall time) {rs['frac']:.3f}.\n")
@@ -80,7 +91,7 @@ out.append(f"\nSum of kernel time per evaluation: {tot:.0f} us (k_sens_profile, 
            "streams beside the solves).\n")
 out.append("PMC bytes are `(2*FETCH_SIZE + WRITE_SIZE)*1024` averaged over ALL launches of the run (late iterations with most systems "
            "converged included). FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads; 2- and 8-byte-per-lane "
-           "accesses are uncalibrated, so treat the complex64 / bf16 rows as +-2x on the read side. The launches are latency-bound: the "
-           "~160 MB working set of one solve sits in the 256 MB Infinity Cache.\n")
+           "accesses are uncalibrated, so treat the complex64 / bf16 rows as +-2x on the read side. At cfg3 the ~230 MB working set sits in "
+           "the 256 MB Infinity Cache; the stencil kernels' load phase runs at ITS bandwidth (profiles/r03_launch_shapes.md).\n")
 open(os.path.join(P, f"{tag}_bench_{cfg}_summary.md"), "w").write("\n".join(out))
 print("\n".join(out)[:4000])
