@@ -27,7 +27,7 @@ using Distributed              # myid
 using HMCMT.HMCFileIO, HMCMT.HMCStruct, HMCMT.HMCUtility
 
 export HipContext, hipContext, compDataGradient, hipForward, setPrior!, proposeLeapfrog, proposeLeapfrogDevice!,
-       hipWait, hipStats, destroy!
+       hipWait, hipStats, destroy!, commId, SampleComm, allgatherSamples
 
 const libhmcmt = get(ENV, "HMCMT_HIP_LIB", joinpath(@__DIR__, "..", "hmcmt2d_amd", "libhmcmt_hip.so"))
 
@@ -260,6 +260,41 @@ function proposeLeapfrogDevice!(ctx::HipContext, d_m::Ptr, d_p::Ptr, dt::Real, L
 end
 
 hipWait(ctx::HipContext) = checkerr(ctx.ptr, ccall((:hmcmt_wait, libhmcmt), Cint, (Ptr{Cvoid},), ctx.ptr))
+
+"""
+    commId() -> Vector{UInt8}(128);  SampleComm(device, nranks, rank, id);  allgatherSamples(comm, block) -> Matrix
+
+The RCCL all-gather of the chains' sample blocks (hmcmt_comm_id / hmcmt_comm_create / hmcmt_allgather_samples): what
+replaces `remotecall_fetch` of every worker's samples in parallelHMCSampler (parallelHMC.jl:23-45) when each worker
+process owns a GPU.  The master obtains the id once and ships it to the workers (e.g. `remotecall_fetch(() -> commId(), 2)`
+on rank 0, then as an argument of the workers' calls); every worker then holds every chain's block.
+"""
+commId() = (id = Vector{UInt8}(undef, 128);
+            checkerr(C_NULL, ccall((:hmcmt_comm_id, libhmcmt), Cint, (Ptr{UInt8},), id)); id)
+
+mutable struct SampleComm
+    ptr::Ptr{Cvoid}
+    nranks::Int
+    function SampleComm(device::Integer, nranks::Integer, rank::Integer, id::Vector{UInt8})
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:hmcmt_comm_create, libhmcmt), Cint, (Ref{Ptr{Cvoid}}, Int32, Int32, Int32, Ptr{UInt8}),
+                   ref, Int32(device), Int32(nranks), Int32(rank), id)
+        rc == 0 || error("libhmcmt_hip error $rc: " *
+                         unsafe_string(ccall((:hmcmt_comm_last_error, libhmcmt), Cstring, (Ptr{Cvoid},), C_NULL)))
+        c = new(ref[], Int(nranks))
+        finalizer(x -> (x.ptr != C_NULL && ccall((:hmcmt_comm_destroy, libhmcmt), Cint, (Ptr{Cvoid},), x.ptr); x.ptr = C_NULL), c)
+        return c
+    end
+end
+
+function allgatherSamples(comm::SampleComm, block::Vector{Float64})
+    recv = Matrix{Float64}(undef, length(block), comm.nranks)          # column r+1 = rank r's block
+    rc = ccall((:hmcmt_allgather_samples, libhmcmt), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int32),
+               comm.ptr, block, recv, length(block), Int32(0))
+    rc == 0 || error("libhmcmt_hip error $rc: " *
+                     unsafe_string(ccall((:hmcmt_comm_last_error, libhmcmt), Cstring, (Ptr{Cvoid},), comm.ptr)))
+    return recv
+end
 
 """
     hipStats(ctx) -> HmcmtStats   (iteration counts, error estimate, fallback counter of the last call)

@@ -128,7 +128,8 @@ def test_julia_binding_mirrors_the_struct_layout():
     assert fields("HmcmtStats") == [f for f, _ in L.Stats._fields_]
     assert "using LinearAlgebra" in src
     for sym in ("hmcmt_create", "hmcmt_grad", "hmcmt_forward", "hmcmt_destroy", "hmcmt_set_prior", "hmcmt_leapfrog",
-                "hmcmt_leapfrog_device", "hmcmt_wait", "hmcmt_get_stats", "hmcmt_last_error"):
+                "hmcmt_leapfrog_device", "hmcmt_wait", "hmcmt_get_stats", "hmcmt_last_error", "hmcmt_comm_id", "hmcmt_comm_create",
+                "hmcmt_allgather_samples", "hmcmt_comm_destroy"):
         assert f":{sym}" in src, sym
     # the component map is the Python binding's (include/hmcmt.h: 1 ZXY .. 6 PhsYX), both data types are accepted, and
     # the ccall signatures carry as many argument types as the header's prototypes have parameters
