@@ -281,14 +281,17 @@ def main():
     chain = Chain(ctx, torch, dev, S.rough_state(nAC, seed=1 + rank), mref, inv.Wm, seed=20250114 + rank)
     chain.run(W)
     chain.iters.clear(); acc0, rej0 = chain.accepted, chain.rejected
+    prof_every, prof_overhead_us = 0, 0.0
     if not os.environ.get("HMCMT_BENCH_NOPROF"):
-        # HIP events around every launch of the iteration kernels, in every n-th evaluation of the timed region, n chosen so
-        # that about ten evaluations (~450 iterations, ~1800 launches) are sampled whatever K is: the driver's 20-step run
-        # samples every 2nd, the default 96-step run every 9th (bracketing every launch of every step costs ~20 % of the
-        # throughput; round 2 sampled every 6th = 3 evaluations of a 20-step run)
-        prof_every = max(1, K // 10)
+        # HIP events between the launches of the iteration kernels, in every n-th evaluation of the timed region, n chosen so
+        # that four evaluations (~200 iterations, ~800 launches) are sampled whatever K is: the driver's 20-step run samples
+        # every 5th, the default 96-step run every 25th.  An event is a marker packet in the queue: 3 us per sampled launch,
+        # +24 % on a sampled evaluation -- 20 steps with 7 sampled evaluations ran at 301 steps/s, without sampling at 337
+        # (round 2 sampled every 6th = 3 evaluations of a 20-step run, with two events per launch: the same cost)
+        prof_every = max(1, K // 4) | 1            # (odd: a trajectory has 8 steps -- an even interval would sample the same steps of every trajectory)
         ctx.profile(["fdm_transform", "tridiagonal", "spmv", "vector_ops", "post_smoother"], every=prof_every)
-    prof_overhead_us = ctx.profile_overhead_us()
+    if prof_every:
+        prof_overhead_us = ctx.profile_overhead_us()
     elapsed = timed(torch, dist, lambda: chain.run(K))
     prof = ctx.profile_read()
     cnt = ctx.profile_counters()
@@ -406,10 +409,13 @@ def main():
         # counted).  One preconditioned COCG iteration = these four launches on the fused path (five when the back
         # transform and the post-smoother run as separate kernels: wide meshes, HMCMT_FUSED_BACK=0):
         #   k_fdm_fwd      forward eigen-transform + tridiagonal solves: read t (8) + inverse pivots (8), write y (8) = 24 U
+        #                  (+ 40 U since round 3: x += alpha p -- x in and out, p in -- by its waves that wait for the sweeps; the
+        #                  preconditioner application in front of the first iteration has no x update)
         #   k_back_post    back transform + both Jacobi halves + dots: read y (8), dinv (16), r (16), write z (8)   = 48 U
         #                  (separate: k_transform_lp<2> 56 U with z1 written, k_post: read r, z1, dinv (48), write z (8) = 56 U)
         #   k_spmv_fused   p = z + beta p, q = A p, p'q: read z, p (8 + 8: complex64), write p (8), q (16)          = 40 U
         #   k_update_fused x, r updates + Jacobi pre-smoothing: read p (8), q, r, x, dinv (64), write x, r (32), t (8) = 112 U
+        #                  (72 U with the x update in k_fdm_fwd)
         # A launch works on the systems still active; U_launch = U * (active systems / S), the active count from the
         # device counter of hmcmt_profile_counters over the SAME sampled launches the HIP events time (every launch of
         # every n-th evaluation of the timed region, the empty ones behind a convergence poll included).
@@ -433,6 +439,10 @@ def main():
         def build_roofline(prof, cnt, population, every):
             fwd_fused = ctx.NYP <= 256                      # the library's own rule (launch_fdm_fwd): wide meshes run the separate kernels
             back_fused = fwd_fused                          # ... and k_back_post goes with it (launch_back_post)
+            # round 3: on the fused path x += alpha p and |x|^2 (x in and out, p in: 40 B per unknown) ride along in k_fdm_fwd,
+            # done by the waves that wait for the tridiagonal sweeps (Solver::xInFwd; HMCMT_XFWD=0 puts them back)
+            x_in_fwd = fwd_fused and os.environ.get("HMCMT_XFWD", "1")[:1] != "0"
+            xb = 40.0 if x_in_fwd else 0.0
             # two damped Jacobi sweeps per side of the FDM stage (chosen per solve by the library, hmcmt_stats.smoother_sweeps):
             # a fifth launch, k_post2 (category post_smoother on the fused path), and 8 B/unknown more in two others.  f2 = the
             # fraction of the sampled preconditioner applications that ran it
@@ -443,13 +453,14 @@ def main():
             it_sys = cnt["active_iter_systems"]             # sum over sampled iterations of active systems
             pre_sys = cnt["start_systems"]                  # + one preconditioner application per solve before the first iteration
             fams = {("k_fdm_fwd (split-bf16 MFMA eigen-transform + LDS-resident complex64 tridiagonal sweeps, one launch)" if fwd_fused else
-                     "k_thomas32 (batched complex64 tridiagonal solve of the FDM stage)"): ("tridiagonal", 24.0, 1, it_sys + pre_sys),
+                     "k_thomas32 (batched complex64 tridiagonal solve of the FDM stage)"): ("tridiagonal", 24.0 + xb * it_sys / max(it_sys + pre_sys, 1), 1, it_sys + pre_sys),
                     ("k_back_post (split-bf16 MFMA back transform + both Jacobi halves of the post-smoother + dot products)" if back_fused else
                      "k_transform_lp<2> (split-bf16 MFMA back transform fused with the first Jacobi half)" if fwd_fused else
                      "k_transform_lp<0>,<2> (split-bf16 MFMA forward and back transforms: 16 U and 56 U)"):
                         ("fdm_transform", ((48.0 + 8.0 * f2) if back_fused else 56.0) if fwd_fused else (16.0 + 56.0 * (1 - f2) + 24.0 * f2) / 2, 1 if fwd_fused else 2, (it_sys + pre_sys) * (1 if fwd_fused else 2)),
                     "k_spmv_fused (p-update + 5-point stencil product + dot)": ("spmv", 40.0 + (24.0 * f2 if merged else 0.0), 1, it_sys),
-                    "k_update_fused (x, r updates + Jacobi pre-smoothing)": ("vector_ops", 112.0 + 8.0 * f2, 1, it_sys)}
+                    ("k_update_fused (r update + Jacobi pre-smoothing; x update in k_fdm_fwd)" if x_in_fwd else
+                     "k_update_fused (x, r updates + Jacobi pre-smoothing)"): ("vector_ops", 112.0 + 8.0 * f2 - xb, 1, it_sys)}
             # two sweeps, bytes per unknown (the Jacobi diagonal is complex64 there, -8 per read): k_update_fused<2> also writes
             # the pre-smoothed iterate z2 and the smoothed residual t as complex64 (+16 - 8), k_back_post<.,2> reads both on top
             # of dinv, r (+16 - 8), k_spmv_fused<2> reads z4, r, dinv instead of z (+24) for the second post-sweep it does itself

@@ -605,7 +605,7 @@ constexpr int FW_NTW = HMCMT_FW_NTW; // column tiles per slab: 2 -> 32 modes, ce
 template <int NTW>                 // column tiles (of 16 modes) per slab
 __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restrict__ A, const u4v* __restrict__ Bhi,
                                                  const u4v* __restrict__ Blo, const float2* __restrict__ ip32,
-                                                 float2* __restrict__ Y, long long* stamps = nullptr) {
+                                                 float2* __restrict__ Y, long long* stamps = nullptr, const float2* __restrict__ pX = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // 1-D grid of nslab*S workgroups.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has
     // its own L2: all slabs of a system are placed on ONE XCD so that system's rows are fetched into one L2 once
@@ -631,6 +631,7 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
     c32* sa = sj + SW + 2 * FW_TB * SW;                  // -> region 0, row 0
     c32* sb = sa + (long)nreg * RL * SW;
     c32* sc = sb + (long)nreg * RL * SW;
+    double* xsh = reinterpret_cast<double*>(sj + (SW + 2 * FW_TB * SW + 3 * (long)nreg * RL * SW + 2 * FW_TB * SW));   // [8], behind the slabs
     auto lidx = [&](int row) { return (tw && row > mid) ? RL + (n + 1 - row) : row; };   // slab row of a matrix row
     const int mode = s >= k.nFreq;
     for (int i = threadIdx.x; i < NZP; i += blockDim.x) sof[i] = (float)k.ofz[(long)mode * NZP + i];
@@ -855,8 +856,48 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
             }
         }
     }
+    else if (pX && wave > 0) {
+        // x += alpha p and |x|^2 of this slab's share of the system's interior rows, by the waves that have nothing to do
+        // while wave 0 sweeps (round 3).  The update kernel's load phase runs at the fabric's bandwidth: the
+        // 40 B per unknown of the x update (x in and out, p in) were 37 % of what it moves there -- here they travel while
+        // this kernel's memory pipes idle, behind the serial sweeps.  alpha is the update kernel's (Solver::alphaBeta),
+        // p the direction k_spmv_fused stored for this iteration; p vanishes on boundary and pad nodes, so x keeps its
+        // Dirichlet values; the norm runs over rows 1 .. nz-1, all columns, as k_update_fused's did.  The per-wave sums go
+        // to 64 bytes BEHIND the slabs (fdm_fwd_lds): a static __shared__ array would move the slabs by 64 bytes, and that
+        // alone doubles the sweeps' time (LDS bank pattern: 6 250 -> 12 150 ticks).
+        const cplx al = k.alphaBeta[s];
+        const int total = (k.nz - 1) * NYP, per = (total + nslab - 1) / nslab;
+        const int lo = slab * per, hi = min(lo + per, total);
+        const int tid = threadIdx.x - 64, nt = blockDim.x - 64;
+        cplx* xs = k.x + so + NYP;
+        const float2* ps = pX + so + NYP;
+        constexpr int XB = 5;          // (nine -- one batch for a slab's 3 150 nodes over 384 threads -- measures the same)
+        double xx = 0;
+        for (int e0 = lo + tid; e0 < hi; e0 += XB * nt) {
+            cplx xv[XB];
+            float2 pv[XB];
+#pragma unroll
+            for (int u = 0; u < XB; ++u) { const unsigned e = (unsigned)min(e0 + u * nt, hi - 1); xv[u] = xs[e]; pv[u] = ps[e]; }
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                const int e = e0 + u * nt;
+                if (e < hi) {
+                    const cplx xn = xv[u] + al * cplx{(double)pv[u].x, (double)pv[u].y};
+                    xs[e] = xn;
+                    xx += cabs2(xn);
+                }
+            }
+        }
+        xx = wave_sum(xx);
+        if (lane == 0) xsh[wave] = xx;
+    }
     FW_STAMP(3)
     __syncthreads();
+    if (pX && threadIdx.x == 0) {
+        double t = 0;
+        for (int wv = 1; wv < nwave; ++wv) t += xsh[wv];
+        k.partB[(long)s * MAXNB + slab] = t;
+    }
     // solved slab -> Y, pre-split for the back transform (store_t32's format).  A thread converts 8 consecutive modes
     // of a row and writes each of the four bf16 planes with one 16-byte store instead of 32 two-byte stores
     // (16.0 -> 15.0 us per launch; the same idea in k_update_fused, through an LDS image of its tile: no gain).

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(NT) void k_update_fused(Solver k, const float2* pcu
                 rv[u] = ri[ee[u]]; dv[u] = di[ee[u]];
                 if (!startOnly) {
                     qv[u] = q[ee[u]];
-                    if (lr >= 2 && lr <= nrows - 1) { xv[u] = x[ee[u]]; pv[u] = p[ee[u]]; }     // (own rows only: a predicated load)
+                    if (!k.xInFwd && lr >= 2 && lr <= nrows - 1) { xv[u] = x[ee[u]]; pv[u] = p[ee[u]]; }     // (own rows only: a predicated load)
                 }
             }
 #pragma unroll
@@ -342,9 +342,11 @@ __global__ __launch_bounds__(NT) void k_update_fused(Solver k, const float2* pcu
                     if (lr >= 1 && lr <= nrows) rs[i - NYP] = c32{(float)rn.re, (float)rn.im};
                     if (!startOnly && lr >= 2 && lr <= nrows - 1) {
                         ro[ee[u]] = rn;
-                        const cplx xn = xv[u] + al * cplx{(double)pv[u].x, (double)pv[u].y};
-                        x[ee[u]] = xn;
-                        xx += cabs2(xn);
+                        if (!k.xInFwd) {
+                            const cplx xn = xv[u] + al * cplx{(double)pv[u].x, (double)pv[u].y};
+                            x[ee[u]] = xn;
+                            xx += cabs2(xn);
+                        }
                     }
                 }
             }
@@ -434,9 +436,14 @@ __global__ __launch_bounds__(NT) void k_update_fused(Solver k, const float2* pcu
         if (tile == 0)                                                 // (fewer tiles than the k.NTR partial sums the consumers add up)
             for (int b = ntiles + threadIdx.x; b < k.NTR; b += NT) {
                 k.partR[(long)s * MAXNB + b] = cplx{0, 0};
-                if (!startOnly) k.partB[(long)s * MAXNB + b] = 0.0;
+                if (!startOnly && !k.xInFwd) k.partB[(long)s * MAXNB + b] = 0.0;
             }
         if (startOnly) return;
+        if (k.xInFwd) {                                                // (x and |x|^2: k_fdm_fwd's idle waves)
+            if (threadIdx.x == 0 && tile == 0) k.alphaBeta[s] = al;
+            PH_STAMP(1, 6)
+            return;
+        }
         block_sum2(xx, dummy, sh2);
         if (threadIdx.x == 0) {
             k.partB[(long)s * MAXNB + tile] = xx;
@@ -467,10 +474,12 @@ __global__ __launch_bounds__(NT) void k_update_fused(Solver k, const float2* pcu
         if (lr >= 1 && lr <= nrows - 2) {
             rs[i - NYP] = rn;
             ro[e] = rn;
-            const float2 pf = p[e];
-            const cplx xv = x[e] + al * cplx{(double)pf.x, (double)pf.y};     // p vanishes outside the interior
-            x[e] = xv;
-            xx += cabs2(xv);
+            if (!k.xInFwd) {
+                const float2 pf = p[e];
+                const cplx xv = x[e] + al * cplx{(double)pf.x, (double)pf.y};     // p vanishes outside the interior
+                x[e] = xv;
+                xx += cabs2(xv);
+            }
         }
     }
     __syncthreads();
@@ -491,6 +500,10 @@ __global__ __launch_bounds__(NT) void k_update_fused(Solver k, const float2* pcu
             out = rs[i] - acc;
         }
         store_t32(k, t, iz0 + lr, iy, (float)out.re, (float)out.im);
+    }
+    if (k.xInFwd) {                                                    // (x and |x|^2: k_fdm_fwd's idle waves)
+        if (threadIdx.x == 0 && tile == 0) k.alphaBeta[s] = al;
+        return;
     }
     block_sum2(xx, dummy, sh);
     if (threadIdx.x == 0) {
