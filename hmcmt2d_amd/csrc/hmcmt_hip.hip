@@ -1110,6 +1110,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     }
     if (const char* eu = getenv("HMCMT_UPD1")) { const int a = atoi(eu); if (a == 256 || a == 512) ctx->upd1Threads = a; }
     if (const char* eu = getenv("HMCMT_SPMV")) { const int a = atoi(eu); if (a == 256 || a == 512 || a == 1024) ctx->spmvThreads = a; }
+    k.actEarly = !(getenv("HMCMT_ACT_EARLY") && getenv("HMCMT_ACT_EARLY")[0] == '0');
     k.xInFwd = 0;       // set with k.splitT (the fused forward kernel is the one that can take the x update along)
     k.stamps = nullptr; k.stampKernel = 0;
     if (const char* es = getenv("HMCMT_STAMPS")) {

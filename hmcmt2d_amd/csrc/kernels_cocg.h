@@ -38,6 +38,7 @@ struct Solver {
     float2 *z32, *p32a, *p32b;            // fused path: preconditioned residual and the two search-direction buffers as complex64
                                           // (x, r, q and every inner product stay fp64; see k_spmv_fused)
     int RT, NTR;                          // rows per tile / row tiles per system of the fused kernels (NTR <= MAXNB)
+    int actEarly;                         // 1: k_back_post tests the system's active flag before its first loads (HMCMT_ACT_EARLY=0: after, as in rounds 1-2)
     int xInFwd;                           // 1: x += alpha p and |x|^2 are done by k_fdm_fwd's idle waves (its pX argument), not by k_update_fused
     int xmap;                             // 1: XCD-aware 1-D grids of the fused stencil kernels (tile_map, kernels_fused.h)
     int RT2;                              // rows per tile of k_update_fused<2> (its two halo rows per side cost less on taller tiles)

@@ -951,7 +951,11 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
                                                    const u4v* __restrict__ Blo, double* partZZ, int NW, long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
     const int s = blockIdx.y, bx = blockIdx.x, nwg = gridDim.x;
-    const int act = k.active[s];       // tested below, after the first loads are on their way
+    const int act = k.active[s];
+    // (round 3) tested HERE: rounds 1-2 tested it after the staging and V-fragment loads had been issued -- one memory round
+    // trip less for an active workgroup, but on a real chain 40 % of a launch's workgroups belong to converged systems and
+    // each of them pulled its 26 KB tile of y and a whole V through the memory system before returning
+    if (k.actEarly && !act) return;
 #define BP_STAMP(i) if (stamps && threadIdx.x == 0) stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime();
     BP_STAMP(0)
     const int bd = NW << 6;            // = blockDim.x, from the kernel argument (a scalar; the implicit-argument load is a vector load here)
@@ -985,8 +989,7 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
         q.cy0 = cYm[e]; q.cy1 = cYm[e - 1u];
         q.cz0 = cZm[e]; q.cz1 = cZu[e];
         q.rv = r[e];
-        if (SW == 2) { const float2 d2 = (k.dinv32 + so)[e]; q.dv = cplx{(double)d2.x, (double)d2.y}; }
-        else q.dv = di[e];
+        { const float2 d2 = (k.dinv32 + so)[e]; q.dv = cplx{(double)d2.x, (double)d2.y}; }      // (complex64 for one sweep too since round 3)
     };
     Sten st[SU], st2[SU];           // 14 NYP <= 8 x blockDim elements: two batches per thread
     {
@@ -1014,7 +1017,7 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
                     for (int t = 0; t < 2; ++t) {
                         const long ub = (long)ru * NYP + min(t0 + t, NT - 1) * 16;
                         if (SW == 2) { zq[rg][t][h2] = (z2i + ub)[lo]; tq[rg][t][h2] = (t2i + ub)[lo]; }
-                        else { dv[rg][t][h2] = (di + ub)[lo]; rv[rg][t][h2] = (r + ub)[lo]; }
+                        else { const float2 d2 = (k.dinv32 + so + ub)[lo]; dv[rg][t][h2] = cplx{(double)d2.x, (double)d2.y}; rv[rg][t][h2] = (r + ub)[lo]; }
                     }
                 }
         };

@@ -461,7 +461,8 @@ __global__ __launch_bounds__(NT) void k_update_fused(Solver k, const float2* pcu
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
     const double w = k.omega[s];
     const float2* p = pcur + so;
-    const cplx *q = k.q + so, *ri = rin + so, *di = k.dinv + so;
+    const cplx *q = k.q + so, *ri = rin + so;
+    const float2* di = k.dinv32 + so;      // (complex64 since round 3, as in the two-sweep form: the smoother's output goes to bf16 planes anyway)
     cplx *x = k.x + so, *ro = rout + so;
     float2* t = k.t32 + so;
     double xx = 0, dummy = 0;
@@ -470,7 +471,8 @@ __global__ __launch_bounds__(NT) void k_update_fused(Solver k, const float2* pcu
         const int lr = i / NYP, iy = i - lr * NYP;
         const long e = (long)(iz0 - 1 + lr) * NYP + iy;
         const cplx rn = ri[e] - al * q[e];
-        cs[i] = di[e] * rn;
+        const float2 d2 = di[e];
+        cs[i] = cplx{(double)d2.x, (double)d2.y} * rn;
         if (lr >= 1 && lr <= nrows - 2) {
             rs[i - NYP] = rn;
             ro[e] = rn;
