@@ -441,7 +441,9 @@ def main():
             back_fused = fwd_fused                          # ... and k_back_post goes with it (launch_back_post)
             # round 3: on the fused path x += alpha p and |x|^2 (x in and out, p in: 40 B per unknown) ride along in k_fdm_fwd,
             # done by the waves that wait for the tridiagonal sweeps (Solver::xInFwd; HMCMT_XFWD=0 puts them back)
-            x_in_fwd = fwd_fused and os.environ.get("HMCMT_XFWD", "1")[:1] != "0"
+            x_in_fwd = fwd_fused and (ctx.nz - 1) * ctx.NYP >= 12000       # (the library's rule, hmcmt_create)
+            if os.environ.get("HMCMT_XFWD"):
+                x_in_fwd = fwd_fused and os.environ["HMCMT_XFWD"][:1] != "0"
             xb = 40.0 if x_in_fwd else 0.0
             # two damped Jacobi sweeps per side of the FDM stage (chosen per solve by the library, hmcmt_stats.smoother_sweeps):
             # a fifth launch, k_post2 (category post_smoother on the fused path), and 8 B/unknown more in two others.  f2 = the

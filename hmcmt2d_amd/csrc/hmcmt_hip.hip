@@ -1094,12 +1094,14 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     // threads,batch,rows 256,6,7 (round 2) 294 | 512,8,14 304 | 512,6,14 301 | 512,4,14 297 | 1024,4,14 305 | 512,8,18 298 |
     // 512,8,21 279 | 512,8,12 281 | 256,6,14 277: twice the rows with twice the threads -- the same work per thread, 4 halo
     // rows per 14 instead of per 7.
-    ctx->spmvThreads = 512;
-    ctx->upd1Threads = 512;                 // (k_update_fused<1>: 367 -> 376 steps/s near the true model, 779 -> 794 on straight lines)
-    ctx->upd2Threads = 512; ctx->upd2Batch = 8;
-    if ((size_t)(3 * 2 * k.RT + 8) * k.NYP * sizeof(float2) <= (size_t)150 * 1024) k.RT2 = 2 * k.RT;
-    else { ctx->upd2Threads = 256; ctx->upd2Batch = 6; }
-    if (k.NYP > 256) { ctx->upd2Threads = 256; ctx->upd2Batch = 6; k.RT2 = k.RT; }      // (cfg5: 52.7 vs 51.8 steps/s with the taller tiles)
+    // ... all of which is for tiles with enough nodes per thread: on the reference's dprism3d example (96x49 cells, 22
+    // systems, tiles of 3 rows x 112 nodes) the wide shapes lose 7 % (392 vs 419 evaluations/s, scripts/gpu_example_ab.sh),
+    // so small tiles keep the round-2 shapes.
+    const int tileNodes = (k.RT + 2) * k.NYP, tile2Nodes = (2 * k.RT + 4) * k.NYP;
+    ctx->spmvThreads = ctx->upd1Threads = tileNodes >= 1280 ? 512 : 256;     // (cfg3 1872, cfg5 2912 | dprism3d 560, cfg2 256)
+    ctx->upd2Threads = 256; ctx->upd2Batch = 6;
+    if (tile2Nodes >= 2560 && k.NYP <= 256 &&                               // (cfg3 3744 | dprism3d 1120; cfg5: 52.7 vs 51.8 steps/s with the taller tiles)
+        (size_t)(3 * 2 * k.RT + 8) * k.NYP * sizeof(float2) <= (size_t)150 * 1024) { ctx->upd2Threads = 512; ctx->upd2Batch = 8; k.RT2 = 2 * k.RT; }
     if (const char* e2 = getenv("HMCMT_RT2")) k.RT2 = std::max(k.RT, atoi(e2));
     if (const char* eu = getenv("HMCMT_UPD2")) {              // "threads,batch,rows"
         int a = 0, b = 0, c = 0;
@@ -1195,7 +1197,10 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
         return rc;
     }
     ctx->sv.splitT = fdm_fwd_ntw(ctx) > 0;
-    ctx->sv.xInFwd = ctx->sv.splitT && !(getenv("HMCMT_XFWD") && getenv("HMCMT_XFWD")[0] == '0');     // (x += alpha p rides along in k_fdm_fwd)
+    // x += alpha p rides along in k_fdm_fwd where the update kernel's burst is long enough to notice (headline size: +2.4 .. 3.5 %;
+    // on dprism3d's 6 160 interior nodes per system it costs 1 %); HMCMT_XFWD=0 / 1 forces it off / on
+    ctx->sv.xInFwd = ctx->sv.splitT && (long)(ctx->sv.nz - 1) * ctx->sv.NYP >= 12000;
+    if (const char* ex = getenv("HMCMT_XFWD")) ctx->sv.xInFwd = ctx->sv.splitT && ex[0] != '0';
     ctx->sv.twist = ctx->v.twist = ctx->sv.splitT && ctx->twistOn;     // the fused forward kernel sweeps both ways at once
     *out = ctx;
     return 0;
