@@ -1002,6 +1002,15 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     View& v = ctx->v;
     v.ny = h.ny; v.nz = h.nz; v.NYP = h.NYP; v.NZP = h.NZP; v.nFreq = h.nFreq; v.S = h.S; v.nRx = h.nRx;
     v.nData = h.nData; v.nAC = h.nAC; v.nCell = h.nCell; v.zid = h.zid; v.vstride = (long)h.NZP * h.NYP;
+    v.dbg = 0;
+    // HMCMT_BGMEAN (experiment, round 3; default 0 = the geometric lateral mean of sigma for both modes): bit 0: TM background =
+    // harmonic lateral mean of sigma, i.e. the arithmetic mean of the coefficient 1/sigma the TM stiffness is linear in; bit 1: TE
+    // background = arithmetic mean of sigma -- fdm_z_values, hmcmt_items.h.  bench.py, headline chain / near the true model,
+    // steps/s: 0: 317 / 391, 1: 324 / 398, 2: 311 / 379, 3: 326 / 379.  Not adopted: at the true model the +2 % of setting 1 is
+    // an earlier stop, not faster convergence -- its error estimate is 5x more optimistic there (true residual 2.4e-9 instead of
+    // 3.1e-10 at the same 19-20 / 24-26 iterations; with tol 3e-12 it needs the old counts for the old accuracy), while on
+    // rough models it is 5x MORE accurate at the same counts (profiles/r03_parity_levels_bgmean{0,1}.log).
+    v.bgMean = getenv("HMCMT_BGMEAN") ? atoi(getenv("HMCMT_BGMEAN")) : 0;
     const size_t VS = (size_t)v.vstride, S = (size_t)h.S;
     int rc;
 #define UP(field, vec) { decltype(vec)::value_type* p_ = nullptr; if ((rc = dupload(ctx, &p_, vec))) return rc; v.field = p_; }
