@@ -20,12 +20,19 @@ or golden vectors for this path.  What pins this file:
   error column as 5 % of its |Z| (tests/test_oracle_kat.py, first test; the HIP
   path is held to the same file in tests/test_gpu_parity_full.py).
 * ADJOINT / GRADIENT HALF (-> dataGrad): PARITY UNPINNED by reference outputs (none
-  exist).  It is pinned by identities only: the adjoint against the explicit
-  Jacobian built as MTSensitivity/compJacMat.jl:206-314 specifies it, interior
-  finite differences of the (pinned) forward map, the Rho/phase chain rule, and
-  the MUMPS wrapper's residual bar (MUMPS/test/testDivGrad.jl:19) for the solver;
-  the reference's boundary-derivative approximations are
-  restated from the source and not observable in any output it ships.
+  exist).  What holds it: (1) at the model the forward pin holds at, Richardson-
+  extrapolated difference quotients of the pinned forward map, cell by cell on 256
+  cells of the mesh core (tests/test_gradient_pin.py, tests/golden/make_fd_pin.py):
+  with the Dirichlet values frozen they equal the P- and Q-terms of J^T v
+  (compJacTMatVec.jl:235 / :306-307, :209 / :280) to 3e-7; with everything
+  recomputed they differ from the full gradient by at most 1.6e-4, within the size
+  of the reference's APPROXIMATE boundary-derivative terms,
+  whose share of the gradient in those cells is <= 1.2e-3 -- that share is restated
+  from compJacTMatVec.jl:237-242, 309-316 / MT1DSensitivity.jl without an independent
+  check, and being approximations of the derivative no finite difference can confirm
+  it; (2) identities: the adjoint against the explicit Jacobian built as
+  MTSensitivity/compJacMat.jl:206-314 specifies it (1e-15), the Rho/phase chain
+  rule, the MUMPS wrapper's residual bar (MUMPS/test/testDivGrad.jl:19) for the solver.
 
 The sparse direct solve of the reference (UMFPACK `lu` via SuiteSparse_jll 7.2.1,
 mt2DTE.jl:48 / MUMPS `sym=1`, mt2DTE.jl:51-53) is a third-party dependency that is
