@@ -80,7 +80,8 @@ __global__ __launch_bounds__(NT) void k_spmv_fused(Solver k, const double* partZ
     cplx paL = ln < k.NB ? k.partA[(long)s * MAXNB + ln] : cplx{0, 0};
     if (SW == 2 && ln < k.NTR) paL += k.partR[(long)s * MAXNB + ln];
     const double pzL = ln < k.NB ? partZZ[(long)s * MAXNB + ln] : 0.0;
-    const double pbL = ln < k.NTR ? k.partB[(long)s * MAXNB + ln] : 0.0;
+    const double pbL = k.partB[(long)s * MAXNB + ln];      // all MAXNB = 64 slots: zeroed at the start of a solve, filled by the row tiles of
+                                                           // k_update_fused (<= NTR) or by the slabs of k_fdm_fwd (Solver::xInFwd; their number is independent of NTR)
     const cplx rhoPrev = k.rho2[(long)((it - 1) & 1) * k.S + s];
     const int mode = s >= k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
