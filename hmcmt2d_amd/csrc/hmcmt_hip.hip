@@ -269,7 +269,10 @@ bool fused_back_ok(const hmcmt_ctx* ctx) {
     return k.splitT && ctx->fusedBack && lds <= ctx->maxLdsBack && k.NYP <= 256;
 }
 // grid of the fused stencil kernels for `ntiles` row tiles per system (tile_map, kernels_fused.h)
-dim3 tile_grid(const Solver& k, int ntiles) { return k.xmap ? dim3(8 * ((k.S + 7) / 8) * ntiles) : dim3(ntiles, k.S); }
+dim3 tile_grid(const Solver& k, int ntiles) {
+    if (k.xmap == 2) return dim3(8 * ((2 * ntiles + 7) / 8) * k.nFreq);
+    return k.xmap ? dim3(8 * ((k.S + 7) / 8) * ntiles) : dim3(ntiles, k.S);
+}
 size_t update2_lds(const Solver& k) { return (size_t)(3 * k.RT2 + 8) * k.NYP * sizeof(float2); }
 int update2_tiles(const Solver& k) { return (k.nz - 1 + k.RT2 - 1) / k.RT2; }
 // The two stencil kernels of the iteration are launched with a thread count / batch size / tile height chosen per

@@ -56,9 +56,25 @@ __device__ __forceinline__ int div_small(int i, float rcp) { return (int)(((floa
 // does not make the XCD's L2 share their rows -- the workgroups in flight on an XCD stream ~20 MB through a 4 MB L2 --
 // so the fabric reads of the halo rows are served by the Infinity Cache either way.  Placement only: any mapping gives
 // the same numbers.
+//
+// k.xmap = 2 places for the OTHER sharing: the stencil coefficients of a row tile are the same for all nFreq systems of a
+// polarisation (32 B per node packed, 48 B in fp64), and at the stress size every tile of every system fetches them
+// through the fabric for itself -- a third of what k_update_fused<2> reads there, half of k_spmv_fused<2>'s.  Unit = (row
+// tile, polarisation); unit u runs on XCD u % 8, its nFreq workgroups -- one per frequency -- back to back, i.e. at the
+// same time, reading the same coefficient rows (scripts/probe/l2_share.hip: co-located workgroups that read the same
+// bytes at the same time fetch them once).  Every XCD gets TE and TM units alike.  Measured: 51.0 vs 53.9 steps/s at cfg5,
+// 313.8 vs 318.7 at cfg3 -- slower; 32 workgroups asking one XCD's L2 for the same lines in the same microsecond queue up
+// on its channels (k_back_post staggers its V stream over the k-groups for the same reason).  Not the default either.
 __device__ __forceinline__ bool tile_map(const Solver& k, int ntiles, int& tile, int& s) {
     if (!k.xmap) { tile = blockIdx.x; s = blockIdx.y; return true; }
-    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, q = j / ntiles;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    if (k.xmap == 2) {
+        const int ul = j / k.nFreq, f = j - ul * k.nFreq, u = x + 8 * ul;
+        tile = u >> 1;
+        s = (u & 1) * k.nFreq + f;
+        return tile < ntiles;
+    }
+    const int q = j / ntiles;
     tile = j - q * ntiles;
     s = x + 8 * q;
     return s < k.S;
