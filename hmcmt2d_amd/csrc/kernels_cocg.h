@@ -59,7 +59,7 @@ struct Solver {
     int* failHost;                        // pinned host word: status (HMCMT_ENOCONV / HMCMT_EBREAKDOWN) of a system that has just given up --
                                           // the host must not build on this solve (adjoint on a failed forward, next leapfrog step)
     long long* stamps;                    // HMCMT_STAMPS=<kernel>: per-workgroup s_memtime stamps of that kernel's phases ([workgroup][8]; printed at hmcmt_destroy)
-    int stampKernel;                      // 1 k_update_fused<2> / k_update2r, 2 k_spmv_fused<2>
+    int stampKernel;                      // 1 k_update_fused<2>, 2 k_spmv_fused<2>
     unsigned long long* cntActive;        // non-null in an evaluation sampled by hmcmt_profile: += systems still active per iteration
 };
 
