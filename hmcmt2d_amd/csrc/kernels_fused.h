@@ -501,24 +501,42 @@ __global__ __launch_bounds__(NT) void k_update_fused(Solver k, const float2* pcu
             }
         }
     }
-    __syncthreads();
+    // The smoother's stencil coefficients as the packed floats the two-sweep form reads (Solver::cf32; its output goes to bf16
+    // planes), a batch of UC nodes per thread requested together, unconditionally, and the first batch BEFORE the barrier
+    // (round 3: until then six fp64 loads per node sat inside `if (interior)` next to their use -- a memory round trip per
+    // node, three in a row per thread).
+    constexpr int UC = 3;
     const int nown = (iz1 - iz0 + 1) * NYP;
-    for (int i = threadIdx.x; i < nown; i += NT) {
-        const int lr = i / NYP, iy = i - lr * NYP;
-        const long e = (long)(iz0 + lr) * NYP + iy;
-        cplx out = cplx{0, 0};
-        if (iy >= 1 && iy <= k.ny - 1) {
-            const int l = (lr + 1) * NYP + iy;
-            const cplx c = cs[l];
-            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
-            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
-            acc += k.cY[mo + e] * cs[l + 1];
-            acc += k.cY[mo + e - 1] * cs[l - 1];
-            acc += k.cZ[mo + e] * cs[l + NYP];
-            acc += k.cZ[mo + e - NYP] * cs[l - NYP];
-            out = rs[i] - acc;
+    const float4* cf = k.cf32 + 2 * mo + 2 * (long)iz0 * NYP;
+    float4 ca[UC], cb[UC];
+    auto ldc = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < UC; ++u) { const unsigned io = (unsigned)min(i0 + u * NT, nown - 1); ca[u] = cf[2u * io]; cb[u] = cf[2u * io + 1u]; }
+    };
+    ldc(threadIdx.x);
+    __syncthreads();
+    for (int i0 = threadIdx.x; i0 < nown; i0 += UC * NT) {
+        if (i0 != (int)threadIdx.x) ldc(i0);
+#pragma unroll
+        for (int u = 0; u < UC; ++u) {
+            const int i = i0 + u * NT;
+            if (i < nown) {
+                const int lr = i / NYP, iy = i - lr * NYP;
+                cplx out = cplx{0, 0};
+                if (iy >= 1 && iy <= k.ny - 1) {
+                    const int l = (lr + 1) * NYP + iy;
+                    const cplx c = cs[l];
+                    const double dk = (double)ca[u].x, dm = w * (double)ca[u].y;
+                    cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+                    acc += (double)ca[u].z * cs[l + 1];
+                    acc += (double)ca[u].w * cs[l - 1];
+                    acc += (double)cb[u].x * cs[l + NYP];
+                    acc += (double)cb[u].y * cs[l - NYP];
+                    out = rs[i] - acc;
+                }
+                store_t32(k, t, iz0 + lr, iy, (float)out.re, (float)out.im);
+            }
         }
-        store_t32(k, t, iz0 + lr, iy, (float)out.re, (float)out.im);
     }
     if (k.xInFwd) {                                                    // (x and |x|^2: k_fdm_fwd's idle waves)
         if (threadIdx.x == 0 && tile == 0) k.alphaBeta[s] = al;
