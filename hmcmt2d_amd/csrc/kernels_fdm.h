@@ -976,18 +976,18 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
     // `if (row < NZP)` / `if (interior)` the compiler keeps each load next to its use and the phase costs one
     // memory round trip per element instead of one per batch (s_memtime stamps: epilogue 3.5 -> us, stencil 4.7 -> us).
     constexpr int SU = 4;               // stencil elements per thread and batch
-    struct Sten { double dk, dm, cy0, cy1, cz0, cz1; cplx rv, dv; int e, iy; };
+    struct Sten { float dk, dm, cy0, cy1, cz0, cz1; cplx rv, dv; int e, iy; };   // (coefficients: the packed floats of Solver::cf32 since round 3 --
+    // two 16-byte loads instead of six 8-byte ones, 32 B per node instead of 48; the post-sweep's output is complex64, and the
+    // pre-sweeps of the two-sweep form have read these floats all along: now both sides of the FDM stage smooth with the same operator)
     // (uniform base + 32-bit lane offset: one address register per element instead of two per load)
-    const double *dKm = k.dK + mo, *dMm = k.dM + mo, *cYm = k.cY + mo, *cZm = k.cZ + mo, *cZu = k.cZ + mo - NYP;
+    const float4* cfm = k.cf32 + 2 * mo;
     const float rNYP = 1.0f / (float)NYP;
     auto ld_st = [&](int i, Sten& q) {
         const int ic = min(i, nown - 1), lr = (int)(((float)ic + 0.5f) * rNYP);      // ic / NYP (exact: ic < 4096)
         q.iy = ic - lr * NYP;
         q.e = (iz0 + lr) * NYP + q.iy;
         const unsigned e = (unsigned)q.e;
-        q.dk = dKm[e]; q.dm = dMm[e];
-        q.cy0 = cYm[e]; q.cy1 = cYm[e - 1u];
-        q.cz0 = cZm[e]; q.cz1 = cZu[e];
+        { const float4 a = cfm[2u * e], b = cfm[2u * e + 1u]; q.dk = a.x; q.dm = a.y; q.cy0 = a.z; q.cy1 = a.w; q.cz0 = b.x; q.cz1 = b.y; }
         q.rv = r[e];
         { const float2 d2 = (k.dinv32 + so)[e]; q.dv = cplx{(double)d2.x, (double)d2.y}; }      // (complex64 for one sweep too since round 3)
     };
@@ -1139,11 +1139,12 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
         if (i < nown) {
             const int l = q.e - (rbase * NYP);                 // tile-local index: tile row 0 = mesh row rbase
             const cplx c = zt[l];
-            cplx acc = cplx{q.dk * c.re - w * q.dm * c.im, q.dk * c.im + w * q.dm * c.re};
-            acc += q.cy0 * zt[l + 1];
-            acc += q.cy1 * zt[l - 1];
-            acc += q.cz0 * zt[l + NYP];
-            acc += q.cz1 * zt[l - NYP];
+            const double dk = (double)q.dk, dm = w * (double)q.dm;
+            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+            acc += (double)q.cy0 * zt[l + 1];
+            acc += (double)q.cy1 * zt[l - 1];
+            acc += (double)q.cz0 * zt[l + NYP];
+            acc += (double)q.cz1 * zt[l - NYP];
             cplx out = c + (SW == 2 ? (double)k.w2 : 1.0) * (q.dv * (q.rv - acc));
             if (q.iy < 1 || q.iy > k.ny - 1) out = cplx{0, 0};
             const float2 of = float2{(float)out.re, (float)out.im};
