@@ -62,7 +62,7 @@ struct hmcmt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;       // sigma-only sensitivity tables run beside the forward solve
-    hipStream_t side2 = nullptr;      // inverse pivots of the FDM tridiagonals run beside the boundary-value kernels
+    hipStream_t side2 = nullptr;      // stencil coefficients and Jacobi diagonal, beside the boundary-value kernels
     hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evPiv = nullptr, evRec = nullptr, evCoef = nullptr;
     bool solveBegun = false;                 // k_resid0 / k_resid_pre has done k_solve_begin's work for the next solve
     bool preDone = false;                    // k_resid_pre has done the first pre-smoothing pass of the next solve
@@ -77,6 +77,10 @@ struct hmcmt_ctx {
     double *d_partRes = nullptr, *d_partBn = nullptr;
     cplx* d_b = nullptr;                  // copy of the right-hand side (verify)
     int dbgFlags = 0;                     // hmcmt_debug_flags
+    double hostUs[4] = {0, 0, 0, 0}; long hostN = 0;      // HMCMT_TICKS: host time of the launch sequences around the solves
+    bool wantTicks = false;               // HMCMT_TICKS: in-kernel wall-clock stamps (View::ticks), printed at destroy
+    int bcCW = 0, bcSlots = 1;            // k_bc_fused: boundary columns per workgroup (0: k_bc_layers + k_bc_forward), edge slots
+    size_t bcLds = 0;
     cplx* d_fieldsOut = nullptr;
     // pinned host staging
     int* h_nactive = nullptr;
@@ -622,9 +626,9 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
 }
 
 // weights of the initial-guess extrapolation for solve kind kd (side stream): partial sums, weights, history shift
-void launch_extrap_weights(hmcmt_ctx* ctx, const double* d_m, int kd) {
-    hipLaunchKernelGGL(k_extrap_prepare, dim3(EXT_NBLK), dim3(256), 0, ctx->side, d_m, ctx->d_mHist[kd], ctx->v.nAC, ctx->d_ext[kd],
-                       ctx->extrapNp, kd == 1 ? 1 : 0);
+void launch_extrap_weights(hmcmt_ctx* ctx, const double* d_m, int kd, hipStream_t sp) {
+    hipLaunchKernelGGL(k_extrap_prepare, dim3(EXT_NBLK), dim3(256), 0, sp, d_m, ctx->d_mHist[kd], ctx->v.nAC, ctx->d_ext[kd],
+                       ctx->extrapNp, kd == 1 ? 1 : 0, ctx->v.ticks);
 }
 
 // side stream, beside the forward solve: the adjoint initial guess and the sigma-only sensitivity tables (joined
@@ -636,7 +640,7 @@ void launch_adjoint_side(hmcmt_ctx* ctx) {
     const View& v = ctx->sideView;
     const int S = v.S;
     if (ctx->sideExtrap) {
-        launch_extrap_weights(ctx, ctx->sideM, 1);
+        launch_extrap_weights(ctx, ctx->sideM, 1, ctx->side);
         hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.Lam, ctx->d_prevField[1], ctx->d_ext[1]);
         hipEventRecord(ctx->evExtA, ctx->side);
     }
@@ -686,7 +690,13 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     ctx->sweepsUsed[0] = sweepsF; if (wantGrad) ctx->sweepsUsed[1] = sweepsA;
     {
         ProfScope ps(ctx, 4);
-        hipLaunchKernelGGL(k_sigma, grid1(v.nCell, 256), dim3(256), 0, st, v);
+        // conductivities and their lateral means, one wave per cell row (meshes of whole rows: always; k_sigma + k_rowmean otherwise)
+        const bool rows = v.nCell == v.ny * v.nz && !getenv("HMCMT_NO_SIGMA_ROWS");
+        const auto hostT0 = std::chrono::steady_clock::now();
+        if (v.ticks) {                                   // HMCMT_TICKS: earliest starts <- max, latest ends <- 0
+            HIPCHK(hipMemsetAsync(v.ticks, 0xff, 32 * sizeof(long long), st));
+            HIPCHK(hipMemsetAsync(v.ticks + 32, 0, 64 * TK_N * sizeof(long long), st));
+        }
         // initial guesses: zero on a cold start, otherwise the previous fields, optionally extrapolated
         if (!warmF) {
             HIPCHK(hipMemsetAsync(v.X, 0, vecBytes, st));
@@ -696,40 +706,57 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             HIPCHK(hipMemsetAsync(v.Lam, 0, vecBytes, st));
             HIPCHK(hipMemsetAsync(ctx->d_ext[1], 0, EXT_PART * sizeof(double), st));
         }
+        hipStream_t sA = ctx->side, sB = ctx->side2;
+        if (rows) hipLaunchKernelGGL(k_sigma_rows, dim3(v.nz), dim3(64), 0, st, v);
+        else hipLaunchKernelGGL(k_sigma, grid1(v.nCell, 256), dim3(256), 0, st, v);
         HIPCHK(hipEventRecord(ctx->evModel, st));
-        // Three chains start from sigma and meet at the forward residual:
-        //   main    boundary-value tables and the serial 1-D recurrences (60 us: the critical one)
-        //   side    the extrapolated forward guess (weights from the model history, then one pass over the fields: 45 us)
-        //   side2   stencil coefficients, Jacobi diagonal (15 us, the residual waits for them), then lateral means ->
-        //           FDM background -> inverse pivots of its tridiagonals (serial, 35-85 us; the preconditioner waits)
+        // Three chains start from sigma and meet at the forward residual (round 3: 108 -> us between k_sigma and the first
+        // iteration kernel near the true model):
+        //   main    the 1-D boundary fields: per-layer terms and serial recurrences in one launch (k_bc_fused, 45 us: the critical one)
+        //   side    the extrapolated forward guess (weights from the model history, then one pass over the fields: 35 us)
+        //   side2   stencil coefficients + Jacobi diagonal + packed float copy in one launch (the residual waits for them), then
+        //           FDM background -> inverse pivots of its tridiagonals (serial, 30-85 us; the preconditioner waits)
         // The host issues them in this order (after the previous evaluation's synchronisation the order of the API
         // calls is the schedule); the side-stream work of the adjoint half follows from inside the forward solve.
         if (!freezeBC) {
-            hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, v.nFreq), dim3(64), 0, st, v);
-            hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, v.nFreq), dim3(64), 4 * (size_t)v.nz * sizeof(cplx), st, v);
+            if (ctx->bcCW > 0) {
+                hipLaunchKernelGGL(k_bc_fused, dim3((v.ny + ctx->bcCW) / ctx->bcCW, v.nFreq), dim3(256), ctx->bcLds, st, v, ctx->bcCW, ctx->bcSlots);
+            } else {
+                hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, v.nFreq), dim3(64), 0, st, v);
+                hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, v.nFreq), dim3(64), 4 * (size_t)v.nz * sizeof(cplx), st, v);
+            }
         }
         const bool pivots = ctx->opt.precond != HMCMT_PRECOND_JACOBI;
+        // the FDM background -> inverse pivots (serial, 17-60 us; the first preconditioner application waits for them)
+        auto issue_pivot = [&](hipStream_t sp) {
+            if (!rows) hipLaunchKernelGGL(k_rowmean, dim3(v.nz), dim3(64), 0, sp, v);
+            if (pivots)
+                hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 4 * (size_t)v.NZP * sizeof(double), sp, v,
+                                   ctx->opt.fdm_precision == 0 ? ctx->d_invp32 : (float2*)nullptr);
+            else
+                hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, sp, v);
+            return hipEventRecord(ctx->evPiv, sp);
+        };
         if (extrap) {
-            // (interior nodes only -- k_bc_forward owns the boundary nodes of X)
-            HIPCHK(hipStreamWaitEvent(ctx->side, ctx->evModel, 0));
-            launch_extrap_weights(ctx, d_m, 0);
-            hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
-            HIPCHK(hipEventRecord(ctx->evExtF, ctx->side));
+            // (interior nodes only -- the boundary-value kernel owns the boundary nodes of X)
+            HIPCHK(hipStreamWaitEvent(sA, ctx->evModel, 0));
+            launch_extrap_weights(ctx, d_m, 0, sA);
+            hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, sA, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
+            HIPCHK(hipEventRecord(ctx->evExtF, sA));
+            HIPCHK(issue_pivot(sA));
         }
-        HIPCHK(hipStreamWaitEvent(ctx->side2, ctx->evModel, 0));
-        hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, ctx->side2, v, 0, 1, 1, 0);
-        if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI) {
-            hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side2, ctx->sv, ctx->jacobiW);
-            hipLaunchKernelGGL(k_coef32, dim3(ctx->sv.NB, 2), dim3(VBLOCK), 0, ctx->side2, ctx->sv, const_cast<float4*>(ctx->sv.cf32));
+        HIPCHK(hipStreamWaitEvent(sB, ctx->evModel, 0));
+        if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && !getenv("HMCMT_NO_COEF_ALL")) {
+            hipLaunchKernelGGL(k_coef_all, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, sB, v, ctx->sv, ctx->jacobiW, const_cast<float4*>(ctx->sv.cf32));
+        } else {
+            hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, sB, v, 0, 1, 1, 0);
+            if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI) {
+                hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, sB, ctx->sv, ctx->jacobiW);
+                hipLaunchKernelGGL(k_coef32, dim3(ctx->sv.NB, 2), dim3(VBLOCK), 0, sB, ctx->sv, const_cast<float4*>(ctx->sv.cf32));
+            }
         }
-        HIPCHK(hipEventRecord(ctx->evCoef, ctx->side2));
-        hipLaunchKernelGGL(k_rowmean, dim3(v.nz), dim3(64), 0, ctx->side2, v);
-        if (pivots)
-            hipLaunchKernelGGL(k_pivot, dim3((v.ny - 1 + 63) / 64, S), dim3(64), 4 * (size_t)v.NZP * sizeof(double), ctx->side2, v,
-                               ctx->opt.fdm_precision == 0 ? ctx->d_invp32 : (float2*)nullptr);
-        else
-            hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, ctx->side2, v);
-        HIPCHK(hipEventRecord(ctx->evPiv, ctx->side2));
+        HIPCHK(hipEventRecord(ctx->evCoef, sB));
+        if (!extrap) HIPCHK(issue_pivot(sB));
         if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtF, 0));
         HIPCHK(hipStreamWaitEvent(st, ctx->evCoef, 0));
         // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X
@@ -741,6 +768,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, 1, ctx->opt.verify ? nullptr : ctx->v.sysOn);
             ctx->solveBegun = !ctx->opt.verify;
         }
+        if (ctx->wantTicks) { ctx->hostUs[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hostT0).count(); ++ctx->hostN; }
         HIPCHK(hipStreamWaitEvent(st, ctx->evPiv, 0));
         // (the adjoint half's side-stream work -- its initial guess, the sigma-only sensitivity tables -- is launched
         // from inside the forward solve, once the main queue holds two iterations: launch_adjoint_side)
@@ -761,6 +789,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         rc = collect_stats(ctx, false);
         return rc ? rc : finish_status(ctx);
     }
+    const auto hostT1 = std::chrono::steady_clock::now();
     launch_adjoint_side(ctx);            // (no-op when the solve has already done it)
     ctx->haveFwd = (rc == 0 && ctx->solveDone[0]);
     if (rc) return rc;
@@ -785,7 +814,9 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
                 ctx->solveBegun = true;
             }
         }
+        if (ctx->wantTicks) ctx->hostUs[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hostT1).count();
         rc = solve(ctx, v.Lam, 1);
+        const auto hostT2 = std::chrono::steady_clock::now();
         if (warmA && fusedStart) std::swap(ctx->sv.r, ctx->sv.r2);
         HIPCHK(hipEventRecord(ctx->evRec, st));                        // behind the last k_solve_end
         ctx->haveAdj = (rc == 0 && ctx->solveDone[1]);
@@ -800,6 +831,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         hipLaunchKernelGGL(k_bcsens_contract, dim3((v.nz + 127) / 128, 2, S), dim3(128), 0, st, v);
         hipLaunchKernelGGL(k_gradcell, dim3((v.nCell + 127) / 128, 2, GRAD_NG), dim3(128), 0, st, v);
         hipLaunchKernelGGL(k_gradfinal, grid1(4 * v.nAC, 128), dim3(128), 0, st, v);
+        if (ctx->wantTicks) ctx->hostUs[2] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hostT2).count();
     }
     HIPCHK(hipGetLastError());
     ctx->haveModel = true;
@@ -905,6 +937,37 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->side) hipStreamSynchronize(ctx->side);      // (side-stream work of an evaluation nobody waited for)
+    if (ctx->side2) hipStreamSynchronize(ctx->side2);
+    if (ctx->v.ticks) {
+        static const char* names[TK_N] = {"k_sigma_rows", "k_bc_fused", "k_extrap_prepare (fwd)", "k_extrap (fwd)", "k_coef_all", "k_pivot",
+            "k_resid_pre (fwd)", "k_spmv_fused (first .. last)", "k_update_fused (first .. last)", "k_fdm_fwd (first .. last)",
+            "k_back_post (first .. last)", "k_solve_end (first .. last)", "k_rxall", "k_src", "k_resid_pre (adj)", "k_wb", "k_bcsens_contract",
+            "k_gradcell", "k_gradfinal", "k_lf_momentum", "k_lf_dmmax", "k_lf_step", "k_sens_profile (side)"};
+        std::vector<long long> traw(32 + 64 * TK_N);
+        long long t[64] = {0};
+        int rate = 100000;                                // kHz
+        hipDeviceGetAttribute(&rate, hipDeviceAttributeWallClockRate, ctx->device);
+        if (hipMemcpy(traw.data(), ctx->v.ticks, traw.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int i = 0; i < TK_N; ++i) {
+                t[i] = traw[i];
+                for (int q = 0; q < 64; ++q) t[32 + i] = std::max(t[32 + i], traw[32 + 64 * i + q]);
+            }
+            fprintf(stderr, "HMCMT_TICKS: start .. end (us since the first kernel of the last evaluation), duration\n");
+            long long t0 = 0x7fffffffffffffffLL;
+            for (int i = 0; i < TK_N; ++i) if (t[i] > 0 && t[i] < t0) t0 = t[i];
+            std::vector<int> order;
+            for (int i = 0; i < TK_N; ++i) if (t[i] > 0) order.push_back(i);
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return t[a] < t[b]; });
+            for (int i : order) {
+                if (t[32 + i] > 0) fprintf(stderr, "  %9.1f %9.1f %8.1f   %s\n", (t[i] - t0) * 1e3 / rate, (t[32 + i] - t0) * 1e3 / rate, (t[32 + i] - t[i]) * 1e3 / rate, names[i]);
+                else fprintf(stderr, "  %9.1f         -        -   %s\n", (t[i] - t0) * 1e3 / rate, names[i]);
+            }
+        }
+        if (ctx->hostN) fprintf(stderr, "HMCMT_TICKS: host time of the launch sequences, mean of %ld evaluations: k_sigma .. forward residual %.1f us, "
+                                "k_rxall .. adjoint residual %.1f us, gradient tail %.1f us\n", ctx->hostN, ctx->hostUs[0] / ctx->hostN,
+                                ctx->hostUs[1] / ctx->hostN, ctx->hostUs[2] / ctx->hostN);
+        hipFree(ctx->v.ticks);
+    }
     if (ctx->sv.stamps) {                                // HMCMT_STAMPS: phase stamps of the last launch that wrote them
         std::vector<long long> st(8 * 4096);
         hipMemcpy(st.data(), ctx->sv.stamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost);
@@ -956,11 +1019,15 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     HIPCHK(hipSetDevice(device_id));
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&ctx->evModel, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ctx->evSens, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ctx->evExtF, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ctx->evCoef, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ctx->evPiv, hipEventDisableTiming));
+    // events between the library's own streams: no system-scope fence at the record (HMCMT_EVENT_FLAGS: 0 the default
+    // system-scope release, 1 hipEventDisableSystemFence, 2 hipEventReleaseToDevice); evRec is waited for by the host
+    const int evMode = getenv("HMCMT_EVENT_FLAGS") ? atoi(getenv("HMCMT_EVENT_FLAGS")) : 1;
+    const unsigned evDev = hipEventDisableTiming | (evMode == 1 ? hipEventDisableSystemFence : evMode == 2 ? hipEventReleaseToDevice : 0u);
+    HIPCHK(hipEventCreateWithFlags(&ctx->evModel, evDev));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evSens, evDev));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evExtF, evDev));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evCoef, evDev));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evPiv, evDev));
     HIPCHK(hipEventCreateWithFlags(&ctx->evRec, hipEventDisableTiming));
     HIPCHK(hipStreamCreate(&ctx->side2));
     {
@@ -979,6 +1046,21 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         if (const char* es = getenv("HMCMT_SWEEPS_UP")) ctx->sweepsUp = std::max(1, atoi(es));
         if (const char* es = getenv("HMCMT_SWEEPS_DOWN")) ctx->sweepsDown = std::max(0, atoi(es));
         if (const char* ep = getenv("HMCMT_EXTRAP_POINTS")) ctx->extrapNp = std::max(2, std::min(EXT_NP, atoi(ep)));
+        {
+            // boundary columns per workgroup of k_bc_fused: all workgroups resident at once (two per CU: registers), else the
+            // two-kernel form (HMCMT_BC_FUSED = 0: never, n: n columns per workgroup)
+            const int cols = ctx->hp.ny + 1, nz = ctx->hp.nz;
+            int cw = std::max(1, (cols * ctx->hp.nFreq + 511) / 512);
+            if (const char* eb = getenv("HMCMT_BC_FUSED")) cw = atoi(eb);
+            const int slots = cols <= cw ? 2 : 1;
+            const size_t lds = ((size_t)5 * nz * cw + (size_t)slots * 2 * nz) * sizeof(cplx);
+            if (cw > 0 && cw <= 256 && lds <= (size_t)80 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_bc_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess) {
+                ctx->bcCW = cw; ctx->bcSlots = slots; ctx->bcLds = lds;
+            }
+        }
+        ctx->wantTicks = getenv("HMCMT_TICKS") != nullptr;
+        if (const char* ed = getenv("HMCMT_DEBUG_FLAGS")) ctx->dbgFlags = atoi(ed);                  // (measurement only: hmcmt_debug_flags)
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<FW_NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
             ctx->maxLds = 160 * 1024;
@@ -1000,12 +1082,12 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_resid_pre), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
     }
-    HIPCHK(hipEventCreateWithFlags(&ctx->evExtA, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->evExtA, evDev));
     const HostProblem& h = ctx->hp;
     View& v = ctx->v;
     v.ny = h.ny; v.nz = h.nz; v.NYP = h.NYP; v.NZP = h.NZP; v.nFreq = h.nFreq; v.S = h.S; v.nRx = h.nRx;
     v.nData = h.nData; v.nAC = h.nAC; v.nCell = h.nCell; v.zid = h.zid; v.vstride = (long)h.NZP * h.NYP;
-    v.dbg = 0;
+    v.dbg = 0; v.ticks = nullptr;
     // HMCMT_BGMEAN (experiment, round 3; default 0 = the geometric lateral mean of sigma for both modes): bit 0: TM background =
     // harmonic lateral mean of sigma, i.e. the arithmetic mean of the coefficient 1/sigma the TM stiffness is linear in; bit 1: TE
     // background = arithmetic mean of sigma -- fdm_z_values, hmcmt_items.h.  bench.py, headline chain / near the true model,
@@ -1127,6 +1209,11 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     k.actEarly = !(getenv("HMCMT_ACT_EARLY") && getenv("HMCMT_ACT_EARLY")[0] == '0');
     k.xInFwd = 0;       // set with k.splitT (the fused forward kernel is the one that can take the x update along)
     k.stamps = nullptr; k.stampKernel = 0;
+    k.ticks = nullptr; k.xTickF = v.X;
+    if (ctx->wantTicks && hipMalloc(&ctx->v.ticks, (32 + 64 * TK_N) * sizeof(long long)) == hipSuccess) {
+        hipMemset(ctx->v.ticks, 0, (32 + 64 * TK_N) * sizeof(long long));
+        k.ticks = ctx->v.ticks;
+    }
     if (const char* es = getenv("HMCMT_STAMPS")) {
         k.stampKernel = !strcmp(es, "upd") ? 1 : (!strcmp(es, "spmv") ? 2 : 0);
         if (k.stampKernel) { HIPCHK(hipMalloc((void**)&k.stamps, sizeof(long long) * 8 * 4096)); HIPCHK(hipMemset(k.stamps, 0, sizeof(long long) * 8 * 4096)); }
@@ -1701,7 +1788,7 @@ static int leapfrog_core(hmcmt_ctx* ctx, double* d_m, double* d_p, double dt, in
     hipStream_t st = ctx->stream;
     HIPCHK(hipMemsetAsync(ctx->d_lfFlag, 0, sizeof(int), st));
     LfView lf{n, ctx->d_mref, ctx->d_invM, ctx->d_wmVal, ctx->d_wmRow, ctx->d_wmCol, d_m, d_p, ctx->d_g,
-              ctx->d_lfPart, ctx->d_lfScal, ctx->d_lfFlag};
+              ctx->d_lfPart, ctx->d_lfScal, ctx->d_lfFlag, ctx->v.ticks};
     const dim3 g1((n + 127) / 128), b1(128);
     int evals = 0;
     int rc = 0;

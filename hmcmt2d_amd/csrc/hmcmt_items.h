@@ -21,6 +21,7 @@ struct View {
     int zid;                       // node row of the receivers (mt2DTE.jl:66-67), 0-based
     int bgMean;                    // lateral mean of the FDM background: 1 (default) the arithmetic mean of the coefficient the operator is
                                    // linear in -- sigma for TE (mass term), 1/sigma for TM (stiffness) --, 0 the geometric mean of sigma for both (rounds 1-2)
+    long long* ticks;              // HMCMT_TICKS (measurement only): [2][32] earliest start / latest end of the kernels around the solves
     int dbg;                       // test hooks (hmcmt_debug_flags): bit 1 = leave the boundary-derivative terms B^T v out of the gradient
     long vstride;                  // NZP*NYP elements per system
     // mesh (constant)
@@ -214,14 +215,14 @@ HD void item_pivot_tab(const View& v, int s, int j, const double* mzq, const dou
         {                                                  // d'_iz = d_iz - of_{iz-1}^2 / d'_{iz-1}
             cplx d = cplx{lam * mzq[it] + dgz[it], w * mzs[it]};
             if (it > 1) d -= (ofz[it - 1] * ofz[it - 1]) * pt;
-            pt = crecip(d);
+            pt = crecip_plain(d);
             ip[(long)it * v.NYP] = pt;
             if (ip32) { ip32[2 * (long)it * v.NYP] = (float)pt.re; ip32[2 * (long)it * v.NYP + 1] = (float)pt.im; }
         }
         if (ib >= mid + 1) {                               // d''_iz = d_iz - of_iz^2 / d''_{iz+1}
             cplx d = cplx{lam * mzq[ib] + dgz[ib], w * mzs[ib]};
             if (ib < n) d -= (ofz[ib] * ofz[ib]) * pb;
-            pb = crecip(d);
+            pb = crecip_plain(d);
             ip[(long)ib * v.NYP] = pb;
             if (ip32) { ip32[2 * (long)ib * v.NYP] = (float)pb.re; ip32[2 * (long)ib * v.NYP + 1] = (float)pb.im; }
         }

@@ -55,6 +55,10 @@ HD cplx operator/(cplx a, cplx b) {
 HD cplx operator/(cplx a, double b) { return cplx{a.re / b, a.im / b}; }
 HD cplx operator/(double a, cplx b) { return cplx{a, 0.0} / b; }
 HD cplx crecip(cplx b) { return cplx{1.0, 0.0} / b; }
+// 1/b = conj(b)/|b|^2 for operands whose square neither overflows nor underflows (the FDM pivots: |b| within 1e-100 .. 1e100 by
+// construction): ONE division on the dependent chain where Smith's form has two and a data-dependent branch -- the serial pivot
+// recurrence (k_pivot) is a chain of these
+HD cplx crecip_plain(cplx b) { const double i2 = 1.0 / (b.re * b.re + b.im * b.im); return cplx{b.re * i2, -(b.im * i2)}; }
 
 // principal square root
 HD cplx csqrt_(cplx z) {
@@ -111,20 +115,71 @@ HD cplx k_eps(double sig, double omega) {
 //   out[4..7] m11 m12 m21 m22 = (pInv*eUD)*e  -- amplitude propagation into the next layer (:69-75), with
 //             kr = k / k_next (1 for the last layer: half-space copy), e = exp(+-i k h)
 constexpr int FWD_NQ = 8;
-HD void layer_forward(double sig, double sigNext, bool lastLayer, double omega, double h, cplx out[FWD_NQ]) {
+// exp(+-ikh) and tanh(ikh) of one layer from ONE exponential and ONE sine/cosine pair (round 3; ctanh_ + two cexp_ were five
+// exponentials and four sine/cosine evaluations -- the per-layer terms are 350 000 independent items per evaluation on the
+// headline mesh and fp64-issue-bound).  With ikh = a + ib:  e+- = e^{+-a} (cos b +- i sin b)  and
+//   tanh(a + ib) = (sinh a cosh a + i sin b cos b) / (sinh^2 a + cos^2 b),
+// sinh a from expm1 (no cancellation in thin or resistive layers), saturated like ctanh_ for |a| > 20.
+struct LayerExp { cplx ep, em, th; };
+HD LayerExp layer_exp(cplx k, double h) {
+    const double a = -k.im * h, b = k.re * h;
+    double s, c;
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(b, &s, &c);
+#else
+    s = sin(b); c = cos(b);
+#endif
+    LayerExp r;
+    double E, Ei;
+    if (fabs(a) > 20.0) {
+        E = exp(a); Ei = exp(-a);
+        const double t = a > 0.0 ? Ei : E;
+        r.th = cplx{a > 0.0 ? 1.0 : -1.0, 4.0 * s * c * t * t};
+    } else {
+        const double em1 = expm1(a);
+        E = em1 + 1.0; Ei = 1.0 / E;
+        const double sh = 0.5 * (em1 + em1 * Ei), ch = 0.5 * (E + Ei);
+        const double den = sh * sh + c * c;
+        r.th = cplx{sh * ch / den, s * c / den};
+    }
+    r.ep = cplx{E * c, E * s};
+    r.em = cplx{Ei * c, -(Ei * s)};
+    return r;
+}
+// amplitude propagation into the next layer from k, k of the layer below and e+-
+HD void layer_matrix(cplx k, cplx kNext, bool lastLayer, cplx ep, cplx em, cplx& m11, cplx& m12, cplx& m21, cplx& m22) {
     const cplx one = cplx{1.0, 0.0};
+    const cplx kr = lastLayer ? one : k * crecip(kNext);
+    m11 = (0.5 * (one + kr)) * ep; m12 = (0.5 * (one - kr)) * em;
+    m21 = (0.5 * (one - kr)) * ep; m22 = (0.5 * (one + kr)) * em;
+}
+HD void layer_forward(double sig, double sigNext, bool lastLayer, double omega, double h, cplx out[FWD_NQ]) {
     const cplx k = k_eps(sig, omega);
-    const cplx ikh = mul_i(k * h);
     const cplx zp = (omega * MU0) * crecip(k);
-    const cplx th = ctanh_(ikh);
-    const cplx ep = cexp_(ikh), em = cexp_(-ikh);
-    const cplx kr = lastLayer ? one : k * crecip(k_eps(sigNext, omega));
+    const LayerExp x = layer_exp(k, h);
     out[0] = k;
     out[1] = zp;
-    out[2] = th;
-    out[3] = zp * (zp * th);
-    out[4] = (0.5 * (one + kr)) * ep; out[5] = (0.5 * (one - kr)) * em;
-    out[6] = (0.5 * (one - kr)) * ep; out[7] = (0.5 * (one + kr)) * em;
+    out[2] = x.th;
+    out[3] = zp * (zp * x.th);
+    layer_matrix(k, lastLayer ? k : k_eps(sigNext, omega), lastLayer, x.ep, x.em, out[4], out[5], out[6], out[7]);
+}
+
+// The same terms in the two groups k_bc_fused builds them in (LDS, one group in the space of the other): first k, e+ and
+// the impedance recurrence's zp, th, zp*(zp*th) ...
+HD void layer_up_terms(double sig, double omega, double h, cplx& k, cplx& ep, cplx& zp, cplx& th, cplx& zt) {
+    k = k_eps(sig, omega);
+    zp = (omega * MU0) * crecip(k);
+    const LayerExp x = layer_exp(k, h);
+    ep = x.ep; th = x.th;
+    zt = zp * (zp * th);
+}
+// ... then the amplitude propagation's m11, m12, m21, m22 from the stored k, k of the layer below and e+
+// (e- = conj(e+) / |e+|^2; zero where e+ has overflowed, as exp(-a) is)
+HD void layer_down_terms(cplx k, cplx kNext, bool lastLayer, cplx ep, cplx& m11, cplx& m12, cplx& m21, cplx& m22) {
+    const double n2 = cabs2(ep);
+    cplx em = cplx{0.0, 0.0};
+    if (n2 > 0.0 && n2 < 1e300) { const double i2 = 1.0 / n2; em = cplx{ep.re * i2, -(ep.im * i2)}; }
+    layer_matrix(k, kNext, lastLayer, ep, em, m11, m12, m21, m22);
 }
 
 // Serial part for one column.  T points at this column's k-entry of layer 0; the FWD_NQ quantities are
@@ -146,18 +201,15 @@ HD void fwd_outputs(const FwdTop& tp, cplx eu, cplx ed, cplx kj, bool dead, cplx
     if (dead) { fnE = cplx{0.0, 0.0}; fnH = cplx{0.0, 0.0}; }
     oE = fnE * tp.if0E; oH = fnH * tp.if0H;
 }
-// Core: amp(i, eu, ed, kj, dead) is called with the amplitudes under every layer i; the outputs of the LAST layer are
-// returned.  A caller that needs every layer's outputs evaluates fwd_outputs in amp (bc1d_forward_tab_2) or stores the
-// amplitudes and evaluates them afterwards, off the serial loop (k_bc_forward's edge columns).
-template <class Amp>
-HD void bc1d_forward_core(double omega, int nz, const cplx* T, long qs, long ls, Amp amp, FwdTop& tp, cplx& lastE_, cplx& lastH_) {
-    const double omu0 = omega * MU0;
+// Impedance recurrence bottom -> top (:48-56) of one column; the tables of zp, th and zp*(zp*th) are `ls` elements
+// apart from layer to layer.  Returns Z at the surface.
+// Z_j = zp (Z + zp th) / (zp + Z th) is a Moebius map: it is carried projectively, Z = N/D, so the serial
+// chain has no division (a robust complex division is ~3 dependent fp64 divides); N and D are rescaled
+// by an exact power of two once per block, and divided once at the top.
+HD cplx bc1d_up(int nz, const cplx* Tzp, const cplx* Tth, const cplx* Tzt, long ls) {
     const cplx one = cplx{1.0, 0.0};
-    // impedance recurrence bottom -> top (:48-56); half-space has the last layer's conductivity.
-    // Z_j = zp (Z + zp th) / (zp + Z th) is a Moebius map: it is carried projectively, Z = N/D, so the serial
-    // chain has no division (a robust complex division is ~3 dependent fp64 divides); N and D are rescaled
-    // by an exact power of two once per block, and divided once at the top.
-    cplx zn = T[qs + (long)(nz - 1) * ls], zd = one;
+    // half-space below the last layer with the last layer's conductivity
+    cplx zn = Tzp[(long)(nz - 1) * ls], zd = one;
     auto rescale = [&]() {
         const int e = -ilogb(fmax(fmax(fabs(zd.re), fabs(zd.im)), fmax(fabs(zn.re), fabs(zn.im))));
         if (e > -1000 && e < 1000) {                     // (zero / inf / nan: leave alone, the division below reports it)
@@ -171,7 +223,7 @@ HD void bc1d_forward_core(double omega, int nz, const cplx* T, long qs, long ls,
 #pragma unroll
         for (int t = 0; t < RBF; ++t) {
             const long j = j0 - t;
-            c1[t] = T[qs + j * ls]; c3[t] = T[2 * qs + j * ls]; c2[t] = T[3 * qs + j * ls];
+            c1[t] = Tzp[j * ls]; c3[t] = Tth[j * ls]; c2[t] = Tzt[j * ls];
         }
 #pragma unroll
         for (int t = 0; t < RBF; ++t) {
@@ -183,15 +235,26 @@ HD void bc1d_forward_core(double omega, int nz, const cplx* T, long qs, long ls,
     }
     for (; j0 >= 0; --j0) {                              // the remaining layers
         const long j = j0;
-        const cplx a1 = T[qs + j * ls], a3 = T[2 * qs + j * ls], a2 = T[3 * qs + j * ls];
+        const cplx a1 = Tzp[j * ls], a3 = Tth[j * ls], a2 = Tzt[j * ls];
         const cplx nn = a1 * zn + a2 * zd;
         zd = a1 * zd + zn * a3;
         zn = nn;
     }
     rescale();
-    const cplx ztmp = zn / zd;
+    return zn / zd;
+}
+
+// Amplitude propagation top -> bottom (:62-83) from the surface impedance ztmp.
+// Core: amp(i, eu, ed, kj, dead) is called with the amplitudes under every layer i; the outputs of the LAST layer are
+// returned.  A caller that needs every layer's outputs evaluates fwd_outputs in amp (bc1d_forward_tab_2) or stores the
+// amplitudes and evaluates them afterwards, off the serial loop (the edge columns of k_bc_forward / k_bc_fused).
+template <class Amp>
+HD void bc1d_down(double omega, int nz, cplx ztmp, const cplx* Tk, const cplx* Tm11, const cplx* Tm12, const cplx* Tm21,
+                  const cplx* Tm22, long ls, Amp amp, FwdTop& tp, cplx& lastE_, cplx& lastH_) {
+    const double omu0 = omega * MU0;
+    const cplx one = cplx{1.0, 0.0};
     // top-layer up/down-going amplitudes (:62-63)
-    cplx kj = T[0];
+    cplx kj = Tk[0];
     const cplx a = omu0 / (ztmp * kj);
     cplx eu = 0.5 * (one - a), ed = 0.5 * (one + a);
     const double iomu0 = 1.0 / omu0;
@@ -218,18 +281,25 @@ HD void bc1d_forward_core(double omega, int nz, const cplx* T, long qs, long ls,
 #pragma unroll
         for (int t = 0; t < RBF; ++t) {
             const long i = i0 + t;
-            kn_[t] = T[(i + 1) * ls];
-            m11[t] = T[4 * qs + i * ls]; m12[t] = T[5 * qs + i * ls]; m21[t] = T[6 * qs + i * ls]; m22[t] = T[7 * qs + i * ls];
+            kn_[t] = Tk[(i + 1) * ls];
+            m11[t] = Tm11[i * ls]; m12[t] = Tm12[i * ls]; m21[t] = Tm21[i * ls]; m22[t] = Tm22[i * ls];
         }
 #pragma unroll
         for (int t = 0; t < RBF; ++t) down(i0 + t, kn_[t], m11[t], m12[t], m21[t], m22[t]);
     }
     for (; i0 < nz; ++i0) {
         const long i = i0;
-        const cplx kn = (i0 + 1 >= nz) ? kj : T[(i + 1) * ls];
-        down(i0, kn, T[4 * qs + i * ls], T[5 * qs + i * ls], T[6 * qs + i * ls], T[7 * qs + i * ls]);
+        const cplx kn = (i0 + 1 >= nz) ? kj : Tk[(i + 1) * ls];
+        down(i0, kn, Tm11[i * ls], Tm12[i * ls], Tm21[i * ls], Tm22[i * ls]);
     }
     fwd_outputs(tp, eu, ed, kj, dead, lastE_, lastH_);
+}
+
+// Both recurrences on one table T (this column's k-entry of layer 0; quantities qs apart, layers ls apart)
+template <class Amp>
+HD void bc1d_forward_core(double omega, int nz, const cplx* T, long qs, long ls, Amp amp, FwdTop& tp, cplx& lastE_, cplx& lastH_) {
+    const cplx ztmp = bc1d_up(nz, T + qs, T + 2 * qs, T + 3 * qs, ls);
+    bc1d_down(omega, nz, ztmp, T, T + 4 * qs, T + 5 * qs, T + 6 * qs, T + 7 * qs, ls, amp, tp, lastE_, lastH_);
 }
 
 // Both polarisations of one frequency, every layer's outputs through outE(i, v) / outH(i, v)

@@ -58,6 +58,8 @@ struct Solver {
     int* stallHost;                       // pinned host flag: a system has not improved its error estimate 10-fold in STALL_IT iterations
     int* failHost;                        // pinned host word: status (HMCMT_ENOCONV / HMCMT_EBREAKDOWN) of a system that has just given up --
                                           // the host must not build on this solve (adjoint on a failed forward, next leapfrog step)
+    long long* ticks;                     // HMCMT_TICKS: View::ticks
+    const cplx* xTickF;                   //   (the forward fields: k_extrap's forward call is the one on the timeline)
     long long* stamps;                    // HMCMT_STAMPS=<kernel>: per-workgroup s_memtime stamps of that kernel's phases ([workgroup][8]; printed at hmcmt_destroy)
     int stampKernel;                      // 1 k_update_fused<2>, 2 k_spmv_fused<2>
     unsigned long long* cntActive;        // non-null in an evaluation sampled by hmcmt_profile: += systems still active per iteration
@@ -76,6 +78,20 @@ __device__ __forceinline__ double dpp_mov_f64(double v) {
 }
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// HMCMT_TICKS: the constant-rate wall clock at the start of the first workgroup / the end of the last one of kernel `id`
+// (a store per workgroup when enabled, a null test otherwise); printed at hmcmt_destroy as the untraced timeline of the
+// last evaluation -- rocprofv3's kernel trace makes the host's launches the bottleneck around the solves
+enum { TK_SIGMA = 0, TK_BC, TK_EXTW, TK_EXT, TK_COEF, TK_PIVOT, TK_RESID_F, TK_SPMV, TK_UPDATE, TK_FWD, TK_BACK, TK_SOLVE_END, TK_RXALL,
+       TK_SRC, TK_RESID_A, TK_WB, TK_BCSENS, TK_GRADCELL, TK_GRADFINAL, TK_LF_MOM, TK_LF_MAX, TK_LF_STEP, TK_SENS, TK_N };
+__device__ __forceinline__ void tick_begin(long long* t, int id) {          // first workgroup of the first launch since the reset
+    if (t && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && t[id] == -1) t[id] = wall_clock64();
+}
+__device__ __forceinline__ void tick_end(long long* t, int id) {            // every workgroup: plain store into one of 64 slots (the host takes the maximum)
+    if (t && threadIdx.x == 0) {
+        const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        t[32 + 64 * id + (b & 63)] = wall_clock64();
+    }
 }
 __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_mov_f64<0xB1>(v);          // quad_perm [1,0,3,2]

@@ -288,6 +288,54 @@ __global__ __launch_bounds__(VBLOCK) void k_dinv(Solver k, double wJ) {
     }
 }
 
+// k_coef + k_dinv + k_coef32 in one launch (three in a row on the side stream the forward residual waits for): thread
+// (node, system) forms the model-dependent half of its mode's stencil at the node from the four cells around it -- TM: the
+// couplings and the stiffness diagonal from 1/sigma, TE: the mass from sigma; the other half is constant and read -- and from
+// it the system's Jacobi diagonal; the threads of the first system of each mode also store the coefficient arrays and
+// their packed float copy (Solver::cf32).  grid (NB, S)
+__global__ __launch_bounds__(VBLOCK) void k_coef_all(View v, Solver k, double wJ, float4* __restrict__ cf) {
+    const int s = blockIdx.y, mode = s >= k.nFreq;
+    tick_begin(v.ticks, TK_COEF);
+    const bool writer = s == mode * k.nFreq;
+    const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
+    const double w = k.omega[s];
+    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
+        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+        const bool rowI = iz >= 1 && iz <= k.nz - 1, colI = iy >= 1 && iy <= k.ny - 1, interior = rowI && colI;
+        double cy = 0.0, cz = 0.0, cym = 0.0, czm = 0.0, dk = 0.0, dm = 0.0;
+        if (mode == 1) {
+            if (rowI && iy <= k.ny - 1) cy = coupY(v, 1, iy, iz);
+            if (colI && iz <= k.nz - 1) cz = coupZ(v, 1, iy, iz);
+            if (interior) {
+                cym = coupY(v, 1, iy - 1, iz); czm = coupZ(v, 1, iy, iz - 1);
+                dk = -(cy + cym + cz + czm);
+                dm = v.dM[mo + e];
+            }
+        } else if (interior) {
+            dk = v.dK[e];
+            const double ya = v.yLen[iy - 1], yb = v.yLen[iy], za = v.zLen[iz - 1], zb = v.zLen[iz];
+            dm = 0.25 * (ya * za * cells(v, 0, iy - 1, iz - 1) + yb * za * cells(v, 0, iy, iz - 1) +
+                         ya * zb * cells(v, 0, iy - 1, iz) + yb * zb * cells(v, 0, iy, iz));
+            if (writer) { cy = v.cY[e]; cym = v.cY[e - 1]; cz = v.cZ[e]; czm = v.cZ[e - k.NYP]; }
+        }
+        cplx d = cplx{0, 0};
+        if (interior) d = wJ / cplx{dk, w * dm};
+        k.dinv[so + e] = d;
+        k.dinv32[so + e] = float2{(float)d.re, (float)d.im};
+        if (writer) {
+            if (iy <= k.ny) {
+                if (mode == 1) { v.cY[mo + e] = cy; v.cZ[mo + e] = cz; v.dK[mo + e] = dk; }
+                else v.dM[e] = dm;
+            }
+            float4 a = float4{0.f, 0.f, 0.f, 0.f}, b = a;
+            if (interior) { a = float4{(float)dk, (float)dm, (float)cy, (float)cym}; b = float4{(float)cz, (float)czm, 0.f, 0.f}; }
+            cf[2 * (mo + e)] = a; cf[2 * (mo + e) + 1] = b;
+        }
+    }
+    tick_end(v.ticks, TK_COEF);
+}
+
 // t = r - A (dinv .* r)
 __global__ __launch_bounds__(VBLOCK) void k_pre(Solver k) {
     const int s = blockIdx.y;
@@ -607,6 +655,7 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
                                                  const u4v* __restrict__ Blo, const float2* __restrict__ ip32,
                                                  float2* __restrict__ Y, long long* stamps = nullptr, const float2* __restrict__ pX = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    tick_begin(k.ticks, TK_FWD);
     // 1-D grid of nslab*S workgroups.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has
     // its own L2: all slabs of a system are placed on ONE XCD so that system's rows are fetched into one L2 once
     const int nslab = ((k.NYP >> 4) + NTW - 1) / NTW;
@@ -929,6 +978,7 @@ __global__ __launch_bounds__(512) void k_fdm_fwd(Solver k, const float2* __restr
         }
     }
     FW_STAMP(4)
+    tick_end(k.ticks, TK_FWD);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -950,6 +1000,7 @@ template <int FMT, int SW = 1>
 __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __restrict__ Y, const u4v* __restrict__ Bhi,
                                                    const u4v* __restrict__ Blo, double* partZZ, int NW, long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem_[];
+    tick_begin(k.ticks, TK_BACK);
     const int s = blockIdx.y, bx = blockIdx.x, nwg = gridDim.x;
     const int act = k.active[s];
     // (round 3) tested HERE: rounds 1-2 tested it after the staging and V-fragment loads had been issued -- one memory round
@@ -1176,6 +1227,7 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
             partZZ[(long)s * MAXNB + b] = 0.0;
         }
     BP_STAMP(6)
+    tick_end(k.ticks, TK_BACK);
 }
 
 // Back half of the two-sweep smoother on meshes too wide for k_back_post (separate back transform k_transform_lp<1>):

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(NT) void k_spmv_fused(Solver k, const double* partZ
     extern __shared__ __attribute__((aligned(16))) char smem_[];
     cplx* pn = reinterpret_cast<cplx*>(smem_);            // [(RT+2)][NYP]
     __shared__ double sh[32];
+    tick_begin(k.ticks, TK_SPMV);
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *(volatile int*)k.progHost = it;   // "iteration it-1 is complete"
     int tile, s;
     if (!tile_map(k, k.NTR, tile, s)) return;
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(NT) void k_spmv_fused(Solver k, const double* partZ
     block_sum2(ar, ai, sh);
     if (threadIdx.x == 0) k.partPQ[(long)s * MAXNB + tile] = cplx{ar, ai};
     PH_STAMP(2, 6)
+    tick_end(k.ticks, TK_SPMV);
 }
 
 // SW = 2 (two damped Jacobi sweeps on each side of the FDM stage, k.sweeps == 2): the pre-smoother becomes
@@ -291,6 +293,7 @@ __global__ __launch_bounds__(NT) void k_spmv_fused(Solver k, const double* partZ
 template <int SW, int NT, int UBX>    // NT: threads per workgroup; UBX: elements per thread and batch of the two-sweep form
 __global__ __launch_bounds__(NT) void k_update_fused(Solver k, const float2* pcur, const cplx* rin, cplx* rout, int it, int startOnly) {
     const int RTt = SW == 2 ? k.RT2 : k.RT;
+    tick_begin(k.ticks, TK_UPDATE);
     const int ntiles = (k.nz - 1 + RTt - 1) / RTt;
     int tile, s;
     if (!tile_map(k, ntiles, tile, s)) return;
@@ -547,6 +550,7 @@ __global__ __launch_bounds__(NT) void k_update_fused(Solver k, const float2* pcu
         k.partB[(long)s * MAXNB + tile] = xx;
         if (tile == 0) k.alphaBeta[s] = al;
     }
+    tick_end(k.ticks, TK_UPDATE);
 }
 
 // warm start: r <- r - A x over interior nodes, x including whatever sits on its boundary nodes
@@ -589,6 +593,7 @@ __global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r
 __global__ __launch_bounds__(VBLOCK) void k_resid_pre(Solver k, const cplx* x, const cplx* rin, cplx* rout, int zero_r,
                                                       const int* __restrict__ sysOn) {
     const int s = blockIdx.y;
+    tick_begin(k.ticks, zero_r ? TK_RESID_F : TK_RESID_A);
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         for (int t = threadIdx.x; t < k.S * MAXNB; t += VBLOCK) k.partB[t] = 0.0;
         for (int t = threadIdx.x; t < k.S; t += VBLOCK) { k.active[t] = sysOn[t]; k.iters[t] = 0; k.status[t] = 0; }
@@ -665,6 +670,7 @@ __global__ __launch_bounds__(VBLOCK) void k_resid_pre(Solver k, const cplx* x, c
         }
         store_t32(k, k.t32 + so, iz0 + lr, iy, (float)out.re, (float)out.im);
     }
+    tick_end(k.ticks, zero_r ? TK_RESID_F : TK_RESID_A);
 }
 
 // start of a solve: every requested system active, records cleared (one launch instead of five copies/memsets)
@@ -684,10 +690,12 @@ __global__ void k_solve_begin(Solver k, const int* __restrict__ sysOn) {
 // rec = [2 kinds][S] iters (int) | [2][S] status (int) | [2][S] error estimate (double)
 __global__ void k_solve_end(Solver k, int kind, int* __restrict__ recI, double* __restrict__ recE) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    tick_begin(k.ticks, TK_SOLVE_END);
     if (s >= k.S) return;
     recI[kind * k.S + s] = k.iters[s];
     recI[(2 + kind) * k.S + s] = k.status[s];
     recE[kind * k.S + s] = k.errEst[s];
+    tick_end(k.ticks, TK_SOLVE_END);
 }
 
 // ---- initial guess extrapolated along the model path (options.warm_start == 2) ----
@@ -769,9 +777,10 @@ __device__ bool extrap_weights(const double* a, double* ext, int maxNp, int cold
 // block that takes the last ticket adds the partial sums up, derives the weights and -- unless the model is a repeat --
 // moves the head onto that slot.
 __global__ __launch_bounds__(256) void k_extrap_prepare(const double* __restrict__ mNew, double* hist, int nAC, double* ext,
-                                                         int maxNp, int coldUnlessSmooth) {
+                                                         int maxNp, int coldUnlessSmooth, long long* ticks) {
     __shared__ double sh[EXT_NS][4];
     __shared__ int lastFlag;
+    if (!coldUnlessSmooth) tick_begin(ticks, TK_EXTW);
     const int hm = (int)ext[EXT_MHEAD];
     double* fresh = hist + (long)((hm + EXT_NP) % (EXT_NP + 1)) * nAC;
     double a[EXT_NS];
@@ -820,7 +829,12 @@ __global__ __launch_bounds__(256) void k_extrap_prepare(const double* __restrict
 #pragma unroll
     for (int q = 0; q < EXT_NS; ++q) a[q] = wave_sum(threadIdx.x < EXT_NBLK ? v[q] : 0.0);
     if (threadIdx.x == 0) extrap_weights(a, ext, maxNp, coldUnlessSmooth);
+    if (!coldUnlessSmooth) tick_end(ticks, TK_EXTW);
 }
+
+// (Round 3 also tried the whole job in ONE workgroup, as an extra block of the launch that forms sigma -- both need nothing but
+// the new model: 26-34 us for 5 000 parameters even with every load of a pass requested up front, against 15 us for this
+// kernel on the side stream; the launch in front of the boundary-value kernel then ends 30 us later.  Removed.)
 
 // x <- sum_j w_j x_{k-j} on interior nodes (runs beside k_bc_forward, which writes X's boundary nodes).  The previous
 // solutions live in a RING of EXT_NP-1 slots xp[slot][S*vstride]: with the head h already moved by k_extrap_weights, the
@@ -829,6 +843,7 @@ __global__ __launch_bounds__(256) void k_extrap_prepare(const double* __restrict
 // fields with a non-zero weight are read: 2 on a path that is not smooth, none for a cold adjoint start (round 1
 // shifted the whole history through memory: 12 vector passes of 11.5 MB per call instead of 2-8).
 __global__ __launch_bounds__(VBLOCK) void k_extrap(Solver k, cplx* x, cplx* xp, const double* __restrict__ ext) {
+    if (x == k.xTickF) tick_begin(k.ticks, TK_EXT);
     if (ext[EXT_KEEP] != 0.0) return;
     double w[EXT_NP];
 #pragma unroll
@@ -847,6 +862,7 @@ __global__ __launch_bounds__(VBLOCK) void k_extrap(Solver k, cplx* x, cplx* xp, 
         xp[(long)h * hs + so + e] = q0;
         x[so + e] = acc;
     }
+    if (x == k.xTickF) tick_end(k.ticks, TK_EXT);
 }
 
 // true residual norm check: partB = |b - A x|^2 with b passed separately (verify option)

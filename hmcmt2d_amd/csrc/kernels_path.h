@@ -27,6 +27,23 @@ __global__ __launch_bounds__(64) void k_rowmean(View v) {
     sa = wave_sum(sa); sl = wave_sum(sl); sh = wave_sum(sh);
     if (threadIdx.x == 0) { v.sigMeanA[kz] = sa / v.ny; v.sigMeanG[kz] = (v.bgMean & 1) ? v.ny / sh : exp(sl / v.ny); }
 }
+// k_sigma + k_rowmean: one wave per cell row computes the row's conductivities and, from the values it has just formed,
+// the lateral means (same summation order as k_rowmean) -- the FDM background (k_pivot) then needs nothing but this launch
+__global__ __launch_bounds__(64) void k_sigma_rows(View v) {
+    tick_begin(v.ticks, TK_SIGMA);
+    const int kz = blockIdx.x;
+    double sa = 0.0, sl = 0.0, sh = 0.0;
+    for (int ky = threadIdx.x; ky < v.ny; ky += 64) {
+        const long cell = (long)kz * v.ny + ky;
+        const int a = v.cell2act[cell];
+        const double s = v.bg[cell] + (a >= 0 ? exp(v.m[a]) : 0.0);
+        v.sigma[cell] = s;
+        sa += s; sl += log(s); sh += 1.0 / s;
+    }
+    sa = wave_sum(sa); sl = wave_sum(sl); sh = wave_sum(sh);
+    if (threadIdx.x == 0) { v.sigMeanA[kz] = sa / v.ny; v.sigMeanG[kz] = (v.bgMean & 1) ? v.ny / sh : exp(sl / v.ny); }
+    tick_end(v.ticks, TK_SIGMA);
+}
 __global__ void k_coef(View v, int te_doK, int te_doM, int tm_doK, int tm_doM) {
     int e = TID1;
     if (e >= v.NZP * (v.ny + 1)) return;
@@ -42,6 +59,7 @@ __global__ void k_fdm_z(View v) { int e = TID1; if (e < 2 * v.NZP) item_fdm_z(v,
 __global__ __launch_bounds__(64) void k_pivot(View v, float2* ip32) {
     extern __shared__ __attribute__((aligned(16))) char smem_pv[];
     double* tab = reinterpret_cast<double*>(smem_pv);
+    tick_begin(v.ticks, TK_PIVOT);
     const int j = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y, mode = s >= v.nFreq;
     const bool store = blockIdx.x == 0 && s == mode * v.nFreq;
     for (int i = threadIdx.x; i < v.NZP; i += blockDim.x) {
@@ -57,6 +75,7 @@ __global__ __launch_bounds__(64) void k_pivot(View v, float2* ip32) {
     if (j < v.ny - 1)
         item_pivot_tab(v, s, j, tab, tab + v.NZP, tab + 2 * v.NZP, tab + 3 * v.NZP,
                        ip32 ? reinterpret_cast<float*>(ip32 + (long)s * v.vstride + j) : nullptr);
+    tick_end(v.ticks, TK_PIVOT);
 }
 __global__ __launch_bounds__(64) void k_bc_layers(View v) {       // grid z: frequencies
     int col = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, f = blockIdx.z;
@@ -119,13 +138,100 @@ __global__ __launch_bounds__(64) void k_bc_forward(View v) {
         }
     }
 }
+// k_bc_layers + k_bc_forward in ONE launch for meshes whose columns fit the chip in one round (round 3): a workgroup takes
+// CW boundary columns of one frequency, builds their per-layer terms in LDS -- first the three of the impedance
+// recurrence, then (in the same space) the five of the amplitude propagation: nz*CW independent items of transcendental
+// fp64 work over 256 threads -- and lanes 0..CW-1 run the serial recurrences from LDS.  The table never goes through
+// global memory (k_bc_forward fetched it from the Infinity Cache, eight layers per round trip: 26 round trips in a row
+// were its 45 us), and one launch is gone from the critical chain in front of the forward residual.
+// LDS: slab[5][nz][CW] complex, amplitudes of the edge column(s) [nslot][nz][2].
+__global__ __launch_bounds__(256) void k_bc_fused(View v, int CW, int nslot) {
+    extern __shared__ __attribute__((aligned(16))) char smem_bcf[];
+    tick_begin(v.ticks, TK_BC);
+    const int nz = v.nz;
+    const long ls = CW, qs = (long)nz * CW;
+    cplx* tab = reinterpret_cast<cplx*>(smem_bcf);
+    cplx* amp = tab + 5 * qs;
+    __shared__ FwdTop top[2];
+    __shared__ int deadAt[2];
+    const int col0 = blockIdx.x * CW, f = blockIdx.y;
+    const bool onE = v.sysOn[f] != 0, onH = v.sysOn[v.nFreq + f] != 0;
+    if (!onE && !onH) return;
+    const double omega = v.omega[f];
+    cplx* XE = v.X + (long)f * v.vstride;
+    cplx* XH = v.X + (long)(v.nFreq + f) * v.vstride;
+    const bool has0 = col0 == 0, hasN = col0 <= v.ny && v.ny < col0 + CW;
+    const int col = col0 + threadIdx.x;
+    const bool serial = (int)threadIdx.x < CW && col <= v.ny;
+    const bool isEdge = serial && (col == 0 || col == v.ny);
+    const int slot = (col == 0 || nslot == 1) ? 0 : 1;    // (one slot: the two edge columns are in different workgroups)
+    if (serial) {
+        if (onE) XE[nidx(v, col, 0)] = cplx{1.0, 0.0};    // top row incl. corners
+        if (onH) XH[nidx(v, col, 0)] = cplx{1.0, 0.0};
+    }
+    // slabs: 0 k, then 1 zp, 2 th, 3 zp*(zp*th), 4 e+  ->  1 m11, 2 m12, 3 m21, 4 m22
+    for (int idx = threadIdx.x; idx < nz * CW; idx += blockDim.x) {
+        const int j = idx / CW, c = idx - j * CW;
+        cplx kk, ep, zp, th, zt;
+        layer_up_terms(bc_column_sigma(v, j, min(col0 + c, v.ny)), omega, v.zLen[j], kk, ep, zp, th, zt);
+        const long o = (long)j * ls + c;
+        tab[o] = kk; tab[qs + o] = zp; tab[2 * qs + o] = th; tab[3 * qs + o] = zt; tab[4 * qs + o] = ep;
+    }
+    __syncthreads();
+    cplx ztmp = cplx{0.0, 0.0};
+    if (serial) ztmp = bc1d_up(nz, tab + qs + threadIdx.x, tab + 2 * qs + threadIdx.x, tab + 3 * qs + threadIdx.x, ls);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nz * CW; idx += blockDim.x) {
+        const int j = idx / CW, c = idx - j * CW;
+        const bool lastLayer = j + 1 >= nz;
+        const long o = (long)j * ls + c;
+        const cplx kk = tab[o], kn = tab[lastLayer ? o : o + ls], ep = tab[4 * qs + o];
+        cplx m11, m12, m21, m22;
+        layer_down_terms(kk, kn, lastLayer, ep, m11, m12, m21, m22);
+        tab[qs + o] = m11; tab[2 * qs + o] = m12; tab[3 * qs + o] = m21; tab[4 * qs + o] = m22;
+    }
+    __syncthreads();
+    if (serial) {
+        cplx* ea = amp + (long)slot * 2 * nz;
+        int dAt = nz;                                     // first layer behind the overflow cut-off
+        FwdTop tp;
+        cplx lastE, lastH;
+        const cplx* T = tab + threadIdx.x;
+        bc1d_down(omega, nz, ztmp, T, T + qs, T + 2 * qs, T + 3 * qs, T + 4 * qs, ls, [&](int i, cplx eu, cplx ed, cplx, bool dead) {
+            if (isEdge) { ea[2 * i] = eu; ea[2 * i + 1] = ed; if (dead && dAt > i) dAt = i; }
+        }, tp, lastE, lastH);
+        if (isEdge) { top[slot] = tp; deadAt[slot] = dAt; }
+        else {
+            if (onE) XE[nidx(v, col, nz)] = lastE;
+            if (onH) XH[nidx(v, col, nz)] = lastH;
+        }
+    }
+    if (has0 || hasN) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nz; i += blockDim.x) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (e == 0 ? !has0 : !hasN) continue;
+                const int ecol = e == 0 ? 0 : v.ny, sl = (e == 0 || nslot == 1) ? 0 : 1;
+                const cplx kj = tab[(long)(i + 1 < nz ? i + 1 : nz - 1) * ls + (ecol - col0)];      // k of the layer below (the last layer: its own)
+                cplx oE, oH;
+                fwd_outputs(top[sl], amp[((long)sl * nz + i) * 2], amp[((long)sl * nz + i) * 2 + 1], kj, i >= deadAt[sl], oE, oH);
+                if (onE) XE[nidx(v, ecol, 1 + i)] = oE;
+                if (onH) XH[nidx(v, ecol, 1 + i)] = oH;
+            }
+        }
+    }
+    tick_end(v.ticks, TK_BC);
+}
 __global__ __launch_bounds__(64) void k_sens_layers(View v) {
     int j = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
     if (j <= v.nz) item_sens_layers(v, s, prof, j);
 }
 __global__ __launch_bounds__(64) void k_sens_profile(View v) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
+    tick_begin(v.ticks, TK_SENS);
     if (e < 3 * v.S) item_sens_profile(v, e / 3, e % 3);
+    tick_end(v.ticks, TK_SENS);
 }
 __global__ void k_rhs(View v) {
     int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
@@ -150,6 +256,7 @@ __global__ void k_misfit(View v, double* out) {
 // misfit itself, a reduction over all data, is not needed by the adjoint half and is summed after the sources).
 __global__ __launch_bounds__(64) void k_rxall(View v, int wantGrad) {        // (64: registers instead of 200 B of spills)
     const int e = TID1;
+    tick_begin(v.ticks, TK_RXALL);
     if (e >= v.S * v.nRx) return;
     const int s = e / v.nRx, r = e % v.nRx;
     item_rx(v, s, r, wantGrad != 0);
@@ -160,6 +267,7 @@ __global__ __launch_bounds__(64) void k_rxall(View v, int wantGrad) {        // 
         c += v.vbar[p];
     }
     if (wantGrad) v.rxCoef[e] = c;
+    tick_end(v.ticks, TK_RXALL);
 }
 __global__ void k_rxcoef(View v) { int e = TID1; if (e < v.S * v.nRx) item_rxcoef(v, e / v.nRx, e % v.nRx); }
 // adjoint sources; workgroup (0,0) also adds up the misfit terms (a reduction nothing on the device waits for: no
@@ -168,6 +276,7 @@ __global__ __launch_bounds__(128) void k_src(View v, double* misfitOut, int nsrc
     // blocks x < nsrc: the sources; the blocks behind them: the receiver-layer Q-terms of the gradient (item_qterm
     // needs nothing from the adjoint solve: here they cost no launch in the gradient tail)
     const int s = blockIdx.y;
+    tick_begin(v.ticks, TK_SRC);
     if ((int)blockIdx.x >= nsrc) {
         const int ky = (blockIdx.x - nsrc) * blockDim.x + threadIdx.x;
         if (ky < v.ny) item_qterm(v, s, ky);
@@ -184,11 +293,14 @@ __global__ __launch_bounds__(128) void k_src(View v, double* misfitOut, int nsrc
         __syncthreads();
         if (threadIdx.x == 0) *misfitOut = sh[0] + sh[1];
     }
+    tick_end(v.ticks, TK_SRC);
 }
 __global__ void k_wb(View v) {
     int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    tick_begin(v.ticks, TK_WB);
     if (e < v.nz) item_wside(v, s, e + 1);
     else if (e < v.nz + v.ny) item_colw(v, s, e - v.nz);
+    tick_end(v.ticks, TK_WB);
 }
 __global__ __launch_bounds__(64) void k_bcsens_pre(View v) {
     int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
@@ -196,11 +308,15 @@ __global__ __launch_bounds__(64) void k_bcsens_pre(View v) {
 }
 __global__ void k_bcsens_contract(View v) {
     int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
+    tick_begin(v.ticks, TK_BCSENS);
     if (c < v.nz) item_bcsens_contract(v, s, prof, c);
+    tick_end(v.ticks, TK_BCSENS);
 }
 __global__ void k_gradcell(View v) {
     int c = blockIdx.x * blockDim.x + threadIdx.x, mode = blockIdx.y, grp = blockIdx.z;
+    tick_begin(v.ticks, TK_GRADCELL);
     if (c < v.nCell) item_gradcell_group(v, mode, grp, c);
+    tick_end(v.ticks, TK_GRADCELL);
 }
 __global__ __launch_bounds__(64) void k_qterm(View v) {
     int ky = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
@@ -210,6 +326,7 @@ __global__ __launch_bounds__(64) void k_qterm(View v) {
 // taking every fourth system / partial sum; the four partial sums are added in lane order
 __global__ void k_gradfinal(View v) {
     const int t = TID1, a = t >> 2, l = t & 3;
+    tick_begin(v.ticks, TK_GRADFINAL);
     double g = 0.0;
     if (a < v.nAC) {
         const int cell = v.act[a];
@@ -223,6 +340,7 @@ __global__ void k_gradfinal(View v) {
     // lanes 4a .. 4a+3 are neighbours in a wave (the grid is a multiple of 64 threads)
     const double g1 = __shfl_down(g, 1, 4), g2 = __shfl_down(g, 2, 4), g3 = __shfl_down(g, 3, 4);
     if (a < v.nAC && l == 0) v.grad[a] = exp(v.m[a]) * (((g + g1) + g2) + g3);
+    tick_end(v.ticks, TK_GRADFINAL);
 }
 
 // copy padded nodal layout -> reference layout [(ny+1)*(nz+1)] per frequency
@@ -245,12 +363,14 @@ struct LfView {
     double *part;                 // [LFNB] partial maxima / sums
     double *scal;                 // [0] mnorm
     int* flag;                    // non-zero: non-finite value met
+    long long* ticks;             // HMCMT_TICKS
 };
 constexpr int LFNB = 64;
 
 // g <- g + lambda*Wm*(m - mref) ; p <- p - c*dt*g      (HMCSampler.jl:223-228, 255-263)
 __global__ void k_lf_momentum(LfView L, double lambda, double cdt) {
     const int a = TID1;
+    tick_begin(L.ticks, TK_LF_MOM);
     if (a >= L.n) return;
     double acc = 0.0;
     for (long long t = L.wmRow[a]; t < L.wmRow[a + 1]; ++t) {
@@ -259,10 +379,12 @@ __global__ void k_lf_momentum(LfView L, double lambda, double cdt) {
     }
     const double g = L.g[a] + lambda * acc;       // L.g stays the data gradient (hmcmt_leapfrog memoises it)
     L.p[a] -= cdt * g;
+    tick_end(L.ticks, TK_LF_MOM);
 }
 // partial max |dt*invM*p|   (HMCSampler.jl:237-240)
 __global__ __launch_bounds__(256) void k_lf_dmmax(LfView L, double dt) {
     __shared__ double sh[4];
+    tick_begin(L.ticks, TK_LF_MAX);
     double mx = 0.0;
     for (int a = blockIdx.x * 256 + threadIdx.x; a < L.n; a += 256 * LFNB) mx = fmax(mx, fabs(dt * L.invM[a] * L.p[a]));
 #pragma unroll
@@ -270,10 +392,12 @@ __global__ __launch_bounds__(256) void k_lf_dmmax(LfView L, double dt) {
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
     __syncthreads();
     if (threadIdx.x == 0) L.part[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+    tick_end(L.ticks, TK_LF_MAX);
 }
 // m += dm (clamped to max |dm| = 3), reflect at the ln-sigma bounds, flip momentum (:241-247, :515-559)
 __global__ void k_lf_step(LfView L, double dt, double lo, double hi) {
     const int a = TID1;
+    tick_begin(L.ticks, TK_LF_STEP);
     if (a >= L.n) return;
     double mx = 0.0;
     for (int b = 0; b < LFNB; ++b) mx = fmax(mx, L.part[b]);
@@ -286,6 +410,7 @@ __global__ void k_lf_step(LfView L, double dt, double lo, double hi) {
         if (m > hi) { m = 2.0 * hi - m; p = -p; }
     }
     L.m[a] = m; L.p[a] = p;
+    tick_end(L.ticks, TK_LF_STEP);
 }
 // mnorm = 0.5*lambda*(m-mref)' Wm (m-mref)   (HMCSampler.jl:389-391): partial sums, then block 0 finishes
 __global__ __launch_bounds__(256) void k_lf_mnorm(LfView L, double lambda) {
