@@ -255,6 +255,27 @@ def test_full_fields_adjoint_fields_and_per_system_terms():
             assert shallow < GRAD_TOL and deep < GRAD_DEEP_TOL, (md, f, shallow, deep)
 
 
+@pytest.mark.parametrize("columns", ["0", "2", "16"])
+def test_boundary_fields_by_every_kernel_form(columns, monkeypatch):
+    """The Dirichlet values of tiny.npz through the two-kernel form (HMCMT_BC_FUSED=0: k_bc_layers + k_bc_forward) and
+    through k_bc_fused with 2 and with 16 boundary columns per workgroup -- 16 puts both edge columns of the 13-column
+    mesh into one workgroup (its two-slot case), which the column count chosen for real meshes never does."""
+    monkeypatch.setenv("HMCMT_BC_FUSED", columns)
+    g = np.load(os.path.join(GOLDEN, "tiny.npz"))
+    mesh, data, inv, m = make_problem("tiny")
+    ny, nz = mesh.gridSize
+    ctx = HipContext(mesh, data, inv)
+    ctx.grad(m)
+    ex, hx = ctx.fields()
+    from oracle import hmcmt_oracle as O
+    ii, io = O.getBoundaryIndex(ny, nz)
+    for got, ref, md in ((ex, g["exTE"], "TE"), (hx, g["hxTM"], "TM")):
+        for f in range(len(data.freqs)):
+            sc = np.abs(ref[:, f]).max()
+            assert np.abs(got[io, f] - g[f"{md}{f}_bc"]).max() < 1e-10 * sc
+    ctx.close()
+
+
 def test_rho_phase_data_type():
     """DataType Rho_Pha (apparent resistivity + phase in degrees, both polarisations, a tenth of the data masked out;
     SURVEY 8(f)4): predicted data, misfit and gradient against the oracle and its golden; then the TE-only subset
