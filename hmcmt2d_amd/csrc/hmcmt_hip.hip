@@ -78,6 +78,7 @@ struct hmcmt_ctx {
     cplx* d_b = nullptr;                  // copy of the right-hand side (verify)
     int dbgFlags = 0;                     // hmcmt_debug_flags
     double hostUs[4] = {0, 0, 0, 0}; long hostN = 0;      // HMCMT_TICKS: host time of the launch sequences around the solves
+    int residThreads = 256;               // k_resid_pre
     bool wantTicks = false;               // HMCMT_TICKS: in-kernel wall-clock stamps (View::ticks), printed at destroy
     int bcCW = 0, bcSlots = 1;            // k_bc_fused: boundary columns per workgroup (0: k_bc_layers + k_bc_forward), edge slots
     size_t bcLds = 0;
@@ -625,6 +626,16 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
     return 0;
 }
 
+// residual + first pre-smoothing pass of a solve (k_resid_pre); threads by tile size like the stencil kernels of the iteration
+// (HMCMT_RESID = 256 / 512 / 1024)
+void launch_resid_pre(hmcmt_ctx* ctx, size_t lds, const cplx* x, int zero_r) {
+    const Solver& k = ctx->sv;
+    const dim3 grid(k.NTR, k.S);
+    if (ctx->residThreads == 1024) hipLaunchKernelGGL(k_resid_pre<1024>, grid, dim3(1024), lds, ctx->stream, k, x, k.r, k.r2, zero_r, ctx->v.sysOn);
+    else if (ctx->residThreads == 512) hipLaunchKernelGGL(k_resid_pre<512>, grid, dim3(512), lds, ctx->stream, k, x, k.r, k.r2, zero_r, ctx->v.sysOn);
+    else hipLaunchKernelGGL(k_resid_pre<256>, grid, dim3(256), lds, ctx->stream, k, x, k.r, k.r2, zero_r, ctx->v.sysOn);
+}
+
 // weights of the initial-guess extrapolation for solve kind kd (side stream): partial sums, weights, history shift
 void launch_extrap_weights(hmcmt_ctx* ctx, const double* d_m, int kd, hipStream_t sp) {
     hipLaunchKernelGGL(k_extrap_prepare, dim3(EXT_NBLK), dim3(256), 0, sp, d_m, ctx->d_mHist[kd], ctx->v.nAC, ctx->d_ext[kd],
@@ -761,7 +772,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         HIPCHK(hipStreamWaitEvent(st, ctx->evCoef, 0));
         // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X
         if (fusedStart) {
-            hipLaunchKernelGGL(k_resid_pre, dim3(ctx->sv.NTR, S), dim3(VBLOCK), startLds, st, ctx->sv, v.X, ctx->sv.r, ctx->sv.r2, 1, ctx->v.sysOn);
+            launch_resid_pre(ctx, startLds, v.X, 1);
             std::swap(ctx->sv.r, ctx->sv.r2);             // (the residual went to the second buffer; swapped back after the solve)
             ctx->solveBegun = ctx->preDone = true;
         } else {
@@ -806,7 +817,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             hipLaunchKernelGGL(k_src, dim3(nsrc + (v.ny + 127) / 128, S), dim3(128), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit, nsrc);
             if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtA, 0));
             if (warmA && fusedStart) {
-                hipLaunchKernelGGL(k_resid_pre, dim3(ctx->sv.NTR, S), dim3(VBLOCK), startLds, st, ctx->sv, v.Lam, ctx->sv.r, ctx->sv.r2, 0, ctx->v.sysOn);
+                launch_resid_pre(ctx, startLds, v.Lam, 0);
                 std::swap(ctx->sv.r, ctx->sv.r2);
                 ctx->solveBegun = ctx->preDone = true;
             } else if (warmA) {
@@ -1080,7 +1091,8 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         for (const void* f : {reinterpret_cast<const void*>(k_spmv_fused<1, 256>), reinterpret_cast<const void*>(k_spmv_fused<1, 512>), reinterpret_cast<const void*>(k_spmv_fused<1, 1024>),
                               reinterpret_cast<const void*>(k_spmv_fused<2, 256>), reinterpret_cast<const void*>(k_spmv_fused<2, 512>), reinterpret_cast<const void*>(k_spmv_fused<2, 1024>)})
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_resid_pre), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
+        for (const void* f : {reinterpret_cast<const void*>(k_resid_pre<256>), reinterpret_cast<const void*>(k_resid_pre<512>), reinterpret_cast<const void*>(k_resid_pre<1024>)})
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
     }
     HIPCHK(hipEventCreateWithFlags(&ctx->evExtA, evDev));
     const HostProblem& h = ctx->hp;
@@ -1193,6 +1205,8 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     // so small tiles keep the round-2 shapes.
     const int tileNodes = (k.RT + 2) * k.NYP, tile2Nodes = (2 * k.RT + 4) * k.NYP;
     ctx->spmvThreads = ctx->upd1Threads = tileNodes >= 1280 ? 512 : 256;     // (cfg3 1872, cfg5 2912 | dprism3d 560, cfg2 256)
+    ctx->residThreads = tileNodes >= 1280 ? 512 : 256;        // (k_resid_pre at the headline size: 16.9 / 13.8 / 18.6 us with 256 / 512 / 1024)
+    if (const char* er = getenv("HMCMT_RESID")) { const int t = atoi(er); if (t == 256 || t == 512 || t == 1024) ctx->residThreads = t; }
     ctx->upd2Threads = 256; ctx->upd2Batch = 6;
     if (tile2Nodes >= 2560 && k.NYP <= 256 &&                               // (cfg3 3744 | dprism3d 1120; cfg5: 52.7 vs 51.8 steps/s with the taller tiles)
         (size_t)(3 * 2 * k.RT + 8) * k.NYP * sizeof(float2) <= (size_t)150 * 1024) { ctx->upd2Threads = 512; ctx->upd2Batch = 8; k.RT2 = 2 * k.RT; }

@@ -575,12 +575,39 @@ __global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r
     const cplx* u = x + so;
     cplx* r = k.r + so;
     const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
-    for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
-        const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
-        cplx out = cplx{0, 0};
-        if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1)
-            out = (zero_r ? cplx{0, 0} : r[e]) - stencil_at(k, u, mo, e, w);
-        r[e] = out;
+    // RB nodes per thread and pass with every operand requested up front, at clamped addresses (inside `if (interior)` the
+    // compiler keeps a load next to its use: one memory round trip per node and thread, lesson (4) of DESIGN.md section 5)
+    constexpr int RB = 4;
+    for (long eb = e0 + threadIdx.x; eb < e1; eb += (long)RB * VBLOCK) {
+        double dk[RB], dm[RB], cy0[RB], cy1[RB], cz0[RB], cz1[RB];
+        cplx uc[RB], ue[RB], uw[RB], us[RB], un[RB], bv[RB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const long e = min(eb + (long)b * VBLOCK, e1 - 1);
+            const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+            const long ec = (long)min(max(iz, 1), k.nz - 1) * k.NYP + min(max(iy, 1), k.ny - 1);
+            dk[b] = k.dK[mo + ec]; dm[b] = k.dM[mo + ec];
+            cy0[b] = k.cY[mo + ec]; cy1[b] = k.cY[mo + ec - 1]; cz0[b] = k.cZ[mo + ec]; cz1[b] = k.cZ[mo + ec - k.NYP];
+            uc[b] = u[ec]; ue[b] = u[ec + 1]; uw[b] = u[ec - 1]; us[b] = u[ec + k.NYP]; un[b] = u[ec - k.NYP];
+            bv[b] = zero_r ? cplx{0, 0} : r[ec];
+        }
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const long e = eb + (long)b * VBLOCK;
+            if (e >= e1) continue;
+            const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
+            cplx out = cplx{0, 0};
+            if (iz >= 1 && iz <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+                const double dmw = w * dm[b];
+                cplx acc = cplx{dk[b] * uc[b].re - dmw * uc[b].im, dk[b] * uc[b].im + dmw * uc[b].re};
+                acc += cy0[b] * ue[b];
+                acc += cy1[b] * uw[b];
+                acc += cz0[b] * us[b];
+                acc += cz1[b] * un[b];
+                out = bv[b] - acc;
+            }
+            r[e] = out;
+        }
     }
 }
 
@@ -590,13 +617,14 @@ __global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r
 // so the residual is not re-read by a second kernel and one launch disappears in front of each solve.  The residual is
 // written to a SECOND buffer (rout): the halo rows' b are read from rin while the neighbouring workgroups write theirs.
 // Workgroup (0,0) also does k_solve_begin's bookkeeping.
-__global__ __launch_bounds__(VBLOCK) void k_resid_pre(Solver k, const cplx* x, const cplx* rin, cplx* rout, int zero_r,
+template <int NT>              // threads: one workgroup per CU at the headline size, so 512-1024 (16 waves) hide what 256 cannot
+__global__ __launch_bounds__(NT) void k_resid_pre(Solver k, const cplx* x, const cplx* rin, cplx* rout, int zero_r,
                                                       const int* __restrict__ sysOn) {
     const int s = blockIdx.y;
     tick_begin(k.ticks, zero_r ? TK_RESID_F : TK_RESID_A);
     if (blockIdx.x == 0 && blockIdx.y == 0) {
-        for (int t = threadIdx.x; t < k.S * MAXNB; t += VBLOCK) k.partB[t] = 0.0;
-        for (int t = threadIdx.x; t < k.S; t += VBLOCK) { k.active[t] = sysOn[t]; k.iters[t] = 0; k.status[t] = 0; }
+        for (int t = threadIdx.x; t < k.S * MAXNB; t += NT) k.partB[t] = 0.0;
+        for (int t = threadIdx.x; t < k.S; t += NT) { k.active[t] = sysOn[t]; k.iters[t] = 0; k.status[t] = 0; }
         if (threadIdx.x == 0) {
             int n = 0;
             for (int q = 0; q < k.S; ++q) n += sysOn[q];
@@ -613,62 +641,99 @@ __global__ __launch_bounds__(VBLOCK) void k_resid_pre(Solver k, const cplx* x, c
     const double w = k.omega[s];
     const float rNYP = 1.0f / (float)NYP;
     const cplx* u = x + so;
-    for (int i = threadIdx.x; i < (nown + 4) * NYP; i += VBLOCK) {
+    for (int i = threadIdx.x; i < (nown + 4) * NYP; i += NT) {
         const int lr = div_small(i, rNYP), g = iz0 - 2 + lr;
         xs[i] = (g >= 0 && g <= k.nz) ? u[(long)g * NYP + (i - lr * NYP)] : cplx{0, 0};
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (nown + 2) * NYP; i += VBLOCK) {
-        const int lr = div_small(i, rNYP), iy = i - lr * NYP, g = iz0 - 1 + lr;
-        const long e = (long)g * NYP + iy;
-        cplx out = cplx{0, 0};
-        if (g >= 1 && g <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
-            const int l = i + NYP;                         // the same node in xs (one more halo row in front)
-            const cplx c = xs[l];
-            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
-            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
-            acc += k.cY[mo + e] * xs[l + 1];
-            acc += k.cY[mo + e - 1] * xs[l - 1];
-            acc += k.cZ[mo + e] * xs[l + NYP];
-            acc += k.cZ[mo + e - NYP] * xs[l - NYP];
-            out = (zero_r ? cplx{0, 0} : rin[so + e]) - acc;
+    constexpr int RB = 4;             // nodes per thread and pass, operands requested up front at clamped addresses (as k_resid0)
+    const int n2 = (nown + 2) * NYP;
+    for (int ib = threadIdx.x; ib < n2; ib += RB * NT) {
+        double dk[RB], dm[RB], cy0[RB], cy1[RB], cz0[RB], cz1[RB];
+        cplx bv[RB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int i = min(ib + b * NT, n2 - 1);
+            const int lr = div_small(i, rNYP), iy = i - lr * NYP, g = iz0 - 1 + lr;
+            const long ec = (long)min(max(g, 1), k.nz - 1) * NYP + min(max(iy, 1), k.ny - 1);
+            dk[b] = k.dK[mo + ec]; dm[b] = k.dM[mo + ec];
+            cy0[b] = k.cY[mo + ec]; cy1[b] = k.cY[mo + ec - 1]; cz0[b] = k.cZ[mo + ec]; cz1[b] = k.cZ[mo + ec - NYP];
+            bv[b] = zero_r ? cplx{0, 0} : rin[so + ec];
         }
-        rs[i] = out;
-        if (lr >= 1 && lr <= nown) rout[so + e] = out;
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int i = ib + b * NT;
+            if (i >= n2) continue;
+            const int lr = div_small(i, rNYP), iy = i - lr * NYP, g = iz0 - 1 + lr;
+            const long e = (long)g * NYP + iy;
+            cplx out = cplx{0, 0};
+            if (g >= 1 && g <= k.nz - 1 && iy >= 1 && iy <= k.ny - 1) {
+                const int l = i + NYP;                         // the same node in xs (one more halo row in front)
+                const cplx c = xs[l];
+                const double dmw = w * dm[b];
+                cplx acc = cplx{dk[b] * c.re - dmw * c.im, dk[b] * c.im + dmw * c.re};
+                acc += cy0[b] * xs[l + 1];
+                acc += cy1[b] * xs[l - 1];
+                acc += cz0[b] * xs[l + NYP];
+                acc += cz1[b] * xs[l - NYP];
+                out = bv[b] - acc;
+            }
+            rs[i] = out;
+            if (lr >= 1 && lr <= nown) rout[so + e] = out;
+        }
     }
     // the two boundary rows of r and of t (zeros)
     if (blockIdx.x == 0 || iz1 == k.nz - 1) {
         const int row = blockIdx.x == 0 ? 0 : k.nz;
-        for (int iy = threadIdx.x; iy < NYP; iy += VBLOCK) {
+        for (int iy = threadIdx.x; iy < NYP; iy += NT) {
             rout[so + (long)row * NYP + iy] = cplx{0, 0};
             store_t32(k, k.t32 + so, row, iy, 0.f, 0.f);
         }
         if (blockIdx.x == 0 && iz1 == k.nz - 1)            // (a single tile: both rows)
-            for (int iy = threadIdx.x; iy < NYP; iy += VBLOCK) {
+            for (int iy = threadIdx.x; iy < NYP; iy += NT) {
                 rout[so + (long)k.nz * NYP + iy] = cplx{0, 0};
                 store_t32(k, k.t32 + so, k.nz, iy, 0.f, 0.f);
             }
     }
     __syncthreads();
-    const cplx* di = k.dinv + so;
-    for (int i = threadIdx.x; i < (nown + 2) * NYP; i += VBLOCK) xs[i] = di[(long)(iz0 - 1) * NYP + i] * rs[i];
+    // t = r - A (dinv r) with the smoother's operands as every later application of this solve reads them (k_update_fused<1>):
+    // the complex64 Jacobi diagonal and the packed float coefficients (Solver::cf32), two 16-byte loads per node
+    const float2* di = k.dinv32 + so;
+    for (int i = threadIdx.x; i < n2; i += NT) {
+        const float2 d = di[(long)(iz0 - 1) * NYP + i];
+        xs[i] = cplx{(double)d.x, (double)d.y} * rs[i];
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < nown * NYP; i += VBLOCK) {
-        const int lr = div_small(i, rNYP), iy = i - lr * NYP;
-        const long e = (long)(iz0 + lr) * NYP + iy;
-        cplx out = cplx{0, 0};
-        if (iy >= 1 && iy <= k.ny - 1) {
-            const int l = i + NYP;
-            const cplx c = xs[l];
-            const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
-            cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
-            acc += k.cY[mo + e] * xs[l + 1];
-            acc += k.cY[mo + e - 1] * xs[l - 1];
-            acc += k.cZ[mo + e] * xs[l + NYP];
-            acc += k.cZ[mo + e - NYP] * xs[l - NYP];
-            out = rs[l] - acc;
+    const float4* cfm = k.cf32 + 2 * mo;
+    const int n4 = nown * NYP;
+    for (int ib = threadIdx.x; ib < n4; ib += RB * NT) {
+        float4 ca[RB], cb[RB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int i = min(ib + b * NT, n4 - 1);
+            const int lr = div_small(i, rNYP), iy = i - lr * NYP;
+            const long ec = (long)(iz0 + lr) * NYP + min(max(iy, 1), k.ny - 1);
+            ca[b] = cfm[2 * ec]; cb[b] = cfm[2 * ec + 1];
         }
-        store_t32(k, k.t32 + so, iz0 + lr, iy, (float)out.re, (float)out.im);
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int i = ib + b * NT;
+            if (i >= n4) continue;
+            const int lr = div_small(i, rNYP), iy = i - lr * NYP;
+            cplx out = cplx{0, 0};
+            if (iy >= 1 && iy <= k.ny - 1) {
+                const int l = i + NYP;
+                const cplx c = xs[l];
+                const double dk = ca[b].x, dm = w * (double)ca[b].y;
+                cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
+                acc += (double)ca[b].z * xs[l + 1];
+                acc += (double)ca[b].w * xs[l - 1];
+                acc += (double)cb[b].x * xs[l + NYP];
+                acc += (double)cb[b].y * xs[l - NYP];
+                out = rs[l] - acc;
+            }
+            store_t32(k, k.t32 + so, iz0 + lr, iy, (float)out.re, (float)out.im);
+        }
     }
     tick_end(k.ticks, zero_r ? TK_RESID_F : TK_RESID_A);
 }
