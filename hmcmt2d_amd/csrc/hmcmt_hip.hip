@@ -717,7 +717,11 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             HIPCHK(hipMemsetAsync(v.Lam, 0, vecBytes, st));
             HIPCHK(hipMemsetAsync(ctx->d_ext[1], 0, EXT_PART * sizeof(double), st));
         }
-        hipStream_t sA = ctx->side, sB = ctx->side2;
+        // The coefficients run on the MAIN stream behind the boundary fields (HMCMT_COEF_MAIN=0: on the second side stream, as
+        // until round 3): alone they take 10 us instead of 20 beside k_bc_fused, and three API calls (wait, record, wait) leave
+        // the host's sequence in front of the residual: 860 -> 870 steps/s on the straight-line trajectories, +0.5 % elsewhere.
+        static const bool coefMain = !(getenv("HMCMT_COEF_MAIN") && getenv("HMCMT_COEF_MAIN")[0] == '0');
+        hipStream_t sA = ctx->side, sB = coefMain ? st : ctx->side2;
         if (rows) hipLaunchKernelGGL(k_sigma_rows, dim3(v.nz), dim3(64), 0, st, v);
         else hipLaunchKernelGGL(k_sigma, grid1(v.nCell, 256), dim3(256), 0, st, v);
         HIPCHK(hipEventRecord(ctx->evModel, st));
@@ -748,15 +752,15 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
                 hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, sp, v);
             return hipEventRecord(ctx->evPiv, sp);
         };
+        if (extrap || coefMain) HIPCHK(hipStreamWaitEvent(sA, ctx->evModel, 0));
         if (extrap) {
             // (interior nodes only -- the boundary-value kernel owns the boundary nodes of X)
-            HIPCHK(hipStreamWaitEvent(sA, ctx->evModel, 0));
             launch_extrap_weights(ctx, d_m, 0, sA);
             hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, sA, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
             HIPCHK(hipEventRecord(ctx->evExtF, sA));
-            HIPCHK(issue_pivot(sA));
         }
-        HIPCHK(hipStreamWaitEvent(sB, ctx->evModel, 0));
+        if (extrap || coefMain) HIPCHK(issue_pivot(sA));
+        if (!coefMain) HIPCHK(hipStreamWaitEvent(sB, ctx->evModel, 0));
         if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && !getenv("HMCMT_NO_COEF_ALL")) {
             hipLaunchKernelGGL(k_coef_all, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, sB, v, ctx->sv, ctx->jacobiW, const_cast<float4*>(ctx->sv.cf32));
         } else {
@@ -766,10 +770,10 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
                 hipLaunchKernelGGL(k_coef32, dim3(ctx->sv.NB, 2), dim3(VBLOCK), 0, sB, ctx->sv, const_cast<float4*>(ctx->sv.cf32));
             }
         }
-        HIPCHK(hipEventRecord(ctx->evCoef, sB));
-        if (!extrap) HIPCHK(issue_pivot(sB));
+        if (!coefMain) HIPCHK(hipEventRecord(ctx->evCoef, sB));
+        if (!extrap && !coefMain) HIPCHK(issue_pivot(sB));
         if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtF, 0));
-        HIPCHK(hipStreamWaitEvent(st, ctx->evCoef, 0));
+        if (!coefMain) HIPCHK(hipStreamWaitEvent(st, ctx->evCoef, 0));
         // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X
         if (fusedStart) {
             launch_resid_pre(ctx, startLds, v.X, 1);
