@@ -473,7 +473,17 @@ int pick_sweeps(const hmcmt_ctx* ctx, int kind) {
 }
 
 // Solves A x = r for all systems (x zero on interior on entry; r destroyed).  kind 0 forward, 1 adjoint.
-int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
+void launch_solve_end(hmcmt_ctx* ctx, int kind) {
+    const int S = ctx->sv.S;
+    hipLaunchKernelGGL(k_solve_end, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, ctx->sv, kind, (int*)ctx->d_recHost, ctx->d_recHost + 2 * S);
+}
+SolveRec solve_rec(hmcmt_ctx* ctx, int kind) {
+    const Solver& k = ctx->sv;
+    return SolveRec{k.iters, k.status, k.errEst, (int*)ctx->d_recHost, ctx->d_recHost + 2 * k.S, kind, k.S};
+}
+
+// deferEnd: the caller's next kernel writes the per-solve records (k_rxall / k_wb with solve_rec) instead of k_solve_end
+int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
     Solver& k = ctx->sv;
     const View& v = ctx->v;
     k.x = x;
@@ -609,7 +619,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind) {
 
     ctx->solveDone[kind] = done;
     // iteration counts / status / error estimates stay on the device; evaluate() reads both solves back at once
-    hipLaunchKernelGGL(k_solve_end, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, k, kind, (int*)ctx->d_recHost, ctx->d_recHost + 2 * S);
+    if (!deferEnd) launch_solve_end(ctx, kind);
     if (ctx->opt.verify) {
         hipLaunchKernelGGL(k_trueres, vg, vb, 0, ctx->stream, k, ctx->d_b, x, ctx->d_partRes, ctx->d_partBn);
         std::vector<double> pr((size_t)S * MAXNB), pb((size_t)S * MAXNB);
@@ -790,12 +800,12 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         ctx->sideView = v; ctx->sideM = d_m; ctx->sideExtrap = extrap && wantGrad; ctx->sideSens = wantGrad;
         ctx->sidePending = wantGrad;
     }
-    int rc = solve(ctx, v.X, 0);
+    int rc = solve(ctx, v.X, 0, true);
     if (fusedStart) std::swap(ctx->sv.r, ctx->sv.r2);
     fusedStart = fusedStartOk && sweepsA == 1;
     ctx->sv.sweeps = sweepsA;
-    if (!wantGrad) HIPCHK(hipEventRecord(ctx->evRec, st));          // behind the last k_solve_end
     if (rc == 0 && ctx->solveFail) {
+        launch_solve_end(ctx, 0);
         // the forward solve gave up (iteration cap / breakdown): no adjoint solve on its fields, no further leapfrog step on
         // its gradient -- the records of k_solve_end carry the status, the caller gets it now
         ctx->sidePending = false;
@@ -810,38 +820,47 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     if (rc) return rc;
     {
         ProfScope ps(ctx, 5);
-        hipLaunchKernelGGL(k_rxall, grid1(S * v.nRx, 64), dim3(64), 0, st, v, wantGrad ? 1 : 0);
-        if (!wantGrad) hipLaunchKernelGGL(k_misfit, dim3(1), dim3(256), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit);
+        hipLaunchKernelGGL(k_rxall, grid1(S * v.nRx, 64), dim3(64), 0, st, v, wantGrad ? 1 : 0, solve_rec(ctx, 0));     // (+ the forward solve's records)
+        if (!wantGrad) {
+            HIPCHK(hipEventRecord(ctx->evRec, st));      // behind the records of the last solve
+            hipLaunchKernelGGL(k_misfit, dim3(1), dim3(256), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit);
+        }
     }
     if (wantGrad) {
         {
             ProfScope ps(ctx, 5);
-            HIPCHK(hipMemsetAsync(v.R, 0, vecBytes, st));       // (k_src assigns the two receiver rows and all of srcB)
+            // k_src assigns the two node rows of the receiver layer and all of srcB.  A warm adjoint start reads the right-hand
+            // side on those rows only (k_resid0 / k_resid_pre, zero_r = 2 + row); a cold one takes the buffer as its residual
+            static const bool denseSrc = getenv("HMCMT_DENSE_SRC") != nullptr;
+            const bool sparseSrc = warmA && !ctx->opt.verify && !denseSrc;
+            if (!sparseSrc) HIPCHK(hipMemsetAsync(v.R, 0, vecBytes, st));
             const int nsrc = (2 * (v.ny + 1) + 127) / 128;
             hipLaunchKernelGGL(k_src, dim3(nsrc + (v.ny + 127) / 128, S), dim3(128), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit, nsrc);
             if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtA, 0));
             if (warmA && fusedStart) {
-                launch_resid_pre(ctx, startLds, v.Lam, 0);
+                launch_resid_pre(ctx, startLds, v.Lam, sparseSrc ? 2 + v.zid : 0);
                 std::swap(ctx->sv.r, ctx->sv.r2);
                 ctx->solveBegun = ctx->preDone = true;
             } else if (warmA) {
-                hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, 0, ctx->v.sysOn);
+                hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, sparseSrc ? 2 + v.zid : 0, ctx->v.sysOn);
                 ctx->solveBegun = true;
             }
         }
         if (ctx->wantTicks) ctx->hostUs[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hostT1).count();
-        rc = solve(ctx, v.Lam, 1);
+        rc = solve(ctx, v.Lam, 1, true);
         const auto hostT2 = std::chrono::steady_clock::now();
         if (warmA && fusedStart) std::swap(ctx->sv.r, ctx->sv.r2);
-        HIPCHK(hipEventRecord(ctx->evRec, st));                        // behind the last k_solve_end
         ctx->haveAdj = (rc == 0 && ctx->solveDone[1]);
         if (rc) return rc;
         if (ctx->solveFail) {             // (as after the forward solve: no gradient from a failed adjoint, and the caller knows NOW)
+            launch_solve_end(ctx, 1);
+            HIPCHK(hipEventRecord(ctx->evRec, st));
             rc = collect_stats(ctx, true);
             return rc ? rc : finish_status(ctx);
         }
         ProfScope ps(ctx, 6);
-        hipLaunchKernelGGL(k_wb, dim3((v.nz + v.ny + 127) / 128, S), dim3(128), 0, st, v);
+        hipLaunchKernelGGL(k_wb, dim3((v.nz + v.ny + 127) / 128, S), dim3(128), 0, st, v, solve_rec(ctx, 1));      // (+ the adjoint solve's records)
+        HIPCHK(hipEventRecord(ctx->evRec, st));                        // behind the records of the last solve
         HIPCHK(hipStreamWaitEvent(st, ctx->evSens, 0));         // sensitivity tables, boundary values, dBC (side stream)
         hipLaunchKernelGGL(k_bcsens_contract, dim3((v.nz + 127) / 128, 2, S), dim3(128), 0, st, v);
         hipLaunchKernelGGL(k_gradcell, dim3((v.nCell + 127) / 128, 2, GRAD_NG), dim3(128), 0, st, v);

@@ -557,6 +557,10 @@ __global__ __launch_bounds__(NT) void k_update_fused(Solver k, const float2* pcu
 // (forward: Dirichlet values, so with r = 0 on entry this is the reference's rhs -Aio*bc minus Aii*x0)
 // sysOn != nullptr: workgroup (0,0) also does k_solve_begin's bookkeeping for the solve that follows (one launch less
 // on the critical path in front of each solve)
+// zero_r: 0 the right-hand side is read from r at every node; 1 it is zero (the forward problem: the sources are the Dirichlet
+// values in x); 2 + row: it is read on node rows row, row + 1 only and zero elsewhere -- the adjoint sources live on the two
+// node rows of the receiver layer (item_src), so the buffer need not be cleared in front of k_src (a 11 MB fill and an API
+// call between the solves) nor read here outside those rows
 __global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r, const int* __restrict__ sysOn) {
     const int s = blockIdx.y;
     if (sysOn && blockIdx.x == 0 && blockIdx.y == 0) {
@@ -589,7 +593,8 @@ __global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r
             dk[b] = k.dK[mo + ec]; dm[b] = k.dM[mo + ec];
             cy0[b] = k.cY[mo + ec]; cy1[b] = k.cY[mo + ec - 1]; cz0[b] = k.cZ[mo + ec]; cz1[b] = k.cZ[mo + ec - k.NYP];
             uc[b] = u[ec]; ue[b] = u[ec + 1]; uw[b] = u[ec - 1]; us[b] = u[ec + k.NYP]; un[b] = u[ec - k.NYP];
-            bv[b] = zero_r ? cplx{0, 0} : r[ec];
+            const int izc = min(max(iz, 1), k.nz - 1);
+            bv[b] = (zero_r == 0 || (zero_r >= 2 && (unsigned)(izc - (zero_r - 2)) < 2u)) ? r[ec] : cplx{0, 0};
         }
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
@@ -621,7 +626,7 @@ template <int NT>              // threads: one workgroup per CU at the headline 
 __global__ __launch_bounds__(NT) void k_resid_pre(Solver k, const cplx* x, const cplx* rin, cplx* rout, int zero_r,
                                                       const int* __restrict__ sysOn) {
     const int s = blockIdx.y;
-    tick_begin(k.ticks, zero_r ? TK_RESID_F : TK_RESID_A);
+    tick_begin(k.ticks, zero_r == 1 ? TK_RESID_F : TK_RESID_A);
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         for (int t = threadIdx.x; t < k.S * MAXNB; t += NT) k.partB[t] = 0.0;
         for (int t = threadIdx.x; t < k.S; t += NT) { k.active[t] = sysOn[t]; k.iters[t] = 0; k.status[t] = 0; }
@@ -658,7 +663,8 @@ __global__ __launch_bounds__(NT) void k_resid_pre(Solver k, const cplx* x, const
             const long ec = (long)min(max(g, 1), k.nz - 1) * NYP + min(max(iy, 1), k.ny - 1);
             dk[b] = k.dK[mo + ec]; dm[b] = k.dM[mo + ec];
             cy0[b] = k.cY[mo + ec]; cy1[b] = k.cY[mo + ec - 1]; cz0[b] = k.cZ[mo + ec]; cz1[b] = k.cZ[mo + ec - NYP];
-            bv[b] = zero_r ? cplx{0, 0} : rin[so + ec];
+            const int gc = min(max(g, 1), k.nz - 1);
+            bv[b] = (zero_r == 0 || (zero_r >= 2 && (unsigned)(gc - (zero_r - 2)) < 2u)) ? rin[so + ec] : cplx{0, 0};
         }
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
@@ -735,7 +741,7 @@ __global__ __launch_bounds__(NT) void k_resid_pre(Solver k, const cplx* x, const
             store_t32(k, k.t32 + so, iz0 + lr, iy, (float)out.re, (float)out.im);
         }
     }
-    tick_end(k.ticks, zero_r ? TK_RESID_F : TK_RESID_A);
+    tick_end(k.ticks, zero_r == 1 ? TK_RESID_F : TK_RESID_A);
 }
 
 // start of a solve: every requested system active, records cleared (one launch instead of five copies/memsets)

@@ -254,9 +254,18 @@ __global__ void k_misfit(View v, double* out) {
 // the data that address this receiver and their sum of conj(W'W r) -- one launch instead of three in a row on the
 // critical path (a datum belongs to exactly one (system, receiver), so there is no cross-thread dependency; the
 // misfit itself, a reduction over all data, is not needed by the adjoint half and is summed after the sources).
-__global__ __launch_bounds__(64) void k_rxall(View v, int wantGrad) {        // (64: registers instead of 200 B of spills)
+// the per-solve records of k_solve_end, written by the first kernel behind a solve instead (one launch less on the critical
+// path behind each solve): iteration counts, status, error estimates -> mapped host memory
+struct SolveRec { const int* iters; const int* status; const double* errEst; int* recI; double* recE; int kind, S; };
+__device__ __forceinline__ void write_solve_rec(const SolveRec& r, int s) {
+    r.recI[r.kind * r.S + s] = r.iters[s];
+    r.recI[(2 + r.kind) * r.S + s] = r.status[s];
+    r.recE[r.kind * r.S + s] = r.errEst[s];
+}
+__global__ __launch_bounds__(64) void k_rxall(View v, int wantGrad, SolveRec rec) {        // (64: registers instead of 200 B of spills)
     const int e = TID1;
     tick_begin(v.ticks, TK_RXALL);
+    if (rec.recI && e < rec.S) write_solve_rec(rec, e);
     if (e >= v.S * v.nRx) return;
     const int s = e / v.nRx, r = e % v.nRx;
     item_rx(v, s, r, wantGrad != 0);
@@ -295,9 +304,10 @@ __global__ __launch_bounds__(128) void k_src(View v, double* misfitOut, int nsrc
     }
     tick_end(v.ticks, TK_SRC);
 }
-__global__ void k_wb(View v) {
+__global__ void k_wb(View v, SolveRec rec) {
     int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
     tick_begin(v.ticks, TK_WB);
+    if (rec.recI && e == 0) write_solve_rec(rec, s);
     if (e < v.nz) item_wside(v, s, e + 1);
     else if (e < v.nz + v.ny) item_colw(v, s, e - v.nz);
     tick_end(v.ticks, TK_WB);
