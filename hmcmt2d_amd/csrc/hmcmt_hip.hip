@@ -934,7 +934,9 @@ int finish_status(hmcmt_ctx* ctx);
 // (its first poll wants the iteration counts, and k_solve_end will overwrite the records) or by hmcmt_wait.
 int collect_pending(hmcmt_ctx* ctx) {
     if (!ctx->statsPending) return 0;
+    const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(hipEventSynchronize(ctx->evRec));
+    if (ctx->wantTicks) ctx->hostUs[3] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     parse_stats(ctx, ctx->pendingAdj);
     ctx->statsPending = false;
     return finish_status(ctx);
@@ -998,8 +1000,8 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
             }
         }
         if (ctx->hostN) fprintf(stderr, "HMCMT_TICKS: host time of the launch sequences, mean of %ld evaluations: k_sigma .. forward residual %.1f us, "
-                                "k_rxall .. adjoint residual %.1f us, gradient tail %.1f us\n", ctx->hostN, ctx->hostUs[0] / ctx->hostN,
-                                ctx->hostUs[1] / ctx->hostN, ctx->hostUs[2] / ctx->hostN);
+                                "k_rxall .. adjoint residual %.1f us, gradient tail %.1f us, wait for the previous evaluation's records %.1f us\n", ctx->hostN, ctx->hostUs[0] / ctx->hostN,
+                                ctx->hostUs[1] / ctx->hostN, ctx->hostUs[2] / ctx->hostN, ctx->hostUs[3] / ctx->hostN);
         hipFree(ctx->v.ticks);
     }
     if (ctx->sv.stamps) {                                // HMCMT_STAMPS: phase stamps of the last launch that wrote them
@@ -1839,9 +1841,9 @@ static int leapfrog_core(hmcmt_ctx* ctx, double* d_m, double* d_p, double dt, in
     }
     if (startGrad != 2) HIPCHK(hipMemcpyAsync(ctx->d_gStart, ctx->d_g, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
     ++evals;                                                 // counted as the reference counts it (hmcprior.nfevals, :217)
-    hipLaunchKernelGGL(k_lf_momentum, g1, b1, 0, st, lf, regParam, 0.5 * dt);
+    // (momentum update and the step bound of the position update behind it in one launch)
+    hipLaunchKernelGGL(k_lf_momentum_max, dim3(LFNB), dim3(256), 0, st, lf, regParam, 0.5 * dt, dt);
     for (int k = 1; k <= L; ++k) {
-        hipLaunchKernelGGL(k_lf_dmmax, dim3(LFNB), dim3(256), 0, st, lf, dt);
         hipLaunchKernelGGL(k_lf_step, g1, b1, 0, st, lf, dt, lnSigMin, lnSigMax);
         rc = evaluate(ctx, d_m, true, d_pred, d_misfit, ctx->d_g);      // (reports a failure of the step before)
         if (rc) return rc;
@@ -1849,7 +1851,7 @@ static int leapfrog_core(hmcmt_ctx* ctx, double* d_m, double* d_p, double dt, in
         ctx->statsPending = true;
         ctx->pendingAdj = true;
         ++evals;
-        hipLaunchKernelGGL(k_lf_momentum, g1, b1, 0, st, lf, regParam, (k < L ? 1.0 : 0.5) * dt);
+        hipLaunchKernelGGL(k_lf_momentum_max, dim3(LFNB), dim3(256), 0, st, lf, regParam, (k < L ? 1.0 : 0.5) * dt, dt);
     }
     if ((rc = collect_pending(ctx))) return rc;
     hipLaunchKernelGGL(k_lf_mnorm, dim3(LFNB), dim3(256), 0, st, lf, regParam);

@@ -378,31 +378,29 @@ struct LfView {
 constexpr int LFNB = 64;
 
 // g <- g + lambda*Wm*(m - mref) ; p <- p - c*dt*g      (HMCSampler.jl:223-228, 255-263)
-__global__ void k_lf_momentum(LfView L, double lambda, double cdt) {
-    const int a = TID1;
-    tick_begin(L.ticks, TK_LF_MOM);
-    if (a >= L.n) return;
-    double acc = 0.0;
-    for (long long t = L.wmRow[a]; t < L.wmRow[a + 1]; ++t) {
-        const long long j = L.wmCol[t];
-        acc += L.wmVal[t] * (L.m[j] - L.mref[j]);
-    }
-    const double g = L.g[a] + lambda * acc;       // L.g stays the data gradient (hmcmt_leapfrog memoises it)
-    L.p[a] -= cdt * g;
-    tick_end(L.ticks, TK_LF_MOM);
-}
-// partial max |dt*invM*p|   (HMCSampler.jl:237-240)
-__global__ __launch_bounds__(256) void k_lf_dmmax(LfView L, double dt) {
+// and the partial maxima of |dt*invM*p| (:237-240) for the position update that follows,
+// both in one launch (the leapfrog loop: momentum update, then the step bound of the position update that follows it)
+__global__ __launch_bounds__(256) void k_lf_momentum_max(LfView L, double lambda, double cdt, double dt) {
     __shared__ double sh[4];
-    tick_begin(L.ticks, TK_LF_MAX);
+    tick_begin(L.ticks, TK_LF_MOM);
     double mx = 0.0;
-    for (int a = blockIdx.x * 256 + threadIdx.x; a < L.n; a += 256 * LFNB) mx = fmax(mx, fabs(dt * L.invM[a] * L.p[a]));
+    for (int a = blockIdx.x * 256 + threadIdx.x; a < L.n; a += 256 * LFNB) {
+        double acc = 0.0;
+        for (long long t = L.wmRow[a]; t < L.wmRow[a + 1]; ++t) {
+            const long long j = L.wmCol[t];
+            acc += L.wmVal[t] * (L.m[j] - L.mref[j]);
+        }
+        const double g = L.g[a] + lambda * acc;
+        const double p = L.p[a] - cdt * g;
+        L.p[a] = p;
+        mx = fmax(mx, fabs(dt * L.invM[a] * p));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
     __syncthreads();
     if (threadIdx.x == 0) L.part[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
-    tick_end(L.ticks, TK_LF_MAX);
+    tick_end(L.ticks, TK_LF_MOM);
 }
 // m += dm (clamped to max |dm| = 3), reflect at the ln-sigma bounds, flip momentum (:241-247, :515-559)
 __global__ void k_lf_step(LfView L, double dt, double lo, double hi) {
