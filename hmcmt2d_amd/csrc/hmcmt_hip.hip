@@ -79,6 +79,7 @@ struct hmcmt_ctx {
     int dbgFlags = 0;                     // hmcmt_debug_flags
     double hostUs[4] = {0, 0, 0, 0}; long hostN = 0;      // HMCMT_TICKS: host time of the launch sequences around the solves
     int residThreads = 256;               // k_resid_pre
+    bool sensWaitPending = false;
     bool wantTicks = false;               // HMCMT_TICKS: in-kernel wall-clock stamps (View::ticks), printed at destroy
     int bcCW = 0, bcSlots = 1;            // k_bc_fused: boundary columns per workgroup (0: k_bc_layers + k_bc_forward), edge slots
     size_t bcLds = 0;
@@ -573,6 +574,10 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
             // wait for the adjoint guess.  Without a tracer attached 2..12 measure the same within 1 %; under
             // rocprofv3, whose launches cost twice as much, the early settings drain the main queue.)
             if (kind == 0 && it == sideIt) launch_adjoint_side(ctx);
+            // the gradient tail needs the sensitivity tables of the side stream (205 + 53 us of serial kernels beside the forward
+            // solve, long complete by the adjoint solve's 8th iteration): the wait goes into the queue HERE, where the host runs
+            // ahead of the device, not behind the solve, where the device waits for every call
+            if (kind == 1 && it == 8 && ctx->sensWaitPending) { ctx->sensWaitPending = false; HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evSens, 0)); }
         }
         if (!done) {
             // stragglers (or the iteration cap): read the counter once more, then hand over to the classic loop
@@ -846,6 +851,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
                 ctx->solveBegun = true;
             }
         }
+        ctx->sensWaitPending = true;     // (the wait for the side stream's sensitivity tables is issued from inside the adjoint solve)
         if (ctx->wantTicks) ctx->hostUs[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hostT1).count();
         rc = solve(ctx, v.Lam, 1, true);
         const auto hostT2 = std::chrono::steady_clock::now();
@@ -859,9 +865,9 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             return rc ? rc : finish_status(ctx);
         }
         ProfScope ps(ctx, 6);
+        if (ctx->sensWaitPending) { ctx->sensWaitPending = false; HIPCHK(hipStreamWaitEvent(st, ctx->evSens, 0)); }     // (a solve of fewer than 8 iterations)
         hipLaunchKernelGGL(k_wb, dim3((v.nz + v.ny + 127) / 128, S), dim3(128), 0, st, v, solve_rec(ctx, 1));      // (+ the adjoint solve's records)
         HIPCHK(hipEventRecord(ctx->evRec, st));                        // behind the records of the last solve
-        HIPCHK(hipStreamWaitEvent(st, ctx->evSens, 0));         // sensitivity tables, boundary values, dBC (side stream)
         hipLaunchKernelGGL(k_bcsens_contract, dim3((v.nz + 127) / 128, 2, S), dim3(128), 0, st, v);
         hipLaunchKernelGGL(k_gradcell, dim3((v.nCell + 127) / 128, 2, GRAD_NG), dim3(128), 0, st, v);
         hipLaunchKernelGGL(k_gradfinal, grid1(4 * v.nAC, 128), dim3(128), 0, st, v);
