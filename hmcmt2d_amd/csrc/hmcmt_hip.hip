@@ -79,6 +79,7 @@ struct hmcmt_ctx {
     int dbgFlags = 0;                     // hmcmt_debug_flags
     double hostUs[4] = {0, 0, 0, 0}; long hostN = 0;      // HMCMT_TICKS: host time of the launch sequences around the solves
     int residThreads = 256;               // k_resid_pre
+    LfStep lfStep{};                      // a position update of hmcmt_leapfrog* still to be performed (by k_sigma_rows, or k_lf_step in front of k_sigma)
     bool sensWaitPending = false;
     bool wantTicks = false;               // HMCMT_TICKS: in-kernel wall-clock stamps (View::ticks), printed at destroy
     int bcCW = 0, bcSlots = 1;            // k_bc_fused: boundary columns per workgroup (0: k_bc_layers + k_bc_forward), edge slots
@@ -737,8 +738,14 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         // the host's sequence in front of the residual: 860 -> 870 steps/s on the straight-line trajectories, +0.5 % elsewhere.
         static const bool coefMain = !(getenv("HMCMT_COEF_MAIN") && getenv("HMCMT_COEF_MAIN")[0] == '0');
         hipStream_t sA = ctx->side, sB = coefMain ? st : ctx->side2;
-        if (rows) hipLaunchKernelGGL(k_sigma_rows, dim3(v.nz), dim3(64), 0, st, v);
+        // (a position update of the device-resident leapfrog that is still due rides along: leapfrog_core)
+        if (ctx->lfStep.on && !(rows && ctx->lfStep.L.m == v.m)) {
+            hipLaunchKernelGGL(k_lf_step, dim3((ctx->lfStep.L.n + 127) / 128), dim3(128), 0, st, ctx->lfStep.L, ctx->lfStep.dt, ctx->lfStep.lo, ctx->lfStep.hi);
+            ctx->lfStep.on = 0;
+        }
+        if (rows) hipLaunchKernelGGL(k_sigma_rows, dim3(v.nz), dim3(64), 0, st, v, ctx->lfStep);
         else hipLaunchKernelGGL(k_sigma, grid1(v.nCell, 256), dim3(256), 0, st, v);
+        ctx->lfStep.on = 0;
         HIPCHK(hipEventRecord(ctx->evModel, st));
         // Three chains start from sigma and meet at the forward residual (round 3: 108 -> us between k_sigma and the first
         // iteration kernel near the true model):
@@ -1850,8 +1857,9 @@ static int leapfrog_core(hmcmt_ctx* ctx, double* d_m, double* d_p, double dt, in
     // (momentum update and the step bound of the position update behind it in one launch)
     hipLaunchKernelGGL(k_lf_momentum_max, dim3(LFNB), dim3(256), 0, st, lf, regParam, 0.5 * dt, dt);
     for (int k = 1; k <= L; ++k) {
-        hipLaunchKernelGGL(k_lf_step, g1, b1, 0, st, lf, dt, lnSigMin, lnSigMax);
+        ctx->lfStep = LfStep{1, lf, dt, lnSigMin, lnSigMax};            // (the position update: performed by the evaluation's first kernel)
         rc = evaluate(ctx, d_m, true, d_pred, d_misfit, ctx->d_g);      // (reports a failure of the step before)
+        ctx->lfStep.on = 0;
         if (rc) return rc;
         // asynchronous, as hmcmt_grad_device_async: the next step's launches overlap this step's gradient tail
         ctx->statsPending = true;

@@ -27,16 +27,51 @@ __global__ __launch_bounds__(64) void k_rowmean(View v) {
     sa = wave_sum(sa); sl = wave_sum(sl); sh = wave_sum(sh);
     if (threadIdx.x == 0) { v.sigMeanA[kz] = sa / v.ny; v.sigMeanG[kz] = (v.bgMean & 1) ? v.ny / sh : exp(sl / v.ny); }
 }
+struct LfView {
+    int n;
+    const double *mref, *invM, *wmVal;
+    const long long *wmRow, *wmCol;
+    double *m, *p, *g;            // model, momentum, data gradient (in) / total gradient (out)
+    double *part;                 // [LFNB] partial maxima / sums
+    double *scal;                 // [0] mnorm
+    int* flag;                    // non-zero: non-finite value met
+    long long* ticks;             // HMCMT_TICKS
+};
+constexpr int LFNB = 64;
+// m += dm (clamped to max |dm| = 3), reflect at the ln-sigma bounds, flip momentum (HMCSampler.jl:241-247, :515-559) for
+// parameter a; mx = the maximum of the partial step bounds.  Returns the new value (the old one on a non-finite step, flagged).
+__device__ __forceinline__ double lf_step_one(const LfView& L, int a, double dt, double lo, double hi, double mx) {
+    double dm = dt * L.invM[a] * L.p[a];
+    if (mx > 3.0) dm = dm / mx * 3.0;
+    double m = L.m[a] + dm, p = L.p[a];
+    if (!isfinite(m)) { atomicExch(L.flag, 1); return L.m[a]; }
+    for (int it = 0; it < 500 && !(m <= hi && m >= lo); ++it) {
+        if (m < lo) { m = 2.0 * lo - m; p = -p; }
+        if (m > hi) { m = 2.0 * hi - m; p = -p; }
+    }
+    L.m[a] = m; L.p[a] = p;
+    return m;
+}
+__device__ __forceinline__ double lf_step_bound(const LfView& L) {
+    double mx = 0.0;
+    for (int b = 0; b < LFNB; ++b) mx = fmax(mx, L.part[b]);
+    return mx;
+}
+// a position update that k_sigma_rows performs on its way (the device-resident leapfrog: one launch less per step)
+struct LfStep { int on; LfView L; double dt, lo, hi; };
 // k_sigma + k_rowmean: one wave per cell row computes the row's conductivities and, from the values it has just formed,
 // the lateral means (same summation order as k_rowmean) -- the FDM background (k_pivot) then needs nothing but this launch
-__global__ __launch_bounds__(64) void k_sigma_rows(View v) {
+__global__ __launch_bounds__(64) void k_sigma_rows(View v, LfStep step) {
     tick_begin(v.ticks, TK_SIGMA);
     const int kz = blockIdx.x;
+    const double mx = step.on ? lf_step_bound(step.L) : 0.0;
     double sa = 0.0, sl = 0.0, sh = 0.0;
     for (int ky = threadIdx.x; ky < v.ny; ky += 64) {
         const long cell = (long)kz * v.ny + ky;
         const int a = v.cell2act[cell];
-        const double s = v.bg[cell] + (a >= 0 ? exp(v.m[a]) : 0.0);
+        double ma = 0.0;
+        if (a >= 0) ma = step.on ? lf_step_one(step.L, a, step.dt, step.lo, step.hi, mx) : v.m[a];      // (every parameter is one cell's)
+        const double s = v.bg[cell] + (a >= 0 ? exp(ma) : 0.0);
         v.sigma[cell] = s;
         sa += s; sl += log(s); sh += 1.0 / s;
     }
@@ -365,17 +400,6 @@ __global__ void k_unpad(View v, const cplx* src, cplx* dst, int s0) {
 // ----------------------------------------------------------------------------------------------
 // leapfrog vector kernels (proposeLeapfrog, HMCSampler.jl:206-269; diagonal mass)
 // ----------------------------------------------------------------------------------------------
-struct LfView {
-    int n;
-    const double *mref, *invM, *wmVal;
-    const long long *wmRow, *wmCol;
-    double *m, *p, *g;            // model, momentum, data gradient (in) / total gradient (out)
-    double *part;                 // [LFNB] partial maxima / sums
-    double *scal;                 // [0] mnorm
-    int* flag;                    // non-zero: non-finite value met
-    long long* ticks;             // HMCMT_TICKS
-};
-constexpr int LFNB = 64;
 
 // g <- g + lambda*Wm*(m - mref) ; p <- p - c*dt*g      (HMCSampler.jl:223-228, 255-263)
 // and the partial maxima of |dt*invM*p| (:237-240) for the position update that follows,
@@ -407,17 +431,7 @@ __global__ void k_lf_step(LfView L, double dt, double lo, double hi) {
     const int a = TID1;
     tick_begin(L.ticks, TK_LF_STEP);
     if (a >= L.n) return;
-    double mx = 0.0;
-    for (int b = 0; b < LFNB; ++b) mx = fmax(mx, L.part[b]);
-    double dm = dt * L.invM[a] * L.p[a];
-    if (mx > 3.0) dm = dm / mx * 3.0;
-    double m = L.m[a] + dm, p = L.p[a];
-    if (!isfinite(m)) { atomicExch(L.flag, 1); return; }
-    for (int it = 0; it < 500 && !(m <= hi && m >= lo); ++it) {
-        if (m < lo) { m = 2.0 * lo - m; p = -p; }
-        if (m > hi) { m = 2.0 * hi - m; p = -p; }
-    }
-    L.m[a] = m; L.p[a] = p;
+    lf_step_one(L, a, dt, lo, hi, lf_step_bound(L));
     tick_end(L.ticks, TK_LF_STEP);
 }
 // mnorm = 0.5*lambda*(m-mref)' Wm (m-mref)   (HMCSampler.jl:389-391): partial sums, then block 0 finishes
