@@ -80,7 +80,7 @@ struct hmcmt_ctx {
     double hostUs[4] = {0, 0, 0, 0}; long hostN = 0;      // HMCMT_TICKS: host time of the launch sequences around the solves
     int residThreads = 256;               // k_resid_pre
     LfStep lfStep{};                      // a position update of hmcmt_leapfrog* still to be performed (by k_sigma_rows, or k_lf_step in front of k_sigma)
-    bool sensWaitPending = false;
+    bool sensWaitPending = false, extAWaitPending = false;
     bool wantTicks = false;               // HMCMT_TICKS: in-kernel wall-clock stamps (View::ticks), printed at destroy
     int bcCW = 0, bcSlots = 1;            // k_bc_fused: boundary columns per workgroup (0: k_bc_layers + k_bc_forward), edge slots
     size_t bcLds = 0;
@@ -575,6 +575,8 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
             // wait for the adjoint guess.  Without a tracer attached 2..12 measure the same within 1 %; under
             // rocprofv3, whose launches cost twice as much, the early settings drain the main queue.)
             if (kind == 0 && it == sideIt) launch_adjoint_side(ctx);
+            // (likewise the wait for the adjoint guess of the side stream, four iterations behind its launch)
+            if (kind == 0 && it == sideIt + 4 && ctx->extAWaitPending) { ctx->extAWaitPending = false; HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evExtA, 0)); }
             // the gradient tail needs the sensitivity tables of the side stream (205 + 53 us of serial kernels beside the forward
             // solve, long complete by the adjoint solve's 8th iteration): the wait goes into the queue HERE, where the host runs
             // ahead of the device, not behind the solve, where the device waits for every call
@@ -670,6 +672,7 @@ void launch_adjoint_side(hmcmt_ctx* ctx) {
         launch_extrap_weights(ctx, ctx->sideM, 1, ctx->side);
         hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, ctx->side, ctx->sv, v.Lam, ctx->d_prevField[1], ctx->d_ext[1]);
         hipEventRecord(ctx->evExtA, ctx->side);
+        ctx->extAWaitPending = true;
     }
     if (ctx->sideSens) {
         hipStreamWaitEvent(ctx->side, ctx->evPiv, 0);          // (the lateral means come from the second side stream)
@@ -848,7 +851,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             if (!sparseSrc) HIPCHK(hipMemsetAsync(v.R, 0, vecBytes, st));
             const int nsrc = (2 * (v.ny + 1) + 127) / 128;
             hipLaunchKernelGGL(k_src, dim3(nsrc + (v.ny + 127) / 128, S), dim3(128), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit, nsrc);
-            if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtA, 0));
+            if (ctx->extAWaitPending) { ctx->extAWaitPending = false; HIPCHK(hipStreamWaitEvent(st, ctx->evExtA, 0)); }   // (a forward solve too short to have issued it)
             if (warmA && fusedStart) {
                 launch_resid_pre(ctx, startLds, v.Lam, sparseSrc ? 2 + v.zid : 0);
                 std::swap(ctx->sv.r, ctx->sv.r2);
