@@ -321,17 +321,60 @@ __global__ __launch_bounds__(128) void k_src(View v, double* misfitOut, int nsrc
     // needs nothing from the adjoint solve: here they cost no launch in the gradient tail)
     const int s = blockIdx.y;
     tick_begin(v.ticks, TK_SRC);
+    // The system's receiver table in LDS: a node (item_src) / a cell column (item_qterm) asks every receiver whether it lies in
+    // the receiver's stencil -- from global memory a dependent load per receiver and thread (12 us for 40 receivers).
+    // Same terms in the same order as the item functions.
+    constexpr int SRC_RX = 256;
+    __shared__ int sN0[SRC_RX];
+    __shared__ cplx sCoef[SRC_RX];
+    const bool tab = v.nRx <= SRC_RX;
+    if (tab) {
+        for (int r = threadIdx.x; r < v.nRx; r += blockDim.x) { sN0[r] = v.rxN0[(long)s * v.nRx + r]; sCoef[r] = v.rxCoef[(long)s * v.nRx + r]; }
+        __syncthreads();
+    }
     if ((int)blockIdx.x >= nsrc) {
         const int ky = (blockIdx.x - nsrc) * blockDim.x + threadIdx.x;
-        if (ky < v.ny) item_qterm(v, s, ky);
+        if (ky < v.ny) {
+            if (!tab) item_qterm(v, s, ky);
+            else {
+                double g = 0.0;
+                if (v.sysOn[s])
+                    for (int r = 0; r < v.nRx; ++r) {
+                        const int o = ky - sN0[r];
+                        if (o >= 0 && o < 3) g += (sCoef[r] * v.rxD[((long)s * v.nRx + r) * 11 + 8 + o]).re;
+                    }
+                v.qPart[(long)s * v.ny + ky] = g;
+            }
+        }
         return;
     }
     int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < 2 * (v.ny + 1)) item_src(v, s, e / (v.ny + 1), e % (v.ny + 1));
+    if (e < 2 * (v.ny + 1)) {
+        if (!tab) item_src(v, s, e / (v.ny + 1), e % (v.ny + 1));
+        else {
+            const int row = e / (v.ny + 1), iy = e % (v.ny + 1), iz = v.zid + row;
+            cplx acc = cplx{0, 0};
+            for (int r = 0; r < v.nRx; ++r) {
+                const int o = iy - sN0[r];
+                if (o >= 0 && o < 4) acc += sCoef[r] * v.rxD[((long)s * v.nRx + r) * 11 + row * 4 + o];
+            }
+            const bool interior = iz >= 1 && iz <= v.nz - 1 && iy >= 1 && iy <= v.ny - 1;
+            if (interior) v.R[(long)s * v.vstride + nidx(v, iy, iz)] = acc;
+            else if (iy == 0) v.srcB[(long)s * 4 + row * 2 + 0] = acc;
+            else if (iy == v.ny) v.srcB[(long)s * 4 + row * 2 + 1] = acc;
+        }
+    }
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         __shared__ double sh[2];
         double a = 0;
-        for (int p = threadIdx.x; p < v.nData; p += 128) a += v.misfitPart[p];
+        // (eight terms requested per pass: one load per pass and thread made this block the kernel's last, 10 round trips in a row)
+        for (int p0 = threadIdx.x; p0 < v.nData; p0 += 8 * 128) {
+            double t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = v.misfitPart[min(p0 + q * 128, v.nData - 1)];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (p0 + q * 128 < v.nData) a += t[q];
+        }
         a = wave_sum(a);
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
         __syncthreads();
