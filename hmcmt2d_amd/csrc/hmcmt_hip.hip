@@ -81,6 +81,7 @@ struct hmcmt_ctx {
     int residThreads = 256;               // k_resid_pre
     LfStep lfStep{};                      // a position update of hmcmt_leapfrog* still to be performed (by k_sigma_rows, or k_lf_step in front of k_sigma)
     bool sensWaitPending = false, extAWaitPending = false;
+    bool noFusedStart = false, noSigmaRows = false, noCoefAll = false, denseSrc = false, coefMain = true;     // environment knobs read at creation
     bool wantTicks = false;               // HMCMT_TICKS: in-kernel wall-clock stamps (View::ticks), printed at destroy
     int bcCW = 0, bcSlots = 1;            // k_bc_fused: boundary columns per workgroup (0: k_bc_layers + k_bc_forward), edge slots
     size_t bcLds = 0;
@@ -712,7 +713,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     // start of a solve on the default path: residual and first pre-smoothing pass in one launch (k_resid_pre)
     const size_t startLds = (size_t)(2 * ctx->sv.RT + 6) * v.NYP * sizeof(cplx);
     const bool fusedStartOk = ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0 && !ctx->opt.verify &&
-                              startLds <= (size_t)150 * 1024 && !getenv("HMCMT_NO_FUSED_START");
+                              startLds <= (size_t)150 * 1024 && !ctx->noFusedStart;
     const int sweepsF = pick_sweeps(ctx, 0), sweepsA = pick_sweeps(ctx, 1);
     bool fusedStart = fusedStartOk && sweepsF == 1;      // (k_resid_pre does ONE pre-sweep; two go through k_resid0 + the solve's own start)
     ctx->sv.sweeps = sweepsF;
@@ -721,7 +722,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     {
         ProfScope ps(ctx, 4);
         // conductivities and their lateral means, one wave per cell row (meshes of whole rows: always; k_sigma + k_rowmean otherwise)
-        const bool rows = v.nCell == v.ny * v.nz && !getenv("HMCMT_NO_SIGMA_ROWS");
+        const bool rows = v.nCell == v.ny * v.nz && !ctx->noSigmaRows;
         const auto hostT0 = std::chrono::steady_clock::now();
         if (v.ticks) {                                   // HMCMT_TICKS: earliest starts <- max, latest ends <- 0
             HIPCHK(hipMemsetAsync(v.ticks, 0xff, 32 * sizeof(long long), st));
@@ -739,7 +740,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         // The coefficients run on the MAIN stream behind the boundary fields (HMCMT_COEF_MAIN=0: on the second side stream, as
         // until round 3): alone they take 10 us instead of 20 beside k_bc_fused, and three API calls (wait, record, wait) leave
         // the host's sequence in front of the residual: 860 -> 870 steps/s on the straight-line trajectories, +0.5 % elsewhere.
-        static const bool coefMain = !(getenv("HMCMT_COEF_MAIN") && getenv("HMCMT_COEF_MAIN")[0] == '0');
+        const bool coefMain = ctx->coefMain;
         hipStream_t sA = ctx->side, sB = coefMain ? st : ctx->side2;
         // (a position update of the device-resident leapfrog that is still due rides along: leapfrog_core)
         if (ctx->lfStep.on && !(rows && ctx->lfStep.L.m == v.m)) {
@@ -786,7 +787,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         }
         if (extrap || coefMain) HIPCHK(issue_pivot(sA));
         if (!coefMain) HIPCHK(hipStreamWaitEvent(sB, ctx->evModel, 0));
-        if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && !getenv("HMCMT_NO_COEF_ALL")) {
+        if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && !ctx->noCoefAll) {
             hipLaunchKernelGGL(k_coef_all, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, sB, v, ctx->sv, ctx->jacobiW, const_cast<float4*>(ctx->sv.cf32));
         } else {
             hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, sB, v, 0, 1, 1, 0);
@@ -846,8 +847,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             ProfScope ps(ctx, 5);
             // k_src assigns the two node rows of the receiver layer and all of srcB.  A warm adjoint start reads the right-hand
             // side on those rows only (k_resid0 / k_resid_pre, zero_r = 2 + row); a cold one takes the buffer as its residual
-            static const bool denseSrc = getenv("HMCMT_DENSE_SRC") != nullptr;
-            const bool sparseSrc = warmA && !ctx->opt.verify && !denseSrc;
+            const bool sparseSrc = warmA && !ctx->opt.verify && !ctx->denseSrc;
             if (!sparseSrc) HIPCHK(hipMemsetAsync(v.R, 0, vecBytes, st));
             const int nsrc = (2 * (v.ny + 1) + 127) / 128;
             hipLaunchKernelGGL(k_src, dim3(nsrc + (v.ny + 127) / 128, S), dim3(128), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit, nsrc);
@@ -1112,6 +1112,11 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
             }
         }
         ctx->wantTicks = getenv("HMCMT_TICKS") != nullptr;
+        ctx->noFusedStart = getenv("HMCMT_NO_FUSED_START") != nullptr;
+        ctx->noSigmaRows = getenv("HMCMT_NO_SIGMA_ROWS") != nullptr;
+        ctx->noCoefAll = getenv("HMCMT_NO_COEF_ALL") != nullptr;
+        ctx->denseSrc = getenv("HMCMT_DENSE_SRC") != nullptr;
+        ctx->coefMain = !(getenv("HMCMT_COEF_MAIN") && getenv("HMCMT_COEF_MAIN")[0] == '0');
         if (const char* ed = getenv("HMCMT_DEBUG_FLAGS")) ctx->dbgFlags = atoi(ed);                  // (measurement only: hmcmt_debug_flags)
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<FW_NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
