@@ -304,7 +304,7 @@ void launch_update2(hmcmt_ctx* ctx, const float2* pcur, const cplx* rin, cplx* r
 template <int SW>
 void launch_spmv(hmcmt_ctx* ctx, size_t lds, const float2* pin, float2* pout, int it) {
     const Solver& k = ctx->sv;
-    const dim3 grid = tile_grid(k, k.NTR);
+    const dim3 grid = tile_grid(k, SW == 2 ? (k.nz - 1 + k.RTS - 1) / k.RTS : k.NTR);
     if (ctx->spmvThreads == 512) hipLaunchKernelGGL((k_spmv_fused<SW, 512>), grid, dim3(512), lds, ctx->stream, k, ctx->d_partZZ, pin, pout, it, ctx->opt.maxit);
     else if (ctx->spmvThreads == 1024) hipLaunchKernelGGL((k_spmv_fused<SW, 1024>), grid, dim3(1024), lds, ctx->stream, k, ctx->d_partZZ, pin, pout, it, ctx->opt.maxit);
     else hipLaunchKernelGGL((k_spmv_fused<SW, 256>), grid, dim3(256), lds, ctx->stream, k, ctx->d_partZZ, pin, pout, it, ctx->opt.maxit);
@@ -312,7 +312,7 @@ void launch_spmv(hmcmt_ctx* ctx, size_t lds, const float2* pin, float2* pout, in
 // two sweeps per side exist on the fused mixed-precision path (and on the fp64 path of the restarts)
 bool sweeps2_ok(const hmcmt_ctx* ctx) {
     const Solver& k = ctx->sv;
-    const size_t spmv2 = (size_t)(k.RT + 2) * k.NYP * sizeof(cplx) + (size_t)(k.RT + 4) * k.NYP * sizeof(float2);
+    const size_t spmv2 = (size_t)(k.RTS + 2) * k.NYP * sizeof(cplx) + (size_t)(k.RTS + 4) * k.NYP * sizeof(float2);
     return ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI &&
            (ctx->opt.fdm_precision != 0 || (update2_lds(k) <= (size_t)150 * 1024 && spmv2 <= (size_t)150 * 1024 &&
                                             (k.merged2 || (fused_back_ok(ctx) && k.NTR <= k.NB))));
@@ -538,7 +538,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
             // decide convergence of the state after iteration it-1, p = z + beta p, q = A p
             if (k.sweeps == 2 && k.merged2) {
                 ProfScope ps(ctx, 2, true);
-                launch_spmv<2>(ctx, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx) + (size_t)(k.RT + 4) * k.NYP * sizeof(float2), pb[(it - 1) & 1], pb[it & 1], it);
+                launch_spmv<2>(ctx, (size_t)(k.RTS + 2) * k.NYP * sizeof(cplx) + (size_t)(k.RTS + 4) * k.NYP * sizeof(float2), pb[(it - 1) & 1], pb[it & 1], it);
             } else { ProfScope ps(ctx, 2, true); launch_spmv<1>(ctx, (size_t)(k.RT + 2) * k.NYP * sizeof(cplx), pb[(it - 1) & 1], pb[it & 1], it); }
             if (k.sweeps == 2) { ProfScope ps(ctx, 3, true); launch_update2(ctx, pb[it & 1], rb[rcur], rb[rcur ^ 1], it, 0); }
             else { ProfScope ps(ctx, 3, true); if (ctx->upd1Threads == 512) hipLaunchKernelGGL((k_update_fused<1, 512, 6>), tile_grid(k, k.NTR), dim3(512), (size_t)(2 * k.RT + 2) * k.NYP * sizeof(cplx), ctx->stream, k, pb[it & 1], rb[rcur], rb[rcur ^ 1], it, 0);
@@ -1240,6 +1240,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     }
     k.NTR = (h.nz - 1 + k.RT - 1) / k.RT;
     k.sweeps = 1;
+    k.RTS = k.RT;      // rows per tile of k_spmv_fused<2> (HMCMT_RTS; headline mesh, steps/s: 7 rows 328, 10 rows 311, 14 rows 325 -- it stays on the short tiles)
     k.RT2 = k.RT;      // rows per tile of k_update_fused<2> (>= RT: its partial sums fill the first slots of the k.NTR the consumers read); set with the launch shapes below
     // launch shapes of the two stencil kernels (launch_update2, launch_spmv).  Measured at the headline size, bench.py, steps/s
     // (round 3, profiles/r03_launch_shapes.md): k_spmv_fused 256 / 512 / 1024 threads 290 / 294 / 275; k_update_fused<2>
@@ -1257,6 +1258,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     if (tile2Nodes >= 2560 && k.NYP <= 256 &&                               // (cfg3 3744 | dprism3d 1120; cfg5: 52.7 vs 51.8 steps/s with the taller tiles)
         (size_t)(3 * 2 * k.RT + 8) * k.NYP * sizeof(float2) <= (size_t)150 * 1024) { ctx->upd2Threads = 512; ctx->upd2Batch = 8; k.RT2 = 2 * k.RT; }
     if (const char* e2 = getenv("HMCMT_RT2")) k.RT2 = std::max(k.RT, atoi(e2));
+    if (const char* e2 = getenv("HMCMT_RTS")) k.RTS = std::max(k.RT, std::min(atoi(e2), 64));
     if (const char* eu = getenv("HMCMT_UPD2")) {              // "threads,batch,rows"
         int a = 0, b = 0, c = 0;
         const int n = sscanf(eu, "%d,%d,%d", &a, &b, &c);

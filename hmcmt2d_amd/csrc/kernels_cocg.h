@@ -42,6 +42,7 @@ struct Solver {
     int xInFwd;                           // 1: x += alpha p and |x|^2 are done by k_fdm_fwd's idle waves (its pX argument), not by k_update_fused
     int xmap;                             // 1: XCD-aware 1-D grids of the fused stencil kernels (tile_map, kernels_fused.h)
     int RT2;                              // rows per tile of k_update_fused<2> (its two halo rows per side cost less on taller tiles)
+    int RTS;                              // ... of k_spmv_fused<2> (HMCMT_RTS)
     cplx *partPQ;                         // [S][MAXNB]  p'q of the fused path
     cplx *rho2;                           // [2][S] rho by iteration parity (fused path)
     cplx *partA;                          // [S][MAXNB]  p'q   | r'z

@@ -87,8 +87,12 @@ __global__ __launch_bounds__(NT) void k_spmv_fused(Solver k, const double* partZ
     __shared__ double sh[32];
     tick_begin(k.ticks, TK_SPMV);
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *(volatile int*)k.progHost = it;   // "iteration it-1 is complete"
+    // rows per tile: the two-sweep form may run on taller tiles of its own (Solver::RTS >= RT, fewer halo rows per own row;
+    // its partial sums then fill the first slots of the k.NTR the consumer adds up, the rest are cleared below)
+    const int RTt = SW == 2 ? k.RTS : k.RT;
+    const int ntiles = (k.nz - 1 + RTt - 1) / RTt;
     int tile, s;
-    if (!tile_map(k, k.NTR, tile, s)) return;
+    if (!tile_map(k, ntiles, tile, s)) return;
     PH_STAMP(2, 0)
     const bool first = it == 1;
     const int act = k.active[s];
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(NT) void k_spmv_fused(Solver k, const double* partZ
     const float2 *z = (SW == 2 ? k.z4_32 : k.z32) + so, *pi = pin_ + so;
     float2* po = pout + so;
     cplx* q = k.q + so;
-    const int NYP = k.NYP, iz0 = 1 + tile * k.RT, iz1 = min(iz0 + k.RT - 1, k.nz - 1);   // own rows iz0..iz1
+    const int NYP = k.NYP, iz0 = 1 + tile * RTt, iz1 = min(iz0 + RTt - 1, k.nz - 1);   // own rows iz0..iz1
     const float rNYP = 1.0f / (float)NYP;
     // rows iz0-1 .. iz1+1 of the new direction (z, p vanish on boundary / pad nodes: no masking needed)
     const int nrows = iz1 - iz0 + 3, ntot = nrows * NYP, ebase = (iz0 - 1) * NYP;
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(NT) void k_spmv_fused(Solver k, const double* partZ
     PH_STAMP(2, 1)
     if constexpr (SW == 2) {
         // z4 on rows iz0-2 .. iz1+2 (outside the mesh: zero) -> LDS, then z = z4 + dinv .* (r - A z4) on rows iz0-1 .. iz1+1
-        c32* z4s = reinterpret_cast<c32*>(pn + (long)(k.RT + 2) * NYP);      // [(RT+4)][NYP]
+        c32* z4s = reinterpret_cast<c32*>(pn + (long)(RTt + 2) * NYP);      // [(RT+4)][NYP]
         for (int i0 = threadIdx.x; i0 < nz4; i0 += ZB * NT) {
             if (i0 != (int)threadIdx.x) ldz(i0);
 #pragma unroll
@@ -278,6 +282,8 @@ __global__ __launch_bounds__(NT) void k_spmv_fused(Solver k, const double* partZ
     }
     block_sum2(ar, ai, sh);
     if (threadIdx.x == 0) k.partPQ[(long)s * MAXNB + tile] = cplx{ar, ai};
+    if (SW == 2 && tile == 0)
+        for (int b = ntiles + threadIdx.x; b < k.NTR; b += NT) k.partPQ[(long)s * MAXNB + b] = cplx{0, 0};
     PH_STAMP(2, 6)
     tick_end(k.ticks, TK_SPMV);
 }
