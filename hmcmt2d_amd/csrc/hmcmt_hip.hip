@@ -751,14 +751,16 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         else hipLaunchKernelGGL(k_sigma, grid1(v.nCell, 256), dim3(256), 0, st, v);
         ctx->lfStep.on = 0;
         HIPCHK(hipEventRecord(ctx->evModel, st));
-        // Three chains start from sigma and meet at the forward residual (round 3: 108 -> us between k_sigma and the first
-        // iteration kernel near the true model):
-        //   main    the 1-D boundary fields: per-layer terms and serial recurrences in one launch (k_bc_fused, 45 us: the critical one)
-        //   side    the extrapolated forward guess (weights from the model history, then one pass over the fields: 35 us)
-        //   side2   stencil coefficients + Jacobi diagonal + packed float copy in one launch (the residual waits for them), then
-        //           FDM background -> inverse pivots of its tridiagonals (serial, 30-85 us; the preconditioner waits)
-        // The host issues them in this order (after the previous evaluation's synchronisation the order of the API
-        // calls is the schedule); the side-stream work of the adjoint half follows from inside the forward solve.
+        // Two chains start from sigma and meet at the forward residual (in-kernel timeline HMCMT_TICKS=1; near the true model
+        // the first preconditioner application starts 92 us after k_sigma_rows, 131 us at the start of round 3):
+        //   main    the 1-D boundary fields: per-layer terms and serial recurrences in one launch (k_bc_fused, 35 us), then the
+        //           stencil coefficients + Jacobi diagonal + packed float copy (k_coef_all, 10 us), then the residual
+        //   side    the extrapolated forward guess (weights from the model history, one pass over the fields: 15 + 15 us; the
+        //           residual waits for it), then the FDM background -> inverse pivots of its tridiagonals (serial, 19-60 us;
+        //           the first preconditioner application waits for them)
+        // This stretch is bound by the host's 4-7 us per API call and by waits on events that are not yet complete when the
+        // queue reaches them, not by the kernels: the order of the calls is the schedule, and every call
+        // that could be dropped or moved to where the host runs ahead of the device has been.
         if (!freezeBC) {
             if (ctx->bcCW > 0) {
                 hipLaunchKernelGGL(k_bc_fused, dim3((v.ny + ctx->bcCW) / ctx->bcCW, v.nFreq), dim3(256), ctx->bcLds, st, v, ctx->bcCW, ctx->bcSlots);
