@@ -7,6 +7,7 @@
 // (dlopen): the hot-path library itself does not depend on it.  One communicator = one GPU of one process.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -50,12 +51,20 @@ bool load_rccl() {
         dir = sl == std::string::npos ? std::string() : dir.substr(0, sl + 1);
     }
     const std::string names[] = {dir + "librccl.so.1", dir + "librccl.so", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string why;                   // dlerror() of the last attempt (the call returns the message once and clears it)
+    const char* forced = getenv("HMCMT_RCCL_PATH");       // this library and no other (deployments with RCCL elsewhere; the loader's test)
+    if (forced && *forced) {
+        g_rccl.h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!g_rccl.h) { const char* e = dlerror(); why = e ? e : "?"; }
+    } else
     for (const std::string& n : names) {
         if (n.empty() || (n[0] != '/' && !dir.empty() && &n < &names[2])) continue;
         g_rccl.h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (g_rccl.h) break;
+        const char* e = dlerror();
+        why = e ? e : "?";
     }
-    if (!g_rccl.h) { g_rccl.err = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "?"); return false; }
+    if (!g_rccl.h) { g_rccl.err = std::string("cannot load librccl.so: ") + (why.empty() ? "?" : why); return false; }
     g_rccl.getUniqueId = (fnGetUniqueId)dlsym(g_rccl.h, "ncclGetUniqueId");
     g_rccl.commInitRank = (fnCommInitRank)dlsym(g_rccl.h, "ncclCommInitRank");
     g_rccl.allGather = (fnAllGather)dlsym(g_rccl.h, "ncclAllGather");

@@ -147,6 +147,24 @@ def test_julia_binding_mirrors_the_struct_layout():
         assert nargs_c == nargs_jl, (sym, nargs_c, nargs_jl)
 
 
+def test_rccl_loader_reports_a_missing_library_instead_of_crashing():
+    """hmcmt_comm_id / hmcmt_comm_create on a box whose librccl cannot be loaded must return HMCMT_ENODEV
+    (include/hmcmt.h), not crash: a fresh process points the loader at a path that does not exist."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys\n"
+            "so = ctypes.CDLL(sys.argv[1])\n"
+            "buf = ctypes.create_string_buffer(128)\n"
+            "rc = so.hmcmt_comm_id(buf)\n"
+            "h = ctypes.c_void_p()\n"
+            "rc2 = so.hmcmt_comm_create(ctypes.byref(h), 0, 1, 0, buf)\n"
+            "print(rc, rc2)\n")
+    env = dict(os.environ, HMCMT_RCCL_PATH="/nonexistent/librccl.so.1")
+    out = subprocess.run([sys.executable, "-c", code, L.SO_PATH], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-400:]
+    assert out.stdout.split() == ["-2", "-2"]
+
+
 @pytest.mark.gpu
 def test_compiled_c_consumer_runs_the_hot_path(tmp_path):
     """The same C program dlopen()s libhmcmt_hip.so and runs hmcmt_create / hmcmt_grad / hmcmt_get_stats /
