@@ -8,6 +8,8 @@
 //                     v_mfma_f32_16x16x32_bf16 by default, v_mfma_f64_16x16x4_f64 for fdm_precision = 1) around batched
 //                     tridiagonal solves in z; k_fdm_fwd / k_back_post are the two fused kernels of the default path
 //   kernels_fused.h   the fused COCG iteration (k_spmv_fused, k_update_fused), solve start / end, initial guesses
+//   kernels_persist.h the whole COCG solve as ONE persistent kernel (round 4: a system = 8 workgroups of one XCD, r in
+//                     registers, per-system barriers in the XCD's L2) -- the default where it applies
 //   kernels_path.h    "item" kernels, one thread per node / cell / receiver / boundary column with bodies in
 //                     hmcmt_items.h (assembly from sigma, 1-D boundary fields and sensitivities, receiver functionals,
 //                     adjoint sources, J^T v accumulation), and the leapfrog vector kernels
@@ -16,6 +18,7 @@
 // There is no host compute path: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +49,7 @@ constexpr int VBLOCK = HMCMT_VBLOCK;        // threads of the vector kernels (bu
 #include "kernels_cocg.h"
 #include "kernels_fdm.h"
 #include "kernels_fused.h"
+#include "kernels_persist.h"
 #include "kernels_path.h"
 
 }  // namespace
@@ -150,6 +154,15 @@ struct hmcmt_ctx {
     double* d_gStart = nullptr;              // data gradient at the start model of the last trajectory (a rejection restarts there)
     bool havePrior = false, lfHaveGrad = false, lfFlagPending = false;
     int solveFail = 0;                    // status a system of the last solve gave up with (mapped failure word), 0 = none
+    // persistent solve kernel (kernels_persist.h)
+    bool persistOn = true;                // HMCMT_PERSIST=0: the launch-per-phase loop only
+    int persistG = 0, persistSlots = 0, persistCW = 0;   // workgroups per system, system slots per XCD, threads / 2 (0: the problem does not fit the kernel)
+    size_t persistLds = 0;
+    unsigned* d_psync = nullptr;          // [8 * slots][32] barrier words | exit counter | fail word
+    size_t psyncBytes = 0;
+    long long* d_pstamps = nullptr;       // HMCMT_STAMPS=persist
+    long long persistSolves = 0, persistFallbacks = 0;
+    bool counted = false;                 // this context is in g_liveContexts
     // results of the last two host-API evaluations, keyed by the model: a sampler re-evaluates the model it has
     // just evaluated (getHamiltonian at the proposal, HMCSampler.jl:364; the first gradient of the next trajectory,
     // :217) or, after a rejection, the start model of the trajectory before -- those calls cost a memcmp
@@ -463,6 +476,58 @@ int collect_stats(hmcmt_ctx* ctx, bool withAdjoint);
 int finish_status(hmcmt_ctx* ctx);
 
 constexpr double SPIN_LIMIT_S = 60.0;       // a convergence poll that sees no progress for this long gives up (HMCMT_EHIP)
+
+std::atomic<int> g_liveContexts{0};         // contexts alive in this process: two persistent kernels on one device could each hold CUs the other needs
+
+// the persistent solve kernel applies to the solve at hand (default path, a mesh its tiles fit, alone on the device)
+bool persist_ok(const hmcmt_ctx* ctx) {
+    return ctx->persistOn && ctx->persistCW > 0 && ctx->sv.splitT && ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0 &&
+           g_liveContexts.load() == 1;
+}
+// one launch = the whole solve (or, precondOnly, one application of the preconditioner to k.r -> zout)
+int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout) {
+    Solver& k = ctx->sv;
+    PersistArgs a{};
+    const int groups = 8 * ctx->persistSlots;
+    a.sync = ctx->d_psync; a.exitCnt = ctx->d_psync + 32 * groups; a.fail = reinterpret_cast<int*>(ctx->d_psync + 32 * groups + 8);
+    a.placeHost = k.stallHost + 2;
+    a.G = ctx->persistG; a.slots = ctx->persistSlots; a.maxit = ctx->opt.maxit; a.precondOnly = precondOnly;
+    a.wJ = (float)ctx->jacobiW;
+    a.Vb = ctx->d_Vb; a.Vtb = ctx->d_Vtb;
+    a.partZZ = ctx->d_partZZ;
+    a.pubR = k.t2_32; a.pubZ = k.zs32; a.pubP = k.p32a;
+    a.yhat = k.y32; a.ysol = k.t32;
+    a.ip32 = ctx->d_invp32;
+    a.zout = zout;
+    a.stamps = ctx->d_pstamps;
+    HIPCHK(hipMemsetAsync(ctx->d_psync, 0, ctx->psyncBytes, ctx->stream));
+    const dim3 grid(groups * ctx->persistG);
+    const size_t lds = ctx->persistLds;
+#define PSL(CW, SWP) hipLaunchKernelGGL((k_cocg_persist<CW, SWP>), grid, dim3(2 * CW), lds, ctx->stream, k, a)
+    if (ctx->persistCW == 256) { if (sweeps == 2) PSL(256, 2); else PSL(256, 1); }
+    else if (ctx->persistCW == 128) { if (sweeps == 2) PSL(128, 2); else PSL(128, 1); }
+    else { if (sweeps == 2) PSL(64, 2); else PSL(64, 1); }
+#undef PSL
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// spin on the mapped progress word until it holds `value` (see the polls of solve(): a spin on host memory wakes within a
+// microsecond; the stream is looked at every 2^16 spins; no progress for SPIN_LIMIT_S seconds is an error)
+int spin_progress(hmcmt_ctx* ctx, int value) {
+    long spins = 0;
+    std::chrono::steady_clock::time_point t0;
+    while (*(volatile int*)ctx->h_prog != value) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xffff) == 0) {
+            if (hipStreamQuery(ctx->stream) != hipErrorNotReady) break;
+            const auto now = std::chrono::steady_clock::now();
+            if (spins == 0x10000) t0 = now;
+            else if (std::chrono::duration<double>(now - t0).count() > SPIN_LIMIT_S) { ctx->err = "the device made no progress on a solve for 60 s"; return HMCMT_EHIP; }
+        }
+    }
+    if (*(volatile int*)ctx->h_prog != value) HIPCHK(hipStreamSynchronize(ctx->stream));   // reports the error, if any
+    return 0;
+}
 constexpr double SWEEPS2_COST = 1.20;       // time of a two-sweep iteration / time of a one-sweep iteration (59-60 us / 50 us at the headline size)
 constexpr int SWEEPS_PROBE_EVERY = 40;      // in two-sweep mode: every so many solves of a kind one solve runs one sweep, to compare
 // damped Jacobi sweeps on each side of the FDM stage for the next solve of this kind.  Two sweeps cut the iterations by
@@ -512,7 +577,29 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
     const dim3 tg((k.ny - 1 + 63) / 64, S);
     const bool fused = ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0;
     cplx* const r_entry = k.r;
-    if (fused) {
+    bool viaPersist = false, stalledP = false;
+    if (fused && persist_ok(ctx)) {
+        // ONE launch solves every system (kernels_persist.h).  The kernel tells the host through mapped words: the progress
+        // word when its last workgroup leaves, the active-system counter, the stagnation / failure / placement flags.
+        ctx->preDone = false;                          // (it does its own first pre-smoothing pass)
+        *(volatile int*)ctx->h_stall = 0;
+        *(volatile int*)(ctx->h_stall + 2) = 0;
+        *(volatile int*)ctx->h_prog = 0;
+        { ProfScope ps(ctx, 2); int prc = launch_persist(ctx, k.sweeps, 0, nullptr); if (prc) return prc; }
+        ++ctx->persistSolves;
+        if (kind == 0) launch_adjoint_side(ctx);        // (the host is free while the device solves)
+        { int prc = spin_progress(ctx, PS_DONE); if (prc) return prc; }
+        if (*(volatile int*)(ctx->h_stall + 2)) {
+            // the group's workgroups were not on one XCD (or the kernel could not be placed): nothing was touched by those
+            // groups -- this context goes back to the launch-per-phase loop for good
+            ctx->persistOn = false; ++ctx->persistFallbacks;
+        } else {
+            viaPersist = true;
+            if (*(volatile int*)ctx->h_nactive == 0) done = true;
+            else if (*(volatile int*)ctx->h_stall) stalledP = true;
+        }
+    }
+    if (fused && !viaPersist) {
         { int prc = apply_precond(ctx); if (prc) return prc; }          // z = P^-1 r and the partial sums of r'z, |z|^2
         float2* pb[2] = {k.p32a, k.p32b};
         cplx* rb[2] = {k.r, k.r2};
@@ -590,7 +677,10 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
         }
         if (done) it = std::max(0, it - 1);
     }
-    if (!done) {
+    if (viaPersist) it = guess;          // (what the kernel needed is in its records: parse_stats)
+    (void)stalledP;
+    if (!done && !(viaPersist && *(volatile int*)(ctx->h_stall + 1))) {
+        if (viaPersist) it = 0;
         const bool restart = fused;      // coming from the fused loop: restart COCG with the fp64 preconditioner
         if (restart) { ctx->lpFallback = true; ++ctx->stats.fallback_solves; }
         // z = P^-1 r ; rho = r'z ; p = z
@@ -988,6 +1078,7 @@ const char* hmcmt_last_error(const hmcmt_ctx* ctx) { return ctx ? ctx->err.c_str
 
 int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (!ctx) return HMCMT_EINVAL;
+    if (ctx->counted) { g_liveContexts.fetch_sub(1); ctx->counted = false; }
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->side) hipStreamSynchronize(ctx->side);      // (side-stream work of an evaluation nobody waited for)
@@ -1021,6 +1112,21 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
                                 "k_rxall .. adjoint residual %.1f us, gradient tail %.1f us, wait for the previous evaluation's records %.1f us\n", ctx->hostN, ctx->hostUs[0] / ctx->hostN,
                                 ctx->hostUs[1] / ctx->hostN, ctx->hostUs[2] / ctx->hostN, ctx->hostUs[3] / ctx->hostN);
         hipFree(ctx->v.ticks);
+    }
+    if (ctx->d_pstamps) {                                // HMCMT_STAMPS=persist: phases of the third iteration of the last solve
+        std::vector<long long> st(16 * 256);
+        hipMemcpy(st.data(), ctx->d_pstamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        double acc[12] = {0}; long n = 0;
+        for (int b = 0; b < 256; ++b) {
+            const long long* p = &st[16 * b];
+            if (!p[0] || !p[11]) continue;
+            ++n;
+            for (int i = 1; i < 12; ++i) acc[i] += (double)(p[i] - p[i - 1]);
+        }
+        if (n) {
+            fprintf(stderr, "HMCMT_STAMPS persist: %ld workgroups; mean ticks: pre-smooth %.0f fwd-transform %.0f wait-T1 %.0f slabs %.0f wait-T2 %.0f back-transform %.0f "
+                            "post-smooth %.0f wait-R1 %.0f scalars+p+q %.0f wait-R2 %.0f update %.0f\n", n, acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7], acc[8], acc[9], acc[10], acc[11]);
+        }
     }
     if (ctx->sv.stamps) {                                // HMCMT_STAMPS: phase stamps of the last launch that wrote them
         std::vector<long long> st(8 * 4096);
@@ -1061,6 +1167,42 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (ctx->side) hipStreamDestroy(ctx->side);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
+    return 0;
+}
+
+// Shape of the persistent solve kernel for this problem (kernels_persist.h): G workgroups of 14 rows per system, all of a
+// system's workgroups on one XCD (32 CUs), one workgroup per CU; 2 * CW threads for meshes up to CW nodes wide.
+static int persist_setup(hmcmt_ctx* ctx) {
+    const Solver& k = ctx->sv;
+    if (const char* e = getenv("HMCMT_PERSIST")) ctx->persistOn = e[0] != '0';
+    ctx->persistCW = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const int cuPerXcd = prop.multiProcessorCount / 8;
+    const int G = (k.nz - 1 + PS_OWN - 1) / PS_OWN;
+    if (!k.splitT || k.NYP > 256 || cuPerXcd < 1 || G > cuPerXcd || G > MAXNB) return 0;
+    const int cw = k.NYP <= 64 ? 64 : (k.NYP <= 128 ? 128 : 256);
+    const size_t lds = 1024 + std::max(fdm_fwd_lds(k, FW_NTW, k.twist), ps_tiles_bytes(k.NYP));
+    if (lds > (size_t)160 * 1024) return 0;
+    const void* fns[6] = {reinterpret_cast<const void*>(k_cocg_persist<256, 1>), reinterpret_cast<const void*>(k_cocg_persist<256, 2>),
+                          reinterpret_cast<const void*>(k_cocg_persist<128, 1>), reinterpret_cast<const void*>(k_cocg_persist<128, 2>),
+                          reinterpret_cast<const void*>(k_cocg_persist<64, 1>), reinterpret_cast<const void*>(k_cocg_persist<64, 2>)};
+    for (const void* f : fns)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    ctx->persistG = G;
+    ctx->persistSlots = std::max(1, std::min((k.S + 7) / 8, cuPerXcd / G));
+    ctx->persistLds = lds;
+    ctx->psyncBytes = ((size_t)(32 * 8 * ctx->persistSlots + 16) * sizeof(unsigned) + 15) & ~(size_t)15;
+    void* q = nullptr;
+    HIPCHK(hipMalloc(&q, ctx->psyncBytes));
+    ctx->allocs.push_back(q);
+    ctx->d_psync = reinterpret_cast<unsigned*>(q);
+    if (const char* es = getenv("HMCMT_STAMPS")) if (!strcmp(es, "persist")) {
+        HIPCHK(hipMalloc((void**)&ctx->d_pstamps, sizeof(long long) * 16 * 256));
+        HIPCHK(hipMemset(ctx->d_pstamps, 0, sizeof(long long) * 16 * 256));
+        ctx->allocs.push_back(ctx->d_pstamps);
+    }
+    ctx->persistCW = cw;
     return 0;
 }
 
@@ -1301,8 +1443,8 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
 #undef DA
     HIPCHK(hipHostMalloc((void**)&ctx->h_nactive, sizeof(int), hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void**)&k.nactHost, ctx->h_nactive, 0));
-    HIPCHK(hipHostMalloc((void**)&ctx->h_stall, 2 * sizeof(int), hipHostMallocMapped));     // [0] stagnation flag, [1] failure status
-    ctx->h_stall[0] = ctx->h_stall[1] = 0;
+    HIPCHK(hipHostMalloc((void**)&ctx->h_stall, 4 * sizeof(int), hipHostMallocMapped));     // [0] stagnation flag, [1] failure status, [2] persistent kernel: placement failed
+    ctx->h_stall[0] = ctx->h_stall[1] = ctx->h_stall[2] = ctx->h_stall[3] = 0;
     HIPCHK(hipHostGetDevicePointer((void**)&k.stallHost, ctx->h_stall, 0));
     k.failHost = k.stallHost + 1;
     k.stallIt = STALL_IT;
@@ -1365,6 +1507,9 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
     ctx->sv.xInFwd = ctx->sv.splitT && (long)(ctx->sv.nz - 1) * ctx->sv.NYP >= 12000;
     if (const char* ex = getenv("HMCMT_XFWD")) ctx->sv.xInFwd = ctx->sv.splitT && ex[0] != '0';
     ctx->sv.twist = ctx->v.twist = ctx->sv.splitT && ctx->twistOn;     // the fused forward kernel sweeps both ways at once
+    if ((rc = persist_setup(ctx))) { g_createError = ctx->err; hmcmt_destroy(ctx); return rc; }
+    g_liveContexts.fetch_add(1);
+    ctx->counted = true;
     *out = ctx;
     return 0;
 }
@@ -1675,6 +1820,31 @@ int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z) {
         return 0;
     }
     HIPCHK(hipMemcpy(z, ctx->sv.z, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// z = P^-1 r by the persistent solve kernel's own preconditioner (its first application, then it stops): the comparator of
+// hmcmt_debug_precond for tests/test_gpu_persist.py.  sweeps = 1 / 2 smoothing sweeps per side.
+int hmcmt_debug_persist_precond(hmcmt_ctx* ctx, int32_t sweeps, const double* r, double* z) {
+    if (!ctx || !r || !z || (sweeps != 1 && sweeps != 2)) return HMCMT_EINVAL;
+    if (!ctx->haveModel) { ctx->err = "no evaluation has been run yet"; return HMCMT_EINVAL; }
+    if (!ctx->persistCW) { ctx->err = "the persistent solve kernel does not apply to this problem"; return HMCMT_EINVAL; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->v.S * ctx->v.vstride;
+    HIPCHK(hipMemcpy(ctx->sv.r, r, n * sizeof(cplx), hipMemcpyHostToDevice));
+    int rc = set_all_active(ctx);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(ctx->sv.z32, 0, n * sizeof(float2), ctx->stream));
+    *(volatile int*)ctx->h_prog = 0;
+    *(volatile int*)(ctx->h_stall + 2) = 0;
+    ctx->sv.tol2 = ctx->opt.tol * ctx->opt.tol;
+    if ((rc = launch_persist(ctx, sweeps, 1, ctx->sv.z32))) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (*(volatile int*)(ctx->h_stall + 2)) { ctx->err = "persistent kernel: the workgroups of a system were not placed on one XCD"; return HMCMT_EHIP; }
+    if (*(volatile int*)(ctx->h_stall + 1)) { ctx->err = "persistent kernel: a wait timed out"; return HMCMT_EHIP; }
+    std::vector<float2> h(n);
+    HIPCHK(hipMemcpy(h.data(), ctx->sv.z32, n * sizeof(float2), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) { z[2 * i] = h[i].x; z[2 * i + 1] = h[i].y; }
     return 0;
 }
 

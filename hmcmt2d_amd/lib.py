@@ -17,7 +17,7 @@ SO_PATH = os.environ.get("HMCMT_LIB_PATH") or os.path.join(HERE, "libhmcmt_hip.s
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = [os.path.join(CSRC, "hmcmt_hip.hip"), os.path.join(CSRC, "mumps_shim.hip"), os.path.join(CSRC, "comm.hip")]
 HEADERS = [os.path.join(CSRC, h) for h in ("hmcmt_math.h", "hmcmt_items.h", "hmcmt_host.h", "kernels_cocg.h", "kernels_fdm.h",
-                                            "kernels_fused.h", "kernels_path.h")] + \
+                                            "kernels_fused.h", "kernels_persist.h", "kernels_path.h")] + \
           [os.path.join(HERE, "..", "include", "hmcmt.h"), os.path.join(HERE, "..", "include", "hmcmt_mumps.h")]
 
 HMCMT_NCAT = 8
@@ -116,13 +116,14 @@ def load_library():
     lib.hmcmt_debug_flags.argtypes = [vp, C.c_int32]
     lib.hmcmt_debug_spmv.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_precond.argtypes = [vp, c_double_p, c_double_p]
+    lib.hmcmt_debug_persist_precond.argtypes = [vp, C.c_int32, c_double_p, c_double_p]
     lib.hmcmt_debug_fdm_fwd.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_back_post.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_double_p]
     for name in ("hmcmt_create", "hmcmt_destroy", "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters",
                  "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async",
                  "hmcmt_wait", "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead",
                  "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond",
-                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post"):
+                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post", "hmcmt_debug_persist_precond"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -133,7 +134,7 @@ EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "h
                     "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async", "hmcmt_wait",
                     "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead", "hmcmt_dims",
                     "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
-                    "hmcmt_debug_back_post", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
+                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
                     "hmcmt_comm_last_error"]
 
 
@@ -388,6 +389,13 @@ class HipContext:
         r = self._vec(r)
         z = np.empty_like(r)
         self._check(self.lib.hmcmt_debug_precond(self.h, _dp(r), _dp(z)))
+        return z
+
+    def debug_persist_precond(self, r, sweeps=1):
+        """z = P^-1 r by the persistent solve kernel's preconditioner (kernels_persist.h)."""
+        r = self._vec(r)
+        z = np.empty_like(r)
+        self._check(self.lib.hmcmt_debug_persist_precond(self.h, int(sweeps), _dp(r), _dp(z)))
         return z
 
     def close(self):
