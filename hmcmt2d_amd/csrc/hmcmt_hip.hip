@@ -496,11 +496,12 @@ int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout) {
     a.Vb = ctx->d_Vb; a.Vtb = ctx->d_Vtb;
     a.partZZ = ctx->d_partZZ;
     a.pubR = k.t2_32; a.pubZ = k.zs32; a.pubP = k.p32a;
-    a.yhat = k.y32; a.ysol = k.t32;
+    a.yhat = k.y32; a.ysol = k.t32; a.tbuf = k.z4_32;
     a.ip32 = ctx->d_invp32;
     a.zout = zout;
     a.stamps = ctx->d_pstamps;
     HIPCHK(hipMemsetAsync(ctx->d_psync, 0, ctx->psyncBytes, ctx->stream));
+    if (ctx->d_pstamps) HIPCHK(hipMemsetAsync(ctx->d_pstamps, 0, sizeof(long long) * 16 * 252, ctx->stream));
     const dim3 grid(groups * ctx->persistG);
     const size_t lds = ctx->persistLds;
 #define PSL(CW, SWP) hipLaunchKernelGGL((k_cocg_persist<CW, SWP>), grid, dim3(2 * CW), lds, ctx->stream, k, a)
@@ -1123,9 +1124,21 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
             ++n;
             for (int i = 1; i < 12; ++i) acc[i] += (double)(p[i] - p[i - 1]);
         }
+#ifdef HMCMT_PS_DBGX
+        fprintf(stderr, "HMCMT_PS_DBGX: halo copies that differ from the owners' values, by halo row j = 0..4: z3 %lld %lld %lld %lld %lld | zf %lld %lld %lld %lld %lld | p %lld (total)\n",
+                st[16 * 254 + 0], st[16 * 254 + 1], st[16 * 254 + 2], st[16 * 254 + 3], st[16 * 254 + 4], st[16 * 254 + 5], st[16 * 254 + 6], st[16 * 254 + 7], st[16 * 254 + 8], st[16 * 254 + 9], st[16 * 255 + 12]);
+        { const double* ex = reinterpret_cast<const double*>(&st[16 * 252]);
+          fprintf(stderr, "   example (zf): mesh row %g col %g j %g half %g: owner %.9g %+.9gi, halo copy %.9g %+.9gi; r used by the copy %.9g %+.9gi, r published %.9g %+.9gi; workgroup %g system %g iteration %g\n",
+                  ex[0], ex[1], ex[2], ex[3], ex[4], ex[6], ex[5], ex[7], ex[8], ex[13], ex[12], ex[14], ex[9], ex[10], ex[11]); }
+#endif
         if (n) {
-            fprintf(stderr, "HMCMT_STAMPS persist: %ld workgroups; mean ticks: pre-smooth %.0f fwd-transform %.0f wait-T1 %.0f slabs %.0f wait-T2 %.0f back-transform %.0f "
-                            "post-smooth %.0f wait-R1 %.0f scalars+p+q %.0f wait-R2 %.0f update %.0f\n", n, acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7], acc[8], acc[9], acc[10], acc[11]);
+            int rate = 100000;                                // kHz
+            hipDeviceGetAttribute(&rate, hipDeviceAttributeWallClockRate, ctx->device);
+            const double us = 1e3 / rate / n;
+            double tot = 0; for (int i = 1; i < 12; ++i) tot += acc[i];
+            fprintf(stderr, "HMCMT_STAMPS persist: %ld workgroups, third iteration of the last solve, mean us: pre-smooth %.2f fwd-transform %.2f wait-T1 %.2f slabs %.2f wait-T2 %.2f back-transform %.2f "
+                            "post-smooth %.2f wait-R1 %.2f scalars+p+q %.2f wait-R2 %.2f update %.2f | iteration %.2f\n", n, acc[1] * us, acc[2] * us, acc[3] * us, acc[4] * us, acc[5] * us, acc[6] * us,
+                    acc[7] * us, acc[8] * us, acc[9] * us, acc[10] * us, acc[11] * us, tot * us);
         }
     }
     if (ctx->sv.stamps) {                                // HMCMT_STAMPS: phase stamps of the last launch that wrote them
@@ -1182,7 +1195,7 @@ static int persist_setup(hmcmt_ctx* ctx) {
     const int G = (k.nz - 1 + PS_OWN - 1) / PS_OWN;
     if (!k.splitT || k.NYP > 256 || cuPerXcd < 1 || G > cuPerXcd || G > MAXNB) return 0;
     const int cw = k.NYP <= 64 ? 64 : (k.NYP <= 128 ? 128 : 256);
-    const size_t lds = 1024 + std::max(fdm_fwd_lds(k, FW_NTW, k.twist), ps_tiles_bytes(k.NYP));
+    const size_t lds = ps_lds_bytes(k.NYP, k.NZP, k.nz, k.twist);
     if (lds > (size_t)160 * 1024) return 0;
     const void* fns[6] = {reinterpret_cast<const void*>(k_cocg_persist<256, 1>), reinterpret_cast<const void*>(k_cocg_persist<256, 2>),
                           reinterpret_cast<const void*>(k_cocg_persist<128, 1>), reinterpret_cast<const void*>(k_cocg_persist<128, 2>),

@@ -53,6 +53,7 @@ struct PersistArgs {
     float2* yhat;              // [S][vstride] complex64 rows of the forward transform
     float2* ysol;              // [S][vstride] solved slabs, pre-split bf16 planes (store_t32's format)
     const float2* ip32;        // inverse pivots (complex64)
+    float2* tbuf;              // [S][vstride] complex64: t of the own rows across the FDM stage (two sweeps: the rho identity)
     float2* zout;              // precondOnly: z = P^-1 r
     long long* stamps;         // [workgroup][16] s_memtime stamps of one iteration's phases (HMCMT_STAMPS=persist)
 };
@@ -78,6 +79,9 @@ __device__ __forceinline__ bool ps_wait(unsigned* cnt, unsigned target, int* fai
     }
 }
 __device__ __forceinline__ c32 operator+(c32 a, c32 b) { return c32{a.re + b.re, a.im + b.im}; }
+// an opaque copy: what is derived from it (a phase's twelve row addresses) is computed in that phase and dies with it, instead
+// of being hoisted out of the iteration loop and kept -- or spilled -- for all of it
+__device__ __forceinline__ int ps_opq(int x) { asm volatile("" : "+v"(x)); return x; }
 // element i of an array addressed as UNIFORM base + 32-bit BYTE offset (one address register per access; with 64-bit element
 // addresses the loop-invariant address of every row of every array was hoisted and spilled: 2.2 KB of scratch per lane)
 template <class T>
@@ -85,42 +89,63 @@ __device__ __forceinline__ T* ps_at(T* base, unsigned i) { return reinterpret_ca
 template <class T>
 __device__ __forceinline__ const T* ps_at(const T* base, unsigned i) { return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + i * (unsigned)sizeof(T)); }
 
-// float stencil coefficients of a thread's 12 tile rows: lateral couplings, omega * mass, and the coupling between its
-// rows j and j + 1 (cV[11]: to the first row of the other half of the tile); the diagonal is minus the sum of the four
-// couplings (Appendix E.1 of SURVEY.md: K_ii = -(c_E + c_W + c_S + c_N))
-struct PsCo { float cE[PS_J], cW[PS_J], dmw[PS_J], cV[PS_J]; };
+// ---- Arithmetic that several workgroups repeat on the same rows must give the SAME BITS in all of them (see ps_rows).  The same
+// source expression does not: the compiler fuses multiplies and adds into FMAs per INSTANCE -- the unrolled copy of a row that
+// is an own row in one workgroup and a halo row in the next came out one ulp apart (the fused complex product inside an inlined
+// operator, whatever the pragma state of its caller).  So: no contraction from here to the end of the file, and every product-sum
+// of the repeated arithmetic written with explicit fma in a fixed order.
+#pragma clang fp contract(off)
+__device__ __forceinline__ c32 ps_cmul(c32 a, c32 b) { return c32{__builtin_fmaf(a.re, b.re, -(a.im * b.im)), __builtin_fmaf(a.re, b.im, a.im * b.re)}; }
+__device__ __forceinline__ c32 ps_cadd(c32 a, c32 b) { return c32{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ c32 ps_csub(c32 a, c32 b) { return c32{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ c32 ps_scal(float f, c32 a) { return c32{f * a.re, f * a.im}; }
+// The float stencil coefficients of the tile live in LDS for the whole solve (three planes [24][NYP] behind the region the
+// phases share: 48 registers per thread in the first version, which the compiler spilled): E = coupling to the east neighbour
+// (the west one is the neighbour's E; column 0 holds the coupling of column 1 to the boundary), M = omega * mass, V = coupling
+// of a row to the next row TOWARDS THE MIDDLE of the tile (the two halves of a tile are mirrored; the last row of a half
+// couples to the first row of the other half).  The diagonal is minus the sum of the four couplings.
+struct PsPl { const float *E, *M, *V; };
+#ifndef HMCMT_PS_GRP
+#define HMCMT_PS_GRP 3
+#endif
+constexpr int PS_GRP = HMCMT_PS_GRP;      // rows the scheduler may interleave in a stencil pass
 
-// (A u) on the thread's rows JLO <= j < JHI: vertical neighbours from its registers, lateral ones (and the inner neighbour
-// of its last row) from the tile in LDS.  A row that two workgroups compute (an own row of one, a halo row of the other)
-// must come out BIT FOR BIT the same in both -- the halo rows' p enters the owners' fp64 q = A p, and x += alpha p, r -=
-// alpha q stay consistent only if every workgroup uses the same p -- so the terms are ordered by MESH direction (north,
-// south), not by the thread's direction (outer, inner; the two halves of a tile are mirrored).
+// (A u) on the thread's rows JLO <= j < JHI of the tile S in LDS -- the five points and the coefficients all come from LDS, no
+// per-row values are kept in registers between passes (the first version held every intermediate vector in twelve-element
+// register arrays: 250 spilled registers); f(j, tile index, u, A u, diagonal, omega * mass) consumes each row.  A row that
+// two workgroups compute (an own row of one, a halo row of the other) must come out BIT FOR BIT the same in both -- the
+// halo rows' p enters the owners' fp64 q = A p, and x += alpha p, r -= alpha q stay consistent only if every workgroup uses
+// the same p -- so the terms are ordered by MESH direction (north, south), not by the thread's direction (outer, inner).
 template <int JLO, int JHI = PS_J, class F>
-__device__ __forceinline__ void ps_apply(const PsCo& co, const c32 (&u)[PS_J], const c32* __restrict__ T, int t0i, int es, int tini, int c, F&& f) {
+__device__ __forceinline__ void ps_rows(const PsPl& co, const c32* __restrict__ S, int t0i_, int es, int c, F&& f) {
+    const int t0i = ps_opq(t0i_);
 #pragma unroll
     for (int j = JLO; j < JHI; ++j) {
         const int ti = t0i + j * es;
-        const c32 ue = T[ti + 1], uw = T[ti - 1];
-        const c32 ui = j + 1 < PS_J ? u[j + 1 < PS_J ? j + 1 : j] : T[tini];
-        const c32 uo = u[j - 1], uc = u[j];
+        const c32 uc = S[ti], ue = S[ti + 1], uw = S[ti - 1], ui = S[ti + es], uo = S[ti - es];
         const c32 un = c ? ui : uo, us = c ? uo : ui;
-        const float cn = c ? co.cV[j] : co.cV[j - 1], cs = c ? co.cV[j - 1] : co.cV[j];
-        float ce = co.cE[j];
-        asm volatile("" : "+v"(ce));               // (see ps_dinv)
-        const float dk = -((ce + co.cW[j]) + (cn + cs));
-        f(j, c32{((dk * uc.re - co.dmw[j] * uc.im) + (ce * ue.re + co.cW[j] * uw.re)) + (cn * un.re + cs * us.re),
-                 ((dk * uc.im + co.dmw[j] * uc.re) + (ce * ue.im + co.cW[j] * uw.im)) + (cn * un.im + cs * us.im)});
+        const float ce = co.E[ti], cw = co.E[ti - 1], dm = co.M[ti], va = co.V[ti], vb = co.V[ti - es];
+        const float cn = c ? va : vb, cs = c ? vb : va;
+        const float dk = -((ce + cw) + (cn + cs));
+        float are = __builtin_fmaf(-dm, uc.im, dk * uc.re), aim = __builtin_fmaf(dm, uc.re, dk * uc.im);
+        are = __builtin_fmaf(ce, ue.re, are); aim = __builtin_fmaf(ce, ue.im, aim);
+        are = __builtin_fmaf(cw, uw.re, are); aim = __builtin_fmaf(cw, uw.im, aim);
+        are = __builtin_fmaf(cn, un.re, are); aim = __builtin_fmaf(cn, un.im, aim);
+        are = __builtin_fmaf(cs, us.re, are); aim = __builtin_fmaf(cs, us.im, aim);
+        f(j, ti, uc, c32{are, aim}, dk, dm);
+        if (((j - JLO) % PS_GRP) == PS_GRP - 1) __builtin_amdgcn_sched_barrier(0);     // (rows in groups: bounds what the scheduler interleaves)
     }
 }
-// damped inverse diagonal wJ / (dk + i omega dm) of row j (the same sum as in ps_apply)
-__device__ __forceinline__ c32 ps_dinv(const PsCo& co, int j, float wJ, int c) {
-    const float va = co.cV[j], vb = co.cV[j > 0 ? j - 1 : 0];
+// damped inverse diagonal wJ / (dk + i omega dm)
+__device__ __forceinline__ c32 ps_dinv(float dk, float dm, float wJ) {
+    const float inv = wJ * __builtin_amdgcn_rcpf(__builtin_fmaf(dk, dk, dm * dm));
+    return c32{dk * inv, -(dm * inv)};
+}
+// ... of tile index ti, from the planes (the same sum as in ps_apply)
+__device__ __forceinline__ c32 ps_dinv_at(const PsPl& co, int ti, int es, int c, float wJ) {
+    const float ce = co.E[ti], cw = co.E[ti - 1], dm = co.M[ti], va = co.V[ti], vb = co.V[ti - es];
     const float cn = c ? va : vb, cs = c ? vb : va;
-    float ce = co.cE[j], dm = co.dmw[j];
-    asm volatile("" : "+v"(ce), "+v"(dm));      // (recomputed at every use: 36 loop-invariant values would otherwise be hoisted and spilled)
-    const float dk = -((ce + co.cW[j]) + (cn + cs));
-    const float inv = wJ * __builtin_amdgcn_rcpf(dk * dk + dm * dm);
-    return c32{dk * inv, -dm * inv};
+    return ps_dinv(-((ce + cw) + (cn + cs)), dm, wJ);
 }
 
 // block-wide deterministic sums of three doubles (NW waves); result in every thread
@@ -137,31 +162,57 @@ __device__ __forceinline__ void ps_block_sum3(double& a, double& b, double& c, d
     a = sa; b = sb; c = sc;
 }
 
-// ---- the tridiagonal solves of one 32-mode slab of one system: k_fdm_fwd's LDS scheme (pre-multiplied recurrences, twisted
-// factorisation, mirrored bottom half, padded regions: kernels_fdm.h) fed from the rows the G workgroups have transformed
+// ---- the tridiagonal solves of one 32-mode slab of one system: k_fdm_fwd's LDS scheme (twisted factorisation, mirrored
+// bottom half, padded regions: kernels_fdm.h) fed from the rows the G workgroups have transformed -- with TWO slabs in LDS
+// instead of three: a = y * ip and the inverse pivots ip; the coefficients of the two sweeps, o_{r-1} ip and o_r ip (o: the real
+// off-diagonal of the row, a per-row scalar), are formed from the prefetched ip in front of their use, off the serial chain.
+// 78 KB instead of 141 KB at the headline size: the stencil coefficients of the tile stay in LDS behind it (k_cocg_persist).
+constexpr int PSL_PAD = 2 * FW_TB;           // rows between the regions of a slab: FW_TB identity rows behind one, FW_TB zero rows in front of the next
+__host__ __device__ inline size_t ps_slab_bytes(int NZP, int nz, int twist) {
+    const int n = nz - 1, mid = twist ? (n + 1) / 2 : n;
+    const size_t rl = (size_t)(twist ? mid + 1 : NZP) + PSL_PAD, nreg = twist ? 2 : 1;
+    return (((size_t)NZP * 4 + 127) & ~(size_t)127) + 2 * nreg * rl * 4 + 32 * 8 + (2 * FW_TB * 32 + 2 * nreg * rl * 32 + 3 * FW_TB * 32) * 8;
+}
 template <int NT>
 __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s, int slab, const float2* __restrict__ yhat,
-                                              float2* __restrict__ ysol, const float2* __restrict__ ip32) {
-    constexpr int NTW = 2, SW = 16 * NTW;
+                                              float2* __restrict__ ysol, const float2* __restrict__ ip32, int tidx) {
+    // (tidx: the caller's OPAQUE copy of tidx -- everything derived from the thread index here is invariant across the
+    //  iterations of the solve, and the compiler hoisted all of it out of the iteration loop into registers it then spilled)
+    constexpr int SW = 32;
     const int NYP = k.NYP, NZP = k.NZP, n = k.nz - 1;
     const int tw = k.twist, mid = twist_mid(n, tw);
-    const int RCAP = tw ? mid + 1 : NZP, RL = RCAP + 4 * FW_TB, nreg = tw ? 2 : 1;
+    const int RCAP = tw ? mid + 1 : NZP, RL = RCAP + PSL_PAD, nreg = tw ? 2 : 1;
     float* sof = reinterpret_cast<float*>(smem);
-    c32* sj = reinterpret_cast<c32*>(smem + (((long)NZP * 4 + 127) & ~127L));
+    float* f1 = reinterpret_cast<float*>(smem + (((long)NZP * 4 + 127) & ~127L));      // [nreg][RL] o of the elimination sweep's coefficient
+    float* f2 = f1 + nreg * RL;                                                          // ... of the substitution sweep's
+    c32* sj = reinterpret_cast<c32*>(f2 + nreg * RL);
     c32* sa = sj + SW + 2 * FW_TB * SW;                  // -> region 0, row 0
-    c32* sb = sa + (long)nreg * RL * SW;
-    c32* sc = sb + (long)nreg * RL * SW;
+    c32* sp = sa + (long)nreg * RL * SW;                 // inverse pivots, same layout
     auto lidx = [&](int row) { return (tw && row > mid) ? RL + (n + 1 - row) : row; };   // slab row of a matrix row
     const int mode = s >= k.nFreq;
     const long so = (long)s * k.vstride;
-    const int t0 = slab * NTW;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < NZP; i += NT) sof[i] = (float)k.ofz[(long)mode * NZP + i];
+    const int t0 = slab * 2;
+    const int lane = tidx & 63, wave = tidx >> 6;
+    for (int i = tidx; i < NZP; i += NT) sof[i] = (float)k.ofz[(long)mode * NZP + i];
     __syncthreads();
-    // rows of the slab: a = y * ip, and the pre-multiplied coefficients of the two sweeps
-    constexpr int PB = 4;
+    // per-row scalars of the two sweeps; padding rows: zeros in front of a region, identity rows behind it (ip = -1, f1 = 1: x stays)
+    for (int i = tidx; i < nreg * RL; i += NT) { f1[i] = 0.f; f2[i] = 0.f; }
+    __syncthreads();
+    for (int row = tidx; row < NZP; row += NT)
+        if (row >= 1 && row <= n) {
+            const bool bottom = tw && row > mid;
+            f1[lidx(row)] = bottom ? sof[row] : sof[row - 1];
+            f2[lidx(row)] = bottom ? sof[row - 1] : sof[row];
+        }
+    for (int idx = tidx; idx < nreg * FW_TB; idx += NT) {
+        const int reg = idx / FW_TB, o = idx % FW_TB;
+        const int last = tw ? (reg == 0 ? mid : n + 1 - (mid + 1)) : NZP - 1;          // last initialised row of the region
+        f1[reg * RL + last + 1 + o] = 1.f;
+    }
+    // rows of the slab: a = y * ip, and ip
+    constexpr int PB = 7;                        // (108 rows x 32 modes over 512 threads: ONE batch of loads, one round trip)
     for (int b0 = 0; b0 < NZP * SW; b0 += PB * NT) {
-        const int i0 = b0 + threadIdx.x;
+        const int i0 = b0 + tidx;
         float2 yv[PB], ipf[PB];
         bool ok[PB];
 #pragma unroll
@@ -179,32 +230,25 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s
             if (idx < NZP * SW) {
                 const int row = idx / SW, j = idx % SW;
                 const int l = lidx(row) * SW + j;
-                c32 av = c32{0, 0}, p1 = c32{0, 0}, p2 = c32{0, 0};
-                if (ok[u]) {
-                    const c32 ip = c32{ipf[u].x, ipf[u].y};
-                    const c32 bb = sof[row - 1] * ip, cc = sof[row] * ip;
-                    av = c32{yv[u].x, yv[u].y} * ip;
-                    const bool bottom = tw && row > mid;
-                    p1 = bottom ? cc : bb; p2 = bottom ? bb : cc;
-                }
-                sa[l] = av; sb[l] = p1; sc[l] = p2;
+                c32 av = c32{0, 0}, ip = c32{0, 0};
+                if (ok[u]) { ip = c32{ipf[u].x, ipf[u].y}; av = c32{yv[u].x, yv[u].y} * ip; }
+                sa[l] = av; sp[l] = ip;
             }
         }
     }
-    // padding rows: in front of a region zeros; behind a region identity rows for the elimination sweep (a = 0, p1 = -1), zero p2
-    for (int idx = threadIdx.x; idx < nreg * FW_TB * SW; idx += NT) {
+    for (int idx = tidx; idx < nreg * FW_TB * SW; idx += NT) {
         const int reg = idx / (FW_TB * SW), o = idx % (FW_TB * SW);
         const c32 z = c32{0, 0};
         const long front = (long)reg * RL * SW - (long)FW_TB * SW + o;
-        const int last = tw ? (reg == 0 ? mid : n + 1 - (mid + 1)) : NZP - 1;          // last initialised row of the region
+        const int last = tw ? (reg == 0 ? mid : n + 1 - (mid + 1)) : NZP - 1;
         const long back = ((long)reg * RL + last + 1) * SW + o;
-        sa[front] = z; sb[front] = z; sc[front] = z;
-        sa[back] = z; sb[back] = c32{-1.f, 0.f}; sc[back] = z;
+        sa[front] = z; sp[front] = z;
+        sa[back] = z; sp[back] = c32{-1.f, 0.f};
     }
-    if (threadIdx.x < SW) {                                 // join factor 1 / (1 - c c') of the two halves (item_pivot)
-        const int c = t0 * 16 + threadIdx.x;
+    if (tidx < SW) {                                 // join factor 1 / (1 - c c') of the two halves (item_pivot)
+        const int c = t0 * 16 + tidx;
         const float2 jf = (tw && c < k.ny - 1) ? ip32[so + c] : float2{1.f, 0.f};
-        sj[threadIdx.x] = c32{jf.x, jf.y};
+        sj[tidx] = c32{jf.x, jf.y};
     }
     __syncthreads();
     if (wave == 0 && lane < nreg * SW && t0 * 16 + (lane % SW) < k.ny - 1) {
@@ -212,31 +256,33 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s
         const int last = tw ? (half == 0 ? mid : n - mid) : n;      // rows 1..last of this lane's region are real
         const int steps = tw ? mid : n;                             // both halves run the longer count (identity rows)
         c32* ra = sa + (long)half * RL * SW + col;
-        const c32* rb = sb + (long)half * RL * SW + col;
-        const c32* rc = sc + (long)half * RL * SW + col;
+        const c32* rp = sp + (long)half * RL * SW + col;
+        const float* g1 = f1 + half * RL;
+        const float* g2 = f2 + half * RL;
         c32 pt = c32{0, 0};
         {
             c32* pa = ra + SW;
-            const c32* pb = rb + SW;
+            const c32* pb = rp + SW;
+            const float* pf = g1 + 1;
             c32 a0[FW_TB], b0[FW_TB], a1[FW_TB], b1[FW_TB];
             const int nblk = (steps + FW_TB - 1) / FW_TB;
 #pragma unroll
-            for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[t * SW]; b0[t] = pb[t * SW]; }
+            for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[t * SW]; b0[t] = pf[t] * pb[t * SW]; }
             int bk = 0;
             for (; bk + 1 < nblk; bk += 2) {
 #pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { a1[t] = pa[(FW_TB + t) * SW]; b1[t] = pb[(FW_TB + t) * SW]; }
+                for (int t = 0; t < FW_TB; ++t) { a1[t] = pa[(FW_TB + t) * SW]; b1[t] = pf[FW_TB + t] * pb[(FW_TB + t) * SW]; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a0[t], b0[t], pt); pa[t * SW] = pt; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[(2 * FW_TB + t) * SW]; b0[t] = pb[(2 * FW_TB + t) * SW]; }
+                for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[(2 * FW_TB + t) * SW]; b0[t] = pf[2 * FW_TB + t] * pb[(2 * FW_TB + t) * SW]; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a1[t], b1[t], pt); pa[(FW_TB + t) * SW] = pt; }
                 __builtin_amdgcn_sched_barrier(0);
-                pa += 2 * FW_TB * SW; pb += 2 * FW_TB * SW;
+                pa += 2 * FW_TB * SW; pb += 2 * FW_TB * SW; pf += 2 * FW_TB;
             }
             if (bk < nblk) {
 #pragma unroll
@@ -245,7 +291,7 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s
         }
         pt = ra[last * SW];                                   // (the identity rows left it unchanged)
         if (tw) {
-            const c32 p2last = rc[last * SW];
+            const c32 p2last = g2[last] * rp[last * SW];
             const float pre = pt.re, pim = pt.im;
             const float ore = __shfl_xor(pre, SW), oim = __shfl_xor(pim, SW);
             const c32 xmid = (c32{pre, pim} - p2last * c32{ore, oim}) * sj[col];       // meaningful in the top half
@@ -257,26 +303,27 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s
         }
         {
             c32* pa = ra + (long)(last - 1) * SW;
-            const c32* pc = rc + (long)(last - 1) * SW;
+            const c32* pc = rp + (long)(last - 1) * SW;
+            const float* pf = g2 + (last - 1);
             c32 a0[FW_TB], b0[FW_TB], a1[FW_TB], b1[FW_TB];
             const int nblk = (steps - 1 + FW_TB - 1) / FW_TB;
 #pragma unroll
-            for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[-t * SW]; b0[t] = pc[-t * SW]; }
+            for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[-t * SW]; b0[t] = pf[-t] * pc[-t * SW]; }
             int bk = 0;
             for (; bk + 1 < nblk; bk += 2) {
 #pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { a1[t] = pa[-(FW_TB + t) * SW]; b1[t] = pc[-(FW_TB + t) * SW]; }
+                for (int t = 0; t < FW_TB; ++t) { a1[t] = pa[-(FW_TB + t) * SW]; b1[t] = pf[-(FW_TB + t)] * pc[-(FW_TB + t) * SW]; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a0[t], b0[t], pt); pa[-t * SW] = pt; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[-(2 * FW_TB + t) * SW]; b0[t] = pc[-(2 * FW_TB + t) * SW]; }
+                for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[-(2 * FW_TB + t) * SW]; b0[t] = pf[-(2 * FW_TB + t)] * pc[-(2 * FW_TB + t) * SW]; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a1[t], b1[t], pt); pa[-(FW_TB + t) * SW] = pt; }
                 __builtin_amdgcn_sched_barrier(0);
-                pa -= 2 * FW_TB * SW; pc -= 2 * FW_TB * SW;
+                pa -= 2 * FW_TB * SW; pc -= 2 * FW_TB * SW; pf -= 2 * FW_TB;
             }
             if (bk < nblk) {
 #pragma unroll
@@ -289,7 +336,7 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s
     {
         constexpr int NG = SW / 8;
         unsigned short* yb = reinterpret_cast<unsigned short*>(ysol + so);
-        for (int idx = threadIdx.x; idx < NZP * NG; idx += NT) {
+        for (int idx = tidx; idx < NZP * NG; idx += NT) {
             const int row = idx / NG, j0 = (idx % NG) * 8, c0 = t0 * 16 + j0;
             if (c0 >= NYP) continue;
             const c32* src = sa + lidx(row) * SW + j0;
@@ -311,12 +358,20 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s
     __syncthreads();
 }
 
-// LDS of the persistent kernel: 1 KB of scratch + max(the slab scheme, planes of 24 rows + two tiles of 24 rows)
-__host__ __device__ inline size_t ps_tiles_bytes(int NYP) {
-    return (((size_t)PS_ROWS * 4 * NYP * 2 + 64 + 255) & ~(size_t)255) + 2 * (((size_t)PS_ROWS * NYP * 8 + 255) & ~(size_t)255) + 512;
+// LDS of the persistent kernel: 1 KB of scratch | the region the phases share (two tiles [24][NYP] complex64 -- the first one
+// doubles as the bf16 planes of the transforms' operands --, each followed by 4 rows more so that q's 14 fp64 rows fit the
+// tile that is free when q is formed; or the slabs of the tridiagonal
+// solves) | the three coefficient planes
+__host__ __device__ inline size_t ps_tile_bytes(int NYP) { return (((size_t)PS_ROWS * NYP * 8 + 64 + 255) & ~(size_t)255) + (size_t)4 * NYP * 8; }   // tile (+ 64 B over-read pad) + tail
+__host__ __device__ inline size_t ps_shared_bytes(int NYP, int NZP, int nz, int twist) {
+    const size_t a = 2 * ps_tile_bytes(NYP), b = ps_slab_bytes(NZP, nz, twist);
+    return ((a > b ? a : b) + 255) & ~(size_t)255;
+}
+__host__ __device__ inline size_t ps_lds_bytes(int NYP, int NZP, int nz, int twist) {
+    return 1024 + ps_shared_bytes(NYP, NZP, nz, twist) + (size_t)3 * PS_ROWS * NYP * 4 + 64;
 }
 
-#define PS_STAMP(i) if (a.stamps && tid == 0 && it == 3) a.stamps[(long)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();
+#define PS_STAMP(i) if (stampNow) a.stamps[(long)blockIdx.x * 16 + (i)] = wall_clock64();
 
 template <int CW, int SW>
 __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a) {
@@ -326,6 +381,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
     volatile int* sflag = reinterpret_cast<volatile int*>(smem + 256);      // [0] give up
     char* arena = smem + 1024;
     const int tid = threadIdx.x, lane = tid & 63;
+    int tidv = tid, lanev = lane, ljv = lane & 15, g4v = lane >> 4, iyv = tid & (CW - 1);      // opaque copies for the iteration loop (PS_PHASE)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = a.G;
     const int xcd = blockIdx.x & 7, lq = blockIdx.x >> 3, slot = lq / G, jwg = lq - slot * G;
@@ -384,6 +440,10 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
         if (g >= 1 && g <= nz - 1 && iy >= 1 && iy <= ny - 1) inM |= 1u << j;
     }
     auto isIn = [&](int j) { return (inM >> j) & 1u; };
+    // ... as a factor 0 / 1: the rows are computed without branches -- non-interior nodes have harmless coefficients in the planes
+    // (mass 1: no division by zero) and their results are multiplied away.  (One `if (interior)` per row and pass made the
+    // compiler keep twelve 64-bit lane masks in scalar registers, spill them, and branch around every row.)
+    auto mk = [&](int j) -> float { return (float)((inM >> j) & 1u); };
     // element offset of (row j, iy) in a system's [NZP][NYP] arrays: ONE 32-bit lane offset serves every array (uniform base
     // pointer + offset: 64-bit per-row addresses of a dozen arrays were what the register allocator spilled).  eo: the node itself
     // (valid where the row is in the mesh), ei: the node if it is an interior one, else a harmless interior node (unconditional loads)
@@ -392,10 +452,13 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
     auto eo = [&](int j) -> unsigned { return (unsigned)(e0 + j * es); };
     auto ei = [&](int j) -> unsigned { return isIn(j) ? (unsigned)(e0 + j * es) : (unsigned)(NYP + 1); };
     int t0i = tb * NYP + iy, tini = tin * NYP + iy;                     // the same for the tiles in LDS: t0i + j * es; inner neighbour of j = 11
-    // LDS carve: planes [24][4][NYP] bf16 (+ 64 B that the last k-group over-reads), two tiles [24][NYP] complex64
-    unsigned short* PL = reinterpret_cast<unsigned short*>(arena);
-    c32* T0 = reinterpret_cast<c32*>(arena + (((size_t)PS_ROWS * 4 * NYP * 2 + 64 + 255) & ~(size_t)255));
-    c32* T1 = T0 + ((((size_t)PS_ROWS * NYP * 8 + 255) & ~(size_t)255) / 8);
+    // LDS carve (ps_lds_bytes)
+    const size_t tileB = ps_tile_bytes(NYP);
+    c32* T0 = reinterpret_cast<c32*>(arena);
+    c32* T1 = reinterpret_cast<c32*>(arena + tileB);
+    unsigned short* PL = reinterpret_cast<unsigned short*>(arena);       // planes [24][4][NYP] bf16 (+ 64 B the last k-group over-reads): the first tile's space
+    float* coE = reinterpret_cast<float*>(arena + ps_shared_bytes(NYP, k.NZP, nz, k.twist));
+    const PsPl co{coE, coE + PS_ROWS * NYP, coE + 2 * PS_ROWS * NYP};
     // MFMA work split: column tiles of 16 over the waves, at most two per wave (NYP <= 32 NWV)
     const int NTc = NYP >> 4, KG = (NYP + 31) >> 5;
     const int tbase = NTc / NWV, textra = NTc - tbase * NWV;
@@ -414,34 +477,40 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
         const float wf = (float)w;
         float2 *pubR = a.pubR + so, *pubZ = a.pubZ + so, *pubP = a.pubP + so;
         cplx *rsys = k.r + so, *xsys = k.x + so;
-        // ---- coefficients of the 12 tile rows (registers for the whole solve)
-        PsCo co;
+        // ---- coefficients of the tile -> the planes in LDS (the previous system's last reads lie in front of a barrier)
         {
             const float4* cf = k.cf32 + 2 * mo;
-            float vin[PS_J + 1], vout[PS_J + 1];
+            float vin[PS_J + 1], vout[PS_J + 1], fe[PS_J], fw[PS_J], fm[PS_J];
 #pragma unroll
             for (int j = 0; j <= PS_J; ++j) {
                 const int g = gb + gs * j, gc = min(max(g, 0), nz);
                 const unsigned e = (unsigned)(gc * NYP + iyc);
                 const float4 ca = cf[2u * e], cb = cf[2u * e + 1u];
                 const bool rowIn = g >= 0 && g <= nz;
-                if (j < PS_J) { co.cE[j] = rowIn ? ca.z : 0.f; co.cW[j] = rowIn ? ca.w : 0.f; co.dmw[j] = rowIn ? wf * ca.y : 0.f; }
+                if (j < PS_J) { fe[j] = rowIn ? ca.z : 0.f; fw[j] = rowIn ? ca.w : 0.f; fm[j] = rowIn ? wf * ca.y : 0.f; }
                 vin[j] = rowIn ? (c ? cb.y : cb.x) : 0.f;
                 vout[j] = rowIn ? (c ? cb.x : cb.y) : 0.f;
             }
+            float* pe = const_cast<float*>(co.E); float* pm = const_cast<float*>(co.M); float* pv = const_cast<float*>(co.V);
 #pragma unroll
-            for (int j = 0; j < PS_J; ++j) co.cV[j] = vin[j] != 0.f ? vin[j] : vout[j + 1];
+            for (int j = 0; j < PS_J; ++j) {
+                const int ti = t0i + j * es;
+                if (colOK) {
+                    if (iy >= 1) pe[ti] = fe[j];
+                    if (iy == 1) pe[ti - 1] = fw[j];                       // column 0: the coupling of column 1 to the boundary
+                    pm[ti] = (fe[j] != 0.f || fw[j] != 0.f) ? fm[j] : 1.f;   // (non-interior nodes: zero couplings, mass 1)
+                    pv[ti] = vin[j] != 0.f ? vin[j] : vout[j + 1];
+                }
+            }
         }
         // ---- state: r of the own rows (fp64), r of the halo rows (complex64, refreshed from the owners every iteration)
         cplx r64[PS_NO];
         c32 rh[PS_HALO];
-        c32 tt[PS_NO];
 #pragma unroll
         for (int q = 0; q < PS_NO; ++q) {
             const int j = PS_HALO + q, g = gb + gs * j;
             r64[q] = *ps_at(rsys, ei(j));
-            if (!isIn(j)) r64[q] = cplx{0, 0};
-            tt[q] = c32{0, 0};
+            r64[q] = (double)mk(j) * r64[q];
             if (colOK && g >= 1 && g <= nz - 1) {
                 *ps_at(pubR, eo(j)) = float2{(float)r64[q].re, (float)r64[q].im};
                 *ps_at(pubP, eo(j)) = float2{0.f, 0.f};
@@ -451,7 +520,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
 #pragma unroll
         for (int j = 0; j < PS_HALO; ++j) {
             rh[j] = ps_ld_c32(ps_at(pubR, ei(j)));
-            if (!isIn(j)) rh[j] = c32{0, 0};
+            rh[j] = mk(j) * rh[j];
         }
         auto rr = [&](int j) -> c32 { return j < PS_HALO ? rh[j < PS_HALO ? j : 0] : c32{(float)r64[j >= PS_HALO ? j - PS_HALO : 0].re, (float)r64[j >= PS_HALO ? j - PS_HALO : 0].im}; };
 
@@ -461,91 +530,138 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
         bool stalled = false;
         int st = 0;
         double est = 0.0;
+        float2* tbuf = a.tbuf + so;            // t of the own rows (complex64): the rho identity of the two-sweep smoother needs it behind the FDM stage
         it = 0;
+#define PS_PHASE() asm volatile("" : "+v"(e0), "+v"(t0i), "+v"(inM), "+v"(tidv), "+v"(lanev), "+v"(ljv), "+v"(g4v), "+v"(iyv))   /* row offsets / masks are re-derived per PHASE instead of living in registers across all of them */
         for (;;) {
-            asm volatile("" : "+v"(e0), "+v"(t0i), "+v"(tini), "+v"(inM));   // (row offsets and masks are re-derived per iteration instead of living in 60 registers)
-            PS_STAMP(0)
-            // ================= pre-smoother: t = G^2-smoothed residual on the own rows =================
-            c32 u1[PS_J];
-            constexpr int JZ1 = SW == 2 ? 3 : 4;
+            PS_PHASE();
+            const bool stampNow = a.stamps && tid == 0 && it == 2;
+#ifdef HMCMT_PS_DBGX
+            bool dbgFail = false;
+            auto dbg_cmp = [&](const c32* TT, int stage, int jlo) {       // own rows of a tile -> memory; the halo rows' copies against the owners'
+                __syncthreads();
+                const int tw0 = ps_opq(t0i);
 #pragma unroll
-            for (int j = 0; j < PS_J; ++j) {
-                u1[j] = (j >= JZ1 && isIn(j)) ? ps_dinv(co, j, a.wJ, c) * rr(j) : c32{0, 0};
-                if (colOK) T0[t0i + j * es] = u1[j];
+                for (int q = 0; q < PS_NO; ++q) {
+                    const int j = PS_HALO + q, g = gb + gs * j;
+                    if ((iyv < NYP) && g >= 1 && g <= nz - 1) *ps_at(a.yhat + so, eo(j)) = float2{TT[tw0 + j * es].re, TT[tw0 + j * es].im};
+                }
+                if (!sys_sync()) { dbgFail = true; return; }
+#pragma unroll
+                for (int j = 0; j < PS_HALO; ++j) {
+                    if (j < jlo) continue;
+                    const c32 ov = mk(j) * ps_ld_c32(ps_at(a.yhat + so, ei(j)));
+                    const c32 mine = TT[tw0 + j * es];
+                    if ((iyv < NYP) && (ov.re != mine.re || ov.im != mine.im)) {
+                        atomicAdd((unsigned long long*)(a.stamps + 16 * 254 + stage * 5 + j), 1ull);
+                        if (stage == 1 && atomicAdd((unsigned long long*)(a.stamps + 16 * 253), 1ull) == 0ull) {     // one example
+                            double* ex = reinterpret_cast<double*>(a.stamps + 16 * 252);
+                            ex[0] = gb + gs * j; ex[1] = iyv; ex[2] = j; ex[3] = c; ex[4] = ov.re; ex[5] = mine.re; ex[6] = ov.im; ex[7] = mine.im;
+                            ex[8] = rr(j).re; ex[9] = jwg; ex[10] = s; ex[11] = it;
+                            const c32 rp = ps_ld_c32(ps_at(pubR, ei(j)));
+                            ex[12] = rp.re; ex[13] = rr(j).im; ex[14] = rp.im;
+                        }
+                    }
+                }
+                if (!sys_sync()) { dbgFail = true; return; }
+            };
+#endif
+            // the wave's V fragments of the forward transform (constant; KG <= 8 k-groups x 2 column tiles): requested here, they
+            // arrive under the pre-smoother (every phase of this loop is a memory round trip + a little arithmetic: what can be
+            // requested a phase early, is)
+            u4v bfw[8][2];
+            {
+                const int lo = lanev;           // (an opaque offset: the loads stay in the iteration instead of being hoisted out of the solve and spilled)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int kg = min(q, KG - 1);
+                    bfw[q][0] = *ps_at(a.Vb, (unsigned)((kg * NTc + tl0) * 64 + lo));
+                    bfw[q][1] = *ps_at(a.Vb, (unsigned)((kg * NTc + tl1) * 64 + lo));
+                }
+            }
+            PS_STAMP(0)
+            // ================= pre-smoother: z1 = D r (T0) [-> z2 = z1 + w2 D (r - A z1) (T1)] -> t = r - A z on the own rows =================
+            constexpr int JZ1 = SW == 2 ? 3 : 4;
+            {
+                const int tw0 = ps_opq(t0i);
+#pragma unroll
+                for (int j = 0; j < PS_J; ++j) {
+                    const int ti = tw0 + j * es;
+                    const c32 v = j >= JZ1 ? ps_scal(mk(j), ps_cmul(ps_dinv_at(co, ti, es, c, a.wJ), rr(j))) : c32{0, 0};
+                    if ((iyv < NYP)) T0[ti] = v;
+                }
             }
             __syncthreads();
             double p1r = 0, p1i = 0, dum = 0;
             if constexpr (SW == 2) {
-                c32 u2[PS_J];
+                {
+                    const int tw0 = ps_opq(t0i);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) u2[j] = c32{0, 0};
-                ps_apply<4>(co, u1, T0, t0i, es, tini, c, [&](int j, c32 av) __attribute__((always_inline)) {
-                    u2[j] = isIn(j) ? u1[j] + (k.w2 * ps_dinv(co, j, a.wJ, c)) * (rr(j) - av) : c32{0, 0};
+                    for (int j = 0; j < 4; ++j) if ((iyv < NYP)) T1[tw0 + j * es] = c32{0, 0};
+                }
+                ps_rows<4>(co, T0, t0i, es, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+                    const c32 u2 = ps_scal(mk(j), ps_cadd(uc, ps_cmul(ps_scal(k.w2, ps_dinv(dk, dm, a.wJ)), ps_csub(rr(j), av))));
+                    if ((iyv < NYP)) T1[ti] = u2;
+                    const int g = gb + gs * j;
+                    if (j >= PS_HALO && (iyv < NYP) && g >= 1 && g <= nz - 1) *ps_at(pubZ, eo(j)) = float2{u2.re, u2.im};
                 });
-#pragma unroll
-                for (int j = 0; j < PS_J; ++j) if (colOK) T1[t0i + j * es] = u2[j];
                 __syncthreads();
-                ps_apply<5>(co, u2, T1, t0i, es, tini, c, [&](int j, c32 av) __attribute__((always_inline)) {
-                    const int q = j - PS_HALO, g = gb + gs * j;
-                    const c32 rv = rr(j);
-                    tt[q] = isIn(j) ? rv - av : c32{0, 0};
-                    const double sr = (double)rv.re + (double)tt[q].re, si = (double)rv.im + (double)tt[q].im;     // (r' + t) .* z2
-                    p1r += sr * u2[j].re - si * u2[j].im; p1i += sr * u2[j].im + si * u2[j].re;
-                    if (colOK && g >= 1 && g <= nz - 1) *ps_at(pubZ, eo(j)) = float2{u2[j].re, u2[j].im};
-                });
             } else {
-                ps_apply<5>(co, u1, T0, t0i, es, tini, c, [&](int j, c32 av) __attribute__((always_inline)) {
-                    const int q = j - PS_HALO, g = gb + gs * j;
-                    tt[q] = isIn(j) ? rr(j) - av : c32{0, 0};
-                    if (colOK && g >= 1 && g <= nz - 1) *ps_at(pubZ, eo(j)) = float2{u1[j].re, u1[j].im};
-                });
-            }
-            PS_STAMP(1)
-            // ================= forward transform of the own rows: t -> bf16 hi/lo planes in LDS -> MFMA -> yhat =================
-            // (T0 / T1 are not touched: PL is a region of its own)
-            if (colOK) {
 #pragma unroll
-                for (int q = 0; q < PS_NO; ++q) {
-                    const int rho = tb + gs * (PS_HALO + q) - PS_HALO;         // row of the 16-row operand: tile row - 5
-                    unsigned short* b = PL + (long)rho * 4 * NYP + iy;
-                    const unsigned hr = bf16_rn(tt[q].re), hi = bf16_rn(tt[q].im);
-                    b[0] = (unsigned short)hr; b[NYP] = (unsigned short)hi;
-                    b[2 * NYP] = (unsigned short)bf16_rn(tt[q].re - bf16_to_f32(hr));
-                    b[3 * NYP] = (unsigned short)bf16_rn(tt[q].im - bf16_to_f32(hi));
+                for (int j = PS_HALO; j < PS_J; ++j) {
+                    const int g = gb + gs * j;
+                    if ((iyv < NYP) && g >= 1 && g <= nz - 1) *ps_at(pubZ, eo(j)) = float2{T0[ps_opq(t0i) + j * es].re, T0[ps_opq(t0i) + j * es].im};
                 }
             }
-            for (int i = tid; i < 2 * 4 * NYP / 2 + 16; i += NT) reinterpret_cast<unsigned*>(PL)[PS_OWN * 4 * NYP / 2 + i] = 0u;   // rows 14, 15 and the over-read pad
+            // t on the own rows, straight into the bf16 hi/lo planes of the forward transform (the first tile's space: with two sweeps
+            // its readers are behind the barrier above; with one, t is formed from the first tile itself, so a barrier separates them)
+            c32 tv[PS_NO];
+            ps_rows<PS_HALO>(co, SW == 2 ? T1 : T0, t0i, es, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+                const c32 rv = rr(j);
+                tv[j - PS_HALO] = ps_scal(mk(j), ps_csub(rv, av));
+                if (SW == 2) {
+                    const double sr = (double)rv.re + (double)tv[j - PS_HALO].re, si = (double)rv.im + (double)tv[j - PS_HALO].im;     // (r' + t) .* z2
+                    p1r += sr * uc.re - si * uc.im; p1i += sr * uc.im + si * uc.re;
+                }
+            });
+            if (SW == 1) __syncthreads();
+            PS_STAMP(1)
+            PS_PHASE();
+            if ((iyv < NYP)) {
+#pragma unroll
+                for (int q = 0; q < PS_NO; ++q) {
+                    const int j = PS_HALO + q, g = gb + gs * j;
+                    const int rho = tb + gs * j - PS_HALO;                     // row of the 16-row operand: tile row - 5
+                    unsigned short* b = PL + (long)rho * 4 * NYP + iyv;
+                    const unsigned hr = bf16_rn(tv[q].re), hi = bf16_rn(tv[q].im);
+                    b[0] = (unsigned short)hr; b[NYP] = (unsigned short)hi;
+                    b[2 * NYP] = (unsigned short)bf16_rn(tv[q].re - bf16_to_f32(hr));
+                    b[3 * NYP] = (unsigned short)bf16_rn(tv[q].im - bf16_to_f32(hi));
+                    if (SW == 2 && g >= 1 && g <= nz - 1) *ps_at(tbuf, eo(j)) = float2{tv[q].re, tv[q].im};
+                }
+            }
+            for (int i = tidv; i < 2 * 4 * NYP / 2 + 16; i += NT) reinterpret_cast<unsigned*>(PL)[PS_OWN * 4 * NYP / 2 + i] = 0u;   // rows 14, 15 and the over-read pad
             __syncthreads();
+            // ================= forward transform of the own rows: MFMA -> yhat =================
             {
                 f4v acc[2][2];
 #pragma unroll
                 for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
                     for (int t = 0; t < 2; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
-                constexpr int KC = 4;
-                for (int kc = 0; kc < KG; kc += KC) {
-                    u4v bh[KC][2];
 #pragma unroll
-                    for (int q = 0; q < KC; ++q) {
-                        const int kg = min(kc + q, KG - 1);
-                        bh[q][0] = *ps_at(a.Vb, (unsigned)((kg * NTc + tl0) * 64 + lane));
-                        bh[q][1] = *ps_at(a.Vb, (unsigned)((kg * NTc + tl1) * 64 + lane));
-                    }
+                for (int kg = 0; kg < 8; ++kg) {
+                    if (kg < KG) {
 #pragma unroll
-                    for (int q = 0; q < KC; ++q) {
-                        if (kc + q < KG) {
-                            const int kg = kc + q;
+                        for (int rg = 0; rg < 2; ++rg) {
+                            const unsigned short* ap = PL + ((long)(8 * rg + (ljv >> 1)) * 4 + (ljv & 1)) * NYP + 32 * kg + 8 * g4v;
+                            const bf8v ah = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap));
+                            const bf8v al = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap + 2 * NYP));
 #pragma unroll
-                            for (int rg = 0; rg < 2; ++rg) {
-                                const unsigned short* ap = PL + ((long)(8 * rg + (lj >> 1)) * 4 + (lj & 1)) * NYP + 32 * kg + 8 * g4;
-                                const bf8v ah = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap));
-                                const bf8v al = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap + 2 * NYP));
-#pragma unroll
-                                for (int t = 0; t < 2; ++t) {
-                                    const bf8v bhf = __builtin_bit_cast(bf8v, bh[q][t]);
-                                    acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
-                                    acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
-                                }
+                            for (int t = 0; t < 2; ++t) {
+                                const bf8v bhf = __builtin_bit_cast(bf8v, bfw[kg][t]);
+                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
+                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
                             }
                         }
                     }
@@ -557,9 +673,9 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
                         for (int h2 = 0; h2 < 2; ++h2) {
-                            const int rho = 8 * rg + 2 * g4 + h2, g = iz0 + rho;
+                            const int rho = 8 * rg + 2 * g4v + h2, g = iz0 + rho;
                             if (t < ntl && rho < PS_OWN && g <= nz - 1)
-                                *ps_at(yh, (unsigned)(g * NYP + (t0w + t) * 16 + lj)) = float2{acc[rg][t][2 * h2], acc[rg][t][2 * h2 + 1]};
+                                *ps_at(yh, (unsigned)(g * NYP + (t0w + t) * 16 + ljv)) = float2{acc[rg][t][2 * h2], acc[rg][t][2 * h2 + 1]};
                         }
             }
             if constexpr (SW == 2) {
@@ -570,154 +686,183 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             if (!sys_sync()) { alive = false; break; }                         // T1: every row of yhat is in the L2
             PS_STAMP(3)
             // ================= tridiagonal solves of this workgroup's mode slabs =================
-            for (int slab = jwg; slab < nslab; slab += G) ps_slab_solve<NT>(k, arena, s, slab, a.yhat, a.ysol, a.ip32);
+            for (int slab = jwg; slab < nslab; slab += G) ps_slab_solve<NT>(k, arena, s, slab, a.yhat, a.ysol, a.ip32, tidv);
             PS_STAMP(4)
+            u4v bbk[8][2];                                                     // the wave's V' fragments of the back transform: in flight during the wait
+            {
+                const int lo = lanev;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int kg = min(q, KG - 1);
+                    bbk[q][0] = *ps_at(a.Vtb, (unsigned)((kg * NTc + tl0) * 64 + lo));
+                    bbk[q][1] = *ps_at(a.Vtb, (unsigned)((kg * NTc + tl1) * 64 + lo));
+                }
+            }
             if (!sys_sync()) { alive = false; break; }                         // T2: every solved slab is in the L2
             PS_STAMP(5)
+            PS_PHASE();
             ++it;
-            // ================= back transform of the 24 tile rows: planes -> LDS, MFMA, V y -> T0 =================
+            // ================= back transform of the 24 tile rows: planes -> LDS, MFMA, z3 = V y + z2 -> T1 =================
+            // epilogue operands in the MFMA's output layout (lane: column 16 t + ljv, rows 8 rg + 2 g4v + h2): the pre-smoothed
+            // iterate of the owners and, two sweeps, t of the own rows (second part of the rho identity: sum of t .* (V y))
+            float2 zq[3][2][2], tq[3][2][2];
+            float mq[3][2][2];
             {
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(a.ysol + so), 0, (int)(k.vstride * 8), 0x00020000);
                 const int rowU = NYP / 2, n16 = PS_ROWS * rowU;             // 16-byte units per row / in the tile
                 u4v tmp[6];
 #pragma unroll
                 for (int u = 0; u < 6; ++u) {
-                    const int i = min(tid + u * NT, n16 - 1);
+                    const int i = min(tidv + u * NT, n16 - 1);
                     const int row = i / rowU, g = R0 + row;
                     const int gc = min(max(g, 0), nz);
                     tmp[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (gc * rowU + (i - row * rowU)) * 16, 0, 16);
                     if (g < 0 || g > nz) tmp[u] = u4v{0u, 0u, 0u, 0u};
                 }
 #pragma unroll
+                for (int rg = 0; rg < 3; ++rg)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const int tau = 8 * rg + 2 * g4v + h2, g = R0 + tau, col = (t ? tl1 : tl0) * 16 + ljv;
+                            const bool in = g >= 1 && g <= nz - 1 && col >= 1 && col <= ny - 1;
+                            const unsigned e = in ? (unsigned)(g * NYP + col) : (unsigned)(NYP + 1);
+                            zq[rg][t][h2] = ps_ld_f2(ps_at(pubZ, e));
+                            if (SW == 2) tq[rg][t][h2] = (in && tau >= PS_HALO && tau < PS_HALO + PS_OWN) ? *ps_at(tbuf, e) : float2{0.f, 0.f};
+                            mq[rg][t][h2] = in ? 1.f : 0.f;
+                        }
+#pragma unroll
+                for (int j = 0; j < PS_HALO; ++j) rh[j] = ps_ld_c32(ps_at(pubR, ei(j)));      // the owners' r' (no drift of the local copies)
+#pragma unroll
                 for (int u = 0; u < 6; ++u) {
-                    const int i = tid + u * NT;
+                    const int i = tidv + u * NT;
                     if (i < n16) reinterpret_cast<u4v*>(PL)[i] = tmp[u];
                 }
-                if (tid < 16) reinterpret_cast<unsigned*>(PL)[PS_ROWS * 4 * NYP / 2 + tid] = 0u;
+                if (tidv < 16) reinterpret_cast<unsigned*>(PL)[PS_ROWS * 4 * NYP / 2 + tid] = 0u;
             }
             __syncthreads();
-            c32 zz2[PS_J];            // the iterate the FDM correction is added to: z2 (two sweeps) / z1 (one), from its owners
+            double ar = 0, ai = 0, zzs = 0;
             {
                 f4v acc[3][2];
 #pragma unroll
                 for (int rg = 0; rg < 3; ++rg)
 #pragma unroll
                     for (int t = 0; t < 2; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
-                constexpr int KC = 4;
-                for (int kc = 0; kc < KG; kc += KC) {
-                    u4v bh[KC][2];
 #pragma unroll
-                    for (int q = 0; q < KC; ++q) {
-                        const int kg = min(kc + q, KG - 1);
-                        bh[q][0] = *ps_at(a.Vtb, (unsigned)((kg * NTc + tl0) * 64 + lane));
-                        bh[q][1] = *ps_at(a.Vtb, (unsigned)((kg * NTc + tl1) * 64 + lane));
-                    }
+                for (int kg = 0; kg < 8; ++kg) {
+                    if (kg < KG) {
 #pragma unroll
-                    for (int q = 0; q < KC; ++q) {
-                        if (kc + q < KG) {
-                            const int kg = kc + q;
+                        for (int rg = 0; rg < 3; ++rg) {
+                            const unsigned short* ap = PL + ((long)(8 * rg + (ljv >> 1)) * 4 + (ljv & 1)) * NYP + 32 * kg + 8 * g4v;
+                            const bf8v ah = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap));
+                            const bf8v al = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap + 2 * NYP));
 #pragma unroll
-                            for (int rg = 0; rg < 3; ++rg) {
-                                const unsigned short* ap = PL + ((long)(8 * rg + (lj >> 1)) * 4 + (lj & 1)) * NYP + 32 * kg + 8 * g4;
-                                const bf8v ah = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap));
-                                const bf8v al = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap + 2 * NYP));
-#pragma unroll
-                                for (int t = 0; t < 2; ++t) {
-                                    const bf8v bhf = __builtin_bit_cast(bf8v, bh[q][t]);
-                                    acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
-                                    acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
-                                }
+                            for (int t = 0; t < 2; ++t) {
+                                const bf8v bhf = __builtin_bit_cast(bf8v, bbk[kg][t]);
+                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
+                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
                             }
                         }
                     }
                 }
-                // (requested here: in flight during the epilogue and the barrier)
-#pragma unroll
-                for (int j = 0; j < PS_J; ++j) {
-                    zz2[j] = ps_ld_c32(ps_at(pubZ, ei(j)));
-                    if (j < PS_HALO) rh[j] = ps_ld_c32(ps_at(pubR, ei(j)));              // the owners' r' (no drift of the local copies)
-                }
-#pragma unroll
-                for (int j = 0; j < PS_J; ++j)
-                    if (!isIn(j)) { zz2[j] = c32{0, 0}; if (j < PS_HALO) rh[j] = c32{0, 0}; }
 #pragma unroll
                 for (int rg = 0; rg < 3; ++rg)
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
                         for (int h2 = 0; h2 < 2; ++h2) {
-                            const int tau = 8 * rg + 2 * g4 + h2;
-                            if (t < ntl) T0[tau * NYP + (t0w + t) * 16 + lj] = c32{acc[rg][t][2 * h2], acc[rg][t][2 * h2 + 1]};
+                            const int tau = 8 * rg + 2 * g4v + h2;
+                            const float ur = acc[rg][t][2 * h2], ui = acc[rg][t][2 * h2 + 1], m = mq[rg][t][h2];
+                            if (t < ntl) {
+                                T1[tau * NYP + (t0w + t) * 16 + ljv] = c32{m * (ur + zq[rg][t][h2].x), m * (ui + zq[rg][t][h2].y)};
+                                if (SW == 2) {
+                                    const double tr = tq[rg][t][h2].x, ti_ = tq[rg][t][h2].y;
+                                    ar += tr * (double)ur - ti_ * (double)ui; ai += tr * (double)ui + ti_ * (double)ur;
+                                }
+                            }
                         }
             }
+#pragma unroll
+            for (int j = 0; j < PS_HALO; ++j) rh[j] = mk(j) * rh[j];
             __syncthreads();
+#ifdef HMCMT_PS_DBGX
+            dbg_cmp(T1, 0, 0); if (dbgFail) { alive = false; break; }
+#endif
             PS_STAMP(6)
-            // ================= post-smoother =================
-            c32 z3[PS_J], zf[PS_J];
-            double ar = 0, ai = 0, zzs = 0;
-#pragma unroll
-            for (int j = 0; j < PS_J; ++j) {
-                const int g = gb + gs * j;
-                const c32 uv = colOK ? T0[t0i + j * es] : c32{0, 0};
-                z3[j] = isIn(j) ? uv + zz2[j] : c32{0, 0};
-                if (SW == 2 && j >= PS_HALO && isIn(j)) {              // second part of the rho identity: t .* (V y) on the own rows
-                    const double tr = tt[j - PS_HALO].re, ti = tt[j - PS_HALO].im;
-                    ar += tr * (double)uv.re - ti * (double)uv.im; ai += tr * (double)uv.im + ti * (double)uv.re;
-                }
-                if (colOK) T1[t0i + j * es] = z3[j];
+            PS_PHASE();
+            // ================= post-smoother: zf = z3 + [w2] D (r - A z3) (T1 -> T0) [-> z = zf + D (r - A zf) (T0 -> T1)] =================
+            {
+                const int tw0 = ps_opq(t0i);
+                if ((iyv < NYP)) T0[tw0] = c32{0, 0};
             }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 1; ++j) zf[j] = c32{0, 0};
-            ps_apply<1>(co, z3, T1, t0i, es, tini, c, [&](int j, c32 av) __attribute__((always_inline)) {
-                zf[j] = c32{0, 0};
-                if (isIn(j)) {
-                    const c32 d = ps_dinv(co, j, a.wJ, c);
-                    zf[j] = z3[j] + (SW == 2 ? k.w2 * d : d) * (rr(j) - av);
-                }
+            ps_rows<1>(co, T1, t0i, es, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+                const c32 d = ps_dinv(dk, dm, a.wJ);
+                const c32 zf = ps_scal(mk(j), ps_cadd(uc, ps_cmul(SW == 2 ? ps_scal(k.w2, d) : d, ps_csub(rr(j), av))));
+                if ((iyv < NYP)) T0[ti] = zf;
                 if (j >= PS_HALO) {
-                    zzs += (double)zf[j].re * zf[j].re + (double)zf[j].im * zf[j].im;
+                    zzs += (double)zf.re * zf.re + (double)zf.im * zf.im;
                     if (SW == 1) {
                         const cplx rv = r64[j >= PS_HALO ? j - PS_HALO : 0];
-                        ar += rv.re * (double)zf[j].re - rv.im * (double)zf[j].im; ai += rv.re * (double)zf[j].im + rv.im * (double)zf[j].re;
+                        ar += rv.re * (double)zf.re - rv.im * (double)zf.im; ai += rv.re * (double)zf.im + rv.im * (double)zf.re;
                     }
                 }
             });
-            ps_block_sum3<NWV>(ar, ai, zzs, sh);
+            ps_block_sum3<NWV>(ar, ai, zzs, sh);                              // (its barriers also complete the tile)
             if (tid == 0) {
                 k.partA[(long)s * MAXNB + jwg] = cplx{ar, ai};
                 a.partZZ[(long)s * MAXNB + jwg] = zzs;
                 sys_arrive();                                                  // R1, first half
             }
+#ifdef HMCMT_PS_DBGX
+            dbg_cmp(T0, 1, 1); if (dbgFail) { alive = false; break; }
+#endif
             if constexpr (SW == 2) {
-                // second post-sweep, while the partial sums travel: z5 = z4 + D (r - A z4) on rows j >= 2
+                // second post-sweep, while the partial sums travel (rows j >= 2)
+                {
+                    const int tw0 = ps_opq(t0i);
 #pragma unroll
-                for (int j = 0; j < PS_J; ++j) if (colOK) T0[t0i + j * es] = zf[j];
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < 2; ++j) z3[j] = c32{0, 0};
-                ps_apply<2>(co, zf, T0, t0i, es, tini, c, [&](int j, c32 av) __attribute__((always_inline)) {
-                    z3[j] = isIn(j) ? zf[j] + ps_dinv(co, j, a.wJ, c) * (rr(j) - av) : c32{0, 0};     // (z3 reused: the preconditioned residual z)
+                    for (int j = 0; j < 2; ++j) if ((iyv < NYP)) T1[tw0 + j * es] = c32{0, 0};
+                }
+                ps_rows<2>(co, T0, t0i, es, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+                    const c32 z5 = ps_scal(mk(j), ps_cadd(uc, ps_cmul(ps_dinv(dk, dm, a.wJ), ps_csub(rr(j), av))));
+                    if ((iyv < NYP)) T1[ti] = z5;
                 });
-            } else {
-#pragma unroll
-                for (int j = 0; j < PS_J; ++j) z3[j] = zf[j];
             }
+            c32* const TZ = SW == 2 ? T1 : T0;           // the preconditioned residual z
+            c32* const TP = SW == 2 ? T0 : T1;           // ... the new direction goes to the other tile, q behind z's
+            cplx* const Qs = reinterpret_cast<cplx*>(TZ);
             if (a.precondOnly) {
+                __syncthreads();
 #pragma unroll
                 for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q, g = gb + gs * j;
-                    if (colOK && g >= 1 && g <= nz - 1) *ps_at(a.zout + so, eo(j)) = float2{z3[j].re, z3[j].im};
+                    const c32 zv = TZ[ps_opq(t0i) + j * es];
+                    if ((iyv < NYP) && g >= 1 && g <= nz - 1) *ps_at(a.zout + so, eo(j)) = float2{zv.re, zv.im};
                 }
                 if (!sys_wait()) alive = false;
                 break;
             }
             PS_STAMP(7)
+            PS_PHASE();
             c32 pold[PS_J];                                                    // the old direction, from its owners: in flight during the wait
 #pragma unroll
             for (int j = 0; j < PS_J; ++j) pold[j] = ps_ld_c32(ps_at(pubP, ei(j)));      // (masked where it is used)
-            if (!sys_wait()) { alive = false; break; }                         // R1, second half
+            if (!sys_wait()) { alive = false; break; }                         // R1, second half (its barrier also completes z's tile)
             PS_STAMP(8)
+            // the fp64 stencil coefficients of the own rows: requested with the partial sums (ONE round trip for all of them);
+            // the diagonal is minus the sum of the couplings
+            const double *dMm = k.dM + mo, *cYm = k.cY + mo, *cZm = k.cZ + mo;
+            double dm64[PS_NO], ce64[PS_NO], cw64[PS_NO], ci64[PS_NO], co64[PS_NO];
+#pragma unroll
+            for (int q = 0; q < PS_NO; ++q) {
+                const int j = PS_HALO + q;
+                const unsigned e = (unsigned)ps_opq((int)ei(j));
+                dm64[q] = *ps_at(dMm, e);
+                ce64[q] = *ps_at(cYm, e); cw64[q] = *ps_at(cYm, e - 1u);
+                const double cs = *ps_at(cZm, e), cn = *ps_at(cZm, e - (unsigned)NYP);
+                ci64[q] = c ? cn : cs; co64[q] = c ? cs : cn;
+            }
             // ================= scalars: rho, error estimate, convergence, beta =================
             cplx rz;
             double zz, xx;
@@ -743,76 +888,85 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             if (!on) break;
             const cplx be = first ? cplx{0, 0} : rz / rhoPrev;
             rhoPrev = rz; rhoCur = rz;
-            // ================= p = z + beta p (rounded to complex64), q = A p, p'q =================
+            // ================= p = z + beta p (rounded to complex64) -> the other tile; q = A p; p'q =================
             constexpr int JP = SW == 2 ? 2 : 1;
-            c32 pn[PS_J];
+            {
+                const int tw0 = ps_opq(t0i);
 #pragma unroll
-            for (int j = 0; j < PS_J; ++j) {
-                pn[j] = c32{0, 0};
-                if (j >= JP && isIn(j)) {
-                    const cplx v = cplx{(double)z3[j].re, (double)z3[j].im} + be * cplx{(double)pold[j].re, (double)pold[j].im};
-                    pn[j] = c32{(float)v.re, (float)v.im};
+                for (int j = 0; j < PS_J; ++j) {
+                    const int ti = tw0 + j * es;
+                    c32 pv = c32{0, 0};
+                    if (j >= JP) {
+                        const c32 zv = TZ[ti];
+                        const double pr = (double)pold[j].re, pi = (double)pold[j].im;
+                        const double vr = __builtin_fma(be.re, pr, __builtin_fma(-be.im, pi, (double)zv.re)), vi = __builtin_fma(be.re, pi, __builtin_fma(be.im, pr, (double)zv.im));
+                        pv = ps_scal(mk(j), c32{(float)vr, (float)vi});
+                    }
+                    if ((iyv < NYP)) TP[ti] = pv;
                 }
-                if (colOK) T1[t0i + j * es] = pn[j];
             }
             __syncthreads();
+#ifdef HMCMT_PS_DBGX
+            {   // diagnosis: the halo rows next to the own rows take the OWNERS' p (an extra exchange + synchronisation)
+                const int tw0 = ps_opq(t0i);
+#pragma unroll
+                for (int q = 0; q < PS_NO; ++q) {
+                    const int j = PS_HALO + q, g = gb + gs * j;
+                    if ((iyv < NYP) && g >= 1 && g <= nz - 1) *ps_at(a.yhat + so, eo(j)) = float2{TP[tw0 + j * es].re, TP[tw0 + j * es].im};
+                }
+                if (!sys_sync()) { alive = false; break; }
+                int bad = 0;
+#pragma unroll
+                for (int j = JP; j < PS_HALO; ++j) {
+                    const c32 ov = mk(j) * ps_ld_c32(ps_at(a.yhat + so, ei(j)));
+                    const c32 mine = TP[tw0 + j * es];
+                    if (ov.re != mine.re || ov.im != mine.im) bad |= 1 << j;
+                    if ((iyv < NYP)) TP[tw0 + j * es] = ov;
+                }
+                if (bad && a.stamps) atomicAdd((unsigned long long*)(a.stamps + 16 * 255 + 12), (unsigned long long)1);
+                __syncthreads();
+            }
+#endif
+            PS_PHASE();
             c32 qh[PS_HALO];                                                   // the halo rows' q: fp32
 #pragma unroll
             for (int j = 0; j < PS_HALO; ++j) qh[j] = c32{0, 0};
-            ps_apply<JP + 1, PS_HALO>(co, pn, T1, t0i, es, tini, c, [&](int j, c32 av) __attribute__((always_inline)) { qh[j] = av; });
-            // own rows: fp64 coefficients, in two batches (registers); q itself waits in LDS for alpha (each thread reads back
-            // what it wrote: the planes / first tile are free here; 28 registers less across the wait)
-            cplx* Qs = reinterpret_cast<cplx*>(arena);
+            ps_rows<JP + 1, PS_HALO>(co, TP, t0i, es, c, [&](int j, int, c32, c32 av, float, float) __attribute__((always_inline)) { qh[j] = av; });
+            // own rows: fp64; q itself waits in LDS for alpha (each thread reads back what it wrote: z's tile is free now)
             double pqr = 0, pqi = 0, dum2 = 0;
-            const double *dKm = k.dK + mo, *dMm = k.dM + mo, *cYm = k.cY + mo, *cZm = k.cZ + mo;
-            auto qrows = [&](auto QLO, auto QHI) {
-                constexpr int q0 = decltype(QLO)::value, q1 = decltype(QHI)::value;
-                double dk64[q1 - q0], dm64[q1 - q0], ce64[q1 - q0], cw64[q1 - q0], ci64[q1 - q0], co64[q1 - q0];
+            {
+                const int tq0 = ps_opq(t0i);
 #pragma unroll
-                for (int q = q0; q < q1; ++q) {
+                for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q;
-                    const unsigned e = ei(j);
-                    dk64[q - q0] = *ps_at(dKm, e); dm64[q - q0] = w * *ps_at(dMm, e);
-                    ce64[q - q0] = *ps_at(cYm, e); cw64[q - q0] = *ps_at(cYm, e - 1u);
-                    const double cs = *ps_at(cZm, e), cn = *ps_at(cZm, e - (unsigned)NYP);
-                    ci64[q - q0] = c ? cn : cs; co64[q - q0] = c ? cs : cn;
+                    const int ti = tq0 + j * es;
+                    const c32 pc = TP[ti], pe = TP[ti + 1], pw = TP[ti - 1], pi = TP[ti + es], po = TP[ti - es];
+                    const double dmw = w * dm64[q];
+                    const double dk = -((ce64[q] + cw64[q]) + (ci64[q] + co64[q]));
+                    cplx acc = cplx{dk * (double)pc.re - dmw * (double)pc.im, dk * (double)pc.im + dmw * (double)pc.re};
+                    acc += ce64[q] * cplx{(double)pe.re, (double)pe.im};
+                    acc += cw64[q] * cplx{(double)pw.re, (double)pw.im};
+                    acc += ci64[q] * cplx{(double)pi.re, (double)pi.im};
+                    acc += co64[q] * cplx{(double)po.re, (double)po.im};
+                    const cplx qv = (double)mk(j) * acc;                      // (a non-interior node: coefficients of a harmless node, p = 0)
+                    pqr += (double)pc.re * qv.re - (double)pc.im * qv.im;
+                    pqi += (double)pc.re * qv.im + (double)pc.im * qv.re;
+                    if ((iyv < NYP)) Qs[ti - PS_HALO * NYP] = qv;
                 }
-#pragma unroll
-                for (int q = q0; q < q1; ++q) {
-                    const int j = PS_HALO + q;
-                    const int ti = t0i + j * es;
-                    cplx qv = cplx{0, 0};
-                    if (isIn(j)) {
-                        const c32 pe = T1[ti + 1], pw = T1[ti - 1];
-                        const c32 pi = j + 1 < PS_J ? pn[j + 1 < PS_J ? j + 1 : j] : T1[tini];
-                        const c32 po = pn[j - 1], pc = pn[j];
-                        cplx acc = cplx{dk64[q - q0] * (double)pc.re - dm64[q - q0] * (double)pc.im, dk64[q - q0] * (double)pc.im + dm64[q - q0] * (double)pc.re};
-                        acc += ce64[q - q0] * cplx{(double)pe.re, (double)pe.im};
-                        acc += cw64[q - q0] * cplx{(double)pw.re, (double)pw.im};
-                        acc += ci64[q - q0] * cplx{(double)pi.re, (double)pi.im};
-                        acc += co64[q - q0] * cplx{(double)po.re, (double)po.im};
-                        qv = acc;
-                        pqr += (double)pc.re * acc.re - (double)pc.im * acc.im;
-                        pqi += (double)pc.re * acc.im + (double)pc.im * acc.re;
-                    }
-                    if (colOK) Qs[ti - PS_HALO * NYP] = qv;
-                }
-            };
-            qrows(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+            }
             __builtin_amdgcn_sched_barrier(0);
-            qrows(std::integral_constant<int, 4>{}, std::integral_constant<int, PS_NO>{});
-            // x of the own rows: requested here, used behind R2
-            cplx xv[PS_NO];
+            cplx xv[PS_NO];                                                    // x of the own rows: requested here, used behind R2
 #pragma unroll
             for (int q = 0; q < PS_NO; ++q) {
                 const int j = PS_HALO + q, g = gb + gs * j;
-                xv[q] = *ps_at(xsys, (colOK && g >= 1 && g <= nz - 1) ? eo(j) : (unsigned)(NYP + 1));
+                xv[q] = *ps_at(xsys, ((iyv < NYP) && g >= 1 && g <= nz - 1) ? eo(j) : (unsigned)(NYP + 1));
             }
             ps_block_sum3<NWV>(pqr, pqi, dum2, sh);
             if (tid == 0) { k.partPQ[(long)s * MAXNB + jwg] = cplx{pqr, pqi}; sys_arrive(); }
             PS_STAMP(9)
             if (!sys_wait()) { alive = false; break; }                         // R2
             PS_STAMP(10)
+            PS_PHASE();
             // ================= alpha; x += alpha p, r -= alpha q; publish r', p =================
             cplx al;
             {
@@ -823,24 +977,26 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             }
             const c32 alf = c32{(float)al.re, (float)al.im};
             double xxs = 0, dum3 = 0, dum4 = 0;
+            {
+                const int tu0 = ps_opq(t0i);
 #pragma unroll
-            for (int q = 0; q < PS_NO; ++q) {
-                const int j = PS_HALO + q, g = gb + gs * j;
-                cplx xn = xv[q];
-                if (isIn(j)) {
-                    xn = xv[q] + al * cplx{(double)pn[j].re, (double)pn[j].im};
-                    *ps_at(xsys, eo(j)) = xn;
-                    r64[q] -= al * Qs[t0i + j * es - PS_HALO * NYP];
-                }
-                if (colOK && g >= 1 && g <= nz - 1) {
-                    xxs += cabs2(xn);                                          // (rows 1 .. nz-1, all columns: as the launch-per-phase kernels)
-                    *ps_at(pubR, eo(j)) = float2{(float)r64[q].re, (float)r64[q].im};
-                    *ps_at(pubP, eo(j)) = float2{pn[j].re, pn[j].im};
+                for (int q = 0; q < PS_NO; ++q) {
+                    const int j = PS_HALO + q, g = gb + gs * j;
+                    if ((iyv < NYP) && g >= 1 && g <= nz - 1) {
+                        // (p and q vanish on boundary and pad nodes: x keeps its Dirichlet values there, r stays zero)
+                        const c32 pv = TP[tu0 + j * es];
+                        const cplx xn = xv[q] + al * cplx{(double)pv.re, (double)pv.im};
+                        *ps_at(xsys, eo(j)) = xn;
+                        r64[q] -= al * Qs[tu0 + j * es - PS_HALO * NYP];
+                        xxs += cabs2(xn);                                      // (rows 1 .. nz-1, all columns: as the launch-per-phase kernels)
+                        *ps_at(pubR, eo(j)) = float2{(float)r64[q].re, (float)r64[q].im};
+                        *ps_at(pubP, eo(j)) = float2{pv.re, pv.im};
+                    }
                 }
             }
 #pragma unroll
             for (int j = 0; j < PS_HALO; ++j)
-                if (j >= JP + 1) rh[j] = isIn(j) ? rh[j] - alf * qh[j] : c32{0, 0};
+                if (j >= JP + 1) rh[j] = mk(j) * (rh[j] - alf * qh[j]);
             ps_block_sum3<NWV>(xxs, dum3, dum4, sh);
             if (tid == 0) k.partB[(long)s * MAXNB + jwg] = xxs;
             PS_STAMP(11)
@@ -873,3 +1029,4 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
         }
     }
 }
+#pragma clang fp contract(fast)
