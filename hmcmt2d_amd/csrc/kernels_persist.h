@@ -193,21 +193,23 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s
     const long so = (long)s * k.vstride;
     const int t0 = slab * 2;
     const int lane = tidx & 63, wave = tidx >> 6;
-    for (int i = tidx; i < NZP; i += NT) sof[i] = (float)k.ofz[(long)mode * NZP + i];
-    __syncthreads();
-    // per-row scalars of the two sweeps; padding rows: zeros in front of a region, identity rows behind it (ip = -1, f1 = 1: x stays)
-    for (int i = tidx; i < nreg * RL; i += NT) { f1[i] = 0.f; f2[i] = 0.f; }
-    __syncthreads();
-    for (int row = tidx; row < NZP; row += NT)
-        if (row >= 1 && row <= n) {
-            const bool bottom = tw && row > mid;
-            f1[lidx(row)] = bottom ? sof[row] : sof[row - 1];
-            f2[lidx(row)] = bottom ? sof[row - 1] : sof[row];
+    // per-row scalars of the two sweeps (o of the row's coefficient; constant over the solve, 2 KB: straight from memory, one pass);
+    // padding rows: zeros in front of a region, identity rows behind it (ip = -1, f1 = 1: x stays)
+    (void)sof;
+    {
+        const double* ofz = k.ofz + (long)mode * NZP;
+        for (int i = tidx; i < nreg * RL; i += NT) {
+            const int reg = i / RL, rl = i - reg * RL;
+            const int row = (tw && reg == 1) ? n + 1 - rl : rl;
+            const int last = tw ? (reg == 0 ? mid : n + 1 - (mid + 1)) : NZP - 1;          // last initialised row of the region
+            float v1 = 0.f, v2 = 0.f;
+            if (rl >= 1 && rl <= last && row >= 1 && row <= n) {
+                const bool bottom = tw && reg == 1;
+                const float o0 = (float)ofz[row - 1], o1 = (float)ofz[row];
+                v1 = bottom ? o1 : o0; v2 = bottom ? o0 : o1;
+            } else if (rl > last && rl <= last + FW_TB) v1 = 1.f;
+            f1[i] = v1; f2[i] = v2;
         }
-    for (int idx = tidx; idx < nreg * FW_TB; idx += NT) {
-        const int reg = idx / FW_TB, o = idx % FW_TB;
-        const int last = tw ? (reg == 0 ? mid : n + 1 - (mid + 1)) : NZP - 1;          // last initialised row of the region
-        f1[reg * RL + last + 1 + o] = 1.f;
     }
     // rows of the slab: a = y * ip, and ip
     constexpr int PB = 7;                        // (108 rows x 32 modes over 512 threads: ONE batch of loads, one round trip)
@@ -705,8 +707,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             // ================= back transform of the 24 tile rows: planes -> LDS, MFMA, z3 = V y + z2 -> T1 =================
             // epilogue operands in the MFMA's output layout (lane: column 16 t + ljv, rows 8 rg + 2 g4v + h2): the pre-smoothed
             // iterate of the owners and, two sweeps, t of the own rows (second part of the rho identity: sum of t .* (V y))
-            float2 zq[3][2][2], tq[3][2][2];
-            float mq[3][2][2];
+            float2 zq[3][2][2];
             {
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(a.ysol + so), 0, (int)(k.vstride * 8), 0x00020000);
                 const int rowU = NYP / 2, n16 = PS_ROWS * rowU;             // 16-byte units per row / in the tile
@@ -729,8 +730,6 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                             const bool in = g >= 1 && g <= nz - 1 && col >= 1 && col <= ny - 1;
                             const unsigned e = in ? (unsigned)(g * NYP + col) : (unsigned)(NYP + 1);
                             zq[rg][t][h2] = ps_ld_f2(ps_at(pubZ, e));
-                            if (SW == 2) tq[rg][t][h2] = (in && tau >= PS_HALO && tau < PS_HALO + PS_OWN) ? *ps_at(tbuf, e) : float2{0.f, 0.f};
-                            mq[rg][t][h2] = in ? 1.f : 0.f;
                         }
 #pragma unroll
                 for (int j = 0; j < PS_HALO; ++j) rh[j] = ps_ld_c32(ps_at(pubR, ei(j)));      // the owners' r' (no drift of the local copies)
@@ -772,19 +771,19 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
                         for (int h2 = 0; h2 < 2; ++h2) {
-                            const int tau = 8 * rg + 2 * g4v + h2;
-                            const float ur = acc[rg][t][2 * h2], ui = acc[rg][t][2 * h2 + 1], m = mq[rg][t][h2];
-                            if (t < ntl) {
-                                T1[tau * NYP + (t0w + t) * 16 + ljv] = c32{m * (ur + zq[rg][t][h2].x), m * (ui + zq[rg][t][h2].y)};
-                                if (SW == 2) {
-                                    const double tr = tq[rg][t][h2].x, ti_ = tq[rg][t][h2].y;
-                                    ar += tr * (double)ur - ti_ * (double)ui; ai += tr * (double)ui + ti_ * (double)ur;
-                                }
-                            }
+                            const int tau = 8 * rg + 2 * g4v + h2, g = R0 + tau, col = (t ? tl1 : tl0) * 16 + ljv;
+                            const float m = (g >= 1 && g <= nz - 1 && col >= 1 && col <= ny - 1) ? 1.f : 0.f;
+                            const float ur = acc[rg][t][2 * h2], ui = acc[rg][t][2 * h2 + 1];
+                            if (t < ntl) T1[tau * NYP + (t0w + t) * 16 + ljv] = c32{m * (ur + zq[rg][t][h2].x), m * (ui + zq[rg][t][h2].y)};
                         }
             }
 #pragma unroll
             for (int j = 0; j < PS_HALO; ++j) rh[j] = mk(j) * rh[j];
+            float2 t7[PS_NO], z7[PS_NO];       // two sweeps: t and z2 of the own rows, for the second part of the rho identity: sum of t .* (V y), V y = z3 - z2
+            if (SW == 2) {
+#pragma unroll
+                for (int q = 0; q < PS_NO; ++q) { t7[q] = *ps_at(tbuf, ei(PS_HALO + q)); z7[q] = ps_ld_f2(ps_at(pubZ, ei(PS_HALO + q))); }
+            }
             __syncthreads();
 #ifdef HMCMT_PS_DBGX
             dbg_cmp(T1, 0, 0); if (dbgFail) { alive = false; break; }
@@ -802,6 +801,11 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                 if ((iyv < NYP)) T0[ti] = zf;
                 if (j >= PS_HALO) {
                     zzs += (double)zf.re * zf.re + (double)zf.im * zf.im;
+                    if (SW == 2) {
+                        const int q = j >= PS_HALO ? j - PS_HALO : 0;
+                        const double m = (double)mk(j), tr = m * t7[q].x, ti_ = m * t7[q].y, ur = (double)uc.re - (double)z7[q].x, ui = (double)uc.im - (double)z7[q].y;
+                        ar += tr * ur - ti_ * ui; ai += tr * ui + ti_ * ur;
+                    }
                     if (SW == 1) {
                         const cplx rv = r64[j >= PS_HALO ? j - PS_HALO : 0];
                         ar += rv.re * (double)zf.re - rv.im * (double)zf.im; ai += rv.re * (double)zf.im + rv.im * (double)zf.re;
