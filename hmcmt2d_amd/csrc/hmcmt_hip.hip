@@ -1836,6 +1836,16 @@ int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z) {
     return 0;
 }
 
+// the persistent solve kernel and this context: out = {threads per workgroup / 2 (0: the problem does not fit the kernel),
+// workgroups per system, system slots per XCD, enabled (HMCMT_PERSIST, no placement failure so far), solves it has run,
+// solves handed back to the launch-per-phase loop because the workgroups of a system were not on one XCD}
+int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out) {
+    if (!ctx || !out) return HMCMT_EINVAL;
+    out[0] = ctx->persistCW; out[1] = ctx->persistG; out[2] = ctx->persistSlots; out[3] = ctx->persistOn ? 1 : 0;
+    out[4] = ctx->persistSolves; out[5] = ctx->persistFallbacks;
+    return 0;
+}
+
 // z = P^-1 r by the persistent solve kernel's own preconditioner (its first application, then it stops): the comparator of
 // hmcmt_debug_precond for tests/test_gpu_persist.py.  sweeps = 1 / 2 smoothing sweeps per side.
 int hmcmt_debug_persist_precond(hmcmt_ctx* ctx, int32_t sweeps, const double* r, double* z) {

@@ -1,0 +1,137 @@
+"""The persistent solve kernel (hmcmt2d_amd/csrc/kernels_persist.h; one launch per solve, a system = G workgroups of one XCD):
+its preconditioner against the launch-per-phase one, whole evaluations against the launch-per-phase loop and the oracle,
+bitwise repeatability, the hand-back to the launch loop, and what it must leave behind for the host's fp64 restart.
+The solves it replaces: MTFwdSolver/mt2DTE.jl:47-55, mt2DTM.jl:46-54, MTSensitivity/compJacTMatVec.jl:220-229, 291-300."""
+import numpy as np
+import pytest
+
+from hmcmt2d_amd.lib import HipContext
+from tests.helpers import make_problem, oracle_eval, relmax, ragged_problem, gerr_split
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(monkeypatch, mesh, data, inv, persist, sweeps=None, **kw):
+    monkeypatch.setenv("HMCMT_PERSIST", "1" if persist else "0")
+    if sweeps is None:
+        monkeypatch.delenv("HMCMT_SWEEPS", raising=False)
+    else:
+        monkeypatch.setenv("HMCMT_SWEEPS", str(sweeps))
+    return HipContext(mesh, data, inv, **kw)
+
+
+@pytest.mark.parametrize("sweeps", [1, 2])
+def test_preconditioner_of_the_persistent_kernel_is_the_launch_per_phase_one(monkeypatch, sweeps):
+    """z = P^-1 r through the kernel's first preconditioner application (hmcmt_debug_persist_precond) against the
+    launch-per-phase kernels (hmcmt_debug_precond): the same operator up to the fp32 / bf16 rounding of its stages (the
+    smoother works from a complex64 copy of r and forms its diagonal from the float couplings; measured 1e-6 .. 4e-6)."""
+    mesh, data, inv, m = make_problem("cfg2")                 # 3 workgroups per system: halo rows, a short last workgroup
+    ctx = _ctx(monkeypatch, mesh, data, inv, persist=False, sweeps=sweeps)
+    ctx.forward(m)
+    info = ctx.persist_info()
+    assert info["threads_half"] == 64 and info["workgroups_per_system"] == 3
+    shape = (ctx.S, ctx.NZP, ctx.NYP)
+    rng = np.random.default_rng(3)
+    x = np.zeros(shape, complex)
+    x[:, 1:ctx.nz, 1:ctx.ny] = rng.standard_normal((ctx.S, ctx.nz - 1, ctx.ny - 1)) + 1j * rng.standard_normal((ctx.S, ctx.nz - 1, ctx.ny - 1))
+    for v in (x, np.cumsum(np.cumsum(x, axis=1), axis=2) / 50.0 * (np.abs(x) > 0)):
+        z0 = ctx.debug_precond(v).reshape(shape)
+        z1 = ctx.debug_persist_precond(v, sweeps).reshape(shape)
+        assert max(relmax(z1[s], z0[s]) for s in range(ctx.S)) < 2e-5
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,sweeps", [("cfg2", 1), ("cfg2", 2), ("tiny", 2)])
+def test_persistent_solve_equals_the_launch_per_phase_loop_and_the_oracle(monkeypatch, name, sweeps):
+    """One evaluation with the true-residual check on, persistent kernel against launch-per-phase loop: the same iteration
+    counts (+-1 per solve kind in the maximum), results to the solver tolerance, the oracle's values at the parity levels
+    of tests/test_gpu_parity.py; the statistics say which path ran."""
+    mesh, data, inv, m = make_problem(name)
+    res = {}
+    for persist in (False, True):
+        ctx = _ctx(monkeypatch, mesh, data, inv, persist, sweeps, verify=True)
+        res[persist] = ctx.grad(m) + (ctx.stats(), ctx.persist_info())
+        ctx.close()
+    (p0, f0, g0, s0, i0), (p1, f1, g1, s1, i1) = res[False], res[True]
+    assert i0["solves"] == 0 and i1["solves"] == 2 and i1["placement_fallbacks"] == 0 and i1["enabled"] == 1
+    assert s1["status"] == 0 and s1["fallback_solves"] == 0 and s1["true_res_max"] < 1e-9
+    assert abs(s1["iters_fwd_max"] - s0["iters_fwd_max"]) <= 1 and abs(s1["iters_adj_max"] - s0["iters_adj_max"]) <= 1
+    assert abs(s1["iters_fwd_sum"] - s0["iters_fwd_sum"]) <= 0.05 * s0["iters_fwd_sum"] + 2
+    assert relmax(p1, p0) < 1e-9 and abs(f1 - f0) / abs(f0) < 1e-9 and relmax(g1, g0) < 1e-8
+    po, mo, go = oracle_eval(mesh, data, inv, m)
+    assert relmax(p1, po) < 1e-9 and abs(f1 - mo) / mo < 1e-9
+    shallow, deep = gerr_split(g1, go, inv, mesh)
+    assert shallow < 1e-8 and deep < 1e-7
+
+
+def test_persistent_solve_on_a_ragged_mesh_and_masked_data(monkeypatch):
+    """Sizes that are multiples of nothing (one workgroup with two own rows left over, pad columns, a polarisation with
+    masked data, a fixed cell): against the oracle."""
+    mesh, data, inv, m = ragged_problem(37, 22, 3, 5, 4, 3)
+    ctx = _ctx(monkeypatch, mesh, data, inv, True, verify=True)
+    p, f, g = ctx.grad(m)
+    st, info = ctx.stats(), ctx.persist_info()
+    ctx.close()
+    assert info["solves"] == 2 and st["status"] == 0 and st["true_res_max"] < 1e-9
+    po, mo, go = oracle_eval(mesh, data, inv, m)
+    assert relmax(p, po) < 1e-9 and abs(f - mo) / mo < 1e-9 and relmax(g, go) < 1e-7
+
+
+def test_persistent_solve_is_bitwise_repeatable(monkeypatch):
+    """Every reduction is a fixed-order sum over per-workgroup partials and the repeated halo arithmetic is written with
+    explicit FMAs: two cold evaluations of one model give the same bits -- and so do two contexts."""
+    mesh, data, inv, m = make_problem("cfg2")
+    outs = []
+    for _ in range(2):
+        ctx = _ctx(monkeypatch, mesh, data, inv, True, warm_start=False)
+        a = ctx.grad(m)
+        b = ctx.grad(m + 0.0)
+        assert ctx.persist_info()["solves"] >= 2
+        ctx.close()
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
+        outs.append(a)
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_two_contexts_use_the_launch_per_phase_loop(monkeypatch):
+    """Two persistent kernels on one device could each hold CUs the other's missing workgroups need (they spin at their
+    barriers): with a second context alive in the process both run the launch-per-phase loop -- same answers."""
+    mesh, data, inv, m = make_problem("cfg2")
+    c1 = _ctx(monkeypatch, mesh, data, inv, True)
+    ref = c1.grad(m)
+    assert c1.persist_info()["solves"] == 2
+    c2 = _ctx(monkeypatch, mesh, data, inv, True)
+    a, b = c1.grad(m + 1e-3), c2.grad(m + 1e-3)
+    assert c1.persist_info()["solves"] == 2 and c2.persist_info()["solves"] == 0
+    assert relmax(a[0], b[0]) < 1e-9 and relmax(a[2], b[2]) < 1e-8
+    c2.close()
+    c1.grad(m - 1e-3)                                      # alone again: the kernel is back
+    assert c1.persist_info()["solves"] == 4
+    c1.close()
+    assert relmax(ref[0], a[0]) < 0.1                      # (sanity: the models are close)
+
+
+def test_stagnating_persistent_solve_hands_over_to_the_fp64_restart(monkeypatch):
+    """HMCMT_STALL_IT = 1 makes the stagnation watch fire at once: the kernel stops, leaves x, r, the iteration counts and
+    the active flags behind, and the host's classic loop finishes the systems with the fp64 preconditioner."""
+    monkeypatch.setenv("HMCMT_STALL_IT", "1")
+    mesh, data, inv, m = make_problem("cfg2")
+    ctx = _ctx(monkeypatch, mesh, data, inv, True, verify=True)
+    p, f, g = ctx.grad(m)
+    st = ctx.stats()
+    ctx.close()
+    assert st["fallback_solves"] >= 1 and st["status"] == 0 and st["true_res_max"] < 1e-9
+    po, mo, go = oracle_eval(mesh, data, inv, m)
+    assert relmax(p, po) < 1e-9 and relmax(g, go) < 1e-7
+
+
+def test_iteration_cap_is_reported_by_the_persistent_kernel(monkeypatch):
+    mesh, data, inv, m = make_problem("cfg2")
+    ctx = _ctx(monkeypatch, mesh, data, inv, True, maxit=3)
+    with pytest.raises(Exception) as e:
+        ctx.grad(m)
+    assert "ENOCONV" in str(e.value)
+    ctx.set_options(maxit=2000)
+    p, f, g = ctx.grad(m)                                  # ... and the context recovers (cold start after a failure)
+    assert ctx.stats()["status"] == 0
+    ctx.close()
