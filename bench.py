@@ -436,7 +436,52 @@ def main():
                  "fdm_transform": ((1, 13), (1, 13)),  # read y (1), z0 = D r (3), z = V y + z0 (3), A z, 4 passes, r'z and |z|^2 (2)
                  "post_smoother": ((1, 6), (1, 6))}
 
+        def build_roofline_persistent(prof, cnt, population, every):
+            """Round 4: the whole solve is ONE launch of k_cocg_persist (kernels_persist.h).  Its algorithmic bytes are those of the
+            iterations it performs, by the per-iteration figure of rounds 1-3 (every vector of the four-kernel iteration read /
+            written once: 224 B per unknown with one smoothing sweep per side, 264 B with two; 96 / 104 B for the preconditioner
+            application in front of the first iteration) -- the kernel itself keeps r in registers and its tiles in LDS and moves
+            far fewer bytes through memory (`traffic`, from the PMC passes), so `frac` says how fast the ITERATIONS are against
+            what the launch-per-phase form had to stream, not how close to the HBM roof this kernel's own traffic is."""
+            f2 = cnt.get("solves_two_sweeps", 0) / max(cnt["solves"], 1)
+            it_sys, pre_sys = cnt["active_iter_systems"], cnt["start_systems"]
+            ms_c, n_c = prof["spmv"]                         # (the launch is timed under this category)
+            avg_us = 1e3 * ms_c / max(n_c, 1)
+            it_bpu, pre_bpu = 224.0 + 40.0 * f2, 96.0 + 8.0 * f2
+            tot_bytes = Usys * (it_bpu * it_sys + pre_bpu * pre_sys)
+            nbytes = tot_bytes / max(n_c, 1)
+            ach = nbytes / (avg_us * 1e-6) / 1e9 if n_c else 0.0
+            (sp1, vp1), (sp2, vp2) = (3, 33), (5, 45)        # canonical CSR: stencil products and vector passes of an iteration (sum of CANON)
+            can_it = (sp1 * B_spmv + vp1 * 16 * Usys) * (1 - f2) + (sp2 * B_spmv + vp2 * 16 * Usys) * f2
+            can = can_it * it_sys / max(n_c, 1) / (avg_us * 1e-6) / 1e9 if n_c else 0.0
+            serial = max(cnt.get("serial_iterations", 0), 1)
+            it_us = 1e3 * ms_c / serial                      # kernel time / iterations of its slowest system (+ 1 application): the iteration's latency
+            sys_per_it = (it_sys + pre_sys) / serial
+            kpad = 32 * ((ctx.NYP + 31) // 32)
+            flops = 2 * 2.0 * (2 * ctx.NZP) * ctx.NYP * kpad * (1.0 + 24.0 / 14.0) * (it_sys + pre_sys) / max(n_c, 1)
+            entry = {"kernel": "k_cocg_persist (the whole COCG solve of all systems in one launch: a system = %d workgroups of one XCD, r in "
+                               "registers, tiles and stencil coefficients in LDS, four per-system synchronisations per iteration)" % ctx.persist_info()["workgroups_per_system"],
+                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic(name, "persist"), "avg_launch_us": avg_us,
+                     "frac_canonical_csr": can / HBM_PEAK_GBS, "evaluations_sampled": cnt["evaluations"], "sampled_every": every,
+                     "event_bracket_overhead_us_subtracted": prof_overhead_us, "rocprofv3_avg_launch_us": rocprof_avg_us(name, "persist"),
+                     "launches_timed": n_c, "bytes_per_launch": nbytes, "ms_timed": ms_c,
+                     "system_iterations_per_launch": it_sys / max(n_c, 1), "preconditioner_applications_per_launch": pre_sys / max(n_c, 1),
+                     "bytes_per_unknown_and_iteration": it_bpu, "us_per_iteration": it_us, "active_systems_per_iteration": sys_per_it,
+                     "active_systems_per_launch": sys_per_it, "launches_per_iteration": 0,
+                     "mfma": {"flops_per_launch": flops, "achieved_tflops": flops / (avg_us * 1e-6) / 1e12, "peak_tflops_bf16_dense": 2500.0},
+                     "population": population}
+            iteration = {"kernels": 1, "two_sweep_fraction": f2, "bytes": Usys * it_bpu * sys_per_it, "us": it_us,
+                         "achieved": Usys * it_bpu * sys_per_it / (it_us * 1e-6) / 1e9 if n_c else 0.0, "unit": "GB/s",
+                         "frac": Usys * it_bpu * sys_per_it / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS if n_c else 0.0,
+                         "note": "one preconditioned COCG iteration inside the persistent kernel: kernel time / iterations of its slowest system; "
+                                 "bytes = the four-kernel iteration's algorithmic bytes x the systems active in an average iteration"}
+            step_bytes = tot_bytes / max(cnt["evaluations"], 1)
+            return [entry], iteration, step_bytes
+
         def build_roofline(prof, cnt, population, every):
+            if cnt.get("persistent_solves", 0) > 0 and cnt["persistent_solves"] >= cnt["solves"]:
+                return build_roofline_persistent(prof, cnt, population, every)
             fwd_fused = ctx.NYP <= 256                      # the library's own rule (launch_fdm_fwd): wide meshes run the separate kernels
             back_fused = fwd_fused                          # ... and k_back_post goes with it (launch_back_post)
             # round 3: on the fused path x += alpha p and |x|^2 (x in and out, p in: 40 B per unknown) ride along in k_fdm_fwd,
@@ -535,7 +580,7 @@ def main():
                                    f"(L = {LTRAJ}, dt = {DT}, prior lambda = {LAMBDA}, bounds rho in [1, 1e4] ohm-m, accept/reject) "
                                    f"started at the rough state m = ln 0.01 + 0.3 N(0,1)",
                        "systems_per_step": ctx.S, "unknowns_per_system": nyi * nzi, "nparam": nAC,
-                       "solver": "batched fp64 COCG, Jacobi/fast-diagonalisation/Jacobi preconditioner (FDM stage in bf16/fp32; one or two Jacobi sweeps per side, chosen per solve), tol 1e-11 (error estimate), warm start",
+                       "solver": "batched fp64 COCG, Jacobi/fast-diagonalisation/Jacobi preconditioner (FDM stage in bf16/fp32; one or two Jacobi sweeps per side, chosen per solve), tol 1e-11 (error estimate), warm start; " + ("one persistent launch per solve (kernels_persist.h)" if ctx.persist_info()["solves"] else "four launches per iteration"),
                        "iters_fwd_max": st["iters_fwd_max"], "iters_adj_max": st["iters_adj_max"],
                        "smoother_sweeps_last_evaluation": st["smoother_sweeps"],
                        "parallelism": f"chains x{world}" if world > 1 else "1 chain"},

@@ -143,7 +143,9 @@ struct hmcmt_ctx {
     double profMs[HMCMT_NCAT] = {0};
     long long profN[HMCMT_NCAT] = {0};
     unsigned long long* d_cnt = nullptr;   // device counter behind Solver::cntActive
-    long long profStartSys = 0, profEvals = 0, profSolves = 0, profSolves2 = 0;   // sampled: systems active at the start of a solve (summed), evaluations, solves, solves with two sweeps
+    long long profStartSys = 0, profEvals = 0, profSolves = 0, profSolves2 = 0;
+    long long profSerialIts = 0, profPersistSolves = 0;    // sampled: sum over solves of (iterations of the slowest system + 1), solves run by the persistent kernel
+    bool evalSampled = false;              // the evaluation whose records are parsed next was a sampled one   // sampled: systems active at the start of a solve (summed), evaluations, solves, solves with two sweeps
     int nSysOn = 0;
     // leapfrog / prior
     double *d_mref = nullptr, *d_invM = nullptr, *d_wmVal = nullptr, *d_p = nullptr, *d_mcur = nullptr, *d_g = nullptr;
@@ -588,6 +590,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
         *(volatile int*)ctx->h_prog = 0;
         { ProfScope ps(ctx, 2); int prc = launch_persist(ctx, k.sweeps, 0, nullptr); if (prc) return prc; }
         ++ctx->persistSolves;
+        if (k.cntActive) ++ctx->profPersistSolves;
         if (kind == 0) launch_adjoint_side(ctx);        // (the host is free while the device solves)
         { int prc = spin_progress(ctx, PS_DONE); if (prc) return prc; }
         if (*(volatile int*)(ctx->h_stall + 2)) {
@@ -791,6 +794,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     ++ctx->evalCount;
     ctx->sv.cntActive = (ctx->profMask && ctx->evalCount % ctx->profEvery == 0) ? ctx->d_cnt : nullptr;
     if (ctx->sv.cntActive) ++ctx->profEvals;
+    ctx->evalSampled = ctx->sv.cntActive != nullptr;
     const int nodes = v.NZP * (v.ny + 1);
     const size_t vecBytes = (size_t)S * v.vstride * sizeof(cplx);
     // initial guesses (options.warm_start): verify checks against the cold right-hand side
@@ -996,6 +1000,7 @@ void parse_stats(hmcmt_ctx* ctx, bool withAdjoint) {
             if (h_status[kind * S + s] != 0 && ctx->stats.status == 0) ctx->stats.status = h_status[kind * S + s];
             if (h_err[kind * S + s] > ctx->stats.err_est_max) ctx->stats.err_est_max = h_err[kind * S + s];
         }
+        if (ctx->evalSampled) ctx->profSerialIts += mx + 1;
         if (kind == 0) { ctx->stats.iters_fwd_max = mx; ctx->stats.iters_fwd_sum = sum; }
         else { ctx->stats.iters_adj_max = mx; ctx->stats.iters_adj_sum = sum; }
         // first convergence poll of the next evaluation: where this one actually finished (the loop itself only
@@ -1557,6 +1562,7 @@ int hmcmt_profile_counters(hmcmt_ctx* ctx, int64_t* out) {
     unsigned long long c = 0;
     HIPCHK(hipMemcpy(&c, ctx->d_cnt, sizeof c, hipMemcpyDeviceToHost));
     out[0] = (int64_t)c; out[1] = ctx->profStartSys; out[2] = ctx->profEvals; out[3] = ctx->profSolves; out[4] = ctx->profSolves2;
+    out[5] = ctx->profSerialIts; out[6] = ctx->profPersistSolves;
     return 0;
 }
 
@@ -1737,6 +1743,7 @@ int hmcmt_profile(hmcmt_ctx* ctx, int32_t enable) {
     ctx->profMask = (unsigned)enable;
     for (int i = 0; i < HMCMT_NCAT; ++i) { ctx->profMs[i] = 0; ctx->profN[i] = 0; }
     ctx->profStartSys = ctx->profEvals = ctx->profSolves = ctx->profSolves2 = 0;
+    ctx->profSerialIts = ctx->profPersistSolves = 0;
     HIPCHK(hipMemsetAsync(ctx->d_cnt, 0, sizeof(unsigned long long), ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;

@@ -1014,6 +1014,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             if (isIn(j)) *ps_at(rsys, eo(j)) = r64[q];
         }
         if (jwg == 0 && tid == 0) {
+            if (k.cntActive) atomicAdd(k.cntActive, (unsigned long long)max(it - 1, 0));   // (roofline accounting: iterations x systems of a sampled evaluation)
             k.iters[s] = it - 1;
             k.errEst[s] = est;
             if (st) { k.status[s] = st; *k.failHost = st; }

@@ -344,11 +344,13 @@ class HipContext:
         return us.value
 
     def profile_counters(self):
-        """{active_iter_systems, start_systems, evaluations, solves, solves_two_sweeps} of the sampled evaluations
-        (hmcmt_profile_counters)."""
-        o = np.zeros(5, dtype=np.int64)
+        """{active_iter_systems, start_systems, evaluations, solves, solves_two_sweeps, serial_iterations, persistent_solves}
+        of the sampled evaluations (hmcmt_profile_counters): serial_iterations = sum over the sampled solves of the slowest
+        system's iterations + 1 (the preconditioner application in front of the first one)."""
+        o = np.zeros(7, dtype=np.int64)
         self._check(self.lib.hmcmt_profile_counters(self.h, o.ctypes.data_as(c_int64_p)))
-        return dict(zip(("active_iter_systems", "start_systems", "evaluations", "solves", "solves_two_sweeps"), (int(x) for x in o)))
+        return dict(zip(("active_iter_systems", "start_systems", "evaluations", "solves", "solves_two_sweeps", "serial_iterations",
+                         "persistent_solves"), (int(x) for x in o)))
 
     def _vec(self, a):
         a = np.ascontiguousarray(a, dtype=np.complex128)

@@ -208,8 +208,9 @@ int hmcmt_profile_overhead(const hmcmt_ctx* ctx, double* us);
  * systems still active (device counter, incremented by k_spmv_fused), out[1] = sum over the sampled solves of the systems
  * active at their start (the preconditioner is applied once before the first iteration), out[2] = evaluations sampled,
  * out[3] = solves sampled, out[4] = those of them that ran two smoothing sweeps per side (hmcmt_stats.smoother_sweeps).
- * Reset by hmcmt_profile. */
-int hmcmt_profile_counters(hmcmt_ctx* ctx, int64_t* out /*[5]*/);
+ * out[5] = sum over the sampled solves of (iterations of the slowest system + 1): the serial length of the solves; out[6] = sampled
+ * solves run by the persistent solve kernel (one launch per solve).  Reset by hmcmt_profile. */
+int hmcmt_profile_counters(hmcmt_ctx* ctx, int64_t* out /*[7]*/);
 
 /* sizes the roofline accounting needs: out = {NYP, NZP, S, ny, nz, zid, nblk} */
 int hmcmt_dims(const hmcmt_ctx* ctx, int32_t* out);

@@ -62,8 +62,9 @@ out.append(f"Bench line: **{d['value']:.1f} leapfrog steps/s** ({d['ms_per_step'
 ri, rs = d["roofline_iteration"], d["roofline_step"]
 out.append(f"Roofline (HIP events, every launch of every n-th evaluation of the timed region (n: `sampled_every` in the JSON); numerators scaled by the device-counted number "
            f"of active systems): dominant kernel `{d['roofline']['kernel'].split(' ')[0]}` {d['roofline']['achieved']:.0f} GB/s algorithmic = "
-           f"**{d['roofline']['frac']:.3f}** of the 8 TB/s HBM peak at {d['roofline']['active_systems_per_launch']:.1f} active systems per launch; one COCG iteration "
-           f"({ri['kernels']} launches) {ri['us']:.1f} us = {ri['frac']:.3f}; whole step (iteration kernels' bytes / wall time) {rs['frac']:.3f}.\n")
+           f"**{d['roofline']['frac']:.3f}** of the 8 TB/s HBM peak at {d['roofline']['active_systems_per_launch']:.1f} active systems per " +
+           ("iteration (one launch = one whole solve, " + f"{d['roofline'].get('avg_launch_us', 0):.0f} us); one COCG iteration inside it" if 'us_per_iteration' in d['roofline'] else "launch; one COCG iteration") +
+           f" ({ri['kernels']} launch{'es' if ri['kernels'] != 1 else ''}) {ri['us']:.1f} us = {ri['frac']:.3f}; whole step (iteration bytes / wall time) {rs['frac']:.3f}.\n")
 nev = None
 for r in rows:
     if "k_sigma" in r["Name"]:

@@ -19,7 +19,8 @@ import sys
 from collections import defaultdict
 
 CATS = {"fdm_transform": ("k_back_post", "k_transform_lp"), "tridiagonal": ("k_fdm_fwd", "k_thomas32"),
-        "spmv": ("k_spmv_fused",), "post_smoother": ("k_post",), "vector_ops": ("k_update_fused",)}
+        "spmv": ("k_spmv_fused",), "post_smoother": ("k_post",), "vector_ops": ("k_update_fused",),
+        "persist": ("k_cocg_persist",)}          # round 4: the whole solve in one launch (kernels_persist.h)
 
 
 def per_kernel(d, counter):
