@@ -162,6 +162,8 @@ struct hmcmt_ctx {
     size_t persistLds = 0;
     unsigned* d_psync = nullptr;          // [8 * slots][32] barrier words | exit counter | fail word
     size_t psyncBytes = 0;
+    u4v* d_prec = nullptr;                // [S][MAXNB][2][8] records of the kernel's reductions (tagged, never cleared)
+    unsigned long long persistTag = 0;    // ... the tag base of the next launch
     long long* d_pstamps = nullptr;       // HMCMT_STAMPS=persist
     long long persistSolves = 0, persistFallbacks = 0;
     bool counted = false;                 // this context is in g_liveContexts
@@ -499,6 +501,8 @@ int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout) {
     a.partZZ = ctx->d_partZZ;
     a.pubR = k.t2_32; a.pubZ = k.zs32; a.pubP = k.p32a;
     a.yhat = k.y32; a.ysol = k.t32; a.tbuf = k.z4_32;
+    ctx->persistTag += 1ull << 20;           // (an iteration takes two tags; a solve never has 2^19 iterations)
+    a.rec = ctx->d_prec; a.tagBase = ctx->persistTag;
     a.ip32 = ctx->d_invp32;
     a.zout = zout;
     a.stamps = ctx->d_pstamps;
@@ -1215,6 +1219,14 @@ static int persist_setup(hmcmt_ctx* ctx) {
     HIPCHK(hipMalloc(&q, ctx->psyncBytes));
     ctx->allocs.push_back(q);
     ctx->d_psync = reinterpret_cast<unsigned*>(q);
+    {
+        const size_t recBytes = (size_t)k.S * MAXNB * 2 * 8 * 16;
+        void* r = nullptr;
+        HIPCHK(hipMalloc(&r, recBytes));
+        HIPCHK(hipMemset(r, 0, recBytes));
+        ctx->allocs.push_back(r);
+        ctx->d_prec = reinterpret_cast<u4v*>(r);
+    }
     if (const char* es = getenv("HMCMT_STAMPS")) if (!strcmp(es, "persist")) {
         HIPCHK(hipMalloc((void**)&ctx->d_pstamps, sizeof(long long) * 16 * 256));
         HIPCHK(hipMemset(ctx->d_pstamps, 0, sizeof(long long) * 16 * 256));

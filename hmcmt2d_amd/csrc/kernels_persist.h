@@ -53,6 +53,8 @@ struct PersistArgs {
     float2* yhat;              // [S][vstride] complex64 rows of the forward transform
     float2* ysol;              // [S][vstride] solved slabs, pre-split bf16 planes (store_t32's format)
     const float2* ip32;        // inverse pivots (complex64)
+    u4v* rec;                  // [S][MAXNB][2][8] 16-byte granules {value, tag} / {tag, value}: the partial sums of the two reductions of an iteration
+    unsigned long long tagBase; // ... their tags are tagBase + 2 * iteration (+ 1): unique over the launches of a context, the records are never cleared
     float2* tbuf;              // [S][vstride] complex64: t of the own rows across the FDM stage (two sweeps: the rho identity)
     float2* zout;              // precondOnly: z = P^-1 r
     long long* stamps;         // [workgroup][16] s_memtime stamps of one iteration's phases (HMCMT_STAMPS=persist)
@@ -99,6 +101,52 @@ __device__ __forceinline__ c32 ps_cmul(c32 a, c32 b) { return c32{__builtin_fmaf
 __device__ __forceinline__ c32 ps_cadd(c32 a, c32 b) { return c32{a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ c32 ps_csub(c32 a, c32 b) { return c32{a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ c32 ps_scal(float f, c32 a) { return c32{f * a.re, f * a.im}; }
+// ---- A reduction over the G workgroups of a system WITHOUT a separate barrier: the data is the flag.  Workgroup j publishes its
+// partial sums as 16-byte granules carrying a tag (the iteration's), each value twice -- {value, tag} and {tag, value}: a 16-byte
+// store has been observed untorn on gfx950, and were one ever torn, the two copies would disagree --, and wave 0 of every workgroup
+// reads all G records in ONE load batch per poll (lane j: workgroup j's) until every tag is the awaited one: the sums are in
+// registers the moment the last workgroup has published.  (Counter barrier + a load of the partial sums behind it: one memory
+// round trip more per reduction, two reductions per iteration.)  Passing it also orders memory like the barrier did: every
+// workgroup has published, i.e. has consumed what it read before.
+template <int NV>
+__device__ __forceinline__ void ps_publish(u4v* rec, const double (&v)[NV], unsigned long long tag) {      // ONE thread
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
+        rec[2 * i] = u4v{(unsigned)b, (unsigned)(b >> 32), (unsigned)tag, (unsigned)(tag >> 32)};
+        rec[2 * i + 1] = u4v{(unsigned)tag, (unsigned)(tag >> 32), (unsigned)b, (unsigned)(b >> 32)};
+    }
+}
+template <int NV>
+__device__ __forceinline__ bool ps_collect(const u4v* recSys, int which, int G, unsigned long long tag, double (&tot)[NV], int* fail, int lane) {   // wave 0, all lanes
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u4v*>(recSys), 0, MAXNB * 2 * 8 * 16, 0x00020000);
+    const unsigned off = (unsigned)(((min(lane, G - 1) * 2 + which) * 8) * 16);
+    for (unsigned spins = 0;; ++spins) {
+        u4v g[2 * NV];
+#pragma unroll
+        for (int i = 0; i < 2 * NV; ++i) g[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16u * i, 0, 16);
+        bool ok = true;
+        double val[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const unsigned long long v0 = (unsigned long long)g[2 * i][0] | ((unsigned long long)g[2 * i][1] << 32), t0 = (unsigned long long)g[2 * i][2] | ((unsigned long long)g[2 * i][3] << 32);
+            const unsigned long long t1 = (unsigned long long)g[2 * i + 1][0] | ((unsigned long long)g[2 * i + 1][1] << 32), v1 = (unsigned long long)g[2 * i + 1][2] | ((unsigned long long)g[2 * i + 1][3] << 32);
+            ok = ok && t0 == tag && t1 == tag && v0 == v1;
+            val[i] = __longlong_as_double((long long)v0);
+        }
+        if (__builtin_amdgcn_ballot_w64(ok || lane >= G) == ~0ull) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) tot[i] = wave_sum(lane < G ? val[i] : 0.0);
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 0x3ff) == 0x3ff) {
+            if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (spins > PS_SPIN_LIMIT) { if (lane == 0) __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+        }
+    }
+}
+
 // The float stencil coefficients of the tile live in LDS for the whole solve (three planes [24][NYP] behind the region the
 // phases share: 48 registers per thread in the first version, which the compiler spilled): E = coupling to the east neighbour
 // (the west one is the neighbour's E; column 0 holds the coupling of column 1 to the boundary), M = omega * mass, V = coupling
@@ -119,6 +167,9 @@ constexpr int PS_GRP = HMCMT_PS_GRP;      // rows the scheduler may interleave i
 template <int JLO, int JHI = PS_J, class F>
 __device__ __forceinline__ void ps_rows(const PsPl& co, const c32* __restrict__ S, int t0i_, int es, int c, F&& f) {
     const int t0i = ps_opq(t0i_);
+    // (a rolling window over the column -- the row's outer neighbour and the row itself are the previous row's centre and inner
+    //  neighbour, three tile reads per row instead of five -- was measured and lost: the values carried from row to row cost the
+    //  two-sweep kernel 60 more spilled registers, 46 -> 51 us per iteration)
 #pragma unroll
     for (int j = JLO; j < JHI; ++j) {
         const int ti = t0i + j * es;
@@ -211,30 +262,35 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s
             f1[i] = v1; f2[i] = v2;
         }
     }
-    // rows of the slab: a = y * ip, and ip
-    constexpr int PB = 7;                        // (108 rows x 32 modes over 512 threads: ONE batch of loads, one round trip)
-    for (int b0 = 0; b0 < NZP * SW; b0 += PB * NT) {
-        const int i0 = b0 + tidx;
-        float2 yv[PB], ipf[PB];
-        bool ok[PB];
+    // rows of the slab: a = y * ip, and ip -- two modes (16 bytes) per load, one batch
+    {
+        constexpr int PB = 4, HW = SW / 2;          // (108 rows x 16 mode pairs over 512 threads: 3.4 pairs per thread)
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(yhat + so), 0, (int)(k.vstride * 8), 0x00020000);
+        for (int b0 = 0; b0 < NZP * HW; b0 += PB * NT) {
+            const int i0 = b0 + tidx;
+            f4v yv[PB], ipf[PB];
+            bool ok0[PB], ok1[PB];
 #pragma unroll
-        for (int u = 0; u < PB; ++u) {
-            const int idx = min(i0 + u * NT, NZP * SW - 1);
-            const int row = idx / SW, c = t0 * 16 + (idx % SW);
-            ok[u] = row >= 1 && row <= n && c < k.ny - 1;
-            const unsigned e = (unsigned)((ok[u] ? row : 1) * NYP + (ok[u] ? c : 1));
-            yv[u] = ps_ld_f2(ps_at(yhat + so, e));
-            ipf[u] = *ps_at(ip32 + so, e);
-        }
+            for (int u = 0; u < PB; ++u) {
+                const int idx = min(i0 + u * NT, NZP * HW - 1);
+                const int row = idx / HW, c = t0 * 16 + 2 * (idx % HW);
+                const bool rok = row >= 1 && row <= n;
+                ok0[u] = rok && c < k.ny - 1; ok1[u] = rok && c + 1 < k.ny - 1;
+                const unsigned e = (unsigned)((rok ? row : 1) * NYP + min(c, NYP - 2));
+                yv[u] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(ry, e * 8u, 0, 16));
+                ipf[u] = *reinterpret_cast<const f4v*>(ps_at(ip32 + so, e));
+            }
 #pragma unroll
-        for (int u = 0; u < PB; ++u) {
-            const int idx = i0 + u * NT;
-            if (idx < NZP * SW) {
-                const int row = idx / SW, j = idx % SW;
-                const int l = lidx(row) * SW + j;
-                c32 av = c32{0, 0}, ip = c32{0, 0};
-                if (ok[u]) { ip = c32{ipf[u].x, ipf[u].y}; av = c32{yv[u].x, yv[u].y} * ip; }
-                sa[l] = av; sp[l] = ip;
+            for (int u = 0; u < PB; ++u) {
+                const int idx = i0 + u * NT;
+                if (idx < NZP * HW) {
+                    const int row = idx / HW, j = 2 * (idx % HW);
+                    const int l = lidx(row) * SW + j;
+                    c32 a0 = c32{0, 0}, p0 = c32{0, 0}, a1 = c32{0, 0}, p1 = c32{0, 0};
+                    if (ok0[u]) { p0 = c32{ipf[u][0], ipf[u][1]}; a0 = c32{yv[u][0], yv[u][1]} * p0; }
+                    if (ok1[u]) { p1 = c32{ipf[u][2], ipf[u][3]}; a1 = c32{yv[u][2], yv[u][3]} * p1; }
+                    sa[l] = a0; sa[l + 1] = a1; sp[l] = p0; sp[l + 1] = p1;
+                }
             }
         }
     }
@@ -527,7 +583,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
         auto rr = [&](int j) -> c32 { return j < PS_HALO ? rh[j < PS_HALO ? j : 0] : c32{(float)r64[j >= PS_HALO ? j - PS_HALO : 0].re, (float)r64[j >= PS_HALO ? j - PS_HALO : 0].im}; };
 
         cplx rhoPrev = cplx{0, 0}, rhoCur = cplx{0, 0};
-        double errRef = 0.0;
+        double errRef = 0.0, xxPrev = 0.0;
         int errRefIt = 0;
         bool stalled = false;
         int st = 0;
@@ -680,10 +736,9 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                                 *ps_at(yh, (unsigned)(g * NYP + (t0w + t) * 16 + ljv)) = float2{acc[rg][t][2 * h2], acc[rg][t][2 * h2 + 1]};
                         }
             }
-            if constexpr (SW == 2) {
-                ps_block_sum3<NWV>(p1r, p1i, dum, sh);
-                if (tid == 0) k.partR[(long)s * MAXNB + jwg] = cplx{p1r, p1i};
-            }
+            // (two sweeps: the first part of the rho identity, the sum of (r' + t) .* z2 over the own rows, stays in registers and
+            //  joins the second part in the reduction behind the first post-sweep: one block reduction less)
+            (void)dum;
             PS_STAMP(2)
             if (!sys_sync()) { alive = false; break; }                         // T1: every row of yhat is in the L2
             PS_STAMP(3)
@@ -812,11 +867,11 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                     }
                 }
             });
+            if (SW == 2) { ar += p1r; ai += p1i; }
             ps_block_sum3<NWV>(ar, ai, zzs, sh);                              // (its barriers also complete the tile)
-            if (tid == 0) {
-                k.partA[(long)s * MAXNB + jwg] = cplx{ar, ai};
-                a.partZZ[(long)s * MAXNB + jwg] = zzs;
-                sys_arrive();                                                  // R1, first half
+            if (tid == 0) {                                                    // R1, first half: this workgroup's partial sums
+                const double v4[4] = {ar, ai, zzs, xxPrev};
+                ps_publish<4>(a.rec + (((long)s * MAXNB + jwg) * 2 + 0) * 8, v4, a.tagBase + 2ull * (unsigned)it);
             }
 #ifdef HMCMT_PS_DBGX
             dbg_cmp(T0, 1, 1); if (dbgFail) { alive = false; break; }
@@ -844,7 +899,6 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                     const c32 zv = TZ[ps_opq(t0i) + j * es];
                     if ((iyv < NYP) && g >= 1 && g <= nz - 1) *ps_at(a.zout + so, eo(j)) = float2{zv.re, zv.im};
                 }
-                if (!sys_wait()) alive = false;
                 break;
             }
             PS_STAMP(7)
@@ -852,10 +906,16 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             c32 pold[PS_J];                                                    // the old direction, from its owners: in flight during the wait
 #pragma unroll
             for (int j = 0; j < PS_J; ++j) pold[j] = ps_ld_c32(ps_at(pubP, ei(j)));      // (masked where it is used)
-            if (!sys_wait()) { alive = false; break; }                         // R1, second half (its barrier also completes z's tile)
+            // R1, second half: wave 0 collects the G records (no counter, no second round trip), the totals go round through LDS
+            if (wave == 0) {
+                double t4[4] = {0, 0, 0, 0};
+                const bool okc = ps_collect<4>(a.rec + (long)s * MAXNB * 2 * 8, 0, G, a.tagBase + 2ull * (unsigned)it, t4, a.fail, lane);
+                if (lane == 0) { sh[24] = t4[0]; sh[25] = t4[1]; sh[26] = t4[2]; sh[27] = t4[3]; if (!okc) sflag[0] = 2; }
+            }
+            __syncthreads();                                                   // (also completes z's tile)
+            if (sflag[0]) { alive = false; break; }
             PS_STAMP(8)
-            // the fp64 stencil coefficients of the own rows: requested with the partial sums (ONE round trip for all of them);
-            // the diagonal is minus the sum of the couplings
+            // the fp64 stencil coefficients of the own rows: requested here, they arrive under the p update
             const double *dMm = k.dM + mo, *cYm = k.cY + mo, *cZm = k.cZ + mo;
             double dm64[PS_NO], ce64[PS_NO], cw64[PS_NO], ci64[PS_NO], co64[PS_NO];
 #pragma unroll
@@ -868,17 +928,8 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                 ci64[q] = c ? cn : cs; co64[q] = c ? cs : cn;
             }
             // ================= scalars: rho, error estimate, convergence, beta =================
-            cplx rz;
-            double zz, xx;
-            {
-                const long sl = (long)s * MAXNB + min(lane, G - 1);
-                double pr_ = ps_ld_f64(&k.partA[sl].re), pi_ = ps_ld_f64(&k.partA[sl].im);
-                if (SW == 2) { pr_ += ps_ld_f64(&k.partR[sl].re); pi_ += ps_ld_f64(&k.partR[sl].im); }
-                double pz_ = ps_ld_f64(a.partZZ + sl), pb_ = ps_ld_f64(k.partB + sl);
-                if (lane >= G) { pr_ = 0; pi_ = 0; pz_ = 0; pb_ = 0; }
-                rz = cplx{wave_sum(pr_), wave_sum(pi_)};
-                zz = wave_sum(pz_); xx = wave_sum(pb_);
-            }
+            const cplx rz = cplx{sh[24], sh[25]};
+            const double zz = sh[26], xx = sh[27];
             const bool first = it == 1;
             bool on = true;
             st = 0;
@@ -966,19 +1017,22 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                 xv[q] = *ps_at(xsys, ((iyv < NYP) && g >= 1 && g <= nz - 1) ? eo(j) : (unsigned)(NYP + 1));
             }
             ps_block_sum3<NWV>(pqr, pqi, dum2, sh);
-            if (tid == 0) { k.partPQ[(long)s * MAXNB + jwg] = cplx{pqr, pqi}; sys_arrive(); }
+            if (tid == 0) {
+                const double v2[2] = {pqr, pqi};
+                ps_publish<2>(a.rec + (((long)s * MAXNB + jwg) * 2 + 1) * 8, v2, a.tagBase + 2ull * (unsigned)it + 1ull);
+            }
             PS_STAMP(9)
-            if (!sys_wait()) { alive = false; break; }                         // R2
+            if (wave == 0) {                                                   // R2
+                double t2[2] = {0, 0};
+                const bool okc = ps_collect<2>(a.rec + (long)s * MAXNB * 2 * 8, 1, G, a.tagBase + 2ull * (unsigned)it + 1ull, t2, a.fail, lane);
+                if (lane == 0) { sh[28] = t2[0]; sh[29] = t2[1]; if (!okc) sflag[0] = 2; }
+            }
+            __syncthreads();
+            if (sflag[0]) { alive = false; break; }
             PS_STAMP(10)
             PS_PHASE();
             // ================= alpha; x += alpha p, r -= alpha q; publish r', p =================
-            cplx al;
-            {
-                const long sl = (long)s * MAXNB + min(lane, G - 1);
-                double pr_ = ps_ld_f64(&k.partPQ[sl].re), pi_ = ps_ld_f64(&k.partPQ[sl].im);
-                if (lane >= G) { pr_ = 0; pi_ = 0; }
-                al = rhoCur / cplx{wave_sum(pr_), wave_sum(pi_)};
-            }
+            const cplx al = rhoCur / cplx{sh[28], sh[29]};
             const c32 alf = c32{(float)al.re, (float)al.im};
             double xxs = 0, dum3 = 0, dum4 = 0;
             {
@@ -1002,7 +1056,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             for (int j = 0; j < PS_HALO; ++j)
                 if (j >= JP + 1) rh[j] = mk(j) * (rh[j] - alf * qh[j]);
             ps_block_sum3<NWV>(xxs, dum3, dum4, sh);
-            if (tid == 0) k.partB[(long)s * MAXNB + jwg] = xxs;
+            xxPrev = xxs;                                                      // (travels with the next reduction's record)
             PS_STAMP(11)
         }
         if (!alive || a.precondOnly) { if (a.precondOnly) continue; break; }
