@@ -199,18 +199,21 @@ __device__ __forceinline__ c32 ps_dinv_at(const PsPl& co, int ti, int es, int c,
     return ps_dinv(-((ce + cw) + (cn + cs)), dm, wJ);
 }
 
-// block-wide deterministic sums of three doubles (NW waves); result in every thread
+// block-wide deterministic sums of four doubles (NWV waves); result in every thread.  Two scratch areas used alternately (`flip`,
+// toggled by the caller): a reduction's readers are separated from the NEXT reduction's writers (other area) by this one's barrier,
+// and from the one after that (same area) by the next one's -- ONE barrier per reduction instead of two.
 template <int NWV>
-__device__ __forceinline__ void ps_block_sum3(double& a, double& b, double& c, double* sh) {
-    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+__device__ __forceinline__ void ps_block_sum4(double& a, double& b, double& c, double& d, double* sh, int& flip) {
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
     const int w = threadIdx.x >> 6;
-    __syncthreads();                                   // (sh may still be read from the previous reduction)
-    if ((threadIdx.x & 63) == 0) { sh[w] = a; sh[8 + w] = b; sh[16 + w] = c; }
+    double* s0 = sh + 32 * flip;
+    flip ^= 1;
+    if ((threadIdx.x & 63) == 0) { s0[w] = a; s0[8 + w] = b; s0[16 + w] = c; s0[24 + w] = d; }
     __syncthreads();
-    double sa = 0, sb = 0, sc = 0;
+    double sa = 0, sb = 0, sc = 0, sd = 0;
 #pragma unroll
-    for (int i = 0; i < NWV; ++i) { sa += sh[i]; sb += sh[8 + i]; sc += sh[16 + i]; }
-    a = sa; b = sb; c = sc;
+    for (int i = 0; i < NWV; ++i) { sa += s0[i]; sb += s0[8 + i]; sc += s0[16 + i]; sd += s0[24 + i]; }
+    a = sa; b = sb; c = sc; d = sd;
 }
 
 // ---- the tridiagonal solves of one 32-mode slab of one system: k_fdm_fwd's LDS scheme (twisted factorisation, mirrored
@@ -435,8 +438,9 @@ template <int CW, int SW>
 __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a) {
     constexpr int NT = 2 * CW, NWV = NT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* sh = reinterpret_cast<double*>(smem);                           // [24] block reductions
-    volatile int* sflag = reinterpret_cast<volatile int*>(smem + 256);      // [0] give up
+    double* sh = reinterpret_cast<double*>(smem);                           // [2][32] block reductions (ps_block_sum4), [64..70) the reductions' totals
+    volatile int* sflag = reinterpret_cast<volatile int*>(smem + 640);      // [0] give up
+    int shFlip = 0;
     char* arena = smem + 1024;
     const int tid = threadIdx.x, lane = tid & 63;
     int tidv = tid, lanev = lane, ljv = lane & 15, g4v = lane >> 4, iyv = tid & (CW - 1);      // opaque copies for the iteration loop (PS_PHASE)
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                 }
             });
             if (SW == 2) { ar += p1r; ai += p1i; }
-            ps_block_sum3<NWV>(ar, ai, zzs, sh);                              // (its barriers also complete the tile)
+            ps_block_sum4<NWV>(ar, ai, zzs, xxPrev, sh, shFlip);              // (its barrier also completes the tile; |x|^2: the previous update's partials)
             if (tid == 0) {                                                    // R1, first half: this workgroup's partial sums
                 const double v4[4] = {ar, ai, zzs, xxPrev};
                 ps_publish<4>(a.rec + (((long)s * MAXNB + jwg) * 2 + 0) * 8, v4, a.tagBase + 2ull * (unsigned)it);
@@ -910,7 +914,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             if (wave == 0) {
                 double t4[4] = {0, 0, 0, 0};
                 const bool okc = ps_collect<4>(a.rec + (long)s * MAXNB * 2 * 8, 0, G, a.tagBase + 2ull * (unsigned)it, t4, a.fail, lane);
-                if (lane == 0) { sh[24] = t4[0]; sh[25] = t4[1]; sh[26] = t4[2]; sh[27] = t4[3]; if (!okc) sflag[0] = 2; }
+                if (lane == 0) { sh[64] = t4[0]; sh[65] = t4[1]; sh[66] = t4[2]; sh[67] = t4[3]; if (!okc) sflag[0] = 2; }
             }
             __syncthreads();                                                   // (also completes z's tile)
             if (sflag[0]) { alive = false; break; }
@@ -928,8 +932,8 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                 ci64[q] = c ? cn : cs; co64[q] = c ? cs : cn;
             }
             // ================= scalars: rho, error estimate, convergence, beta =================
-            const cplx rz = cplx{sh[24], sh[25]};
-            const double zz = sh[26], xx = sh[27];
+            const cplx rz = cplx{sh[64], sh[65]};
+            const double zz = sh[66], xx = sh[67];
             const bool first = it == 1;
             bool on = true;
             st = 0;
@@ -1016,7 +1020,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                 const int j = PS_HALO + q, g = gb + gs * j;
                 xv[q] = *ps_at(xsys, ((iyv < NYP) && g >= 1 && g <= nz - 1) ? eo(j) : (unsigned)(NYP + 1));
             }
-            ps_block_sum3<NWV>(pqr, pqi, dum2, sh);
+            { double dz = 0; ps_block_sum4<NWV>(pqr, pqi, dum2, dz, sh, shFlip); }
             if (tid == 0) {
                 const double v2[2] = {pqr, pqi};
                 ps_publish<2>(a.rec + (((long)s * MAXNB + jwg) * 2 + 1) * 8, v2, a.tagBase + 2ull * (unsigned)it + 1ull);
@@ -1025,14 +1029,14 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             if (wave == 0) {                                                   // R2
                 double t2[2] = {0, 0};
                 const bool okc = ps_collect<2>(a.rec + (long)s * MAXNB * 2 * 8, 1, G, a.tagBase + 2ull * (unsigned)it + 1ull, t2, a.fail, lane);
-                if (lane == 0) { sh[28] = t2[0]; sh[29] = t2[1]; if (!okc) sflag[0] = 2; }
+                if (lane == 0) { sh[68] = t2[0]; sh[69] = t2[1]; if (!okc) sflag[0] = 2; }
             }
             __syncthreads();
             if (sflag[0]) { alive = false; break; }
             PS_STAMP(10)
             PS_PHASE();
             // ================= alpha; x += alpha p, r -= alpha q; publish r', p =================
-            const cplx al = rhoCur / cplx{sh[28], sh[29]};
+            const cplx al = rhoCur / cplx{sh[68], sh[69]};
             const c32 alf = c32{(float)al.re, (float)al.im};
             double xxs = 0, dum3 = 0, dum4 = 0;
             {
@@ -1055,8 +1059,8 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
 #pragma unroll
             for (int j = 0; j < PS_HALO; ++j)
                 if (j >= JP + 1) rh[j] = mk(j) * (rh[j] - alf * qh[j]);
-            ps_block_sum3<NWV>(xxs, dum3, dum4, sh);
-            xxPrev = xxs;                                                      // (travels with the next reduction's record)
+            (void)dum3; (void)dum4;
+            xxPrev = xxs;                                                      // (this thread's part: reduced and published with the next reduction)
             PS_STAMP(11)
         }
         if (!alive || a.precondOnly) { if (a.precondOnly) continue; break; }
