@@ -66,8 +66,7 @@ struct hmcmt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;       // sigma-only sensitivity tables run beside the forward solve
-    hipStream_t side2 = nullptr;      // stencil coefficients and Jacobi diagonal, beside the boundary-value kernels
-    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evPiv = nullptr, evRec = nullptr, evCoef = nullptr;
+    hipEvent_t evModel = nullptr, evSens = nullptr, evExtF = nullptr, evExtA = nullptr, evPiv = nullptr, evRec = nullptr;
     bool solveBegun = false;                 // k_resid0 / k_resid_pre has done k_solve_begin's work for the next solve
     bool preDone = false;                    // k_resid_pre has done the first pre-smoothing pass of the next solve
     bool statsPending = false, pendingAdj = false;   // records of an asynchronous evaluation not read yet
@@ -85,7 +84,7 @@ struct hmcmt_ctx {
     int residThreads = 256;               // k_resid_pre
     LfStep lfStep{};                      // a position update of hmcmt_leapfrog* still to be performed (by k_sigma_rows, or k_lf_step in front of k_sigma)
     bool sensWaitPending = false, extAWaitPending = false;
-    bool noFusedStart = false, noSigmaRows = false, noCoefAll = false, denseSrc = false, coefMain = true;     // environment knobs read at creation
+    bool noFusedStart = false, noSigmaRows = false, noCoefAll = false;     // environment knobs read at creation
     bool wantTicks = false;               // HMCMT_TICKS: in-kernel wall-clock stamps (View::ticks), printed at destroy
     int bcCW = 0, bcSlots = 1;            // k_bc_fused: boundary columns per workgroup (0: k_bc_layers + k_bc_forward), edge slots
     size_t bcLds = 0;
@@ -167,6 +166,15 @@ struct hmcmt_ctx {
     long long* d_pstamps = nullptr;       // HMCMT_STAMPS=persist
     long long persistSolves = 0, persistFallbacks = 0;
     bool counted = false;                 // this context is in g_liveContexts
+    // production guard on the error-estimate stopping rule: every guardEvery-th evaluation the TRUE residual of both
+    // solves is formed (two vector passes and a read-back: ~0.1 ms once in guardEvery evaluations) -- hmcmt_guard
+    int guardEvery = 100;                 // HMCMT_GUARD_EVERY (0: off)
+    long long guardChecks = 0;
+    double guardWorst = 0.0, guardLast = 0.0;
+    double guardLimit = 1e-6;             // HMCMT_GUARD_LIMIT: a checked residual above it is a "trip" (warning, next evaluation starts cold)
+    long long guardTrips = 0;
+    bool guardNow = false;                // the evaluation at hand is a guarded one
+    bool guardDropWarm = false;           // a trip: the next evaluation starts both solves cold
     // results of the last two host-API evaluations, keyed by the model: a sampler re-evaluates the model it has
     // just evaluated (getHamiltonian at the proposal, HMCSampler.jl:364; the first gradient of the next trajectory,
     // :217) or, after a rejection, the start model of the trajectory before -- those calls cost a memcmp
@@ -295,8 +303,7 @@ bool fused_back_ok(const hmcmt_ctx* ctx) {
 }
 // grid of the fused stencil kernels for `ntiles` row tiles per system (tile_map, kernels_fused.h)
 dim3 tile_grid(const Solver& k, int ntiles) {
-    if (k.xmap == 2) return dim3(8 * ((2 * ntiles + 7) / 8) * k.nFreq);
-    return k.xmap ? dim3(8 * ((k.S + 7) / 8) * ntiles) : dim3(ntiles, k.S);
+    return dim3(ntiles, k.S);
 }
 size_t update2_lds(const Solver& k) { return (size_t)(3 * k.RT2 + 8) * k.NYP * sizeof(float2); }
 int update2_tiles(const Solver& k) { return (k.nz - 1 + k.RT2 - 1) / k.RT2; }
@@ -362,7 +369,7 @@ int launch_back_post(hmcmt_ctx* ctx) {
     if (k.sweeps == 2) {                     // wide meshes, two sweeps: F t as fp64, then z4 and the sums of the rho identity
         if ((rc = launch_transform_lp<1>(ctx, k.y32, true, k.z, k.active))) return rc;
         { ProfScope ps(ctx, 7, true); hipLaunchKernelGGL(k_post_w2, vg, vb, 0, ctx->stream, k, ctx->d_partZZ); }
-        if (!k.merged2) hipLaunchKernelGGL(k_post2, dim3(k.NTR, k.S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(float2), ctx->stream, k, ctx->d_partZZ);
+        if (!k.merged2) { ProfScope ps2(ctx, 7, true); hipLaunchKernelGGL(k_post2, dim3(k.NTR, k.S), vb, (size_t)(k.RT + 2) * k.NYP * sizeof(float2), ctx->stream, k, ctx->d_partZZ); }
         return 0;
     }
     if ((rc = launch_transform_lp<2>(ctx, k.y32, true, k.z, k.active))) return rc;   // z = F t + dinv r
@@ -384,8 +391,6 @@ int fdm_fwd_ntw(const hmcmt_ctx* ctx) {
     // forces it (16-mode slabs if need be), =0 disables it.
     if (!ctx->fusedFwd) return 0;
     const int tw = ctx->twistOn ? 1 : 0;
-    static const int ntwEnv = getenv("HMCMT_FWD_NTW") ? atoi(getenv("HMCMT_FWD_NTW")) : 0;      // 1: 16-mode slabs (twice the workgroups)
-    if (ntwEnv == 1 && k.NYP <= 256 && fdm_fwd_lds(k, 1, tw) <= ctx->maxLds) return 1;
     if (fdm_fwd_lds(k, FW_NTW, tw) <= ctx->maxLds && (k.NYP <= 256 || ctx->fusedFwdForce)) return FW_NTW;
     if (ctx->fusedFwdForce && fdm_fwd_lds(k, 1, tw) <= ctx->maxLds) return 1;
     return 0;
@@ -567,6 +572,9 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
     dim3 vg(k.NB, S), vb(VBLOCK);
     const size_t vecBytes = (size_t)S * k.vstride * sizeof(cplx);
     if (ctx->opt.verify) HIPCHK(hipMemcpyAsync(ctx->d_b, k.r, vecBytes, hipMemcpyDeviceToDevice, ctx->stream));
+    // production guard (every guardEvery-th evaluation): the true residual of this solve without options.verify -- the forward
+    // problem's right-hand side lives in x's boundary nodes (k_trueres forms it), the adjoint one was copied to d_b by evaluate()
+    const bool guard = !ctx->opt.verify && ctx->guardNow;
     // all systems of the requested modes start active (device copy: no host round trip)
     if (!ctx->solveBegun)           // (otherwise done by the residual kernel in front of this solve)
         hipLaunchKernelGGL(k_solve_begin, dim3((S * MAXNB + 255) / 256), dim3(256), 0, ctx->stream, k, ctx->v.sysOn);
@@ -672,11 +680,11 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
             // rocprofv3, whose launches cost twice as much, the early settings drain the main queue.)
             if (kind == 0 && it == sideIt) launch_adjoint_side(ctx);
             // (likewise the wait for the adjoint guess of the side stream, four iterations behind its launch)
-            if (kind == 0 && it == sideIt + 4 && ctx->extAWaitPending) { ctx->extAWaitPending = false; HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evExtA, 0)); }
+            if (kind == 0 && it == sideIt + 4 && ctx->extAWaitPending) { ctx->extAWaitPending = false; ctx->chainEnd = (size_t)-1; HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evExtA, 0)); }
             // the gradient tail needs the sensitivity tables of the side stream (205 + 53 us of serial kernels beside the forward
             // solve, long complete by the adjoint solve's 8th iteration): the wait goes into the queue HERE, where the host runs
             // ahead of the device, not behind the solve, where the device waits for every call
-            if (kind == 1 && it == 8 && ctx->sensWaitPending) { ctx->sensWaitPending = false; HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evSens, 0)); }
+            if (kind == 1 && it == 8 && ctx->sensWaitPending) { ctx->sensWaitPending = false; ctx->chainEnd = (size_t)-1; HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evSens, 0)); }
         }
         if (!done) {
             // stragglers (or the iteration cap): read the counter once more, then hand over to the classic loop
@@ -727,8 +735,8 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
     ctx->solveDone[kind] = done;
     // iteration counts / status / error estimates stay on the device; evaluate() reads both solves back at once
     if (!deferEnd) launch_solve_end(ctx, kind);
-    if (ctx->opt.verify) {
-        hipLaunchKernelGGL(k_trueres, vg, vb, 0, ctx->stream, k, ctx->d_b, x, ctx->d_partRes, ctx->d_partBn);
+    if (ctx->opt.verify || (guard && done)) {
+        hipLaunchKernelGGL(k_trueres, vg, vb, 0, ctx->stream, k, (guard && kind == 0) ? (const cplx*)nullptr : ctx->d_b, x, ctx->d_partRes, ctx->d_partBn);
         std::vector<double> pr((size_t)S * MAXNB), pb((size_t)S * MAXNB);
         HIPCHK(hipMemcpyAsync(pr.data(), ctx->d_partRes, pr.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipMemcpyAsync(pb.data(), ctx->d_partBn, pb.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -737,6 +745,16 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
             double rr = 0, bb = 0;
             for (int b = 0; b < k.NB; ++b) { rr += pr[(size_t)s * MAXNB + b]; bb += pb[(size_t)s * MAXNB + b]; }
             if (bb > 0) ctx->stats.true_res_max = std::max(ctx->stats.true_res_max, std::sqrt(rr / bb));
+        }
+        if (guard) {
+            ++ctx->guardChecks; ctx->guardLast = ctx->stats.true_res_max; ctx->guardWorst = std::max(ctx->guardWorst, ctx->guardLast);
+            if (!(ctx->guardLast <= ctx->guardLimit)) {
+                // the estimate ||z|| <= tol ||x|| stopped a solve whose residual is not small: say so, and do not warm-start from it
+                ++ctx->guardTrips;
+                ctx->guardDropWarm = true;
+                fprintf(stderr, "hmcmt: stopping-rule guard: evaluation %lld, %s solve: true residual %.3e > %.1e (tol %.1e)\n",
+                        ctx->evalCount, kind == 0 ? "forward" : "adjoint", ctx->guardLast, ctx->guardLimit, ctx->opt.tol);
+            }
         }
     }
     (void)v;
@@ -799,6 +817,8 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     ctx->sv.cntActive = (ctx->profMask && ctx->evalCount % ctx->profEvery == 0) ? ctx->d_cnt : nullptr;
     if (ctx->sv.cntActive) ++ctx->profEvals;
     ctx->evalSampled = ctx->sv.cntActive != nullptr;
+    ctx->guardNow = !ctx->opt.verify && ctx->guardEvery > 0 && ctx->evalCount % ctx->guardEvery == 0;
+    if (ctx->guardDropWarm) { ctx->guardDropWarm = false; ctx->haveFwd = ctx->haveAdj = false; }
     const int nodes = v.NZP * (v.ny + 1);
     const size_t vecBytes = (size_t)S * v.vstride * sizeof(cplx);
     // initial guesses (options.warm_start): verify checks against the cold right-hand side
@@ -836,11 +856,10 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             HIPCHK(hipMemsetAsync(v.Lam, 0, vecBytes, st));
             HIPCHK(hipMemsetAsync(ctx->d_ext[1], 0, EXT_PART * sizeof(double), st));
         }
-        // The coefficients run on the MAIN stream behind the boundary fields (HMCMT_COEF_MAIN=0: on the second side stream, as
-        // until round 3): alone they take 10 us instead of 20 beside k_bc_fused, and three API calls (wait, record, wait) leave
-        // the host's sequence in front of the residual: 860 -> 870 steps/s on the straight-line trajectories, +0.5 % elsewhere.
-        const bool coefMain = ctx->coefMain;
-        hipStream_t sA = ctx->side, sB = coefMain ? st : ctx->side2;
+        // The coefficients run on the MAIN stream behind the boundary fields (until round 3 on a second side stream: alone they take
+        // 10 us instead of 20 beside k_bc_fused, and three API calls -- wait, record, wait -- leave the host's sequence in front of the
+        // residual: 860 -> 870 steps/s on the straight-line trajectories, +0.5 % elsewhere; the other placement was removed in round 4).
+        hipStream_t sA = ctx->side, sB = st;
         // (a position update of the device-resident leapfrog that is still due rides along: leapfrog_core)
         if (ctx->lfStep.on && !(rows && ctx->lfStep.L.m == v.m)) {
             hipLaunchKernelGGL(k_lf_step, dim3((ctx->lfStep.L.n + 127) / 128), dim3(128), 0, st, ctx->lfStep.L, ctx->lfStep.dt, ctx->lfStep.lo, ctx->lfStep.hi);
@@ -879,15 +898,14 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
                 hipLaunchKernelGGL(k_fdm_z, grid1(2 * v.NZP, 64), dim3(64), 0, sp, v);
             return hipEventRecord(ctx->evPiv, sp);
         };
-        if (extrap || coefMain) HIPCHK(hipStreamWaitEvent(sA, ctx->evModel, 0));
+        HIPCHK(hipStreamWaitEvent(sA, ctx->evModel, 0));
         if (extrap) {
             // (interior nodes only -- the boundary-value kernel owns the boundary nodes of X)
             launch_extrap_weights(ctx, d_m, 0, sA);
             hipLaunchKernelGGL(k_extrap, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, sA, ctx->sv, v.X, ctx->d_prevField[0], ctx->d_ext[0]);
             HIPCHK(hipEventRecord(ctx->evExtF, sA));
         }
-        if (extrap || coefMain) HIPCHK(issue_pivot(sA));
-        if (!coefMain) HIPCHK(hipStreamWaitEvent(sB, ctx->evModel, 0));
+        HIPCHK(issue_pivot(sA));
         if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && !ctx->noCoefAll) {
             hipLaunchKernelGGL(k_coef_all, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, sB, v, ctx->sv, ctx->jacobiW, const_cast<float4*>(ctx->sv.cf32));
         } else {
@@ -897,10 +915,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
                 hipLaunchKernelGGL(k_coef32, dim3(ctx->sv.NB, 2), dim3(VBLOCK), 0, sB, ctx->sv, const_cast<float4*>(ctx->sv.cf32));
             }
         }
-        if (!coefMain) HIPCHK(hipEventRecord(ctx->evCoef, sB));
-        if (!extrap && !coefMain) HIPCHK(issue_pivot(sB));
         if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtF, 0));
-        if (!coefMain) HIPCHK(hipStreamWaitEvent(st, ctx->evCoef, 0));
         // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X
         if (fusedStart) {
             launch_resid_pre(ctx, startLds, v.X, 1);
@@ -926,6 +941,11 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         // the forward solve gave up (iteration cap / breakdown): no adjoint solve on its fields, no further leapfrog step on
         // its gradient -- the records of k_solve_end carry the status, the caller gets it now
         ctx->sidePending = false;
+        // (side-stream work of the adjoint half that is already in flight -- its initial guess writes Lam, the sensitivity tables --
+        //  must not run into the next evaluation: joined here, the pending waits dropped)
+        if (ctx->extAWaitPending) { ctx->extAWaitPending = false; HIPCHK(hipStreamWaitEvent(st, ctx->evExtA, 0)); }
+        if (ctx->sideSens && !ctx->sidePending) HIPCHK(hipStreamSynchronize(ctx->side));
+        ctx->sensWaitPending = false;
         HIPCHK(hipEventRecord(ctx->evRec, st));
         ctx->haveFwd = false;
         rc = collect_stats(ctx, false);
@@ -948,10 +968,11 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             ProfScope ps(ctx, 5);
             // k_src assigns the two node rows of the receiver layer and all of srcB.  A warm adjoint start reads the right-hand
             // side on those rows only (k_resid0 / k_resid_pre, zero_r = 2 + row); a cold one takes the buffer as its residual
-            const bool sparseSrc = warmA && !ctx->opt.verify && !ctx->denseSrc;
+            const bool sparseSrc = warmA && !ctx->opt.verify && !ctx->guardNow;       // (a guarded evaluation keeps a copy of the whole right-hand side)
             if (!sparseSrc) HIPCHK(hipMemsetAsync(v.R, 0, vecBytes, st));
             const int nsrc = (2 * (v.ny + 1) + 127) / 128;
             hipLaunchKernelGGL(k_src, dim3(nsrc + (v.ny + 127) / 128, S), dim3(128), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit, nsrc);
+            if (ctx->guardNow) HIPCHK(hipMemcpyAsync(ctx->d_b, v.R, vecBytes, hipMemcpyDeviceToDevice, st));
             if (ctx->extAWaitPending) { ctx->extAWaitPending = false; HIPCHK(hipStreamWaitEvent(st, ctx->evExtA, 0)); }   // (a forward solve too short to have issued it)
             if (warmA && fusedStart) {
                 launch_resid_pre(ctx, startLds, v.Lam, sparseSrc ? 2 + v.zid : 0);
@@ -970,6 +991,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         ctx->haveAdj = (rc == 0 && ctx->solveDone[1]);
         if (rc) return rc;
         if (ctx->solveFail) {             // (as after the forward solve: no gradient from a failed adjoint, and the caller knows NOW)
+            if (ctx->sensWaitPending) { ctx->sensWaitPending = false; HIPCHK(hipStreamSynchronize(ctx->side)); }   // (the tables of the side stream: not into the next evaluation)
             launch_solve_end(ctx, 1);
             HIPCHK(hipEventRecord(ctx->evRec, st));
             rc = collect_stats(ctx, true);
@@ -1092,7 +1114,6 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->side) hipStreamSynchronize(ctx->side);      // (side-stream work of an evaluation nobody waited for)
-    if (ctx->side2) hipStreamSynchronize(ctx->side2);
     if (ctx->v.ticks) {
         static const char* names[TK_N] = {"k_sigma_rows", "k_bc_fused", "k_extrap_prepare (fwd)", "k_extrap (fwd)", "k_coef_all", "k_pivot",
             "k_resid_pre (fwd)", "k_spmv_fused (first .. last)", "k_update_fused (first .. last)", "k_fdm_fwd (first .. last)",
@@ -1168,7 +1189,6 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
         }
         hipFree(ctx->sv.stamps);
     }
-    if (ctx->side2) hipStreamSynchronize(ctx->side2);
     for (void* p : ctx->allocs) hipFree(p);
     for (hipEvent_t e : ctx->evPool) hipEventDestroy(e);
     if (ctx->h_nactive) hipHostFree(ctx->h_nactive);
@@ -1181,10 +1201,8 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (ctx->evModel) hipEventDestroy(ctx->evModel);
     if (ctx->evSens) hipEventDestroy(ctx->evSens);
     if (ctx->evExtF) hipEventDestroy(ctx->evExtF);
-    if (ctx->evCoef) hipEventDestroy(ctx->evCoef);
     if (ctx->evPiv) hipEventDestroy(ctx->evPiv);
     if (ctx->evRec) hipEventDestroy(ctx->evRec);
-    if (ctx->side2) hipStreamDestroy(ctx->side2);
     if (ctx->evExtA) hipEventDestroy(ctx->evExtA);
     if (ctx->side) hipStreamDestroy(ctx->side);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -1252,10 +1270,8 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     HIPCHK(hipEventCreateWithFlags(&ctx->evModel, evDev));
     HIPCHK(hipEventCreateWithFlags(&ctx->evSens, evDev));
     HIPCHK(hipEventCreateWithFlags(&ctx->evExtF, evDev));
-    HIPCHK(hipEventCreateWithFlags(&ctx->evCoef, evDev));
     HIPCHK(hipEventCreateWithFlags(&ctx->evPiv, evDev));
     HIPCHK(hipEventCreateWithFlags(&ctx->evRec, hipEventDisableTiming));
-    HIPCHK(hipStreamCreate(&ctx->side2));
     {
         const char* e = getenv("HMCMT_FUSED_FWD");
         ctx->fusedFwd = !(e && e[0] == '0');
@@ -1269,6 +1285,8 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         else (void)hipGetLastError();
         if (const char* ew = getenv("HMCMT_JACOBI_W")) ctx->jacobiW = std::min(1.2, std::max(0.1, atof(ew)));
         if (const char* es = getenv("HMCMT_SWEEPS")) ctx->sweepsMode = std::max(0, std::min(2, atoi(es)));     // 0 / "auto": per solve
+        if (const char* eg = getenv("HMCMT_GUARD_EVERY")) ctx->guardEvery = std::max(0, atoi(eg));
+        if (const char* eg = getenv("HMCMT_GUARD_LIMIT")) ctx->guardLimit = atof(eg);
         if (const char* es = getenv("HMCMT_SWEEPS_UP")) ctx->sweepsUp = std::max(1, atoi(es));
         if (const char* es = getenv("HMCMT_SWEEPS_DOWN")) ctx->sweepsDown = std::max(0, atoi(es));
         if (const char* ep = getenv("HMCMT_EXTRAP_POINTS")) ctx->extrapNp = std::max(2, std::min(EXT_NP, atoi(ep)));
@@ -1289,8 +1307,6 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         ctx->noFusedStart = getenv("HMCMT_NO_FUSED_START") != nullptr;
         ctx->noSigmaRows = getenv("HMCMT_NO_SIGMA_ROWS") != nullptr;
         ctx->noCoefAll = getenv("HMCMT_NO_COEF_ALL") != nullptr;
-        ctx->denseSrc = getenv("HMCMT_DENSE_SRC") != nullptr;
-        ctx->coefMain = !(getenv("HMCMT_COEF_MAIN") && getenv("HMCMT_COEF_MAIN")[0] == '0');
         if (const char* ed = getenv("HMCMT_DEBUG_FLAGS")) ctx->dbgFlags = atoi(ed);                  // (measurement only: hmcmt_debug_flags)
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<FW_NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
@@ -1320,14 +1336,9 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     v.ny = h.ny; v.nz = h.nz; v.NYP = h.NYP; v.NZP = h.NZP; v.nFreq = h.nFreq; v.S = h.S; v.nRx = h.nRx;
     v.nData = h.nData; v.nAC = h.nAC; v.nCell = h.nCell; v.zid = h.zid; v.vstride = (long)h.NZP * h.NYP;
     v.dbg = 0; v.ticks = nullptr;
-    // HMCMT_BGMEAN (experiment, round 3; default 0 = the geometric lateral mean of sigma for both modes): bit 0: TM background =
-    // harmonic lateral mean of sigma, i.e. the arithmetic mean of the coefficient 1/sigma the TM stiffness is linear in; bit 1: TE
-    // background = arithmetic mean of sigma -- fdm_z_values, hmcmt_items.h.  bench.py, headline chain / near the true model,
-    // steps/s: 0: 317 / 391, 1: 324 / 398, 2: 311 / 379, 3: 326 / 379.  Not adopted: at the true model the +2 % of setting 1 is
-    // an earlier stop, not faster convergence -- its error estimate is 5x more optimistic there (true residual 2.4e-9 instead of
-    // 3.1e-10 at the same 19-20 / 24-26 iterations; with tol 3e-12 it needs the old counts for the old accuracy), while on
-    // rough models it is 5x MORE accurate at the same counts (profiles/r03_parity_levels_bgmean{0,1}.log).
-    v.bgMean = getenv("HMCMT_BGMEAN") ? atoi(getenv("HMCMT_BGMEAN")) : 0;
+    // (the lateral mean of the FDM background is the geometric mean of sigma for both modes.  Round 3's experiment HMCMT_BGMEAN --
+    // the arithmetic mean of the coefficient the operator is linear in -- was removed in round 4: +2 % at the bench, but at the true
+    // model the gain was an earlier stop at a 5x looser error, not faster convergence: DESIGN section 9.)
     const size_t VS = (size_t)v.vstride, S = (size_t)h.S;
     int rc;
 #define UP(field, vec) { decltype(vec)::value_type* p_ = nullptr; if ((rc = dupload(ctx, &p_, vec))) return rc; v.field = p_; }
@@ -1442,7 +1453,6 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     }
     if (const char* eu = getenv("HMCMT_UPD1")) { const int a = atoi(eu); if (a == 256 || a == 512) ctx->upd1Threads = a; }
     if (const char* eu = getenv("HMCMT_SPMV")) { const int a = atoi(eu); if (a == 256 || a == 512 || a == 1024) ctx->spmvThreads = a; }
-    k.actEarly = !(getenv("HMCMT_ACT_EARLY") && getenv("HMCMT_ACT_EARLY")[0] == '0');
     k.xInFwd = 0;       // set with k.splitT (the fused forward kernel is the one that can take the x update along)
     k.stamps = nullptr; k.stampKernel = 0;
     k.ticks = nullptr; k.xTickF = v.X;
@@ -1454,9 +1464,8 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         k.stampKernel = !strcmp(es, "upd") ? 1 : (!strcmp(es, "spmv") ? 2 : 0);
         if (k.stampKernel) { HIPCHK(hipMalloc((void**)&k.stamps, sizeof(long long) * 8 * 4096)); HIPCHK(hipMemset(k.stamps, 0, sizeof(long long) * 8 * 4096)); }
     }
-    k.xmap = getenv("HMCMT_XMAP") ? atoi(getenv("HMCMT_XMAP")) : 0;     // (XCD-aware tile placement: measured neutral, kernels_fused.h tile_map)
     k.w2 = getenv("HMCMT_JACOBI_W2") ? (float)atof(getenv("HMCMT_JACOBI_W2")) : 1.0f;
-    k.merged2 = getenv("HMCMT_POST2") && atoi(getenv("HMCMT_POST2")) == 1 ? 0 : 1;
+    k.merged2 = 1;
     k.omega = v.omega; k.cY = v.cY; k.cZ = v.cZ; k.dK = v.dK; k.dM = v.dM; k.ofz = v.ofz; k.invp = v.invp;
     { float4* cf = nullptr; if ((rc = dalloc(ctx, &cf, 2 * 2 * VS))) return rc; k.cf32 = cf; }
     k.r = v.R;
@@ -1536,6 +1545,11 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
     // on dprism3d's 6 160 interior nodes per system it costs 1 %); HMCMT_XFWD=0 / 1 forces it off / on
     ctx->sv.xInFwd = ctx->sv.splitT && (long)(ctx->sv.nz - 1) * ctx->sv.NYP >= 12000;
     if (const char* ex = getenv("HMCMT_XFWD")) ctx->sv.xInFwd = ctx->sv.splitT && ex[0] != '0';
+    {   // the x update is done by the fused kernel's waves 1.. and its per-slab sums fill MAXNB slots: not with one wave, not with more slabs
+        const Solver& kk = ctx->sv;
+        const int Gq = (kk.NZP + 7) / 8, per = (Gq + 7) / 8, nw = (Gq + per - 1) / per, nslab = ((kk.NYP >> 4) + FW_NTW - 1) / FW_NTW;
+        if (nw < 2 || nslab > MAXNB) ctx->sv.xInFwd = 0;
+    }
     ctx->sv.twist = ctx->v.twist = ctx->sv.splitT && ctx->twistOn;     // the fused forward kernel sweeps both ways at once
     if ((rc = persist_setup(ctx))) { g_createError = ctx->err; hmcmt_destroy(ctx); return rc; }
     g_liveContexts.fetch_add(1);
@@ -1852,6 +1866,15 @@ int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z) {
         return 0;
     }
     HIPCHK(hipMemcpy(z, ctx->sv.z, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// production guard on the error-estimate stopping rule: out = {checks so far, largest true residual ||b - A x|| / ||b|| any check has
+// seen, the last check's, checks above HMCMT_GUARD_LIMIT (default 1e-6: each prints a warning and makes the next evaluation start cold)}.  Every HMCMT_GUARD_EVERY-th evaluation (default 100; 0: never) forms the true residual of its two solves
+// without options.verify, so a chain cannot run unnoticed on an optimistic estimate.
+int hmcmt_guard(const hmcmt_ctx* ctx, double* out) {
+    if (!ctx || !out) return HMCMT_EINVAL;
+    out[0] = (double)ctx->guardChecks; out[1] = ctx->guardWorst; out[2] = ctx->guardLast; out[3] = (double)ctx->guardTrips;
     return 0;
 }
 

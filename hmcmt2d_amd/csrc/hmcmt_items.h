@@ -19,8 +19,6 @@ struct View {
     int ny, nz, NYP, NZP, nFreq, S, nRx, nData, nAC, nCell;
     int twist;                     // 1: twisted (two-sided) factorisation of the FDM tridiagonals, see item_pivot
     int zid;                       // node row of the receivers (mt2DTE.jl:66-67), 0-based
-    int bgMean;                    // lateral mean of the FDM background: 1 (default) the arithmetic mean of the coefficient the operator is
-                                   // linear in -- sigma for TE (mass term), 1/sigma for TM (stiffness) --, 0 the geometric mean of sigma for both (rounds 1-2)
     long long* ticks;              // HMCMT_TICKS (measurement only): [2][32] earliest start / latest end of the kernels around the solves
     int dbg;                       // test hooks (hmcmt_debug_flags): bit 1 = leave the boundary-derivative terms B^T v out of the gradient
     long vstride;                  // NZP*NYP elements per system
@@ -37,7 +35,7 @@ struct View {
     const double* bg;              // [nCell]
     const int* act;                // [nAC] cell id of each active cell
     double* sigMeanA;              // [nz] arithmetic lateral mean (MT1DSensitivity.jl:313)
-    double* sigMeanG;              // [nz] lateral mean of the TM background: harmonic mean of sigma (bgMean = 1) or geometric (0)
+    double* sigMeanG;              // [nz] geometric lateral mean (the FDM background of both modes)
     // stencil coefficients on the padded nodal grid, per mode: [2][NZP*NYP]
     double* cY;                    // coupling node (iy,iz) <-> (iy+1,iz)
     double* cZ;                    // coupling node (iy,iz) <-> (iy,iz+1)
@@ -115,15 +113,14 @@ HD void item_sigma(const View& v, int cell) {
 
 // --- lateral means of one cell row (arithmetic: MT1DSensitivity.jl:313; geometric: FDM background)
 HD void item_rowmean(const View& v, int kz) {
-    double sa = 0.0, sl = 0.0, sh = 0.0;
+    double sa = 0.0, sl = 0.0;
     for (int ky = 0; ky < v.ny; ++ky) {
         double s = v.sigma[(long)kz * v.ny + ky];
         sa += s;
         sl += log(s);
-        sh += 1.0 / s;
     }
     v.sigMeanA[kz] = sa / v.ny;
-    v.sigMeanG[kz] = (v.bgMean & 1) ? v.ny / sh : exp(sl / v.ny);
+    v.sigMeanG[kz] = exp(sl / v.ny);
 }
 
 // --- 5-point stencil of  Grad' diag(AveCF*F*q) Grad  and node mass AveCN*F*s at one node
@@ -169,14 +166,9 @@ HD void item_coef(const View& v, int mode, int iy, int iz, bool doK, bool doM) {
 HD void fdm_z_values(const View& v, int mode, int iz, double& mzq, double& dgz, double& ofz, double& mzs) {
     if (iz < 1 || iz > v.nz - 1) { mzq = 0; dgz = 0; ofz = 0; mzs = 0; return; }
     double qa, qb, sa, sb;
-    // View::bgMean (HMCMT_BGMEAN, an experiment of round 3; default 0 = geometric lateral mean of sigma for both modes): bit 0
-    // makes the TM background the operator of the lateral ARITHMETIC mean of the coefficient it is linear in, rho = 1/sigma
-    // (the harmonic mean of sigma: the perturbation A - P then has zero lateral mean), bit 1 the same for TE's mass term.
-    // CPU prototype scripts/proto_aniso.py (headline mesh, one / two sweeps): TM equal at the true model, 41-53 -> 40-46 /
-    // 28-35 -> 28-33 iterations on white-noise models of std 1, 55-83 -> 49-75 / 42-67 -> 37-62 on smooth large-scale
-    // structure; different means for the y- and z-stiffness terms, as homogenisation would have them, are worse by 10-30 %.
-    // On the GPU the gain of bit 0 near the true model turned out to be an earlier stop at a 5x looser error (hmcmt_hip.hip).
-    const double* sTE = (v.bgMean & 2) ? v.sigMeanA : v.sigMeanG;      // (with bit 0 clear sigMeanG is the geometric mean)
+    // the lateral mean of the background is the geometric mean of sigma for both modes (the arithmetic mean of the coefficient the
+    // operator is linear in was tried in round 3 and removed: DESIGN section 9)
+    const double* sTE = v.sigMeanG;
     if (mode == 0) { qa = qb = 1.0 / MU0; sa = sTE[iz - 1]; sb = sTE[iz]; }
     else { qa = 1.0 / v.sigMeanG[iz - 1]; qb = 1.0 / v.sigMeanG[iz]; sa = sb = MU0; }
     double za = v.zLen[iz - 1], zb = v.zLen[iz];

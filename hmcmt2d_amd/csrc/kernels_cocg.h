@@ -33,14 +33,12 @@ struct Solver {
                                           // symmetric construction (G'^2 r = t for the smoother's iteration matrix G) -- so that sweep can run
                                           // inside k_spmv_fused<2>, after the reduction that needs rho
     float w2;                             // two sweeps: damping of the INNER sweeps (second pre-sweep, first post-sweep) relative to the outer ones
-    int merged2;                          // two sweeps: 1 = second post-sweep inside k_spmv_fused<2> (default), 0 = k_post2 launch (HMCMT_POST2=1)
+    int merged2;                          // two sweeps: 1 = second post-sweep inside k_spmv_fused<2> (always, in solves), 0 = k_post2 launch (the test hook that needs z in memory)
     int sweeps;                           // damped Jacobi sweeps on each side of the FDM stage in the solve at hand (1 or 2)
     float2 *z32, *p32a, *p32b;            // fused path: preconditioned residual and the two search-direction buffers as complex64
                                           // (x, r, q and every inner product stay fp64; see k_spmv_fused)
     int RT, NTR;                          // rows per tile / row tiles per system of the fused kernels (NTR <= MAXNB)
-    int actEarly;                         // 1: k_back_post tests the system's active flag before its first loads (HMCMT_ACT_EARLY=0: after, as in rounds 1-2)
     int xInFwd;                           // 1: x += alpha p and |x|^2 are done by k_fdm_fwd's idle waves (its pX argument), not by k_update_fused
-    int xmap;                             // 1: XCD-aware 1-D grids of the fused stencil kernels (tile_map, kernels_fused.h)
     int RT2;                              // rows per tile of k_update_fused<2> (its two halo rows per side cost less on taller tiles)
     int RTS;                              // ... of k_spmv_fused<2> (HMCMT_RTS)
     cplx *partPQ;                         // [S][MAXNB]  p'q of the fused path
@@ -279,11 +277,11 @@ __global__ void k_check(Solver k, const double* partZZ, int first, int maxit) {
             else {
                 k.alphaBeta[s] = rz / k.rho[s];
                 k.rho[s] = rz;
-                if (k.iters[s] >= maxit) { on = false; k.status[s] = HMCMT_ENOCONV; *k.failHost = HMCMT_ENOCONV; }
+                if (k.iters[s] >= maxit) { on = false; k.status[s] = HMCMT_ENOCONV; *k.failHost = HMCMT_ENOCONV; __threadfence_system(); }
             }
         }
         if (!(isfinite(rz.re) && isfinite(rz.im) && isfinite(zz) && isfinite(xx))) {
-            on = false; k.status[s] = HMCMT_EBREAKDOWN; *k.failHost = HMCMT_EBREAKDOWN;
+            on = false; k.status[s] = HMCMT_EBREAKDOWN; *k.failHost = HMCMT_EBREAKDOWN; __threadfence_system();
         }
         if (!on) k.active[s] = 0;
         else atomicAdd(&cnt, 1);

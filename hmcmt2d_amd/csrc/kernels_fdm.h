@@ -995,7 +995,7 @@ constexpr int BP_OWN = 14;         // interior rows owned by a workgroup (tile =
 // SW = 2 (two sweeps per side): the first term added to the FDM correction is the pre-smoothed iterate z2 that
 // k_update_fused<2> stored (instead of dinv .* r), and the result -- the iterate after the FIRST post-sweep -- goes to
 // z4_32 together with the second part of the rho identity (Solver::partR) and |z4|^2; the second post-sweep runs inside
-// k_spmv_fused<2> (or, HMCMT_POST2=1 and the test hook, as k_post2).
+// k_spmv_fused<2> (or, for the test hook that needs z in memory, as k_post2).
 template <int FMT, int SW = 1>
 __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __restrict__ Y, const u4v* __restrict__ Bhi,
                                                    const u4v* __restrict__ Blo, double* partZZ, int NW, long long* stamps) {
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(512) void k_back_post(Solver k, const float2* __res
     // (round 3) tested HERE: rounds 1-2 tested it after the staging and V-fragment loads had been issued -- one memory round
     // trip less for an active workgroup, but on a real chain 40 % of a launch's workgroups belong to converged systems and
     // each of them pulled its 26 KB tile of y and a whole V through the memory system before returning
-    if (k.actEarly && !act) return;
+    if (!act) return;
 #define BP_STAMP(i) if (stamps && threadIdx.x == 0) stamps[((long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime();
     BP_STAMP(0)
     const int bd = NW << 6;            // = blockDim.x, from the kernel argument (a scalar; the implicit-argument load is a vector load here)

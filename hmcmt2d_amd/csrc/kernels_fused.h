@@ -26,7 +26,7 @@
 // batch go out together before the active flag is even tested, the stencil coefficients of the first batch before
 // the staging barrier (11.0 -> 10.3 us; the same treatment of k_update_fused, which moves twice the bytes and sits
 // at 5 TB/s, changed nothing, and neither did computing its dinv from dK, dM instead of loading it).
-#define PH_STAMP(kid, i) if (k.stamps && k.stampKernel == (kid) && threadIdx.x == 0) k.stamps[((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#define PH_STAMP(kid, i) if (k.stamps && k.stampKernel == (kid) && threadIdx.x == 0 && (long)blockIdx.x + (long)gridDim.x * blockIdx.y < 4096) k.stamps[((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 + (i)] = __builtin_amdgcn_s_memtime();
 constexpr int SB = 4;                  // elements per thread and batch
 constexpr int STALL_IT = 30;           // mixed-precision stagnation watch: iterations allowed per 10-fold drop of the error estimate
 struct StenCo { double dk, dm, cy0, cy1, cz0, cz1; };
@@ -42,42 +42,17 @@ __device__ __forceinline__ int div_small(int i, float rcp) { return (int)(((floa
 // post-sweep (k_back_post<., 2>), with rho = r'z already known from the identity of Solver::partR and |z4|^2 as the
 // error estimate; the second post-sweep  z = z4 + dinv .* (r - A z4)  is done here, on the tile's rows and one halo row
 // on each side (z4 staged with two), in fp32 like the rest of the smoother -- no launch of its own (k_post2: 8 us).
-// Workgroup -> (row tile, system) of the two stencil kernels of the iteration.  Workgroups are dealt to the 8 XCDs
-// round-robin by linear id (checked on the box: scripts/probe/xcc_map.hip, XCD(b) == XCD(b % 8) for every workgroup of
-// 1-D and 2-D grids) and each XCD has its own 4 MB L2: with the plain 2-D grid (tile = blockIdx.x) the row tiles above
-// and below a tile -- whose edge rows it reads as halo -- and the same tile of the mode's other frequencies -- whose
-// stencil coefficients it shares -- all sit on OTHER XCDs.  k.xmap = 1 (HMCMT_XMAP=1; NOT the default) is the
-// experiment that tested whether that matters: a 1-D grid of 8 * ceil(S / 8) * ntiles workgroups, XCD x owning ALL tiles
-// of the systems x, x + 8, x + 16, .. (every XCD gets TE and TM systems of several frequencies: a first version with
-// contiguous system ranges per XCD emptied whole XCDs when the TE systems converged, -3 % at cfg3, -9 % at cfg5) and
-// walking them system by system, tile by tile.  Measured (round 3, profiles/r03_xmap.md): the same time within noise at cfg3
-// (286.6 vs 286.6-290.6 steps/s), 2 % slower at cfg5 (49.3 vs 50.3), and the PMC bytes per launch did NOT fall
-// (k_update_fused<2> at cfg5: 640.6 vs 645.8 MB, k_spmv_fused<2> 459.9 vs 406.1 MB): co-locating a tile's neighbours
-// does not make the XCD's L2 share their rows -- the workgroups in flight on an XCD stream ~20 MB through a 4 MB L2 --
-// so the fabric reads of the halo rows are served by the Infinity Cache either way.  Placement only: any mapping gives
-// the same numbers.
-//
-// k.xmap = 2 places for the OTHER sharing: the stencil coefficients of a row tile are the same for all nFreq systems of a
-// polarisation (32 B per node packed, 48 B in fp64), and at the stress size every tile of every system fetches them
-// through the fabric for itself -- a third of what k_update_fused<2> reads there, half of k_spmv_fused<2>'s.  Unit = (row
-// tile, polarisation); unit u runs on XCD u % 8, its nFreq workgroups -- one per frequency -- back to back, i.e. at the
-// same time, reading the same coefficient rows (scripts/probe/l2_share.hip: co-located workgroups that read the same
-// bytes at the same time fetch them once).  Every XCD gets TE and TM units alike.  Measured: 51.0 vs 53.9 steps/s at cfg5,
-// 313.8 vs 318.7 at cfg3 -- slower; 32 workgroups asking one XCD's L2 for the same lines in the same microsecond queue up
-// on its channels (k_back_post staggers its V stream over the k-groups for the same reason).  Not the default either.
+// Workgroup -> (row tile, system) of the two stencil kernels of the iteration: the plain 2-D grid.  Workgroups are dealt to the
+// 8 XCDs round-robin by linear id, each XCD with its own 4 MB L2.  Two XCD-aware placements were measured in round 3
+// (profiles/r03_xmap.md) and removed in round 4: a system's tiles on one XCD (shared halo rows: the same time and the same PMC
+// bytes -- an XCD's workgroups stream ~20 MB through its 4 MB L2, the halo rows are served by the Infinity Cache either way), and
+// the 16 frequencies of a (tile, polarisation) on one XCD (shared stencil coefficients: 2-5 % SLOWER -- 32 workgroups asking one L2
+// for the same lines in the same microsecond queue up on its channels).  The persistent kernel (kernels_persist.h) is where
+// placement pays: there a system's workgroups exchange through their XCD's L2 by design.
 __device__ __forceinline__ bool tile_map(const Solver& k, int ntiles, int& tile, int& s) {
-    if (!k.xmap) { tile = blockIdx.x; s = blockIdx.y; return true; }
-    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-    if (k.xmap == 2) {
-        const int ul = j / k.nFreq, f = j - ul * k.nFreq, u = x + 8 * ul;
-        tile = u >> 1;
-        s = (u & 1) * k.nFreq + f;
-        return tile < ntiles;
-    }
-    const int q = j / ntiles;
-    tile = j - q * ntiles;
-    s = x + 8 * q;
-    return s < k.S;
+    (void)k; (void)ntiles;
+    tile = blockIdx.x; s = blockIdx.y;
+    return true;
 }
 
 template <int SW, int NT>             // NT: threads per workgroup (chosen by the host: launch_spmv)
@@ -176,7 +151,7 @@ __global__ __launch_bounds__(NT) void k_spmv_fused(Solver k, const double* partZ
         k.iters[s] = it - 1;
         const double est = first ? (zz == 0.0 ? 0.0 : 1.0) : sqrt(zz / xx);
         k.errEst[s] = est;
-        if (st) { k.status[s] = st; *k.failHost = st; }
+        if (st) { k.status[s] = st; *k.failHost = st; __threadfence_system(); }     // (in front of the counter the host polls: it reads this word right behind it)
         // stagnation watch (the host restarts the stragglers with the fp64 preconditioner when it fires)
         if (first || est < 0.1 * k.errRef[s]) { k.errRef[s] = est; k.errRefIt[s] = it; }
         else if (on && it - k.errRefIt[s] > k.stallIt) *k.stallHost = 1;
@@ -942,7 +917,9 @@ __global__ __launch_bounds__(VBLOCK) void k_extrap(Solver k, cplx* x, cplx* xp, 
     if (x == k.xTickF) tick_end(k.ticks, TK_EXT);
 }
 
-// true residual norm check: partB = |b - A x|^2 with b passed separately (verify option)
+// true residual norm check: partB = |b - A x|^2 with b passed separately (verify option, and the production guard on the
+// error-estimate stopping rule).  b == nullptr: the forward problem -- the right-hand side is what the Dirichlet values in x's
+// boundary nodes contribute, b_i = - sum over the boundary neighbours of i of c_ib x_b (mt2DTE.jl:38-44), formed here.
 __global__ __launch_bounds__(VBLOCK) void k_trueres(Solver k, const cplx* b, const cplx* x, double* partRes, double* partBn) {
     const int s = blockIdx.y;
     __shared__ double sh[32];
@@ -959,12 +936,14 @@ __global__ __launch_bounds__(VBLOCK) void k_trueres(Solver k, const cplx* b, con
             const double dk = k.dK[mo + e], dm = w * k.dM[mo + e];
             cplx acc = cplx{dk * c.re - dm * c.im, dk * c.im + dm * c.re};
             // boundary entries of x hold Dirichlet values: they belong to the right-hand side
-            if (iy + 1 <= k.ny - 1) acc += k.cY[mo + e] * p[e + 1];
-            if (iy - 1 >= 1) acc += k.cY[mo + e - 1] * p[e - 1];
-            if (iz + 1 <= k.nz - 1) acc += k.cZ[mo + e] * p[e + k.NYP];
-            if (iz - 1 >= 1) acc += k.cZ[mo + e - k.NYP] * p[e - k.NYP];
-            rr += cabs2(b[so + e] - acc);
-            bb += cabs2(b[so + e]);
+            cplx bnd = cplx{0, 0};
+            if (iy + 1 <= k.ny - 1) acc += k.cY[mo + e] * p[e + 1]; else bnd -= k.cY[mo + e] * p[e + 1];
+            if (iy - 1 >= 1) acc += k.cY[mo + e - 1] * p[e - 1]; else bnd -= k.cY[mo + e - 1] * p[e - 1];
+            if (iz + 1 <= k.nz - 1) acc += k.cZ[mo + e] * p[e + k.NYP]; else bnd -= k.cZ[mo + e] * p[e + k.NYP];
+            if (iz - 1 >= 1) acc += k.cZ[mo + e - k.NYP] * p[e - k.NYP]; else bnd -= k.cZ[mo + e - k.NYP] * p[e - k.NYP];
+            const cplx bv = b ? b[so + e] : bnd;
+            rr += cabs2(bv - acc);
+            bb += cabs2(bv);
         }
     }
     block_sum2(rr, bb, sh);

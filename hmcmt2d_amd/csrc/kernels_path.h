@@ -19,13 +19,13 @@ __global__ void k_sigma(View v) { int c = TID1; if (c < v.nCell) item_sigma(v, c
 // lateral means of one cell row per wave (deterministic shuffle reduction)
 __global__ __launch_bounds__(64) void k_rowmean(View v) {
     const int kz = blockIdx.x;
-    double sa = 0.0, sl = 0.0, sh = 0.0;
+    double sa = 0.0, sl = 0.0;
     for (int ky = threadIdx.x; ky < v.ny; ky += 64) {
         const double s = v.sigma[(long)kz * v.ny + ky];
-        sa += s; sl += log(s); sh += 1.0 / s;
+        sa += s; sl += log(s);
     }
-    sa = wave_sum(sa); sl = wave_sum(sl); sh = wave_sum(sh);
-    if (threadIdx.x == 0) { v.sigMeanA[kz] = sa / v.ny; v.sigMeanG[kz] = (v.bgMean & 1) ? v.ny / sh : exp(sl / v.ny); }
+    sa = wave_sum(sa); sl = wave_sum(sl);
+    if (threadIdx.x == 0) { v.sigMeanA[kz] = sa / v.ny; v.sigMeanG[kz] = exp(sl / v.ny); }
 }
 struct LfView {
     int n;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64) void k_sigma_rows(View v, LfStep step) {
     tick_begin(v.ticks, TK_SIGMA);
     const int kz = blockIdx.x;
     const double mx = step.on ? lf_step_bound(step.L) : 0.0;
-    double sa = 0.0, sl = 0.0, sh = 0.0;
+    double sa = 0.0, sl = 0.0;
     for (int ky = threadIdx.x; ky < v.ny; ky += 64) {
         const long cell = (long)kz * v.ny + ky;
         const int a = v.cell2act[cell];
@@ -73,10 +73,10 @@ __global__ __launch_bounds__(64) void k_sigma_rows(View v, LfStep step) {
         if (a >= 0) ma = step.on ? lf_step_one(step.L, a, step.dt, step.lo, step.hi, mx) : v.m[a];      // (every parameter is one cell's)
         const double s = v.bg[cell] + (a >= 0 ? exp(ma) : 0.0);
         v.sigma[cell] = s;
-        sa += s; sl += log(s); sh += 1.0 / s;
+        sa += s; sl += log(s);
     }
-    sa = wave_sum(sa); sl = wave_sum(sl); sh = wave_sum(sh);
-    if (threadIdx.x == 0) { v.sigMeanA[kz] = sa / v.ny; v.sigMeanG[kz] = (v.bgMean & 1) ? v.ny / sh : exp(sl / v.ny); }
+    sa = wave_sum(sa); sl = wave_sum(sl);
+    if (threadIdx.x == 0) { v.sigMeanA[kz] = sa / v.ny; v.sigMeanG[kz] = exp(sl / v.ny); }
     tick_end(v.ticks, TK_SIGMA);
 }
 __global__ void k_coef(View v, int te_doK, int te_doM, int tm_doK, int tm_doM) {

@@ -118,13 +118,14 @@ def load_library():
     lib.hmcmt_debug_precond.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_persist_precond.argtypes = [vp, C.c_int32, c_double_p, c_double_p]
     lib.hmcmt_persist_info.argtypes = [vp, c_int64_p]
+    lib.hmcmt_guard.argtypes = [vp, c_double_p]
     lib.hmcmt_debug_fdm_fwd.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_back_post.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_double_p]
     for name in ("hmcmt_create", "hmcmt_destroy", "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters",
                  "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async",
                  "hmcmt_wait", "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead",
                  "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond",
-                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info"):
+                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -135,7 +136,7 @@ EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "h
                     "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async", "hmcmt_wait",
                     "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead", "hmcmt_dims",
                     "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
-                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
+                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
                     "hmcmt_comm_last_error"]
 
 
@@ -393,6 +394,12 @@ class HipContext:
         z = np.empty_like(r)
         self._check(self.lib.hmcmt_debug_precond(self.h, _dp(r), _dp(z)))
         return z
+
+    def guard(self):
+        """Production guard of the stopping rule (hmcmt_guard): true residuals formed every HMCMT_GUARD_EVERY-th evaluation."""
+        out = (C.c_double * 4)()
+        self._check(self.lib.hmcmt_guard(self.h, out))
+        return {"checks": int(out[0]), "worst_true_res": float(out[1]), "last_true_res": float(out[2]), "trips": int(out[3])}
 
     def persist_info(self):
         """The persistent solve kernel and this context (kernels_persist.h): shape, whether it is enabled, how many solves it ran."""

@@ -72,7 +72,7 @@ typedef struct hmcmt_stats {
     int32_t iters_fwd_max, iters_adj_max;   /* max over systems of the last call */
     int32_t iters_fwd_sum, iters_adj_sum;   /* sum over systems */
     double  err_est_max;                    /* max over systems of ||P^-1 r||/||x|| at exit */
-    double  true_res_max;                   /* max ||b-Ax||/||b|| (only with options.verify) */
+    double  true_res_max;                   /* max ||b-Ax||/||b|| (with options.verify, and in the guarded evaluations: hmcmt_guard) */
     int32_t status;                         /* 0 or HMCMT_ENOCONV / HMCMT_EBREAKDOWN */
     int32_t nsystems;                       /* 2*nFreq */
     int32_t fallback_solves;                /* solves of the last call (0..2) whose stragglers were restarted with the fp64
@@ -229,6 +229,7 @@ int hmcmt_debug_transform(hmcmt_ctx* ctx, int32_t which, const double* A, double
 int hmcmt_debug_flags(hmcmt_ctx* ctx, int32_t flags);
 int hmcmt_debug_spmv(hmcmt_ctx* ctx, const double* p, double* q);
 int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z);
+int hmcmt_guard(const hmcmt_ctx* ctx, double* out4);   /* {checks, worst true residual seen, last, trips (checks above HMCMT_GUARD_LIMIT, default 1e-6)}: the production guard of the stopping rule (every HMCMT_GUARD_EVERY-th evaluation, default 100) */
 int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out6);   /* {threads/2 (0: not applicable), workgroups per system, slots per XCD, enabled, solves, placement fallbacks} */
 int hmcmt_debug_persist_precond(hmcmt_ctx* ctx, int32_t sweeps, const double* r, double* z);   /* the persistent solve kernel's preconditioner (tests) */
 int hmcmt_debug_fdm_fwd(hmcmt_ctx* ctx, const double* t, double* out);   /* [2][S*vstride] complex: fused kernel | separate kernels */

@@ -25,7 +25,7 @@ struct Emul {
     void bind() {
         const HostProblem& h = hp;
         v.ny = h.ny; v.nz = h.nz; v.NYP = h.NYP; v.NZP = h.NZP; v.nFreq = h.nFreq; v.S = h.S; v.nRx = h.nRx;
-        v.nData = h.nData; v.nAC = h.nAC; v.nCell = h.nCell; v.zid = h.zid; v.dbg = 0; v.bgMean = 0; v.vstride = (long)h.NZP * h.NYP;
+        v.nData = h.nData; v.nAC = h.nAC; v.nCell = h.nCell; v.zid = h.zid; v.dbg = 0; v.vstride = (long)h.NZP * h.NYP;
         const size_t VS = (size_t)v.vstride;
         sigma.assign(h.nCell, 0); sigMeanA.assign(h.nz, 0); sigMeanG.assign(h.nz, 0);
         cY.assign(2 * VS, 0); cZ.assign(2 * VS, 0); dK.assign(2 * VS, 0); dM.assign(2 * VS, 0);
