@@ -1147,12 +1147,13 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (ctx->d_pstamps) {                                // HMCMT_STAMPS=persist: phases of the third iteration of the last solve
         std::vector<long long> st(16 * 256);
         hipMemcpy(st.data(), ctx->d_pstamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost);
-        double acc[12] = {0}; long n = 0;
+        double acc[12] = {0}, sl[3] = {0}; long n = 0, nsl = 0;
         for (int b = 0; b < 256; ++b) {
             const long long* p = &st[16 * b];
             if (!p[0] || !p[11]) continue;
             ++n;
             for (int i = 1; i < 12; ++i) acc[i] += (double)(p[i] - p[i - 1]);
+            if (p[12] && p[13]) { ++nsl; sl[0] += (double)(p[12] - p[3]); sl[1] += (double)(p[13] - p[12]); sl[2] += (double)(p[4] - p[13]); }   // (workgroups with a slab)
         }
 #ifdef HMCMT_PS_DBGX
         fprintf(stderr, "HMCMT_PS_DBGX: halo copies that differ from the owners' values, by halo row j = 0..4: z3 %lld %lld %lld %lld %lld | zf %lld %lld %lld %lld %lld | p %lld (total)\n",
@@ -1169,6 +1170,7 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
             fprintf(stderr, "HMCMT_STAMPS persist: %ld workgroups, third iteration of the last solve, mean us: pre-smooth %.2f fwd-transform %.2f wait-T1 %.2f slabs %.2f wait-T2 %.2f back-transform %.2f "
                             "post-smooth %.2f wait-R1 %.2f scalars+p+q %.2f wait-R2 %.2f update %.2f | iteration %.2f\n", n, acc[1] * us, acc[2] * us, acc[3] * us, acc[4] * us, acc[5] * us, acc[6] * us,
                     acc[7] * us, acc[8] * us, acc[9] * us, acc[10] * us, acc[11] * us, tot * us);
+            if (nsl) fprintf(stderr, "   slabs, the %ld workgroups that have one: load %.2f, the two sweeps %.2f, store %.2f us\n", nsl, sl[0] * us * n / nsl, sl[1] * us * n / nsl, sl[2] * us * n / nsl);
         }
     }
     if (ctx->sv.stamps) {                                // HMCMT_STAMPS: phase stamps of the last launch that wrote them

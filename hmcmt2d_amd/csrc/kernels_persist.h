@@ -227,9 +227,55 @@ __host__ __device__ inline size_t ps_slab_bytes(int NZP, int nz, int twist) {
     const size_t rl = (size_t)(twist ? mid + 1 : NZP) + PSL_PAD, nreg = twist ? 2 : 1;
     return (((size_t)NZP * 4 + 127) & ~(size_t)127) + 2 * nreg * rl * 4 + 32 * 8 + (2 * FW_TB * 32 + 2 * nreg * rl * 32 + 3 * FW_TB * 32) * 8;
 }
+// One sweep of a slab's serial chain x <- a - b x over whole blocks of FW_TB rows (DIR = +1 down the region, -1 up), b = f * ip.
+// The chain is ONE wave, and what it costs is that wave's instruction stream -- about 65 cycles a row whatever the arithmetic is
+// written in (unpacked FMAs, v_pk_fma_f32, compiler-scheduled fmaf: 3.25 / 3.23 / 3.07 us for the two sweeps of 50 rows), most of it
+// the LDS traffic of a lone wave (MI355X_MICROARCH.md, LDS: a store's operand transfer runs at half rate from one wave).  The rows
+// of the next block are REQUESTED before the chain of the block at hand and multiplied after it, so their LDS latency (three
+// dependent round trips per block when requested and used in one scheduling region: 4.7 us) runs under the chain's FMAs.
+// (Measured and lost: one 16-byte {a, b} record per row and mode, the elimination sweep writing {x, b'} back -- a row is one read,
+//  four FMAs, one write, but the 16-byte write costs the lone wave more than the multiply it saves: sweeps 2.8 us, the strided
+//  store pass +0.6 us.)
+__device__ __forceinline__ c32 ps_cms(c32 a, c32 b, c32 x) {
+    return c32{__builtin_fmaf(b.im, x.im, __builtin_fmaf(-b.re, x.re, a.re)), __builtin_fmaf(-b.im, x.re, __builtin_fmaf(-b.re, x.im, a.im))};
+}
+template <int DIR>
+__device__ __forceinline__ c32 ps_sweep(c32* pa, const c32* pb, const float* pf, int nblk, c32 pt) {
+    constexpr int D = DIR * 32;
+    c32 a0[FW_TB], b0[FW_TB], a1[FW_TB], b1[FW_TB], q[FW_TB];
+    float g[FW_TB];
+#pragma unroll
+    for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[t * D]; b0[t] = pf[t * DIR] * pb[t * D]; }
+    int bk = 0;
+    for (; bk + 1 < nblk; bk += 2) {
+#pragma unroll
+        for (int t = 0; t < FW_TB; ++t) { a1[t] = pa[(FW_TB + t) * D]; q[t] = pb[(FW_TB + t) * D]; g[t] = pf[(FW_TB + t) * DIR]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < FW_TB; ++t) { pt = ps_cms(a0[t], b0[t], pt); pa[t * D] = pt; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < FW_TB; ++t) b1[t] = g[t] * q[t];
+#pragma unroll
+        for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[(2 * FW_TB + t) * D]; q[t] = pb[(2 * FW_TB + t) * D]; g[t] = pf[(2 * FW_TB + t) * DIR]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < FW_TB; ++t) { pt = ps_cms(a1[t], b1[t], pt); pa[(FW_TB + t) * D] = pt; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < FW_TB; ++t) b0[t] = g[t] * q[t];
+        pa += 2 * FW_TB * D; pb += 2 * FW_TB * D; pf += 2 * FW_TB * DIR;
+    }
+    if (bk < nblk) {
+#pragma unroll
+        for (int t = 0; t < FW_TB; ++t) { pt = ps_cms(a0[t], b0[t], pt); pa[t * D] = pt; }
+    }
+    return pt;
+}
+
 template <int NT>
 __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s, int slab, const float2* __restrict__ yhat,
-                                              float2* __restrict__ ysol, const float2* __restrict__ ip32, int tidx) {
+                                              float2* __restrict__ ysol, const float2* __restrict__ ip32, int tidx, long long* stp = nullptr) {
     // (tidx: the caller's OPAQUE copy of tidx -- everything derived from the thread index here is invariant across the
     //  iterations of the solve, and the compiler hoisted all of it out of the iteration loop into registers it then spilled)
     constexpr int SW = 32;
@@ -312,6 +358,7 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s
         sj[tidx] = c32{jf.x, jf.y};
     }
     __syncthreads();
+    if (stp) stp[12] = wall_clock64();
     if (wave == 0 && lane < nreg * SW && t0 * 16 + (lane % SW) < k.ny - 1) {
         const int half = lane / SW, col = lane % SW;
         const int last = tw ? (half == 0 ? mid : n - mid) : n;      // rows 1..last of this lane's region are real
@@ -320,36 +367,7 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s
         const c32* rp = sp + (long)half * RL * SW + col;
         const float* g1 = f1 + half * RL;
         const float* g2 = f2 + half * RL;
-        c32 pt = c32{0, 0};
-        {
-            c32* pa = ra + SW;
-            const c32* pb = rp + SW;
-            const float* pf = g1 + 1;
-            c32 a0[FW_TB], b0[FW_TB], a1[FW_TB], b1[FW_TB];
-            const int nblk = (steps + FW_TB - 1) / FW_TB;
-#pragma unroll
-            for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[t * SW]; b0[t] = pf[t] * pb[t * SW]; }
-            int bk = 0;
-            for (; bk + 1 < nblk; bk += 2) {
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { a1[t] = pa[(FW_TB + t) * SW]; b1[t] = pf[FW_TB + t] * pb[(FW_TB + t) * SW]; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a0[t], b0[t], pt); pa[t * SW] = pt; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[(2 * FW_TB + t) * SW]; b0[t] = pf[2 * FW_TB + t] * pb[(2 * FW_TB + t) * SW]; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a1[t], b1[t], pt); pa[(FW_TB + t) * SW] = pt; }
-                __builtin_amdgcn_sched_barrier(0);
-                pa += 2 * FW_TB * SW; pb += 2 * FW_TB * SW; pf += 2 * FW_TB;
-            }
-            if (bk < nblk) {
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a0[t], b0[t], pt); pa[t * SW] = pt; }
-            }
-        }
+        c32 pt = ps_sweep<1>(ra + SW, rp + SW, g1 + 1, (steps + FW_TB - 1) / FW_TB, c32{0, 0});
         pt = ra[last * SW];                                   // (the identity rows left it unchanged)
         if (tw) {
             const c32 p2last = g2[last] * rp[last * SW];
@@ -362,37 +380,10 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s
             pt = half == 0 ? c32{xre, xim} : xbot;
             ra[last * SW] = pt;
         }
-        {
-            c32* pa = ra + (long)(last - 1) * SW;
-            const c32* pc = rp + (long)(last - 1) * SW;
-            const float* pf = g2 + (last - 1);
-            c32 a0[FW_TB], b0[FW_TB], a1[FW_TB], b1[FW_TB];
-            const int nblk = (steps - 1 + FW_TB - 1) / FW_TB;
-#pragma unroll
-            for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[-t * SW]; b0[t] = pf[-t] * pc[-t * SW]; }
-            int bk = 0;
-            for (; bk + 1 < nblk; bk += 2) {
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { a1[t] = pa[-(FW_TB + t) * SW]; b1[t] = pf[-(FW_TB + t)] * pc[-(FW_TB + t) * SW]; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a0[t], b0[t], pt); pa[-t * SW] = pt; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[-(2 * FW_TB + t) * SW]; b0[t] = pf[-(2 * FW_TB + t)] * pc[-(2 * FW_TB + t) * SW]; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a1[t], b1[t], pt); pa[-(FW_TB + t) * SW] = pt; }
-                __builtin_amdgcn_sched_barrier(0);
-                pa -= 2 * FW_TB * SW; pc -= 2 * FW_TB * SW; pf -= 2 * FW_TB;
-            }
-            if (bk < nblk) {
-#pragma unroll
-                for (int t = 0; t < FW_TB; ++t) { pt = cmsub(a0[t], b0[t], pt); pa[-t * SW] = pt; }
-            }
-        }
+        (void)ps_sweep<-1>(ra + (long)(last - 1) * SW, rp + (long)(last - 1) * SW, g2 + (last - 1), (steps - 1 + FW_TB - 1) / FW_TB, pt);
     }
     __syncthreads();
+    if (stp) stp[13] = wall_clock64();
     // solved slab -> ysol, pre-split for the back transform (store_t32's format), 16-byte stores
     {
         constexpr int NG = SW / 8;
@@ -747,7 +738,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             if (!sys_sync()) { alive = false; break; }                         // T1: every row of yhat is in the L2
             PS_STAMP(3)
             // ================= tridiagonal solves of this workgroup's mode slabs =================
-            for (int slab = jwg; slab < nslab; slab += G) ps_slab_solve<NT>(k, arena, s, slab, a.yhat, a.ysol, a.ip32, tidv);
+            for (int slab = jwg; slab < nslab; slab += G) ps_slab_solve<NT>(k, arena, s, slab, a.yhat, a.ysol, a.ip32, tidv, stampNow ? a.stamps + (long)blockIdx.x * 16 : nullptr);
             PS_STAMP(4)
             u4v bbk[8][2];                                                     // the wave's V' fragments of the back transform: in flight during the wait
             {

@@ -132,3 +132,41 @@ def test_hip_gradient_against_richardson_differences_of_its_own_forward():
     # and the HIP difference quotients against the oracle's committed ones
     sc = _scale(g, cells)
     assert (np.abs(fd_full - fd["fd_full"]) / sc).max() < 1e-5 and (np.abs(fd_frozen - fd["fd_frozen"]) / sc).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_share_of_the_boundary_derivative_terms_on_the_headline_mesh(capsys):
+    """How much of the HEADLINE gradient (cfg3: 200 x 100 cells, 16 frequencies, the rough state bench.py's chain starts
+    from) rests on the restated boundary-derivative terms BTvii + BTvio (compJacTMatVec.jl:237-242, 309-316 with
+    MT1DSensitivity.jl:94-243) -- the part of J^T v the difference-quotient pin above checks only to within its own size.
+    Per cell: |g - g_without_boundary_terms| / max(|g|, 1e-3 max|g|); reported over the core, the padding columns and the
+    deepest five rows (DESIGN section 2 quotes this line), and bounded loosely so that a change of regime is noticed."""
+    import json
+    from hmcmt2d_amd.lib import HipContext
+    from tests.helpers import make_problem
+    mesh, data, inv, m = make_problem("cfg3")
+    ny = mesh.gridSize[0]
+    assert len(m) % ny == 0
+    rows = len(m) // ny
+    ctx = HipContext(mesh, data, inv)
+    _, _, g = ctx.grad(m)
+    ctx.debug_flags(no_boundary_terms=True)
+    _, _, pq = ctx.grad(m + 0.0)
+    ctx.debug_flags()
+    ctx.close()
+    share = (np.abs(g - pq) / np.maximum(np.abs(g), 1e-3 * np.abs(g).max())).reshape(rows, ny)
+    npy, npz = 7, 8                                        # synthetic.make_mesh defaults: padding columns per side, padding rows
+    col = np.arange(ny)
+    pad_c = (col < npy) | (col >= ny - npy)
+    regions = {"core": share[:rows - npz][:, ~pad_c], "padding_columns": share[:, pad_c], "deepest_5_rows": share[rows - 5:, :]}
+    out = {k: {"median": float(np.median(v)), "max": float(v.max())} for k, v in regions.items()}
+    out["all"] = {"median": float(np.median(share)), "max": float(share.max()),
+                  "l2_share": float(np.linalg.norm(g - pq) / np.linalg.norm(g))}
+    with capsys.disabled():
+        print("\n[cfg3, rough state] share of BTvii + BTvio per cell: " +
+              "; ".join(f"{k} median {v['median']:.2e} max {v['max']:.2e}" for k, v in out.items()) +
+              f"; ||g - g_PQ|| / ||g|| = {out['all']['l2_share']:.2e}")
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/boundary_share_cfg3.json", "w") as f:
+            json.dump(out, f, indent=1)
+    assert out["core"]["median"] < 0.05 and out["all"]["l2_share"] < 0.2
