@@ -521,6 +521,10 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
     const int nslab = (NTc + 1) / 2;
 
     for (int round = 0; alive; ++round) {
+        // (XCD x takes systems x, x + 8, ...: frequencies far apart, both polarisations.  Consecutive systems per XCD -- its L2
+        //  would hold the fp64 stencil coefficients of one polarisation instead of two -- leave the iteration at 42 us and cost the
+        //  headline chain 3 %: the slow systems of a solve are neighbours in frequency and then share an L2 to the end, while
+        //  here they are spread over the XCDs, each running alone at 39 us per iteration once its neighbours are done.)
         const int s = xcd + 8 * (slot + a.slots * round);
         if (s >= k.S) break;
         if (!k.active[s]) continue;
