@@ -273,8 +273,35 @@ __device__ __forceinline__ c32 ps_sweep(c32* pa, const c32* pb, const float* pf,
     return pt;
 }
 
+// per-row scalars of a system's slab sweeps (o of the row's coefficient in the elimination / in the substitution sweep): constant
+// over the solve, so they are formed once per system and live behind the coefficient planes -- in the slab arena they were formed
+// again in every iteration, a dependent round trip to memory in front of the slab's loads.  Padding rows: zeros in front of a
+// region, identity rows behind it (ip = -1, f1 = 1: x stays).
+__host__ __device__ inline int ps_tab_floats(int NZP, int nz, int twist) {
+    const int n = nz - 1, mid = twist ? (n + 1) / 2 : n;
+    return (twist ? 2 : 1) * ((twist ? mid + 1 : NZP) + PSL_PAD);
+}
 template <int NT>
-__device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s, int slab, const float2* __restrict__ yhat,
+__device__ __forceinline__ void ps_slab_tables(const Solver& k, int mode, float* f1, float* f2, int tidx) {
+    const int NZP = k.NZP, n = k.nz - 1;
+    const int tw = k.twist, mid = twist_mid(n, tw);
+    const int RCAP = tw ? mid + 1 : NZP, RL = RCAP + PSL_PAD, nreg = tw ? 2 : 1;
+    const double* ofz = k.ofz + (long)mode * NZP;
+    for (int i = tidx; i < nreg * RL; i += NT) {
+        const int reg = i / RL, rl = i - reg * RL;
+        const int row = (tw && reg == 1) ? n + 1 - rl : rl;
+        const int last = tw ? (reg == 0 ? mid : n + 1 - (mid + 1)) : NZP - 1;          // last initialised row of the region
+        float v1 = 0.f, v2 = 0.f;
+        if (rl >= 1 && rl <= last && row >= 1 && row <= n) {
+            const bool bottom = tw && reg == 1;
+            const float o0 = (float)ofz[row - 1], o1 = (float)ofz[row];
+            v1 = bottom ? o1 : o0; v2 = bottom ? o0 : o1;
+        } else if (rl > last && rl <= last + FW_TB) v1 = 1.f;
+        f1[i] = v1; f2[i] = v2;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, const float* f1, const float* f2, int s, int slab, const float2* __restrict__ yhat,
                                               float2* __restrict__ ysol, const float2* __restrict__ ip32, int tidx, long long* stp = nullptr) {
     // (tidx: the caller's OPAQUE copy of tidx -- everything derived from the thread index here is invariant across the
     //  iterations of the solve, and the compiler hoisted all of it out of the iteration loop into registers it then spilled)
@@ -282,35 +309,16 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s
     const int NYP = k.NYP, NZP = k.NZP, n = k.nz - 1;
     const int tw = k.twist, mid = twist_mid(n, tw);
     const int RCAP = tw ? mid + 1 : NZP, RL = RCAP + PSL_PAD, nreg = tw ? 2 : 1;
-    float* sof = reinterpret_cast<float*>(smem);
-    float* f1 = reinterpret_cast<float*>(smem + (((long)NZP * 4 + 127) & ~127L));      // [nreg][RL] o of the elimination sweep's coefficient
-    float* f2 = f1 + nreg * RL;                                                          // ... of the substitution sweep's
-    c32* sj = reinterpret_cast<c32*>(f2 + nreg * RL);
+    c32* sj = reinterpret_cast<c32*>(smem + (((long)NZP * 4 + 127) & ~127L) + (long)2 * nreg * RL * 4);
     c32* sa = sj + SW + 2 * FW_TB * SW;                  // -> region 0, row 0
     c32* sp = sa + (long)nreg * RL * SW;                 // inverse pivots, same layout
     auto lidx = [&](int row) { return (tw && row > mid) ? RL + (n + 1 - row) : row; };   // slab row of a matrix row
-    const int mode = s >= k.nFreq;
     const long so = (long)s * k.vstride;
     const int t0 = slab * 2;
     const int lane = tidx & 63, wave = tidx >> 6;
-    // per-row scalars of the two sweeps (o of the row's coefficient; constant over the solve, 2 KB: straight from memory, one pass);
-    // padding rows: zeros in front of a region, identity rows behind it (ip = -1, f1 = 1: x stays)
-    (void)sof;
-    {
-        const double* ofz = k.ofz + (long)mode * NZP;
-        for (int i = tidx; i < nreg * RL; i += NT) {
-            const int reg = i / RL, rl = i - reg * RL;
-            const int row = (tw && reg == 1) ? n + 1 - rl : rl;
-            const int last = tw ? (reg == 0 ? mid : n + 1 - (mid + 1)) : NZP - 1;          // last initialised row of the region
-            float v1 = 0.f, v2 = 0.f;
-            if (rl >= 1 && rl <= last && row >= 1 && row <= n) {
-                const bool bottom = tw && reg == 1;
-                const float o0 = (float)ofz[row - 1], o1 = (float)ofz[row];
-                v1 = bottom ? o1 : o0; v2 = bottom ? o0 : o1;
-            } else if (rl > last && rl <= last + FW_TB) v1 = 1.f;
-            f1[i] = v1; f2[i] = v2;
-        }
-    }
+    // join factor 1 / (1 - c c') of the two halves (item_pivot): requested with the slab's rows, not behind them
+    const int cj = t0 * 16 + (tidx & (SW - 1));
+    const float2 jfl = *ps_at(ip32 + so, (unsigned)min(cj, NYP - 1));
     // rows of the slab: a = y * ip, and ip -- two modes (16 bytes) per load, one batch
     {
         constexpr int PB = 4, HW = SW / 2;          // (108 rows x 16 mode pairs over 512 threads: 3.4 pairs per thread)
@@ -352,11 +360,7 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, int s
         sa[front] = z; sp[front] = z;
         sa[back] = z; sp[back] = c32{-1.f, 0.f};
     }
-    if (tidx < SW) {                                 // join factor 1 / (1 - c c') of the two halves (item_pivot)
-        const int c = t0 * 16 + tidx;
-        const float2 jf = (tw && c < k.ny - 1) ? ip32[so + c] : float2{1.f, 0.f};
-        sj[tidx] = c32{jf.x, jf.y};
-    }
+    if (tidx < SW) sj[tidx] = (tw && cj < k.ny - 1) ? c32{jfl.x, jfl.y} : c32{1.f, 0.f};
     __syncthreads();
     if (stp) stp[12] = wall_clock64();
     if (wave == 0 && lane < nreg * SW && t0 * 16 + (lane % SW) < k.ny - 1) {
@@ -420,7 +424,7 @@ __host__ __device__ inline size_t ps_shared_bytes(int NYP, int NZP, int nz, int 
     return ((a > b ? a : b) + 255) & ~(size_t)255;
 }
 __host__ __device__ inline size_t ps_lds_bytes(int NYP, int NZP, int nz, int twist) {
-    return 1024 + ps_shared_bytes(NYP, NZP, nz, twist) + (size_t)3 * PS_ROWS * NYP * 4 + 64;
+    return 1024 + ps_shared_bytes(NYP, NZP, nz, twist) + (size_t)3 * PS_ROWS * NYP * 4 + 64 + (((size_t)2 * ps_tab_floats(NZP, nz, twist) * 4 + 128 + 63) & ~(size_t)63);
 }
 
 #define PS_STAMP(i) if (stampNow) a.stamps[(long)blockIdx.x * 16 + (i)] = wall_clock64();
@@ -512,6 +516,8 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
     unsigned short* PL = reinterpret_cast<unsigned short*>(arena);       // planes [24][4][NYP] bf16 (+ 64 B the last k-group over-reads): the first tile's space
     float* coE = reinterpret_cast<float*>(arena + ps_shared_bytes(NYP, k.NZP, nz, k.twist));
     const PsPl co{coE, coE + PS_ROWS * NYP, coE + 2 * PS_ROWS * NYP};
+    float* const tabF1 = coE + 3 * PS_ROWS * NYP + 16;                     // row scalars of the slab sweeps (ps_slab_tables), per system
+    float* const tabF2 = tabF1 + ps_tab_floats(k.NZP, nz, k.twist);
     // MFMA work split: column tiles of 16 over the waves, at most two per wave (NYP <= 32 NWV)
     const int NTc = NYP >> 4, KG = (NYP + 31) >> 5;
     const int tbase = NTc / NWV, textra = NTc - tbase * NWV;
@@ -560,6 +566,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                 }
             }
         }
+        ps_slab_tables<NT>(k, mode, tabF1, tabF2, tid);
         // ---- state: r of the own rows (fp64), r of the halo rows (complex64, refreshed from the owners every iteration)
         cplx r64[PS_NO];
         c32 rh[PS_HALO];
@@ -742,7 +749,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             if (!sys_sync()) { alive = false; break; }                         // T1: every row of yhat is in the L2
             PS_STAMP(3)
             // ================= tridiagonal solves of this workgroup's mode slabs =================
-            for (int slab = jwg; slab < nslab; slab += G) ps_slab_solve<NT>(k, arena, s, slab, a.yhat, a.ysol, a.ip32, tidv, stampNow ? a.stamps + (long)blockIdx.x * 16 : nullptr);
+            for (int slab = jwg; slab < nslab; slab += G) ps_slab_solve<NT>(k, arena, tabF1, tabF2, s, slab, a.yhat, a.ysol, a.ip32, tidv, stampNow ? a.stamps + (long)blockIdx.x * 16 : nullptr);
             PS_STAMP(4)
             u4v bbk[8][2];                                                     // the wave's V' fragments of the back transform: in flight during the wait
             {
