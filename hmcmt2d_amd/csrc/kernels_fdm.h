@@ -468,6 +468,16 @@ constexpr int KCH = 7;             // k-groups (of 32) whose operands are reques
 constexpr int LP_NTW = 2;          // column tiles per wave of the mixed-precision transform: many light waves hide latency
 
 __device__ __forceinline__ float bf16_to_f32(unsigned h) { return __uint_as_float(h << 16); }
+// two floats -> their bf16 roundings (to nearest even) packed in one word, and the bf16 roundings of what the first rounding left:
+// v_cvt_pk_bf16_f32 (gfx950) -- 5 instructions for the hi/lo split of a pair against ~20 with the integer rounding of bf16_rn
+// (same results on finite values)
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16_pk(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{a, b}, bf2v)); }
+__device__ __forceinline__ void bf16_split_pk(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = bf16_pk(a, b);
+    lo = bf16_pk(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
 
 // A: complex64 rows.  Every value is split in registers into hi = bf16(x), lo = bf16(x - hi) and the
 // product is accumulated as Ah*Bh + Al*Bh [+ Ah*Bl with HMCMT_VLO] (fp32 accumulators): the input to ~16 mantissa

@@ -400,11 +400,10 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, const
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const c32 v0 = src[2 * q], v1 = src[2 * q + 1];
-                const unsigned r0 = bf16_rn(v0.re), i0 = bf16_rn(v0.im), r1 = bf16_rn(v1.re), i1 = bf16_rn(v1.im);
-                pl[0][q] = r0 | (r1 << 16);
-                pl[1][q] = i0 | (i1 << 16);
-                pl[2][q] = bf16_rn(v0.re - bf16_to_f32(r0)) | (bf16_rn(v1.re - bf16_to_f32(r1)) << 16);
-                pl[3][q] = bf16_rn(v0.im - bf16_to_f32(i0)) | (bf16_rn(v1.im - bf16_to_f32(i1)) << 16);
+                unsigned hr, lr, hi, li;
+                bf16_split_pk(v0.re, v1.re, hr, lr);
+                bf16_split_pk(v0.im, v1.im, hi, li);
+                pl[0][q] = hr; pl[1][q] = hi; pl[2][q] = lr; pl[3][q] = li;
             }
             unsigned short* b = yb + (long)row * 4 * NYP + c0;
 #pragma unroll
@@ -697,10 +696,10 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                     const int j = PS_HALO + q, g = gb + gs * j;
                     const int rho = tb + gs * j - PS_HALO;                     // row of the 16-row operand: tile row - 5
                     unsigned short* b = PL + (long)rho * 4 * NYP + iyv;
-                    const unsigned hr = bf16_rn(tv[q].re), hi = bf16_rn(tv[q].im);
-                    b[0] = (unsigned short)hr; b[NYP] = (unsigned short)hi;
-                    b[2 * NYP] = (unsigned short)bf16_rn(tv[q].re - bf16_to_f32(hr));
-                    b[3 * NYP] = (unsigned short)bf16_rn(tv[q].im - bf16_to_f32(hi));
+                    unsigned hp, lp;                                           // {re, im} packed: hi parts, lo parts
+                    bf16_split_pk(tv[q].re, tv[q].im, hp, lp);
+                    b[0] = (unsigned short)hp; b[NYP] = (unsigned short)(hp >> 16);
+                    b[2 * NYP] = (unsigned short)lp; b[3 * NYP] = (unsigned short)(lp >> 16);
                     if (SW == 2 && g >= 1 && g <= nz - 1) *ps_at(tbuf, eo(j)) = float2{tv[q].re, tv[q].im};
                 }
             }
