@@ -1262,6 +1262,9 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     if (device_id < 0 || device_id >= ndev) { ctx->err = "device_id out of range"; return HMCMT_ENODEV; }
     ctx->device = device_id;
     if (ctx->hp.NZP > MAXNZP) { ctx->err = "nz too large for the tridiagonal kernel (nz+1 > 1024)"; return HMCMT_EINVAL; }
+    // the fp64 eigen-transform kernel (fdm_precision = 1, and the restart of a stagnating mixed-precision solve) holds at most
+    // 28 column tiles of 16 nodes: wider meshes are refused here, not at the first solve that needs it
+    if (ctx->hp.NYP / 16 > 28) { ctx->err = "mesh too wide: ny + 1 > 448 nodes (include/hmcmt.h, hmcmt_create)"; return HMCMT_EINVAL; }
     HIPCHK(hipSetDevice(device_id));
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));

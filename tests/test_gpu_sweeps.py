@@ -140,3 +140,21 @@ def test_wide_mesh_path_against_the_oracle(sweeps, monkeypatch):
     shallow, deep = gerr_split(grad, go, inv, mesh)
     assert shallow < 1e-8 + 10 * noise[0] and deep < 5e-6 + 10 * noise[1], (shallow, deep, noise)
     ctx.close()
+
+
+def test_mesh_wider_than_the_transform_kernels_is_refused_at_create():
+    """include/hmcmt.h, hmcmt_create: ny + 1 <= 448 nodes.  The fp64 eigen-transform (fdm_precision = 1, and the restart of a
+    stagnating mixed-precision solve) holds 28 column tiles; a wider mesh used to fail at the first solve that needed it."""
+    from tests.helpers import ragged_problem
+    from hmcmt2d_amd.lib import HmcmtError
+    mesh, data, inv, m = ragged_problem(452, 12, 1, 4, 4, 3)
+    with pytest.raises(HmcmtError) as e:
+        HipContext(mesh, data, inv)
+    assert "EINVAL" in str(e.value) and "448" in str(e.value)
+    mesh, data, inv, m = ragged_problem(440, 12, 1, 4, 4, 3)          # NYP = 448: the widest mesh, launch-per-phase path
+    ctx = HipContext(mesh, data, inv, verify=True)
+    assert ctx.NYP == 448 and ctx.persist_info()["threads_half"] == 0
+    p, f, g = ctx.grad(m)
+    st = ctx.stats()
+    ctx.close()
+    assert st["status"] == 0 and st["true_res_max"] < 1e-9 and np.isfinite(g).all()
