@@ -27,7 +27,7 @@ using Distributed              # myid
 using HMCMT.HMCFileIO, HMCMT.HMCStruct, HMCMT.HMCUtility
 
 export HipContext, hipContext, compDataGradient, hipForward, setPrior!, proposeLeapfrog, proposeLeapfrogDevice!,
-       hipWait, hipStats, destroy!, commId, SampleComm, allgatherSamples
+       hipWait, hipStats, hipGuard, destroy!, commId, SampleComm, allgatherSamples
 
 const libhmcmt = get(ENV, "HMCMT_HIP_LIB", joinpath(@__DIR__, "..", "hmcmt2d_amd", "libhmcmt_hip.so"))
 
@@ -304,6 +304,20 @@ function hipStats(ctx::HipContext)
     rc = ccall((:hmcmt_get_stats, libhmcmt), Cint, (Ptr{Cvoid}, Ref{HmcmtStats}), ctx.ptr, st)
     checkerr(ctx.ptr, rc)
     return st[]
+end
+
+"""
+    hipGuard(ctx) -> (checks, worst, last, trips)
+
+The production guard of the iterative solves (`hmcmt_guard`, DESIGN 4.3): true residuals of both solves, formed every
+`HMCMT_GUARD_EVERY`-th evaluation; `trips` counts the checks above `HMCMT_GUARD_LIMIT`.  A sampler loop reads it once per
+output interval next to `hmcstats` and stops the chain on a trip.
+"""
+function hipGuard(ctx::HipContext)
+    out = zeros(Float64, 4)
+    rc = ccall((:hmcmt_guard, libhmcmt), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.ptr, out)
+    checkerr(ctx.ptr, rc)
+    return (checks = Int(out[1]), worst = out[2], last = out[3], trips = Int(out[4]))
 end
 
 end # module
