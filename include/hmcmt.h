@@ -98,8 +98,9 @@ void hmcmt_default_options(hmcmt_options* opts);
  *   activeIdx[nAC]    1-based cell id of each active cell (= activeCell.rowval), bgModel[ny*nz]
  *   opts              NULL for defaults
  * Limits: ny + 1 <= 448 nodes across (HMCMT_EINVAL otherwise: the fp64 eigen-transform of the preconditioner holds 28 column
- * tiles); meshes up to 256 nodes wide and ~250 rows deep run the one-launch-per-solve kernel, wider ones four to six launches
- * per iteration. */
+ * tiles); meshes up to 207 cells wide (and nz up to 139 rows at that width, more on narrower meshes: DESIGN 5.0, "Envelope")
+ * run the one-launch-per-solve kernel, all others four to six launches per iteration;
+ * hmcmt_persist_info tells which. */
 int hmcmt_create(hmcmt_ctx** ctx, int32_t device_id,
                  int64_t ny, int64_t nz, const double* yLen, const double* zLen, const double* origin,
                  int64_t nFreq, const double* freqs,

@@ -33,17 +33,38 @@ def start_model(mesh, inv):
     return np.log(S.true_model_sigma(mesh)[inv.activeIdx])
 
 
+# the second chain (round 4): BASELINE configs[0]'s mesh -- 96 x 49 earth cells, 4 frequencies, the 2-layer model without the
+# block (synthetic.CONFIGS["cfg1"], observations of cfg1.npz) --, 100 samples, the same sampler settings
+CHAINS = {"cfg2": dict(nsamples=NSAMPLES, burn=50), "cfg1": dict(nsamples=100, burn=25)}
+
+
+def chain_prior_of(name):
+    from hmcmt2d_amd.structs import HMCPrior
+    c = CHAINS[name]
+    return HMCPrior(totalsamples=c["nsamples"], burninsamples=c["burn"], dt=0.015, timestep=[6, 10], sigBounds=[1e-4, 1.0], regParam=1.0)
+
+
+def start_model_of(name, mesh, inv):
+    from hmcmt2d_amd import synthetic as S
+    return np.log(S.true_model_sigma(mesh, block=(name != "cfg1"))[inv.activeIdx])
+
+
 if __name__ == "__main__":
     from oracle import hmcmt_oracle as O
     from tests.helpers import make_problem
-    mesh, data, inv, _ = make_problem("cfg2")
+    name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+    nmax = int(sys.argv[2]) if len(sys.argv) > 2 else None         # (a shorter trial run: nothing is written)
+    mesh, data, inv, _ = make_problem(name)
     O.setupTensorMesh2D(mesh)
-    prior = chain_prior()
-    inv.strModel = start_model(mesh, inv)
+    prior = chain_prior_of(name)
+    if nmax:
+        prior.totalsamples = nmax; prior.burninsamples = min(prior.burninsamples, nmax // 2)
+    inv.strModel = start_model_of(name, mesh, inv)
     t0 = time.time()
     hm, st, hd = O.runHMCSampler(mesh, data, copy.deepcopy(inv), prior, np.random.default_rng(SEED), rhoref=RHOREF, dense_dbc=False)
     print("chain done in %.0f s: accepted %d of %d, nfevals %d, misfit %.1f -> %.1f" % (
-        time.time() - t0, st["nAccept"], NSAMPLES, prior.nfevals, st["hmstats"][0, 0], st["hmstats"][0, -1]))
-    np.savez_compressed(os.path.join(HERE, "cfg2_chain.npz"), hmstats=st["hmstats"], acceptstats=st["acceptstats"],
-                        samples32=hm.astype(np.float32), mean=hm.mean(1), std=hm.std(1), nfevals=prior.nfevals,
-                        first=hm[:, :5], last=hm[:, -1], data_last=hd[:, -1])
+        time.time() - t0, st["nAccept"], prior.totalsamples, prior.nfevals, st["hmstats"][0, 0], st["hmstats"][0, -1]))
+    if not nmax:
+        np.savez_compressed(os.path.join(HERE, f"{name}_chain.npz"), hmstats=st["hmstats"], acceptstats=st["acceptstats"],
+                            samples32=hm.astype(np.float32), mean=hm.mean(1), std=hm.std(1), nfevals=prior.nfevals,
+                            first=hm[:, :5], last=hm[:, -1], data_last=hd[:, -1])
