@@ -135,3 +135,30 @@ def test_iteration_cap_is_reported_by_the_persistent_kernel(monkeypatch):
     p, f, g = ctx.grad(m)                                  # ... and the context recovers (cold start after a failure)
     assert ctx.stats()["status"] == 0
     ctx.close()
+
+
+def test_more_systems_than_slots_run_in_rounds(monkeypatch):
+    """A system group (G workgroups of one XCD) takes the next system when its own is done: 44 systems on a mesh whose 100 rows
+    need 8 workgroups each (4 groups per XCD, 32 at a time) -- every system solved, to the launch-per-phase loop's results."""
+    from hmcmt2d_amd import synthetic as S, invsetup as I
+    from tests.helpers import start_sigma
+    mesh = S.make_mesh(60, 93)
+    data = S.make_data_layout(S.log_freqs(22), np.arange(-2000.0, 2001.0, 500.0))
+    n = len(data.rxID)
+    obs = np.full(n, 0.02 + 0.02j) * np.where(data.dtID == 1, 1.0, -1.0)
+    mesh.sigma = start_sigma(mesh)
+    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, obs, np.full(n, 1e-3))
+    m = S.rough_state(len(inv.strModel))
+    res = {}
+    for persist in (False, True):
+        ctx = _ctx(monkeypatch, mesh, data, inv, persist, 2, verify=True)
+        res[persist] = ctx.grad(m) + (ctx.stats(), ctx.persist_info())
+        if persist:
+            a = ctx.grad(m + 0.01)                                        # (a warm-started one as well)
+            assert ctx.stats()["status"] == 0
+        ctx.close()
+    (p0, f0, g0, s0, i0), (p1, f1, g1, s1, i1) = res[False], res[True]
+    assert s1["nsystems"] == 44 and i1["workgroups_per_system"] == 8 and i1["slots_per_xcd"] == 4 and i1["solves"] == 2
+    assert s1["status"] == 0 and s1["true_res_max"] < 1e-9 and s1["fallback_solves"] == 0
+    assert abs(s1["iters_fwd_sum"] - s0["iters_fwd_sum"]) <= 0.05 * s0["iters_fwd_sum"] + 2
+    assert relmax(p1, p0) < 1e-9 and abs(f1 - f0) / abs(f0) < 1e-9 and relmax(g1, g0) < 1e-8
