@@ -1,0 +1,42 @@
+"""Soak of the persistent solve kernel: thousands of warm-started evaluations along a random walk of models on every shape
+of the kernel (64 / 128 / 256 threads per half; 1, 3, 8 workgroups per system), the stopping-rule guard on every 10th
+evaluation, the true-residual check at the end.  Prints what a reader needs to see: no failed solve, no placement
+fallback, no guard trip, the worst true residual, evaluations per second.
+    python -m scripts.gpu_persist_soak [evaluations]"""
+import os
+import sys
+import time
+import numpy as np
+
+os.environ["HMCMT_GUARD_EVERY"] = "10"
+os.environ["HMCMT_PERSIST"] = "1"
+from hmcmt2d_amd.lib import HipContext
+from tests.helpers import make_problem
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+for name in ("tiny", "cfg2", "cfg1", "cfg3"):
+    mesh, data, inv, m = make_problem(name)
+    ctx = HipContext(mesh, data, inv)
+    rng = np.random.default_rng(11)
+    mm = m.copy()
+    n = N if name != "cfg3" else N
+    bad = 0
+    t0 = time.time()
+    for k in range(n):
+        mm = np.clip(mm + 0.02 * rng.standard_normal(mm.size), np.log(1e-4), 0.0)
+        try:
+            p, f, g = ctx.grad(mm)
+            if not (np.isfinite(f) and np.isfinite(g).all()):
+                bad += 1
+        except Exception as e:
+            bad += 1
+            print(f"   {name} evaluation {k}: {e}", flush=True)
+    dt = time.time() - t0
+    info, gd = ctx.persist_info(), ctx.guard()
+    ctx.set_options(verify=True)
+    ctx.grad(mm + 1e-3)
+    st = ctx.stats()
+    ctx.close()
+    print(f"{name}: {n} evaluations in {dt:.1f} s ({n / dt:.0f}/s), failed {bad}, persistent solves {info['solves']} of {2 * n + 2}, placement fallbacks {info['placement_fallbacks']}, "
+          f"guard checks {gd['checks']} trips {gd['trips']} worst {gd['worst_true_res']:.1e}; final verify: status {st['status']} true_res {st['true_res_max']:.1e} "
+          f"iters {st['iters_fwd_max']}/{st['iters_adj_max']} fp64 restarts in the last evaluation {st['fallback_solves']}", flush=True)
