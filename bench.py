@@ -400,7 +400,9 @@ def main():
         t5 = time.perf_counter() - t5
         extras["two_chains_per_gpu"] = {"steps_per_s_aggregate": 2 * Ke / t5, "steps_per_chain": Ke,
                                         "state": "two independent chains near the true model on ONE GPU (two contexts, two host "
-                                                 "threads): the launches of one chain are latency-bound, two overlap"}
+                                                 "threads). Since round 4 a second context makes both use the launch-per-phase loop (two "
+                                                 "persistent kernels cannot share a device), so this leg is round 3's path: compare with "
+                                                 "near_true_state, ONE chain with the persistent kernel -- the lever is superseded (DESIGN 7)"}
         ctxb.close()
 
     if rank == 0:
