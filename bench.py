@@ -471,7 +471,7 @@ def main():
                      "system_iterations_per_launch": it_sys / max(n_c, 1), "preconditioner_applications_per_launch": pre_sys / max(n_c, 1),
                      "bytes_per_unknown_and_iteration": it_bpu, "us_per_iteration": it_us, "active_systems_per_iteration": sys_per_it,
                      "active_systems_per_launch": sys_per_it, "launches_per_iteration": 0,
-                     "mfma": {"flops_per_launch": flops, "achieved_tflops": flops / (avg_us * 1e-6) / 1e12, "peak_tflops_bf16_dense": 2500.0},
+                     "mfma": {"flops_per_launch": flops, "achieved_tflops": flops / (avg_us * 1e-6) / 1e12 if n_c else 0.0, "peak_tflops_bf16_dense": 2500.0},
                      "population": population}
             iteration = {"kernels": 1, "two_sweep_fraction": f2, "bytes": Usys * it_bpu * sys_per_it, "us": it_us,
                          "achieved": Usys * it_bpu * sys_per_it / (it_us * 1e-6) / 1e9 if n_c else 0.0, "unit": "GB/s",
@@ -482,7 +482,8 @@ def main():
             return [entry], iteration, step_bytes
 
         def build_roofline(prof, cnt, population, every):
-            if cnt.get("persistent_solves", 0) > 0 and cnt["persistent_solves"] >= cnt["solves"]:
+            if (cnt.get("persistent_solves", 0) > 0 and cnt["persistent_solves"] >= cnt["solves"]) or \
+               (cnt.get("solves", 0) == 0 and ctx.persist_info()["solves"] > 0):       # (nothing sampled, HMCMT_BENCH_NOPROF: name the path that ran)
                 return build_roofline_persistent(prof, cnt, population, every)
             fwd_fused = ctx.NYP <= 256                      # the library's own rule (launch_fdm_fwd): wide meshes run the separate kernels
             back_fused = fwd_fused                          # ... and k_back_post goes with it (launch_back_post)
