@@ -1,15 +1,15 @@
 // kernels_persist.h -- part of libhmcmt_hip.so; included by hmcmt_hip.hip INSIDE its anonymous namespace (one translation unit).
 //
 // The whole COCG solve of the default path (Jacobi / FDM / Jacobi preconditioner, mixed precision) as ONE persistent
-// kernel (round 4; VERDICT r3 item 1, DESIGN section 5a).  The launch-per-phase form (k_spmv_fused -> k_update_fused ->
+// kernel (round 4; VERDICT r3 item 1, DESIGN section 5.0).  The launch-per-phase form (k_spmv_fused -> k_update_fused ->
 // k_fdm_fwd -> k_back_post, kernels_fused.h / kernels_fdm.h) moves every vector of every system through the fabric four
 // times per iteration and pays four launch ramps; but every dependency of an iteration is per SYSTEM, a system's vectors
 // (x, r, p: 0.9 MB) fit the registers of a few CUs, and a barrier among workgroups of ONE XCD costs ~1 us
 // (scripts/probe/xcd_barrier.hip).  Here a system is solved by G = ceil((nz-1)/14) workgroups of one XCD:
 //
 //   * workgroup j of a system OWNS the interior node rows 1+14j .. 14+14j; thread (iy, c) owns the column iy of 7 of them
-//     and keeps r (fp64) of those nodes in registers for the whole solve, together with the float stencil coefficients of
-//     its 12 tile rows; x stays in memory (touched once per iteration by its owner);
+//     and keeps r (fp64) of those nodes in registers for the whole solve; the float stencil coefficients of the 24 tile rows
+//     live in three LDS planes beside the tiles; x stays in memory (touched once per iteration by its owner);
 //   * the tile of a workgroup is its 14 rows + 5 halo rows on each side = 24 rows = three 8-row MFMA groups.  The back
 //     transform of the FDM stage produces V y on all 24 rows, and everything between two FDM stages -- post-sweeps, p = z +
 //     beta p, q = A p, r -= alpha q, pre-sweeps -- is recomputed on the halo rows, shrinking by one row per stencil
@@ -17,11 +17,12 @@
 //     its own.  What the halo rows need from their owners (r', the pre-smoothed iterate z2, the old direction p, all
 //     complex64) is published through the XCD's L2 before the FDM stage's first synchronisation and picked up behind its
 //     second;
-//   * four synchronisations per iteration among the G workgroups of the system (R1: rho, |z|, |x| -> beta and the
-//     convergence decision; R2: p'q -> alpha; T1: rows -> mode slabs of the forward transform; T2: solved slabs -> rows),
-//     each an atomic add in the L2 + a poll by one lane (agent scope), payload by plain stores (they stay in the XCD's
-//     L2) drained with s_waitcnt vmcnt(0), picked up by loads that bypass the L1 (sc1).  R1 is split: arrive behind the
-//     first post-sweep, wait in front of the p update, the second post-sweep in between.
+//   * four synchronisations per iteration among the G workgroups of the system.  T1 (rows -> mode slabs of the forward
+//     transform) and T2 (solved slabs -> rows) are counter barriers: an atomic add in the L2 + a poll by one lane (agent
+//     scope), payload by plain stores (they stay in the XCD's L2) drained with s_waitcnt vmcnt(0), picked up by loads that
+//     bypass the L1 (sc1).  R1 (rho, |z|, |x| -> beta and the convergence decision) and R2 (p'q -> alpha) have no barrier:
+//     the partial sums travel as tagged 16-byte granules and are their own flag (ps_publish / ps_collect); R1's are
+//     published behind the first post-sweep and collected in front of the p update, the second post-sweep in between.
 //   * workgroups b, b + 8, b + 16, .. share an XCD (round-robin dispatch; NOT a HIP guarantee): every group checks it at
 //     kernel start with XCC_ID and gives up -- systems untouched, the host runs the launch-per-phase loop -- if it does
 //     not hold.  All spins are bounded.
