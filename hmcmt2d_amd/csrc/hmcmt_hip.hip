@@ -25,6 +25,10 @@
 #include <string>
 #include <chrono>
 #include <vector>
+#include <mutex>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/file.h>
 #include "../../include/hmcmt.h"
 #include "hmcmt_host.h"
 #include "hmcmt_items.h"
@@ -165,7 +169,7 @@ struct hmcmt_ctx {
     unsigned long long persistTag = 0;    // ... the tag base of the next launch
     long long* d_pstamps = nullptr;       // HMCMT_STAMPS=persist
     long long persistSolves = 0, persistFallbacks = 0;
-    bool counted = false;                 // this context is in g_liveContexts
+    bool counted = false;                 // this context is in g_liveOnDev / holds a reference on the device lock
     // production guard on the error-estimate stopping rule: every guardEvery-th evaluation the TRUE residual of both
     // solves is formed (two vector passes and a read-back: ~0.1 ms once in guardEvery evaluations) -- hmcmt_guard
     int guardEvery = 100;                 // HMCMT_GUARD_EVERY (0: off)
@@ -486,12 +490,59 @@ int finish_status(hmcmt_ctx* ctx);
 
 constexpr double SPIN_LIMIT_S = 60.0;       // a convergence poll that sees no progress for this long gives up (HMCMT_EHIP)
 
-std::atomic<int> g_liveContexts{0};         // contexts alive in this process: two persistent kernels on one device could each hold CUs the other needs
+// Two persistent kernels on one device could each hold CUs the other's missing workgroups need (they spin at their barriers
+// until the bounded waits give up).  Inside a process: the contexts alive on each device are counted, and the kernel runs only
+// for a context that is alone on its device.  Across processes: an advisory lock per device -- flock on
+// $HMCMT_LOCK_DIR (/tmp) /hmcmt_persist_<PCI bus id>.lock, taken by the first context of a process on that device and held
+// while it has one there; a process that does not get it runs the launch-per-phase loop and asks again every 256 solves.
+// (Protects hmcmt processes from each other where they share the lock directory; HMCMT_PERSIST_LOCK=0 skips it.)
+constexpr int MAXDEV = 64;
+std::atomic<int> g_liveOnDev[MAXDEV];
+struct DevLock { int fd = -1; int refs = 0; bool held = false; long asked = 0; };
+std::mutex g_lockMu;
+DevLock g_devLock[MAXDEV];
+
+static bool devlock_try(DevLock& L) {
+    if (L.fd < 0) return false;
+    L.held = flock(L.fd, LOCK_EX | LOCK_NB) == 0;
+    return L.held;
+}
+static void devlock_ref(int dev) {
+    if (dev < 0 || dev >= MAXDEV) return;
+    std::lock_guard<std::mutex> g(g_lockMu);
+    DevLock& L = g_devLock[dev];
+    if (L.refs++ > 0) return;
+    const char* off = getenv("HMCMT_PERSIST_LOCK");
+    if (off && off[0] == '0') { L.held = true; return; }
+    char bus[64] = "unknown";
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, dev) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof bus, "dev%d", dev); }
+    for (char* c = bus; *c; ++c) if (*c == ':' || *c == '/') *c = '_';
+    const char* dir = getenv("HMCMT_LOCK_DIR");
+    const std::string path = std::string(dir && dir[0] ? dir : "/tmp") + "/hmcmt_persist_" + bus + ".lock";
+    L.fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    if (L.fd < 0) { L.held = true; return; }           // (no lock directory: nothing to coordinate through)
+    devlock_try(L);
+}
+static void devlock_unref(int dev) {
+    if (dev < 0 || dev >= MAXDEV) return;
+    std::lock_guard<std::mutex> g(g_lockMu);
+    DevLock& L = g_devLock[dev];
+    if (--L.refs > 0) return;
+    if (L.fd >= 0) close(L.fd);                         // (drops the lock)
+    L = DevLock{};
+}
+static bool devlock_held(int dev) {
+    if (dev < 0 || dev >= MAXDEV) return true;
+    std::lock_guard<std::mutex> g(g_lockMu);
+    DevLock& L = g_devLock[dev];
+    if (!L.held && (++L.asked & 255) == 0) devlock_try(L);
+    return L.held;
+}
 
 // the persistent solve kernel applies to the solve at hand (default path, a mesh its tiles fit, alone on the device)
 bool persist_ok(const hmcmt_ctx* ctx) {
     return ctx->persistOn && ctx->persistCW > 0 && ctx->sv.splitT && ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0 &&
-           g_liveContexts.load() == 1;
+           ctx->device >= 0 && ctx->device < MAXDEV && g_liveOnDev[ctx->device].load() == 1 && devlock_held(ctx->device);
 }
 // one launch = the whole solve (or, precondOnly, one application of the preconditioner to k.r -> zout)
 int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout) {
@@ -1110,7 +1161,7 @@ const char* hmcmt_last_error(const hmcmt_ctx* ctx) { return ctx ? ctx->err.c_str
 
 int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (!ctx) return HMCMT_EINVAL;
-    if (ctx->counted) { g_liveContexts.fetch_sub(1); ctx->counted = false; }
+    if (ctx->counted) { if (ctx->device >= 0 && ctx->device < MAXDEV) g_liveOnDev[ctx->device].fetch_sub(1); devlock_unref(ctx->device); ctx->counted = false; }
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->side) hipStreamSynchronize(ctx->side);      // (side-stream work of an evaluation nobody waited for)
@@ -1557,7 +1608,8 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
     }
     ctx->sv.twist = ctx->v.twist = ctx->sv.splitT && ctx->twistOn;     // the fused forward kernel sweeps both ways at once
     if ((rc = persist_setup(ctx))) { g_createError = ctx->err; hmcmt_destroy(ctx); return rc; }
-    g_liveContexts.fetch_add(1);
+    if (ctx->device >= 0 && ctx->device < MAXDEV) g_liveOnDev[ctx->device].fetch_add(1);
+    devlock_ref(ctx->device);
     ctx->counted = true;
     *out = ctx;
     return 0;
@@ -1890,6 +1942,7 @@ int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out) {
     if (!ctx || !out) return HMCMT_EINVAL;
     out[0] = ctx->persistCW; out[1] = ctx->persistG; out[2] = ctx->persistSlots; out[3] = ctx->persistOn ? 1 : 0;
     out[4] = ctx->persistSolves; out[5] = ctx->persistFallbacks;
+    out[6] = persist_ok(ctx) ? 1 : 0;              // would the next default-path solve use it (alone on the device, device lock held)
     return 0;
 }
 

@@ -162,3 +162,37 @@ def test_more_systems_than_slots_run_in_rounds(monkeypatch):
     assert s1["status"] == 0 and s1["true_res_max"] < 1e-9 and s1["fallback_solves"] == 0
     assert abs(s1["iters_fwd_sum"] - s0["iters_fwd_sum"]) <= 0.05 * s0["iters_fwd_sum"] + 2
     assert relmax(p1, p0) < 1e-9 and abs(f1 - f0) / abs(f0) < 1e-9 and relmax(g1, g0) < 1e-8
+
+
+def test_a_second_process_on_the_device_runs_the_launch_per_phase_loop(monkeypatch, tmp_path):
+    """Across processes the persistent kernel is guarded by an advisory lock per device (flock on
+    $HMCMT_LOCK_DIR/hmcmt_persist_<PCI bus id>.lock, held by a process while it has a context on the device): a second process
+    does not get it, runs the launch-per-phase loop -- same answers -- and this process keeps the kernel."""
+    import subprocess, sys, json, os
+    monkeypatch.setenv("HMCMT_LOCK_DIR", str(tmp_path))
+    mesh, data, inv, m = make_problem("cfg2")
+    ctx = _ctx(monkeypatch, mesh, data, inv, True)
+    p, f, g = ctx.grad(m)
+    assert ctx.persist_info()["usable_now"] == 1 and ctx.persist_info()["solves"] == 2 and len(os.listdir(tmp_path)) == 1
+    child = ("import json, numpy as np\n"
+             "from hmcmt2d_amd.lib import HipContext\n"
+             "from tests.helpers import make_problem\n"
+             "mesh, data, inv, m = make_problem('cfg2')\n"
+             "c = HipContext(mesh, data, inv)\n"
+             "p, f, g = c.grad(m)\n"
+             "print(json.dumps({'info': c.persist_info(), 'misfit': f, 'g0': float(g[0])}))\n"
+             "c.close()\n")
+    env = dict(os.environ, HMCMT_PERSIST="1", HMCMT_LOCK_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["info"]["usable_now"] == 0 and out["info"]["solves"] == 0 and out["info"]["enabled"] == 1
+    assert abs(out["misfit"] - f) / abs(f) < 1e-9 and abs(out["g0"] - g[0]) <= 1e-8 * np.abs(g).max()
+    ctx.grad(m - 1e-3)
+    assert ctx.persist_info()["solves"] == 4
+    ctx.close()
+    # ... and with this process's context gone the next process gets the lock
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["info"]["solves"] == 2
