@@ -520,6 +520,7 @@ static void devlock_ref(int dev) {
     const char* dir = getenv("HMCMT_LOCK_DIR");
     const std::string path = std::string(dir && dir[0] ? dir : "/tmp") + "/hmcmt_persist_" + bus + ".lock";
     L.fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    if (L.fd < 0) L.fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);      // (another user's file: a shared lock needs no write access)
     if (L.fd < 0) { L.held = true; return; }           // (no lock directory: nothing to coordinate through)
     devlock_try(L);
 }
