@@ -465,6 +465,7 @@ def main():
                                "registers, tiles and stencil coefficients in LDS, four per-system synchronisations per iteration)" % ctx.persist_info()["workgroups_per_system"],
                      "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(name, "persist"), "avg_launch_us": avg_us,
+                     "frac_traffic": (pmc_traffic(name, "persist") / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (n_c and pmc_traffic(name, "persist")) else None,
                      "frac_canonical_csr": can / HBM_PEAK_GBS, "evaluations_sampled": cnt["evaluations"], "sampled_every": every,
                      "event_bracket_overhead_us_subtracted": prof_overhead_us, "rocprofv3_avg_launch_us": rocprof_avg_us(name, "persist"),
                      "launches_timed": n_c, "bytes_per_launch": nbytes, "ms_timed": ms_c,
