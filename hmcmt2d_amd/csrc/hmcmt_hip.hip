@@ -558,7 +558,7 @@ int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout) {
     a.partZZ = ctx->d_partZZ;
     a.pubR = k.t2_32; a.pubZ = k.zs32; a.pubP = k.p32a;
     a.yhat = k.y32; a.ysol = k.t32; a.tbuf = k.z4_32;
-    ctx->persistTag += 1ull << 20;           // (an iteration takes two tags; a solve never has 2^19 iterations)
+    ctx->persistTag += std::max(1ull << 20, 2ull * ((unsigned long long)std::max(ctx->opt.maxit, 0) + 8));   // (an iteration takes two tags: a launch's range never reaches the next one's)
     a.rec = ctx->d_prec; a.tagBase = ctx->persistTag;
     a.ip32 = ctx->d_invp32;
     a.zout = zout;
