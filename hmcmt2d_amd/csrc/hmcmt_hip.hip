@@ -546,7 +546,7 @@ bool persist_ok(const hmcmt_ctx* ctx) {
            ctx->device >= 0 && ctx->device < MAXDEV && g_liveOnDev[ctx->device].load() == 1 && devlock_held(ctx->device);
 }
 // one launch = the whole solve (or, precondOnly, one application of the preconditioner to k.r -> zout)
-int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout) {
+int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout, int kind = 0) {
     Solver& k = ctx->sv;
     PersistArgs a{};
     const int groups = 8 * ctx->persistSlots;
@@ -563,7 +563,8 @@ int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout) {
     a.ip32 = ctx->d_invp32;
     a.zout = zout;
     a.stamps = ctx->d_pstamps;
-    HIPCHK(hipMemsetAsync(ctx->d_psync, 0, ctx->psyncBytes, ctx->stream));
+    a.tickId = kind == 1 ? TK_PERSIST_A : TK_PERSIST_F;
+    a.syncWords = (int)(ctx->psyncBytes / sizeof(unsigned));      // (zero at create; every launch's last workgroup leaves them zero)
     if (ctx->d_pstamps) HIPCHK(hipMemsetAsync(ctx->d_pstamps, 0, sizeof(long long) * 16 * 252, ctx->stream));
     const dim3 grid(groups * ctx->persistG);
     const size_t lds = ctx->persistLds;
@@ -652,7 +653,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
         *(volatile int*)ctx->h_stall = 0;
         *(volatile int*)(ctx->h_stall + 2) = 0;
         *(volatile int*)ctx->h_prog = 0;
-        { ProfScope ps(ctx, 2); int prc = launch_persist(ctx, k.sweeps, 0, nullptr); if (prc) return prc; }
+        { ProfScope ps(ctx, 2); int prc = launch_persist(ctx, k.sweeps, 0, nullptr, kind); if (prc) return prc; }
         ++ctx->persistSolves;
         if (k.cntActive) ++ctx->profPersistSolves;
         if (kind == 0) launch_adjoint_side(ctx);        // (the host is free while the device solves)
@@ -1170,7 +1171,7 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
         static const char* names[TK_N] = {"k_sigma_rows", "k_bc_fused", "k_extrap_prepare (fwd)", "k_extrap (fwd)", "k_coef_all", "k_pivot",
             "k_resid_pre (fwd)", "k_spmv_fused (first .. last)", "k_update_fused (first .. last)", "k_fdm_fwd (first .. last)",
             "k_back_post (first .. last)", "k_solve_end (first .. last)", "k_rxall", "k_src", "k_resid_pre (adj)", "k_wb", "k_bcsens_contract",
-            "k_gradcell", "k_gradfinal", "k_lf_momentum", "k_lf_dmmax", "k_lf_step", "k_sens_profile (side)"};
+            "k_gradcell", "k_gradfinal", "k_lf_momentum", "k_lf_dmmax", "k_lf_step", "k_sens_profile (side)", "k_cocg_persist (forward)", "k_cocg_persist (adjoint)"};
         std::vector<long long> traw(32 + 64 * TK_N);
         long long t[64] = {0};
         int rate = 100000;                                // kHz
@@ -1289,6 +1290,7 @@ static int persist_setup(hmcmt_ctx* ctx) {
     ctx->psyncBytes = ((size_t)(32 * 8 * ctx->persistSlots + 16) * sizeof(unsigned) + 15) & ~(size_t)15;
     void* q = nullptr;
     HIPCHK(hipMalloc(&q, ctx->psyncBytes));
+    HIPCHK(hipMemset(q, 0, ctx->psyncBytes));
     ctx->allocs.push_back(q);
     ctx->d_psync = reinterpret_cast<unsigned*>(q);
     {

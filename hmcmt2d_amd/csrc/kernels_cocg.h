@@ -82,7 +82,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // (a store per workgroup when enabled, a null test otherwise); printed at hmcmt_destroy as the untraced timeline of the
 // last evaluation -- rocprofv3's kernel trace makes the host's launches the bottleneck around the solves
 enum { TK_SIGMA = 0, TK_BC, TK_EXTW, TK_EXT, TK_COEF, TK_PIVOT, TK_RESID_F, TK_SPMV, TK_UPDATE, TK_FWD, TK_BACK, TK_SOLVE_END, TK_RXALL,
-       TK_SRC, TK_RESID_A, TK_WB, TK_BCSENS, TK_GRADCELL, TK_GRADFINAL, TK_LF_MOM, TK_LF_MAX, TK_LF_STEP, TK_SENS, TK_N };
+       TK_SRC, TK_RESID_A, TK_WB, TK_BCSENS, TK_GRADCELL, TK_GRADFINAL, TK_LF_MOM, TK_LF_MAX, TK_LF_STEP, TK_SENS, TK_PERSIST_F, TK_PERSIST_A, TK_N };
 __device__ __forceinline__ void tick_begin(long long* t, int id) {          // first workgroup of the first launch since the reset
     if (t && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && t[id] == -1) t[id] = wall_clock64();
 }

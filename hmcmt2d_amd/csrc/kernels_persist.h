@@ -59,6 +59,8 @@ struct PersistArgs {
     float2* tbuf;              // [S][vstride] complex64: t of the own rows across the FDM stage (two sweeps: the rho identity)
     float2* zout;              // precondOnly: z = P^-1 r
     long long* stamps;         // [workgroup][16] s_memtime stamps of one iteration's phases (HMCMT_STAMPS=persist)
+    int tickId;                // HMCMT_TICKS: TK_PERSIST_F / TK_PERSIST_A
+    int syncWords;             // words of `sync` (+ exitCnt, fail behind it): zeroed by the last workgroup to leave
 };
 
 __device__ __forceinline__ unsigned ps_xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 0xf; }
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
     constexpr int NT = 2 * CW, NWV = NT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sh = reinterpret_cast<double*>(smem);                           // [2][32] block reductions (ps_block_sum4), [64..70) the reductions' totals
-    volatile int* sflag = reinterpret_cast<volatile int*>(smem + 640);      // [0] give up
+    volatile int* sflag = reinterpret_cast<volatile int*>(smem + 640);      // [0] give up, [1] this is the last workgroup to leave
     int shFlip = 0;
     char* arena = smem + 1024;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -446,6 +448,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
     unsigned epoch = 0;                 // synchronisations of this group so far (the same in all its threads)
     int it = 0;
     if (tid == 0) sflag[0] = 0;
+    tick_begin(k.ticks, a.tickId);
     __syncthreads();
     // ---- placement check: the G workgroups of the group must share an XCD (their hand-offs go through ITS L2)
     if (tid == 0) {
@@ -1084,11 +1087,22 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
     }
     // ---- exit: the last workgroup to leave tells the host
     __syncthreads();
+    tick_end(k.ticks, a.tickId);
     if (tid == 0) {
         if (sflag[0] == 2) *k.failHost = HMCMT_EHIP;       // a wait timed out: the solve is void
         __threadfence_system();
         const unsigned nLeft = __hip_atomic_fetch_add(a.exitCnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (nLeft == gridDim.x - 1) {
+        sflag[1] = nLeft == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (sflag[1]) {
+        // every other workgroup has left: the barrier counters, the exit counter and the failure word go back to zero for the
+        // next launch (a memset in front of every launch was a 5 us fill kernel on the stream: 12 us between the residual kernel
+        // and this one, now 6)
+        for (int i = tid; i < a.syncWords; i += NT) a.sync[i] = 0u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
             __threadfence_system();
             *(volatile int*)k.progHost = PS_DONE;
         }
