@@ -26,6 +26,7 @@
 #include <chrono>
 #include <vector>
 #include <mutex>
+#include <functional>
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/file.h>
@@ -177,6 +178,11 @@ struct hmcmt_ctx {
     double guardWorst = 0.0, guardLast = 0.0;
     double guardLimit = 1e-6;             // HMCMT_GUARD_LIMIT: a checked residual above it is a "trip" (warning, next evaluation starts cold)
     long long guardTrips = 0;
+    // kernels queued behind a persistent solve before the host knows its outcome (View::gate; evaluate(), solve())
+    int* d_gate = nullptr;                // [2] device words written by the persistent kernel's last workgroup, per solve kind
+    int gateGen = 0;                      // serial number of the persistent launches
+    bool specValid = false;               // the last solve's speculative followers ran (the solve ended clean)
+    bool specOn = true;                   // HMCMT_SPEC=0: followers are queued after the host has seen the solve's outcome
     bool guardNow = false;                // the evaluation at hand is a guarded one
     bool guardDropWarm = false;           // a trip: the next evaluation starts both solves cold
     // results of the last two host-API evaluations, keyed by the model: a sampler re-evaluates the model it has
@@ -564,6 +570,9 @@ int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout, in
     a.zout = zout;
     a.stamps = ctx->d_pstamps;
     a.tickId = kind == 1 ? TK_PERSIST_A : TK_PERSIST_F;
+    a.gateOut = precondOnly ? nullptr : ctx->d_gate + (kind == 1 ? 1 : 0);
+    a.gateGen = ++ctx->gateGen;
+    if (ctx->gateGen > 0x3fffffff) ctx->gateGen = 0;
     a.syncWords = (int)(ctx->psyncBytes / sizeof(unsigned));      // (zero at create; every launch's last workgroup leaves them zero)
     if (ctx->d_pstamps) HIPCHK(hipMemsetAsync(ctx->d_pstamps, 0, sizeof(long long) * 16 * 252, ctx->stream));
     const dim3 grid(groups * ctx->persistG);
@@ -616,7 +625,12 @@ SolveRec solve_rec(hmcmt_ctx* ctx, int kind) {
 }
 
 // deferEnd: the caller's next kernel writes the per-solve records (k_rxall / k_wb with solve_rec) instead of k_solve_end
-int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
+// spec: launches the caller wants queued right behind the solve -- with the persistent kernel they go out BEFORE the host has seen
+// the solve end, gated on the device word the kernel's last workgroup writes (View::gate): the host's wake-up and launch latency
+// (18 us behind the forward solve, 11 behind the adjoint one) run under kernels that are already in the queue.  ctx->specValid
+// says whether they ran; if not (a stalled, failed or displaced solve: they returned at once) the caller queues them again.
+using SpecFn = std::function<void(const int* gate, int gen)>;
+int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn* spec = nullptr) {
     Solver& k = ctx->sv;
     const View& v = ctx->v;
     k.x = x;
@@ -645,7 +659,8 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
     const dim3 tg((k.ny - 1 + 63) / 64, S);
     const bool fused = ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0;
     cplx* const r_entry = k.r;
-    bool viaPersist = false, stalledP = false;
+    bool viaPersist = false, stalledP = false, specIssued = false;
+    ctx->specValid = false;
     if (fused && persist_ok(ctx)) {
         // ONE launch solves every system (kernels_persist.h).  The kernel tells the host through mapped words: the progress
         // word when its last workgroup leaves, the active-system counter, the stagnation / failure / placement flags.
@@ -657,6 +672,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
         ++ctx->persistSolves;
         if (k.cntActive) ++ctx->profPersistSolves;
         if (kind == 0) launch_adjoint_side(ctx);        // (the host is free while the device solves)
+        if (spec && ctx->specOn) { (*spec)(ctx->d_gate + kind, ctx->gateGen); specIssued = true; }
         { int prc = spin_progress(ctx, PS_DONE); if (prc) return prc; }
         if (*(volatile int*)(ctx->h_stall + 2)) {
             // the group's workgroups were not on one XCD (or the kernel could not be placed): nothing was touched by those
@@ -786,6 +802,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false) {
     guess = it;        // (launched iterations; collect_stats replaces it with the iterations actually needed)
 
     ctx->solveDone[kind] = done;
+    ctx->specValid = specIssued && viaPersist && done && !stalledP;       // (the device decided the same from the same words: k_cocg_persist's exit)
     // iteration counts / status / error estimates stay on the device; evaluate() reads both solves back at once
     if (!deferEnd) launch_solve_end(ctx, kind);
     if (ctx->opt.verify || (guard && done)) {
@@ -985,7 +1002,21 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         ctx->sideView = v; ctx->sideM = d_m; ctx->sideExtrap = extrap && wantGrad; ctx->sideSens = wantGrad;
         ctx->sidePending = wantGrad;
     }
-    int rc = solve(ctx, v.X, 0, true);
+    // Followers of the two solves that need nothing but the View (receiver functionals and adjoint sources behind the forward solve;
+    // the gradient's tail behind the adjoint one) are handed to solve() to be queued behind the persistent launch at once (SpecFn).
+    // Only where that is the plain case: a gradient evaluation with a warm adjoint start (no clearing of the right-hand side), no
+    // true-residual check, no guard copy, no HIP-event sampling.
+    const bool sparseSrcPlan = warmA && !ctx->opt.verify && !ctx->guardNow;
+    const bool specPlain = wantGrad && sparseSrcPlan && !ctx->evalSampled;
+    const int nsrcBlocks = (2 * (v.ny + 1) + 127) / 128;
+    double* const misfitPtr = d_misfit ? d_misfit : ctx->d_misfit;
+    const SpecFn specF = [&](const int* gate, int gen) {
+        View vg = v; vg.gate = gate; vg.gateGen = gen;
+        hipLaunchKernelGGL(k_rxall, grid1(S * v.nRx, 64), dim3(64), 0, st, vg, 1, solve_rec(ctx, 0));
+        hipLaunchKernelGGL(k_src, dim3(nsrcBlocks + (v.ny + 127) / 128, S), dim3(128), 0, st, vg, misfitPtr, nsrcBlocks);
+    };
+    int rc = solve(ctx, v.X, 0, true, specPlain ? &specF : nullptr);
+    const bool specFwd = ctx->specValid;
     if (fusedStart) std::swap(ctx->sv.r, ctx->sv.r2);
     fusedStart = fusedStartOk && sweepsA == 1;
     ctx->sv.sweeps = sweepsA;
@@ -1008,7 +1039,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
     launch_adjoint_side(ctx);            // (no-op when the solve has already done it)
     ctx->haveFwd = (rc == 0 && ctx->solveDone[0]);
     if (rc) return rc;
-    {
+    if (!specFwd) {
         ProfScope ps(ctx, 5);
         hipLaunchKernelGGL(k_rxall, grid1(S * v.nRx, 64), dim3(64), 0, st, v, wantGrad ? 1 : 0, solve_rec(ctx, 0));     // (+ the forward solve's records)
         if (!wantGrad) {
@@ -1021,10 +1052,11 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             ProfScope ps(ctx, 5);
             // k_src assigns the two node rows of the receiver layer and all of srcB.  A warm adjoint start reads the right-hand
             // side on those rows only (k_resid0 / k_resid_pre, zero_r = 2 + row); a cold one takes the buffer as its residual
-            const bool sparseSrc = warmA && !ctx->opt.verify && !ctx->guardNow;       // (a guarded evaluation keeps a copy of the whole right-hand side)
-            if (!sparseSrc) HIPCHK(hipMemsetAsync(v.R, 0, vecBytes, st));
-            const int nsrc = (2 * (v.ny + 1) + 127) / 128;
-            hipLaunchKernelGGL(k_src, dim3(nsrc + (v.ny + 127) / 128, S), dim3(128), 0, st, v, d_misfit ? d_misfit : ctx->d_misfit, nsrc);
+            const bool sparseSrc = sparseSrcPlan;                                     // (a guarded evaluation keeps a copy of the whole right-hand side)
+            if (!specFwd) {
+                if (!sparseSrc) HIPCHK(hipMemsetAsync(v.R, 0, vecBytes, st));
+                hipLaunchKernelGGL(k_src, dim3(nsrcBlocks + (v.ny + 127) / 128, S), dim3(128), 0, st, v, misfitPtr, nsrcBlocks);
+            }
             if (ctx->guardNow) HIPCHK(hipMemcpyAsync(ctx->d_b, v.R, vecBytes, hipMemcpyDeviceToDevice, st));
             if (ctx->extAWaitPending) { ctx->extAWaitPending = false; HIPCHK(hipStreamWaitEvent(st, ctx->evExtA, 0)); }   // (a forward solve too short to have issued it)
             if (warmA && fusedStart) {
@@ -1038,7 +1070,17 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         }
         ctx->sensWaitPending = true;     // (the wait for the side stream's sensitivity tables is issued from inside the adjoint solve)
         if (ctx->wantTicks) ctx->hostUs[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hostT1).count();
-        rc = solve(ctx, v.Lam, 1, true);
+        const SpecFn specA = [&](const int* gate, int gen) {
+            View vg = v; vg.gate = gate; vg.gateGen = gen;
+            if (ctx->sensWaitPending) { ctx->sensWaitPending = false; hipStreamWaitEvent(st, ctx->evSens, 0); }
+            hipLaunchKernelGGL(k_wb, dim3((v.nz + v.ny + 127) / 128, S), dim3(128), 0, st, vg, solve_rec(ctx, 1));
+            hipEventRecord(ctx->evRec, st);
+            hipLaunchKernelGGL(k_bcsens_contract, dim3((v.nz + 127) / 128, 2, S), dim3(128), 0, st, vg);
+            hipLaunchKernelGGL(k_gradcell, dim3((v.nCell + 127) / 128, 2, GRAD_NG), dim3(128), 0, st, vg);
+            hipLaunchKernelGGL(k_gradfinal, grid1(4 * v.nAC, 128), dim3(128), 0, st, vg);
+        };
+        rc = solve(ctx, v.Lam, 1, true, specPlain ? &specA : nullptr);
+        const bool specAdj = ctx->specValid;
         const auto hostT2 = std::chrono::steady_clock::now();
         if (warmA && fusedStart) std::swap(ctx->sv.r, ctx->sv.r2);
         ctx->haveAdj = (rc == 0 && ctx->solveDone[1]);
@@ -1050,13 +1092,15 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
             rc = collect_stats(ctx, true);
             return rc ? rc : finish_status(ctx);
         }
-        ProfScope ps(ctx, 6);
-        if (ctx->sensWaitPending) { ctx->sensWaitPending = false; HIPCHK(hipStreamWaitEvent(st, ctx->evSens, 0)); }     // (a solve of fewer than 8 iterations)
-        hipLaunchKernelGGL(k_wb, dim3((v.nz + v.ny + 127) / 128, S), dim3(128), 0, st, v, solve_rec(ctx, 1));      // (+ the adjoint solve's records)
-        HIPCHK(hipEventRecord(ctx->evRec, st));                        // behind the records of the last solve
-        hipLaunchKernelGGL(k_bcsens_contract, dim3((v.nz + 127) / 128, 2, S), dim3(128), 0, st, v);
-        hipLaunchKernelGGL(k_gradcell, dim3((v.nCell + 127) / 128, 2, GRAD_NG), dim3(128), 0, st, v);
-        hipLaunchKernelGGL(k_gradfinal, grid1(4 * v.nAC, 128), dim3(128), 0, st, v);
+        if (!specAdj) {
+            ProfScope ps(ctx, 6);
+            if (ctx->sensWaitPending) { ctx->sensWaitPending = false; HIPCHK(hipStreamWaitEvent(st, ctx->evSens, 0)); }     // (a solve of fewer than 8 iterations)
+            hipLaunchKernelGGL(k_wb, dim3((v.nz + v.ny + 127) / 128, S), dim3(128), 0, st, v, solve_rec(ctx, 1));      // (+ the adjoint solve's records)
+            HIPCHK(hipEventRecord(ctx->evRec, st));                        // behind the records of the last solve
+            hipLaunchKernelGGL(k_bcsens_contract, dim3((v.nz + 127) / 128, 2, S), dim3(128), 0, st, v);
+            hipLaunchKernelGGL(k_gradcell, dim3((v.nCell + 127) / 128, 2, GRAD_NG), dim3(128), 0, st, v);
+            hipLaunchKernelGGL(k_gradfinal, grid1(4 * v.nAC, 128), dim3(128), 0, st, v);
+        }
         if (ctx->wantTicks) ctx->hostUs[2] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hostT2).count();
     }
     HIPCHK(hipGetLastError());
@@ -1291,6 +1335,13 @@ static int persist_setup(hmcmt_ctx* ctx) {
     void* q = nullptr;
     HIPCHK(hipMalloc(&q, ctx->psyncBytes));
     HIPCHK(hipMemset(q, 0, ctx->psyncBytes));
+    {
+        void* gq = nullptr;
+        HIPCHK(hipMalloc(&gq, 2 * sizeof(int)));
+        HIPCHK(hipMemset(gq, 0, 2 * sizeof(int)));
+        ctx->allocs.push_back(gq);
+        ctx->d_gate = reinterpret_cast<int*>(gq);
+    }
     ctx->allocs.push_back(q);
     ctx->d_psync = reinterpret_cast<unsigned*>(q);
     {
@@ -1345,6 +1396,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         if (const char* ew = getenv("HMCMT_JACOBI_W")) ctx->jacobiW = std::min(1.2, std::max(0.1, atof(ew)));
         if (const char* es = getenv("HMCMT_SWEEPS")) ctx->sweepsMode = std::max(0, std::min(2, atoi(es)));     // 0 / "auto": per solve
         if (const char* eg = getenv("HMCMT_GUARD_EVERY")) ctx->guardEvery = std::max(0, atoi(eg));
+        if (const char* eg = getenv("HMCMT_SPEC")) ctx->specOn = eg[0] != '0';
         if (const char* eg = getenv("HMCMT_GUARD_LIMIT")) ctx->guardLimit = atof(eg);
         if (const char* es = getenv("HMCMT_SWEEPS_UP")) ctx->sweepsUp = std::max(1, atoi(es));
         if (const char* es = getenv("HMCMT_SWEEPS_DOWN")) ctx->sweepsDown = std::max(0, atoi(es));

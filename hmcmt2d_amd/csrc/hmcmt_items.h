@@ -21,6 +21,8 @@ struct View {
     int zid;                       // node row of the receivers (mt2DTE.jl:66-67), 0-based
     long long* ticks;              // HMCMT_TICKS (measurement only): [2][32] earliest start / latest end of the kernels around the solves
     int dbg;                       // test hooks (hmcmt_debug_flags): bit 1 = leave the boundary-derivative terms B^T v out of the gradient
+    const int* gate;               // non-null: the kernel was queued BEHIND a persistent solve before the host knew its outcome and runs only if
+    int gateGen;                   //   the solve left *gate == gateGen (every system converged); else it returns at once and the host queues it again
     long vstride;                  // NZP*NYP elements per system
     // mesh (constant)
     const double* yLen;            // [ny]

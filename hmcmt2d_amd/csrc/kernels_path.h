@@ -297,7 +297,10 @@ __device__ __forceinline__ void write_solve_rec(const SolveRec& r, int s) {
     r.recI[(2 + r.kind) * r.S + s] = r.status[s];
     r.recE[r.kind * r.S + s] = r.errEst[s];
 }
-__global__ __launch_bounds__(64) void k_rxall(View v, int wantGrad, SolveRec rec) {        // (64: registers instead of 200 B of spills)
+// kernels queued speculatively behind a persistent solve (View::gate): true = the solve did not end clean, do nothing
+__device__ __forceinline__ bool gate_closed(const View& v) { return v.gate && *(volatile const int*)v.gate != v.gateGen; }
+__global__ __launch_bounds__(64) void k_rxall(View v, int wantGrad, SolveRec rec) {
+    if (gate_closed(v)) return;        // (64: registers instead of 200 B of spills)
     const int e = TID1;
     tick_begin(v.ticks, TK_RXALL);
     if (rec.recI && e < rec.S) write_solve_rec(rec, e);
@@ -317,6 +320,7 @@ __global__ void k_rxcoef(View v) { int e = TID1; if (e < v.S * v.nRx) item_rxcoe
 // adjoint sources; workgroup (0,0) also adds up the misfit terms (a reduction nothing on the device waits for: no
 // launch of its own on the critical path between the solves)
 __global__ __launch_bounds__(128) void k_src(View v, double* misfitOut, int nsrc) {
+    if (gate_closed(v)) return;
     // blocks x < nsrc: the sources; the blocks behind them: the receiver-layer Q-terms of the gradient (item_qterm
     // needs nothing from the adjoint solve: here they cost no launch in the gradient tail)
     const int s = blockIdx.y;
@@ -383,6 +387,7 @@ __global__ __launch_bounds__(128) void k_src(View v, double* misfitOut, int nsrc
     tick_end(v.ticks, TK_SRC);
 }
 __global__ void k_wb(View v, SolveRec rec) {
+    if (gate_closed(v)) return;
     int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
     tick_begin(v.ticks, TK_WB);
     if (rec.recI && e == 0) write_solve_rec(rec, s);
@@ -395,12 +400,14 @@ __global__ __launch_bounds__(64) void k_bcsens_pre(View v) {
     if (c < v.nz) item_bcsens_pre(v, s, prof, c);
 }
 __global__ void k_bcsens_contract(View v) {
+    if (gate_closed(v)) return;
     int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
     tick_begin(v.ticks, TK_BCSENS);
     if (c < v.nz) item_bcsens_contract(v, s, prof, c);
     tick_end(v.ticks, TK_BCSENS);
 }
 __global__ void k_gradcell(View v) {
+    if (gate_closed(v)) return;
     int c = blockIdx.x * blockDim.x + threadIdx.x, mode = blockIdx.y, grp = blockIdx.z;
     tick_begin(v.ticks, TK_GRADCELL);
     if (c < v.nCell) item_gradcell_group(v, mode, grp, c);
@@ -413,6 +420,7 @@ __global__ __launch_bounds__(64) void k_qterm(View v) {
 // final assembly with four lanes per active cell (a latency-bound loop over the systems: 4x the threads), each
 // taking every fourth system / partial sum; the four partial sums are added in lane order
 __global__ void k_gradfinal(View v) {
+    if (gate_closed(v)) return;
     const int t = TID1, a = t >> 2, l = t & 3;
     tick_begin(v.ticks, TK_GRADFINAL);
     double g = 0.0;

@@ -61,6 +61,8 @@ struct PersistArgs {
     long long* stamps;         // [workgroup][16] s_memtime stamps of one iteration's phases (HMCMT_STAMPS=persist)
     int tickId;                // HMCMT_TICKS: TK_PERSIST_F / TK_PERSIST_A
     int syncWords;             // words of `sync` (+ exitCnt, fail behind it): zeroed by the last workgroup to leave
+    int* gateOut;              // device word for the kernels queued behind this launch (View::gate): gateGen if every system ended
+    int gateGen;               //   converged and without a failure, -gateGen otherwise -- written by the last workgroup to leave
 };
 
 __device__ __forceinline__ unsigned ps_xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 0xf; }
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
     constexpr int NT = 2 * CW, NWV = NT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sh = reinterpret_cast<double*>(smem);                           // [2][32] block reductions (ps_block_sum4), [64..70) the reductions' totals
-    volatile int* sflag = reinterpret_cast<volatile int*>(smem + 640);      // [0] give up, [1] this is the last workgroup to leave
+    volatile int* sflag = reinterpret_cast<volatile int*>(smem + 640);      // [0] give up, [1] this is the last workgroup to leave, [2] its OR of the systems' states
     int shFlip = 0;
     char* arena = smem + 1024;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1096,7 +1098,22 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
     }
     __syncthreads();
     if (sflag[1]) {
-        // every other workgroup has left: the barrier counters, the exit counter and the failure word go back to zero for the
+        // every other workgroup has left.  The word the speculatively queued followers look at (View::gate): clean = no system
+        // still active (stalled, cut off, never started: placement) and none with a status
+        {
+            int bad = __hip_atomic_load(a.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1 : 0;
+            for (int s = tid; s < k.S; s += NT)
+                bad |= (__hip_atomic_load(k.status + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                        __hip_atomic_load(k.active + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
+            // (an OR over the workgroup through the scratch kilobyte: __syncthreads_or brings a static __shared__ word of its own,
+            //  and static + dynamic LDS beyond 160 KB makes hipFuncSetAttribute refuse the kernel)
+            if (tid == 0) sflag[2] = 0;
+            __syncthreads();
+            if (bad) sflag[2] = 1;
+            __syncthreads();
+            if (tid == 0 && a.gateOut) *a.gateOut = sflag[2] ? -a.gateGen : a.gateGen;
+        }
+        // The barrier counters, the exit counter and the failure word go back to zero for the
         // next launch (a memset in front of every launch was a 5 us fill kernel on the stream: 12 us between the residual kernel
         // and this one, now 6)
         for (int i = tid; i < a.syncWords; i += NT) a.sync[i] = 0u;

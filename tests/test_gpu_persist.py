@@ -196,3 +196,30 @@ def test_a_second_process_on_the_device_runs_the_launch_per_phase_loop(monkeypat
     r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=300, env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["info"]["solves"] == 2
+
+
+def test_followers_queued_behind_the_solve_change_nothing(monkeypatch):
+    """The receiver functionals / adjoint sources and the gradient's tail are queued behind a persistent solve before the host
+    knows its outcome, gated on a device word (HMCMT_SPEC): warm-started evaluations with and without give the same
+    bits; and when the solve does NOT end clean -- HMCMT_STALL_IT = 1 makes every solve hand over to the fp64 restart -- the
+    gated kernels do nothing and the host queues them again: results to the oracle's."""
+    mesh, data, inv, m = make_problem("cfg2")
+    outs = {}
+    for spec in ("0", "1"):
+        monkeypatch.setenv("HMCMT_SPEC", spec)
+        ctx = _ctx(monkeypatch, mesh, data, inv, True)
+        outs[spec] = [ctx.grad(m + 0.01 * i) for i in range(5)]
+        assert ctx.persist_info()["solves"] == 10
+        ctx.close()
+    for a, b in zip(outs["0"], outs["1"]):
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
+    monkeypatch.setenv("HMCMT_SPEC", "1")
+    monkeypatch.setenv("HMCMT_STALL_IT", "1")
+    ctx = _ctx(monkeypatch, mesh, data, inv, True)
+    ctx.grad(m)                                            # (cold: no followers queued early)
+    p, f, g = ctx.grad(m + 0.02)                           # warm: queued early, gate closed by the stalled solves
+    st = ctx.stats()
+    ctx.close()
+    assert st["fallback_solves"] >= 1 and st["status"] == 0
+    po, mo, go = oracle_eval(mesh, data, inv, m + 0.02)
+    assert relmax(p, po) < 1e-9 and abs(f - mo) / mo < 1e-9 and relmax(g, go) < 1e-7
