@@ -179,6 +179,7 @@ struct hmcmt_ctx {
     double guardLimit = 1e-6;             // HMCMT_GUARD_LIMIT: a checked residual above it is a "trip" (warning, next evaluation starts cold)
     long long guardTrips = 0;
     // kernels queued behind a persistent solve before the host knows its outcome (View::gate; evaluate(), solve())
+    int persistMW = 32;                   // modes per slab of the persistent kernel's tridiagonal solves (32; 16 on tall meshes)
     int* d_gate = nullptr;                // [2] device words written by the persistent kernel's last workgroup, per solve kind
     int gateGen = 0;                      // serial number of the persistent launches
     bool specValid = false;               // the last solve's speculative followers ran (the solve ended clean)
@@ -548,7 +549,7 @@ static bool devlock_held(int dev) {
 
 // the persistent solve kernel applies to the solve at hand (default path, a mesh its tiles fit, alone on the device)
 bool persist_ok(const hmcmt_ctx* ctx) {
-    return ctx->persistOn && ctx->persistCW > 0 && ctx->sv.splitT && ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0 &&
+    return ctx->persistOn && ctx->persistCW > 0 && ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0 &&
            ctx->device >= 0 && ctx->device < MAXDEV && g_liveOnDev[ctx->device].load() == 1 && devlock_held(ctx->device);
 }
 // one launch = the whole solve (or, precondOnly, one application of the preconditioner to k.r -> zout)
@@ -577,7 +578,8 @@ int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout, in
     if (ctx->d_pstamps) HIPCHK(hipMemsetAsync(ctx->d_pstamps, 0, sizeof(long long) * 16 * 252, ctx->stream));
     const dim3 grid(groups * ctx->persistG);
     const size_t lds = ctx->persistLds;
-#define PSL(CW, SWP) hipLaunchKernelGGL((k_cocg_persist<CW, SWP>), grid, dim3(2 * CW), lds, ctx->stream, k, a)
+#define PSL(CW, SWP) do { if (ctx->persistMW == 16) hipLaunchKernelGGL((k_cocg_persist<CW, SWP, 16>), grid, dim3(2 * CW), lds, ctx->stream, k, a); \
+                         else hipLaunchKernelGGL((k_cocg_persist<CW, SWP, 32>), grid, dim3(2 * CW), lds, ctx->stream, k, a); } while (0)
     if (ctx->persistCW == 256) { if (sweeps == 2) PSL(256, 2); else PSL(256, 1); }
     else if (ctx->persistCW == 128) { if (sweeps == 2) PSL(128, 2); else PSL(128, 1); }
     else { if (sweeps == 2) PSL(64, 2); else PSL(64, 1); }
@@ -1311,21 +1313,35 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
 
 // Shape of the persistent solve kernel for this problem (kernels_persist.h): G workgroups of 14 rows per system, all of a
 // system's workgroups on one XCD (32 CUs), one workgroup per CU; 2 * CW threads for meshes up to CW nodes wide.
+// does the mesh fit the kernel (its LDS, a system's workgroups on one XCD)?  twist: the factorisation the solves will use
+static bool persist_shape(const hmcmt_ctx* ctx, int twist, int& cuPerXcd, int& G, int& cw, int& mw, size_t& lds) {
+    const Solver& k = ctx->sv;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    cuPerXcd = prop.multiProcessorCount / 8;
+    G = (k.nz - 1 + PS_OWN - 1) / PS_OWN;
+    if (k.NYP > 256 || cuPerXcd < 1 || G > cuPerXcd || G > MAXNB || !ctx->d_Vb || !ctx->d_Vtb) return false;
+    cw = k.NYP <= 64 ? 64 : (k.NYP <= 128 ? 128 : 256);
+    // modes per slab of the tridiagonal solves: 32, or 16 where the 32-mode slab of a tall mesh does not fit the LDS beside the planes
+    mw = 32;
+    lds = ps_lds_bytes(k.NYP, k.NZP, k.nz, twist, 32);
+    if (lds > (size_t)160 * 1024) { mw = 16; lds = ps_lds_bytes(k.NYP, k.NZP, k.nz, twist, 16); }
+    return lds <= (size_t)160 * 1024;
+}
 static int persist_setup(hmcmt_ctx* ctx) {
     const Solver& k = ctx->sv;
     if (const char* e = getenv("HMCMT_PERSIST")) ctx->persistOn = e[0] != '0';
     ctx->persistCW = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    const int cuPerXcd = prop.multiProcessorCount / 8;
-    const int G = (k.nz - 1 + PS_OWN - 1) / PS_OWN;
-    if (!k.splitT || k.NYP > 256 || cuPerXcd < 1 || G > cuPerXcd || G > MAXNB) return 0;
-    const int cw = k.NYP <= 64 ? 64 : (k.NYP <= 128 ? 128 : 256);
-    const size_t lds = ps_lds_bytes(k.NYP, k.NZP, k.nz, k.twist);
-    if (lds > (size_t)160 * 1024) return 0;
-    const void* fns[6] = {reinterpret_cast<const void*>(k_cocg_persist<256, 1>), reinterpret_cast<const void*>(k_cocg_persist<256, 2>),
-                          reinterpret_cast<const void*>(k_cocg_persist<128, 1>), reinterpret_cast<const void*>(k_cocg_persist<128, 2>),
-                          reinterpret_cast<const void*>(k_cocg_persist<64, 1>), reinterpret_cast<const void*>(k_cocg_persist<64, 2>)};
+    int cuPerXcd = 0, G = 0, cw = 0, mw = 32;
+    size_t lds = 0;
+    if (!persist_shape(ctx, k.twist, cuPerXcd, G, cw, mw, lds)) return 0;
+    ctx->persistMW = mw;
+    const void* fns[12] = {reinterpret_cast<const void*>(k_cocg_persist<256, 1, 32>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 32>),
+                           reinterpret_cast<const void*>(k_cocg_persist<128, 1, 32>), reinterpret_cast<const void*>(k_cocg_persist<128, 2, 32>),
+                           reinterpret_cast<const void*>(k_cocg_persist<64, 1, 32>), reinterpret_cast<const void*>(k_cocg_persist<64, 2, 32>),
+                           reinterpret_cast<const void*>(k_cocg_persist<256, 1, 16>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 16>),
+                           reinterpret_cast<const void*>(k_cocg_persist<128, 1, 16>), reinterpret_cast<const void*>(k_cocg_persist<128, 2, 16>),
+                           reinterpret_cast<const void*>(k_cocg_persist<64, 1, 16>), reinterpret_cast<const void*>(k_cocg_persist<64, 2, 16>)};
     for (const void* f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return 0; }
     ctx->persistG = G;
@@ -1661,7 +1677,12 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
         const int Gq = (kk.NZP + 7) / 8, per = (Gq + 7) / 8, nw = (Gq + per - 1) / per, nslab = ((kk.NYP >> 4) + FW_NTW - 1) / FW_NTW;
         if (nw < 2 || nslab > MAXNB) ctx->sv.xInFwd = 0;
     }
-    ctx->sv.twist = ctx->v.twist = ctx->sv.splitT && ctx->twistOn;     // the fused forward kernel sweeps both ways at once
+    {   // the twisted factorisation goes with the kernels that sweep both ways at once: the fused forward kernel of the launch-per-phase
+        // path, and the persistent kernel (which does not need the fused one to fit: tall meshes)
+        int a1, a2, a3, a4; size_t a5;
+        const bool pshape = persist_shape(ctx, ctx->twistOn ? 1 : 0, a1, a2, a3, a4, a5);
+        ctx->sv.twist = ctx->v.twist = (ctx->sv.splitT || pshape) && ctx->twistOn;
+    }
     if ((rc = persist_setup(ctx))) { g_createError = ctx->err; hmcmt_destroy(ctx); return rc; }
     if (ctx->device >= 0 && ctx->device < MAXDEV) g_liveOnDev[ctx->device].fetch_add(1);
     devlock_ref(ctx->device);
@@ -1998,6 +2019,7 @@ int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out) {
     out[0] = ctx->persistCW; out[1] = ctx->persistG; out[2] = ctx->persistSlots; out[3] = ctx->persistOn ? 1 : 0;
     out[4] = ctx->persistSolves; out[5] = ctx->persistFallbacks;
     out[6] = persist_ok(ctx) ? 1 : 0;              // would the next default-path solve use it (alone on the device, device lock held)
+    out[7] = ctx->persistCW ? ctx->persistMW : 0;  // modes per slab
     return 0;
 }
 

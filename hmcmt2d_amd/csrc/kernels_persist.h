@@ -227,10 +227,11 @@ __device__ __forceinline__ void ps_block_sum4(double& a, double& b, double& c, d
 // off-diagonal of the row, a per-row scalar), are formed from the prefetched ip in front of their use, off the serial chain.
 // 78 KB instead of 141 KB at the headline size: the stencil coefficients of the tile stay in LDS behind it (k_cocg_persist).
 constexpr int PSL_PAD = 2 * FW_TB;           // rows between the regions of a slab: FW_TB identity rows behind one, FW_TB zero rows in front of the next
-__host__ __device__ inline size_t ps_slab_bytes(int NZP, int nz, int twist) {
+// (mw: modes per slab -- 32, or 16 where the 32-mode slab of a tall mesh does not fit beside the coefficient planes)
+__host__ __device__ inline size_t ps_slab_bytes(int NZP, int nz, int twist, int mw = 32) {
     const int n = nz - 1, mid = twist ? (n + 1) / 2 : n;
-    const size_t rl = (size_t)(twist ? mid + 1 : NZP) + PSL_PAD, nreg = twist ? 2 : 1;
-    return (((size_t)NZP * 4 + 127) & ~(size_t)127) + 2 * nreg * rl * 4 + 32 * 8 + (2 * FW_TB * 32 + 2 * nreg * rl * 32 + 3 * FW_TB * 32) * 8;
+    const size_t rl = (size_t)(twist ? mid + 1 : NZP) + PSL_PAD, nreg = twist ? 2 : 1, w = (size_t)mw;
+    return (((size_t)NZP * 4 + 127) & ~(size_t)127) + 2 * nreg * rl * 4 + w * 8 + (2 * FW_TB * w + 2 * nreg * rl * w + 3 * FW_TB * w) * 8;
 }
 // One sweep of a slab's serial chain x <- a - b x over whole blocks of FW_TB rows (DIR = +1 down the region, -1 up), b = f * ip.
 // The chain is ONE wave, and what it costs is that wave's instruction stream -- about 65 cycles a row whatever the arithmetic is
@@ -244,9 +245,9 @@ __host__ __device__ inline size_t ps_slab_bytes(int NZP, int nz, int twist) {
 __device__ __forceinline__ c32 ps_cms(c32 a, c32 b, c32 x) {
     return c32{__builtin_fmaf(b.im, x.im, __builtin_fmaf(-b.re, x.re, a.re)), __builtin_fmaf(-b.im, x.re, __builtin_fmaf(-b.re, x.im, a.im))};
 }
-template <int DIR>
+template <int DIR, int MW>
 __device__ __forceinline__ c32 ps_sweep(c32* pa, const c32* pb, const float* pf, int nblk, c32 pt) {
-    constexpr int D = DIR * 32;
+    constexpr int D = DIR * MW;
     c32 a0[FW_TB], b0[FW_TB], a1[FW_TB], b1[FW_TB], q[FW_TB];
     float g[FW_TB];
 #pragma unroll
@@ -305,12 +306,12 @@ __device__ __forceinline__ void ps_slab_tables(const Solver& k, int mode, float*
         f1[i] = v1; f2[i] = v2;
     }
 }
-template <int NT>
+template <int NT, int MW>
 __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, const float* f1, const float* f2, int s, int slab, const float2* __restrict__ yhat,
                                               float2* __restrict__ ysol, const float2* __restrict__ ip32, int tidx, long long* stp = nullptr) {
     // (tidx: the caller's OPAQUE copy of tidx -- everything derived from the thread index here is invariant across the
     //  iterations of the solve, and the compiler hoisted all of it out of the iteration loop into registers it then spilled)
-    constexpr int SW = 32;
+    constexpr int SW = MW;                              // modes per slab (32, or 16: tall meshes)
     const int NYP = k.NYP, NZP = k.NZP, n = k.nz - 1;
     const int tw = k.twist, mid = twist_mid(n, tw);
     const int RCAP = tw ? mid + 1 : NZP, RL = RCAP + PSL_PAD, nreg = tw ? 2 : 1;
@@ -319,10 +320,10 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, const
     c32* sp = sa + (long)nreg * RL * SW;                 // inverse pivots, same layout
     auto lidx = [&](int row) { return (tw && row > mid) ? RL + (n + 1 - row) : row; };   // slab row of a matrix row
     const long so = (long)s * k.vstride;
-    const int t0 = slab * 2;
+    const int cb = slab * SW;                           // first mode of the slab
     const int lane = tidx & 63, wave = tidx >> 6;
     // join factor 1 / (1 - c c') of the two halves (item_pivot): requested with the slab's rows, not behind them
-    const int cj = t0 * 16 + (tidx & (SW - 1));
+    const int cj = cb + (tidx & (SW - 1));
     const float2 jfl = *ps_at(ip32 + so, (unsigned)min(cj, NYP - 1));
     // rows of the slab: a = y * ip, and ip -- two modes (16 bytes) per load, one batch
     {
@@ -335,7 +336,7 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, const
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
                 const int idx = min(i0 + u * NT, NZP * HW - 1);
-                const int row = idx / HW, c = t0 * 16 + 2 * (idx % HW);
+                const int row = idx / HW, c = cb + 2 * (idx % HW);
                 const bool rok = row >= 1 && row <= n;
                 ok0[u] = rok && c < k.ny - 1; ok1[u] = rok && c + 1 < k.ny - 1;
                 const unsigned e = (unsigned)((rok ? row : 1) * NYP + min(c, NYP - 2));
@@ -368,7 +369,7 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, const
     if (tidx < SW) sj[tidx] = (tw && cj < k.ny - 1) ? c32{jfl.x, jfl.y} : c32{1.f, 0.f};
     __syncthreads();
     if (stp) stp[12] = wall_clock64();
-    if (wave == 0 && lane < nreg * SW && t0 * 16 + (lane % SW) < k.ny - 1) {
+    if (wave == 0 && lane < nreg * SW && cb + (lane % SW) < k.ny - 1) {
         const int half = lane / SW, col = lane % SW;
         const int last = tw ? (half == 0 ? mid : n - mid) : n;      // rows 1..last of this lane's region are real
         const int steps = tw ? mid : n;                             // both halves run the longer count (identity rows)
@@ -376,7 +377,7 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, const
         const c32* rp = sp + (long)half * RL * SW + col;
         const float* g1 = f1 + half * RL;
         const float* g2 = f2 + half * RL;
-        c32 pt = ps_sweep<1>(ra + SW, rp + SW, g1 + 1, (steps + FW_TB - 1) / FW_TB, c32{0, 0});
+        c32 pt = ps_sweep<1, SW>(ra + SW, rp + SW, g1 + 1, (steps + FW_TB - 1) / FW_TB, c32{0, 0});
         pt = ra[last * SW];                                   // (the identity rows left it unchanged)
         if (tw) {
             const c32 p2last = g2[last] * rp[last * SW];
@@ -389,7 +390,7 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, const
             pt = half == 0 ? c32{xre, xim} : xbot;
             ra[last * SW] = pt;
         }
-        (void)ps_sweep<-1>(ra + (long)(last - 1) * SW, rp + (long)(last - 1) * SW, g2 + (last - 1), (steps - 1 + FW_TB - 1) / FW_TB, pt);
+        (void)ps_sweep<-1, SW>(ra + (long)(last - 1) * SW, rp + (long)(last - 1) * SW, g2 + (last - 1), (steps - 1 + FW_TB - 1) / FW_TB, pt);
     }
     __syncthreads();
     if (stp) stp[13] = wall_clock64();
@@ -398,7 +399,7 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, const
         constexpr int NG = SW / 8;
         unsigned short* yb = reinterpret_cast<unsigned short*>(ysol + so);
         for (int idx = tidx; idx < NZP * NG; idx += NT) {
-            const int row = idx / NG, j0 = (idx % NG) * 8, c0 = t0 * 16 + j0;
+            const int row = idx / NG, j0 = (idx % NG) * 8, c0 = cb + j0;
             if (c0 >= NYP) continue;
             const c32* src = sa + lidx(row) * SW + j0;
             u4v pl[4];
@@ -423,17 +424,17 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, const
 // tile that is free when q is formed; or the slabs of the tridiagonal
 // solves) | the three coefficient planes
 __host__ __device__ inline size_t ps_tile_bytes(int NYP) { return (((size_t)PS_ROWS * NYP * 8 + 64 + 255) & ~(size_t)255) + (size_t)4 * NYP * 8; }   // tile (+ 64 B over-read pad) + tail
-__host__ __device__ inline size_t ps_shared_bytes(int NYP, int NZP, int nz, int twist) {
-    const size_t a = 2 * ps_tile_bytes(NYP), b = ps_slab_bytes(NZP, nz, twist);
+__host__ __device__ inline size_t ps_shared_bytes(int NYP, int NZP, int nz, int twist, int mw = 32) {
+    const size_t a = 2 * ps_tile_bytes(NYP), b = ps_slab_bytes(NZP, nz, twist, mw);
     return ((a > b ? a : b) + 255) & ~(size_t)255;
 }
-__host__ __device__ inline size_t ps_lds_bytes(int NYP, int NZP, int nz, int twist) {
-    return 1024 + ps_shared_bytes(NYP, NZP, nz, twist) + (size_t)3 * PS_ROWS * NYP * 4 + 64 + (((size_t)2 * ps_tab_floats(NZP, nz, twist) * 4 + 128 + 63) & ~(size_t)63);
+__host__ __device__ inline size_t ps_lds_bytes(int NYP, int NZP, int nz, int twist, int mw = 32) {
+    return 1024 + ps_shared_bytes(NYP, NZP, nz, twist, mw) + (size_t)3 * PS_ROWS * NYP * 4 + 64 + (((size_t)2 * ps_tab_floats(NZP, nz, twist) * 4 + 128 + 63) & ~(size_t)63);
 }
 
 #define PS_STAMP(i) if (stampNow) a.stamps[(long)blockIdx.x * 16 + (i)] = wall_clock64();
 
-template <int CW, int SW>
+template <int CW, int SW, int MW = 32>
 __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a) {
     constexpr int NT = 2 * CW, NWV = NT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
     c32* T0 = reinterpret_cast<c32*>(arena);
     c32* T1 = reinterpret_cast<c32*>(arena + tileB);
     unsigned short* PL = reinterpret_cast<unsigned short*>(arena);       // planes [24][4][NYP] bf16 (+ 64 B the last k-group over-reads): the first tile's space
-    float* coE = reinterpret_cast<float*>(arena + ps_shared_bytes(NYP, k.NZP, nz, k.twist));
+    float* coE = reinterpret_cast<float*>(arena + ps_shared_bytes(NYP, k.NZP, nz, k.twist, MW));
     const PsPl co{coE, coE + PS_ROWS * NYP, coE + 2 * PS_ROWS * NYP};
     float* const tabF1 = coE + 3 * PS_ROWS * NYP + 16;                     // row scalars of the slab sweeps (ps_slab_tables), per system
     float* const tabF2 = tabF1 + ps_tab_floats(k.NZP, nz, k.twist);
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
     const int ntl = tbase + (wave < textra ? 1 : 0), t0w = wave * tbase + min(wave, textra);
     const int tl0 = min(t0w, NTc - 1), tl1 = min(t0w + 1, NTc - 1);
     const int lj = lane & 15, g4 = lane >> 4;
-    const int nslab = (NTc + 1) / 2;
+    const int nslab = (NYP + MW - 1) / MW;
 
     for (int round = 0; alive; ++round) {
         // (XCD x takes systems x, x + 8, ...: frequencies far apart, both polarisations.  Consecutive systems per XCD -- its L2
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             if (!sys_sync()) { alive = false; break; }                         // T1: every row of yhat is in the L2
             PS_STAMP(3)
             // ================= tridiagonal solves of this workgroup's mode slabs =================
-            for (int slab = jwg; slab < nslab; slab += G) ps_slab_solve<NT>(k, arena, tabF1, tabF2, s, slab, a.yhat, a.ysol, a.ip32, tidv, stampNow ? a.stamps + (long)blockIdx.x * 16 : nullptr);
+            for (int slab = jwg; slab < nslab; slab += G) ps_slab_solve<NT, MW>(k, arena, tabF1, tabF2, s, slab, a.yhat, a.ysol, a.ip32, tidv, stampNow ? a.stamps + (long)blockIdx.x * 16 : nullptr);
             PS_STAMP(4)
             u4v bbk[8][2];                                                     // the wave's V' fragments of the back transform: in flight during the wait
             {

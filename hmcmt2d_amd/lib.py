@@ -403,9 +403,9 @@ class HipContext:
 
     def persist_info(self):
         """The persistent solve kernel and this context (kernels_persist.h): shape, whether it is enabled, how many solves it ran."""
-        out = (C.c_int64 * 7)()
+        out = (C.c_int64 * 8)()
         self._check(self.lib.hmcmt_persist_info(self.h, out))
-        return dict(zip(("threads_half", "workgroups_per_system", "slots_per_xcd", "enabled", "solves", "placement_fallbacks", "usable_now"),
+        return dict(zip(("threads_half", "workgroups_per_system", "slots_per_xcd", "enabled", "solves", "placement_fallbacks", "usable_now", "slab_modes"),
                         (int(x) for x in out)))
 
     def debug_persist_precond(self, r, sweeps=1):

@@ -98,7 +98,7 @@ void hmcmt_default_options(hmcmt_options* opts);
  *   activeIdx[nAC]    1-based cell id of each active cell (= activeCell.rowval), bgModel[ny*nz]
  *   opts              NULL for defaults
  * Limits: ny + 1 <= 448 nodes across (HMCMT_EINVAL otherwise: the fp64 eigen-transform of the preconditioner holds 28 column
- * tiles); meshes up to 207 cells wide (and nz up to 139 rows at that width, more on narrower meshes: DESIGN 5.0, "Envelope")
+ * tiles); meshes up to 207 cells wide (and nz up to 319 rows at that width, more on narrower meshes: DESIGN 5.0, "Envelope")
  * run the one-launch-per-solve kernel, all others four to six launches per iteration;
  * hmcmt_persist_info tells which. */
 int hmcmt_create(hmcmt_ctx** ctx, int32_t device_id,
@@ -234,8 +234,9 @@ int hmcmt_debug_flags(hmcmt_ctx* ctx, int32_t flags);
 int hmcmt_debug_spmv(hmcmt_ctx* ctx, const double* p, double* q);
 int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z);
 int hmcmt_guard(const hmcmt_ctx* ctx, double* out4);   /* {checks, worst true residual seen, last, trips (checks above HMCMT_GUARD_LIMIT, default 1e-6)}: the production guard of the stopping rule (every HMCMT_GUARD_EVERY-th evaluation, default 100) */
-int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out7);   /* {threads/2 (0: not applicable), workgroups per system, slots per XCD, enabled, solves, placement fallbacks,
-                                                                   usable now (this context alone on its device in the process AND the process holds the device's advisory lock)} */
+int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out8);   /* {threads/2 (0: not applicable), workgroups per system, slots per XCD, enabled, solves, placement fallbacks,
+                                                                   usable now (this context alone on its device in the process AND the process holds the device's advisory lock),
+                                                                   modes per slab of its tridiagonal solves (32; 16 on tall meshes)} */
 int hmcmt_debug_persist_precond(hmcmt_ctx* ctx, int32_t sweeps, const double* r, double* z);   /* the persistent solve kernel's preconditioner (tests) */
 int hmcmt_debug_fdm_fwd(hmcmt_ctx* ctx, const double* t, double* out);   /* [2][S*vstride] complex: fused kernel | separate kernels */
 int hmcmt_debug_back_post(hmcmt_ctx* ctx, const double* y, const double* r, double* out, double* sums);   /* out: [2][S*vstride] complex (fused | separate), sums[6] */

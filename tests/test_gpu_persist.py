@@ -223,3 +223,28 @@ def test_followers_queued_behind_the_solve_change_nothing(monkeypatch):
     assert st["fallback_solves"] >= 1 and st["status"] == 0
     po, mo, go = oracle_eval(mesh, data, inv, m + 0.02)
     assert relmax(p, po) < 1e-9 and abs(f - mo) / mo < 1e-9 and relmax(g, go) < 1e-7
+
+
+def test_tall_mesh_runs_the_persistent_kernel_with_16_mode_slabs(monkeypatch):
+    """200 x 150 cells (+7 air rows): the 32-mode slab of the tridiagonal solves (2 x 2 x 95 rows x 32 modes x 8 B) no longer fits
+    the LDS beside the coefficient planes, the kernel is instantiated with 16-mode slabs (13 slabs on 12 workgroups: one workgroup
+    solves two) -- against the launch-per-phase loop, with the true-residual check."""
+    from hmcmt2d_amd import synthetic as S, invsetup as I
+    from tests.helpers import start_sigma
+    mesh = S.make_mesh(200, 150)
+    data = S.make_data_layout(S.log_freqs(4), np.arange(-8000.0, 8001.0, 2000.0))
+    n = len(data.rxID)
+    obs = np.full(n, 0.02 + 0.02j) * np.where(data.dtID == 1, 1.0, -1.0)
+    mesh.sigma = start_sigma(mesh)
+    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, obs, np.full(n, 1e-3))
+    m = S.rough_state(len(inv.strModel))
+    res = {}
+    for persist in (False, True):
+        ctx = _ctx(monkeypatch, mesh, data, inv, persist, 2, verify=True)
+        res[persist] = ctx.grad(m) + (ctx.stats(), ctx.persist_info())
+        ctx.close()
+    (p0, f0, g0, s0, i0), (p1, f1, g1, s1, i1) = res[False], res[True]
+    assert i1["slab_modes"] == 16 and i1["threads_half"] == 256 and i1["workgroups_per_system"] == 12 and i1["solves"] == 2
+    assert s1["status"] == 0 and s1["true_res_max"] < 1e-9 and s1["fallback_solves"] == 0
+    assert abs(s1["iters_fwd_max"] - s0["iters_fwd_max"]) <= 1 and abs(s1["iters_adj_max"] - s0["iters_adj_max"]) <= 1
+    assert relmax(p1, p0) < 1e-9 and abs(f1 - f0) / abs(f0) < 1e-9 and relmax(g1, g0) < 1e-8
