@@ -225,6 +225,33 @@ def timed(torch, dist, fn):
         gc.enable()
 
 
+def spawn_ranks(n):
+    """N child processes, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets them), started
+    BEFORE this process has made any GPU call (it never makes one: no exec of a process that has initialised the GPU).  Rank 0's
+    stdout -- the one JSON line -- is this process's stdout; the exit code is the first non-zero one of the ranks."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for r, p in enumerate(procs):
+        c = p.wait()
+        if c != 0 and rc == 0:
+            rc = c if c > 0 else 1
+            print(f"bench.py: rank {r} exited with {c}", file=sys.stderr)
+            for q in procs:                      # (the others would wait at the barrier for ever)
+                if q.poll() is None:
+                    q.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,6 +262,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed-region legs (near_true_state, straight_line, cold_start)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (parallelHMC.jl:10-49 is one call, too): this process touches no GPU, it starts N rank
+        # processes with the environment torch.distributed.run would give them and hands rank 0's JSON line through
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -248,8 +279,7 @@ def main():
         cpu = cpu_baseline(args.config)          # before this process touches the GPU: the workers are spawned
     import torch
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or without it")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
@@ -438,21 +468,47 @@ def main():
                  "fdm_transform": ((1, 13), (1, 13)),  # read y (1), z0 = D r (3), z = V y + z0 (3), A z, 4 passes, r'z and |z|^2 (2)
                  "post_smoother": ((1, 6), (1, 6))}
 
+        def persist_design_bytes(f2):
+            """What k_cocg_persist's OWN design moves through global memory, per OWNED unknown: (per iteration, per application of
+            the preconditioner in front of the first iteration).  r lives in registers, the tiles and the float stencil
+            coefficients in LDS; what crosses the CU boundary is
+              x                     read 16 + write 16 (fp64 complex, by its owner, once)
+              r' (complex64)        published 8, the neighbours' halo rows read back: 2 x 5 halo rows per 14 own rows
+              z2, p (complex64)     published 8 each; read back on the WHOLE tile (24 rows per 14 own rows, W_t columns per W_o own)
+              t (two sweeps)        written 8 + read 8 (the rho identity behind the FDM stage)
+              yhat                  the forward transform's rows: written 8 per column part, read by the slab owner
+              inverse pivots        8 (complex64)
+              solved slabs          written 8 (split bf16 planes), read back on the tile's 24 rows (every mode: no column factor)
+              fp64 coefficients     dM, cY, cZ of the own rows for q = A p: 24 B per node and POLARISATION, shared by the systems of
+                                    that polarisation an XCD runs at a time (half its slots)
+            The bf16 eigenvector fragments (shared by every workgroup of the chip, 87-350 KB) are served by the L2 and not counted."""
+            pi = ctx.persist_info()
+            cs = max(int(pi.get("column_parts", 1)), 1)
+            own_w = ctx.NYP / cs
+            tile_w = own_w + (8 if cs > 1 else 0) * min(cs - 1, 2)       # halo columns of a column part (kernels_persist.h: PS_HC)
+            rows, cols = 24.0 / 14.0, tile_w / own_w
+            halo_r = (10.0 / 14.0) * cols + (cols - 1.0)                 # halo rows + (column split) the halo columns of the own rows
+            common = 8 + 8 * halo_r + 8 + 8 * rows * cols + 8 * cs + 8 * cs + 8 + 8 + 8 * rows + 16 * f2
+            it = 32 + common + 8 + 8 * rows * cols + 24.0 / max(pi["slots_per_xcd"] / 2.0, 1.0)
+            pre = common
+            return it, pre
+
         def build_roofline_persistent(prof, cnt, population, every):
-            """Round 4: the whole solve is ONE launch of k_cocg_persist (kernels_persist.h).  Its algorithmic bytes are those of the
-            iterations it performs, by the per-iteration figure of rounds 1-3 (every vector of the four-kernel iteration read /
-            written once: 224 B per unknown with one smoothing sweep per side, 264 B with two; 96 / 104 B for the preconditioner
-            application in front of the first iteration) -- the kernel itself keeps r in registers and its tiles in LDS and moves
-            far fewer bytes through memory (`traffic`, from the PMC passes), so `frac` says how fast the ITERATIONS are against
-            what the launch-per-phase form had to stream, not how close to the HBM roof this kernel's own traffic is."""
+            """The whole solve is ONE launch of k_cocg_persist (kernels_persist.h).  `achieved` / `frac`: the bytes the kernel's OWN
+            design moves (persist_design_bytes: ~168 B per unknown and iteration with two sweeps per side at cfg3; the PMC passes
+            measure 173) x the system-iterations the launch performed (device counter) / the HIP-event duration of the launch.
+            `frac_four_kernel_bytes` keeps rounds 1-4's figure (every vector of the launch-per-phase iteration streamed once: 224 /
+            264 B) for round-to-round comparison; `frac_traffic` is the PMC-measured rate."""
             f2 = cnt.get("solves_two_sweeps", 0) / max(cnt["solves"], 1)
             it_sys, pre_sys = cnt["active_iter_systems"], cnt["start_systems"]
             ms_c, n_c = prof["spmv"]                         # (the launch is timed under this category)
             avg_us = 1e3 * ms_c / max(n_c, 1)
-            it_bpu, pre_bpu = 224.0 + 40.0 * f2, 96.0 + 8.0 * f2
+            it_bpu, pre_bpu = persist_design_bytes(f2)
+            it4_bpu, pre4_bpu = 224.0 + 40.0 * f2, 96.0 + 8.0 * f2
             tot_bytes = Usys * (it_bpu * it_sys + pre_bpu * pre_sys)
             nbytes = tot_bytes / max(n_c, 1)
             ach = nbytes / (avg_us * 1e-6) / 1e9 if n_c else 0.0
+            ach4 = Usys * (it4_bpu * it_sys + pre4_bpu * pre_sys) / max(n_c, 1) / (avg_us * 1e-6) / 1e9 if n_c else 0.0
             (sp1, vp1), (sp2, vp2) = (3, 33), (5, 45)        # canonical CSR: stencil products and vector passes of an iteration (sum of CANON)
             can_it = (sp1 * B_spmv + vp1 * 16 * Usys) * (1 - f2) + (sp2 * B_spmv + vp2 * 16 * Usys) * f2
             can = can_it * it_sys / max(n_c, 1) / (avg_us * 1e-6) / 1e9 if n_c else 0.0
@@ -470,7 +526,8 @@ def main():
                      "event_bracket_overhead_us_subtracted": prof_overhead_us, "rocprofv3_avg_launch_us": rocprof_avg_us(name, "persist"),
                      "launches_timed": n_c, "bytes_per_launch": nbytes, "ms_timed": ms_c,
                      "system_iterations_per_launch": it_sys / max(n_c, 1), "preconditioner_applications_per_launch": pre_sys / max(n_c, 1),
-                     "bytes_per_unknown_and_iteration": it_bpu, "us_per_iteration": it_us, "active_systems_per_iteration": sys_per_it,
+                     "bytes_per_unknown_and_iteration": it_bpu, "frac_four_kernel_bytes": ach4 / HBM_PEAK_GBS,
+                     "four_kernel_bytes_per_unknown_and_iteration": it4_bpu, "us_per_iteration": it_us, "active_systems_per_iteration": sys_per_it,
                      "active_systems_per_launch": sys_per_it, "launches_per_iteration": 0,
                      "mfma": {"flops_per_launch": flops, "achieved_tflops": flops / (avg_us * 1e-6) / 1e12 if n_c else 0.0, "peak_tflops_bf16_dense": 2500.0},
                      "population": population}
@@ -478,7 +535,7 @@ def main():
                          "achieved": Usys * it_bpu * sys_per_it / (it_us * 1e-6) / 1e9 if n_c else 0.0, "unit": "GB/s",
                          "frac": Usys * it_bpu * sys_per_it / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS if n_c else 0.0,
                          "note": "one preconditioned COCG iteration inside the persistent kernel: kernel time / iterations of its slowest system; "
-                                 "bytes = the four-kernel iteration's algorithmic bytes x the systems active in an average iteration"}
+                                 "bytes = the kernel's own design bytes x the systems active in an average iteration"}
             step_bytes = tot_bytes / max(cnt["evaluations"], 1)
             return [entry], iteration, step_bytes
 
