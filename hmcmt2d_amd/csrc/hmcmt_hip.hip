@@ -169,7 +169,13 @@ struct hmcmt_ctx {
     u4v* d_prec = nullptr;                // [S][MAXNB][2][8] records of the kernel's reductions (tagged, never cleared)
     unsigned long long persistTag = 0;    // ... the tag base of the next launch
     long long* d_pstamps = nullptr;       // HMCMT_STAMPS=persist
-    long long persistSolves = 0, persistFallbacks = 0;
+    long long persistSolves = 0, persistFallbacks = 0, persistTimeouts = 0;
+    int persistCS = 1, persistGZ = 0;     // column parts of a row block (2: wide meshes, kernels_persist.h), row blocks per system
+    PsConst psShadow{};                   // what d_psConst holds (launch_persist refreshes the device copy when a field differs)
+    PsConst* d_psConst = nullptr;         // the kernel's launch-invariant state, read through a constant-address-space pointer
+    bool psConstValid = false;
+    float2* d_yhat2 = nullptr;            // column parts: the second part's partial product of the forward transform
+    int dbgPlace = 0;                     // test hook (hmcmt_debug_flags bit 2): the next persistent launch's first group fails its placement check
     bool counted = false;                 // this context is in g_liveOnDev / holds a reference on the device lock
     // production guard on the error-estimate stopping rule: every guardEvery-th evaluation the TRUE residual of both
     // solves is formed (two vector passes and a read-back: ~0.1 ms once in guardEvery evaluations) -- hmcmt_guard
@@ -548,38 +554,61 @@ static bool devlock_held(int dev) {
 }
 
 // the persistent solve kernel applies to the solve at hand (default path, a mesh its tiles fit, alone on the device)
+// (this context is alone on its device in the process, and the process holds the device's lock)
+bool persist_alone(const hmcmt_ctx* ctx) {
+    return ctx->device >= 0 && ctx->device < MAXDEV && g_liveOnDev[ctx->device].load() == 1 && devlock_held(ctx->device);
+}
 bool persist_ok(const hmcmt_ctx* ctx) {
-    return ctx->persistOn && ctx->persistCW > 0 && ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0 &&
-           ctx->device >= 0 && ctx->device < MAXDEV && g_liveOnDev[ctx->device].load() == 1 && devlock_held(ctx->device);
+    return ctx->persistOn && ctx->persistCW > 0 && ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0 && persist_alone(ctx);
 }
 // one launch = the whole solve (or, precondOnly, one application of the preconditioner to k.r -> zout)
 int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout, int kind = 0) {
     Solver& k = ctx->sv;
-    PersistArgs a{};
     const int groups = 8 * ctx->persistSlots;
-    a.sync = ctx->d_psync; a.exitCnt = ctx->d_psync + 32 * groups; a.fail = reinterpret_cast<int*>(ctx->d_psync + 32 * groups + 8);
-    a.placeHost = k.stallHost + 2;
-    a.G = ctx->persistG; a.slots = ctx->persistSlots; a.maxit = ctx->opt.maxit; a.precondOnly = precondOnly;
-    a.wJ = (float)ctx->jacobiW;
-    a.Vb = ctx->d_Vb; a.Vtb = ctx->d_Vtb;
-    a.partZZ = ctx->d_partZZ;
-    a.pubR = k.t2_32; a.pubZ = k.zs32; a.pubP = k.p32a;
-    a.yhat = k.y32; a.ysol = k.t32; a.tbuf = k.z4_32;
+    // the launch-invariant state: rebuilt from the solver's structures on every launch (a few hundred bytes of host work) and
+    // compared with what the device copy holds -- any field that changes (an option, a buffer) refreshes it, nothing has to
+    // remember to
+    PsConst c{};
+    c.S = k.S; c.nFreq = k.nFreq; c.NYP = k.NYP; c.NZP = k.NZP; c.ny = k.ny; c.nz = k.nz; c.twist = k.twist; c.stallIt = k.stallIt;
+    c.vstride = k.vstride;
+    c.G = ctx->persistG; c.GZ = ctx->persistGZ; c.slots = ctx->persistSlots;
+    c.C0 = ctx->persistCS > 1 ? ps_split_col(k.NYP) : k.NYP; c.TW = ps_tile_width(k.NYP, ctx->persistCS); c.PLW = ctx->persistCS > 1 ? ps_plane_width(k.NYP) : k.NYP;
+    c.syncWords = (int)(ctx->psyncBytes / sizeof(unsigned));      // (zero at create; every launch's last workgroup leaves them zero)
+    c.wJ = (float)ctx->jacobiW;
+    c.omega = k.omega; c.ofz = k.ofz; c.dM = k.dM; c.cY = k.cY; c.cZ = k.cZ; c.cf32 = k.cf32;
+    c.active = k.active; c.iters = k.iters; c.status = k.status; c.nactive = k.nactive; c.nactHost = k.nactHost;
+    c.failHost = k.failHost; c.stallHost = k.stallHost; c.progHost = k.progHost; c.errEst = k.errEst; c.ticks = k.ticks;
+    c.sync = ctx->d_psync; c.exitCnt = ctx->d_psync + 32 * groups; c.fail = reinterpret_cast<int*>(ctx->d_psync + 32 * groups + 8);
+    c.placeHost = k.stallHost + 2;
+    c.Vb = ctx->d_Vb; c.Vtb = ctx->d_Vtb;
+    c.pubR = k.t2_32; c.pubZ = k.zs32; c.pubP = k.p32a;
+    c.yhat = k.y32; c.yhat2 = ctx->d_yhat2; c.ysol = k.t32; c.tbuf = k.z4_32;
+    c.ip32 = ctx->d_invp32; c.rec = ctx->d_prec;
+    if (!ctx->psConstValid || std::memcmp(&c, &ctx->psShadow, sizeof c) != 0) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));             // (rare: an earlier launch may still read the old copy)
+        HIPCHK(hipMemcpy(ctx->d_psConst, &c, sizeof c, hipMemcpyHostToDevice));
+        ctx->psShadow = c; ctx->psConstValid = true;
+    }
+    PsLaunch a{};
+    a.kc = ctx->d_psConst;
+    a.x = k.x; a.r = k.r; a.tol2 = k.tol2; a.w2 = k.w2;
+    a.maxit = ctx->opt.maxit; a.precondOnly = precondOnly;
     ctx->persistTag += std::max(1ull << 20, 2ull * ((unsigned long long)std::max(ctx->opt.maxit, 0) + 8));   // (an iteration takes two tags: a launch's range never reaches the next one's)
-    a.rec = ctx->d_prec; a.tagBase = ctx->persistTag;
-    a.ip32 = ctx->d_invp32;
+    a.tagBase = ctx->persistTag;
     a.zout = zout;
     a.stamps = ctx->d_pstamps;
+    a.cntActive = k.cntActive;
     a.tickId = kind == 1 ? TK_PERSIST_A : TK_PERSIST_F;
     a.gateOut = precondOnly ? nullptr : ctx->d_gate + (kind == 1 ? 1 : 0);
+    if (ctx->gateGen >= 0x3fffffff) ctx->gateGen = 0;           // (wrap BEFORE the increment: the followers are handed ctx->gateGen, the value this launch writes)
     a.gateGen = ++ctx->gateGen;
-    if (ctx->gateGen > 0x3fffffff) ctx->gateGen = 0;
-    a.syncWords = (int)(ctx->psyncBytes / sizeof(unsigned));      // (zero at create; every launch's last workgroup leaves them zero)
-    if (ctx->d_pstamps) HIPCHK(hipMemsetAsync(ctx->d_pstamps, 0, sizeof(long long) * 16 * 252, ctx->stream));
+    a.dbgPlace = ctx->dbgPlace; ctx->dbgPlace = 0;
+    if (ctx->d_pstamps) HIPCHK(hipMemsetAsync(ctx->d_pstamps, 0, sizeof(long long) * 16 * 256, ctx->stream));
     const dim3 grid(groups * ctx->persistG);
     const size_t lds = ctx->persistLds;
-#define PSL(CW, SWP) do { if (ctx->persistMW == 16) hipLaunchKernelGGL((k_cocg_persist<CW, SWP, 16>), grid, dim3(2 * CW), lds, ctx->stream, k, a); \
-                         else hipLaunchKernelGGL((k_cocg_persist<CW, SWP, 32>), grid, dim3(2 * CW), lds, ctx->stream, k, a); } while (0)
+#define PSL(CW, SWP) do { if (ctx->persistCS > 1) hipLaunchKernelGGL((k_cocg_persist<CW, SWP, 16, 2>), grid, dim3(2 * CW), lds, ctx->stream, a); \
+                         else if (ctx->persistMW == 16) hipLaunchKernelGGL((k_cocg_persist<CW, SWP, 16, 1>), grid, dim3(2 * CW), lds, ctx->stream, a); \
+                         else hipLaunchKernelGGL((k_cocg_persist<CW, SWP, 32, 1>), grid, dim3(2 * CW), lds, ctx->stream, a); } while (0)
     if (ctx->persistCW == 256) { if (sweeps == 2) PSL(256, 2); else PSL(256, 1); }
     else if (ctx->persistCW == 128) { if (sweeps == 2) PSL(128, 2); else PSL(128, 1); }
     else { if (sweeps == 2) PSL(64, 2); else PSL(64, 1); }
@@ -1311,40 +1340,71 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     return 0;
 }
 
-// Shape of the persistent solve kernel for this problem (kernels_persist.h): G workgroups of 14 rows per system, all of a
-// system's workgroups on one XCD (32 CUs), one workgroup per CU; 2 * CW threads for meshes up to CW nodes wide.
+// Shape of the persistent solve kernel for this problem (kernels_persist.h): a system = GZ row blocks of 14 rows x CS column
+// parts = G workgroups, all on one XCD (32 CUs), one workgroup per CU; 2 * CW threads for tiles up to CW columns wide.
+// CS = 1 where the whole row fits one tile (its LDS); CS = 2 (two column parts per row block) on wider meshes -- the stress size.
 // does the mesh fit the kernel (its LDS, a system's workgroups on one XCD)?  twist: the factorisation the solves will use
-static bool persist_shape(const hmcmt_ctx* ctx, int twist, int& cuPerXcd, int& G, int& cw, int& mw, size_t& lds) {
+static bool persist_shape_cs(const hmcmt_ctx* ctx, int twist, int cs, int cuPerXcd, int& G, int& cw, int& mw, size_t& lds) {
     const Solver& k = ctx->sv;
+    const int GZ = (k.nz - 1 + PS_OWN - 1) / PS_OWN;
+    G = GZ * cs;
+    const int TW = ps_tile_width(k.NYP, cs);
+    if (TW > 256 || G > cuPerXcd || G > MAXNB) return false;
+    cw = TW <= 64 ? 64 : (TW <= 128 ? 128 : 256);
+    if (cs > 1) {
+        // the MFMA work split of the kernel: at most 4 mode tiles (forward) and 2 tile columns (back) per wave, at most 8 K-groups
+        // of own columns, at most 16 in all; every slab has a workgroup
+        const int NWV = cw / 32, C0 = ps_split_col(k.NYP), NTc = k.NYP / 16, KG = (k.NYP + 31) / 32;
+        const int ntb0 = (C0 + PS_HC + 15) / 16, ntb1 = NTc - (C0 - PS_HC) / 16;
+        if (k.NYP < 64 || (k.NYP & 15) || NTc > 4 * NWV || std::max(ntb0, ntb1) > 2 * NWV || ps_plane_width(k.NYP) > 256 || KG > 16 || k.NYP > 2 * cw) return false;
+        if ((size_t)16 * 4 * ps_plane_width(k.NYP) * 2 > ps_tile_bytes(TW) - (size_t)4 * TW * 8) return false;      // (the forward operand planes live in the first tile)
+        if ((k.NYP + 15) / 16 > G) return false;
+        mw = 16;
+        lds = ps_lds_bytes(TW, k.NYP, k.NZP, k.nz, twist, 16);
+        return lds <= (size_t)160 * 1024;
+    }
+    // modes per slab of the tridiagonal solves: 32, or 16 where the 32-mode slab of a tall mesh does not fit the LDS beside the planes
+    mw = 32;
+    lds = ps_lds_bytes(TW, k.NYP, k.NZP, k.nz, twist, 32);
+    if (lds > (size_t)160 * 1024) { mw = 16; lds = ps_lds_bytes(TW, k.NYP, k.NZP, k.nz, twist, 16); }
+    return lds <= (size_t)160 * 1024;
+}
+static bool persist_shape(const hmcmt_ctx* ctx, int twist, int& cuPerXcd, int& G, int& cw, int& mw, size_t& lds, int* csOut = nullptr) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) { (void)hipGetLastError(); return false; }
     cuPerXcd = prop.multiProcessorCount / 8;
-    G = (k.nz - 1 + PS_OWN - 1) / PS_OWN;
-    if (k.NYP > 256 || cuPerXcd < 1 || G > cuPerXcd || G > MAXNB || !ctx->d_Vb || !ctx->d_Vtb) return false;
-    cw = k.NYP <= 64 ? 64 : (k.NYP <= 128 ? 128 : 256);
-    // modes per slab of the tridiagonal solves: 32, or 16 where the 32-mode slab of a tall mesh does not fit the LDS beside the planes
-    mw = 32;
-    lds = ps_lds_bytes(k.NYP, k.NZP, k.nz, twist, 32);
-    if (lds > (size_t)160 * 1024) { mw = 16; lds = ps_lds_bytes(k.NYP, k.NZP, k.nz, twist, 16); }
-    return lds <= (size_t)160 * 1024;
+    if (cuPerXcd < 1 || !ctx->d_Vb || !ctx->d_Vtb) return false;
+    // HMCMT_PERSIST_CS = 1 | 2 forces the column parts (tests: the two-part kernel on meshes one tile would hold)
+    const char* e = getenv("HMCMT_PERSIST_CS");
+    const int force = e ? atoi(e) : 0;
+    for (int cs = 1; cs <= 2; ++cs) {
+        if (force && cs != force) continue;
+        if (persist_shape_cs(ctx, twist, cs, cuPerXcd, G, cw, mw, lds)) { if (csOut) *csOut = cs; return true; }
+    }
+    return false;
 }
 static int persist_setup(hmcmt_ctx* ctx) {
     const Solver& k = ctx->sv;
     if (const char* e = getenv("HMCMT_PERSIST")) ctx->persistOn = e[0] != '0';
     ctx->persistCW = 0;
-    int cuPerXcd = 0, G = 0, cw = 0, mw = 32;
+    int cuPerXcd = 0, G = 0, cw = 0, mw = 32, cs = 1;
     size_t lds = 0;
-    if (!persist_shape(ctx, k.twist, cuPerXcd, G, cw, mw, lds)) return 0;
+    if (!persist_shape(ctx, k.twist, cuPerXcd, G, cw, mw, lds, &cs)) return 0;
     ctx->persistMW = mw;
-    const void* fns[12] = {reinterpret_cast<const void*>(k_cocg_persist<256, 1, 32>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 32>),
-                           reinterpret_cast<const void*>(k_cocg_persist<128, 1, 32>), reinterpret_cast<const void*>(k_cocg_persist<128, 2, 32>),
-                           reinterpret_cast<const void*>(k_cocg_persist<64, 1, 32>), reinterpret_cast<const void*>(k_cocg_persist<64, 2, 32>),
-                           reinterpret_cast<const void*>(k_cocg_persist<256, 1, 16>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 16>),
-                           reinterpret_cast<const void*>(k_cocg_persist<128, 1, 16>), reinterpret_cast<const void*>(k_cocg_persist<128, 2, 16>),
-                           reinterpret_cast<const void*>(k_cocg_persist<64, 1, 16>), reinterpret_cast<const void*>(k_cocg_persist<64, 2, 16>)};
+    const void* fns[18] = {reinterpret_cast<const void*>(k_cocg_persist<256, 1, 32, 1>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 32, 1>),
+                           reinterpret_cast<const void*>(k_cocg_persist<128, 1, 32, 1>), reinterpret_cast<const void*>(k_cocg_persist<128, 2, 32, 1>),
+                           reinterpret_cast<const void*>(k_cocg_persist<64, 1, 32, 1>), reinterpret_cast<const void*>(k_cocg_persist<64, 2, 32, 1>),
+                           reinterpret_cast<const void*>(k_cocg_persist<256, 1, 16, 1>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 16, 1>),
+                           reinterpret_cast<const void*>(k_cocg_persist<128, 1, 16, 1>), reinterpret_cast<const void*>(k_cocg_persist<128, 2, 16, 1>),
+                           reinterpret_cast<const void*>(k_cocg_persist<64, 1, 16, 1>), reinterpret_cast<const void*>(k_cocg_persist<64, 2, 16, 1>),
+                           reinterpret_cast<const void*>(k_cocg_persist<256, 1, 16, 2>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 16, 2>),
+                           reinterpret_cast<const void*>(k_cocg_persist<128, 1, 16, 2>), reinterpret_cast<const void*>(k_cocg_persist<128, 2, 16, 2>),
+                           reinterpret_cast<const void*>(k_cocg_persist<64, 1, 16, 2>), reinterpret_cast<const void*>(k_cocg_persist<64, 2, 16, 2>)};
     for (const void* f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return 0; }
     ctx->persistG = G;
+    ctx->persistCS = cs;
+    ctx->persistGZ = G / cs;
     ctx->persistSlots = std::max(1, std::min((k.S + 7) / 8, cuPerXcd / G));
     ctx->persistLds = lds;
     ctx->psyncBytes = ((size_t)(32 * 8 * ctx->persistSlots + 16) * sizeof(unsigned) + 15) & ~(size_t)15;
@@ -1367,6 +1427,21 @@ static int persist_setup(hmcmt_ctx* ctx) {
         HIPCHK(hipMemset(r, 0, recBytes));
         ctx->allocs.push_back(r);
         ctx->d_prec = reinterpret_cast<u4v*>(r);
+    }
+    {
+        void* pc = nullptr;
+        HIPCHK(hipMalloc(&pc, sizeof(PsConst)));
+        ctx->allocs.push_back(pc);
+        ctx->d_psConst = reinterpret_cast<PsConst*>(pc);
+        ctx->psConstValid = false;
+    }
+    if (cs > 1) {
+        void* y2 = nullptr;
+        const size_t nb = (size_t)k.S * k.vstride * sizeof(float2);
+        HIPCHK(hipMalloc(&y2, nb));
+        HIPCHK(hipMemset(y2, 0, nb));
+        ctx->allocs.push_back(y2);
+        ctx->d_yhat2 = reinterpret_cast<float2*>(y2);
     }
     if (const char* es = getenv("HMCMT_STAMPS")) if (!strcmp(es, "persist")) {
         HIPCHK(hipMalloc((void**)&ctx->d_pstamps, sizeof(long long) * 16 * 256));
@@ -1955,7 +2030,9 @@ int hmcmt_debug_transform(hmcmt_ctx* ctx, int32_t which, const double* A, double
 }
 
 int hmcmt_debug_flags(hmcmt_ctx* ctx, int32_t flags) {
-    if (!ctx || (flags & ~3)) return HMCMT_EINVAL;
+    if (!ctx || (flags & ~7)) return HMCMT_EINVAL;
+    if (flags & 4) ctx->dbgPlace = 1;                     // (one-shot: the next persistent launch's first system group fails its placement check)
+    flags &= 3;
     ctx->dbgFlags = flags;
     ctx->memo[0].valid = ctx->memo[1].valid = false;      // (stored results belong to the flags they were computed under)
     ctx->lfHaveGrad = false;
@@ -2020,6 +2097,8 @@ int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out) {
     out[4] = ctx->persistSolves; out[5] = ctx->persistFallbacks;
     out[6] = persist_ok(ctx) ? 1 : 0;              // would the next default-path solve use it (alone on the device, device lock held)
     out[7] = ctx->persistCW ? ctx->persistMW : 0;  // modes per slab
+    out[8] = ctx->persistCW ? ctx->persistCS : 0;  // column parts per row block (2: wide meshes)
+    out[9] = ctx->persistTimeouts;                 // timed-out waits (the evaluation was redone with the launch-per-phase loop)
     return 0;
 }
 
@@ -2029,6 +2108,7 @@ int hmcmt_debug_persist_precond(hmcmt_ctx* ctx, int32_t sweeps, const double* r,
     if (!ctx || !r || !z || (sweeps != 1 && sweeps != 2)) return HMCMT_EINVAL;
     if (!ctx->haveModel) { ctx->err = "no evaluation has been run yet"; return HMCMT_EINVAL; }
     if (!ctx->persistCW) { ctx->err = "the persistent solve kernel does not apply to this problem"; return HMCMT_EINVAL; }
+    if (!persist_alone(ctx)) { ctx->err = "the persistent solve kernel may not run now (another context or process holds the device)"; return HMCMT_EINVAL; }
     HIPCHK(hipSetDevice(ctx->device));
     const size_t n = (size_t)ctx->v.S * ctx->v.vstride;
     HIPCHK(hipMemcpy(ctx->sv.r, r, n * sizeof(cplx), hipMemcpyHostToDevice));

@@ -30,39 +30,77 @@
 // same stagnation watch, z and p rounded to complex64, x, r, q and all inner products fp64) except that the smoother
 // works from a complex64 copy of r throughout, its diagonal is formed from the float couplings, and the halo rows' q is
 // fp32: iteration counts agree within +-1, results to the solver tolerance (tests/test_gpu_persist.py).
+// Round 5: (1) COLUMN PARTS -- on meshes too wide for one tile (the stress size, 400 cells) a row block is shared by CS = 2
+// workgroups: a system = ceil((nz-1)/14) x 2 workgroups of one XCD (cfg5: 15 x 2 = 30 of its 32 CUs, one system per XCD at a time,
+// the 64 systems in rounds).  Part h owns the columns [0, C0) / [C0, NYP) and keeps PS_HC = 8 halo columns of its neighbour in
+// the tile; everything the row halos do -- recomputed, shrinking by one column per stencil, refreshed from the owners' published
+// r', z2, p behind T2 -- the column halos do too (a thread of a halo column holds r of ITS 12 rows as a copy).  The eigen-
+// transforms couple all columns of a row: the forward one is the sum of the two parts' partial products (each part multiplies its
+// own columns of t with the matching rows of V; two partial yhat rows, added by the slab owner when it loads them behind T1 -- no
+// further synchronisation), the back one multiplies the whole solved slab rows (all modes) with the part's columns of V'.
+// (2) ARGUMENTS -- the launch-invariant state (PsConst: geometry, every array of the solver) lives in device memory and is read
+// through a CONSTANT-address-space pointer that is laundered at every phase: a phase loads the scalars it needs with s_load from a
+// hot line and drops them, instead of 968 bytes of by-value kernarg being held in (and spilled from: 417 SGPR spills, 821
+// v_readlane in the iteration loop) scalar registers for the whole solve.  What changes per launch is PsLaunch (88 B).
 // Reference: the solves at MTFwdSolver/mt2DTE.jl:47-55, mt2DTM.jl:46-54, MTSensitivity/compJacTMatVec.jl:220-229, 291-300.
 #pragma once
+
 
 constexpr int PS_OWN = 14;                        // interior rows owned by a workgroup
 constexpr int PS_HALO = 5;                        // rows recomputed on each side
 constexpr int PS_ROWS = PS_OWN + 2 * PS_HALO;     // 24 = three MFMA row groups
 constexpr int PS_J = PS_ROWS / 2;                 // tile rows per thread
 constexpr int PS_NO = PS_OWN / 2;                 // own rows per thread: j = PS_HALO .. PS_J - 1
+constexpr int PS_HC = 8;                          // column parts: halo columns kept of the neighbouring part (>= PS_HALO, the depth of the chain)
 constexpr int PS_DONE = 0x7fffffff;               // progress word: the kernel has ended
 constexpr unsigned PS_SPIN_LIMIT = 1u << 22;      // polls (~1 us each) before a wait gives up
 
-struct PersistArgs {
+// Launch-invariant state of the kernel, in DEVICE memory (one copy per context, refreshed by launch_persist when a field changes).
+// The kernel reads it through a constant-address-space pointer (scalar loads) that is laundered at every phase (PS_PHASE): a
+// phase loads what it needs from a hot line of the scalar cache; nothing of this is held -- or spilled -- across the solve.
+struct PsConst {
+    int S, nFreq, NYP, NZP, ny, nz, twist, stallIt;
+    long vstride;
+    int G, GZ, slots;          // workgroups per system (GZ row blocks x column parts), row blocks, system slots per XCD
+    int C0, TW, PLW;           // column parts: first column of part 1; tile width (own + halo columns); width of the forward transform's operand planes
+    int syncWords;             // words of `sync` (+ exitCnt, fail behind it): zeroed by the last workgroup to leave
+    float wJ;                  // damping of the Jacobi sweeps (the factor k_coef_all folds into Solver::dinv)
+    const double *omega, *ofz, *dM, *cY, *cZ;
+    const float4* cf32;
+    int *active, *iters, *status, *nactive, *nactHost, *failHost, *stallHost, *progHost;
+    double* errEst;
+    long long* ticks;
     unsigned* sync;            // [groups][32] per group: [0] barrier counter, [1] arrivals of the placement check, [2] OR of 1 << XCC_ID
     unsigned* exitCnt;         // workgroups that have left the kernel
     int* fail;                 // device word: 1 = a group's workgroups are not on one XCD, 2 = a wait timed out
     int* placeHost;            // pinned host word: set when a group's workgroups are not on one XCD (the host then runs the launch-per-phase loop)
-    int G, slots, maxit, precondOnly;
-    float wJ;                  // damping of the Jacobi sweeps (the factor k_coef_all folds into Solver::dinv)
     const u4v *Vb, *Vtb;       // bf16 fragment-order copies of V, V'
-    double* partZZ;            // [S][MAXNB]
-    float2 *pubR, *pubZ, *pubP;   // [S][vstride] complex64: r', the pre-smoothed iterate (z2; one sweep: z1), p of the own rows
-    float2* yhat;              // [S][vstride] complex64 rows of the forward transform
+    float2 *pubR, *pubZ, *pubP;   // [S][vstride] complex64: r', the pre-smoothed iterate (z2; one sweep: z1), p of the own nodes
+    float2 *yhat, *yhat2;      // [S][vstride] complex64 rows of the forward transform (column parts: one partial product per part)
     float2* ysol;              // [S][vstride] solved slabs, pre-split bf16 planes (store_t32's format)
+    float2* tbuf;              // [S][vstride] complex64: t of the own nodes across the FDM stage (two sweeps: the rho identity)
     const float2* ip32;        // inverse pivots (complex64)
     u4v* rec;                  // [S][MAXNB][2][8] 16-byte granules {value, tag} / {tag, value}: the partial sums of the two reductions of an iteration
-    unsigned long long tagBase; // ... their tags are tagBase + 2 * iteration (+ 1): unique over the launches of a context, the records are never cleared
-    float2* tbuf;              // [S][vstride] complex64: t of the own rows across the FDM stage (two sweeps: the rho identity)
+};
+typedef const __attribute__((address_space(4))) PsConst* PsKP;
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T* ps_c4(const T* p) { return (const __attribute__((address_space(4))) T*)p; }   // arrays no kernel of the launch writes: scalar loads
+
+// What changes from launch to launch: the kernel's only argument (88 bytes).
+struct PsLaunch {
+    const PsConst* kc;
+    cplx *x, *r;               // the solve's iterate and residual [S][vstride]
+    double tol2;
+    unsigned long long tagBase; // tags of the reductions' records: tagBase + 2 * iteration (+ 1): unique over the launches of a context, the records are never cleared
     float2* zout;              // precondOnly: z = P^-1 r
-    long long* stamps;         // [workgroup][16] s_memtime stamps of one iteration's phases (HMCMT_STAMPS=persist)
-    int tickId;                // HMCMT_TICKS: TK_PERSIST_F / TK_PERSIST_A
-    int syncWords;             // words of `sync` (+ exitCnt, fail behind it): zeroed by the last workgroup to leave
     int* gateOut;              // device word for the kernels queued behind this launch (View::gate): gateGen if every system ended
+    unsigned long long* cntActive;   // non-null in an evaluation sampled by hmcmt_profile: += iterations x systems
+    long long* stamps;         // [workgroup][16] wall-clock stamps of one iteration's phases (HMCMT_STAMPS=persist)
+    float w2;                  // two sweeps: damping of the inner sweeps relative to the outer ones
+    int maxit, precondOnly;
     int gateGen;               //   converged and without a failure, -gateGen otherwise -- written by the last workgroup to leave
+    int tickId;                // HMCMT_TICKS: TK_PERSIST_F / TK_PERSIST_A
+    int dbgPlace;              // test hook: 1 + index of a group that is to FAIL its placement check (hmcmt_debug_flags)
 };
 
 __device__ __forceinline__ unsigned ps_xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 0xf; }
@@ -80,7 +118,7 @@ __device__ __forceinline__ bool ps_wait(unsigned* cnt, unsigned target, int* fai
         if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
         __builtin_amdgcn_s_sleep(1);
         if ((spins & 0x3ff) == 0x3ff) {
-            if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2) return false;      // (1 = ANOTHER group was misplaced: its systems are untouched, this one finishes its own)
             if (spins > PS_SPIN_LIMIT) { __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
         }
     }
@@ -146,7 +184,7 @@ __device__ __forceinline__ bool ps_collect(const u4v* recSys, int which, int G, 
         }
         __builtin_amdgcn_s_sleep(1);
         if ((spins & 0x3ff) == 0x3ff) {
-            if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2) return false;      // (1 = ANOTHER group was misplaced: its systems are untouched, this one finishes its own)
             if (spins > PS_SPIN_LIMIT) { if (lane == 0) __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
         }
     }
@@ -288,11 +326,11 @@ __host__ __device__ inline int ps_tab_floats(int NZP, int nz, int twist) {
     return (twist ? 2 : 1) * ((twist ? mid + 1 : NZP) + PSL_PAD);
 }
 template <int NT>
-__device__ __forceinline__ void ps_slab_tables(const Solver& k, int mode, float* f1, float* f2, int tidx) {
-    const int NZP = k.NZP, n = k.nz - 1;
-    const int tw = k.twist, mid = twist_mid(n, tw);
+__device__ __forceinline__ void ps_slab_tables(PsKP kb, int mode, float* f1, float* f2, int tidx) {
+    const int NZP = kb->NZP, n = kb->nz - 1;
+    const int tw = kb->twist, mid = twist_mid(n, tw);
     const int RCAP = tw ? mid + 1 : NZP, RL = RCAP + PSL_PAD, nreg = tw ? 2 : 1;
-    const double* ofz = k.ofz + (long)mode * NZP;
+    const double* ofz = kb->ofz + (long)mode * NZP;
     for (int i = tidx; i < nreg * RL; i += NT) {
         const int reg = i / RL, rl = i - reg * RL;
         const int row = (tw && reg == 1) ? n + 1 - rl : rl;
@@ -306,42 +344,45 @@ __device__ __forceinline__ void ps_slab_tables(const Solver& k, int mode, float*
         f1[i] = v1; f2[i] = v2;
     }
 }
-template <int NT, int MW>
-__device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, const float* f1, const float* f2, int s, int slab, const float2* __restrict__ yhat,
-                                              float2* __restrict__ ysol, const float2* __restrict__ ip32, int tidx, long long* stp = nullptr) {
+// (CS: column parts -- the slab's rows are the SUM of the parts' partial products yhat + yhat2)
+template <int NT, int MW, int CS>
+__device__ __forceinline__ void ps_slab_solve(PsKP kb, char* smem, const float* f1, const float* f2, int s, int slab, int tidx, long long* stp = nullptr) {
     // (tidx: the caller's OPAQUE copy of tidx -- everything derived from the thread index here is invariant across the
     //  iterations of the solve, and the compiler hoisted all of it out of the iteration loop into registers it then spilled)
-    constexpr int SW = MW;                              // modes per slab (32, or 16: tall meshes)
-    const int NYP = k.NYP, NZP = k.NZP, n = k.nz - 1;
-    const int tw = k.twist, mid = twist_mid(n, tw);
+    constexpr int SW = MW;                              // modes per slab (32, or 16: tall meshes, column parts)
+    const int NYP = kb->NYP, NZP = kb->NZP, n = kb->nz - 1, nyi = kb->ny - 1;
+    const int tw = kb->twist, mid = twist_mid(n, tw);
     const int RCAP = tw ? mid + 1 : NZP, RL = RCAP + PSL_PAD, nreg = tw ? 2 : 1;
     c32* sj = reinterpret_cast<c32*>(smem + (((long)NZP * 4 + 127) & ~127L) + (long)2 * nreg * RL * 4);
     c32* sa = sj + SW + 2 * FW_TB * SW;                  // -> region 0, row 0
     c32* sp = sa + (long)nreg * RL * SW;                 // inverse pivots, same layout
     auto lidx = [&](int row) { return (tw && row > mid) ? RL + (n + 1 - row) : row; };   // slab row of a matrix row
-    const long so = (long)s * k.vstride;
+    const long vs = kb->vstride, so = (long)s * vs;
+    const float2* ip32 = kb->ip32 + so;
     const int cb = slab * SW;                           // first mode of the slab
     const int lane = tidx & 63, wave = tidx >> 6;
     // join factor 1 / (1 - c c') of the two halves (item_pivot): requested with the slab's rows, not behind them
     const int cj = cb + (tidx & (SW - 1));
-    const float2 jfl = *ps_at(ip32 + so, (unsigned)min(cj, NYP - 1));
+    const float2 jfl = *ps_at(ip32, (unsigned)min(cj, NYP - 1));
     // rows of the slab: a = y * ip, and ip -- two modes (16 bytes) per load, one batch
     {
-        constexpr int PB = 4, HW = SW / 2;          // (108 rows x 16 mode pairs over 512 threads: 3.4 pairs per thread)
-        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(yhat + so), 0, (int)(k.vstride * 8), 0x00020000);
+        constexpr int PB = 4, HW = SW / 2;        // (108 rows x 16 mode pairs over 512 threads: 3.4 pairs per thread)
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(kb->yhat + so), 0, (int)(vs * 8), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>((CS == 1 ? kb->yhat : kb->yhat2) + so), 0, (int)(vs * 8), 0x00020000);
         for (int b0 = 0; b0 < NZP * HW; b0 += PB * NT) {
             const int i0 = b0 + tidx;
-            f4v yv[PB], ipf[PB];
+            f4v yv[PB], yw[PB], ipf[PB];
             bool ok0[PB], ok1[PB];
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
                 const int idx = min(i0 + u * NT, NZP * HW - 1);
                 const int row = idx / HW, c = cb + 2 * (idx % HW);
                 const bool rok = row >= 1 && row <= n;
-                ok0[u] = rok && c < k.ny - 1; ok1[u] = rok && c + 1 < k.ny - 1;
+                ok0[u] = rok && c < nyi; ok1[u] = rok && c + 1 < nyi;
                 const unsigned e = (unsigned)((rok ? row : 1) * NYP + min(c, NYP - 2));
                 yv[u] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(ry, e * 8u, 0, 16));
-                ipf[u] = *reinterpret_cast<const f4v*>(ps_at(ip32 + so, e));
+                if (CS > 1) yw[u] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(ry2, e * 8u, 0, 16));
+                ipf[u] = *reinterpret_cast<const f4v*>(ps_at(ip32, e));
             }
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
@@ -349,6 +390,7 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, const
                 if (idx < NZP * HW) {
                     const int row = idx / HW, j = 2 * (idx % HW);
                     const int l = lidx(row) * SW + j;
+                    if (CS > 1) yv[u] = yv[u] + yw[u];
                     c32 a0 = c32{0, 0}, p0 = c32{0, 0}, a1 = c32{0, 0}, p1 = c32{0, 0};
                     if (ok0[u]) { p0 = c32{ipf[u][0], ipf[u][1]}; a0 = c32{yv[u][0], yv[u][1]} * p0; }
                     if (ok1[u]) { p1 = c32{ipf[u][2], ipf[u][3]}; a1 = c32{yv[u][2], yv[u][3]} * p1; }
@@ -366,10 +408,10 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, const
         sa[front] = z; sp[front] = z;
         sa[back] = z; sp[back] = c32{-1.f, 0.f};
     }
-    if (tidx < SW) sj[tidx] = (tw && cj < k.ny - 1) ? c32{jfl.x, jfl.y} : c32{1.f, 0.f};
+    if (tidx < SW) sj[tidx] = (tw && cj < nyi) ? c32{jfl.x, jfl.y} : c32{1.f, 0.f};
     __syncthreads();
     if (stp) stp[12] = wall_clock64();
-    if (wave == 0 && lane < nreg * SW && cb + (lane % SW) < k.ny - 1) {
+    if (wave == 0 && lane < nreg * SW && cb + (lane % SW) < nyi) {
         const int half = lane / SW, col = lane % SW;
         const int last = tw ? (half == 0 ? mid : n - mid) : n;      // rows 1..last of this lane's region are real
         const int steps = tw ? mid : n;                             // both halves run the longer count (identity rows)
@@ -397,7 +439,7 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, const
     // solved slab -> ysol, pre-split for the back transform (store_t32's format), 16-byte stores
     {
         constexpr int NG = SW / 8;
-        unsigned short* yb = reinterpret_cast<unsigned short*>(ysol + so);
+        unsigned short* yb = reinterpret_cast<unsigned short*>(kb->ysol + so);
         for (int idx = tidx; idx < NZP * NG; idx += NT) {
             const int row = idx / NG, j0 = (idx % NG) * 8, c0 = cb + j0;
             if (c0 >= NYP) continue;
@@ -419,50 +461,68 @@ __device__ __forceinline__ void ps_slab_solve(const Solver& k, char* smem, const
     __syncthreads();
 }
 
-// LDS of the persistent kernel: 1 KB of scratch | the region the phases share (two tiles [24][NYP] complex64 -- the first one
-// doubles as the bf16 planes of the transforms' operands --, each followed by 4 rows more so that q's 14 fp64 rows fit the
-// tile that is free when q is formed; or the slabs of the tridiagonal
-// solves) | the three coefficient planes
-__host__ __device__ inline size_t ps_tile_bytes(int NYP) { return (((size_t)PS_ROWS * NYP * 8 + 64 + 255) & ~(size_t)255) + (size_t)4 * NYP * 8; }   // tile (+ 64 B over-read pad) + tail
-__host__ __device__ inline size_t ps_shared_bytes(int NYP, int NZP, int nz, int twist, int mw = 32) {
-    const size_t a = 2 * ps_tile_bytes(NYP), b = ps_slab_bytes(NZP, nz, twist, mw);
-    return ((a > b ? a : b) + 255) & ~(size_t)255;
+// LDS of the persistent kernel: 1 KB of scratch | the region the phases share (two tiles [24][TW] complex64 -- the first one
+// doubles as the bf16 planes of the forward transform's operand --, each followed by 4 rows more so that q's 14 fp64 rows fit the
+// tile that is free when q is formed; or the slabs of the tridiagonal solves; or, column parts, the back transform's operand
+// planes [24][4][NYP] bf16: all modes of the tile's rows) | the three coefficient planes [24][TW] | the slab sweeps' row scalars.
+// TW = NYP without column parts.
+__host__ __device__ inline size_t ps_tile_bytes(int TW) { return (((size_t)PS_ROWS * TW * 8 + 64 + 255) & ~(size_t)255) + (size_t)4 * TW * 8; }   // tile (+ 64 B over-read pad) + tail
+__host__ __device__ inline size_t ps_shared_bytes(int TW, int NYP, int NZP, int nz, int twist, int mw = 32) {
+    const size_t a = 2 * ps_tile_bytes(TW), b = ps_slab_bytes(NZP, nz, twist, mw), c = TW == NYP ? 0 : (size_t)PS_ROWS * 4 * NYP * 2 + 64;
+    const size_t m = a > b ? (a > c ? a : c) : (b > c ? b : c);
+    return (m + 255) & ~(size_t)255;
 }
-__host__ __device__ inline size_t ps_lds_bytes(int NYP, int NZP, int nz, int twist, int mw = 32) {
-    return 1024 + ps_shared_bytes(NYP, NZP, nz, twist, mw) + (size_t)3 * PS_ROWS * NYP * 4 + 64 + (((size_t)2 * ps_tab_floats(NZP, nz, twist) * 4 + 128 + 63) & ~(size_t)63);
+__host__ __device__ inline size_t ps_lds_bytes(int TW, int NYP, int NZP, int nz, int twist, int mw = 32) {
+    return 1024 + ps_shared_bytes(TW, NYP, NZP, nz, twist, mw) + (size_t)3 * PS_ROWS * TW * 4 + 64 + (((size_t)2 * ps_tab_floats(NZP, nz, twist) * 4 + 128 + 63) & ~(size_t)63);
+}
+// column parts (CS = 2): part 0 owns the columns [0, C0), part 1 [C0, NYP); a tile = own columns + PS_HC halo columns
+__host__ __device__ inline int ps_split_col(int NYP) { return 16 * ((NYP + 31) / 32); }
+__host__ __device__ inline int ps_tile_width(int NYP, int cs) { if (cs == 1) return NYP; const int c0 = ps_split_col(NYP); return (c0 > NYP - c0 ? c0 : NYP - c0) + PS_HC; }
+// ... width of the forward transform's operand planes: whole K-groups of 32 columns covering a part's own columns
+__host__ __device__ inline int ps_plane_width(int NYP) {
+    const int c0 = ps_split_col(NYP), k0 = (c0 + 31) / 32, k1 = (NYP + 31) / 32 - c0 / 32;
+    return 32 * (k0 > k1 ? k0 : k1);
 }
 
-#define PS_STAMP(i) if (stampNow) a.stamps[(long)blockIdx.x * 16 + (i)] = wall_clock64();
+#define PS_STAMP(i) if (stampNow) L.stamps[(long)blockIdx.x * 16 + (i)] = wall_clock64();
 
-template <int CW, int SW, int MW = 32>
-__global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a) {
+template <int CW, int SW, int MW = 32, int CS = 1>
+__global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
     constexpr int NT = 2 * CW, NWV = NT / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sh = reinterpret_cast<double*>(smem);                           // [2][32] block reductions (ps_block_sum4), [64..70) the reductions' totals
     volatile int* sflag = reinterpret_cast<volatile int*>(smem + 640);      // [0] give up, [1] this is the last workgroup to leave, [2] its OR of the systems' states
     int shFlip = 0;
     char* arena = smem + 1024;
+    const PsKP kb0 = (PsKP)L.kc;       // (never laundered: uniform everywhere; the phases work on fresh opaque copies of it)
+    PsKP kb = kb0;
     const int tid = threadIdx.x, lane = tid & 63;
     int tidv = tid, lanev = lane, ljv = lane & 15, g4v = lane >> 4, iyv = tid & (CW - 1);      // opaque copies for the iteration loop (PS_PHASE)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int G = a.G;
-    const int xcd = blockIdx.x & 7, lq = blockIdx.x >> 3, slot = lq / G, jwg = lq - slot * G;
-    unsigned* sy = a.sync + 32 * (xcd * a.slots + slot);
+    const int G = kb->G;
+    const int xcd = blockIdx.x & 7, lq = blockIdx.x >> 3, slot = lq / G, jw = lq - slot * G;
+    const int jwg = CS == 1 ? jw : (jw >> 1);           // row block
+    const int hp = CS == 1 ? 0 : (jw & 1);              // column part
+    const int slots = kb->slots;
+    unsigned* sy = kb->sync + 32 * (xcd * slots + slot);
     unsigned epoch = 0;                 // synchronisations of this group so far (the same in all its threads)
     int it = 0;
     if (tid == 0) sflag[0] = 0;
-    tick_begin(k.ticks, a.tickId);
+    tick_begin(kb->ticks, L.tickId);
     __syncthreads();
     // ---- placement check: the G workgroups of the group must share an XCD (their hand-offs go through ITS L2)
     if (tid == 0) {
-        __hip_atomic_fetch_or(sy + 2, 1u << ps_xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned forced = L.dbgPlace == 1 + xcd * slots + slot ? 1u << 31 : 0u;      // (test hook: this group fails)
+        __hip_atomic_fetch_or(sy + 2, (1u << ps_xcc_id()) | forced, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(sy + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!ps_wait(sy + 1, (unsigned)G, a.fail)) sflag[0] = 2;
+        if (!ps_wait(sy + 1, (unsigned)G, kb->fail)) sflag[0] = 2;
         else if (__popc(__hip_atomic_load(sy + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 1) {
+            // (every workgroup of the group reads the same word behind the same arrivals: they all leave, their systems untouched
+            //  and still active; the other groups finish theirs -- ps_wait / ps_collect give up on a TIMED-OUT wait only)
             sflag[0] = 1;
-            __hip_atomic_store(a.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *a.placeHost = 1;
+            __hip_atomic_store(kb->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *kb->placeHost = 1;
         }
     }
     __syncthreads();
@@ -474,7 +534,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
     };
     auto sys_wait = [&]() -> bool {     // all threads
         ++epoch;
-        if (tid == 0 && !ps_wait(sy, (unsigned)G * epoch, a.fail)) sflag[0] = 2;
+        if (tid == 0 && !ps_wait(sy, (unsigned)G * epoch, kb->fail)) sflag[0] = 2;
         __syncthreads();
         return sflag[0] == 0;
     };
@@ -485,51 +545,71 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
         return sys_wait();
     };
 
-    // ---- geometry of this thread: column iy of tile rows j = 0..11; half c = 1 is MIRRORED (j = 0 is the outermost halo
-    // row of either half, j >= 5 are own rows, j = 11 borders the other half)
+    // ---- geometry of this thread: LOCAL column iy of tile rows j = 0..11; half c = 1 is MIRRORED (j = 0 is the outermost halo
+    // row of either half, j >= 5 are own rows, j = 11 borders the other half).  Column parts: local column iy is mesh column
+    // cbase + iy; the part owns [ownLo, ownHi), the rest of its tile are halo columns (copies, like the halo rows)
     const int c = __builtin_amdgcn_readfirstlane(tid / CW);
     const int iy = tid & (CW - 1);
-    const int NYP = k.NYP, ny = k.ny, nz = k.nz;
-    const bool colOK = iy < NYP;
-    const int iyc = min(iy, NYP - 1);
+    const int NYP = kb->NYP, ny = kb->ny, nz = kb->nz;
+    const int TWc = CS == 1 ? NYP : kb->TW;                             // the wider part's tile: the LDS carve
+    const int C0 = CS == 1 ? NYP : kb->C0;
+    const int cbase = (CS > 1 && hp) ? C0 - PS_HC : 0;
+    const int LWh = CS == 1 ? NYP : (hp ? NYP - C0 + PS_HC : C0 + PS_HC);      // width of this part's tile
+    const int TW = LWh;                                                 // ... and its row stride in LDS: column LWh - 1's east neighbour is the next row's
+                                                                        // column 0 (a boundary / halo value), never a word nothing has written
+    const int ownLo = (CS > 1 && hp) ? C0 : 0, ownW = CS == 1 ? NYP : (hp ? NYP - C0 : C0);
+    const bool colOK = iy < LWh;
+    const int gy = cbase + iy;                                          // mesh column
+    const int gyc = min(gy, NYP - 1);
     const int iz0 = 1 + PS_OWN * jwg, R0 = iz0 - PS_HALO;
     const int gb = c ? R0 + PS_ROWS - 1 : R0, gs = c ? -1 : 1;          // mesh row of thread-row j: gb + gs * j
     const int tb = c ? PS_ROWS - 1 : 0;                                 // tile row of thread-row j: tb + gs * j
-    const int tin = c ? PS_J - 1 : PS_J;                                // tile row of the inner neighbour of j = 11
-    unsigned inM = 0;                                                   // bit j: node (row j, iy) is an interior node of the mesh
+    unsigned inM = 0;                                                   // bit j: node (row j, gy) is an interior node of the mesh
 #pragma unroll
     for (int j = 0; j < PS_J; ++j) {
         const int g = gb + gs * j;
-        if (g >= 1 && g <= nz - 1 && iy >= 1 && iy <= ny - 1) inM |= 1u << j;
+        if (g >= 1 && g <= nz - 1 && gy >= 1 && gy <= ny - 1) inM |= 1u << j;
     }
     auto isIn = [&](int j) { return (inM >> j) & 1u; };
     // ... as a factor 0 / 1: the rows are computed without branches -- non-interior nodes have harmless coefficients in the planes
     // (mass 1: no division by zero) and their results are multiplied away.  (One `if (interior)` per row and pass made the
     // compiler keep twelve 64-bit lane masks in scalar registers, spill them, and branch around every row.)
     auto mk = [&](int j) -> float { return (float)((inM >> j) & 1u); };
-    // element offset of (row j, iy) in a system's [NZP][NYP] arrays: ONE 32-bit lane offset serves every array (uniform base
+    // this thread's column is one the part OWNS (publishes, updates x, counts in the sums); without column parts: any column of the tile
+    auto own = [&]() -> bool { return CS == 1 ? iyv < LWh : (unsigned)(cbase + iyv - ownLo) < (unsigned)ownW; };
+    // element offset of (row j, gy) in a system's [NZP][NYP] arrays: ONE 32-bit lane offset serves every array (uniform base
     // pointer + offset: 64-bit per-row addresses of a dozen arrays were what the register allocator spilled).  eo: the node itself
     // (valid where the row is in the mesh), ei: the node if it is an interior one, else a harmless interior node (unconditional loads)
-    int e0 = gb * NYP + iy;
+    int e0 = gb * NYP + gy;
     const int es = gs * NYP;
     auto eo = [&](int j) -> unsigned { return (unsigned)(e0 + j * es); };
     auto ei = [&](int j) -> unsigned { return isIn(j) ? (unsigned)(e0 + j * es) : (unsigned)(NYP + 1); };
-    int t0i = tb * NYP + iy, tini = tin * NYP + iy;                     // the same for the tiles in LDS: t0i + j * es; inner neighbour of j = 11
+    int t0i = tb * TW + iy;                                             // the same for the tiles in LDS: t0i + j * ts
+    const int ts = gs * TW;
     // LDS carve (ps_lds_bytes)
-    const size_t tileB = ps_tile_bytes(NYP);
+    const size_t tileB = ps_tile_bytes(TWc);
     c32* T0 = reinterpret_cast<c32*>(arena);
     c32* T1 = reinterpret_cast<c32*>(arena + tileB);
-    unsigned short* PL = reinterpret_cast<unsigned short*>(arena);       // planes [24][4][NYP] bf16 (+ 64 B the last k-group over-reads): the first tile's space
-    float* coE = reinterpret_cast<float*>(arena + ps_shared_bytes(NYP, k.NZP, nz, k.twist, MW));
-    const PsPl co{coE, coE + PS_ROWS * NYP, coE + 2 * PS_ROWS * NYP};
-    float* const tabF1 = coE + 3 * PS_ROWS * NYP + 16;                     // row scalars of the slab sweeps (ps_slab_tables), per system
-    float* const tabF2 = tabF1 + ps_tab_floats(k.NZP, nz, k.twist);
-    // MFMA work split: column tiles of 16 over the waves, at most two per wave (NYP <= 32 NWV)
+    unsigned short* PL = reinterpret_cast<unsigned short*>(arena);       // bf16 operand planes of the transforms: the tiles' space
+    float* coE = reinterpret_cast<float*>(arena + ps_shared_bytes(TWc, NYP, kb->NZP, nz, kb->twist, MW));
+    const PsPl co{coE, coE + PS_ROWS * TWc, coE + 2 * PS_ROWS * TWc};
+    float* const tabF1 = coE + 3 * PS_ROWS * TWc + 16;                      // row scalars of the slab sweeps (ps_slab_tables), per system
+    float* const tabF2 = tabF1 + ps_tab_floats(kb->NZP, nz, kb->twist);
+    // MFMA work split.  NTc: column tiles of 16 of a whole row (modes / mesh columns), KG: K-groups of 32 of a whole row.
+    //   without column parts: both transforms produce NTc tiles, at most two per wave (NYP <= 32 NWV);
+    //   column parts: the forward transform produces ALL NTc mode tiles from the part's own columns (at most four per wave, two
+    //   passes; K-groups kg0 .. kg0 + KGF - 1), the back transform the tiles tB0 .. tB0 + NTb - 1 that cover the part's tile
+    //   (at most two per wave) from all KG K-groups (two chunks of eight).
     const int NTc = NYP >> 4, KG = (NYP + 31) >> 5;
-    const int tbase = NTc / NWV, textra = NTc - tbase * NWV;
-    const int ntl = tbase + (wave < textra ? 1 : 0), t0w = wave * tbase + min(wave, textra);
+    const int tB0 = cbase >> 4, NTb = CS == 1 ? NTc : ((cbase + LWh + 15) >> 4) - tB0;
+    const int tbase = NTb / NWV, textra = NTb - tbase * NWV;
+    const int ntl = tbase + (wave < textra ? 1 : 0), t0w = tB0 + wave * tbase + min(wave, textra);
     const int tl0 = min(t0w, NTc - 1), tl1 = min(t0w + 1, NTc - 1);
-    const int lj = lane & 15, g4 = lane >> 4;
+    const int tbaseF = NTc / NWV, textraF = NTc - tbaseF * NWV;
+    const int ntlF = CS == 1 ? ntl : tbaseF + (wave < textraF ? 1 : 0), t0wF = CS == 1 ? t0w : wave * tbaseF + min(wave, textraF);
+    const int kg0 = (CS > 1 && hp) ? (C0 >> 5) : 0;
+    const int KGF = CS == 1 ? KG : (hp ? KG - kg0 : (C0 + 31) >> 5);
+    const int PLW = CS == 1 ? NYP : kb->PLW;                            // width of the forward transform's operand planes
     const int nslab = (NYP + MW - 1) / MW;
 
     for (int round = 0; alive; ++round) {
@@ -537,23 +617,30 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
         //  would hold the fp64 stencil coefficients of one polarisation instead of two -- leave the iteration at 42 us and cost the
         //  headline chain 3 %: the slow systems of a solve are neighbours in frequency and then share an L2 to the end, while
         //  here they are spread over the XCDs, each running alone at 39 us per iteration once its neighbours are done.)
-        const int s = xcd + 8 * (slot + a.slots * round);
-        if (s >= k.S) break;
-        if (!k.active[s]) continue;
-        const int mode = s >= k.nFreq;
-        const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
-        const double w = k.omega[s];
+        const int s = xcd + 8 * (slot + slots * round);
+        if (s >= kb->S) break;
+        if (!kb->active[s]) continue;
+        const int mode = s >= kb->nFreq;
+        const double w = ps_c4(kb->omega)[s];
         const float wf = (float)w;
-        float2 *pubR = a.pubR + so, *pubZ = a.pubZ + so, *pubP = a.pubP + so;
-        cplx *rsys = k.r + so, *xsys = k.x + so;
+        // per-system bases, re-derived where they are used (kb is laundered per phase: none of this lives across the solve)
+        auto so = [&]() -> long { return (long)s * kb->vstride; };
+        auto mo = [&]() -> long { return (long)mode * kb->vstride; };
+        auto pubR = [&]() -> float2* { return kb->pubR + so(); };
+        auto pubZ = [&]() -> float2* { return kb->pubZ + so(); };
+        auto pubP = [&]() -> float2* { return kb->pubP + so(); };
+        auto tbuf = [&]() -> float2* { return kb->tbuf + so(); };      // t of the own rows (complex64): the rho identity of the two-sweep smoother needs it behind the FDM stage
+        auto xsys = [&]() -> cplx* { return L.x + so(); };
+        auto rsys = [&]() -> cplx* { return L.r + so(); };
+        auto recS = [&]() -> u4v* { return kb->rec + (long)s * MAXNB * 2 * 8; };
         // ---- coefficients of the tile -> the planes in LDS (the previous system's last reads lie in front of a barrier)
         {
-            const float4* cf = k.cf32 + 2 * mo;
+            const float4* cf = kb->cf32 + 2 * mo();
             float vin[PS_J + 1], vout[PS_J + 1], fe[PS_J], fw[PS_J], fm[PS_J];
 #pragma unroll
             for (int j = 0; j <= PS_J; ++j) {
                 const int g = gb + gs * j, gc = min(max(g, 0), nz);
-                const unsigned e = (unsigned)(gc * NYP + iyc);
+                const unsigned e = (unsigned)(gc * NYP + gyc);
                 const float4 ca = cf[2u * e], cb = cf[2u * e + 1u];
                 const bool rowIn = g >= 0 && g <= nz;
                 if (j < PS_J) { fe[j] = rowIn ? ca.z : 0.f; fw[j] = rowIn ? ca.w : 0.f; fm[j] = rowIn ? wf * ca.y : 0.f; }
@@ -563,33 +650,34 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             float* pe = const_cast<float*>(co.E); float* pm = const_cast<float*>(co.M); float* pv = const_cast<float*>(co.V);
 #pragma unroll
             for (int j = 0; j < PS_J; ++j) {
-                const int ti = t0i + j * es;
+                const int ti = t0i + j * ts;
                 if (colOK) {
-                    if (iy >= 1) pe[ti] = fe[j];
-                    if (iy == 1) pe[ti - 1] = fw[j];                       // column 0: the coupling of column 1 to the boundary
+                    if (gy >= 1) pe[ti] = fe[j];
+                    if (gy == 1) pe[ti - 1] = fw[j];                       // column 0: the coupling of column 1 to the boundary
                     pm[ti] = (fe[j] != 0.f || fw[j] != 0.f) ? fm[j] : 1.f;   // (non-interior nodes: zero couplings, mass 1)
                     pv[ti] = vin[j] != 0.f ? vin[j] : vout[j + 1];
                 }
             }
         }
-        ps_slab_tables<NT>(k, mode, tabF1, tabF2, tid);
-        // ---- state: r of the own rows (fp64), r of the halo rows (complex64, refreshed from the owners every iteration)
+        ps_slab_tables<NT>(kb, mode, tabF1, tabF2, tid);
+        // ---- state: r of the thread's rows j >= 5 (fp64: the OWNED nodes' residual lives here for the whole solve; a halo column's
+        // is a copy, refreshed from the owners like the halo rows'), r of the halo rows (complex64, refreshed every iteration)
         cplx r64[PS_NO];
         c32 rh[PS_HALO];
 #pragma unroll
         for (int q = 0; q < PS_NO; ++q) {
             const int j = PS_HALO + q, g = gb + gs * j;
-            r64[q] = *ps_at(rsys, ei(j));
+            r64[q] = *ps_at(rsys(), ei(j));
             r64[q] = (double)mk(j) * r64[q];
-            if (colOK && g >= 1 && g <= nz - 1) {
-                *ps_at(pubR, eo(j)) = float2{(float)r64[q].re, (float)r64[q].im};
-                *ps_at(pubP, eo(j)) = float2{0.f, 0.f};
+            if (own() && g >= 1 && g <= nz - 1) {
+                *ps_at(pubR(), eo(j)) = float2{(float)r64[q].re, (float)r64[q].im};
+                *ps_at(pubP(), eo(j)) = float2{0.f, 0.f};
             }
         }
         if (!sys_sync()) { alive = false; break; }
 #pragma unroll
         for (int j = 0; j < PS_HALO; ++j) {
-            rh[j] = ps_ld_c32(ps_at(pubR, ei(j)));
+            rh[j] = ps_ld_c32(ps_at(pubR(), ei(j)));
             rh[j] = mk(j) * rh[j];
         }
         auto rr = [&](int j) -> c32 { return j < PS_HALO ? rh[j < PS_HALO ? j : 0] : c32{(float)r64[j >= PS_HALO ? j - PS_HALO : 0].re, (float)r64[j >= PS_HALO ? j - PS_HALO : 0].im}; };
@@ -600,53 +688,23 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
         bool stalled = false;
         int st = 0;
         double est = 0.0;
-        float2* tbuf = a.tbuf + so;            // t of the own rows (complex64): the rho identity of the two-sweep smoother needs it behind the FDM stage
         it = 0;
-#define PS_PHASE() asm volatile("" : "+v"(e0), "+v"(t0i), "+v"(inM), "+v"(tidv), "+v"(lanev), "+v"(ljv), "+v"(g4v), "+v"(iyv))   /* row offsets / masks are re-derived per PHASE instead of living in registers across all of them */
+#define PS_PHASE() kb = kb0; asm volatile("" : "+v"(e0), "+v"(t0i), "+v"(inM), "+v"(tidv), "+v"(lanev), "+v"(ljv), "+v"(g4v), "+v"(iyv), "+s"(kb))   /* row offsets / masks / the state block's scalars are re-derived per PHASE instead of living in registers across all of them */
         for (;;) {
             PS_PHASE();
-            const bool stampNow = a.stamps && tid == 0 && it == 2;
-#ifdef HMCMT_PS_DBGX
-            bool dbgFail = false;
-            auto dbg_cmp = [&](const c32* TT, int stage, int jlo) {       // own rows of a tile -> memory; the halo rows' copies against the owners'
-                __syncthreads();
-                const int tw0 = ps_opq(t0i);
-#pragma unroll
-                for (int q = 0; q < PS_NO; ++q) {
-                    const int j = PS_HALO + q, g = gb + gs * j;
-                    if ((iyv < NYP) && g >= 1 && g <= nz - 1) *ps_at(a.yhat + so, eo(j)) = float2{TT[tw0 + j * es].re, TT[tw0 + j * es].im};
-                }
-                if (!sys_sync()) { dbgFail = true; return; }
-#pragma unroll
-                for (int j = 0; j < PS_HALO; ++j) {
-                    if (j < jlo) continue;
-                    const c32 ov = mk(j) * ps_ld_c32(ps_at(a.yhat + so, ei(j)));
-                    const c32 mine = TT[tw0 + j * es];
-                    if ((iyv < NYP) && (ov.re != mine.re || ov.im != mine.im)) {
-                        atomicAdd((unsigned long long*)(a.stamps + 16 * 254 + stage * 5 + j), 1ull);
-                        if (stage == 1 && atomicAdd((unsigned long long*)(a.stamps + 16 * 253), 1ull) == 0ull) {     // one example
-                            double* ex = reinterpret_cast<double*>(a.stamps + 16 * 252);
-                            ex[0] = gb + gs * j; ex[1] = iyv; ex[2] = j; ex[3] = c; ex[4] = ov.re; ex[5] = mine.re; ex[6] = ov.im; ex[7] = mine.im;
-                            ex[8] = rr(j).re; ex[9] = jwg; ex[10] = s; ex[11] = it;
-                            const c32 rp = ps_ld_c32(ps_at(pubR, ei(j)));
-                            ex[12] = rp.re; ex[13] = rr(j).im; ex[14] = rp.im;
-                        }
-                    }
-                }
-                if (!sys_sync()) { dbgFail = true; return; }
-            };
-#endif
-            // the wave's V fragments of the forward transform (constant; KG <= 8 k-groups x 2 column tiles): requested here, they
+            const bool stampNow = L.stamps && tid == 0 && it == 2;
+            // the wave's V fragments of the forward transform (constant; KGF <= 8 k-groups x 2 column tiles): requested here, they
             // arrive under the pre-smoother (every phase of this loop is a memory round trip + a little arithmetic: what can be
             // requested a phase early, is)
             u4v bfw[8][2];
             {
                 const int lo = lanev;           // (an opaque offset: the loads stay in the iteration instead of being hoisted out of the solve and spilled)
+                const int ta = CS == 1 ? tl0 : min(t0wF, NTc - 1), tc = CS == 1 ? tl1 : min(t0wF + 1, NTc - 1);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const int kg = min(q, KG - 1);
-                    bfw[q][0] = *ps_at(a.Vb, (unsigned)((kg * NTc + tl0) * 64 + lo));
-                    bfw[q][1] = *ps_at(a.Vb, (unsigned)((kg * NTc + tl1) * 64 + lo));
+                    const int kg = kg0 + min(q, KGF - 1);
+                    bfw[q][0] = *ps_at(kb->Vb, (unsigned)((kg * NTc + ta) * 64 + lo));
+                    bfw[q][1] = *ps_at(kb->Vb, (unsigned)((kg * NTc + tc) * 64 + lo));
                 }
             }
             PS_STAMP(0)
@@ -656,9 +714,9 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                 const int tw0 = ps_opq(t0i);
 #pragma unroll
                 for (int j = 0; j < PS_J; ++j) {
-                    const int ti = tw0 + j * es;
-                    const c32 v = j >= JZ1 ? ps_scal(mk(j), ps_cmul(ps_dinv_at(co, ti, es, c, a.wJ), rr(j))) : c32{0, 0};
-                    if ((iyv < NYP)) T0[ti] = v;
+                    const int ti = tw0 + j * ts;
+                    const c32 v = j >= JZ1 ? ps_scal(mk(j), ps_cmul(ps_dinv_at(co, ti, ts, c, kb->wJ), rr(j))) : c32{0, 0};
+                    if ((iyv < LWh)) T0[ti] = v;
                 }
             }
             __syncthreads();
@@ -667,26 +725,27 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                 {
                     const int tw0 = ps_opq(t0i);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if ((iyv < NYP)) T1[tw0 + j * es] = c32{0, 0};
+                    for (int j = 0; j < 4; ++j) if ((iyv < LWh)) T1[tw0 + j * ts] = c32{0, 0};
                 }
-                ps_rows<4>(co, T0, t0i, es, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
-                    const c32 u2 = ps_scal(mk(j), ps_cadd(uc, ps_cmul(ps_scal(k.w2, ps_dinv(dk, dm, a.wJ)), ps_csub(rr(j), av))));
-                    if ((iyv < NYP)) T1[ti] = u2;
+                const float wJ = kb->wJ;
+                ps_rows<4>(co, T0, t0i, ts, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+                    const c32 u2 = ps_scal(mk(j), ps_cadd(uc, ps_cmul(ps_scal(L.w2, ps_dinv(dk, dm, wJ)), ps_csub(rr(j), av))));
+                    if ((iyv < LWh)) T1[ti] = u2;
                     const int g = gb + gs * j;
-                    if (j >= PS_HALO && (iyv < NYP) && g >= 1 && g <= nz - 1) *ps_at(pubZ, eo(j)) = float2{u2.re, u2.im};
+                    if (j >= PS_HALO && own() && g >= 1 && g <= nz - 1) *ps_at(pubZ(), eo(j)) = float2{u2.re, u2.im};
                 });
                 __syncthreads();
             } else {
 #pragma unroll
                 for (int j = PS_HALO; j < PS_J; ++j) {
                     const int g = gb + gs * j;
-                    if ((iyv < NYP) && g >= 1 && g <= nz - 1) *ps_at(pubZ, eo(j)) = float2{T0[ps_opq(t0i) + j * es].re, T0[ps_opq(t0i) + j * es].im};
+                    if (own() && g >= 1 && g <= nz - 1) *ps_at(pubZ(), eo(j)) = float2{T0[ps_opq(t0i) + j * ts].re, T0[ps_opq(t0i) + j * ts].im};
                 }
             }
             // t on the own rows, straight into the bf16 hi/lo planes of the forward transform (the first tile's space: with two sweeps
             // its readers are behind the barrier above; with one, t is formed from the first tile itself, so a barrier separates them)
             c32 tv[PS_NO];
-            ps_rows<PS_HALO>(co, SW == 2 ? T1 : T0, t0i, es, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+            ps_rows<PS_HALO>(co, SW == 2 ? T1 : T0, t0i, ts, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
                 const c32 rv = rr(j);
                 tv[j - PS_HALO] = ps_scal(mk(j), ps_csub(rv, av));
                 if (SW == 2) {
@@ -697,23 +756,37 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             if (SW == 1) __syncthreads();
             PS_STAMP(1)
             PS_PHASE();
-            if ((iyv < NYP)) {
+            if (own()) {
+                // (column parts: plane column of mesh column gy = gy - 32 kg0 -- whole K-groups, the part's own columns only: the
+                //  forward transform is the sum of the parts' partial products)
+                const int pc = cbase + iyv - 32 * kg0;
 #pragma unroll
                 for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q, g = gb + gs * j;
                     const int rho = tb + gs * j - PS_HALO;                     // row of the 16-row operand: tile row - 5
-                    unsigned short* b = PL + (long)rho * 4 * NYP + iyv;
-                    unsigned hp, lp;                                           // {re, im} packed: hi parts, lo parts
-                    bf16_split_pk(tv[q].re, tv[q].im, hp, lp);
-                    b[0] = (unsigned short)hp; b[NYP] = (unsigned short)(hp >> 16);
-                    b[2 * NYP] = (unsigned short)lp; b[3 * NYP] = (unsigned short)(lp >> 16);
-                    if (SW == 2 && g >= 1 && g <= nz - 1) *ps_at(tbuf, eo(j)) = float2{tv[q].re, tv[q].im};
+                    unsigned short* b = PL + (long)rho * 4 * PLW + pc;
+                    unsigned hp2, lp;                                          // {re, im} packed: hi parts, lo parts
+                    bf16_split_pk(tv[q].re, tv[q].im, hp2, lp);
+                    b[0] = (unsigned short)hp2; b[PLW] = (unsigned short)(hp2 >> 16);
+                    b[2 * PLW] = (unsigned short)lp; b[3 * PLW] = (unsigned short)(lp >> 16);
+                    if (SW == 2 && g >= 1 && g <= nz - 1) *ps_at(tbuf(), eo(j)) = float2{tv[q].re, tv[q].im};
                 }
             }
-            for (int i = tidv; i < 2 * 4 * NYP / 2 + 16; i += NT) reinterpret_cast<unsigned*>(PL)[PS_OWN * 4 * NYP / 2 + i] = 0u;   // rows 14, 15 and the over-read pad
+            if constexpr (CS == 1) {
+                for (int i = tidv; i < 2 * 4 * NYP / 2 + 16; i += NT) reinterpret_cast<unsigned*>(PL)[PS_OWN * 4 * NYP / 2 + i] = 0u;   // rows 14, 15 and the over-read pad
+            } else {
+                for (int i = tidv; i < 2 * 4 * PLW / 2; i += NT) reinterpret_cast<unsigned*>(PL)[PS_OWN * 4 * PLW / 2 + i] = 0u;        // rows 14, 15
+                // ... and the plane columns of rows 0..13 no own column maps to (the K-groups' remainder; the neighbour part's columns)
+                const int plo = ownLo - 32 * kg0, uc2 = (PLW - ownW) >> 1;       // own columns: plane columns [plo, plo + ownW)
+                for (int i = tidv; i < PS_OWN * 4 * uc2; i += NT) {
+                    const int rp = i / uc2, u = 2 * (i - rp * uc2);
+                    const int col = u < plo ? u : u + ownW;
+                    reinterpret_cast<unsigned*>(PL)[(rp * PLW + col) >> 1] = 0u;
+                }
+            }
             __syncthreads();
             // ================= forward transform of the own rows: MFMA -> yhat =================
-            {
+            if constexpr (CS == 1) {
                 f4v acc[2][2];
 #pragma unroll
                 for (int rg = 0; rg < 2; ++rg)
@@ -736,7 +809,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                         }
                     }
                 }
-                float2* yh = a.yhat + so;
+                float2* yh = kb->yhat + so();
 #pragma unroll
                 for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
@@ -747,6 +820,50 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                             if (t < ntl && rho < PS_OWN && g <= nz - 1)
                                 *ps_at(yh, (unsigned)(g * NYP + (t0w + t) * 16 + ljv)) = float2{acc[rg][t][2 * h2], acc[rg][t][2 * h2 + 1]};
                         }
+            } else {
+                // the part's partial product: its own columns (K-groups kg0 ..) x ALL mode tiles -- this wave's up to four, two
+                // at a time; the second pair's V fragments are requested as the first pair's are used up
+                float2* yh = (hp ? kb->yhat2 : kb->yhat) + so();
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    f4v acc[2][2];
+#pragma unroll
+                    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
+                    const int tn0 = min(t0wF + 2, NTc - 1), tn1 = min(t0wF + 3, NTc - 1);
+#pragma unroll
+                    for (int kg = 0; kg < 8; ++kg) {
+                        if (kg < KGF) {
+#pragma unroll
+                            for (int rg = 0; rg < 2; ++rg) {
+                                const unsigned short* ap = PL + ((long)(8 * rg + (ljv >> 1)) * 4 + (ljv & 1)) * PLW + 32 * kg + 8 * g4v;
+                                const bf8v ah = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap));
+                                const bf8v al = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap + 2 * PLW));
+#pragma unroll
+                                for (int t = 0; t < 2; ++t) {
+                                    const bf8v bhf = __builtin_bit_cast(bf8v, bfw[kg][t]);
+                                    acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
+                                    acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
+                                }
+                            }
+                            if (pp == 0) {
+                                bfw[kg][0] = *ps_at(kb->Vb, (unsigned)(((kg0 + kg) * NTc + tn0) * 64 + lanev));
+                                bfw[kg][1] = *ps_at(kb->Vb, (unsigned)(((kg0 + kg) * NTc + tn1) * 64 + lanev));
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                const int rho = 8 * rg + 2 * g4v + h2, g = iz0 + rho;
+                                if (2 * pp + t < ntlF && rho < PS_OWN && g <= nz - 1)
+                                    *ps_at(yh, (unsigned)(g * NYP + (t0wF + 2 * pp + t) * 16 + ljv)) = float2{acc[rg][t][2 * h2], acc[rg][t][2 * h2 + 1]};
+                            }
+                }
             }
             // (two sweeps: the first part of the rho identity, the sum of (r' + t) .* z2 over the own rows, stays in registers and
             //  joins the second part in the reduction behind the first post-sweep: one block reduction less)
@@ -755,7 +872,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             if (!sys_sync()) { alive = false; break; }                         // T1: every row of yhat is in the L2
             PS_STAMP(3)
             // ================= tridiagonal solves of this workgroup's mode slabs =================
-            for (int slab = jwg; slab < nslab; slab += G) ps_slab_solve<NT, MW>(k, arena, tabF1, tabF2, s, slab, a.yhat, a.ysol, a.ip32, tidv, stampNow ? a.stamps + (long)blockIdx.x * 16 : nullptr);
+            for (int slab = jw; slab < nslab; slab += G) ps_slab_solve<NT, MW, CS>(kb, arena, tabF1, tabF2, s, slab, tidv, stampNow ? L.stamps + (long)blockIdx.x * 16 : nullptr);
             PS_STAMP(4)
             u4v bbk[8][2];                                                     // the wave's V' fragments of the back transform: in flight during the wait
             {
@@ -763,8 +880,8 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int kg = min(q, KG - 1);
-                    bbk[q][0] = *ps_at(a.Vtb, (unsigned)((kg * NTc + tl0) * 64 + lo));
-                    bbk[q][1] = *ps_at(a.Vtb, (unsigned)((kg * NTc + tl1) * 64 + lo));
+                    bbk[q][0] = *ps_at(kb->Vtb, (unsigned)((kg * NTc + tl0) * 64 + lo));
+                    bbk[q][1] = *ps_at(kb->Vtb, (unsigned)((kg * NTc + tl1) * 64 + lo));
                 }
             }
             if (!sys_sync()) { alive = false; break; }                         // T2: every solved slab is in the L2
@@ -776,17 +893,28 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             // iterate of the owners and, two sweeps, t of the own rows (second part of the rho identity: sum of t .* (V y))
             float2 zq[3][2][2];
             {
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(a.ysol + so), 0, (int)(k.vstride * 8), 0x00020000);
-                const int rowU = NYP / 2, n16 = PS_ROWS * rowU;             // 16-byte units per row / in the tile
-                u4v tmp[6];
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(kb->ysol + so()), 0, (int)(kb->vstride * 8), 0x00020000);
+                const int rowU = NYP / 2, n16 = PS_ROWS * rowU;             // 16-byte units per row / in the tile: every mode of the tile's rows
+                constexpr int NU = 6, NBT = CS == 1 ? 1 : 2;                // (column parts: NYP <= 2 CW modes -- two batches)
+                u4v tmp[NU];
+                auto ld_units = [&](int b) {
 #pragma unroll
-                for (int u = 0; u < 6; ++u) {
-                    const int i = min(tidv + u * NT, n16 - 1);
-                    const int row = i / rowU, g = R0 + row;
-                    const int gc = min(max(g, 0), nz);
-                    tmp[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (gc * rowU + (i - row * rowU)) * 16, 0, 16);
-                    if (g < 0 || g > nz) tmp[u] = u4v{0u, 0u, 0u, 0u};
-                }
+                    for (int u = 0; u < NU; ++u) {
+                        const int i = min(tidv + (b * NU + u) * NT, n16 - 1);
+                        const int row = i / rowU, g = R0 + row;
+                        const int gc = min(max(g, 0), nz);
+                        tmp[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (gc * rowU + (i - row * rowU)) * 16, 0, 16);
+                        if (g < 0 || g > nz) tmp[u] = u4v{0u, 0u, 0u, 0u};
+                    }
+                };
+                auto st_units = [&](int b) {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int i = tidv + (b * NU + u) * NT;
+                        if (i < n16) reinterpret_cast<u4v*>(PL)[i] = tmp[u];
+                    }
+                };
+                ld_units(0);
 #pragma unroll
                 for (int rg = 0; rg < 3; ++rg)
 #pragma unroll
@@ -796,16 +924,23 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                             const int tau = 8 * rg + 2 * g4v + h2, g = R0 + tau, col = (t ? tl1 : tl0) * 16 + ljv;
                             const bool in = g >= 1 && g <= nz - 1 && col >= 1 && col <= ny - 1;
                             const unsigned e = in ? (unsigned)(g * NYP + col) : (unsigned)(NYP + 1);
-                            zq[rg][t][h2] = ps_ld_f2(ps_at(pubZ, e));
+                            zq[rg][t][h2] = ps_ld_f2(ps_at(pubZ(), e));
                         }
 #pragma unroll
-                for (int j = 0; j < PS_HALO; ++j) rh[j] = ps_ld_c32(ps_at(pubR, ei(j)));      // the owners' r' (no drift of the local copies)
-#pragma unroll
-                for (int u = 0; u < 6; ++u) {
-                    const int i = tidv + u * NT;
-                    if (i < n16) reinterpret_cast<u4v*>(PL)[i] = tmp[u];
-                }
+                for (int j = 0; j < PS_HALO; ++j) rh[j] = ps_ld_c32(ps_at(pubR(), ei(j)));      // the owners' r' (no drift of the local copies)
+                st_units(0);
+                if (NBT > 1) { ld_units(1); st_units(1); }
                 if (tidv < 16) reinterpret_cast<unsigned*>(PL)[PS_ROWS * 4 * NYP / 2 + tid] = 0u;
+                if constexpr (CS > 1) {
+                    // a halo COLUMN's copy of r (rows j >= 5): the owners' r', like the halo rows'
+                    if (!own() && (iyv < LWh)) {
+#pragma unroll
+                        for (int q = 0; q < PS_NO; ++q) {
+                            const c32 v = ps_ld_c32(ps_at(pubR(), ei(PS_HALO + q)));
+                            r64[q] = (double)mk(PS_HALO + q) * cplx{(double)v.re, (double)v.im};
+                        }
+                    }
+                }
             }
             __syncthreads();
             double ar = 0, ai = 0, zzs = 0;
@@ -816,22 +951,32 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
 #pragma unroll
                     for (int t = 0; t < 2; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
 #pragma unroll
-                for (int kg = 0; kg < 8; ++kg) {
-                    if (kg < KG) {
+                for (int ch = 0; ch < (CS == 1 ? 1 : 2); ++ch) {
 #pragma unroll
-                        for (int rg = 0; rg < 3; ++rg) {
-                            const unsigned short* ap = PL + ((long)(8 * rg + (ljv >> 1)) * 4 + (ljv & 1)) * NYP + 32 * kg + 8 * g4v;
-                            const bf8v ah = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap));
-                            const bf8v al = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap + 2 * NYP));
+                    for (int q = 0; q < 8; ++q) {
+                        const int kg = 8 * ch + q;
+                        if (kg < KG) {
 #pragma unroll
-                            for (int t = 0; t < 2; ++t) {
-                                const bf8v bhf = __builtin_bit_cast(bf8v, bbk[kg][t]);
-                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
-                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
+                            for (int rg = 0; rg < 3; ++rg) {
+                                const unsigned short* ap = PL + ((long)(8 * rg + (ljv >> 1)) * 4 + (ljv & 1)) * NYP + 32 * kg + 8 * g4v;
+                                const bf8v ah = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap));
+                                const bf8v al = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap + 2 * NYP));
+#pragma unroll
+                                for (int t = 0; t < 2; ++t) {
+                                    const bf8v bhf = __builtin_bit_cast(bf8v, bbk[q][t]);
+                                    acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
+                                    acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
+                                }
+                            }
+                            if (CS > 1 && ch == 0) {                     // the second chunk's fragments, as the first's are used up
+                                const int kn = min(kg + 8, KG - 1);
+                                bbk[q][0] = *ps_at(kb->Vtb, (unsigned)((kn * NTc + tl0) * 64 + lanev));
+                                bbk[q][1] = *ps_at(kb->Vtb, (unsigned)((kn * NTc + tl1) * 64 + lanev));
                             }
                         }
                     }
                 }
+                if constexpr (CS > 1) __syncthreads();                    // (the operand planes span both tiles: every wave's reads before the output)
 #pragma unroll
                 for (int rg = 0; rg < 3; ++rg)
 #pragma unroll
@@ -841,7 +986,8 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                             const int tau = 8 * rg + 2 * g4v + h2, g = R0 + tau, col = (t ? tl1 : tl0) * 16 + ljv;
                             const float m = (g >= 1 && g <= nz - 1 && col >= 1 && col <= ny - 1) ? 1.f : 0.f;
                             const float ur = acc[rg][t][2 * h2], ui = acc[rg][t][2 * h2 + 1];
-                            if (t < ntl) T1[tau * NYP + (t0w + t) * 16 + ljv] = c32{m * (ur + zq[rg][t][h2].x), m * (ui + zq[rg][t][h2].y)};
+                            const int lc = (t0w + t) * 16 + ljv - cbase;    // local column
+                            if (t < ntl && (CS == 1 || (lc >= 0 && lc < LWh))) T1[tau * TW + lc] = c32{m * (ur + zq[rg][t][h2].x), m * (ui + zq[rg][t][h2].y)};
                         }
             }
 #pragma unroll
@@ -849,67 +995,66 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             float2 t7[PS_NO], z7[PS_NO];       // two sweeps: t and z2 of the own rows, for the second part of the rho identity: sum of t .* (V y), V y = z3 - z2
             if (SW == 2) {
 #pragma unroll
-                for (int q = 0; q < PS_NO; ++q) { t7[q] = *ps_at(tbuf, ei(PS_HALO + q)); z7[q] = ps_ld_f2(ps_at(pubZ, ei(PS_HALO + q))); }
+                for (int q = 0; q < PS_NO; ++q) { t7[q] = *ps_at(tbuf(), ei(PS_HALO + q)); z7[q] = ps_ld_f2(ps_at(pubZ(), ei(PS_HALO + q))); }
             }
             __syncthreads();
-#ifdef HMCMT_PS_DBGX
-            dbg_cmp(T1, 0, 0); if (dbgFail) { alive = false; break; }
-#endif
             PS_STAMP(6)
             PS_PHASE();
             // ================= post-smoother: zf = z3 + [w2] D (r - A z3) (T1 -> T0) [-> z = zf + D (r - A zf) (T0 -> T1)] =================
             {
                 const int tw0 = ps_opq(t0i);
-                if ((iyv < NYP)) T0[tw0] = c32{0, 0};
+                if ((iyv < LWh)) T0[tw0] = c32{0, 0};
             }
-            ps_rows<1>(co, T1, t0i, es, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
-                const c32 d = ps_dinv(dk, dm, a.wJ);
-                const c32 zf = ps_scal(mk(j), ps_cadd(uc, ps_cmul(SW == 2 ? ps_scal(k.w2, d) : d, ps_csub(rr(j), av))));
-                if ((iyv < NYP)) T0[ti] = zf;
-                if (j >= PS_HALO) {
-                    zzs += (double)zf.re * zf.re + (double)zf.im * zf.im;
-                    if (SW == 2) {
-                        const int q = j >= PS_HALO ? j - PS_HALO : 0;
-                        const double m = (double)mk(j), tr = m * t7[q].x, ti_ = m * t7[q].y, ur = (double)uc.re - (double)z7[q].x, ui = (double)uc.im - (double)z7[q].y;
-                        ar += tr * ur - ti_ * ui; ai += tr * ui + ti_ * ur;
+            {
+                const float wJ = kb->wJ;
+                ps_rows<1>(co, T1, t0i, ts, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+                    const c32 d = ps_dinv(dk, dm, wJ);
+                    const c32 zf = ps_scal(mk(j), ps_cadd(uc, ps_cmul(SW == 2 ? ps_scal(L.w2, d) : d, ps_csub(rr(j), av))));
+                    if ((iyv < LWh)) T0[ti] = zf;
+                    if (j >= PS_HALO) {
+                        zzs += (double)zf.re * zf.re + (double)zf.im * zf.im;
+                        if (SW == 2) {
+                            const int q = j >= PS_HALO ? j - PS_HALO : 0;
+                            const double m = (double)mk(j), tr = m * t7[q].x, ti_ = m * t7[q].y, ur = (double)uc.re - (double)z7[q].x, ui = (double)uc.im - (double)z7[q].y;
+                            ar += tr * ur - ti_ * ui; ai += tr * ui + ti_ * ur;
+                        }
+                        if (SW == 1) {
+                            const cplx rv = r64[j >= PS_HALO ? j - PS_HALO : 0];
+                            ar += rv.re * (double)zf.re - rv.im * (double)zf.im; ai += rv.re * (double)zf.im + rv.im * (double)zf.re;
+                        }
                     }
-                    if (SW == 1) {
-                        const cplx rv = r64[j >= PS_HALO ? j - PS_HALO : 0];
-                        ar += rv.re * (double)zf.re - rv.im * (double)zf.im; ai += rv.re * (double)zf.im + rv.im * (double)zf.re;
-                    }
-                }
-            });
+                });
+            }
             if (SW == 2) { ar += p1r; ai += p1i; }
+            if (CS > 1 && !own()) { ar = 0; ai = 0; zzs = 0; }                 // (a halo column's rows belong to the neighbour part's sums)
             ps_block_sum4<NWV>(ar, ai, zzs, xxPrev, sh, shFlip);              // (its barrier also completes the tile; |x|^2: the previous update's partials)
             if (tid == 0) {                                                    // R1, first half: this workgroup's partial sums
                 const double v4[4] = {ar, ai, zzs, xxPrev};
-                ps_publish<4>(a.rec + (((long)s * MAXNB + jwg) * 2 + 0) * 8, v4, a.tagBase + 2ull * (unsigned)it);
+                ps_publish<4>(recS() + ((long)jw * 2 + 0) * 8, v4, L.tagBase + 2ull * (unsigned)it);
             }
-#ifdef HMCMT_PS_DBGX
-            dbg_cmp(T0, 1, 1); if (dbgFail) { alive = false; break; }
-#endif
             if constexpr (SW == 2) {
                 // second post-sweep, while the partial sums travel (rows j >= 2)
                 {
                     const int tw0 = ps_opq(t0i);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) if ((iyv < NYP)) T1[tw0 + j * es] = c32{0, 0};
+                    for (int j = 0; j < 2; ++j) if ((iyv < LWh)) T1[tw0 + j * ts] = c32{0, 0};
                 }
-                ps_rows<2>(co, T0, t0i, es, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
-                    const c32 z5 = ps_scal(mk(j), ps_cadd(uc, ps_cmul(ps_dinv(dk, dm, a.wJ), ps_csub(rr(j), av))));
-                    if ((iyv < NYP)) T1[ti] = z5;
+                const float wJ = kb->wJ;
+                ps_rows<2>(co, T0, t0i, ts, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+                    const c32 z5 = ps_scal(mk(j), ps_cadd(uc, ps_cmul(ps_dinv(dk, dm, wJ), ps_csub(rr(j), av))));
+                    if ((iyv < LWh)) T1[ti] = z5;
                 });
             }
             c32* const TZ = SW == 2 ? T1 : T0;           // the preconditioned residual z
             c32* const TP = SW == 2 ? T0 : T1;           // ... the new direction goes to the other tile, q behind z's
             cplx* const Qs = reinterpret_cast<cplx*>(TZ);
-            if (a.precondOnly) {
+            if (L.precondOnly) {
                 __syncthreads();
 #pragma unroll
                 for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q, g = gb + gs * j;
-                    const c32 zv = TZ[ps_opq(t0i) + j * es];
-                    if ((iyv < NYP) && g >= 1 && g <= nz - 1) *ps_at(a.zout + so, eo(j)) = float2{zv.re, zv.im};
+                    const c32 zv = TZ[ps_opq(t0i) + j * ts];
+                    if (own() && g >= 1 && g <= nz - 1) *ps_at(L.zout + so(), eo(j)) = float2{zv.re, zv.im};
                 }
                 break;
             }
@@ -917,27 +1062,29 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             PS_PHASE();
             c32 pold[PS_J];                                                    // the old direction, from its owners: in flight during the wait
 #pragma unroll
-            for (int j = 0; j < PS_J; ++j) pold[j] = ps_ld_c32(ps_at(pubP, ei(j)));      // (masked where it is used)
+            for (int j = 0; j < PS_J; ++j) pold[j] = ps_ld_c32(ps_at(pubP(), ei(j)));      // (masked where it is used)
             // R1, second half: wave 0 collects the G records (no counter, no second round trip), the totals go round through LDS
             if (wave == 0) {
                 double t4[4] = {0, 0, 0, 0};
-                const bool okc = ps_collect<4>(a.rec + (long)s * MAXNB * 2 * 8, 0, G, a.tagBase + 2ull * (unsigned)it, t4, a.fail, lane);
+                const bool okc = ps_collect<4>(recS(), 0, G, L.tagBase + 2ull * (unsigned)it, t4, kb->fail, lane);
                 if (lane == 0) { sh[64] = t4[0]; sh[65] = t4[1]; sh[66] = t4[2]; sh[67] = t4[3]; if (!okc) sflag[0] = 2; }
             }
             __syncthreads();                                                   // (also completes z's tile)
             if (sflag[0]) { alive = false; break; }
             PS_STAMP(8)
             // the fp64 stencil coefficients of the own rows: requested here, they arrive under the p update
-            const double *dMm = k.dM + mo, *cYm = k.cY + mo, *cZm = k.cZ + mo;
             double dm64[PS_NO], ce64[PS_NO], cw64[PS_NO], ci64[PS_NO], co64[PS_NO];
+            {
+                const double *dMm = kb->dM + mo(), *cYm = kb->cY + mo(), *cZm = kb->cZ + mo();
 #pragma unroll
-            for (int q = 0; q < PS_NO; ++q) {
-                const int j = PS_HALO + q;
-                const unsigned e = (unsigned)ps_opq((int)ei(j));
-                dm64[q] = *ps_at(dMm, e);
-                ce64[q] = *ps_at(cYm, e); cw64[q] = *ps_at(cYm, e - 1u);
-                const double cs = *ps_at(cZm, e), cn = *ps_at(cZm, e - (unsigned)NYP);
-                ci64[q] = c ? cn : cs; co64[q] = c ? cs : cn;
+                for (int q = 0; q < PS_NO; ++q) {
+                    const int j = PS_HALO + q;
+                    const unsigned e = (unsigned)ps_opq((int)ei(j));
+                    dm64[q] = *ps_at(dMm, e);
+                    ce64[q] = *ps_at(cYm, e); cw64[q] = *ps_at(cYm, e - 1u);
+                    const double cs = *ps_at(cZm, e), cn = *ps_at(cZm, e - (unsigned)NYP);
+                    ci64[q] = c ? cn : cs; co64[q] = c ? cs : cn;
+                }
             }
             // ================= scalars: rho, error estimate, convergence, beta =================
             const cplx rz = cplx{sh[64], sh[65]};
@@ -946,12 +1093,12 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             bool on = true;
             st = 0;
             if (first) { if (zz == 0.0) on = false; }
-            else if (zz <= k.tol2 * xx) on = false;
-            else if (it - 1 >= a.maxit) { on = false; st = HMCMT_ENOCONV; }
+            else if (zz <= L.tol2 * xx) on = false;
+            else if (it - 1 >= L.maxit) { on = false; st = HMCMT_ENOCONV; }
             if (!(isfinite(rz.re) && isfinite(rz.im) && isfinite(zz) && isfinite(xx))) { on = false; st = HMCMT_EBREAKDOWN; }
             est = first ? (zz == 0.0 ? 0.0 : 1.0) : sqrt(zz / xx);
             if (first || est < 0.1 * errRef) { errRef = est; errRefIt = it; }
-            else if (on && it - errRefIt > k.stallIt) { stalled = true; on = false; }
+            else if (on && it - errRefIt > kb->stallIt) { stalled = true; on = false; }
             if (!on) break;
             const cplx be = first ? cplx{0, 0} : rz / rhoPrev;
             rhoPrev = rz; rhoCur = rz;
@@ -961,7 +1108,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                 const int tw0 = ps_opq(t0i);
 #pragma unroll
                 for (int j = 0; j < PS_J; ++j) {
-                    const int ti = tw0 + j * es;
+                    const int ti = tw0 + j * ts;
                     c32 pv = c32{0, 0};
                     if (j >= JP) {
                         const c32 zv = TZ[ti];
@@ -969,36 +1116,15 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                         const double vr = __builtin_fma(be.re, pr, __builtin_fma(-be.im, pi, (double)zv.re)), vi = __builtin_fma(be.re, pi, __builtin_fma(be.im, pr, (double)zv.im));
                         pv = ps_scal(mk(j), c32{(float)vr, (float)vi});
                     }
-                    if ((iyv < NYP)) TP[ti] = pv;
+                    if ((iyv < LWh)) TP[ti] = pv;
                 }
             }
             __syncthreads();
-#ifdef HMCMT_PS_DBGX
-            {   // diagnosis: the halo rows next to the own rows take the OWNERS' p (an extra exchange + synchronisation)
-                const int tw0 = ps_opq(t0i);
-#pragma unroll
-                for (int q = 0; q < PS_NO; ++q) {
-                    const int j = PS_HALO + q, g = gb + gs * j;
-                    if ((iyv < NYP) && g >= 1 && g <= nz - 1) *ps_at(a.yhat + so, eo(j)) = float2{TP[tw0 + j * es].re, TP[tw0 + j * es].im};
-                }
-                if (!sys_sync()) { alive = false; break; }
-                int bad = 0;
-#pragma unroll
-                for (int j = JP; j < PS_HALO; ++j) {
-                    const c32 ov = mk(j) * ps_ld_c32(ps_at(a.yhat + so, ei(j)));
-                    const c32 mine = TP[tw0 + j * es];
-                    if (ov.re != mine.re || ov.im != mine.im) bad |= 1 << j;
-                    if ((iyv < NYP)) TP[tw0 + j * es] = ov;
-                }
-                if (bad && a.stamps) atomicAdd((unsigned long long*)(a.stamps + 16 * 255 + 12), (unsigned long long)1);
-                __syncthreads();
-            }
-#endif
             PS_PHASE();
             c32 qh[PS_HALO];                                                   // the halo rows' q: fp32
 #pragma unroll
             for (int j = 0; j < PS_HALO; ++j) qh[j] = c32{0, 0};
-            ps_rows<JP + 1, PS_HALO>(co, TP, t0i, es, c, [&](int j, int, c32, c32 av, float, float) __attribute__((always_inline)) { qh[j] = av; });
+            ps_rows<JP + 1, PS_HALO>(co, TP, t0i, ts, c, [&](int j, int, c32, c32 av, float, float) __attribute__((always_inline)) { qh[j] = av; });
             // own rows: fp64; q itself waits in LDS for alpha (each thread reads back what it wrote: z's tile is free now)
             double pqr = 0, pqi = 0, dum2 = 0;
             {
@@ -1006,8 +1132,8 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
 #pragma unroll
                 for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q;
-                    const int ti = tq0 + j * es;
-                    const c32 pc = TP[ti], pe = TP[ti + 1], pw = TP[ti - 1], pi = TP[ti + es], po = TP[ti - es];
+                    const int ti = tq0 + j * ts;
+                    const c32 pc = TP[ti], pe = TP[ti + 1], pw = TP[ti - 1], pi = TP[ti + ts], po = TP[ti - ts];
                     const double dmw = w * dm64[q];
                     const double dk = -((ce64[q] + cw64[q]) + (ci64[q] + co64[q]));
                     cplx acc = cplx{dk * (double)pc.re - dmw * (double)pc.im, dk * (double)pc.im + dmw * (double)pc.re};
@@ -1018,7 +1144,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
                     const cplx qv = (double)mk(j) * acc;                      // (a non-interior node: coefficients of a harmless node, p = 0)
                     pqr += (double)pc.re * qv.re - (double)pc.im * qv.im;
                     pqi += (double)pc.re * qv.im + (double)pc.im * qv.re;
-                    if ((iyv < NYP)) Qs[ti - PS_HALO * NYP] = qv;
+                    if ((iyv < LWh)) Qs[ti - PS_HALO * TW] = qv;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1026,17 +1152,18 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
 #pragma unroll
             for (int q = 0; q < PS_NO; ++q) {
                 const int j = PS_HALO + q, g = gb + gs * j;
-                xv[q] = *ps_at(xsys, ((iyv < NYP) && g >= 1 && g <= nz - 1) ? eo(j) : (unsigned)(NYP + 1));
+                xv[q] = *ps_at(xsys(), (own() && g >= 1 && g <= nz - 1) ? eo(j) : (unsigned)(NYP + 1));
             }
+            if (CS > 1 && !own()) { pqr = 0; pqi = 0; }
             { double dz = 0; ps_block_sum4<NWV>(pqr, pqi, dum2, dz, sh, shFlip); }
             if (tid == 0) {
                 const double v2[2] = {pqr, pqi};
-                ps_publish<2>(a.rec + (((long)s * MAXNB + jwg) * 2 + 1) * 8, v2, a.tagBase + 2ull * (unsigned)it + 1ull);
+                ps_publish<2>(recS() + ((long)jw * 2 + 1) * 8, v2, L.tagBase + 2ull * (unsigned)it + 1ull);
             }
             PS_STAMP(9)
             if (wave == 0) {                                                   // R2
                 double t2[2] = {0, 0};
-                const bool okc = ps_collect<2>(a.rec + (long)s * MAXNB * 2 * 8, 1, G, a.tagBase + 2ull * (unsigned)it + 1ull, t2, a.fail, lane);
+                const bool okc = ps_collect<2>(recS(), 1, G, L.tagBase + 2ull * (unsigned)it + 1ull, t2, kb->fail, lane);
                 if (lane == 0) { sh[68] = t2[0]; sh[69] = t2[1]; if (!okc) sflag[0] = 2; }
             }
             __syncthreads();
@@ -1049,18 +1176,21 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             double xxs = 0, dum3 = 0, dum4 = 0;
             {
                 const int tu0 = ps_opq(t0i);
+                const bool mine = own();
 #pragma unroll
                 for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q, g = gb + gs * j;
-                    if ((iyv < NYP) && g >= 1 && g <= nz - 1) {
+                    if ((iyv < LWh) && g >= 1 && g <= nz - 1) {
                         // (p and q vanish on boundary and pad nodes: x keeps its Dirichlet values there, r stays zero)
-                        const c32 pv = TP[tu0 + j * es];
-                        const cplx xn = xv[q] + al * cplx{(double)pv.re, (double)pv.im};
-                        *ps_at(xsys, eo(j)) = xn;
-                        r64[q] -= al * Qs[tu0 + j * es - PS_HALO * NYP];
-                        xxs += cabs2(xn);                                      // (rows 1 .. nz-1, all columns: as the launch-per-phase kernels)
-                        *ps_at(pubR, eo(j)) = float2{(float)r64[q].re, (float)r64[q].im};
-                        *ps_at(pubP, eo(j)) = float2{pv.re, pv.im};
+                        r64[q] -= al * Qs[tu0 + j * ts - PS_HALO * TW];        // (a halo column's copy: the same bits as its owner's)
+                        if (CS == 1 || mine) {
+                            const c32 pv = TP[tu0 + j * ts];
+                            const cplx xn = xv[q] + al * cplx{(double)pv.re, (double)pv.im};
+                            *ps_at(xsys(), eo(j)) = xn;
+                            xxs += cabs2(xn);                                  // (rows 1 .. nz-1, all columns: as the launch-per-phase kernels)
+                            *ps_at(pubR(), eo(j)) = float2{(float)r64[q].re, (float)r64[q].im};
+                            *ps_at(pubP(), eo(j)) = float2{pv.re, pv.im};
+                        }
                     }
                 }
             }
@@ -1071,30 +1201,34 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
             xxPrev = xxs;                                                      // (this thread's part: reduced and published with the next reduction)
             PS_STAMP(11)
         }
-        if (!alive || a.precondOnly) { if (a.precondOnly) continue; break; }
+        kb = kb0;                            // (behind a loop the compiler takes for one with divergent exits: a uniform copy again)
+        if (!alive || L.precondOnly) { if (L.precondOnly) continue; break; }
         // ---- the system has left the iteration: records (workgroup 0 of the group), r back to memory (a stalled or capped
         // system is continued by the host's classic loop with the fp64 preconditioner)
+        if (own()) {
 #pragma unroll
-        for (int q = 0; q < PS_NO; ++q) {
-            const int j = PS_HALO + q;
-            if (isIn(j)) *ps_at(rsys, eo(j)) = r64[q];
+            for (int q = 0; q < PS_NO; ++q) {
+                const int j = PS_HALO + q;
+                if (isIn(j)) *ps_at(rsys(), eo(j)) = r64[q];
+            }
         }
-        if (jwg == 0 && tid == 0) {
-            if (k.cntActive) atomicAdd(k.cntActive, (unsigned long long)max(it - 1, 0));   // (roofline accounting: iterations x systems of a sampled evaluation)
-            k.iters[s] = it - 1;
-            k.errEst[s] = est;
-            if (st) { k.status[s] = st; *k.failHost = st; }
-            if (stalled) *k.stallHost = 1;
-            else { k.active[s] = 0; if (atomicSub(k.nactive, 1) == 1) *k.nactHost = 0; }
+        if (jw == 0 && tid == 0) {
+            if (L.cntActive) atomicAdd(L.cntActive, (unsigned long long)max(it - 1, 0));   // (roofline accounting: iterations x systems of a sampled evaluation)
+            kb->iters[s] = it - 1;
+            kb->errEst[s] = est;
+            if (st) { kb->status[s] = st; *kb->failHost = st; }
+            if (stalled) *kb->stallHost = 1;
+            else { kb->active[s] = 0; if (atomicSub(kb->nactive, 1) == 1) *kb->nactHost = 0; }
         }
     }
     // ---- exit: the last workgroup to leave tells the host
+    kb = kb0;
     __syncthreads();
-    tick_end(k.ticks, a.tickId);
+    tick_end(kb->ticks, L.tickId);
     if (tid == 0) {
-        if (sflag[0] == 2) *k.failHost = HMCMT_EHIP;       // a wait timed out: the solve is void
+        if (sflag[0] == 2) *kb->failHost = HMCMT_EHIP;       // a wait timed out: the solve is void (the host redoes it with the launch-per-phase loop)
         __threadfence_system();
-        const unsigned nLeft = __hip_atomic_fetch_add(a.exitCnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned nLeft = __hip_atomic_fetch_add(kb->exitCnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sflag[1] = nLeft == gridDim.x - 1 ? 1 : 0;
     }
     __syncthreads();
@@ -1102,27 +1236,29 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(Solver k, PersistArgs a
         // every other workgroup has left.  The word the speculatively queued followers look at (View::gate): clean = no system
         // still active (stalled, cut off, never started: placement) and none with a status
         {
-            int bad = __hip_atomic_load(a.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1 : 0;
-            for (int s = tid; s < k.S; s += NT)
-                bad |= (__hip_atomic_load(k.status + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                        __hip_atomic_load(k.active + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
+            const int S = kb->S;
+            int bad = __hip_atomic_load(kb->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1 : 0;
+            for (int s = tid; s < S; s += NT)
+                bad |= (__hip_atomic_load(kb->status + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                        __hip_atomic_load(kb->active + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
             // (an OR over the workgroup through the scratch kilobyte: __syncthreads_or brings a static __shared__ word of its own,
             //  and static + dynamic LDS beyond 160 KB makes hipFuncSetAttribute refuse the kernel)
             if (tid == 0) sflag[2] = 0;
             __syncthreads();
             if (bad) sflag[2] = 1;
             __syncthreads();
-            if (tid == 0 && a.gateOut) *a.gateOut = sflag[2] ? -a.gateGen : a.gateGen;
+            if (tid == 0 && L.gateOut) *L.gateOut = sflag[2] ? -L.gateGen : L.gateGen;
         }
         // The barrier counters, the exit counter and the failure word go back to zero for the
         // next launch (a memset in front of every launch was a 5 us fill kernel on the stream: 12 us between the residual kernel
         // and this one, now 6)
-        for (int i = tid; i < a.syncWords; i += NT) a.sync[i] = 0u;
+        unsigned* const syn = kb->sync;
+        for (int i = tid; i < kb->syncWords; i += NT) syn[i] = 0u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
             __threadfence_system();
-            *(volatile int*)k.progHost = PS_DONE;
+            *(volatile int*)kb->progHost = PS_DONE;
         }
     }
 }

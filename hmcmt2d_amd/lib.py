@@ -378,10 +378,11 @@ class HipContext:
         self._check(self.lib.hmcmt_debug_transform(self.h, which, _dp(A), _dp(Cc)))
         return Cc
 
-    def debug_flags(self, freeze_boundary=False, no_boundary_terms=False):
-        """Test hook (include/hmcmt.h): hold the Dirichlet values at the previous evaluation's / leave dBC^T w out of the gradient."""
+    def debug_flags(self, freeze_boundary=False, no_boundary_terms=False, fail_placement=False):
+        """Test hook (include/hmcmt.h): hold the Dirichlet values at the previous evaluation's / leave dBC^T w out of the gradient /
+        (one-shot) let the first system group of the next persistent launch fail its placement check."""
         self._cache = None
-        self._check(self.lib.hmcmt_debug_flags(self.h, (1 if freeze_boundary else 0) | (2 if no_boundary_terms else 0)))
+        self._check(self.lib.hmcmt_debug_flags(self.h, (1 if freeze_boundary else 0) | (2 if no_boundary_terms else 0) | (4 if fail_placement else 0)))
 
     def debug_spmv(self, p):
         p = self._vec(p)
@@ -403,10 +404,10 @@ class HipContext:
 
     def persist_info(self):
         """The persistent solve kernel and this context (kernels_persist.h): shape, whether it is enabled, how many solves it ran."""
-        out = (C.c_int64 * 8)()
+        out = (C.c_int64 * 10)()
         self._check(self.lib.hmcmt_persist_info(self.h, out))
-        return dict(zip(("threads_half", "workgroups_per_system", "slots_per_xcd", "enabled", "solves", "placement_fallbacks", "usable_now", "slab_modes"),
-                        (int(x) for x in out)))
+        return dict(zip(("threads_half", "workgroups_per_system", "slots_per_xcd", "enabled", "solves", "placement_fallbacks", "usable_now", "slab_modes",
+                         "column_parts", "timeouts"), (int(x) for x in out)))
 
     def debug_persist_precond(self, r, sweeps=1):
         """z = P^-1 r by the persistent solve kernel's preconditioner (kernels_persist.h)."""

@@ -229,14 +229,18 @@ int hmcmt_debug_transform(hmcmt_ctx* ctx, int32_t which, const double* A, double
  *   (mt2DTE.jl:100-134, mt2DTM.jl:100-134) are NOT recomputed from the model but stay those of the previous evaluation;
  *   bit 1 -- the boundary-derivative terms dBC^T w (compJacTMatVec.jl:237-242, :309-313, :316) are left out of the
  *   gradient.  A frozen-boundary finite difference of the misfit must then equal the gradient with bit 1 set.
+ *   bit 2 (one-shot, not stored) -- the first system group of the NEXT persistent launch fails its placement check, as if its
+ *   workgroups were not on one XCD (tests/test_gpu_persist.py: the other groups finish, the launch-per-phase loop takes the rest).
  *   0 restores the product behaviour; stored results of earlier calls are dropped. */
 int hmcmt_debug_flags(hmcmt_ctx* ctx, int32_t flags);
 int hmcmt_debug_spmv(hmcmt_ctx* ctx, const double* p, double* q);
 int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z);
 int hmcmt_guard(const hmcmt_ctx* ctx, double* out4);   /* {checks, worst true residual seen, last, trips (checks above HMCMT_GUARD_LIMIT, default 1e-6)}: the production guard of the stopping rule (every HMCMT_GUARD_EVERY-th evaluation, default 100) */
-int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out8);   /* {threads/2 (0: not applicable), workgroups per system, slots per XCD, enabled, solves, placement fallbacks,
+int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out10);  /* {threads/2 (0: not applicable), workgroups per system, slots per XCD, enabled, solves, placement fallbacks,
                                                                    usable now (this context alone on its device in the process AND the process holds the device's advisory lock),
-                                                                   modes per slab of its tridiagonal solves (32; 16 on tall meshes)} */
+                                                                   modes per slab of its tridiagonal solves (32; 16 on tall meshes and with column parts),
+                                                                   column parts per row block (1; 2 on meshes wider than one tile: the stress size),
+                                                                   timed-out waits (each one: the evaluation redone with the launch-per-phase loop)} */
 int hmcmt_debug_persist_precond(hmcmt_ctx* ctx, int32_t sweeps, const double* r, double* z);   /* the persistent solve kernel's preconditioner (tests) */
 int hmcmt_debug_fdm_fwd(hmcmt_ctx* ctx, const double* t, double* out);   /* [2][S*vstride] complex: fused kernel | separate kernels */
 int hmcmt_debug_back_post(hmcmt_ctx* ctx, const double* y, const double* r, double* out, double* sums);   /* out: [2][S*vstride] complex (fused | separate), sums[6] */
