@@ -175,6 +175,8 @@ struct hmcmt_ctx {
     PsConst* d_psConst = nullptr;         // the kernel's launch-invariant state, read through a constant-address-space pointer
     bool psConstValid = false;
     float2* d_yhat2 = nullptr;            // column parts: the second part's partial product of the forward transform
+    unsigned persistSpin = PS_SPIN_LIMIT; // HMCMT_PS_SPIN: polls before a wait of the kernel gives up (tests shorten it)
+    bool persistTimedOut = false;         // a wait of the last persistent launch timed out: evaluate() redoes the evaluation with the launch-per-phase loop
     int dbgPlace = 0;                     // test hook (hmcmt_debug_flags bit 2): the next persistent launch's first group fails its placement check
     bool counted = false;                 // this context is in g_liveOnDev / holds a reference on the device lock
     // production guard on the error-estimate stopping rule: every guardEvery-th evaluation the TRUE residual of both
@@ -530,12 +532,17 @@ static void devlock_ref(int dev) {
     char bus[64] = "unknown";
     if (hipDeviceGetPCIBusId(bus, sizeof bus, dev) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof bus, "dev%d", dev); }
     for (char* c = bus; *c; ++c) if (*c == ':' || *c == '/') *c = '_';
+    // $HMCMT_LOCK_DIR, else /tmp: the one directory every user's processes on a machine share (a per-user runtime directory would
+    // not coordinate two users' processes on one GPU).  The name is predictable, so the open follows no symlink (a planted link
+    // could make it create or open a file elsewhere with this process's rights) and the file carries no data.
     const char* dir = getenv("HMCMT_LOCK_DIR");
     const std::string path = std::string(dir && dir[0] ? dir : "/tmp") + "/hmcmt_persist_" + bus + ".lock";
-    L.fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-    if (L.fd < 0) L.fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);      // (another user's file: a shared lock needs no write access)
+    L.fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);
+    if (L.fd < 0) L.fd = open(path.c_str(), O_RDONLY | O_CLOEXEC | O_NOFOLLOW);      // (another user's file: a shared lock needs no write access)
     if (L.fd < 0) { L.held = true; return; }           // (no lock directory: nothing to coordinate through)
-    devlock_try(L);
+    if (!devlock_try(L))
+        fprintf(stderr, "libhmcmt_hip: %s is held by another process: this one runs the launch-per-phase solver on device %d until it is free "
+                        "(hmcmt_persist_info: usable_now)\n", path.c_str(), dev);
 }
 static void devlock_unref(int dev) {
     if (dev < 0 || dev >= MAXDEV) return;
@@ -574,6 +581,7 @@ int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout, in
     c.G = ctx->persistG; c.GZ = ctx->persistGZ; c.slots = ctx->persistSlots;
     c.C0 = ctx->persistCS > 1 ? ps_split_col(k.NYP) : k.NYP; c.TW = ps_tile_width(k.NYP, ctx->persistCS); c.PLW = ctx->persistCS > 1 ? ps_plane_width(k.NYP) : k.NYP;
     c.syncWords = (int)(ctx->psyncBytes / sizeof(unsigned));      // (zero at create; every launch's last workgroup leaves them zero)
+    c.spinLimit = ctx->persistSpin;
     c.wJ = (float)ctx->jacobiW;
     c.omega = k.omega; c.ofz = k.ofz; c.dM = k.dM; c.cY = k.cY; c.cZ = k.cZ; c.cf32 = k.cf32;
     c.active = k.active; c.iters = k.iters; c.status = k.status; c.nactive = k.nactive; c.nactHost = k.nactHost;
@@ -705,6 +713,13 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
         if (kind == 0) launch_adjoint_side(ctx);        // (the host is free while the device solves)
         if (spec && ctx->specOn) { (*spec)(ctx->d_gate + kind, ctx->gateGen); specIssued = true; }
         { int prc = spin_progress(ctx, PS_DONE); if (prc) return prc; }
+        if (*(volatile int*)(ctx->h_stall + 1) == HMCMT_EHIP) {
+            // a wait inside the kernel timed out (its grid was not co-resident: a foreign kernel holds CUs, a lock directory that
+            // does not coordinate): the systems are in no defined state.  This context leaves the persistent kernel for good, and
+            // evaluate() runs the evaluation again, cold, with the launch-per-phase loop -- which works under any sharing
+            ctx->persistTimedOut = true;
+            ctx->persistOn = false; ++ctx->persistTimeouts;
+        }
         if (*(volatile int*)(ctx->h_stall + 2)) {
             // the group's workgroups were not on one XCD (or the kernel could not be placed): nothing was touched by those
             // groups -- this context goes back to the launch-per-phase loop for good
@@ -903,7 +918,28 @@ void launch_adjoint_side(hmcmt_ctx* ctx) {
 }
 
 // the whole hot path on device buffers
+int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, double* d_misfit, double* d_grad);
 int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, double* d_misfit, double* d_grad) {
+    ctx->persistTimedOut = false;
+    int rc = evaluate_once(ctx, d_m, wantGrad, d_pred, d_misfit, d_grad);
+    if (ctx->persistTimedOut) {
+        // (solve(): a wait of the persistent kernel timed out.)  Everything in flight is drained, the leapfrog position update --
+        // done by the first attempt's first kernel -- is not repeated, no warm start from fields in an undefined state
+        ctx->persistTimedOut = false;
+        fprintf(stderr, "libhmcmt_hip: a wait of the persistent solve kernel timed out (the device is shared?); this context continues with the "
+                        "launch-per-phase loop, the evaluation is redone\n");
+        (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->side);
+        (void)hipGetLastError();
+        ctx->statsPending = false; ctx->sidePending = false; ctx->sensWaitPending = ctx->extAWaitPending = false;
+        ctx->haveFwd = ctx->haveAdj = false; ctx->lastItFwd = ctx->lastItAdj = 0;
+        ctx->lfStep.on = 0;
+        ctx->solveFail = 0;
+        *(volatile int*)(ctx->h_stall + 1) = 0;
+        rc = evaluate_once(ctx, d_m, wantGrad, d_pred, d_misfit, d_grad);
+    }
+    return rc;
+}
+int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, double* d_misfit, double* d_grad) {
     View v = ctx->v;
     v.m = d_m;
     v.dbg = ctx->dbgFlags;
@@ -1216,6 +1252,15 @@ int finish_status(hmcmt_ctx* ctx) {
     return 0;
 }
 
+// test hook (hmcmt_debug_hog): workgroups that hold a CU's whole LDS and spin for a while -- a foreign tenant on the device
+__global__ __launch_bounds__(64) void k_hog(long long ticks, int* sink) {
+    extern __shared__ __attribute__((aligned(16))) char hogmem[];
+    hogmem[threadIdx.x] = (char)threadIdx.x;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (sink && hogmem[threadIdx.x] == 77 && ticks < 0) *sink = 1;
+}
+
 }  // namespace
 
 // ----------------------------------------------------------------------------------------------
@@ -1353,12 +1398,11 @@ static bool persist_shape_cs(const hmcmt_ctx* ctx, int twist, int cs, int cuPerX
     cw = TW <= 64 ? 64 : (TW <= 128 ? 128 : 256);
     if (cs > 1) {
         // the MFMA work split of the kernel: at most 4 mode tiles (forward) and 2 tile columns (back) per wave, at most 8 K-groups
-        // of own columns, at most 16 in all; every slab has a workgroup
+        // of own columns, at most 16 in all
         const int NWV = cw / 32, C0 = ps_split_col(k.NYP), NTc = k.NYP / 16, KG = (k.NYP + 31) / 32;
         const int ntb0 = (C0 + PS_HC + 15) / 16, ntb1 = NTc - (C0 - PS_HC) / 16;
         if (k.NYP < 64 || (k.NYP & 15) || NTc > 4 * NWV || std::max(ntb0, ntb1) > 2 * NWV || ps_plane_width(k.NYP) > 256 || KG > 16 || k.NYP > 2 * cw) return false;
         if ((size_t)16 * 4 * ps_plane_width(k.NYP) * 2 > ps_tile_bytes(TW) - (size_t)4 * TW * 8) return false;      // (the forward operand planes live in the first tile)
-        if ((k.NYP + 15) / 16 > G) return false;
         mw = 16;
         lds = ps_lds_bytes(TW, k.NYP, k.NZP, k.nz, twist, 16);
         return lds <= (size_t)160 * 1024;
@@ -1386,6 +1430,7 @@ static bool persist_shape(const hmcmt_ctx* ctx, int twist, int& cuPerXcd, int& G
 static int persist_setup(hmcmt_ctx* ctx) {
     const Solver& k = ctx->sv;
     if (const char* e = getenv("HMCMT_PERSIST")) ctx->persistOn = e[0] != '0';
+    if (const char* e = getenv("HMCMT_PS_SPIN")) ctx->persistSpin = (unsigned)std::max(1024l, atol(e));
     ctx->persistCW = 0;
     int cuPerXcd = 0, G = 0, cw = 0, mw = 32, cs = 1;
     size_t lds = 0;
@@ -2099,6 +2144,19 @@ int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out) {
     out[7] = ctx->persistCW ? ctx->persistMW : 0;  // modes per slab
     out[8] = ctx->persistCW ? ctx->persistCS : 0;  // column parts per row block (2: wide meshes)
     out[9] = ctx->persistTimeouts;                 // timed-out waits (the evaluation was redone with the launch-per-phase loop)
+    return 0;
+}
+
+// Test hook: `nblocks` workgroups that each hold 160 KB of LDS (a whole CU) and spin for `ms` milliseconds, on a stream of their
+// own -- returns at once.  What another application on the device does to the persistent kernel's co-residency (tests/test_gpu_persist.py).
+int hmcmt_debug_hog(hmcmt_ctx* ctx, int32_t nblocks, int32_t ms) {
+    if (!ctx || nblocks < 1 || nblocks > 4096 || ms < 0 || ms > 10000) return HMCMT_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    static hipStream_t hogStream = nullptr;
+    if (!hogStream) HIPCHK(hipStreamCreateWithFlags(&hogStream, hipStreamNonBlocking));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hog), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(k_hog, dim3(nblocks), dim3(64), 160 * 1024, hogStream, (long long)ms * 100000ll, (int*)nullptr);   // (wall_clock64: 100 MHz)
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -53,7 +53,7 @@ constexpr int PS_J = PS_ROWS / 2;                 // tile rows per thread
 constexpr int PS_NO = PS_OWN / 2;                 // own rows per thread: j = PS_HALO .. PS_J - 1
 constexpr int PS_HC = 8;                          // column parts: halo columns kept of the neighbouring part (>= PS_HALO, the depth of the chain)
 constexpr int PS_DONE = 0x7fffffff;               // progress word: the kernel has ended
-constexpr unsigned PS_SPIN_LIMIT = 1u << 22;      // polls (~1 us each) before a wait gives up
+constexpr unsigned PS_SPIN_LIMIT = 1u << 22;      // polls (~1 us each) before a wait gives up (PsConst::spinLimit; HMCMT_PS_SPIN)
 
 // Launch-invariant state of the kernel, in DEVICE memory (one copy per context, refreshed by launch_persist when a field changes).
 // The kernel reads it through a constant-address-space pointer (scalar loads) that is laundered at every phase (PS_PHASE): a
@@ -64,6 +64,7 @@ struct PsConst {
     int G, GZ, slots;          // workgroups per system (GZ row blocks x column parts), row blocks, system slots per XCD
     int C0, TW, PLW;           // column parts: first column of part 1; tile width (own + halo columns); width of the forward transform's operand planes
     int syncWords;             // words of `sync` (+ exitCnt, fail behind it): zeroed by the last workgroup to leave
+    unsigned spinLimit;        // polls before a wait gives up (PS_SPIN_LIMIT; HMCMT_PS_SPIN)
     float wJ;                  // damping of the Jacobi sweeps (the factor k_coef_all folds into Solver::dinv)
     const double *omega, *ofz, *dM, *cY, *cZ;
     const float4* cf32;
@@ -113,13 +114,13 @@ __device__ __forceinline__ c32 ps_ld_c32(const float2* p) { const float2 v = ps_
 __device__ __forceinline__ double ps_ld_f64(const double* p) {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
-__device__ __forceinline__ bool ps_wait(unsigned* cnt, unsigned target, int* fail) {
+__device__ __forceinline__ bool ps_wait(unsigned* cnt, unsigned target, int* fail, unsigned limit) {
     for (unsigned spins = 0;; ++spins) {
         if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
         __builtin_amdgcn_s_sleep(1);
         if ((spins & 0x3ff) == 0x3ff) {
             if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2) return false;      // (1 = ANOTHER group was misplaced: its systems are untouched, this one finishes its own)
-            if (spins > PS_SPIN_LIMIT) { __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+            if (spins > limit) { __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
         }
     }
 }
@@ -161,7 +162,7 @@ __device__ __forceinline__ void ps_publish(u4v* rec, const double (&v)[NV], unsi
     }
 }
 template <int NV>
-__device__ __forceinline__ bool ps_collect(const u4v* recSys, int which, int G, unsigned long long tag, double (&tot)[NV], int* fail, int lane) {   // wave 0, all lanes
+__device__ __forceinline__ bool ps_collect(const u4v* recSys, int which, int G, unsigned long long tag, double (&tot)[NV], int* fail, int lane, unsigned limit) {   // wave 0, all lanes
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u4v*>(recSys), 0, MAXNB * 2 * 8 * 16, 0x00020000);
     const unsigned off = (unsigned)(((min(lane, G - 1) * 2 + which) * 8) * 16);
     for (unsigned spins = 0;; ++spins) {
@@ -185,7 +186,7 @@ __device__ __forceinline__ bool ps_collect(const u4v* recSys, int which, int G, 
         __builtin_amdgcn_s_sleep(1);
         if ((spins & 0x3ff) == 0x3ff) {
             if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2) return false;      // (1 = ANOTHER group was misplaced: its systems are untouched, this one finishes its own)
-            if (spins > PS_SPIN_LIMIT) { if (lane == 0) __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+            if (spins > limit) { if (lane == 0) __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
         }
     }
 }
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
         __hip_atomic_fetch_or(sy + 2, (1u << ps_xcc_id()) | forced, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(sy + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!ps_wait(sy + 1, (unsigned)G, kb->fail)) sflag[0] = 2;
+        if (!ps_wait(sy + 1, (unsigned)G, kb->fail, kb->spinLimit)) sflag[0] = 2;
         else if (__popc(__hip_atomic_load(sy + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 1) {
             // (every workgroup of the group reads the same word behind the same arrivals: they all leave, their systems untouched
             //  and still active; the other groups finish theirs -- ps_wait / ps_collect give up on a TIMED-OUT wait only)
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
     };
     auto sys_wait = [&]() -> bool {     // all threads
         ++epoch;
-        if (tid == 0 && !ps_wait(sy, (unsigned)G * epoch, kb->fail)) sflag[0] = 2;
+        if (tid == 0 && !ps_wait(sy, (unsigned)G * epoch, kb->fail, kb->spinLimit)) sflag[0] = 2;
         __syncthreads();
         return sflag[0] == 0;
     };
@@ -1066,7 +1067,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             // R1, second half: wave 0 collects the G records (no counter, no second round trip), the totals go round through LDS
             if (wave == 0) {
                 double t4[4] = {0, 0, 0, 0};
-                const bool okc = ps_collect<4>(recS(), 0, G, L.tagBase + 2ull * (unsigned)it, t4, kb->fail, lane);
+                const bool okc = ps_collect<4>(recS(), 0, G, L.tagBase + 2ull * (unsigned)it, t4, kb->fail, lane, kb->spinLimit);
                 if (lane == 0) { sh[64] = t4[0]; sh[65] = t4[1]; sh[66] = t4[2]; sh[67] = t4[3]; if (!okc) sflag[0] = 2; }
             }
             __syncthreads();                                                   // (also completes z's tile)
@@ -1163,7 +1164,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             PS_STAMP(9)
             if (wave == 0) {                                                   // R2
                 double t2[2] = {0, 0};
-                const bool okc = ps_collect<2>(recS(), 1, G, L.tagBase + 2ull * (unsigned)it + 1ull, t2, kb->fail, lane);
+                const bool okc = ps_collect<2>(recS(), 1, G, L.tagBase + 2ull * (unsigned)it + 1ull, t2, kb->fail, lane, kb->spinLimit);
                 if (lane == 0) { sh[68] = t2[0]; sh[69] = t2[1]; if (!okc) sflag[0] = 2; }
             }
             __syncthreads();

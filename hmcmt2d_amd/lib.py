@@ -118,6 +118,7 @@ def load_library():
     lib.hmcmt_debug_precond.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_persist_precond.argtypes = [vp, C.c_int32, c_double_p, c_double_p]
     lib.hmcmt_persist_info.argtypes = [vp, c_int64_p]
+    lib.hmcmt_debug_hog.argtypes = [vp, C.c_int32, C.c_int32]
     lib.hmcmt_guard.argtypes = [vp, c_double_p]
     lib.hmcmt_debug_fdm_fwd.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_back_post.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_double_p]
@@ -125,7 +126,7 @@ def load_library():
                  "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async",
                  "hmcmt_wait", "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead",
                  "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond",
-                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard"):
+                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -136,7 +137,7 @@ EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "h
                     "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async", "hmcmt_wait",
                     "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead", "hmcmt_dims",
                     "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
-                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
+                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
                     "hmcmt_comm_last_error"]
 
 
@@ -189,6 +190,8 @@ class SampleComm:
 
 class HipContext:
     """One GPU context: the drop-in for the reference's per-call solver state."""
+    live = 0          # contexts created and not yet closed in this process (a second one on a device switches BOTH to the
+                      # launch-per-phase loop: tests/conftest.py fails a test that leaves one behind)
 
     def __init__(self, mtMesh, mtData, invParam, device_id=0, precond="fdmj", tol=None, maxit=None,
                  verify=False, check_every=None, warm_start=True, fdm_precision="mixed"):
@@ -214,6 +217,7 @@ class HipContext:
         if rc != 0:
             raise HmcmtError(rc, (self.lib.hmcmt_last_error(None) or b"").decode())
         self.h = h
+        HipContext.live += 1
         d = (C.c_int32 * 7)()
         self.lib.hmcmt_dims(self.h, d)
         self.NYP, self.NZP, self.S, self.ny, self.nz, self.zid, self.nblk = list(d)
@@ -409,6 +413,10 @@ class HipContext:
         return dict(zip(("threads_half", "workgroups_per_system", "slots_per_xcd", "enabled", "solves", "placement_fallbacks", "usable_now", "slab_modes",
                          "column_parts", "timeouts"), (int(x) for x in out)))
 
+    def debug_hog(self, nblocks, ms):
+        """Test hook: nblocks workgroups holding a CU's LDS each for ms milliseconds on a stream of their own (returns at once)."""
+        self._check(self.lib.hmcmt_debug_hog(self.h, int(nblocks), int(ms)))
+
     def debug_persist_precond(self, r, sweeps=1):
         """z = P^-1 r by the persistent solve kernel's preconditioner (kernels_persist.h)."""
         r = self._vec(r)
@@ -420,6 +428,7 @@ class HipContext:
         if getattr(self, "h", None):
             self.lib.hmcmt_destroy(self.h)
             self.h = None
+            HipContext.live -= 1
 
     def __del__(self):
         try:

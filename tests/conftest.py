@@ -38,3 +38,26 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _no_context_left_alive(request):
+    """A HipContext left alive by one test silently moves every later context of the process to the launch-per-phase loop
+    (one persistent kernel per device: hmcmt_persist_info 'usable_now') -- a parity test would then test the other solver
+    without saying so.  A test that leaks a context fails here, and the leak is cleaned up for the tests behind it."""
+    if "gpu" not in request.keywords:
+        yield
+        return
+    import gc
+    from hmcmt2d_amd.lib import HipContext
+    before = HipContext.live              # (contexts of module-scoped fixtures: set up before this one, theirs to close)
+    known = {id(o) for o in gc.get_objects() if isinstance(o, HipContext) and getattr(o, "h", None)} if before else set()
+    yield
+    if HipContext.live > before:
+        gc.collect()                      # (contexts dropped without close(): __del__ closes them)
+    left = HipContext.live - before
+    if left > 0:
+        for o in gc.get_objects():
+            if isinstance(o, HipContext) and getattr(o, "h", None) and id(o) not in known:
+                o.close()
+        pytest.fail(f"{left} HipContext(s) left open by this test")

@@ -18,8 +18,9 @@ from tests.helpers import GOLDEN, make_problem, oracle_eval, relmax
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def tiny_ctx():
+    # (per test, not per module: a context that outlives its test moves every context created meanwhile to the launch-per-phase loop)
     mesh, data, inv, m = make_problem("tiny")
     ctx = HipContext(mesh, data, inv, verify=True)
     yield mesh, data, inv, m, ctx
@@ -650,17 +651,25 @@ def test_device_resident_trajectories_match_the_host_entry_point():
     ctx.close()
 
 
-def test_concurrent_chains_on_one_gpu_equal_sequential_ones():
+def test_concurrent_chains_on_one_gpu_equal_sequential_ones(monkeypatch):
     """parallelHMCSampler(chains_per_gpu=2): two chains of this rank run concurrently on the GPU (one context and one
-    host thread each) -- the samples must be the ones the same chains produce one after another."""
+    host thread each) -- the samples must be the ones the same chains produce one after another.  Concurrent contexts run
+    the launch-per-phase loop (one persistent kernel per device); with the sequential chains on that solver too
+    (HMCMT_PERSIST=0) the samples are the same BITS -- no cross-talk between the contexts -- and against the sequential
+    chains' default solver, the persistent kernel, they agree to the solver tolerance with the same accept decisions."""
     from hmcmt2d_amd import sampler
     mesh, data, inv, m = make_problem("tiny")
     prior = HMCPrior(totalsamples=3, burninsamples=1, dt=0.02, timestep=[2, 3], sigBounds=[1e-4, 1.0])
+    seq_p = sampler.parallelHMCSampler(mesh, data, inv, prior, nchains=3, seed=4)
+    con_p = sampler.parallelHMCSampler(mesh, data, inv, prior, nchains=3, seed=4, chains_per_gpu=2)     # (its third chain runs alone: the persistent kernel)
+    monkeypatch.setenv("HMCMT_PERSIST", "0")
     seq = sampler.parallelHMCSampler(mesh, data, inv, prior, nchains=3, seed=4)
     con = sampler.parallelHMCSampler(mesh, data, inv, prior, nchains=3, seed=4, chains_per_gpu=2)
     for c in range(3):
         assert np.array_equal(seq[0][c], con[0][c]) and np.array_equal(seq[2][c], con[2][c])
         assert np.array_equal(seq[1][c].acceptstats, con[1][c].acceptstats)
+        assert relmax(seq_p[0][c], con_p[0][c]) < 1e-7 and relmax(seq_p[2][c], con_p[2][c]) < 1e-7
+        assert np.array_equal(seq_p[1][c].acceptstats, con_p[1][c].acceptstats)
 
 
 def test_library_allgather_of_sample_blocks_over_rccl():

@@ -46,6 +46,15 @@ def _check(ctx, m, pred_ref, misfit_ref, grad_refs, inv, mesh, deep_rows=5, grad
     return pred, misfit, grad
 
 
+def _ran_the_persistent_kernel(ctx, parts=None):
+    """Which solver a parity test tested: the one-launch-per-solve kernel, with the expected number of column
+    parts -- not, silently, the launch-per-phase loop (a context leaked by an earlier test, a lost device lock)."""
+    info = ctx.persist_info()
+    assert info["usable_now"] == 1 and info["enabled"] == 1 and info["solves"] >= 2 and info["placement_fallbacks"] == 0 and info["timeouts"] == 0, info
+    if parts is not None:
+        assert info["column_parts"] == parts, info
+
+
 def test_cfg1_full_parity():
     """BASELINE configs[0]: the dprism example mesh (96x49 + 7 air rows), 2-layer model, 4 frequencies -- oracle live
     and the committed golden."""
@@ -59,6 +68,7 @@ def test_cfg1_full_parity():
     ny = mesh.gridSize[0]; zid = len(mesh.airLayer)
     rows = slice(zid * (ny + 1), (zid + 2) * (ny + 1))
     assert relmax(ex[rows], g["exTE_rx"]) < 1e-9 and relmax(hx[rows], g["hxTM_rx"]) < 1e-9
+    _ran_the_persistent_kernel(ctx, 1)
     ctx.close()
 
 
@@ -85,6 +95,7 @@ def test_cfg3_mesh_frequency_subset_parity_and_full_run_agreement():
     #  same absolute error: 3e-7 of its own maximum (measured 2e-8 .. 1e-7), i.e. 1e-10 of the rough state's.
     _, _, g_true = _check(ctx, m_true, g["pred_true"], float(g["misfit_true"]), g["grad_true"], inv, mesh, grad_tol=3e-7, misfit_tol=2e-8)
     assert np.abs(g_true - g["grad_true"]).max() < 1e-9 * np.abs(g["grad"]).max()
+    _ran_the_persistent_kernel(ctx, 1)
     ctx.close()
     # full headline problem: 16 frequencies, the subset's observations at the subset's frequencies
     ctx16 = HipContext(mesh, data16, inv16, verify=True)
@@ -97,6 +108,7 @@ def test_cfg3_mesh_frequency_subset_parity_and_full_run_agreement():
     ea16, ha16 = ctx16.fields(adjoint=True)
     for a, b in ((ex16[:, fidx], ex), (hx16[:, fidx], hx), (ea16[:, fidx], ea), (ha16[:, fidx], ha)):
         assert np.abs(a - b).max() <= 1e-10 * np.abs(b).max()
+    _ran_the_persistent_kernel(ctx16, 1)
     ctx16.close()
 
 
@@ -123,12 +135,15 @@ def test_cfg3_all_sixteen_frequencies_parity():
     for _ in range(2):
         pred, misfit, grad = ctx.grad(m + 0.0)
     assert relmax(pred, g["pred"]) < PRED_TOL and gerr_split(grad, g["grad"], inv, mesh)[0] < GRAD_TOL
+    info = ctx.persist_info()            # the headline shape of the kernel: 8 workgroups of 512 threads per system, 4 systems per XCD at a time
+    assert info["threads_half"] == 256 and info["workgroups_per_system"] == 8 and info["slots_per_xcd"] == 4 and info["solves"] >= 6
+    _ran_the_persistent_kernel(ctx, 1)
     ctx.close()
 
 
 def test_cfg5_mesh_frequency_subset_parity_and_full_run_agreement():
-    """BASELINE configs[4]'s mesh (400x200 cells + 7 air rows, 82 194 unknowns per system: the wide-mesh kernels, separate
-    transform / tridiagonal launches) with 3 of its 32 frequencies (100, 0.59, 0.01 Hz): predData / misfit / gradient
+    """BASELINE configs[4]'s mesh (400x200 cells + 7 air rows, 82 194 unknowns per system: since round 5 the persistent kernel
+    with two column parts per row block; rounds 1-4: the wide-mesh launch-per-phase kernels) with 3 of its 32 frequencies (100, 0.59, 0.01 Hz): predData / misfit / gradient
     against the oracle's golden at the rough state and at the true model; then the full 32-frequency context must give,
     at the subset's frequencies, the subset run's predicted data."""
     g = np.load(os.path.join(GOLDEN, "cfg5s.npz"))
@@ -152,6 +167,9 @@ def test_cfg5_mesh_frequency_subset_parity_and_full_run_agreement():
     m_true = np.log(sig_true[inv.activeIdx])
     _, _, g_true = _check(ctx, m_true, g["pred_true"], float(g["misfit_true"]), g["grad_true"], inv, mesh, grad_tol=3e-7, misfit_tol=2e-8, res_tol=2e-8)
     assert np.abs(g_true - g["grad_true"]).max() < 1e-9 * np.abs(g["grad"]).max()
+    info = ctx.persist_info()            # the wide mesh runs the persistent kernel with two column parts: 15 row blocks x 2 = 30 workgroups, one system per XCD
+    assert info["workgroups_per_system"] == 30 and info["slots_per_xcd"] == 1 and info["slab_modes"] == 16
+    _ran_the_persistent_kernel(ctx, 2)
     ctx.close()
     # all 32 frequencies (the stress configuration itself): the subset's systems inside the full batch
     n32 = len(data32.rxID)
@@ -163,6 +181,7 @@ def test_cfg5_mesh_frequency_subset_parity_and_full_run_agreement():
     pred32, _, _ = ctx32.grad(m)
     assert ctx32.stats()["status"] == 0 and ctx32.stats()["true_res_max"] < 2e-8
     assert relmax(pred32[sel], g["pred"]) < PRED_TOL
+    _ran_the_persistent_kernel(ctx32, 2)
     ctx32.close()
 
 
@@ -186,6 +205,7 @@ def test_reference_example_directories(name):
     ny = mesh.gridSize[0]; zid = len(mesh.airLayer)
     rows = slice(zid * (ny + 1), (zid + 2) * (ny + 1))
     assert relmax(ex[rows], g["exTE_rx"]) < 1e-9 and relmax(hx[rows], g["hxTM_rx"]) < 1e-9
+    _ran_the_persistent_kernel(ctx, 1)
     ctx.close()
 
 

@@ -248,3 +248,122 @@ def test_tall_mesh_runs_the_persistent_kernel_with_16_mode_slabs(monkeypatch):
     assert s1["status"] == 0 and s1["true_res_max"] < 1e-9 and s1["fallback_solves"] == 0
     assert abs(s1["iters_fwd_max"] - s0["iters_fwd_max"]) <= 1 and abs(s1["iters_adj_max"] - s0["iters_adj_max"]) <= 1
     assert relmax(p1, p0) < 1e-9 and abs(f1 - f0) / abs(f0) < 1e-9 and relmax(g1, g0) < 1e-8
+
+
+# ---- round 5: column parts (two workgroups per row block: meshes wider than one tile), robustness of the fallbacks ----
+
+@pytest.mark.parametrize("sweeps", [1, 2])
+def test_preconditioner_with_column_parts_is_the_launch_per_phase_one(monkeypatch, sweeps):
+    """HMCMT_PERSIST_CS=2 forces the two-part kernel onto a mesh one tile would hold (cfg2: 64 padded columns = 32 + 32, a system
+    = 3 row blocks x 2 parts): the forward transform as the sum of two partial products, the halo columns, the back transform of
+    all modes per part -- the same operator as the launch-per-phase kernels' (and as the one-part kernel's) to rounding."""
+    monkeypatch.setenv("HMCMT_PERSIST_CS", "2")
+    mesh, data, inv, m = make_problem("cfg2")
+    ctx = _ctx(monkeypatch, mesh, data, inv, persist=False, sweeps=sweeps)
+    ctx.forward(m)
+    info = ctx.persist_info()
+    assert info["column_parts"] == 2 and info["workgroups_per_system"] == 6 and info["slab_modes"] == 16
+    shape = (ctx.S, ctx.NZP, ctx.NYP)
+    rng = np.random.default_rng(3)
+    x = np.zeros(shape, complex)
+    x[:, 1:ctx.nz, 1:ctx.ny] = rng.standard_normal((ctx.S, ctx.nz - 1, ctx.ny - 1)) + 1j * rng.standard_normal((ctx.S, ctx.nz - 1, ctx.ny - 1))
+    for v in (x, np.cumsum(np.cumsum(x, axis=1), axis=2) / 50.0 * (np.abs(x) > 0)):
+        z0 = ctx.debug_precond(v).reshape(shape)
+        z1 = ctx.debug_persist_precond(v, sweeps).reshape(shape)
+        assert max(relmax(z1[s], z0[s]) for s in range(ctx.S)) < 2e-5
+    ctx.close()
+
+
+@pytest.mark.parametrize("sweeps", [1, 2])
+def test_solve_with_column_parts_equals_the_launch_per_phase_loop_and_the_oracle(monkeypatch, sweeps):
+    monkeypatch.setenv("HMCMT_PERSIST_CS", "2")
+    mesh, data, inv, m = make_problem("cfg2")
+    res = {}
+    for persist in (False, True):
+        ctx = _ctx(monkeypatch, mesh, data, inv, persist, sweeps, verify=True)
+        res[persist] = ctx.grad(m) + (ctx.stats(), ctx.persist_info())
+        if persist:
+            a = ctx.grad(m)
+            b = ctx.grad(m + 0.0)                  # bitwise repeatable, column parts as well (fixed-order sums, bit-identical halo copies)
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
+        ctx.close()
+    (p0, f0, g0, s0, i0), (p1, f1, g1, s1, i1) = res[False], res[True]
+    assert i1["column_parts"] == 2 and i1["solves"] == 2 and i1["placement_fallbacks"] == 0 and i1["timeouts"] == 0
+    assert s1["status"] == 0 and s1["fallback_solves"] == 0 and s1["true_res_max"] < 1e-9
+    assert abs(s1["iters_fwd_max"] - s0["iters_fwd_max"]) <= 1 and abs(s1["iters_adj_max"] - s0["iters_adj_max"]) <= 1
+    assert relmax(p1, p0) < 1e-9 and abs(f1 - f0) / abs(f0) < 1e-9 and relmax(g1, g0) < 1e-8
+    po, mo, go = oracle_eval(mesh, data, inv, m)
+    assert relmax(p1, po) < 1e-9 and abs(f1 - mo) / mo < 1e-9
+    shallow, deep = gerr_split(g1, go, inv, mesh)
+    assert shallow < 1e-8 and deep < 1e-7
+
+
+def test_wide_ragged_mesh_runs_the_column_parts_against_the_launch_loop_and_the_oracle(monkeypatch):
+    """301 x 19 cells (+3 air rows), masked data, a fixed cell: wider than one tile, so the kernel runs with two column parts by
+    its own choice (304 padded columns = 160 + 144; the K-group of 32 columns that straddles the split is shared by the parts'
+    partial products; 2 row blocks x 2 parts per system) -- persistent kernel vs launch-per-phase loop vs the oracle."""
+    mesh, data, inv, m = ragged_problem(301, 19, 2, 6, 4, 3)
+    res = {}
+    for persist in (False, True):
+        ctx = _ctx(monkeypatch, mesh, data, inv, persist, 2, verify=True)
+        res[persist] = ctx.grad(m) + (ctx.stats(), ctx.persist_info())
+        ctx.close()
+    (p0, f0, g0, s0, i0), (p1, f1, g1, s1, i1) = res[False], res[True]
+    assert i1["column_parts"] == 2 and i1["solves"] == 2 and i1["workgroups_per_system"] == 4 and i0["solves"] == 0
+    assert s1["status"] == 0 and s1["true_res_max"] < 1e-9 and s1["fallback_solves"] == 0
+    assert abs(s1["iters_fwd_max"] - s0["iters_fwd_max"]) <= 1 and abs(s1["iters_adj_max"] - s0["iters_adj_max"]) <= 1
+    assert relmax(p1, p0) < 1e-9 and abs(f1 - f0) / abs(f0) < 1e-9 and relmax(g1, g0) < 1e-8
+    po, mo, go = oracle_eval(mesh, data, inv, m)
+    assert relmax(p1, po) < 1e-9 and abs(f1 - mo) / mo < 1e-9 and relmax(g1, go) < 1e-7
+
+
+def test_a_misplaced_group_leaves_the_other_groups_results_intact(monkeypatch):
+    """hmcmt_debug_flags bit 2: the first system group of the next launch fails its placement check (as if its workgroups were not
+    on one XCD).  Its systems stay untouched and active; every OTHER group finishes its systems (a running group gives up only on a
+    timed-out wait, not on another group's misplacement -- ADVICE r4: it used to leave with x advanced and r in registers); the
+    host's launch-per-phase loop takes what is left.  Results to the oracle's, true residual checked."""
+    mesh, data, inv, m = make_problem("cfg2")
+    ctx = _ctx(monkeypatch, mesh, data, inv, True, 2, verify=True)
+    ctx.debug_flags(fail_placement=True)
+    p, f, g = ctx.grad(m)
+    st, info = ctx.stats(), ctx.persist_info()
+    assert info["placement_fallbacks"] == 1 and info["enabled"] == 0 and st["status"] == 0 and st["true_res_max"] < 1e-9
+    po, mo, go = oracle_eval(mesh, data, inv, m)
+    assert relmax(p, po) < 1e-9 and abs(f - mo) / mo < 1e-9 and relmax(g, go) < 1e-7
+    p2, f2, g2 = ctx.grad(m + 0.01)                        # ... and the context goes on with the launch-per-phase loop
+    assert ctx.stats()["status"] == 0 and ctx.persist_info()["solves"] == 1
+    ctx.close()
+
+
+def test_a_timed_out_wait_falls_back_to_the_launch_per_phase_loop(monkeypatch):
+    """A foreign kernel whose backlog of workgroups keeps every CU busy (hmcmt_debug_hog: 1500 workgroups with a CU's whole LDS
+    each, 100 ms apiece: six rounds over the chip) competes with the persistent kernel's workgroups for the CUs that come free:
+    its grid is partly resident, the placed workgroups wait for the others, the bounded waits (HMCMT_PS_SPIN shortens them to
+    milliseconds here) give up, the kernel drains.  The evaluation used to end with HMCMT_EHIP -- a 10 000-sample chain died on
+    it; now the context leaves the persistent kernel and the evaluation is redone with the launch-per-phase loop.  (Which of the
+    bounded waits fails -- or the placement check -- depends on the dispatcher; up to three tries to see one.)"""
+    import time
+    monkeypatch.setenv("HMCMT_PS_SPIN", "2048")
+    mesh, data, inv, m = make_problem("cfg2")
+    hit = False
+    for attempt in range(3):
+        ctx = _ctx(monkeypatch, mesh, data, inv, True, 2)
+        ctx.grad(m)
+        assert ctx.persist_info()["solves"] == 2 and ctx.persist_info()["timeouts"] == 0
+        ctx.debug_hog(1500, 100)
+        time.sleep(0.02)                                   # (the hog is resident before the solve is launched)
+        p, f, g = ctx.grad(m + 0.01)                       # must succeed whatever the dispatcher does
+        info, st = ctx.persist_info(), ctx.stats()
+        assert st["status"] == 0
+        hit = info["timeouts"] + info["placement_fallbacks"] >= 1
+        if hit:
+            assert info["enabled"] == 0 and info["usable_now"] == 0
+        po, mo, go = oracle_eval(mesh, data, inv, m + 0.01)
+        assert relmax(p, po) < 1e-9 and abs(f - mo) / mo < 1e-9 and relmax(g, go) < 1e-7
+        ctx.grad(m + 0.02)                                 # ... and the context goes on
+        assert ctx.stats()["status"] == 0
+        ctx.close()
+        time.sleep(0.8)                                    # (the hog's backlog drains)
+        if hit:
+            break
+    assert hit, "no wait timed out in three tries: the hog did not displace the persistent kernel"

@@ -116,20 +116,25 @@ def test_sweeps_are_chosen_per_solve(monkeypatch):
     assert relmax(p_auto, p1) < 1e-9
 
 
+@pytest.mark.parametrize("persist", ["1", "0"])
 @pytest.mark.parametrize("sweeps", ["1", "2"])
-def test_wide_mesh_path_against_the_oracle(sweeps, monkeypatch):
-    """Meshes wider than 256 nodes run the separate forward / back kernels (k_transform_lp, k_thomas32, k_post); with two
-    sweeps the back half is k_transform_lp<1> + k_post_w2.  A ragged 270-cell-wide problem (NYP = 272), rough model,
-    both smoothers against the oracle."""
+def test_wide_mesh_path_against_the_oracle(sweeps, persist, monkeypatch):
+    """Meshes wider than 256 nodes: since round 5 the persistent kernel with two column parts per row block (272 padded columns =
+    144 + 128, 8.5 K-groups of 32: the straddling one is shared by the parts' partial products); with HMCMT_PERSIST=0 -- and for
+    second contexts, shared devices, meshes beyond its LDS -- the separate forward / back kernels of the launch-per-phase loop
+    (k_transform_lp, k_thomas32, k_post; two sweeps: k_transform_lp<1> + k_post_w2).  A ragged 270-cell-wide problem, rough
+    model, both smoothers, both paths against the oracle."""
     from tests.helpers import ragged_problem
     monkeypatch.setenv("HMCMT_SWEEPS", sweeps)
+    monkeypatch.setenv("HMCMT_PERSIST", persist)
     mesh, data, inv, m = ragged_problem(270, 14, 2, 4, 4, 3)
     ny, nt = mesh.gridSize
     mm = np.clip(m + 0.8 * np.random.default_rng(3).standard_normal(m.size), LO, HI)
     ctx = HipContext(mesh, data, inv, verify=True)
     assert ctx.NYP > 256
     pred, misfit, grad = ctx.grad(mm)
-    st = ctx.stats()
+    st, info = ctx.stats(), ctx.persist_info()
+    assert info["column_parts"] == 2 and info["solves"] == (2 if persist == "1" else 0) and info["placement_fallbacks"] == 0, info
     assert st["status"] == 0 and st["true_res_max"] < 1e-9 and st["smoother_sweeps"] == 11 * int(sweeps), st
     po, mo, go = oracle_eval(mesh, data, inv, mm)
     noise = (0.0, 0.0)
