@@ -1394,24 +1394,25 @@ static bool persist_shape_cs(const hmcmt_ctx* ctx, int twist, int cs, int cuPerX
     const int GZ = (k.nz - 1 + PS_OWN - 1) / PS_OWN;
     G = GZ * cs;
     const int TW = ps_tile_width(k.NYP, cs);
-    if (TW > 256 || G > cuPerXcd || G > MAXNB) return false;
-    cw = TW <= 64 ? 64 : (TW <= 128 ? 128 : 256);
-    if (cs > 1) {
-        // the MFMA work split of the kernel: at most 4 mode tiles (forward) and 2 tile columns (back) per wave, at most 8 K-groups
-        // of own columns, at most 16 in all
-        const int NWV = cw / 32, C0 = ps_split_col(k.NYP), NTc = k.NYP / 16, KG = (k.NYP + 31) / 32;
-        const int ntb0 = (C0 + PS_HC + 15) / 16, ntb1 = NTc - (C0 - PS_HC) / 16;
-        if (k.NYP < 64 || (k.NYP & 15) || NTc > 4 * NWV || std::max(ntb0, ntb1) > 2 * NWV || ps_plane_width(k.NYP) > 256 || KG > 16 || k.NYP > 2 * cw) return false;
-        if ((size_t)16 * 4 * ps_plane_width(k.NYP) * 2 > ps_tile_bytes(TW) - (size_t)4 * TW * 8) return false;      // (the forward operand planes live in the first tile)
-        mw = 16;
-        lds = ps_lds_bytes(TW, k.NYP, k.NZP, k.nz, twist, 16);
-        return lds <= (size_t)160 * 1024;
+    if (!twist || TW > 256 || G > cuPerXcd || G > MAXNB) return false;       // (the slab solves are those of the twisted factorisation)
+    // threads: 2 x the tile's columns -- more where a tall mesh needs the lanes for its tridiagonal sweeps (every lane takes a
+    // chunk of PS_RCMAX rows of one mode and half); modes per slab: 32, or 16 (twice the chunks per half)
+    for (cw = TW <= 64 ? 64 : (TW <= 128 ? 128 : 256); cw <= 256; cw *= 2) {
+        if (cs > 1) {
+            // the MFMA work split of the kernel: at most 4 mode tiles (forward) and 2 tile columns (back) per wave, at most 8 K-groups
+            // of own columns, at most 16 in all
+            const int NWV = cw / 32, C0 = ps_split_col(k.NYP), NTc = k.NYP / 16, KG = (k.NYP + 31) / 32;
+            const int ntb0 = (C0 + PS_HC + 15) / 16, ntb1 = NTc - (C0 - PS_HC) / 16;
+            if (k.NYP < 64 || (k.NYP & 15) || NTc > 4 * NWV || std::max(ntb0, ntb1) > 2 * NWV || ps_plane_width(k.NYP) > 256 || KG > 16 || k.NYP > 2 * cw) continue;
+            if ((size_t)16 * 4 * ps_plane_width(k.NYP) * 2 > ps_tile_bytes(TW) - (size_t)4 * TW * 8) return false;      // (the forward operand planes live in the first tile)
+        }
+        for (mw = cs > 1 ? 16 : 32; mw >= 16; mw /= 2) {
+            if (!ps_slab_fits(k.nz, mw, 2 * cw)) continue;
+            lds = ps_lds_bytes(TW, k.NYP, k.NZP, k.nz, mw, 2 * cw);
+            if (lds <= (size_t)160 * 1024) return true;
+        }
     }
-    // modes per slab of the tridiagonal solves: 32, or 16 where the 32-mode slab of a tall mesh does not fit the LDS beside the planes
-    mw = 32;
-    lds = ps_lds_bytes(TW, k.NYP, k.NZP, k.nz, twist, 32);
-    if (lds > (size_t)160 * 1024) { mw = 16; lds = ps_lds_bytes(TW, k.NYP, k.NZP, k.nz, twist, 16); }
-    return lds <= (size_t)160 * 1024;
+    return false;
 }
 static bool persist_shape(const hmcmt_ctx* ctx, int twist, int& cuPerXcd, int& G, int& cw, int& mw, size_t& lds, int* csOut = nullptr) {
     hipDeviceProp_t prop;

@@ -260,63 +260,18 @@ __device__ __forceinline__ void ps_block_sum4(double& a, double& b, double& c, d
     a = sa; b = sb; c = sc; d = sd;
 }
 
-// ---- the tridiagonal solves of one 32-mode slab of one system: k_fdm_fwd's LDS scheme (twisted factorisation, mirrored
-// bottom half, padded regions: kernels_fdm.h) fed from the rows the G workgroups have transformed -- with TWO slabs in LDS
-// instead of three: a = y * ip and the inverse pivots ip; the coefficients of the two sweeps, o_{r-1} ip and o_r ip (o: the real
-// off-diagonal of the row, a per-row scalar), are formed from the prefetched ip in front of their use, off the serial chain.
-// 78 KB instead of 141 KB at the headline size: the stencil coefficients of the tile stay in LDS behind it (k_cocg_persist).
-constexpr int PSL_PAD = 2 * FW_TB;           // rows between the regions of a slab: FW_TB identity rows behind one, FW_TB zero rows in front of the next
-// (mw: modes per slab -- 32, or 16 where the 32-mode slab of a tall mesh does not fit beside the coefficient planes)
-__host__ __device__ inline size_t ps_slab_bytes(int NZP, int nz, int twist, int mw = 32) {
-    const int n = nz - 1, mid = twist ? (n + 1) / 2 : n;
-    const size_t rl = (size_t)(twist ? mid + 1 : NZP) + PSL_PAD, nreg = twist ? 2 : 1, w = (size_t)mw;
-    return (((size_t)NZP * 4 + 127) & ~(size_t)127) + 2 * nreg * rl * 4 + w * 8 + (2 * FW_TB * w + 2 * nreg * rl * w + 3 * FW_TB * w) * 8;
+// ---- the tridiagonal solves of one slab (MW modes x all rows) of one system: the twisted factorisation of k_fdm_fwd (kernels_fdm.h;
+// rows 1..mid swept from the top, n..mid+1 from the bottom, joined in the middle), fed from the rows the G workgroups have
+// transformed: ps_slab_solve_reg below.  What it keeps in LDS (ps_slab_bytes): the chunks' records of its two sweeps, the inverse
+// pivots of the halves' last rows, and the solved slab for the store pass's transpose.
+constexpr int PSL_PAD = 2 * FW_TB;           // rows between the halves' regions of the solved slab (the row scalars' tables have the same layout)
+constexpr int PS_RCMAX = 8;                  // rows of a chunk of the sweeps (registers: three complex arrays of this length)
+// nt: threads of the workgroup (every lane has a chunk: P = nt / (2 mw) chunks per half; needs mid <= PS_RCMAX P)
+__host__ __device__ inline size_t ps_slab_bytes(int nz, int mw, int nt) {
+    const int n = nz - 1, mid = (n + 1) / 2;
+    return (size_t)32 * nt + (size_t)2 * mw * 8 + (size_t)2 * (mid + 1 + PSL_PAD) * mw * 8;
 }
-// One sweep of a slab's serial chain x <- a - b x over whole blocks of FW_TB rows (DIR = +1 down the region, -1 up), b = f * ip.
-// The chain is ONE wave, and what it costs is that wave's instruction stream -- about 65 cycles a row whatever the arithmetic is
-// written in (unpacked FMAs, v_pk_fma_f32, compiler-scheduled fmaf: 3.25 / 3.23 / 3.07 us for the two sweeps of 50 rows), most of it
-// the LDS traffic of a lone wave (MI355X_MICROARCH.md, LDS: a store's operand transfer runs at half rate from one wave).  The rows
-// of the next block are REQUESTED before the chain of the block at hand and multiplied after it, so their LDS latency (three
-// dependent round trips per block when requested and used in one scheduling region: 4.7 us) runs under the chain's FMAs.
-// (Measured and lost: one 16-byte {a, b} record per row and mode, the elimination sweep writing {x, b'} back -- a row is one read,
-//  four FMAs, one write, but the 16-byte write costs the lone wave more than the multiply it saves: sweeps 2.8 us, the strided
-//  store pass +0.6 us.)
-__device__ __forceinline__ c32 ps_cms(c32 a, c32 b, c32 x) {
-    return c32{__builtin_fmaf(b.im, x.im, __builtin_fmaf(-b.re, x.re, a.re)), __builtin_fmaf(-b.im, x.re, __builtin_fmaf(-b.re, x.im, a.im))};
-}
-template <int DIR, int MW>
-__device__ __forceinline__ c32 ps_sweep(c32* pa, const c32* pb, const float* pf, int nblk, c32 pt) {
-    constexpr int D = DIR * MW;
-    c32 a0[FW_TB], b0[FW_TB], a1[FW_TB], b1[FW_TB], q[FW_TB];
-    float g[FW_TB];
-#pragma unroll
-    for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[t * D]; b0[t] = pf[t * DIR] * pb[t * D]; }
-    int bk = 0;
-    for (; bk + 1 < nblk; bk += 2) {
-#pragma unroll
-        for (int t = 0; t < FW_TB; ++t) { a1[t] = pa[(FW_TB + t) * D]; q[t] = pb[(FW_TB + t) * D]; g[t] = pf[(FW_TB + t) * DIR]; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < FW_TB; ++t) { pt = ps_cms(a0[t], b0[t], pt); pa[t * D] = pt; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < FW_TB; ++t) b1[t] = g[t] * q[t];
-#pragma unroll
-        for (int t = 0; t < FW_TB; ++t) { a0[t] = pa[(2 * FW_TB + t) * D]; q[t] = pb[(2 * FW_TB + t) * D]; g[t] = pf[(2 * FW_TB + t) * DIR]; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < FW_TB; ++t) { pt = ps_cms(a1[t], b1[t], pt); pa[(FW_TB + t) * D] = pt; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < FW_TB; ++t) b0[t] = g[t] * q[t];
-        pa += 2 * FW_TB * D; pb += 2 * FW_TB * D; pf += 2 * FW_TB * DIR;
-    }
-    if (bk < nblk) {
-#pragma unroll
-        for (int t = 0; t < FW_TB; ++t) { pt = ps_cms(a0[t], b0[t], pt); pa[t * D] = pt; }
-    }
-    return pt;
-}
+__host__ __device__ inline bool ps_slab_fits(int nz, int mw, int nt) { return nt / (2 * mw) >= 1 && (nz - 1 + 1) / 2 <= PS_RCMAX * (nt / (2 * mw)); }
 
 // per-row scalars of a system's slab sweeps (o of the row's coefficient in the elimination / in the substitution sweep): constant
 // over the solve, so they are formed once per system and live behind the coefficient planes -- in the slab arena they were formed
@@ -345,110 +300,183 @@ __device__ __forceinline__ void ps_slab_tables(PsKP kb, int mode, float* f1, flo
         f1[i] = v1; f2[i] = v2;
     }
 }
-// (CS: column parts -- the slab's rows are the SUM of the parts' partial products yhat + yhat2)
+// ---- Round 5: the same solves with the slab's rows in REGISTERS and the sweeps on every wave.  The LDS scheme above runs the two
+// first-order recurrences of a slab (elimination, substitution: x_i = a_i - b_i x_{i-1}) on ONE wave -- lanes = modes x the two
+// halves of the twisted factorisation --, 50 (cfg3) to 103 (cfg5) dependent rows from each end at ~65 cycles a row of LDS
+// traffic, seven waves idle (3.1 / 5.2 us), behind a 2.4 / 3.3 us pass that stages rows and pivots in LDS.  A first-order linear
+// recurrence splits: a half's rows are cut into P chunks, lane (mode, half, chunk) loads ITS rows of yhat and of the inverse
+// pivots from memory straight into registers, runs the recurrence over them with a zero inflow and, beside it, the product
+// c_i = prod(-b_j) of the chunk so far -- the true value is x_i = x_i(local) + c_i x_in --; the chunks' (last value, last
+// product) go round through LDS (one barrier), every lane chains the P records in front of its chunk (and the other half's: the
+// join of the twisted halves needs both end values), and the substitution sweep does the same in the other direction with the
+// correction of the first folded into its input.  Per lane: RC = 8 rows (P = 8 chunks per half at cfg3, 16 at cfg5) of eight
+// to ten FMAs, twice, + 4 P FMAs of chaining -- no LDS in the dependent chain, every SIMD busy.  The solved rows meet in LDS only
+// for the store pass's transpose (mode-major lanes -> 16-byte rows of eight modes).
+template <int NT, int MW> struct PsChunks { static constexpr int P = NT / (2 * MW); };      // every lane of the workgroup has a chunk (2 .. 16 per half)
+__device__ __forceinline__ c32 ps_cfma(c32 a, c32 b, c32 x) {      // a + b x
+    return c32{__builtin_fmaf(-b.im, x.im, __builtin_fmaf(b.re, x.re, a.re)), __builtin_fmaf(b.im, x.re, __builtin_fmaf(b.re, x.im, a.im))};
+}
 template <int NT, int MW, int CS>
-__device__ __forceinline__ void ps_slab_solve(PsKP kb, char* smem, const float* f1, const float* f2, int s, int slab, int tidx, long long* stp = nullptr) {
-    // (tidx: the caller's OPAQUE copy of tidx -- everything derived from the thread index here is invariant across the
-    //  iterations of the solve, and the compiler hoisted all of it out of the iteration loop into registers it then spilled)
-    constexpr int SW = MW;                              // modes per slab (32, or 16: tall meshes, column parts)
+__device__ __forceinline__ void ps_slab_solve_reg(PsKP kb, char* smem, const float* f1, const float* f2, int s, int slab, int tidx, long long* stp = nullptr) {
+    constexpr int P = PsChunks<NT, MW>::P, NL = 2 * MW * P, RC = PS_RCMAX;      // (chunks of RC rows exactly: rows behind a half's last one are identity rows)
     const int NYP = kb->NYP, NZP = kb->NZP, n = kb->nz - 1, nyi = kb->ny - 1;
-    const int tw = kb->twist, mid = twist_mid(n, tw);
-    const int RCAP = tw ? mid + 1 : NZP, RL = RCAP + PSL_PAD, nreg = tw ? 2 : 1;
-    c32* sj = reinterpret_cast<c32*>(smem + (((long)NZP * 4 + 127) & ~127L) + (long)2 * nreg * RL * 4);
-    c32* sa = sj + SW + 2 * FW_TB * SW;                  // -> region 0, row 0
-    c32* sp = sa + (long)nreg * RL * SW;                 // inverse pivots, same layout
-    auto lidx = [&](int row) { return (tw && row > mid) ? RL + (n + 1 - row) : row; };   // slab row of a matrix row
+    const int mid = twist_mid(n, 1), RL = mid + 1 + PSL_PAD;
+    c32* recF = reinterpret_cast<c32*>(smem);             // [2][P][MW] x {last local value, last product} of the elimination sweep
+    c32* recB = recF + 2 * P * MW * 2;                    // ... of the substitution sweep
+    c32* ipl = recB + 2 * P * MW * 2;                     // [2][MW] inverse pivot of a half's last row (the join)
+    c32* sa = ipl + 2 * MW;                               // [2 RL][MW] the solved slab in the store pass's layout
     const long vs = kb->vstride, so = (long)s * vs;
     const float2* ip32 = kb->ip32 + so;
-    const int cb = slab * SW;                           // first mode of the slab
-    const int lane = tidx & 63, wave = tidx >> 6;
-    // join factor 1 / (1 - c c') of the two halves (item_pivot): requested with the slab's rows, not behind them
-    const int cj = cb + (tidx & (SW - 1));
-    const float2 jfl = *ps_at(ip32, (unsigned)min(cj, NYP - 1));
-    // rows of the slab: a = y * ip, and ip -- two modes (16 bytes) per load, one batch
+    const int cb = slab * MW;
+    const bool act = tidx < NL;
+    const int m = tidx % MW, h = (tidx / MW) & 1, k = tidx / (2 * MW);
+    const int lastH = h == 0 ? mid : n - mid;
+    const int r0 = 1 + k * RC;
+    const bool mok = act && cb + m < nyi;
+    const float* g1 = f1 + h * RL;                        // row scalars of this half (ps_slab_tables)
+    const float* g2 = f2 + h * RL;
+    c32 a[RC], ipv[RC], cc[RC];
+    // ---- rows -> registers: a = yhat (the sum of the column parts' partial products) x inverse pivot
     {
-        constexpr int PB = 4, HW = SW / 2;        // (108 rows x 16 mode pairs over 512 threads: 3.4 pairs per thread)
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(kb->yhat + so), 0, (int)(vs * 8), 0x00020000);
         const __amdgpu_buffer_rsrc_t ry2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>((CS == 1 ? kb->yhat : kb->yhat2) + so), 0, (int)(vs * 8), 0x00020000);
-        for (int b0 = 0; b0 < NZP * HW; b0 += PB * NT) {
-            const int i0 = b0 + tidx;
-            f4v yv[PB], yw[PB], ipf[PB];
-            bool ok0[PB], ok1[PB];
 #pragma unroll
-            for (int u = 0; u < PB; ++u) {
-                const int idx = min(i0 + u * NT, NZP * HW - 1);
-                const int row = idx / HW, c = cb + 2 * (idx % HW);
-                const bool rok = row >= 1 && row <= n;
-                ok0[u] = rok && c < nyi; ok1[u] = rok && c + 1 < nyi;
-                const unsigned e = (unsigned)((rok ? row : 1) * NYP + min(c, NYP - 2));
-                yv[u] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(ry, e * 8u, 0, 16));
-                if (CS > 1) yw[u] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(ry2, e * 8u, 0, 16));
-                ipf[u] = *reinterpret_cast<const f4v*>(ps_at(ip32, e));
+        for (int i = 0; i < RC; ++i) {
+            const int rl = r0 + i;
+            const bool ok = mok && rl <= lastH;
+            const int row = h ? n + 1 - rl : rl;
+            const unsigned e = ok ? (unsigned)(row * NYP + cb + m) : (unsigned)(NYP + 1);
+            const float2 y = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(ry, e * 8u, 0, 16));       // (16 = sc1: other CUs wrote these)
+            a[i] = c32{y.x, y.y};
+            if (CS > 1) { const float2 y2 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(ry2, e * 8u, 0, 16)); cc[i] = c32{y2.x, y2.y}; }
+            const float2 pv = *ps_at(ip32, e);
+            ipv[i] = c32{pv.x, pv.y};
+        }
+#pragma unroll
+        for (int i = 0; i < RC; ++i) {
+            const bool ok = mok && r0 + i <= lastH;
+            if (CS > 1) a[i] = c32{a[i].re + cc[i].re, a[i].im + cc[i].im};
+            ipv[i] = ok ? ipv[i] : c32{0, 0};
+            a[i] = ok ? a[i] * ipv[i] : c32{0, 0};
+        }
+    }
+    // join factor 1 / (1 - c c') of the two halves (item_pivot; row 0 of the inverse pivots)
+    const float2 jfl = *ps_at(ip32, (unsigned)min(cb + m, NYP - 1));
+    if (stp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stp[12] = wall_clock64(); }      // (stamped runs only: the loads have arrived)
+    // ---- elimination sweep over the chunk, zero inflow; rows behind the half's last one carry the value on (identity)
+    {
+        c32 xl = c32{0, 0}, cp = c32{1.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < RC; ++i) {
+            const int rl = r0 + i;
+            if (rl <= lastH) {
+                const c32 nb = (-g1[rl]) * ipv[i];
+                xl = ps_cfma(a[i], nb, xl);
+                cp = nb * cp;
             }
+            a[i] = xl; cc[i] = cp;
+        }
+        if (act) {
+            c32* r = recF + ((h * P + k) * MW + m) * 2;
+            r[0] = xl; r[1] = cp;
+            if (lastH >= r0 && lastH < r0 + RC) {
+                c32 pl = c32{0, 0};
 #pragma unroll
-            for (int u = 0; u < PB; ++u) {
-                const int idx = i0 + u * NT;
-                if (idx < NZP * HW) {
-                    const int row = idx / HW, j = 2 * (idx % HW);
-                    const int l = lidx(row) * SW + j;
-                    if (CS > 1) yv[u] = yv[u] + yw[u];
-                    c32 a0 = c32{0, 0}, p0 = c32{0, 0}, a1 = c32{0, 0}, p1 = c32{0, 0};
-                    if (ok0[u]) { p0 = c32{ipf[u][0], ipf[u][1]}; a0 = c32{yv[u][0], yv[u][1]} * p0; }
-                    if (ok1[u]) { p1 = c32{ipf[u][2], ipf[u][3]}; a1 = c32{yv[u][2], yv[u][3]} * p1; }
-                    sa[l] = a0; sa[l + 1] = a1; sp[l] = p0; sp[l + 1] = p1;
-                }
+                for (int i = 0; i < RC; ++i) if (r0 + i == lastH) pl = ipv[i];
+                ipl[h * MW + m] = pl;
             }
         }
     }
-    for (int idx = tidx; idx < nreg * FW_TB * SW; idx += NT) {
-        const int reg = idx / (FW_TB * SW), o = idx % (FW_TB * SW);
-        const c32 z = c32{0, 0};
-        const long front = (long)reg * RL * SW - (long)FW_TB * SW + o;
-        const int last = tw ? (reg == 0 ? mid : n + 1 - (mid + 1)) : NZP - 1;
-        const long back = ((long)reg * RL + last + 1) * SW + o;
-        sa[front] = z; sp[front] = z;
-        sa[back] = z; sp[back] = c32{-1.f, 0.f};
-    }
-    if (tidx < SW) sj[tidx] = (tw && cj < nyi) ? c32{jfl.x, jfl.y} : c32{1.f, 0.f};
     __syncthreads();
-    if (stp) stp[12] = wall_clock64();
-    if (wave == 0 && lane < nreg * SW && cb + (lane % SW) < nyi) {
-        const int half = lane / SW, col = lane % SW;
-        const int last = tw ? (half == 0 ? mid : n - mid) : n;      // rows 1..last of this lane's region are real
-        const int steps = tw ? mid : n;                             // both halves run the longer count (identity rows)
-        c32* ra = sa + (long)half * RL * SW + col;
-        const c32* rp = sp + (long)half * RL * SW + col;
-        const float* g1 = f1 + half * RL;
-        const float* g2 = f2 + half * RL;
-        c32 pt = ps_sweep<1, SW>(ra + SW, rp + SW, g1 + 1, (steps + FW_TB - 1) / FW_TB, c32{0, 0});
-        pt = ra[last * SW];                                   // (the identity rows left it unchanged)
-        if (tw) {
-            const c32 p2last = g2[last] * rp[last * SW];
-            const float pre = pt.re, pim = pt.im;
-            const float ore = __shfl_xor(pre, SW), oim = __shfl_xor(pim, SW);
-            const c32 xmid = (c32{pre, pim} - p2last * c32{ore, oim}) * sj[col];       // meaningful in the top half
-            const float xre = xmid.re, xim = xmid.im;
-            const float mre = __shfl_xor(xre, SW), mim = __shfl_xor(xim, SW);
-            const c32 xbot = c32{pre, pim} - p2last * c32{mre, mim};
-            pt = half == 0 ? c32{xre, xim} : xbot;
-            ra[last * SW] = pt;
+    c32 xin = c32{0, 0}, xlast = c32{0, 0};
+    if (act) {
+        // the inflow of this chunk, the end values of both halves (chains of P records), the join
+        c32 v = c32{0, 0}, u = c32{0, 0};
+        constexpr int PG = P < 4 ? P : 4;                 // (records in groups of four: all 2 P loads at once are 128 registers at P = 16)
+#pragma unroll 1
+        for (int k0 = 0; k0 < P; k0 += PG) {
+            c32 rx[PG], rc[PG], qx[PG], qc[PG];
+#pragma unroll
+            for (int j = 0; j < PG; ++j) {
+                const c32* r = recF + ((h * P + k0 + j) * MW + m) * 2;
+                const c32* q = recF + (((h ^ 1) * P + k0 + j) * MW + m) * 2;
+                rx[j] = r[0]; rc[j] = r[1]; qx[j] = q[0]; qc[j] = q[1];
+            }
+#pragma unroll
+            for (int j = 0; j < PG; ++j) {
+                if (k0 + j == k) xin = v;
+                v = ps_cfma(rx[j], rc[j], v);
+                u = ps_cfma(qx[j], qc[j], u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        (void)ps_sweep<-1, SW>(ra + (long)(last - 1) * SW, rp + (long)(last - 1) * SW, g2 + (last - 1), (steps - 1 + FW_TB - 1) / FW_TB, pt);
+        const c32 ptTop = h ? u : v, ptBot = h ? v : u;
+        const c32 p2Top = f2[mid] * ipl[m], p2Bot = f2[RL + (n - mid)] * ipl[MW + m];
+        const c32 sj = (cb + m < nyi) ? c32{jfl.x, jfl.y} : c32{1.f, 0.f};
+        const c32 xmid = (ptTop - p2Top * ptBot) * sj;
+        const c32 xbot = ptBot - p2Bot * xmid;
+        xlast = h ? xbot : xmid;
+    }
+    // ---- substitution sweep over the chunk (towards the ends), its input corrected by the inflow of the first
+    {
+        c32 yl = c32{0, 0}, dp = c32{1.f, 0.f};
+#pragma unroll
+        for (int i = RC - 1; i >= 0; --i) {
+            const int rl = r0 + i;
+            if (rl == lastH) { yl = xlast; dp = c32{0, 0}; }
+            else if (rl < lastH) {
+                const c32 x1 = ps_cfma(a[i], cc[i], xin);
+                const c32 nb = (-g2[rl]) * ipv[i];
+                yl = ps_cfma(x1, nb, yl);
+                dp = nb * dp;
+            }
+            a[i] = yl; cc[i] = dp;
+        }
+        if (act) {
+            c32* r = recB + ((h * P + k) * MW + m) * 2;
+            r[0] = yl; r[1] = dp;
+        }
+    }
+    __syncthreads();
+    if (act) {
+        c32 xout = c32{0, 0}, v = c32{0, 0};
+        constexpr int PG = P < 4 ? P : 4;
+#pragma unroll 1
+        for (int k0 = P - PG; k0 >= 0; k0 -= PG) {
+            c32 rx[PG], rc[PG];
+#pragma unroll
+            for (int j = 0; j < PG; ++j) {
+                const c32* r = recB + ((h * P + k0 + j) * MW + m) * 2;
+                rx[j] = r[0]; rc[j] = r[1];
+            }
+#pragma unroll
+            for (int j = PG - 1; j >= 0; --j) {
+                if (k0 + j == k) xout = v;
+                v = ps_cfma(rx[j], rc[j], v);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < RC; ++i) {
+            const int rl = r0 + i;
+            if (rl <= lastH) sa[(h * RL + rl) * MW + m] = ps_cfma(a[i], cc[i], xout);
+        }
     }
     __syncthreads();
     if (stp) stp[13] = wall_clock64();
     // solved slab -> ysol, pre-split for the back transform (store_t32's format), 16-byte stores
     {
-        constexpr int NG = SW / 8;
+        constexpr int NG = MW / 8;
         unsigned short* yb = reinterpret_cast<unsigned short*>(kb->ysol + so);
         for (int idx = tidx; idx < NZP * NG; idx += NT) {
             const int row = idx / NG, j0 = (idx % NG) * 8, c0 = cb + j0;
             if (c0 >= NYP) continue;
-            const c32* src = sa + lidx(row) * SW + j0;
+            const bool rin = row >= 1 && row <= n;
+            const c32* src = sa + ((row > mid) ? RL + (n + 1 - row) : row) * MW + j0;
             u4v pl[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const c32 v0 = src[2 * q], v1 = src[2 * q + 1];
+                const c32 v0 = rin ? src[2 * q] : c32{0, 0}, v1 = rin ? src[2 * q + 1] : c32{0, 0};
                 unsigned hr, lr, hi, li;
                 bf16_split_pk(v0.re, v1.re, hr, lr);
                 bf16_split_pk(v0.im, v1.im, hi, li);
@@ -468,13 +496,13 @@ __device__ __forceinline__ void ps_slab_solve(PsKP kb, char* smem, const float* 
 // planes [24][4][NYP] bf16: all modes of the tile's rows) | the three coefficient planes [24][TW] | the slab sweeps' row scalars.
 // TW = NYP without column parts.
 __host__ __device__ inline size_t ps_tile_bytes(int TW) { return (((size_t)PS_ROWS * TW * 8 + 64 + 255) & ~(size_t)255) + (size_t)4 * TW * 8; }   // tile (+ 64 B over-read pad) + tail
-__host__ __device__ inline size_t ps_shared_bytes(int TW, int NYP, int NZP, int nz, int twist, int mw = 32) {
-    const size_t a = 2 * ps_tile_bytes(TW), b = ps_slab_bytes(NZP, nz, twist, mw), c = TW == NYP ? 0 : (size_t)PS_ROWS * 4 * NYP * 2 + 64;
+__host__ __device__ inline size_t ps_shared_bytes(int TW, int NYP, int nz, int mw, int nt) {
+    const size_t a = 2 * ps_tile_bytes(TW), b = ps_slab_bytes(nz, mw, nt), c = TW == NYP ? 0 : (size_t)PS_ROWS * 4 * NYP * 2 + 64;
     const size_t m = a > b ? (a > c ? a : c) : (b > c ? b : c);
     return (m + 255) & ~(size_t)255;
 }
-__host__ __device__ inline size_t ps_lds_bytes(int TW, int NYP, int NZP, int nz, int twist, int mw = 32) {
-    return 1024 + ps_shared_bytes(TW, NYP, NZP, nz, twist, mw) + (size_t)3 * PS_ROWS * TW * 4 + 64 + (((size_t)2 * ps_tab_floats(NZP, nz, twist) * 4 + 128 + 63) & ~(size_t)63);
+__host__ __device__ inline size_t ps_lds_bytes(int TW, int NYP, int NZP, int nz, int mw, int nt) {
+    return 1024 + ps_shared_bytes(TW, NYP, nz, mw, nt) + (size_t)3 * PS_ROWS * TW * 4 + 64 + (((size_t)2 * ps_tab_floats(NZP, nz, 1) * 4 + 128 + 63) & ~(size_t)63);
 }
 // column parts (CS = 2): part 0 owns the columns [0, C0), part 1 [C0, NYP); a tile = own columns + PS_HC halo columns
 __host__ __device__ inline int ps_split_col(int NYP) { return 16 * ((NYP + 31) / 32); }
@@ -592,10 +620,10 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
     c32* T0 = reinterpret_cast<c32*>(arena);
     c32* T1 = reinterpret_cast<c32*>(arena + tileB);
     unsigned short* PL = reinterpret_cast<unsigned short*>(arena);       // bf16 operand planes of the transforms: the tiles' space
-    float* coE = reinterpret_cast<float*>(arena + ps_shared_bytes(TWc, NYP, kb->NZP, nz, kb->twist, MW));
+    float* coE = reinterpret_cast<float*>(arena + ps_shared_bytes(TWc, NYP, nz, MW, NT));
     const PsPl co{coE, coE + PS_ROWS * TWc, coE + 2 * PS_ROWS * TWc};
     float* const tabF1 = coE + 3 * PS_ROWS * TWc + 16;                      // row scalars of the slab sweeps (ps_slab_tables), per system
-    float* const tabF2 = tabF1 + ps_tab_floats(kb->NZP, nz, kb->twist);
+    float* const tabF2 = tabF1 + ps_tab_floats(kb->NZP, nz, 1);
     // MFMA work split.  NTc: column tiles of 16 of a whole row (modes / mesh columns), KG: K-groups of 32 of a whole row.
     //   without column parts: both transforms produce NTc tiles, at most two per wave (NYP <= 32 NWV);
     //   column parts: the forward transform produces ALL NTc mode tiles from the part's own columns (at most four per wave, two
@@ -873,7 +901,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             if (!sys_sync()) { alive = false; break; }                         // T1: every row of yhat is in the L2
             PS_STAMP(3)
             // ================= tridiagonal solves of this workgroup's mode slabs =================
-            for (int slab = jw; slab < nslab; slab += G) ps_slab_solve<NT, MW, CS>(kb, arena, tabF1, tabF2, s, slab, tidv, stampNow ? L.stamps + (long)blockIdx.x * 16 : nullptr);
+            for (int slab = jw; slab < nslab; slab += G) ps_slab_solve_reg<NT, MW, CS>(kb, arena, tabF1, tabF2, s, slab, tidv, stampNow ? L.stamps + (long)blockIdx.x * 16 : nullptr);
             PS_STAMP(4)
             u4v bbk[8][2];                                                     // the wave's V' fragments of the back transform: in flight during the wait
             {
@@ -894,28 +922,20 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             // iterate of the owners and, two sweeps, t of the own rows (second part of the rho identity: sum of t .* (V y))
             float2 zq[3][2][2];
             {
+                // the operand planes: rows R0 .. R0 + 23 of the solved slabs, every mode, straight into LDS (buffer_load ... lds: a wave
+                // copies 64 consecutive 16-byte units per instruction, no registers in between, all of a wave's ten-odd loads in
+                // flight at once -- round 4 staged them through 24 registers per lane, six at a time).  Rows outside the mesh take
+                // a copy of the nearest row: their products are multiplied away in the epilogue (m = 0).
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(kb->ysol + so()), 0, (int)(kb->vstride * 8), 0x00020000);
                 const int rowU = NYP / 2, n16 = PS_ROWS * rowU;             // 16-byte units per row / in the tile: every mode of the tile's rows
-                constexpr int NU = 6, NBT = CS == 1 ? 1 : 2;                // (column parts: NYP <= 2 CW modes -- two batches)
-                u4v tmp[NU];
-                auto ld_units = [&](int b) {
-#pragma unroll
-                    for (int u = 0; u < NU; ++u) {
-                        const int i = min(tidv + (b * NU + u) * NT, n16 - 1);
-                        const int row = i / rowU, g = R0 + row;
-                        const int gc = min(max(g, 0), nz);
-                        tmp[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (gc * rowU + (i - row * rowU)) * 16, 0, 16);
-                        if (g < 0 || g > nz) tmp[u] = u4v{0u, 0u, 0u, 0u};
-                    }
-                };
-                auto st_units = [&](int b) {
-#pragma unroll
-                    for (int u = 0; u < NU; ++u) {
-                        const int i = tidv + (b * NU + u) * NT;
-                        if (i < n16) reinterpret_cast<u4v*>(PL)[i] = tmp[u];
-                    }
-                };
-                ld_units(0);
+                for (int i0 = wave * 64; i0 < n16; i0 += NT) {
+                    const int i = min(i0 + lanev, n16 - 1);
+                    const int row = i / rowU;
+                    const int gc = min(max(R0 + row, 0), nz);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(PL) + (size_t)i0 * 16), 16,
+                                                             (gc * rowU + (i - row * rowU)) * 16, 0, 0, 16);      // (aux 16 = sc1: other CUs wrote these)
+                }
+                if (tidv < 16) reinterpret_cast<unsigned*>(PL)[PS_ROWS * 4 * NYP / 2 + tid] = 0u;          // the last K-group's over-read pad (n16 is a multiple of 64: no lane writes there)
 #pragma unroll
                 for (int rg = 0; rg < 3; ++rg)
 #pragma unroll
@@ -929,9 +949,6 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                         }
 #pragma unroll
                 for (int j = 0; j < PS_HALO; ++j) rh[j] = ps_ld_c32(ps_at(pubR(), ei(j)));      // the owners' r' (no drift of the local copies)
-                st_units(0);
-                if (NBT > 1) { ld_units(1); st_units(1); }
-                if (tidv < 16) reinterpret_cast<unsigned*>(PL)[PS_ROWS * 4 * NYP / 2 + tid] = 0u;
                 if constexpr (CS > 1) {
                     // a halo COLUMN's copy of r (rows j >= 5): the owners' r', like the halo rows'
                     if (!own() && (iyv < LWh)) {
@@ -943,6 +960,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                     }
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (the planes' direct loads: in LDS before the barrier)
             __syncthreads();
             double ar = 0, ai = 0, zzs = 0;
             {
