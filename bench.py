@@ -225,6 +225,39 @@ def timed(torch, dist, fn):
         gc.enable()
 
 
+def two_chains_leg(torch, HipContext, mesh, data, inv, local, dev, m_true, mref, Ke):
+    """(v) two chains on this GPU at once (what parallelHMCSampler(chains_per_gpu=2) does): two contexts, each confined to half
+    the CUs of every XCD (hmcmt_next_cu_share: CU-masked streams, half the system slots of the persistent kernel each), one host
+    thread per chain; aggregate steps/s of both chains near the true model.  Runs with the bench's own context closed: a context
+    on the whole device overlaps both shares, and all three would use the launch-per-phase loop."""
+    import threading
+    ctxa = HipContext(mesh, data, inv, device_id=local, cu_share=(0, 2))
+    ctxb = HipContext(mesh, data, inv, device_id=local, cu_share=(1, 2))
+    ca = Chain(ctxa, torch, dev, m_true, mref, inv.Wm, seed=7)
+    cb_ = Chain(ctxb, torch, dev, m_true, mref, inv.Wm, seed=8)
+    for c in (ca, cb_):
+        c.run(2 * LTRAJ)
+    th = [threading.Thread(target=c.run, args=(Ke,)) for c in (ca, cb_)]
+    torch.cuda.synchronize()
+    t5 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    t5 = time.perf_counter() - t5
+    res = {"steps_per_s_aggregate": 2 * Ke / t5, "steps_per_chain": Ke,
+           "persistent_solves": [ctxa.persist_info()["solves"], ctxb.persist_info()["solves"]],
+           "slots_per_xcd": [ctxa.persist_info()["slots_per_xcd"], ctxb.persist_info()["slots_per_xcd"]],
+           "state": "two independent chains near the true model on ONE GPU: two contexts, two host threads, "
+                    "each context on half the CUs of every XCD (CU-masked streams), their persistent solve "
+                    "kernels side by side with half the system slots each; compare with near_true_state "
+                    "(ONE chain on the whole device)"}
+    ctxa.close()
+    ctxb.close()
+    return res
+
+
 def spawn_ranks(n):
     """N child processes, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets them), started
     BEFORE this process has made any GPU call (it never makes one: no exec of a process that has initialised the GPU).  Rank 0's
@@ -411,30 +444,6 @@ def main():
         full_prof, full_cnt = ctx.profile_read(), ctx.profile_counters()
         ctx.profile(False)
         ctx.set_options(warm_start=2, tol=1e-11, maxit=2000)
-        # (v) two chains on this GPU at once (what parallelHMCSampler(chains_per_gpu=2) does): a second context, one
-        # host thread per chain; aggregate steps/s of both chains near the true model
-        import threading
-        ctxb = HipContext(mesh, data, inv, device_id=local)
-        ca = Chain(ctx, torch, dev, m_true, mref, inv.Wm, seed=7)
-        cb_ = Chain(ctxb, torch, dev, m_true, mref, inv.Wm, seed=8)
-        for c in (ca, cb_):
-            c.run(2 * LTRAJ)
-        th = [threading.Thread(target=c.run, args=(Ke,)) for c in (ca, cb_)]
-        torch.cuda.synchronize()
-        t5 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        torch.cuda.synchronize()
-        t5 = time.perf_counter() - t5
-        extras["two_chains_per_gpu"] = {"steps_per_s_aggregate": 2 * Ke / t5, "steps_per_chain": Ke,
-                                        "state": "two independent chains near the true model on ONE GPU (two contexts, two host "
-                                                 "threads). Since round 4 a second context makes both use the launch-per-phase loop (two "
-                                                 "persistent kernels cannot share a device), so this leg is round 3's path: compare with "
-                                                 "near_true_state, ONE chain with the persistent kernel -- the lever is superseded (DESIGN 7)"}
-        ctxb.close()
-
     if rank == 0:
         # Algorithmic bytes per launch: U = S*(nz-1)*(ny-1) interior unknowns, complex128 = 16 B,
         # complex64 / split-bf16 = 8 B; the real stencil coefficients are shared by all frequencies of a mode (not
@@ -658,6 +667,9 @@ def main():
             out["allgather"] = gather
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if world == 1 and not args.no_extras:
+            ctx.close()                          # (a context on the whole device overlaps the two chains' shares)
+            out["two_chains_per_gpu"] = two_chains_leg(torch, HipContext, mesh, data, inv, local, dev, m_true, mref, min(K, 48))
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if dist is not None:

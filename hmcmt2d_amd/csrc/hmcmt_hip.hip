@@ -170,6 +170,8 @@ struct hmcmt_ctx {
     unsigned long long persistTag = 0;    // ... the tag base of the next launch
     long long* d_pstamps = nullptr;       // HMCMT_STAMPS=persist
     long long persistSolves = 0, persistFallbacks = 0, persistTimeouts = 0;
+    int shareIdx = 0, shareCnt = 1;       // this context's share of every XCD's CUs (hmcmt_next_cu_share): index, 1 / 2 / 4 parts
+    unsigned shareMask = 0xF;             // ... as quarters
     int persistCS = 1, persistGZ = 0;     // column parts of a row block (2: wide meshes, kernels_persist.h), row blocks per system
     PsConst psShadow{};                   // what d_psConst holds (launch_persist refreshes the device copy when a field differs)
     PsConst* d_psConst = nullptr;         // the kernel's launch-invariant state, read through a constant-address-space pointer
@@ -513,6 +515,12 @@ constexpr double SPIN_LIMIT_S = 60.0;       // a convergence poll that sees no p
 // (Protects hmcmt processes from each other where they share the lock directory; HMCMT_PERSIST_LOCK=0 skips it.)
 constexpr int MAXDEV = 64;
 std::atomic<int> g_liveOnDev[MAXDEV];
+// CU shares (hmcmt_next_cu_share): a context may be confined to 1/2 or 1/4 of the CUs of EVERY XCD -- its streams carry a CU
+// mask -- so that the persistent kernels of 2 or 4 contexts (chains) are co-resident on one device, each with a share of the
+// system slots.  Use of the four quarters per device; a context runs the persistent kernel when it is alone in ALL its quarters.
+std::atomic<int> g_quarterUse[MAXDEV][4];
+thread_local int g_nextShareIdx = 0, g_nextShareCnt = 1;
+static unsigned quarter_mask(int idx, int cnt) { return cnt == 1 ? 0xFu : cnt == 2 ? (idx ? 0xCu : 0x3u) : 1u << idx; }
 struct DevLock { int fd = -1; int refs = 0; bool held = false; long asked = 0; };
 std::mutex g_lockMu;
 DevLock g_devLock[MAXDEV];
@@ -563,7 +571,10 @@ static bool devlock_held(int dev) {
 // the persistent solve kernel applies to the solve at hand (default path, a mesh its tiles fit, alone on the device)
 // (this context is alone on its device in the process, and the process holds the device's lock)
 bool persist_alone(const hmcmt_ctx* ctx) {
-    return ctx->device >= 0 && ctx->device < MAXDEV && g_liveOnDev[ctx->device].load() == 1 && devlock_held(ctx->device);
+    if (ctx->device < 0 || ctx->device >= MAXDEV) return false;
+    for (int q = 0; q < 4; ++q)
+        if (((ctx->shareMask >> q) & 1u) && g_quarterUse[ctx->device][q].load() != 1) return false;
+    return devlock_held(ctx->device);
 }
 bool persist_ok(const hmcmt_ctx* ctx) {
     return ctx->persistOn && ctx->persistCW > 0 && ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0 && persist_alone(ctx);
@@ -1283,7 +1294,13 @@ const char* hmcmt_last_error(const hmcmt_ctx* ctx) { return ctx ? ctx->err.c_str
 
 int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (!ctx) return HMCMT_EINVAL;
-    if (ctx->counted) { if (ctx->device >= 0 && ctx->device < MAXDEV) g_liveOnDev[ctx->device].fetch_sub(1); devlock_unref(ctx->device); ctx->counted = false; }
+    if (ctx->counted) {
+        if (ctx->device >= 0 && ctx->device < MAXDEV) {
+            g_liveOnDev[ctx->device].fetch_sub(1);
+            for (int q = 0; q < 4; ++q) if ((ctx->shareMask >> q) & 1u) g_quarterUse[ctx->device][q].fetch_sub(1);
+        }
+        devlock_unref(ctx->device); ctx->counted = false;
+    }
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->side) hipStreamSynchronize(ctx->side);      // (side-stream work of an evaluation nobody waited for)
@@ -1417,7 +1434,7 @@ static bool persist_shape_cs(const hmcmt_ctx* ctx, int twist, int cs, int cuPerX
 static bool persist_shape(const hmcmt_ctx* ctx, int twist, int& cuPerXcd, int& G, int& cw, int& mw, size_t& lds, int* csOut = nullptr) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) { (void)hipGetLastError(); return false; }
-    cuPerXcd = prop.multiProcessorCount / 8;
+    cuPerXcd = prop.multiProcessorCount / 8 / std::max(ctx->shareCnt, 1);        // (this context's share of an XCD's CUs)
     if (cuPerXcd < 1 || !ctx->d_Vb || !ctx->d_Vtb) return false;
     // HMCMT_PERSIST_CS = 1 | 2 forces the column parts (tests: the two-part kernel on meshes one tile would hold)
     const char* e = getenv("HMCMT_PERSIST_CS");
@@ -1508,8 +1525,27 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     // 28 column tiles of 16 nodes: wider meshes are refused here, not at the first solve that needs it
     if (ctx->hp.NYP / 16 > 28) { ctx->err = "mesh too wide: ny + 1 > 448 nodes (include/hmcmt.h, hmcmt_create)"; return HMCMT_EINVAL; }
     HIPCHK(hipSetDevice(device_id));
-    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    // (hmcmt_next_cu_share, consumed here: this thread's next context, then back to the whole device)
+    ctx->shareIdx = g_nextShareIdx; ctx->shareCnt = g_nextShareCnt;
+    g_nextShareIdx = 0; g_nextShareCnt = 1;
+    ctx->shareMask = quarter_mask(ctx->shareIdx, ctx->shareCnt);
+    if (ctx->shareCnt > 1) {
+        // a share of EVERY XCD's CUs: mask bit n is CU n / nXCD of XCD n % nXCD (measured, scripts/probe/cumask.hip: a mask that
+        // leaves an XCD without a bit leaves that XCD unrestricted), so share i of c takes the CU indices [i, i + 1) * cuPerXcd / c
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device_id));
+        const int nxcd = 8, ncu = prop.multiProcessorCount, per = ncu / nxcd;
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int n = 0; n < ncu; ++n) {
+            const int cu = n / nxcd;
+            if (cu * ctx->shareCnt / per == ctx->shareIdx) mask[n / 32] |= 1u << (n % 32);
+        }
+        HIPCHK(hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)mask.size(), mask.data()));
+        HIPCHK(hipExtStreamCreateWithCUMask(&ctx->side, (uint32_t)mask.size(), mask.data()));
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    }
     // events between the library's own streams: no system-scope fence at the record (HMCMT_EVENT_FLAGS: 0 the default
     // system-scope release, 1 hipEventDisableSystemFence, 2 hipEventReleaseToDevice); evRec is waited for by the host
     const int evMode = getenv("HMCMT_EVENT_FLAGS") ? atoi(getenv("HMCMT_EVENT_FLAGS")) : 1;
@@ -1805,7 +1841,10 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
         ctx->sv.twist = ctx->v.twist = (ctx->sv.splitT || pshape) && ctx->twistOn;
     }
     if ((rc = persist_setup(ctx))) { g_createError = ctx->err; hmcmt_destroy(ctx); return rc; }
-    if (ctx->device >= 0 && ctx->device < MAXDEV) g_liveOnDev[ctx->device].fetch_add(1);
+    if (ctx->device >= 0 && ctx->device < MAXDEV) {
+        g_liveOnDev[ctx->device].fetch_add(1);
+        for (int q = 0; q < 4; ++q) if ((ctx->shareMask >> q) & 1u) g_quarterUse[ctx->device][q].fetch_add(1);
+    }
     devlock_ref(ctx->device);
     ctx->counted = true;
     *out = ctx;
@@ -2145,6 +2184,17 @@ int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out) {
     out[7] = ctx->persistCW ? ctx->persistMW : 0;  // modes per slab
     out[8] = ctx->persistCW ? ctx->persistCS : 0;  // column parts per row block (2: wide meshes)
     out[9] = ctx->persistTimeouts;                 // timed-out waits (the evaluation was redone with the launch-per-phase loop)
+    out[10] = ctx->shareIdx; out[11] = ctx->shareCnt;   // this context's share of every XCD's CUs (hmcmt_next_cu_share)
+    return 0;
+}
+
+// The NEXT hmcmt_create of the calling thread builds a context confined to share `index` of `count` (1, 2 or 4) equal shares of
+// the CUs of every XCD of its device: its streams carry a CU mask, and its persistent solve kernel takes that share of the system
+// slots -- the persistent kernels of `count` such contexts (independent chains, parallelHMC.jl:23-45 with more chains than
+// devices) are co-resident on the device instead of falling back to the launch-per-phase loop (what it buys).
+int hmcmt_next_cu_share(int32_t index, int32_t count) {
+    if ((count != 1 && count != 2 && count != 4) || index < 0 || index >= count) return HMCMT_EINVAL;
+    g_nextShareIdx = index; g_nextShareCnt = count;
     return 0;
 }
 

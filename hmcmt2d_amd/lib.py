@@ -119,6 +119,7 @@ def load_library():
     lib.hmcmt_debug_persist_precond.argtypes = [vp, C.c_int32, c_double_p, c_double_p]
     lib.hmcmt_persist_info.argtypes = [vp, c_int64_p]
     lib.hmcmt_debug_hog.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.hmcmt_next_cu_share.argtypes = [C.c_int32, C.c_int32]
     lib.hmcmt_guard.argtypes = [vp, c_double_p]
     lib.hmcmt_debug_fdm_fwd.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_back_post.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_double_p]
@@ -126,7 +127,7 @@ def load_library():
                  "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async",
                  "hmcmt_wait", "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead",
                  "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond",
-                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog"):
+                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -137,7 +138,7 @@ EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "h
                     "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async", "hmcmt_wait",
                     "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead", "hmcmt_dims",
                     "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
-                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
+                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
                     "hmcmt_comm_last_error"]
 
 
@@ -194,7 +195,9 @@ class HipContext:
                       # launch-per-phase loop: tests/conftest.py fails a test that leaves one behind)
 
     def __init__(self, mtMesh, mtData, invParam, device_id=0, precond="fdmj", tol=None, maxit=None,
-                 verify=False, check_every=None, warm_start=True, fdm_precision="mixed"):
+                 verify=False, check_every=None, warm_start=True, fdm_precision="mixed", cu_share=None):
+        """cu_share = (index, count): the context is confined to that share (count 1, 2 or 4) of the CUs of every XCD
+        (hmcmt_next_cu_share): `count` contexts -- chains -- on one device then run their persistent solve kernels side by side."""
         self.lib = load_library()
         self.args = CreateArgs(mtMesh, mtData, invParam)
         opts = Options()
@@ -213,6 +216,10 @@ class HipContext:
         opts.fdm_precision = {"mixed": 0, "fp64": 1}[fdm_precision]
         self.opts = opts
         h = C.c_void_p()
+        if cu_share is not None:
+            rc = self.lib.hmcmt_next_cu_share(int(cu_share[0]), int(cu_share[1]))       # (this thread's next create)
+            if rc != 0:
+                raise HmcmtError(rc, f"cu_share {cu_share}: (index, count) with count 1, 2 or 4")
         rc = self.lib.hmcmt_create(C.byref(h), device_id, *self.args.as_tuple(), C.byref(opts))
         if rc != 0:
             raise HmcmtError(rc, (self.lib.hmcmt_last_error(None) or b"").decode())
@@ -408,10 +415,10 @@ class HipContext:
 
     def persist_info(self):
         """The persistent solve kernel and this context (kernels_persist.h): shape, whether it is enabled, how many solves it ran."""
-        out = (C.c_int64 * 10)()
+        out = (C.c_int64 * 12)()
         self._check(self.lib.hmcmt_persist_info(self.h, out))
         return dict(zip(("threads_half", "workgroups_per_system", "slots_per_xcd", "enabled", "solves", "placement_fallbacks", "usable_now", "slab_modes",
-                         "column_parts", "timeouts"), (int(x) for x in out)))
+                         "column_parts", "timeouts", "cu_share_index", "cu_share_count"), (int(x) for x in out)))
 
     def debug_hog(self, nblocks, ms):
         """Test hook: nblocks workgroups holding a CU's LDS each for ms milliseconds on a stream of their own (returns at once)."""

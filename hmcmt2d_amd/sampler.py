@@ -369,10 +369,14 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
     after another.  `pids` is kept for signature parity: its length is the number of chains (default:
     world size).  `context_factory(mesh, data, inv, device_id)` replaces `get_context` (the CPU tests run
     the real sampler on an oracle-backed stand-in); `run_chain(chain_index, rng)` replaces the sampler.
-    `chains_per_gpu` > 1 runs that many of the rank's chains CONCURRENTLY on its GPU, one context and one host
-    thread each: a single chain's launches are latency-bound at the headline size, and two chains overlap to
-    1.34x the throughput of one (measured, scripts/gpu_two_chains.py); the chains and their results are the same as
-    run one after another (independent contexts, per-chain RNG streams).
+    `chains_per_gpu` = 2 or 4 runs that many of the rank's chains CONCURRENTLY on its GPU, one context and one host
+    thread each, every context confined to its share of the CUs of every XCD (HipContext(cu_share=...),
+    hmcmt_next_cu_share: CU-masked streams): the persistent solve kernels of the chains are co-resident, each with its share of
+    the system slots.  One chain alone leaves the slots of its converged systems idle (25 of 32 busy on average at the headline
+    size); two chains on half the slots each give 1.2x the aggregate steps/s of one (bench.py, `two_chains_per_gpu`).  The chains
+    and their results are the same as run one after another (independent contexts, per-chain RNG streams; the same solver, so
+    the same bits).  Rounds 2-3 ran the concurrent contexts on the launch-per-phase loop (1.34x then); round 4 had no mode that
+    composed with the persistent kernel (0.95x).
     `gather="library"`: the sample blocks are all-gathered by the library's own RCCL entry point
     (hmcmt_allgather_samples, include/hmcmt.h -- what a non-Python host would call) instead of torch's; the process
     group then only carries the 128-byte RCCL id from rank 0 to the others.  Works without a process group too (one rank).
@@ -397,6 +401,14 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
     mine = list(range(rank, nchains, world))
     results = {}
 
+    shares = int(chains_per_gpu) if int(chains_per_gpu) in (2, 4) and len(mine) > 1 else 1
+    if int(chains_per_gpu) > 1 and int(chains_per_gpu) not in (2, 4):
+        import warnings
+        warnings.warn("chains_per_gpu must be 1, 2 or 4 (shares of every XCD's CUs): other values run concurrent contexts on the "
+                      "launch-per-phase loop, slower than one chain after another")
+    import threading
+    free_shares, share_lock = list(range(shares)), threading.Lock()
+
     def one_chain(c):
         rng = np.random.default_rng([seed, c])
         t0 = time.time()
@@ -404,13 +416,21 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
             model, stats, data = run_chain(c, rng)
         else:
             inv_c, prior_c, mesh_c = copy.deepcopy(invParam), copy.deepcopy(hmcprior), copy.deepcopy(mtMesh)
+            with share_lock:
+                my_share = free_shares.pop(0) if shares > 1 else None
+            ctx_kw = {} if my_share is None else {"cu_share": (my_share, shares)}
             ctx_c = context_factory(mesh_c, mtData, inv_c, dev_id) if context_factory is not None else \
-                get_context(mesh_c, mtData, inv_c, device_id=dev_id)
+                get_context(mesh_c, mtData, inv_c, device_id=dev_id, **ctx_kw)
             kw = dict(sampler_kw)
             if kw.get("checkpoint"):                        # one checkpoint file per chain
                 kw["checkpoint"] = f"{kw['checkpoint']}.chain{c + 1}"
-            model, stats, data = runHMCSampler(mesh_c, mtData, inv_c, prior_c, rng, ctx=ctx_c, **kw)
-            release_context(inv_c)
+            try:
+                model, stats, data = runHMCSampler(mesh_c, mtData, inv_c, prior_c, rng, ctx=ctx_c, **kw)
+            finally:
+                release_context(inv_c)
+                if my_share is not None:
+                    with share_lock:
+                        free_shares.append(my_share)
         results[c] = (model, stats, data, time.time() - t0)
 
     if chains_per_gpu > 1 and len(mine) > 1:

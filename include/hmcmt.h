@@ -236,11 +236,16 @@ int hmcmt_debug_flags(hmcmt_ctx* ctx, int32_t flags);
 int hmcmt_debug_spmv(hmcmt_ctx* ctx, const double* p, double* q);
 int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z);
 int hmcmt_guard(const hmcmt_ctx* ctx, double* out4);   /* {checks, worst true residual seen, last, trips (checks above HMCMT_GUARD_LIMIT, default 1e-6)}: the production guard of the stopping rule (every HMCMT_GUARD_EVERY-th evaluation, default 100) */
-int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out10);  /* {threads/2 (0: not applicable), workgroups per system, slots per XCD, enabled, solves, placement fallbacks,
+int hmcmt_next_cu_share(int32_t index, int32_t count);   /* the calling thread's NEXT hmcmt_create builds a context confined to share `index` of `count`
+                                                             (1, 2, 4) equal shares of the CUs of every XCD (CU-masked streams): the persistent solve kernels of
+                                                             `count` such contexts -- independent chains on one device, parallelHMC.jl:23-45 -- run side by side,
+                                                             each with its share of the system slots.  Consumed by that create; default: the whole device */
+int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out12);  /* {threads/2 (0: not applicable), workgroups per system, slots per XCD, enabled, solves, placement fallbacks,
                                                                    usable now (this context alone on its device in the process AND the process holds the device's advisory lock),
                                                                    modes per slab of its tridiagonal solves (32; 16 on tall meshes and with column parts),
                                                                    column parts per row block (1; 2 on meshes wider than one tile: the stress size),
-                                                                   timed-out waits (each one: the evaluation redone with the launch-per-phase loop)} */
+                                                                   timed-out waits (each one: the evaluation redone with the launch-per-phase loop),
+                                                                   CU share index, CU share count (hmcmt_next_cu_share)} */
 int hmcmt_debug_hog(hmcmt_ctx* ctx, int32_t nblocks, int32_t ms);   /* test hook: nblocks workgroups that each hold a CU's LDS for ms milliseconds on a stream of their own (a foreign tenant on the device); returns at once */
 int hmcmt_debug_persist_precond(hmcmt_ctx* ctx, int32_t sweeps, const double* r, double* z);   /* the persistent solve kernel's preconditioner (tests) */
 int hmcmt_debug_fdm_fwd(hmcmt_ctx* ctx, const double* t, double* out);   /* [2][S*vstride] complex: fused kernel | separate kernels */

@@ -367,3 +367,43 @@ def test_a_timed_out_wait_falls_back_to_the_launch_per_phase_loop(monkeypatch):
         if hit:
             break
     assert hit, "no wait timed out in three tries: the hog did not displace the persistent kernel"
+
+
+def test_two_contexts_with_cu_shares_run_their_persistent_kernels_side_by_side(monkeypatch):
+    """hmcmt_next_cu_share (HipContext(cu_share=(i, 2))): each context is confined to half the CUs of every XCD -- CU-masked
+    streams -- and takes half the system slots; the two persistent kernels are co-resident (no context falls back to the
+    launch-per-phase loop, no wait times out) while two host threads drive them concurrently.  A system's arithmetic does not
+    depend on the slot or the round it runs in: the same bits as one context on the whole device."""
+    import threading
+    mesh, data, inv, m = make_problem("cfg2")
+    ref_ctx = _ctx(monkeypatch, mesh, data, inv, True, 2, warm_start=False)
+    ref = [ref_ctx.grad(m + 0.01 * i) for i in range(6)]
+    full_slots = ref_ctx.persist_info()["slots_per_xcd"]
+    ref_ctx.close()
+    ctxs = [_ctx(monkeypatch, mesh, data, inv, True, 2, warm_start=False, cu_share=(i, 2)) for i in range(2)]
+    outs = [[None] * 6, [None] * 6]
+
+    def run(j):
+        for rep in range(3):                               # (long enough that the two really overlap)
+            for i in range(6):
+                outs[j][i] = ctxs[j].grad(m + 0.01 * i)
+
+    th = [threading.Thread(target=run, args=(j,)) for j in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for j in range(2):
+        info = ctxs[j].persist_info()
+        assert info["cu_share_index"] == j and info["cu_share_count"] == 2 and info["usable_now"] == 1, info
+        assert info["solves"] == 36 and info["placement_fallbacks"] == 0 and info["timeouts"] == 0 and info["enabled"] == 1, info
+        assert info["slots_per_xcd"] * info["workgroups_per_system"] <= 16 and info["slots_per_xcd"] <= full_slots     # (its half of an XCD's 32 CUs)
+        for i in range(6):
+            assert np.array_equal(outs[j][i][0], ref[i][0]) and outs[j][i][1] == ref[i][1] and np.array_equal(outs[j][i][2], ref[i][2])
+    # a third context on the whole device overlaps both shares: all three are then on the launch-per-phase loop
+    c3 = _ctx(monkeypatch, mesh, data, inv, True, 2)
+    assert c3.persist_info()["usable_now"] == 0 and ctxs[0].persist_info()["usable_now"] == 0
+    c3.close()
+    assert ctxs[0].persist_info()["usable_now"] == 1
+    for c in ctxs:
+        c.close()
