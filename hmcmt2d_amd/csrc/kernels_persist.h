@@ -728,12 +728,21 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             u4v bfw[8][2];
             {
                 const int lo = lanev;           // (an opaque offset: the loads stay in the iteration instead of being hoisted out of the solve and spilled)
-                const int ta = CS == 1 ? tl0 : min(t0wF, NTc - 1), tc = CS == 1 ? tl1 : min(t0wF + 1, NTc - 1);
+                if constexpr (CS == 1) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int kg = kg0 + min(q, KGF - 1);
-                    bfw[q][0] = *ps_at(kb->Vb, (unsigned)((kg * NTc + ta) * 64 + lo));
-                    bfw[q][1] = *ps_at(kb->Vb, (unsigned)((kg * NTc + tc) * 64 + lo));
+                    for (int q = 0; q < 8; ++q) {
+                        const int kg = min(q, KGF - 1);
+                        bfw[q][0] = *ps_at(kb->Vb, (unsigned)((kg * NTc + tl0) * 64 + lo));
+                        bfw[q][1] = *ps_at(kb->Vb, (unsigned)((kg * NTc + tl1) * 64 + lo));
+                    }
+                } else {
+                    // column parts: the wave's FOUR mode tiles x the first four K-groups (slot q & 3 of k-group q, tile t at
+                    // [2 (q & 3) + (t >> 1)][t & 1]); k-group q + 4 takes the slot when q has been used
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            bfw[2 * q + (t >> 1)][t & 1] = *ps_at(kb->Vb, (unsigned)(((kg0 + min(q, KGF - 1)) * NTc + min(t0wF + t, NTc - 1)) * 64 + lo));
                 }
             }
             PS_STAMP(0)
@@ -850,49 +859,53 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                                 *ps_at(yh, (unsigned)(g * NYP + (t0w + t) * 16 + ljv)) = float2{acc[rg][t][2 * h2], acc[rg][t][2 * h2 + 1]};
                         }
             } else {
-                // the part's partial product: its own columns (K-groups kg0 ..) x ALL mode tiles -- this wave's up to four, two
-                // at a time; the second pair's V fragments are requested as the first pair's are used up
+                // the part's partial product: its own columns (K-groups kg0 ..) x ALL mode tiles -- this wave's up to four at once:
+                // a k-group's operand rows are read from LDS once, its four V fragments come from the slot requested four
+                // k-groups earlier (round 5, first version: two passes of two tiles, the second pair's fragments requested inside
+                // the first pass and waited for in front of the second: 5.6 us)
                 float2* yh = (hp ? kb->yhat2 : kb->yhat) + so();
+                f4v acc[2][4];
 #pragma unroll
-                for (int pp = 0; pp < 2; ++pp) {
-                    f4v acc[2][2];
+                for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
-                    for (int rg = 0; rg < 2; ++rg)
+                    for (int t = 0; t < 4; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
-                    const int tn0 = min(t0wF + 2, NTc - 1), tn1 = min(t0wF + 3, NTc - 1);
+                for (int kg = 0; kg < 8; ++kg) {
+                    if (kg < KGF) {
+                        const int q = kg & 3;
+                        bf8v ah[2], al[2];
 #pragma unroll
-                    for (int kg = 0; kg < 8; ++kg) {
-                        if (kg < KGF) {
+                        for (int rg = 0; rg < 2; ++rg) {
+                            const unsigned short* ap = PL + ((long)(8 * rg + (ljv >> 1)) * 4 + (ljv & 1)) * PLW + 32 * kg + 8 * g4v;
+                            ah[rg] = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap));
+                            al[rg] = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap + 2 * PLW));
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const bf8v bhf = __builtin_bit_cast(bf8v, bfw[2 * q + (t >> 1)][t & 1]);
 #pragma unroll
                             for (int rg = 0; rg < 2; ++rg) {
-                                const unsigned short* ap = PL + ((long)(8 * rg + (ljv >> 1)) * 4 + (ljv & 1)) * PLW + 32 * kg + 8 * g4v;
-                                const bf8v ah = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap));
-                                const bf8v al = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap + 2 * PLW));
-#pragma unroll
-                                for (int t = 0; t < 2; ++t) {
-                                    const bf8v bhf = __builtin_bit_cast(bf8v, bfw[kg][t]);
-                                    acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
-                                    acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
-                                }
-                            }
-                            if (pp == 0) {
-                                bfw[kg][0] = *ps_at(kb->Vb, (unsigned)(((kg0 + kg) * NTc + tn0) * 64 + lanev));
-                                bfw[kg][1] = *ps_at(kb->Vb, (unsigned)(((kg0 + kg) * NTc + tn1) * 64 + lanev));
+                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rg], bhf, acc[rg][t], 0, 0, 0);
+                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rg], bhf, acc[rg][t], 0, 0, 0);
                             }
                         }
+                        if (kg + 4 < KGF) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                bfw[2 * q + (t >> 1)][t & 1] = *ps_at(kb->Vb, (unsigned)(((kg0 + kg + 4) * NTc + min(t0wF + t, NTc - 1)) * 64 + lanev));
+                        }
                     }
-#pragma unroll
-                    for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int h2 = 0; h2 < 2; ++h2) {
-                                const int rho = 8 * rg + 2 * g4v + h2, g = iz0 + rho;
-                                if (2 * pp + t < ntlF && rho < PS_OWN && g <= nz - 1)
-                                    *ps_at(yh, (unsigned)(g * NYP + (t0wF + 2 * pp + t) * 16 + ljv)) = float2{acc[rg][t][2 * h2], acc[rg][t][2 * h2 + 1]};
-                            }
                 }
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const int rho = 8 * rg + 2 * g4v + h2, g = iz0 + rho;
+                            if (t < ntlF && rho < PS_OWN && g <= nz - 1)
+                                *ps_at(yh, (unsigned)(g * NYP + (t0wF + t) * 16 + ljv)) = float2{acc[rg][t][2 * h2], acc[rg][t][2 * h2 + 1]};
+                        }
             }
             // (two sweeps: the first part of the rho identity, the sum of (r' + t) .* z2 over the own rows, stays in registers and
             //  joins the second part in the reduction behind the first post-sweep: one block reduction less)
