@@ -1231,6 +1231,13 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                 if (j >= JP + 1) rh[j] = mk(j) * (rh[j] - alf * qh[j]);
             (void)dum3; (void)dum4;
             xxPrev = xxs;                                                      // (this thread's part: reduced and published with the next reduction)
+            // One sweep per side: q's fp64 rows sit in the FIRST tile's space (TZ = T0), whose complex64 slots belong to other
+            // threads -- and the next iteration's first act is to write z1 there.  A wave that leaves this phase early (few
+            // rows in the mesh, halo columns without an x update) overwrote q of a wave still reading it: x += alpha p with
+            // r -= alpha (garbage) -- true residuals of 1e-8 .. 1e+3 in a fifth of the cold solves of the two-part kernel on
+            // cfg3's mesh (round 5's soak; the one-part kernel has the same window and never hit it in 10^5 solves).  With two
+            // sweeps q lives in the second tile, which the next iteration writes behind a barrier.
+            if (SW == 1) __syncthreads();
             PS_STAMP(11)
         }
         kb = kb0;                            // (behind a loop the compiler takes for one with divergent exits: a uniform copy again)

@@ -14,12 +14,17 @@ from hmcmt2d_amd.lib import HipContext
 from tests.helpers import make_problem
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-for name in ("tiny", "cfg2", "cfg1", "cfg3"):
+# (name, HMCMT_PERSIST_CS, evaluations): round 5 adds the column-part shapes -- forced onto cfg2 / cfg3, and cfg5's own
+for name, cs, n_eval in (("tiny", "", N), ("cfg2", "", N), ("cfg1", "", N), ("cfg3", "", N), ("cfg2", "2", N), ("cfg3", "2", N), ("cfg5", "", max(N // 5, 200))):
+    if cs:
+        os.environ["HMCMT_PERSIST_CS"] = cs
+    else:
+        os.environ.pop("HMCMT_PERSIST_CS", None)
     mesh, data, inv, m = make_problem(name)
     ctx = HipContext(mesh, data, inv)
     rng = np.random.default_rng(11)
     mm = m.copy()
-    n = N if name != "cfg3" else N
+    n = n_eval
     bad = 0
     t0 = time.time()
     for k in range(n):
@@ -37,6 +42,6 @@ for name in ("tiny", "cfg2", "cfg1", "cfg3"):
     ctx.grad(mm + 1e-3)
     st = ctx.stats()
     ctx.close()
-    print(f"{name}: {n} evaluations in {dt:.1f} s ({n / dt:.0f}/s), failed {bad}, persistent solves {info['solves']} of {2 * n + 2}, placement fallbacks {info['placement_fallbacks']}, "
+    print(f"{name}{' (column parts forced)' if cs else ''} [parts {info['column_parts']}, {info['workgroups_per_system']} workgroups/system, {info['slots_per_xcd']} slots/XCD]: {n} evaluations in {dt:.1f} s ({n / dt:.0f}/s), failed {bad}, persistent solves {info['solves']} of {2 * n + 2}, placement fallbacks {info['placement_fallbacks']} timeouts {info['timeouts']}, "
           f"guard checks {gd['checks']} trips {gd['trips']} worst {gd['worst_true_res']:.1e}; final verify: status {st['status']} true_res {st['true_res_max']:.1e} "
           f"iters {st['iters_fwd_max']}/{st['iters_adj_max']} fp64 restarts in the last evaluation {st['fallback_solves']}", flush=True)

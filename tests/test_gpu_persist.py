@@ -407,3 +407,26 @@ def test_two_contexts_with_cu_shares_run_their_persistent_kernels_side_by_side(m
     assert ctxs[0].persist_info()["usable_now"] == 1
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("parts", ["1", "2"])
+def test_one_sweep_solves_do_not_lose_q_to_the_next_iterations_first_write(monkeypatch, parts):
+    """With one smoothing sweep per side q's fp64 rows wait for alpha in the FIRST tile's space, whose complex64 slots are other
+    threads' -- and the next iteration starts by writing z1 there.  Without a barrier behind the update a wave that leaves it early
+    overwrote q of a wave still reading it: found by round 5's soak on the two-part kernel forced onto cfg3's mesh (true residuals
+    of 1e-8 .. 1e+3 in a fifth of the cold solves; the one-part kernel has had the same window since round 4 and never hit it).
+    150 cold evaluations with the true-residual check, one sweep per side, both kernels."""
+    monkeypatch.setenv("HMCMT_PERSIST_CS", parts)
+    mesh, data, inv, m = make_problem("cfg3")
+    ctx = _ctx(monkeypatch, mesh, data, inv, True, 1, verify=True)
+    assert ctx.persist_info()["column_parts"] == int(parts)
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for k in range(150):
+        ctx.grad(m + 0.05 * rng.standard_normal(m.size))
+        st = ctx.stats()
+        assert st["status"] == 0 and st["smoother_sweeps"] == 11
+        worst = max(worst, st["true_res_max"])
+    assert ctx.persist_info()["solves"] == 300
+    ctx.close()
+    assert worst < 1e-8, worst
