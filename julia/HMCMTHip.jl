@@ -27,7 +27,7 @@ using Distributed              # myid
 using HMCMT.HMCFileIO, HMCMT.HMCStruct, HMCMT.HMCUtility
 
 export HipContext, hipContext, compDataGradient, hipForward, setPrior!, proposeLeapfrog, proposeLeapfrogDevice!,
-       hipWait, hipStats, hipGuard, destroy!, commId, SampleComm, allgatherSamples
+       hipWait, hipStats, hipGuard, hipPersistInfo, hipNextCuShare, destroy!, commId, SampleComm, allgatherSamples
 
 const libhmcmt = get(ENV, "HMCMT_HIP_LIB", joinpath(@__DIR__, "..", "hmcmt2d_amd", "libhmcmt_hip.so"))
 
@@ -318,6 +318,37 @@ function hipGuard(ctx::HipContext)
     rc = ccall((:hmcmt_guard, libhmcmt), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.ptr, out)
     checkerr(ctx.ptr, rc)
     return (checks = Int(out[1]), worst = out[2], last = out[3], trips = Int(out[4]))
+end
+
+"""
+    hipPersistInfo(ctx) -> NamedTuple
+
+Shape and use of the one-launch-per-solve kernel (`hmcmt_persist_info`, include/hmcmt.h; DESIGN 5.0): `threads_half == 0` --
+the mesh is outside its envelope; `usable_now == 0` -- this context is not alone on its share of the device (all solves then run
+the launch-per-phase loop: same results, slower); `timeouts` / `placement_fallbacks` > 0 -- the device is shared with something
+this library cannot see.
+"""
+function hipPersistInfo(ctx::HipContext)
+    out = zeros(Int64, 12)
+    rc = ccall((:hmcmt_persist_info, libhmcmt), Cint, (Ptr{Cvoid}, Ptr{Int64}), ctx.ptr, out)
+    checkerr(ctx.ptr, rc)
+    return (threads_half = out[1], workgroups_per_system = out[2], slots_per_xcd = out[3], enabled = out[4], solves = out[5],
+            placement_fallbacks = out[6], usable_now = out[7], slab_modes = out[8], column_parts = out[9], timeouts = out[10],
+            cu_share_index = out[11], cu_share_count = out[12])
+end
+
+"""
+    hipNextCuShare(index, count)
+
+The calling task's NEXT `HipContext(...)` is confined to share `index` (0-based) of `count` = 1, 2 or 4 equal shares of the CUs of
+every XCD (`hmcmt_next_cu_share`): what `parallelHMCSampler` calls before it builds the contexts of `count` chains that are to
+run concurrently on one GPU (parallelHMC.jl:23-45 with more chains than devices).  Julia tasks may migrate between threads:
+call it and the constructor without a yield in between (or pin the task).
+"""
+function hipNextCuShare(index::Integer, count::Integer)
+    rc = ccall((:hmcmt_next_cu_share, libhmcmt), Cint, (Int32, Int32), Int32(index), Int32(count))
+    rc == 0 || error("hmcmt_next_cu_share($index, $count): (index, count) with count 1, 2 or 4")
+    return nothing
 end
 
 end # module

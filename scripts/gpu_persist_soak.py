@@ -8,18 +8,24 @@ import sys
 import time
 import numpy as np
 
-os.environ["HMCMT_GUARD_EVERY"] = "10"
 os.environ["HMCMT_PERSIST"] = "1"
 from hmcmt2d_amd.lib import HipContext
 from tests.helpers import make_problem
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-# (name, HMCMT_PERSIST_CS, evaluations): round 5 adds the column-part shapes -- forced onto cfg2 / cfg3, and cfg5's own
-for name, cs, n_eval in (("tiny", "", N), ("cfg2", "", N), ("cfg1", "", N), ("cfg3", "", N), ("cfg2", "2", N), ("cfg3", "2", N), ("cfg5", "", max(N // 5, 200))):
-    if cs:
-        os.environ["HMCMT_PERSIST_CS"] = cs
-    else:
-        os.environ.pop("HMCMT_PERSIST_CS", None)
+os.environ["HMCMT_GUARD_EVERY"] = sys.argv[2] if len(sys.argv) > 2 else "10"
+# (name, HMCMT_PERSIST_CS, HMCMT_SWEEPS, evaluations): round 5 adds the column-part shapes -- forced onto cfg1 / cfg2 / cfg3 (three thread
+# counts, equal and unequal parts), cfg5's own -- and forces the smoother both ways (the library's own choice mixes them)
+cases = []
+for sw in ("", "1", "2"):
+    cases += [("tiny", "", sw, N), ("cfg2", "", sw, N), ("cfg1", "", sw, N), ("cfg3", "", sw, N), ("cfg2", "2", sw, N), ("cfg1", "2", sw, N),
+              ("cfg3", "2", sw, N), ("cfg5", "", sw, max(N // 5, 100))]
+for name, cs, sw, n_eval in cases:
+    for key, val in (("HMCMT_PERSIST_CS", cs), ("HMCMT_SWEEPS", sw)):
+        if val:
+            os.environ[key] = val
+        else:
+            os.environ.pop(key, None)
     mesh, data, inv, m = make_problem(name)
     ctx = HipContext(mesh, data, inv)
     rng = np.random.default_rng(11)
@@ -42,6 +48,6 @@ for name, cs, n_eval in (("tiny", "", N), ("cfg2", "", N), ("cfg1", "", N), ("cf
     ctx.grad(mm + 1e-3)
     st = ctx.stats()
     ctx.close()
-    print(f"{name}{' (column parts forced)' if cs else ''} [parts {info['column_parts']}, {info['workgroups_per_system']} workgroups/system, {info['slots_per_xcd']} slots/XCD]: {n} evaluations in {dt:.1f} s ({n / dt:.0f}/s), failed {bad}, persistent solves {info['solves']} of {2 * n + 2}, placement fallbacks {info['placement_fallbacks']} timeouts {info['timeouts']}, "
+    print(f"{name}{' (column parts forced)' if cs else ''}{' sweeps ' + sw if sw else ''} [parts {info['column_parts']}, {info['workgroups_per_system']} workgroups/system, {info['slots_per_xcd']} slots/XCD]: {n} evaluations in {dt:.1f} s ({n / dt:.0f}/s), failed {bad}, persistent solves {info['solves']} of {2 * n + 2}, placement fallbacks {info['placement_fallbacks']} timeouts {info['timeouts']}, "
           f"guard checks {gd['checks']} trips {gd['trips']} worst {gd['worst_true_res']:.1e}; final verify: status {st['status']} true_res {st['true_res_max']:.1e} "
           f"iters {st['iters_fwd_max']}/{st['iters_adj_max']} fp64 restarts in the last evaluation {st['fallback_solves']}", flush=True)
