@@ -2191,7 +2191,8 @@ int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out) {
 // The NEXT hmcmt_create of the calling thread builds a context confined to share `index` of `count` (1, 2 or 4) equal shares of
 // the CUs of every XCD of its device: its streams carry a CU mask, and its persistent solve kernel takes that share of the system
 // slots -- the persistent kernels of `count` such contexts (independent chains, parallelHMC.jl:23-45 with more chains than
-// devices) are co-resident on the device instead of falling back to the launch-per-phase loop (what it buys).
+// devices) are co-resident on the device instead of falling back to the launch-per-phase loop (what it buys -- at the
+// headline size two chains on halves run at 1.01-1.04 x the aggregate steps/s of one chain on the whole device).
 int hmcmt_next_cu_share(int32_t index, int32_t count) {
     if ((count != 1 && count != 2 && count != 4) || index < 0 || index >= count) return HMCMT_EINVAL;
     g_nextShareIdx = index; g_nextShareCnt = count;

@@ -372,8 +372,10 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
     `chains_per_gpu` = 2 or 4 runs that many of the rank's chains CONCURRENTLY on its GPU, one context and one host
     thread each, every context confined to its share of the CUs of every XCD (HipContext(cu_share=...),
     hmcmt_next_cu_share: CU-masked streams): the persistent solve kernels of the chains are co-resident, each with its share of
-    the system slots.  One chain alone leaves the slots of its converged systems idle (25 of 32 busy on average at the headline
-    size); two chains on half the slots each give 1.2x the aggregate steps/s of one (bench.py, `two_chains_per_gpu`).  The chains
+    the system slots.  Measured at the headline size near the true model (bench.py `two_chains_per_gpu`,
+    scripts/gpu_cu_share_probe.py): two chains on halves 1.01-1.04x the aggregate steps/s of one chain on the whole device, four
+    on quarters 0.79x -- concurrency without a throughput cost, not a speed-up (DESIGN 7 says why).  A mesh whose systems need
+    more workgroups than a share's CUs per XCD hold (the stress size: 30 of 16) runs the launch-per-phase loop in each share.  The chains
     and their results are the same as run one after another (independent contexts, per-chain RNG streams; the same solver, so
     the same bits).  Rounds 2-3 ran the concurrent contexts on the launch-per-phase loop (1.34x then); round 4 had no mode that
     composed with the persistent kernel (0.95x).
