@@ -237,7 +237,14 @@ def two_chains_leg(torch, HipContext, mesh, data, inv, local, dev, m_true, mref,
     cb_ = Chain(ctxb, torch, dev, m_true, mref, inv.Wm, seed=8)
     for c in (ca, cb_):
         c.run(2 * LTRAJ)
-    th = [threading.Thread(target=c.run, args=(Ke,)) for c in (ca, cb_)]
+
+    def run_on_own_stream(c):
+        # CU-masked streams are BLOCKING streams (hipExtStreamCreateWithCUMask takes no flags): torch work on the legacy default
+        # stream would wait for the other chain's trajectory in flight, and make it wait -- each chain's torch ops (momentum draw,
+        # kinetic energies) go to a stream of its own, as a multi-chain host would arrange it
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            c.run(Ke)
+    th = [threading.Thread(target=run_on_own_stream, args=(c,)) for c in (ca, cb_)]
     torch.cuda.synchronize()
     t5 = time.perf_counter()
     for t in th:
@@ -251,8 +258,8 @@ def two_chains_leg(torch, HipContext, mesh, data, inv, local, dev, m_true, mref,
            "slots_per_xcd": [ctxa.persist_info()["slots_per_xcd"], ctxb.persist_info()["slots_per_xcd"]],
            "state": "two independent chains near the true model on ONE GPU: two contexts, two host threads, "
                     "each context on half the CUs of every XCD (CU-masked streams), their persistent solve "
-                    "kernels side by side with half the system slots each; compare with near_true_state "
-                    "(ONE chain on the whole device)"}
+                    "kernels side by side with half the system slots each, each chain's torch ops on a stream of its own; "
+                    "compare with near_true_state (ONE chain on the whole device)"}
     ctxa.close()
     ctxb.close()
     return res

@@ -2192,7 +2192,8 @@ int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out) {
 // the CUs of every XCD of its device: its streams carry a CU mask, and its persistent solve kernel takes that share of the system
 // slots -- the persistent kernels of `count` such contexts (independent chains, parallelHMC.jl:23-45 with more chains than
 // devices) are co-resident on the device instead of falling back to the launch-per-phase loop (what it buys -- at the
-// headline size two chains on halves run at 1.01-1.04 x the aggregate steps/s of one chain on the whole device).
+// headline size two chains on halves run at 1.15 x the aggregate steps/s of one chain on the whole device).  The CU-masked streams
+// are BLOCKING streams (hipExtStreamCreateWithCUMask takes no flags): they synchronise with the legacy default stream.
 int hmcmt_next_cu_share(int32_t index, int32_t count) {
     if ((count != 1 && count != 2 && count != 4) || index < 0 || index >= count) return HMCMT_EINVAL;
     g_nextShareIdx = index; g_nextShareCnt = count;

@@ -373,8 +373,9 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
     thread each, every context confined to its share of the CUs of every XCD (HipContext(cu_share=...),
     hmcmt_next_cu_share: CU-masked streams): the persistent solve kernels of the chains are co-resident, each with its share of
     the system slots.  Measured at the headline size near the true model (bench.py `two_chains_per_gpu`,
-    scripts/gpu_cu_share_probe.py): two chains on halves 1.01-1.04x the aggregate steps/s of one chain on the whole device, four
-    on quarters 0.79x -- concurrency without a throughput cost, not a speed-up (DESIGN 7 says why).  A mesh whose systems need
+    scripts/gpu_cu_share_probe.py): two chains on halves 1.15x the aggregate steps/s of one chain on the whole device, four
+    on quarters 1.17x.  (The shares' streams are BLOCKING HIP streams: keep other GPU work of the process off the legacy
+    default stream while chains sample, or it serialises them -- DESIGN 7.)  A mesh whose systems need
     more workgroups than a share's CUs per XCD hold (the stress size: 30 of 16) runs the launch-per-phase loop in each share.  The chains
     and their results are the same as run one after another (independent contexts, per-chain RNG streams; the same solver, so
     the same bits).  Rounds 2-3 ran the concurrent contexts on the launch-per-phase loop (1.34x then); round 4 had no mode that

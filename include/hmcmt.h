@@ -239,7 +239,9 @@ int hmcmt_guard(const hmcmt_ctx* ctx, double* out4);   /* {checks, worst true re
 int hmcmt_next_cu_share(int32_t index, int32_t count);   /* the calling thread's NEXT hmcmt_create builds a context confined to share `index` of `count`
                                                              (1, 2, 4) equal shares of the CUs of every XCD (CU-masked streams): the persistent solve kernels of
                                                              `count` such contexts -- independent chains on one device, parallelHMC.jl:23-45 -- run side by side,
-                                                             each with its share of the system slots.  Consumed by that create; default: the whole device */
+                                                             each with its share of the system slots (cfg3: two chains 1.15x one chain's steps/s).  Such a context's
+                                                             streams are blocking HIP streams: they synchronise with the legacy default stream.
+                                                             Consumed by that create; default: the whole device */
 int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out12);  /* {threads/2 (0: not applicable), workgroups per system, slots per XCD, enabled, solves, placement fallbacks,
                                                                    usable now (this context alone on its device in the process AND the process holds the device's advisory lock),
                                                                    modes per slab of its tridiagonal solves (32; 16 on tall meshes and with column parts),

@@ -25,7 +25,12 @@ for label, shares in (("1 chain, whole device", [None]), ("1 chain on half the C
     chains = [B.Chain(c, torch, dev, m_true, mref, inv.Wm, seed=7 + j) for j, c in enumerate(ctxs)]
     for c in chains:
         c.run(16)
-    th = [threading.Thread(target=c.run, args=(K,)) for c in chains]
+    def run_on_own_stream(c):
+        # (CU-masked streams are BLOCKING streams -- hipExtStreamCreateWithCUMask has no flags --, so torch work on the legacy
+        #  default stream would wait for the other chain's trajectory and make it wait: every chain's torch ops on a stream of its own)
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            c.run(K)
+    th = [threading.Thread(target=run_on_own_stream, args=(c,)) for c in chains]
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for t in th: t.start()
     for t in th: t.join()
