@@ -179,3 +179,26 @@ def test_only_hip_solver_is_accepted():
     mesh, data, inv, m = make_problem("tiny")
     with pytest.raises(ValueError):
         sampler.compDataGradient(mesh, data, inv, HMCPrior(linearSolver="mumps"))
+
+
+def test_bench_gpus_n_spawns_one_rank_process_per_gpu():
+    """`python bench.py --gpus 2` as a plain command (no torch.distributed.run, no WORLD_SIZE): the parent touches no GPU, starts
+    two rank processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, hands rank 0's stdout through and exits non-zero when a
+    rank fails -- in this GPU-less container both ranks get as far as "needs a GPU" (the reference's parallel entry is one call
+    too: parallelHMC.jl:10-49).  With WORLD_SIZE set and a different --gpus the mismatch is an error, not a silent single rank."""
+    import subprocess
+    import sys
+    from tests.conftest import HAVE_GPU
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if HAVE_GPU:
+        pytest.skip("the spawn path is exercised for real on the GPU box by bench.py itself")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=root)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") == 2, r.stderr[-1500:]
+    assert "exited with" in r.stderr and r.stdout.strip() == ""
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=root)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
