@@ -178,6 +178,7 @@ struct hmcmt_ctx {
     bool psConstValid = false;
     float2* d_yhat2 = nullptr;            // column parts: the second part's partial product of the forward transform
     unsigned persistSpin = PS_SPIN_LIMIT; // HMCMT_PS_SPIN: polls before a wait of the kernel gives up (tests shorten it)
+    long persistBackoff = 0;              // after a timed-out wait: solves on the launch-per-phase loop before the kernel is tried again (doubles per timeout)
     bool persistTimedOut = false;         // a wait of the last persistent launch timed out: evaluate() redoes the evaluation with the launch-per-phase loop
     int dbgPlace = 0;                     // test hook (hmcmt_debug_flags bit 2): the next persistent launch's first group fails its placement check
     bool counted = false;                 // this context is in g_liveOnDev / holds a reference on the device lock
@@ -711,6 +712,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
     cplx* const r_entry = k.r;
     bool viaPersist = false, stalledP = false, specIssued = false;
     ctx->specValid = false;
+    if (!ctx->persistOn && ctx->persistBackoff > 0 && --ctx->persistBackoff == 0) ctx->persistOn = true;      // (after a timed-out wait: another try)
     if (fused && persist_ok(ctx)) {
         // ONE launch solves every system (kernels_persist.h).  The kernel tells the host through mapped words: the progress
         // word when its last workgroup leaves, the active-system counter, the stagnation / failure / placement flags.
@@ -726,10 +728,12 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
         { int prc = spin_progress(ctx, PS_DONE); if (prc) return prc; }
         if (*(volatile int*)(ctx->h_stall + 1) == HMCMT_EHIP) {
             // a wait inside the kernel timed out (its grid was not co-resident: a foreign kernel holds CUs, a lock directory that
-            // does not coordinate): the systems are in no defined state.  This context leaves the persistent kernel for good, and
-            // evaluate() runs the evaluation again, cold, with the launch-per-phase loop -- which works under any sharing
+            // does not coordinate): the systems are in no defined state.  This context leaves the persistent kernel -- for 256 solves
+            // after the first timeout, twice as long after every further one --, and evaluate() runs the evaluation again, cold,
+            // with the launch-per-phase loop, which works under any sharing
             ctx->persistTimedOut = true;
             ctx->persistOn = false; ++ctx->persistTimeouts;
+            ctx->persistBackoff = 256l << std::min<long long>(ctx->persistTimeouts - 1, 6);     // (the tenant may leave: 256, 512, .. 16 384 solves, then another try)
         }
         if (*(volatile int*)(ctx->h_stall + 2)) {
             // the group's workgroups were not on one XCD (or the kernel could not be placed): nothing was touched by those
@@ -938,7 +942,7 @@ int evaluate(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pred, d
         // done by the first attempt's first kernel -- is not repeated, no warm start from fields in an undefined state
         ctx->persistTimedOut = false;
         fprintf(stderr, "libhmcmt_hip: a wait of the persistent solve kernel timed out (the device is shared?); this context continues with the "
-                        "launch-per-phase loop, the evaluation is redone\n");
+                        "launch-per-phase loop for the next %ld solves, the evaluation is redone\n", ctx->persistBackoff);
         (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->side);
         (void)hipGetLastError();
         ctx->statsPending = false; ctx->sidePending = false; ctx->sensWaitPending = ctx->extAWaitPending = false;

@@ -362,6 +362,13 @@ def test_a_timed_out_wait_falls_back_to_the_launch_per_phase_loop(monkeypatch):
         assert relmax(p, po) < 1e-9 and abs(f - mo) / mo < 1e-9 and relmax(g, go) < 1e-7
         ctx.grad(m + 0.02)                                 # ... and the context goes on
         assert ctx.stats()["status"] == 0
+        if hit and info["timeouts"]:
+            # after a timeout the kernel is tried again 256 solves later (the tenant may have left)
+            time.sleep(0.8)
+            for k in range(130):
+                ctx.grad(m + 0.001 * k)
+            back = ctx.persist_info()
+            assert back["enabled"] == 1 and back["solves"] > info["solves"] and back["timeouts"] == info["timeouts"], back
         ctx.close()
         time.sleep(0.8)                                    # (the hog's backlog drains)
         if hit:
