@@ -1526,13 +1526,12 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     ctx->device = device_id;
     if (ctx->hp.NZP > MAXNZP) { ctx->err = "nz too large for the tridiagonal kernel (nz+1 > 1024)"; return HMCMT_EINVAL; }
     // the fp64 eigen-transform kernel (fdm_precision = 1, and the restart of a stagnating mixed-precision solve) holds at most
-    // 28 column tiles of 16 nodes: wider meshes are refused here, not at the first solve that needs it
-    if (ctx->hp.NYP / 16 > 28) { ctx->err = "mesh too wide: ny + 1 > 448 nodes (include/hmcmt.h, hmcmt_create)"; return HMCMT_EINVAL; }
+    // 28 column tiles of 16 nodes.  A wider mesh runs the default mixed-precision path (the reference takes any mesh,
+    // readEMModel2D.jl:11-154); it is refused here only where fp64 is ASKED for, and a restart that needs the kernel fails that
+    // evaluation with HMCMT_EINVAL (launch_transform) -- the safety net is what such a mesh goes without, not the solver.
+    if (ctx->hp.NYP / 16 > 28 && ctx->opt.fdm_precision == 1) { ctx->err = "fdm_precision = 1 on a mesh wider than 447 cells: the fp64 eigen-transform holds ny + 1 <= 448 nodes (include/hmcmt.h, hmcmt_create)"; return HMCMT_EINVAL; }
     HIPCHK(hipSetDevice(device_id));
-    // (hmcmt_next_cu_share, consumed here: this thread's next context, then back to the whole device)
-    ctx->shareIdx = g_nextShareIdx; ctx->shareCnt = g_nextShareCnt;
-    g_nextShareIdx = 0; g_nextShareCnt = 1;
-    ctx->shareMask = quarter_mask(ctx->shareIdx, ctx->shareCnt);
+    ctx->shareMask = quarter_mask(ctx->shareIdx, ctx->shareCnt);      // (hmcmt_next_cu_share, taken over by hmcmt_create)
     if (ctx->shareCnt > 1) {
         // a share of EVERY XCD's CUs: mask bit n is CU n / nXCD of XCD n % nXCD (measured, scripts/probe/cumask.hip: a mask that
         // leaves an XCD without a bit leaves that XCD unrestricted), so share i of c takes the CU indices [i, i + 1) * cuPerXcd / c
@@ -1806,6 +1805,9 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
                  const int64_t* freqID, const int64_t* rxID, const int64_t* dtID, const uint8_t* dataID,
                  const double* obs, const double* dataW, int64_t nAC, const int64_t* activeIdx,
                  const double* bgModel, const hmcmt_options* opts) {
+    // (hmcmt_next_cu_share is consumed by THIS call, whatever becomes of it: a create that fails must not leave the share to the next one)
+    const int shareIdx = g_nextShareIdx, shareCnt = g_nextShareCnt;
+    g_nextShareIdx = 0; g_nextShareCnt = 1;
     if (!out) { g_createError = "null ctx pointer"; return HMCMT_EINVAL; }
     *out = nullptr;
     if (!yLen || !zLen || !origin || !freqs || !rxY || !rxZ || !compMode || !dataID || !activeIdx || !bgModel ||
@@ -1822,6 +1824,7 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
         delete ctx;
         return HMCMT_EINVAL;
     }
+    ctx->shareIdx = shareIdx; ctx->shareCnt = shareCnt;
     int rc = create_impl(ctx, device_id);
     if (rc) {
         g_createError = ctx->err;
@@ -1858,6 +1861,7 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
 int hmcmt_set_options(hmcmt_ctx* ctx, const hmcmt_options* o) {
     if (!ctx || !o) return HMCMT_EINVAL;
     if (const char* e = options_error(o)) { ctx->err = e; return HMCMT_EINVAL; }
+    if (o->fdm_precision == 1 && ctx->hp.NYP / 16 > 28) { ctx->err = "fdm_precision = 1 on a mesh wider than 447 cells (the fp64 eigen-transform holds ny + 1 <= 448 nodes)"; return HMCMT_EINVAL; }
     ctx->opt = *o;
     ctx->lastItFwd = ctx->lastItAdj = 0;
     ctx->haveFwd = ctx->haveAdj = false;

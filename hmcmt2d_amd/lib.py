@@ -236,6 +236,15 @@ class HipContext:
             raise HmcmtError(rc, (self.lib.hmcmt_last_error(self.h) or b"").decode())
 
     def set_options(self, **kw):
+        before = {k: getattr(self.opts, k) for k in kw}
+        try:
+            self._set_options(**kw)
+        except HmcmtError:
+            for k, v in before.items():              # (the library kept its options: so does the mirror)
+                setattr(self.opts, k, v)
+            raise
+
+    def _set_options(self, **kw):
         for k, v in kw.items():
             if k == "precond":
                 v = PRECOND[v]

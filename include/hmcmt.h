@@ -97,9 +97,11 @@ void hmcmt_default_options(hmcmt_options* opts);
  *   obs[nData] complex, dataW[nData] = diag of InvDataModel.dataW
  *   activeIdx[nAC]    1-based cell id of each active cell (= activeCell.rowval), bgModel[ny*nz]
  *   opts              NULL for defaults
- * Limits: ny + 1 <= 448 nodes across (HMCMT_EINVAL otherwise: the fp64 eigen-transform of the preconditioner holds 28 column
- * tiles); meshes up to 207 cells wide (and nz up to 319 rows at that width, more on narrower meshes: DESIGN 5.0, "Envelope")
- * run the one-launch-per-solve kernel, all others four to six launches per iteration;
+ * Limits: the one-launch-per-solve kernel runs meshes up to 415 cells wide (two column parts per row block beyond 207; nz up to
+ * 225 rows at that width, more on narrower meshes: DESIGN 5.0, "Envelope"), all others four to six launches per iteration
+ * (DESIGN 5.1).  options.fdm_precision = 1 needs ny + 1 <= 448 nodes (HMCMT_EINVAL otherwise: the fp64 eigen-transform of the
+ * preconditioner holds 28 column tiles); wider meshes run the default mixed-precision path WITHOUT its fp64 safety net (a
+ * stagnating solve then fails its evaluation with HMCMT_EINVAL instead of being restarted);
  * hmcmt_persist_info tells which. */
 int hmcmt_create(hmcmt_ctx** ctx, int32_t device_id,
                  int64_t ny, int64_t nz, const double* yLen, const double* zLen, const double* origin,
