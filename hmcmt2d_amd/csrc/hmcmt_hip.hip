@@ -1410,8 +1410,13 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
 // parts = G workgroups, all on one XCD (32 CUs), one workgroup per CU; 2 * CW threads for tiles up to CW columns wide.
 // CS = 1 where the whole row fits one tile (its LDS); CS = 2 (two column parts per row block) on wider meshes -- the stress size.
 // does the mesh fit the kernel (its LDS, a system's workgroups on one XCD)?  twist: the factorisation the solves will use
+struct ShapeDims { int NYP, NZP, nz; };
+static bool persist_shape_dims(const ShapeDims& k, int twist, int cs, int cuPerXcd, int& G, int& cw, int& mw, size_t& lds);
 static bool persist_shape_cs(const hmcmt_ctx* ctx, int twist, int cs, int cuPerXcd, int& G, int& cw, int& mw, size_t& lds) {
-    const Solver& k = ctx->sv;
+    return persist_shape_dims(ShapeDims{ctx->sv.NYP, ctx->sv.NZP, ctx->sv.nz}, twist, cs, cuPerXcd, G, cw, mw, lds);
+}
+// (pure arithmetic on the mesh sizes: also behind hmcmt_persist_envelope, which needs no device)
+static bool persist_shape_dims(const ShapeDims& k, int twist, int cs, int cuPerXcd, int& G, int& cw, int& mw, size_t& lds) {
     const int GZ = (k.nz - 1 + PS_OWN - 1) / PS_OWN;
     G = GZ * cs;
     const int TW = ps_tile_width(k.NYP, cs);
@@ -2193,6 +2198,25 @@ int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out) {
     out[8] = ctx->persistCW ? ctx->persistCS : 0;  // column parts per row block (2: wide meshes)
     out[9] = ctx->persistTimeouts;                 // timed-out waits (the evaluation was redone with the launch-per-phase loop)
     out[10] = ctx->shareIdx; out[11] = ctx->shareCnt;   // this context's share of every XCD's CUs (hmcmt_next_cu_share)
+    return 0;
+}
+
+// Would a mesh of ny x nz cells (nz INCLUDING the air layers, as in hmcmt_create) run the one-launch-per-solve kernel on a device
+// with `cus_per_xcd` CUs per XCD (32 on MI355X; 16 / 8 for a half / quarter CU share), and in which shape?  Pure arithmetic, no
+// device needed: out = {column parts (0: outside the envelope -- the launch-per-phase loop), threads per workgroup / 2,
+// workgroups per system, modes per slab, LDS bytes per workgroup, systems per XCD at a time for `nsystems` systems}.
+int hmcmt_persist_envelope(int64_t ny, int64_t nz, int32_t cus_per_xcd, int64_t nsystems, int64_t* out) {
+    if (!out || ny < 2 || nz < 3 || cus_per_xcd < 1 || nsystems < 1) return HMCMT_EINVAL;
+    const ShapeDims k{(int)(((ny + 1) + 15) / 16 * 16), (int)(nz + 1), (int)nz};
+    for (int i = 0; i < 6; ++i) out[i] = 0;
+    for (int cs = 1; cs <= 2; ++cs) {
+        int G = 0, cw = 0, mw = 0; size_t lds = 0;
+        if (persist_shape_dims(k, 1, cs, cus_per_xcd, G, cw, mw, lds)) {
+            out[0] = cs; out[1] = cw; out[2] = G; out[3] = mw; out[4] = (int64_t)lds;
+            out[5] = std::max<int64_t>(1, std::min<int64_t>((nsystems + 7) / 8, cus_per_xcd / G));
+            break;
+        }
+    }
     return 0;
 }
 

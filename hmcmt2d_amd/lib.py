@@ -120,6 +120,7 @@ def load_library():
     lib.hmcmt_persist_info.argtypes = [vp, c_int64_p]
     lib.hmcmt_debug_hog.argtypes = [vp, C.c_int32, C.c_int32]
     lib.hmcmt_next_cu_share.argtypes = [C.c_int32, C.c_int32]
+    lib.hmcmt_persist_envelope.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int64, c_int64_p]
     lib.hmcmt_guard.argtypes = [vp, c_double_p]
     lib.hmcmt_debug_fdm_fwd.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_back_post.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_double_p]
@@ -127,7 +128,7 @@ def load_library():
                  "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async",
                  "hmcmt_wait", "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead",
                  "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond",
-                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share"):
+                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_persist_envelope"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -138,7 +139,7 @@ EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "h
                     "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async", "hmcmt_wait",
                     "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead", "hmcmt_dims",
                     "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
-                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
+                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_persist_envelope", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
                     "hmcmt_comm_last_error"]
 
 
@@ -187,6 +188,17 @@ class SampleComm:
         if self.h:
             self.lib.hmcmt_comm_destroy(self.h)
             self.h = None
+
+
+def persist_envelope(ny, nz, cus_per_xcd=32, nsystems=32):
+    """Would a mesh of ny x nz cells (nz incl. the air layers) run the one-launch-per-solve kernel, and in which shape
+    (hmcmt_persist_envelope: pure arithmetic, no GPU needed)?  column_parts == 0: outside its envelope."""
+    lib = load_library()
+    out = (C.c_int64 * 6)()
+    rc = lib.hmcmt_persist_envelope(int(ny), int(nz), int(cus_per_xcd), int(nsystems), out)
+    if rc != 0:
+        raise HmcmtError(rc, "hmcmt_persist_envelope: ny >= 2, nz >= 3, cus_per_xcd >= 1, nsystems >= 1")
+    return dict(zip(("column_parts", "threads_half", "workgroups_per_system", "slab_modes", "lds_bytes", "slots_per_xcd"), (int(x) for x in out)))
 
 
 class HipContext:

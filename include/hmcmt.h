@@ -238,6 +238,10 @@ int hmcmt_debug_flags(hmcmt_ctx* ctx, int32_t flags);
 int hmcmt_debug_spmv(hmcmt_ctx* ctx, const double* p, double* q);
 int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z);
 int hmcmt_guard(const hmcmt_ctx* ctx, double* out4);   /* {checks, worst true residual seen, last, trips (checks above HMCMT_GUARD_LIMIT, default 1e-6)}: the production guard of the stopping rule (every HMCMT_GUARD_EVERY-th evaluation, default 100) */
+int hmcmt_persist_envelope(int64_t ny, int64_t nz, int32_t cus_per_xcd, int64_t nsystems, int64_t* out6);   /* no device needed: would a mesh of ny x nz cells (nz incl. air
+                                                             layers) run the one-launch-per-solve kernel on a device with cus_per_xcd CUs per XCD (MI355X: 32; a half / quarter CU
+                                                             share: 16 / 8), and how: {column parts (0 = outside its envelope: the launch-per-phase loop), threads / 2, workgroups per
+                                                             system, modes per slab, LDS bytes per workgroup, systems per XCD at a time} */
 int hmcmt_next_cu_share(int32_t index, int32_t count);   /* the calling thread's NEXT hmcmt_create builds a context confined to share `index` of `count`
                                                              (1, 2, 4) equal shares of the CUs of every XCD (CU-masked streams): the persistent solve kernels of
                                                              `count` such contexts -- independent chains on one device, parallelHMC.jl:23-45 -- run side by side,

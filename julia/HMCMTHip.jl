@@ -27,7 +27,7 @@ using Distributed              # myid
 using HMCMT.HMCFileIO, HMCMT.HMCStruct, HMCMT.HMCUtility
 
 export HipContext, hipContext, compDataGradient, hipForward, setPrior!, proposeLeapfrog, proposeLeapfrogDevice!,
-       hipWait, hipStats, hipGuard, hipPersistInfo, hipNextCuShare, destroy!, commId, SampleComm, allgatherSamples
+       hipWait, hipStats, hipGuard, hipPersistInfo, hipPersistEnvelope, hipNextCuShare, destroy!, commId, SampleComm, allgatherSamples
 
 const libhmcmt = get(ENV, "HMCMT_HIP_LIB", joinpath(@__DIR__, "..", "hmcmt2d_amd", "libhmcmt_hip.so"))
 
@@ -335,6 +335,19 @@ function hipPersistInfo(ctx::HipContext)
     return (threads_half = out[1], workgroups_per_system = out[2], slots_per_xcd = out[3], enabled = out[4], solves = out[5],
             placement_fallbacks = out[6], usable_now = out[7], slab_modes = out[8], column_parts = out[9], timeouts = out[10],
             cu_share_index = out[11], cu_share_count = out[12])
+end
+
+"""
+    hipPersistEnvelope(ny, nz; cus_per_xcd = 32, nsystems = 32) -> NamedTuple
+
+Would a mesh of ny x nz cells (nz including the air layers) run the one-launch-per-solve kernel, and in which shape
+(`hmcmt_persist_envelope`; pure arithmetic, no device needed)?  `column_parts == 0`: outside its envelope.
+"""
+function hipPersistEnvelope(ny::Integer, nz::Integer; cus_per_xcd::Integer = 32, nsystems::Integer = 32)
+    out = zeros(Int64, 6)
+    rc = ccall((:hmcmt_persist_envelope, libhmcmt), Cint, (Int64, Int64, Int32, Int64, Ptr{Int64}), ny, nz, Int32(cus_per_xcd), nsystems, out)
+    rc == 0 || error("hmcmt_persist_envelope: invalid sizes")
+    return (column_parts = out[1], threads_half = out[2], workgroups_per_system = out[3], slab_modes = out[4], lds_bytes = out[5], slots_per_xcd = out[6])
 end
 
 """

@@ -185,3 +185,27 @@ def test_compiled_c_consumer_runs_the_hot_path(tmp_path):
     po, mo, go = oracle_eval(mesh, data, inv, m)
     assert relmax(pred, po) < 1e-9 and relmax(grad, go) < 1e-7 and abs(float(kv["misfit"][0]) - mo) / mo < 1e-9
     assert float(kv["true_res"][0]) < 1e-9 and int(kv["iters"][0]) > 0
+
+
+def test_envelope_of_the_persistent_kernel_without_a_device():
+    """hmcmt_persist_envelope: which meshes run the one-launch-per-solve kernel and in which shape -- pure arithmetic in the
+    library (the same function hmcmt_create uses), so it is checked here, in the GPU-less container, against the shapes the GPU
+    runs reported (profiles/r05_shape_fuzz.log, tests/test_gpu_persist.py): BASELINE's configurations, the width limits of one
+    and two column parts, tall narrow meshes that take more threads than their width needs, CU shares."""
+    from hmcmt2d_amd.lib import persist_envelope as env
+    e = env(200, 107, nsystems=32)                       # cfg3: one part, 8 workgroups of 512 threads per system, 4 systems per XCD
+    assert (e["column_parts"], e["threads_half"], e["workgroups_per_system"], e["slab_modes"], e["slots_per_xcd"]) == (1, 256, 8, 32, 4)
+    assert 150 * 1024 < e["lds_bytes"] <= 160 * 1024
+    e = env(400, 207, nsystems=64)                       # cfg5: two column parts, 15 x 2 workgroups, one system per XCD at a time
+    assert (e["column_parts"], e["threads_half"], e["workgroups_per_system"], e["slab_modes"], e["slots_per_xcd"]) == (2, 256, 30, 16, 1)
+    assert 158 * 1024 < e["lds_bytes"] <= 160 * 1024
+    assert (env(50, 32, nsystems=16)["column_parts"], env(50, 32, nsystems=16)["threads_half"]) == (1, 64)        # cfg2
+    assert env(96, 56, nsystems=8)["workgroups_per_system"] == 4                                                    # cfg1
+    assert env(207, 107)["column_parts"] == 1 and env(208, 107)["column_parts"] == 2                                # the width of one tile
+    assert env(415, 47)["column_parts"] == 2 and env(416, 47)["column_parts"] == 0 and env(440, 15)["column_parts"] == 0
+    e = env(60, 100)                                      # narrow and tall: 2 x 128 threads for a 64-column tile, 16-mode slabs
+    assert (e["column_parts"], e["threads_half"], e["slab_modes"]) == (1, 128, 16)
+    e = env(100, 257)                                     # 19 row blocks: 2 x 256 threads, 16-mode slabs
+    assert (e["column_parts"], e["threads_half"], e["workgroups_per_system"], e["slab_modes"]) == (1, 256, 19, 16)
+    assert env(100, 600)["column_parts"] == 0             # 43 row blocks do not fit an XCD
+    assert env(200, 107, cus_per_xcd=16)["slots_per_xcd"] == 2 and env(400, 207, cus_per_xcd=16, nsystems=64)["column_parts"] == 0   # CU shares
