@@ -181,7 +181,7 @@ struct hmcmt_ctx {
     long persistBackoff = 0;              // after a timed-out wait: solves on the launch-per-phase loop before the kernel is tried again (doubles per timeout)
     bool persistTimedOut = false;         // a wait of the last persistent launch timed out: evaluate() redoes the evaluation with the launch-per-phase loop
     int dbgPlace = 0;                     // test hook (hmcmt_debug_flags bit 2): the next persistent launch's first group fails its placement check
-    bool counted = false;                 // this context is in g_liveOnDev / holds a reference on the device lock
+    bool counted = false;                 // this context is counted in g_quarterUse / holds a reference on the device lock
     // production guard on the error-estimate stopping rule: every guardEvery-th evaluation the TRUE residual of both
     // solves is formed (two vector passes and a read-back: ~0.1 ms once in guardEvery evaluations) -- hmcmt_guard
     int guardEvery = 100;                 // HMCMT_GUARD_EVERY (0: off)
@@ -509,13 +509,12 @@ int finish_status(hmcmt_ctx* ctx);
 constexpr double SPIN_LIMIT_S = 60.0;       // a convergence poll that sees no progress for this long gives up (HMCMT_EHIP)
 
 // Two persistent kernels on one device could each hold CUs the other's missing workgroups need (they spin at their barriers
-// until the bounded waits give up).  Inside a process: the contexts alive on each device are counted, and the kernel runs only
-// for a context that is alone on its device.  Across processes: an advisory lock per device -- flock on
+// until the bounded waits give up).  Inside a process: the contexts alive on each device are counted (per quarter of every XCD's CUs:
+// g_quarterUse below), and the kernel runs only for a context that is alone on its share of the device.  Across processes: an advisory lock per device -- flock on
 // $HMCMT_LOCK_DIR (/tmp) /hmcmt_persist_<PCI bus id>.lock, taken by the first context of a process on that device and held
 // while it has one there; a process that does not get it runs the launch-per-phase loop and asks again every 256 solves.
 // (Protects hmcmt processes from each other where they share the lock directory; HMCMT_PERSIST_LOCK=0 skips it.)
 constexpr int MAXDEV = 64;
-std::atomic<int> g_liveOnDev[MAXDEV];
 // CU shares (hmcmt_next_cu_share): a context may be confined to 1/2 or 1/4 of the CUs of EVERY XCD -- its streams carry a CU
 // mask -- so that the persistent kernels of 2 or 4 contexts (chains) are co-resident on one device, each with a share of the
 // system slots.  Use of the four quarters per device; a context runs the persistent kernel when it is alone in ALL its quarters.
@@ -1300,7 +1299,6 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (!ctx) return HMCMT_EINVAL;
     if (ctx->counted) {
         if (ctx->device >= 0 && ctx->device < MAXDEV) {
-            g_liveOnDev[ctx->device].fetch_sub(1);
             for (int q = 0; q < 4; ++q) if ((ctx->shareMask >> q) & 1u) g_quarterUse[ctx->device][q].fetch_sub(1);
         }
         devlock_unref(ctx->device); ctx->counted = false;
@@ -1854,7 +1852,6 @@ int hmcmt_create(hmcmt_ctx** out, int32_t device_id, int64_t ny, int64_t nz, con
     }
     if ((rc = persist_setup(ctx))) { g_createError = ctx->err; hmcmt_destroy(ctx); return rc; }
     if (ctx->device >= 0 && ctx->device < MAXDEV) {
-        g_liveOnDev[ctx->device].fetch_add(1);
         for (int q = 0; q < 4; ++q) if ((ctx->shareMask >> q) & 1u) g_quarterUse[ctx->device][q].fetch_add(1);
     }
     devlock_ref(ctx->device);
@@ -2237,7 +2234,9 @@ int hmcmt_next_cu_share(int32_t index, int32_t count) {
 int hmcmt_debug_hog(hmcmt_ctx* ctx, int32_t nblocks, int32_t ms) {
     if (!ctx || nblocks < 1 || nblocks > 4096 || ms < 0 || ms > 10000) return HMCMT_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
-    static hipStream_t hogStream = nullptr;
+    static hipStream_t hogStreams[MAXDEV] = {};                   // (one per device, kept: the kernel outlives this call)
+    if (ctx->device < 0 || ctx->device >= MAXDEV) return HMCMT_EINVAL;
+    hipStream_t& hogStream = hogStreams[ctx->device];
     if (!hogStream) HIPCHK(hipStreamCreateWithFlags(&hogStream, hipStreamNonBlocking));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hog), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL(k_hog, dim3(nblocks), dim3(64), 160 * 1024, hogStream, (long long)ms * 100000ll, (int*)nullptr);   // (wall_clock64: 100 MHz)
