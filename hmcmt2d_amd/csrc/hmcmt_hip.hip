@@ -172,6 +172,7 @@ struct hmcmt_ctx {
     long long persistSolves = 0, persistFallbacks = 0, persistTimeouts = 0;
     int shareIdx = 0, shareCnt = 1;       // this context's share of every XCD's CUs (hmcmt_next_cu_share): index, 1 / 2 / 4 parts
     unsigned shareMask = 0xF;             // ... as quarters
+    int persistWidthK = 0;                // 208 / 416: the mesh's padded row width has a width-specialised persistent kernel (launch_persist)
     int persistCS = 1, persistGZ = 0;     // column parts of a row block (2: wide meshes, kernels_persist.h), row blocks per system
     PsConst psShadow{};                   // what d_psConst holds (launch_persist refreshes the device copy when a field differs)
     PsConst* d_psConst = nullptr;         // the kernel's launch-invariant state, read through a constant-address-space pointer
@@ -628,6 +629,15 @@ int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout, in
 #define PSL(CW, SWP) do { if (ctx->persistCS > 1) hipLaunchKernelGGL((k_cocg_persist<CW, SWP, 16, 2>), grid, dim3(2 * CW), lds, ctx->stream, a); \
                          else if (ctx->persistMW == 16) hipLaunchKernelGGL((k_cocg_persist<CW, SWP, 16, 1>), grid, dim3(2 * CW), lds, ctx->stream, a); \
                          else hipLaunchKernelGGL((k_cocg_persist<CW, SWP, 32, 1>), grid, dim3(2 * CW), lds, ctx->stream, a); } while (0)
+    // width-specialised instantiations (PS_WIDTHS: the row width is a compile-time constant) where the mesh has one of those widths
+    const int wk = ctx->persistWidthK;
+    if (wk == 208 && ctx->persistCW == 256 && ctx->persistCS == 1 && ctx->persistMW == 32) {
+        if (sweeps == 2) hipLaunchKernelGGL((k_cocg_persist<256, 2, 32, 1, 208>), grid, dim3(512), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((k_cocg_persist<256, 1, 32, 1, 208>), grid, dim3(512), lds, ctx->stream, a);
+    } else if (wk == 416 && ctx->persistCW == 256 && ctx->persistCS == 2 && ctx->persistMW == 16) {
+        if (sweeps == 2) hipLaunchKernelGGL((k_cocg_persist<256, 2, 16, 2, 416>), grid, dim3(512), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((k_cocg_persist<256, 1, 16, 2, 416>), grid, dim3(512), lds, ctx->stream, a);
+    } else
     if (ctx->persistCW == 256) { if (sweeps == 2) PSL(256, 2); else PSL(256, 1); }
     else if (ctx->persistCW == 128) { if (sweeps == 2) PSL(128, 2); else PSL(128, 1); }
     else { if (sweeps == 2) PSL(64, 2); else PSL(64, 1); }
@@ -1267,12 +1277,13 @@ int finish_status(hmcmt_ctx* ctx) {
 }
 
 // test hook (hmcmt_debug_hog): workgroups that hold a CU's whole LDS and spin for a while -- a foreign tenant on the device
-__global__ __launch_bounds__(64) void k_hog(long long ticks, int* sink) {
+__global__ __launch_bounds__(64) void k_hog(long long ticks, int* started) {
     extern __shared__ __attribute__((aligned(16))) char hogmem[];
     hogmem[threadIdx.x] = (char)threadIdx.x;
+    if (started && threadIdx.x == 0) __hip_atomic_fetch_add(started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (mapped host word: hmcmt_debug_hog waits for it)
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
-    if (sink && hogmem[threadIdx.x] == 77 && ticks < 0) *sink = 1;
+    if (hogmem[threadIdx.x] == 77 && ticks < 0) hogmem[0] = 1;
 }
 
 }  // namespace
@@ -1461,7 +1472,9 @@ static int persist_setup(hmcmt_ctx* ctx) {
     size_t lds = 0;
     if (!persist_shape(ctx, k.twist, cuPerXcd, G, cw, mw, lds, &cs)) return 0;
     ctx->persistMW = mw;
-    const void* fns[18] = {reinterpret_cast<const void*>(k_cocg_persist<256, 1, 32, 1>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 32, 1>),
+    const void* fns[22] = {reinterpret_cast<const void*>(k_cocg_persist<256, 1, 32, 1, 208>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 32, 1, 208>),
+                           reinterpret_cast<const void*>(k_cocg_persist<256, 1, 16, 2, 416>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 16, 2, 416>),
+                           reinterpret_cast<const void*>(k_cocg_persist<256, 1, 32, 1>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 32, 1>),
                            reinterpret_cast<const void*>(k_cocg_persist<128, 1, 32, 1>), reinterpret_cast<const void*>(k_cocg_persist<128, 2, 32, 1>),
                            reinterpret_cast<const void*>(k_cocg_persist<64, 1, 32, 1>), reinterpret_cast<const void*>(k_cocg_persist<64, 2, 32, 1>),
                            reinterpret_cast<const void*>(k_cocg_persist<256, 1, 16, 1>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 16, 1>),
@@ -1475,6 +1488,9 @@ static int persist_setup(hmcmt_ctx* ctx) {
     ctx->persistG = G;
     ctx->persistCS = cs;
     ctx->persistGZ = G / cs;
+    // the width-specialised instantiations (launch_persist); HMCMT_PERSIST_WIDTHK=0 keeps the generic kernels (A/B runs, tests)
+    ctx->persistWidthK = (k.NYP == 208 || k.NYP == 416) ? k.NYP : 0;
+    if (const char* e = getenv("HMCMT_PERSIST_WIDTHK")) if (e[0] == '0') ctx->persistWidthK = 0;
     ctx->persistSlots = std::max(1, std::min((k.S + 7) / 8, cuPerXcd / G));
     ctx->persistLds = lds;
     ctx->psyncBytes = ((size_t)(32 * 8 * ctx->persistSlots + 16) * sizeof(unsigned) + 15) & ~(size_t)15;
@@ -2230,7 +2246,7 @@ int hmcmt_next_cu_share(int32_t index, int32_t count) {
 }
 
 // Test hook: `nblocks` workgroups that each hold 160 KB of LDS (a whole CU) and spin for `ms` milliseconds, on a stream of their
-// own -- returns at once.  What another application on the device does to the persistent kernel's co-residency (tests/test_gpu_persist.py).
+// own -- returns once they are resident (or after 2 s).  What another application on the device does to the persistent kernel's co-residency (tests/test_gpu_persist.py).
 int hmcmt_debug_hog(hmcmt_ctx* ctx, int32_t nblocks, int32_t ms) {
     if (!ctx || nblocks < 1 || nblocks > 4096 || ms < 0 || ms > 10000) return HMCMT_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
@@ -2239,8 +2255,19 @@ int hmcmt_debug_hog(hmcmt_ctx* ctx, int32_t nblocks, int32_t ms) {
     hipStream_t& hogStream = hogStreams[ctx->device];
     if (!hogStream) HIPCHK(hipStreamCreateWithFlags(&hogStream, hipStreamNonBlocking));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hog), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(k_hog, dim3(nblocks), dim3(64), 160 * 1024, hogStream, (long long)ms * 100000ll, (int*)nullptr);   // (wall_clock64: 100 MHz)
+    // (returns when the hog is RESIDENT -- min(nblocks, the device's CUs) of its workgroups have started, counted in a mapped host
+    //  word; a fresh process loads the code object at this first launch, which a fixed sleep in the test did not cover -- or after 2 s)
+    static int* hogStarted[MAXDEV] = {};
+    int*& started = hogStarted[ctx->device];
+    if (!started) HIPCHK(hipHostMalloc((void**)&started, sizeof(int), hipHostMallocMapped));
+    *(volatile int*)started = 0;
+    hipLaunchKernelGGL(k_hog, dim3(nblocks), dim3(64), 160 * 1024, hogStream, (long long)ms * 100000ll, started);   // (wall_clock64: 100 MHz)
     HIPCHK(hipGetLastError());
+    int ncu = 0;
+    HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    const int want = std::min(nblocks, ncu > 0 ? ncu : 256);
+    const auto t0 = std::chrono::steady_clock::now();
+    while (*(volatile int*)started < want && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.0) __builtin_ia32_pause();
     return 0;
 }
 

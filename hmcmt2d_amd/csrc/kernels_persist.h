@@ -195,7 +195,9 @@ __device__ __forceinline__ bool ps_collect(const u4v* recSys, int which, int G, 
 // phases share: 48 registers per thread in the first version, which the compiler spilled): E = coupling to the east neighbour
 // (the west one is the neighbour's E; column 0 holds the coupling of column 1 to the boundary), M = omega * mass, V = coupling
 // of a row to the next row TOWARDS THE MIDDLE of the tile (the two halves of a tile are mirrored; the last row of a half
-// couples to the first row of the other half).  The diagonal is minus the sum of the four couplings.
+// couples to the first row of the other half) -- in the width-specialised kernels (NYK) the coupling of a tile row to the next
+// tile row to the SOUTH instead (mesh orientation: no select of north / south from inner / outer in every row of every pass).
+// The diagonal is minus the sum of the four couplings.
 struct PsPl { const float *E, *M, *V; };
 #ifndef HMCMT_PS_GRP
 #define HMCMT_PS_GRP 3
@@ -208,19 +210,37 @@ constexpr int PS_GRP = HMCMT_PS_GRP;      // rows the scheduler may interleave i
 // two workgroups compute (an own row of one, a halo row of the other) must come out BIT FOR BIT the same in both -- the
 // halo rows' p enters the owners' fp64 q = A p, and x += alpha p, r -= alpha q stay consistent only if every workgroup uses
 // the same p -- so the terms are ordered by MESH direction (north, south), not by the thread's direction (outer, inner).
-template <int JLO, int JHI = PS_J, class F>
-__device__ __forceinline__ void ps_rows(const PsPl& co, const c32* __restrict__ S, int t0i_, int es, int c, F&& f) {
+template <bool MESH, int JLO, int JHI = PS_J, class F>
+__device__ __forceinline__ void ps_rows(const PsPl& co, const c32* __restrict__ S, int t0i_, int es, int c, int tw, F&& f) {
     const int t0i = ps_opq(t0i_);
     // (a rolling window over the column -- the row's outer neighbour and the row itself are the previous row's centre and inner
     //  neighbour, three tile reads per row instead of five -- was measured and lost: the values carried from row to row cost the
     //  two-sweep kernel 60 more spilled registers, 46 -> 51 us per iteration)
+    // MESH (the width-specialised kernels, NYK: the V plane in mesh orientation): neighbours and couplings are addressed by mesh
+    // direction -- north is one tile row up (index - tw), whichever way the thread walks its column -- from the lowest address of
+    // the row's five points: with the tile width a compile-time constant every access of a row is ONE address register + an
+    // immediate offset, and there is no select between "inner" and "outer" (the stencil passes issued ~50 vector instructions
+    // per row, half of them address arithmetic, selects and reloads of spilled bases).  Without a constant width this form costs
+    // the generic kernels 40 more spilled registers: they keep the select.
 #pragma unroll
     for (int j = JLO; j < JHI; ++j) {
         const int ti = t0i + j * es;
-        const c32 uc = S[ti], ue = S[ti + 1], uw = S[ti - 1], ui = S[ti + es], uo = S[ti - es];
-        const c32 un = c ? ui : uo, us = c ? uo : ui;
-        const float ce = co.E[ti], cw = co.E[ti - 1], dm = co.M[ti], va = co.V[ti], vb = co.V[ti - es];
-        const float cn = c ? va : vb, cs = c ? vb : va;
+        c32 un, us, uw, uc, ue;
+        float cw, ce, dm, cn, cs;
+        if constexpr (MESH) {
+            const c32* __restrict__ p0 = S + (ti - tw - 1);
+            un = p0[1]; uw = p0[tw]; uc = p0[tw + 1]; ue = p0[tw + 2]; us = p0[2 * tw + 1];
+            const float* __restrict__ e0 = co.E + (ti - 1);
+            const float* __restrict__ v0 = co.V + (ti - tw);
+            cw = e0[0]; ce = e0[1]; dm = co.M[ti]; cn = v0[0]; cs = v0[tw];
+        } else {
+            uc = S[ti]; ue = S[ti + 1]; uw = S[ti - 1];
+            const c32 ui = S[ti + es], uo = S[ti - es];
+            un = c ? ui : uo; us = c ? uo : ui;
+            ce = co.E[ti]; cw = co.E[ti - 1]; dm = co.M[ti];
+            const float va = co.V[ti], vb = co.V[ti - es];
+            cn = c ? va : vb; cs = c ? vb : va;
+        }
         const float dk = -((ce + cw) + (cn + cs));
         float are = __builtin_fmaf(-dm, uc.im, dk * uc.re), aim = __builtin_fmaf(dm, uc.re, dk * uc.im);
         are = __builtin_fmaf(ce, ue.re, are); aim = __builtin_fmaf(ce, ue.im, aim);
@@ -236,11 +256,19 @@ __device__ __forceinline__ c32 ps_dinv(float dk, float dm, float wJ) {
     const float inv = wJ * __builtin_amdgcn_rcpf(__builtin_fmaf(dk, dk, dm * dm));
     return c32{dk * inv, -(dm * inv)};
 }
-// ... of tile index ti, from the planes (the same sum as in ps_apply)
-__device__ __forceinline__ c32 ps_dinv_at(const PsPl& co, int ti, int es, int c, float wJ) {
-    const float ce = co.E[ti], cw = co.E[ti - 1], dm = co.M[ti], va = co.V[ti], vb = co.V[ti - es];
-    const float cn = c ? va : vb, cs = c ? vb : va;
-    return ps_dinv(-((ce + cw) + (cn + cs)), dm, wJ);
+// ... of tile index ti, from the planes (the same sum as in ps_rows)
+template <bool MESH>
+__device__ __forceinline__ c32 ps_dinv_at(const PsPl& co, int ti, int es, int c, int tw, float wJ) {
+    if constexpr (MESH) {
+        const float* __restrict__ e0 = co.E + (ti - 1);
+        const float* __restrict__ v0 = co.V + (ti - tw);
+        const float cw = e0[0], ce = e0[1], dm = co.M[ti], cn = v0[0], cs = v0[tw];
+        return ps_dinv(-((ce + cw) + (cn + cs)), dm, wJ);
+    } else {
+        const float ce = co.E[ti], cw = co.E[ti - 1], dm = co.M[ti], va = co.V[ti], vb = co.V[ti - es];
+        const float cn = c ? va : vb, cs = c ? vb : va;
+        return ps_dinv(-((ce + cw) + (cn + cs)), dm, wJ);
+    }
 }
 
 // block-wide deterministic sums of four doubles (NWV waves); result in every thread.  Two scratch areas used alternately (`flip`,
@@ -316,10 +344,10 @@ template <int NT, int MW> struct PsChunks { static constexpr int P = NT / (2 * M
 __device__ __forceinline__ c32 ps_cfma(c32 a, c32 b, c32 x) {      // a + b x
     return c32{__builtin_fmaf(-b.im, x.im, __builtin_fmaf(b.re, x.re, a.re)), __builtin_fmaf(b.im, x.re, __builtin_fmaf(b.re, x.im, a.im))};
 }
-template <int NT, int MW, int CS>
+template <int NT, int MW, int CS, int NYK = 0>
 __device__ __forceinline__ void ps_slab_solve_reg(PsKP kb, char* smem, const float* f1, const float* f2, int s, int slab, int tidx, long long* stp = nullptr) {
     constexpr int P = PsChunks<NT, MW>::P, NL = 2 * MW * P, RC = PS_RCMAX;      // (chunks of RC rows exactly: rows behind a half's last one are identity rows)
-    const int NYP = kb->NYP, NZP = kb->NZP, n = kb->nz - 1, nyi = kb->ny - 1;
+    const int NYP = NYK ? NYK : kb->NYP, NZP = kb->NZP, n = kb->nz - 1, nyi = kb->ny - 1;
     const int mid = twist_mid(n, 1), RL = mid + 1 + PSL_PAD;
     c32* recF = reinterpret_cast<c32*>(smem);             // [2][P][MW] x {last local value, last product} of the elimination sweep
     c32* recB = recF + 2 * P * MW * 2;                    // ... of the substitution sweep
@@ -515,9 +543,14 @@ __host__ __device__ inline int ps_plane_width(int NYP) {
 
 #define PS_STAMP(i) if (stampNow) L.stamps[(long)blockIdx.x * 16 + (i)] = wall_clock64();
 
-template <int CW, int SW, int MW = 32, int CS = 1>
+// NYK > 0: the kernel is specialised for meshes of NYK padded nodes per row (tile width, plane strides and the LDS carve's row
+// strides are compile-time constants: the stencil passes address a row's points and coefficients as one register + immediates);
+// NYK = 0 takes the width from the state block.  Column parts: NYK must be a multiple of 32 (two parts of equal width).
+template <int CW, int SW, int MW = 32, int CS = 1, int NYK = 0>
 __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
     constexpr int NT = 2 * CW, NWV = NT / 64;
+    constexpr bool MESH = NYK > 0;       // the V plane in mesh orientation (ps_rows)
+    static_assert(NYK == 0 || (NYK % 16 == 0 && (CS == 1 || NYK % 32 == 0)), "width specialisation: whole MFMA tiles, equal column parts");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sh = reinterpret_cast<double*>(smem);                           // [2][32] block reductions (ps_block_sum4), [64..70) the reductions' totals
     volatile int* sflag = reinterpret_cast<volatile int*>(smem + 640);      // [0] give up, [1] this is the last workgroup to leave, [2] its OR of the systems' states
@@ -579,9 +612,9 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
     // cbase + iy; the part owns [ownLo, ownHi), the rest of its tile are halo columns (copies, like the halo rows)
     const int c = __builtin_amdgcn_readfirstlane(tid / CW);
     const int iy = tid & (CW - 1);
-    const int NYP = kb->NYP, ny = kb->ny, nz = kb->nz;
-    const int TWc = CS == 1 ? NYP : kb->TW;                             // the wider part's tile: the LDS carve
-    const int C0 = CS == 1 ? NYP : kb->C0;
+    const int NYP = NYK ? NYK : kb->NYP, ny = kb->ny, nz = kb->nz;
+    const int TWc = CS == 1 ? NYP : (NYK ? ps_tile_width(NYK, 2) : kb->TW);      // the wider part's tile: the LDS carve
+    const int C0 = CS == 1 ? NYP : (NYK ? ps_split_col(NYK) : kb->C0);
     const int cbase = (CS > 1 && hp) ? C0 - PS_HC : 0;
     const int LWh = CS == 1 ? NYP : (hp ? NYP - C0 + PS_HC : C0 + PS_HC);      // width of this part's tile
     const int TW = LWh;                                                 // ... and its row stride in LDS: column LWh - 1's east neighbour is the next row's
@@ -638,7 +671,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
     const int ntlF = CS == 1 ? ntl : tbaseF + (wave < textraF ? 1 : 0), t0wF = CS == 1 ? t0w : wave * tbaseF + min(wave, textraF);
     const int kg0 = (CS > 1 && hp) ? (C0 >> 5) : 0;
     const int KGF = CS == 1 ? KG : (hp ? KG - kg0 : (C0 + 31) >> 5);
-    const int PLW = CS == 1 ? NYP : kb->PLW;                            // width of the forward transform's operand planes
+    const int PLW = CS == 1 ? NYP : (NYK ? ps_plane_width(NYK) : kb->PLW);      // width of the forward transform's operand planes
     const int nslab = (NYP + MW - 1) / MW;
 
     for (int round = 0; alive; ++round) {
@@ -684,7 +717,12 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                     if (gy >= 1) pe[ti] = fe[j];
                     if (gy == 1) pe[ti - 1] = fw[j];                       // column 0: the coupling of column 1 to the boundary
                     pm[ti] = (fe[j] != 0.f || fw[j] != 0.f) ? fm[j] : 1.f;   // (non-interior nodes: zero couplings, mass 1)
-                    pv[ti] = vin[j] != 0.f ? vin[j] : vout[j + 1];
+                    // V[tile row] = the coupling to the next tile row to the SOUTH.  This thread knows the edge between its row j and
+                    // the next one inwards: for the upper half that is the row's own south edge, for the mirrored half the south edge
+                    // of the row above it in the tile (both halves write the edge between rows 11 and 12: the same value)
+                    // (generic kernels: V[tile row] = the coupling towards the middle of the tile)
+                    pv[(MESH && c) ? ti - TW : ti] = vin[j] != 0.f ? vin[j] : vout[j + 1];
+                    if (MESH && c && j == 0) pv[ti] = 0.f;                 // (the last tile row's south edge: never used, never garbage)
                 }
             }
         }
@@ -753,12 +791,16 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
 #pragma unroll
                 for (int j = 0; j < PS_J; ++j) {
                     const int ti = tw0 + j * ts;
-                    const c32 v = j >= JZ1 ? ps_scal(mk(j), ps_cmul(ps_dinv_at(co, ti, ts, c, kb->wJ), rr(j))) : c32{0, 0};
+                    const c32 v = j >= JZ1 ? ps_scal(mk(j), ps_cmul(ps_dinv_at<MESH>(co, ti, ts, c, TW, kb->wJ), rr(j))) : c32{0, 0};
                     if ((iyv < LWh)) T0[ti] = v;
                 }
             }
             __syncthreads();
             double p1r = 0, p1i = 0, dum = 0;
+            // (the arrays of this system a phase stores to or loads from, row after row: their bases are formed ONCE per phase -- inside
+            //  the rows' conditional stores the compiler re-derived each from the state block per row: two scalar loads, a wait and a
+            //  64-bit multiply in front of every store)
+            float2* const pubZ1 = pubZ();
             if constexpr (SW == 2) {
                 {
                     const int tw0 = ps_opq(t0i);
@@ -766,24 +808,24 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                     for (int j = 0; j < 4; ++j) if ((iyv < LWh)) T1[tw0 + j * ts] = c32{0, 0};
                 }
                 const float wJ = kb->wJ;
-                ps_rows<4>(co, T0, t0i, ts, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+                ps_rows<MESH, 4>(co, T0, t0i, ts, c, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
                     const c32 u2 = ps_scal(mk(j), ps_cadd(uc, ps_cmul(ps_scal(L.w2, ps_dinv(dk, dm, wJ)), ps_csub(rr(j), av))));
                     if ((iyv < LWh)) T1[ti] = u2;
                     const int g = gb + gs * j;
-                    if (j >= PS_HALO && own() && g >= 1 && g <= nz - 1) *ps_at(pubZ(), eo(j)) = float2{u2.re, u2.im};
+                    if (j >= PS_HALO && own() && g >= 1 && g <= nz - 1) *ps_at(pubZ1, eo(j)) = float2{u2.re, u2.im};
                 });
                 __syncthreads();
             } else {
 #pragma unroll
                 for (int j = PS_HALO; j < PS_J; ++j) {
                     const int g = gb + gs * j;
-                    if (own() && g >= 1 && g <= nz - 1) *ps_at(pubZ(), eo(j)) = float2{T0[ps_opq(t0i) + j * ts].re, T0[ps_opq(t0i) + j * ts].im};
+                    if (own() && g >= 1 && g <= nz - 1) *ps_at(pubZ1, eo(j)) = float2{T0[ps_opq(t0i) + j * ts].re, T0[ps_opq(t0i) + j * ts].im};
                 }
             }
             // t on the own rows, straight into the bf16 hi/lo planes of the forward transform (the first tile's space: with two sweeps
             // its readers are behind the barrier above; with one, t is formed from the first tile itself, so a barrier separates them)
             c32 tv[PS_NO];
-            ps_rows<PS_HALO>(co, SW == 2 ? T1 : T0, t0i, ts, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+            ps_rows<MESH, PS_HALO>(co, SW == 2 ? T1 : T0, t0i, ts, c, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
                 const c32 rv = rr(j);
                 tv[j - PS_HALO] = ps_scal(mk(j), ps_csub(rv, av));
                 if (SW == 2) {
@@ -794,6 +836,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             if (SW == 1) __syncthreads();
             PS_STAMP(1)
             PS_PHASE();
+            float2* const tbuf1 = tbuf();
             if (own()) {
                 // (column parts: plane column of mesh column gy = gy - 32 kg0 -- whole K-groups, the part's own columns only: the
                 //  forward transform is the sum of the parts' partial products)
@@ -807,7 +850,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                     bf16_split_pk(tv[q].re, tv[q].im, hp2, lp);
                     b[0] = (unsigned short)hp2; b[PLW] = (unsigned short)(hp2 >> 16);
                     b[2 * PLW] = (unsigned short)lp; b[3 * PLW] = (unsigned short)(lp >> 16);
-                    if (SW == 2 && g >= 1 && g <= nz - 1) *ps_at(tbuf(), eo(j)) = float2{tv[q].re, tv[q].im};
+                    if (SW == 2 && g >= 1 && g <= nz - 1) *ps_at(tbuf1, eo(j)) = float2{tv[q].re, tv[q].im};
                 }
             }
             if constexpr (CS == 1) {
@@ -914,7 +957,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             if (!sys_sync()) { alive = false; break; }                         // T1: every row of yhat is in the L2
             PS_STAMP(3)
             // ================= tridiagonal solves of this workgroup's mode slabs =================
-            for (int slab = jw; slab < nslab; slab += G) ps_slab_solve_reg<NT, MW, CS>(kb, arena, tabF1, tabF2, s, slab, tidv, stampNow ? L.stamps + (long)blockIdx.x * 16 : nullptr);
+            for (int slab = jw; slab < nslab; slab += G) ps_slab_solve_reg<NT, MW, CS, NYK>(kb, arena, tabF1, tabF2, s, slab, tidv, stampNow ? L.stamps + (long)blockIdx.x * 16 : nullptr);
             PS_STAMP(4)
             u4v bbk[8][2];                                                     // the wave's V' fragments of the back transform: in flight during the wait
             {
@@ -934,6 +977,8 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             // epilogue operands in the MFMA's output layout (lane: column 16 t + ljv, rows 8 rg + 2 g4v + h2): the pre-smoothed
             // iterate of the owners and, two sweeps, t of the own rows (second part of the rho identity: sum of t .* (V y))
             float2 zq[3][2][2];
+            const float2* const pubZ2 = pubZ();
+            const float2* const pubR2 = pubR();
             {
                 // the operand planes: rows R0 .. R0 + 23 of the solved slabs, every mode, straight into LDS (buffer_load ... lds: a wave
                 // copies 64 consecutive 16-byte units per instruction, no registers in between, all of a wave's ten-odd loads in
@@ -958,16 +1003,16 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                             const int tau = 8 * rg + 2 * g4v + h2, g = R0 + tau, col = (t ? tl1 : tl0) * 16 + ljv;
                             const bool in = g >= 1 && g <= nz - 1 && col >= 1 && col <= ny - 1;
                             const unsigned e = in ? (unsigned)(g * NYP + col) : (unsigned)(NYP + 1);
-                            zq[rg][t][h2] = ps_ld_f2(ps_at(pubZ(), e));
+                            zq[rg][t][h2] = ps_ld_f2(ps_at(pubZ2, e));
                         }
 #pragma unroll
-                for (int j = 0; j < PS_HALO; ++j) rh[j] = ps_ld_c32(ps_at(pubR(), ei(j)));      // the owners' r' (no drift of the local copies)
+                for (int j = 0; j < PS_HALO; ++j) rh[j] = ps_ld_c32(ps_at(pubR2, ei(j)));      // the owners' r' (no drift of the local copies)
                 if constexpr (CS > 1) {
                     // a halo COLUMN's copy of r (rows j >= 5): the owners' r', like the halo rows'
                     if (!own() && (iyv < LWh)) {
 #pragma unroll
                         for (int q = 0; q < PS_NO; ++q) {
-                            const c32 v = ps_ld_c32(ps_at(pubR(), ei(PS_HALO + q)));
+                            const c32 v = ps_ld_c32(ps_at(pubR2, ei(PS_HALO + q)));
                             r64[q] = (double)mk(PS_HALO + q) * cplx{(double)v.re, (double)v.im};
                         }
                     }
@@ -1026,8 +1071,9 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             for (int j = 0; j < PS_HALO; ++j) rh[j] = mk(j) * rh[j];
             float2 t7[PS_NO], z7[PS_NO];       // two sweeps: t and z2 of the own rows, for the second part of the rho identity: sum of t .* (V y), V y = z3 - z2
             if (SW == 2) {
+                const float2* const tbuf2 = tbuf();
 #pragma unroll
-                for (int q = 0; q < PS_NO; ++q) { t7[q] = *ps_at(tbuf(), ei(PS_HALO + q)); z7[q] = ps_ld_f2(ps_at(pubZ(), ei(PS_HALO + q))); }
+                for (int q = 0; q < PS_NO; ++q) { t7[q] = *ps_at(tbuf2, ei(PS_HALO + q)); z7[q] = ps_ld_f2(ps_at(pubZ2, ei(PS_HALO + q))); }
             }
             __syncthreads();
             PS_STAMP(6)
@@ -1039,7 +1085,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             }
             {
                 const float wJ = kb->wJ;
-                ps_rows<1>(co, T1, t0i, ts, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+                ps_rows<MESH, 1>(co, T1, t0i, ts, c, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
                     const c32 d = ps_dinv(dk, dm, wJ);
                     const c32 zf = ps_scal(mk(j), ps_cadd(uc, ps_cmul(SW == 2 ? ps_scal(L.w2, d) : d, ps_csub(rr(j), av))));
                     if ((iyv < LWh)) T0[ti] = zf;
@@ -1072,7 +1118,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                     for (int j = 0; j < 2; ++j) if ((iyv < LWh)) T1[tw0 + j * ts] = c32{0, 0};
                 }
                 const float wJ = kb->wJ;
-                ps_rows<2>(co, T0, t0i, ts, c, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+                ps_rows<MESH, 2>(co, T0, t0i, ts, c, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
                     const c32 z5 = ps_scal(mk(j), ps_cadd(uc, ps_cmul(ps_dinv(dk, dm, wJ), ps_csub(rr(j), av))));
                     if ((iyv < LWh)) T1[ti] = z5;
                 });
@@ -1093,8 +1139,11 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             PS_STAMP(7)
             PS_PHASE();
             c32 pold[PS_J];                                                    // the old direction, from its owners: in flight during the wait
+            {
+                const float2* const pubP1 = pubP();
 #pragma unroll
-            for (int j = 0; j < PS_J; ++j) pold[j] = ps_ld_c32(ps_at(pubP(), ei(j)));      // (masked where it is used)
+                for (int j = 0; j < PS_J; ++j) pold[j] = ps_ld_c32(ps_at(pubP1, ei(j)));      // (masked where it is used)
+            }
             // R1, second half: wave 0 collects the G records (no counter, no second round trip), the totals go round through LDS
             if (wave == 0) {
                 double t4[4] = {0, 0, 0, 0};
@@ -1156,7 +1205,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             c32 qh[PS_HALO];                                                   // the halo rows' q: fp32
 #pragma unroll
             for (int j = 0; j < PS_HALO; ++j) qh[j] = c32{0, 0};
-            ps_rows<JP + 1, PS_HALO>(co, TP, t0i, ts, c, [&](int j, int, c32, c32 av, float, float) __attribute__((always_inline)) { qh[j] = av; });
+            ps_rows<MESH, JP + 1, PS_HALO>(co, TP, t0i, ts, c, TW, [&](int j, int, c32, c32 av, float, float) __attribute__((always_inline)) { qh[j] = av; });
             // own rows: fp64; q itself waits in LDS for alpha (each thread reads back what it wrote: z's tile is free now)
             double pqr = 0, pqi = 0, dum2 = 0;
             {
@@ -1181,10 +1230,13 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             }
             __builtin_amdgcn_sched_barrier(0);
             cplx xv[PS_NO];                                                    // x of the own rows: requested here, used behind R2
+            {
+                const cplx* const xs1 = xsys();
 #pragma unroll
-            for (int q = 0; q < PS_NO; ++q) {
-                const int j = PS_HALO + q, g = gb + gs * j;
-                xv[q] = *ps_at(xsys(), (own() && g >= 1 && g <= nz - 1) ? eo(j) : (unsigned)(NYP + 1));
+                for (int q = 0; q < PS_NO; ++q) {
+                    const int j = PS_HALO + q, g = gb + gs * j;
+                    xv[q] = *ps_at(xs1, (own() && g >= 1 && g <= nz - 1) ? eo(j) : (unsigned)(NYP + 1));
+                }
             }
             if (CS > 1 && !own()) { pqr = 0; pqi = 0; }
             { double dz = 0; ps_block_sum4<NWV>(pqr, pqi, dum2, dz, sh, shFlip); }
@@ -1209,6 +1261,9 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             {
                 const int tu0 = ps_opq(t0i);
                 const bool mine = own();
+                cplx* const xs2 = xsys();
+                float2* const pubR3 = pubR();
+                float2* const pubP3 = pubP();
 #pragma unroll
                 for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q, g = gb + gs * j;
@@ -1218,10 +1273,10 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                         if (CS == 1 || mine) {
                             const c32 pv = TP[tu0 + j * ts];
                             const cplx xn = xv[q] + al * cplx{(double)pv.re, (double)pv.im};
-                            *ps_at(xsys(), eo(j)) = xn;
+                            *ps_at(xs2, eo(j)) = xn;
                             xxs += cabs2(xn);                                  // (rows 1 .. nz-1, all columns: as the launch-per-phase kernels)
-                            *ps_at(pubR(), eo(j)) = float2{(float)r64[q].re, (float)r64[q].im};
-                            *ps_at(pubP(), eo(j)) = float2{pv.re, pv.im};
+                            *ps_at(pubR3, eo(j)) = float2{(float)r64[q].re, (float)r64[q].im};
+                            *ps_at(pubP3, eo(j)) = float2{pv.re, pv.im};
                         }
                     }
                 }

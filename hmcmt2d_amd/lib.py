@@ -442,7 +442,7 @@ class HipContext:
                          "column_parts", "timeouts", "cu_share_index", "cu_share_count"), (int(x) for x in out)))
 
     def debug_hog(self, nblocks, ms):
-        """Test hook: nblocks workgroups holding a CU's LDS each for ms milliseconds on a stream of their own (returns at once)."""
+        """Test hook: nblocks workgroups holding a CU's LDS each for ms milliseconds on a stream of their own (returns once they are resident)."""
         self._check(self.lib.hmcmt_debug_hog(self.h, int(nblocks), int(ms)))
 
     def debug_persist_precond(self, r, sweeps=1):

@@ -351,7 +351,6 @@ def test_a_timed_out_wait_falls_back_to_the_launch_per_phase_loop(monkeypatch):
         ctx.grad(m)
         assert ctx.persist_info()["solves"] == 2 and ctx.persist_info()["timeouts"] == 0
         ctx.debug_hog(1500, 100)
-        time.sleep(0.02)                                   # (the hog is resident before the solve is launched)
         p, f, g = ctx.grad(m + 0.01)                       # must succeed whatever the dispatcher does
         info, st = ctx.persist_info(), ctx.stats()
         assert st["status"] == 0
