@@ -541,7 +541,9 @@ __host__ __device__ inline int ps_plane_width(int NYP) {
     return 32 * (k0 > k1 ? k0 : k1);
 }
 
-#define PS_STAMP(i) if (stampNow) L.stamps[(long)blockIdx.x * 16 + (i)] = wall_clock64();
+// (a UNIFORM branch around the stamp -- stamps requested and third iteration --, thread 0 inside it: as one per-lane condition the
+//  compiler kept its lane mask and the stamps' address in spilled scalar registers and reloaded both at each of the twelve stamps)
+#define PS_STAMP(i) if (stampIt) { if (tid == 0) L.stamps[(long)blockIdx.x * 16 + (i)] = wall_clock64(); }
 
 // NYK > 0: the kernel is specialised for meshes of NYK padded nodes per row (tile width, plane strides and the LDS carve's row
 // strides are compile-time constants: the stencil passes address a row's points and coefficients as one register + immediates);
@@ -549,7 +551,10 @@ __host__ __device__ inline int ps_plane_width(int NYP) {
 template <int CW, int SW, int MW = 32, int CS = 1, int NYK = 0>
 __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
     constexpr int NT = 2 * CW, NWV = NT / 64;
-    constexpr bool MESH = NYK > 0;       // the V plane in mesh orientation (ps_rows)
+#ifndef HMCMT_PS_MESH_CS2
+#define HMCMT_PS_MESH_CS2 0
+#endif
+    constexpr bool MESH = NYK > 0 && (CS == 1 || HMCMT_PS_MESH_CS2);       // the V plane in mesh orientation (ps_rows)
     static_assert(NYK == 0 || (NYK % 16 == 0 && (CS == 1 || NYK % 32 == 0)), "width specialisation: whole MFMA tiles, equal column parts");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sh = reinterpret_cast<double*>(smem);                           // [2][32] block reductions (ps_block_sum4), [64..70) the reductions' totals
@@ -759,7 +764,8 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
 #define PS_PHASE() kb = kb0; asm volatile("" : "+v"(e0), "+v"(t0i), "+v"(inM), "+v"(tidv), "+v"(lanev), "+v"(ljv), "+v"(g4v), "+v"(iyv), "+s"(kb))   /* row offsets / masks / the state block's scalars are re-derived per PHASE instead of living in registers across all of them */
         for (;;) {
             PS_PHASE();
-            const bool stampNow = L.stamps && tid == 0 && it == 2;
+            const bool stampIt = L.stamps != nullptr && it == 2;      // (uniform)
+            const bool stampNow = stampIt && tid == 0;
             // the wave's V fragments of the forward transform (constant; KGF <= 8 k-groups x 2 column tiles): requested here, they
             // arrive under the pre-smoother (every phase of this loop is a memory round trip + a little arithmetic: what can be
             // requested a phase early, is)
