@@ -125,6 +125,13 @@ __device__ __forceinline__ bool ps_wait(unsigned* cnt, unsigned target, int* fai
     }
 }
 __device__ __forceinline__ c32 operator+(c32 a, c32 b) { return c32{a.re + b.re, a.im + b.im}; }
+// a value every lane holds alike, as a SCALAR: the solve's loop-carried scalars (rho, the error estimate's reference) live in scalar
+// registers -- or, spilled, in lanes of a vector register -- instead of ten vector registers that the iteration loop spilled to scratch
+__device__ __forceinline__ double ps_unif(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 // an opaque copy: what is derived from it (a phase's twelve row addresses) is computed in that phase and dies with it, instead
 // of being hoisted out of the iteration loop and kept -- or spilled -- for all of it
 __device__ __forceinline__ int ps_opq(int x) { asm volatile("" : "+v"(x)); return x; }
@@ -593,7 +600,9 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
         }
     }
     __syncthreads();
-    bool alive = sflag[0] == 0;
+    // (what decides a loop's exit is read as a SCALAR -- readfirstlane of the LDS word every lane reads alike --: the compiler then knows
+    //  the solve's loops for uniform ones, and what they carry from iteration to iteration may live in scalar registers)
+    bool alive = __builtin_amdgcn_readfirstlane(sflag[0]) == 0;
 
     auto sys_arrive = [&]() {           // ONE thread, behind ITS OWN payload stores (or behind a drained workgroup barrier)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -603,7 +612,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
         ++epoch;
         if (tid == 0 && !ps_wait(sy, (unsigned)G * epoch, kb->fail, kb->spinLimit)) sflag[0] = 2;
         __syncthreads();
-        return sflag[0] == 0;
+        return __builtin_amdgcn_readfirstlane(sflag[0]) == 0;
     };
     auto sys_sync = [&]() -> bool {     // all threads: every wave's stores drained, then arrive + wait
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1157,7 +1166,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                 if (lane == 0) { sh[64] = t4[0]; sh[65] = t4[1]; sh[66] = t4[2]; sh[67] = t4[3]; if (!okc) sflag[0] = 2; }
             }
             __syncthreads();                                                   // (also completes z's tile)
-            if (sflag[0]) { alive = false; break; }
+            if (__builtin_amdgcn_readfirstlane(sflag[0])) { alive = false; break; }
             PS_STAMP(8)
             // the fp64 stencil coefficients of the own rows: requested here, they arrive under the p update
             double dm64[PS_NO], ce64[PS_NO], cw64[PS_NO], ci64[PS_NO], co64[PS_NO];
@@ -1174,8 +1183,8 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                 }
             }
             // ================= scalars: rho, error estimate, convergence, beta =================
-            const cplx rz = cplx{sh[64], sh[65]};
-            const double zz = sh[66], xx = sh[67];
+            const cplx rz = cplx{ps_unif(sh[64]), ps_unif(sh[65])};
+            const double zz = ps_unif(sh[66]), xx = ps_unif(sh[67]);
             const bool first = it == 1;
             bool on = true;
             st = 0;
@@ -1257,7 +1266,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                 if (lane == 0) { sh[68] = t2[0]; sh[69] = t2[1]; if (!okc) sflag[0] = 2; }
             }
             __syncthreads();
-            if (sflag[0]) { alive = false; break; }
+            if (__builtin_amdgcn_readfirstlane(sflag[0])) { alive = false; break; }
             PS_STAMP(10)
             PS_PHASE();
             // ================= alpha; x += alpha p, r -= alpha q; publish r', p =================
