@@ -764,7 +764,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
         auto rr = [&](int j) -> c32 { return j < PS_HALO ? rh[j < PS_HALO ? j : 0] : c32{(float)r64[j >= PS_HALO ? j - PS_HALO : 0].re, (float)r64[j >= PS_HALO ? j - PS_HALO : 0].im}; };
 
         cplx rhoPrev = cplx{0, 0}, rhoCur = cplx{0, 0};
-        double errRef = 0.0, xxPrev = 0.0;
+        double errRef = 0.0, xxPrev = 0.0;      // errRef: a tenth of the error estimate the stagnation watch counts from
         int errRefIt = 0;
         bool stalled = false;
         int st = 0;
@@ -1179,7 +1179,8 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                     dm64[q] = *ps_at(dMm, e);
                     ce64[q] = *ps_at(cYm, e); cw64[q] = *ps_at(cYm, e - 1u);
                     const double cs = *ps_at(cZm, e), cn = *ps_at(cZm, e - (unsigned)NYP);
-                    ci64[q] = c ? cn : cs; co64[q] = c ? cs : cn;
+                    // (generic kernels: inner / outer neighbour of the mirrored half; width-specialised ones: north / south, no select)
+                    ci64[q] = MESH ? cn : (c ? cn : cs); co64[q] = MESH ? cs : (c ? cs : cn);
                 }
             }
             // ================= scalars: rho, error estimate, convergence, beta =================
@@ -1193,8 +1194,16 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             else if (it - 1 >= L.maxit) { on = false; st = HMCMT_ENOCONV; }
             if (!(isfinite(rz.re) && isfinite(rz.im) && isfinite(zz) && isfinite(xx))) { on = false; st = HMCMT_EBREAKDOWN; }
             est = first ? (zz == 0.0 ? 0.0 : 1.0) : sqrt(zz / xx);
-            if (first || est < 0.1 * errRef) { errRef = est; errRefIt = it; }
-            else if (on && it - errRefIt > kb->stallIt) { stalled = true; on = false; }
+            {
+                // (the reference of the stagnation watch as a scalar, assigned unconditionally: as a conditionally assigned vector value
+                //  it was the one register pair the loop still kept in scratch -- reloaded here behind an s_waitcnt vmcnt(0) that also
+                //  waited for the coefficient loads this phase has just requested)
+                // (errRef holds a TENTH of the reference estimate: the product formed where it is assigned, once, not at every comparison)
+                const bool better = first || est < errRef;
+                errRef = ps_unif(better ? 0.1 * est : errRef);
+                if (better) errRefIt = it;
+                else if (on && it - errRefIt > kb->stallIt) { stalled = true; on = false; }
+            }
             if (!on) break;
             const cplx be = first ? cplx{0, 0} : rz / rhoPrev;
             rhoPrev = rz; rhoCur = rz;
@@ -1229,7 +1238,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                 for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q;
                     const int ti = tq0 + j * ts;
-                    const c32 pc = TP[ti], pe = TP[ti + 1], pw = TP[ti - 1], pi = TP[ti + ts], po = TP[ti - ts];
+                    const c32 pc = TP[ti], pe = TP[ti + 1], pw = TP[ti - 1], pi = TP[MESH ? ti - TW : ti + ts], po = TP[MESH ? ti + TW : ti - ts];
                     const double dmw = w * dm64[q];
                     const double dk = -((ce64[q] + cw64[q]) + (ci64[q] + co64[q]));
                     cplx acc = cplx{dk * (double)pc.re - dmw * (double)pc.im, dk * (double)pc.im + dmw * (double)pc.re};
