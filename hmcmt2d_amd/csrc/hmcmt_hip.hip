@@ -172,7 +172,7 @@ struct hmcmt_ctx {
     long long persistSolves = 0, persistFallbacks = 0, persistTimeouts = 0;
     int shareIdx = 0, shareCnt = 1;       // this context's share of every XCD's CUs (hmcmt_next_cu_share): index, 1 / 2 / 4 parts
     unsigned shareMask = 0xF;             // ... as quarters
-    int persistWidthK = 0;                // 208: the mesh's padded row width has a width-specialised persistent kernel (launch_persist)
+    int persistWidthK = 0;                // 112 / 208 / 416: the mesh's padded row width has a width-specialised persistent kernel (launch_persist)
     int persistCS = 1, persistGZ = 0;     // column parts of a row block (2: wide meshes, kernels_persist.h), row blocks per system
     PsConst psShadow{};                   // what d_psConst holds (launch_persist refreshes the device copy when a field differs)
     PsConst* d_psConst = nullptr;         // the kernel's launch-invariant state, read through a constant-address-space pointer
@@ -634,6 +634,12 @@ int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout, in
     if (wk == 208 && ctx->persistCW == 256 && ctx->persistCS == 1 && ctx->persistMW == 32) {
         if (sweeps == 2) hipLaunchKernelGGL((k_cocg_persist<256, 2, 32, 1, 208>), grid, dim3(512), lds, ctx->stream, a);
         else hipLaunchKernelGGL((k_cocg_persist<256, 1, 32, 1, 208>), grid, dim3(512), lds, ctx->stream, a);
+    } else if (wk == 112 && ctx->persistCW == 128 && ctx->persistCS == 1 && ctx->persistMW == 32) {      // (the reference's example meshes: 96 cells)
+        if (sweeps == 2) hipLaunchKernelGGL((k_cocg_persist<128, 2, 32, 1, 112>), grid, dim3(256), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((k_cocg_persist<128, 1, 32, 1, 112>), grid, dim3(256), lds, ctx->stream, a);
+    } else if (wk == 416 && ctx->persistCW == 256 && ctx->persistCS == 2 && ctx->persistMW == 16) {
+        if (sweeps == 2) hipLaunchKernelGGL((k_cocg_persist<256, 2, 16, 2, 416>), grid, dim3(512), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((k_cocg_persist<256, 1, 16, 2, 416>), grid, dim3(512), lds, ctx->stream, a);
     } else
     if (ctx->persistCW == 256) { if (sweeps == 2) PSL(256, 2); else PSL(256, 1); }
     else if (ctx->persistCW == 128) { if (sweeps == 2) PSL(128, 2); else PSL(128, 1); }
@@ -1469,7 +1475,9 @@ static int persist_setup(hmcmt_ctx* ctx) {
     size_t lds = 0;
     if (!persist_shape(ctx, k.twist, cuPerXcd, G, cw, mw, lds, &cs)) return 0;
     ctx->persistMW = mw;
-    const void* fns[20] = {reinterpret_cast<const void*>(k_cocg_persist<256, 1, 32, 1, 208>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 32, 1, 208>),
+    const void* fns[24] = {reinterpret_cast<const void*>(k_cocg_persist<256, 1, 32, 1, 208>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 32, 1, 208>),
+                           reinterpret_cast<const void*>(k_cocg_persist<128, 1, 32, 1, 112>), reinterpret_cast<const void*>(k_cocg_persist<128, 2, 32, 1, 112>),
+                           reinterpret_cast<const void*>(k_cocg_persist<256, 1, 16, 2, 416>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 16, 2, 416>),
                            reinterpret_cast<const void*>(k_cocg_persist<256, 1, 32, 1>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 32, 1>),
                            reinterpret_cast<const void*>(k_cocg_persist<128, 1, 32, 1>), reinterpret_cast<const void*>(k_cocg_persist<128, 2, 32, 1>),
                            reinterpret_cast<const void*>(k_cocg_persist<64, 1, 32, 1>), reinterpret_cast<const void*>(k_cocg_persist<64, 2, 32, 1>),
@@ -1481,11 +1489,12 @@ static int persist_setup(hmcmt_ctx* ctx) {
                            reinterpret_cast<const void*>(k_cocg_persist<64, 1, 16, 2>), reinterpret_cast<const void*>(k_cocg_persist<64, 2, 16, 2>)};
     for (const void* f : fns)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return 0; }
+
     ctx->persistG = G;
     ctx->persistCS = cs;
     ctx->persistGZ = G / cs;
     // the width-specialised instantiations (launch_persist); HMCMT_PERSIST_WIDTHK=0 keeps the generic kernels (A/B runs, tests)
-    ctx->persistWidthK = (k.NYP == 208 && cs == 1) ? k.NYP : 0;      // (the two-part kernel at 416 nodes, the stress size, was built too: its stencil phases gain 1.3 us, its transforms lose 1.8)
+    ctx->persistWidthK = (((k.NYP == 208 || k.NYP == 112) && cs == 1) || (k.NYP == 416 && cs == 2)) ? k.NYP : 0;
     if (const char* e = getenv("HMCMT_PERSIST_WIDTHK")) if (e[0] == '0') ctx->persistWidthK = 0;
     ctx->persistSlots = std::max(1, std::min((k.S + 7) / 8, cuPerXcd / G));
     ctx->persistLds = lds;

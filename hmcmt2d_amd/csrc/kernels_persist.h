@@ -888,20 +888,30 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                 for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
                     for (int t = 0; t < 2; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
+                // (two-stage pipeline as in the back transform below: the operand rows of the next step are requested before this step's MFMAs)
+                auto ldF = [&](int kg, int rg, u4v& h, u4v& l) __attribute__((always_inline)) {
+                    const unsigned short* ap = PL + ((long)(8 * rg + (ljv >> 1)) * 4 + (ljv & 1)) * NYP + 32 * kg + 8 * g4v;
+                    h = *reinterpret_cast<const u4v*>(ap);
+                    l = *reinterpret_cast<const u4v*>(ap + 2 * NYP);
+                };
+                u4v ahc, alc;
+                ldF(0, 0, ahc, alc);
 #pragma unroll
                 for (int kg = 0; kg < 8; ++kg) {
                     if (kg < KG) {
 #pragma unroll
                         for (int rg = 0; rg < 2; ++rg) {
-                            const unsigned short* ap = PL + ((long)(8 * rg + (ljv >> 1)) * 4 + (ljv & 1)) * NYP + 32 * kg + 8 * g4v;
-                            const bf8v ah = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap));
-                            const bf8v al = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap + 2 * NYP));
+                            u4v ahn = ahc, aln = alc;
+                            const int kgn = rg < 1 ? kg : kg + 1, rgn = rg < 1 ? 1 : 0;
+                            if (kgn < KG && kgn < 8) ldF(kgn, rgn, ahn, aln);
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                             for (int t = 0; t < 2; ++t) {
                                 const bf8v bhf = __builtin_bit_cast(bf8v, bfw[kg][t]);
-                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
-                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
+                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, alc), bhf, acc[rg][t], 0, 0, 0);
+                                acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, ahc), bhf, acc[rg][t], 0, 0, 0);
                             }
+                            ahc = ahn; alc = aln;
                         }
                     }
                 }
@@ -952,6 +962,10 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                             for (int t = 0; t < 4; ++t)
                                 bfw[2 * q + (t >> 1)][t & 1] = *ps_at(kb->Vb, (unsigned)(((kg0 + kg + 4) * NTc + min(t0wF + t, NTc - 1)) * 64 + lanev));
                         }
+                        // (k-group by k-group: with the row width a compile-time constant the loop is straight-line code and the scheduler
+                        //  pulled the streamed V fragments' loads together behind the MFMAs they were meant to run ahead of: 5.05 us for
+                        //  this transform at the stress size, 3.35 with the barrier, 4.1-4.3 in the generic kernel with or without it)
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
 #pragma unroll
@@ -1042,6 +1056,16 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                 for (int rg = 0; rg < 3; ++rg)
 #pragma unroll
                     for (int t = 0; t < 2; ++t) acc[rg][t] = f4v{0, 0, 0, 0};
+                // The operand rows of step (k-group, row group) + 1 are requested BEFORE the four MFMAs of the step at hand (an explicit
+                // two-stage pipeline, pinned by the scheduling barrier): as the compiler laid the plain loop out, every step was
+                // 2 ds_read_b128 -> s_waitcnt lgkmcnt(0) -> 4 MFMAs, the LDS round trip exposed 21 times at cfg3 (back transform 4.96 -> 4.69 us).
+                auto ldA = [&](int kg, int rg, u4v& h, u4v& l) __attribute__((always_inline)) {
+                    const unsigned short* ap = PL + ((long)(8 * rg + (ljv >> 1)) * 4 + (ljv & 1)) * NYP + 32 * kg + 8 * g4v;
+                    h = *reinterpret_cast<const u4v*>(ap);
+                    l = *reinterpret_cast<const u4v*>(ap + 2 * NYP);
+                };
+                u4v ahc, alc;
+                ldA(0, 0, ahc, alc);
 #pragma unroll
                 for (int ch = 0; ch < (CS == 1 ? 1 : 2); ++ch) {
 #pragma unroll
@@ -1050,15 +1074,23 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                         if (kg < KG) {
 #pragma unroll
                             for (int rg = 0; rg < 3; ++rg) {
-                                const unsigned short* ap = PL + ((long)(8 * rg + (ljv >> 1)) * 4 + (ljv & 1)) * NYP + 32 * kg + 8 * g4v;
-                                const bf8v ah = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap));
-                                const bf8v al = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v*>(ap + 2 * NYP));
+                                u4v ahn = ahc, aln = alc;
+                                if constexpr (CS == 1 || NYK > 0) {
+                                    const int kgn = rg < 2 ? kg : kg + 1, rgn = rg < 2 ? rg + 1 : 0;
+                                    if (kgn < KG && kgn < (CS == 1 ? 8 : 16)) ldA(kgn, rgn, ahn, aln);
+                                    __builtin_amdgcn_sched_barrier(0);
+                                } else {
+                                    // (column parts: the eight registers of the second stage cost the two-part kernel 66 spilled registers -- its
+                                    //  steps load their own rows)
+                                    if (kg + rg > 0) ldA(kg, rg, ahc, alc);
+                                }
 #pragma unroll
                                 for (int t = 0; t < 2; ++t) {
                                     const bf8v bhf = __builtin_bit_cast(bf8v, bbk[q][t]);
-                                    acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhf, acc[rg][t], 0, 0, 0);
-                                    acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhf, acc[rg][t], 0, 0, 0);
+                                    acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, alc), bhf, acc[rg][t], 0, 0, 0);
+                                    acc[rg][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, ahc), bhf, acc[rg][t], 0, 0, 0);
                                 }
+                                ahc = ahn; alc = aln;
                             }
                             if (CS > 1 && ch == 0) {                     // the second chunk's fragments, as the first's are used up
                                 const int kn = min(kg + 8, KG - 1);
