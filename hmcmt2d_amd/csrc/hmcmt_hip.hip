@@ -2219,6 +2219,14 @@ int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out) {
     return 0;
 }
 
+// The compile-time row width of the width-specialised persistent kernel this context launches (112 / 208 / 416 padded nodes per
+// row: kernels_persist.h, NYK), 0 = the generic kernel (or no persistent kernel at all).
+int hmcmt_persist_width(const hmcmt_ctx* ctx, int32_t* width) {
+    if (!ctx || !width) return HMCMT_EINVAL;
+    *width = ctx->persistCW ? ctx->persistWidthK : 0;
+    return 0;
+}
+
 // Would a mesh of ny x nz cells (nz INCLUDING the air layers, as in hmcmt_create) run the one-launch-per-solve kernel on a device
 // with `cus_per_xcd` CUs per XCD (32 on MI355X; 16 / 8 for a half / quarter CU share), and in which shape?  Pure arithmetic, no
 // device needed: out = {column parts (0: outside the envelope -- the launch-per-phase loop), threads per workgroup / 2,

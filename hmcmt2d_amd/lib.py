@@ -120,6 +120,7 @@ def load_library():
     lib.hmcmt_persist_info.argtypes = [vp, c_int64_p]
     lib.hmcmt_debug_hog.argtypes = [vp, C.c_int32, C.c_int32]
     lib.hmcmt_next_cu_share.argtypes = [C.c_int32, C.c_int32]
+    lib.hmcmt_persist_width.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.hmcmt_persist_envelope.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int64, c_int64_p]
     lib.hmcmt_guard.argtypes = [vp, c_double_p]
     lib.hmcmt_debug_fdm_fwd.argtypes = [vp, c_double_p, c_double_p]
@@ -128,7 +129,7 @@ def load_library():
                  "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async",
                  "hmcmt_wait", "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead",
                  "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond",
-                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_persist_envelope"):
+                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_persist_envelope", "hmcmt_persist_width"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -139,7 +140,7 @@ EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "h
                     "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async", "hmcmt_wait",
                     "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead", "hmcmt_dims",
                     "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
-                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_persist_envelope", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
+                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_persist_envelope", "hmcmt_persist_width", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
                     "hmcmt_comm_last_error"]
 
 
@@ -440,6 +441,12 @@ class HipContext:
         self._check(self.lib.hmcmt_persist_info(self.h, out))
         return dict(zip(("threads_half", "workgroups_per_system", "slots_per_xcd", "enabled", "solves", "placement_fallbacks", "usable_now", "slab_modes",
                          "column_parts", "timeouts", "cu_share_index", "cu_share_count"), (int(x) for x in out)))
+
+    def persist_width(self):
+        """Row width (padded nodes) of the width-specialised persistent kernel this context launches; 0: the generic kernel."""
+        w = C.c_int32(0)
+        self._check(self.lib.hmcmt_persist_width(self.h, C.byref(w)))
+        return int(w.value)
 
     def debug_hog(self, nblocks, ms):
         """Test hook: nblocks workgroups holding a CU's LDS each for ms milliseconds on a stream of their own (returns once they are resident)."""

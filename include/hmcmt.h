@@ -254,6 +254,8 @@ int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out12);  /* {threads/2 (0:
                                                                    column parts per row block (1; 2 on meshes wider than one tile: the stress size),
                                                                    timed-out waits (each one: the evaluation redone with the launch-per-phase loop),
                                                                    CU share index, CU share count (hmcmt_next_cu_share)} */
+int hmcmt_persist_width(const hmcmt_ctx* ctx, int32_t* width);   /* the compile-time row width (padded nodes: 112 / 208 / 416) of the width-specialised persistent
+                                                                     kernel this context launches; 0: the generic kernel (HMCMT_PERSIST_WIDTHK=0 forces it) */
 int hmcmt_debug_hog(hmcmt_ctx* ctx, int32_t nblocks, int32_t ms);   /* test hook: nblocks workgroups that each hold a CU's LDS for ms milliseconds on a stream of their own (a foreign tenant on the device); returns once they are resident, without waiting for them to end */
 int hmcmt_debug_persist_precond(hmcmt_ctx* ctx, int32_t sweeps, const double* r, double* z);   /* the persistent solve kernel's preconditioner (tests) */
 int hmcmt_debug_fdm_fwd(hmcmt_ctx* ctx, const double* t, double* out);   /* [2][S*vstride] complex: fused kernel | separate kernels */

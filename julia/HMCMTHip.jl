@@ -338,6 +338,19 @@ function hipPersistInfo(ctx::HipContext)
 end
 
 """
+    hipPersistWidth(ctx) -> Int
+
+Row width (padded nodes: 112 / 208 / 416) of the width-specialised persistent kernel the context launches (`hmcmt_persist_width`);
+0: the generic kernel.
+"""
+function hipPersistWidth(ctx::HipContext)
+    w = Ref{Int32}(0)
+    rc = ccall((:hmcmt_persist_width, libhmcmt), Cint, (Ptr{Cvoid}, Ptr{Int32}), ctx.ptr, w)
+    rc == 0 || error("hmcmt_persist_width failed")
+    return Int(w[])
+end
+
+"""
     hipPersistEnvelope(ny, nz; cus_per_xcd = 32, nsystems = 32) -> NamedTuple
 
 Would a mesh of ny x nz cells (nz including the air layers) run the one-launch-per-solve kernel, and in which shape

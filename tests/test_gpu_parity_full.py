@@ -46,13 +46,16 @@ def _check(ctx, m, pred_ref, misfit_ref, grad_refs, inv, mesh, deep_rows=5, grad
     return pred, misfit, grad
 
 
-def _ran_the_persistent_kernel(ctx, parts=None):
+def _ran_the_persistent_kernel(ctx, parts=None, width=None):
     """Which solver a parity test tested: the one-launch-per-solve kernel, with the expected number of column
-    parts -- not, silently, the launch-per-phase loop (a context leaked by an earlier test, a lost device lock)."""
+    parts -- not, silently, the launch-per-phase loop (a context leaked by an earlier test, a lost device lock) -- and, where
+    the mesh has one, the width-specialised instantiation of it (hmcmt_persist_width: 112 / 208 / 416 padded nodes per row)."""
     info = ctx.persist_info()
     assert info["usable_now"] == 1 and info["enabled"] == 1 and info["solves"] >= 2 and info["placement_fallbacks"] == 0 and info["timeouts"] == 0, info
     if parts is not None:
         assert info["column_parts"] == parts, info
+    if width is not None:
+        assert ctx.persist_width() == width, ctx.persist_width()
 
 
 def test_cfg1_full_parity():
@@ -68,7 +71,7 @@ def test_cfg1_full_parity():
     ny = mesh.gridSize[0]; zid = len(mesh.airLayer)
     rows = slice(zid * (ny + 1), (zid + 2) * (ny + 1))
     assert relmax(ex[rows], g["exTE_rx"]) < 1e-9 and relmax(hx[rows], g["hxTM_rx"]) < 1e-9
-    _ran_the_persistent_kernel(ctx, 1)
+    _ran_the_persistent_kernel(ctx, 1, width=112)
     ctx.close()
 
 
@@ -95,7 +98,7 @@ def test_cfg3_mesh_frequency_subset_parity_and_full_run_agreement():
     #  same absolute error: 3e-7 of its own maximum (measured 2e-8 .. 1e-7), i.e. 1e-10 of the rough state's.
     _, _, g_true = _check(ctx, m_true, g["pred_true"], float(g["misfit_true"]), g["grad_true"], inv, mesh, grad_tol=3e-7, misfit_tol=2e-8)
     assert np.abs(g_true - g["grad_true"]).max() < 1e-9 * np.abs(g["grad"]).max()
-    _ran_the_persistent_kernel(ctx, 1)
+    _ran_the_persistent_kernel(ctx, 1, width=208)
     ctx.close()
     # full headline problem: 16 frequencies, the subset's observations at the subset's frequencies
     ctx16 = HipContext(mesh, data16, inv16, verify=True)
@@ -108,7 +111,7 @@ def test_cfg3_mesh_frequency_subset_parity_and_full_run_agreement():
     ea16, ha16 = ctx16.fields(adjoint=True)
     for a, b in ((ex16[:, fidx], ex), (hx16[:, fidx], hx), (ea16[:, fidx], ea), (ha16[:, fidx], ha)):
         assert np.abs(a - b).max() <= 1e-10 * np.abs(b).max()
-    _ran_the_persistent_kernel(ctx16, 1)
+    _ran_the_persistent_kernel(ctx16, 1, width=208)
     ctx16.close()
 
 
@@ -137,7 +140,7 @@ def test_cfg3_all_sixteen_frequencies_parity():
     assert relmax(pred, g["pred"]) < PRED_TOL and gerr_split(grad, g["grad"], inv, mesh)[0] < GRAD_TOL
     info = ctx.persist_info()            # the headline shape of the kernel: 8 workgroups of 512 threads per system, 4 systems per XCD at a time
     assert info["threads_half"] == 256 and info["workgroups_per_system"] == 8 and info["slots_per_xcd"] == 4 and info["solves"] >= 6
-    _ran_the_persistent_kernel(ctx, 1)
+    _ran_the_persistent_kernel(ctx, 1, width=208)
     ctx.close()
 
 
@@ -169,7 +172,7 @@ def test_cfg5_mesh_frequency_subset_parity_and_full_run_agreement():
     assert np.abs(g_true - g["grad_true"]).max() < 1e-9 * np.abs(g["grad"]).max()
     info = ctx.persist_info()            # the wide mesh runs the persistent kernel with two column parts: 15 row blocks x 2 = 30 workgroups, one system per XCD
     assert info["workgroups_per_system"] == 30 and info["slots_per_xcd"] == 1 and info["slab_modes"] == 16
-    _ran_the_persistent_kernel(ctx, 2)
+    _ran_the_persistent_kernel(ctx, 2, width=416)
     ctx.close()
     # all 32 frequencies (the stress configuration itself): the subset's systems inside the full batch
     n32 = len(data32.rxID)
@@ -181,7 +184,7 @@ def test_cfg5_mesh_frequency_subset_parity_and_full_run_agreement():
     pred32, _, _ = ctx32.grad(m)
     assert ctx32.stats()["status"] == 0 and ctx32.stats()["true_res_max"] < 2e-8
     assert relmax(pred32[sel], g["pred"]) < PRED_TOL
-    _ran_the_persistent_kernel(ctx32, 2)
+    _ran_the_persistent_kernel(ctx32, 2, width=416)
     ctx32.close()
 
 

@@ -436,3 +436,34 @@ def test_one_sweep_solves_do_not_lose_q_to_the_next_iterations_first_write(monke
     assert ctx.persist_info()["solves"] == 300
     ctx.close()
     assert worst < 1e-8, worst
+
+
+@pytest.mark.parametrize("ny,width,parts,sweeps", [(100, 112, 1, 1), (100, 112, 1, 2), (200, 208, 1, 1), (200, 208, 1, 2), (405, 416, 2, 1), (405, 416, 2, 2)])
+def test_width_specialised_kernels_equal_the_generic_ones_and_the_oracle(monkeypatch, ny, width, parts, sweeps):
+    """The persistent kernel has instantiations with the row width as a compile-time constant (NYK: 112 padded nodes -- the
+    reference's 96-cell example meshes --, 208 -- the headline mesh --, 416 -- the stress size, two column parts): the stencil
+    passes address a row's points as one register + immediates (one-part kernels: in mesh orientation, no inner / outer selects),
+    the transforms' MFMA loops are explicit two-stage pipelines.  Same arithmetic as the generic kernel up to the order of two
+    fp64 additions in q = A p: predicted data, misfit and gradient agree to the solver tolerance, the iteration counts to +-1 --
+    and both stand against the oracle (ragged meshes of those widths: masked data, a fixed cell, a rough model; the full-size
+    meshes against the oracle: tests/test_gpu_parity_full.py, which runs the specialised kernels by default).
+    HMCMT_PERSIST_WIDTHK=0 forces the generic kernel; hmcmt_persist_width says which one a context launches."""
+    mesh, data, inv, m = ragged_problem(ny, 23, 2, 6, 4, 3)
+    res = {}
+    for wk in (1, 0):
+        if wk:
+            monkeypatch.delenv("HMCMT_PERSIST_WIDTHK", raising=False)
+        else:
+            monkeypatch.setenv("HMCMT_PERSIST_WIDTHK", "0")
+        ctx = _ctx(monkeypatch, mesh, data, inv, True, sweeps, verify=True)
+        assert ctx.persist_width() == (width if wk else 0), ctx.persist_width()
+        res[wk] = ctx.grad(m) + (ctx.stats(), ctx.persist_info(), ctx.iters())
+        ctx.close()
+    (p1, f1, g1, s1, i1, it1), (p0, f0, g0, s0, i0, it0) = res[1], res[0]
+    for s_, i_ in ((s1, i1), (s0, i0)):
+        assert s_["status"] == 0 and s_["true_res_max"] < 1e-9 and s_["fallback_solves"] == 0
+        assert i_["solves"] == 2 and i_["column_parts"] == parts
+    assert relmax(p1, p0) < 1e-9 and abs(f1 - f0) / abs(f0) < 1e-9 and relmax(g1, g0) < 1e-8
+    assert np.abs(it1 - it0).max() <= 1, (it1, it0)
+    po, mo, go = oracle_eval(mesh, data, inv, m)
+    assert relmax(p1, po) < 1e-9 and abs(f1 - mo) / mo < 1e-9 and relmax(g1, go) < 1e-7
