@@ -278,21 +278,32 @@ __device__ __forceinline__ c32 ps_dinv_at(const PsPl& co, int ti, int es, int c,
     }
 }
 
-// block-wide deterministic sums of four doubles (NWV waves); result in every thread.  Two scratch areas used alternately (`flip`,
-// toggled by the caller): a reduction's readers are separated from the NEXT reduction's writers (other area) by this one's barrier,
-// and from the one after that (same area) by the next one's -- ONE barrier per reduction instead of two.
-template <int NWV>
-__device__ __forceinline__ void ps_block_sum4(double& a, double& b, double& c, double& d, double* sh, int& flip) {
-    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
+// block-wide deterministic sums of NV doubles (NWV waves); the totals arrive in THREAD 0 only -- it is the one that publishes them
+// (as first written every thread added the eight waves' partial sums of four values, two of the second reduction's four being
+// zeros: 150 vector instructions per wave and iteration for nobody).  Two scratch areas used alternately (`flip`, toggled by the
+// caller): a reduction's readers are separated from the NEXT reduction's writers (other area) by this one's barrier, and from the
+// one after that (same area) by the next one's -- ONE barrier per reduction instead of two.  Same order of additions as ever.
+template <int NWV, int NV>
+__device__ __forceinline__ void ps_block_sum_t0(double (&v)[NV], double* sh, int& flip) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
     const int w = threadIdx.x >> 6;
     double* s0 = sh + 32 * flip;
     flip ^= 1;
-    if ((threadIdx.x & 63) == 0) { s0[w] = a; s0[8 + w] = b; s0[16 + w] = c; s0[24 + w] = d; }
-    __syncthreads();
-    double sa = 0, sb = 0, sc = 0, sd = 0;
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int i = 0; i < NWV; ++i) { sa += s0[i]; sb += s0[8 + i]; sc += s0[16 + i]; sd += s0[24 + i]; }
-    a = sa; b = sb; c = sc; d = sd;
+        for (int i = 0; i < NV; ++i) s0[8 * i + w] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double t = 0;
+#pragma unroll
+            for (int k = 0; k < NWV; ++k) t += s0[8 * i + k];
+            v[i] = t;
+        }
+    }
 }
 
 // ---- the tridiagonal solves of one slab (MW modes x all rows) of one system: the twisted factorisation of k_fdm_fwd (kernels_fdm.h;
@@ -564,7 +575,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
     constexpr bool MESH = NYK > 0 && (CS == 1 || HMCMT_PS_MESH_CS2);       // the V plane in mesh orientation (ps_rows)
     static_assert(NYK == 0 || (NYK % 16 == 0 && (CS == 1 || NYK % 32 == 0)), "width specialisation: whole MFMA tiles, equal column parts");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* sh = reinterpret_cast<double*>(smem);                           // [2][32] block reductions (ps_block_sum4), [64..70) the reductions' totals
+    double* sh = reinterpret_cast<double*>(smem);                           // [2][32] block reductions (ps_block_sum_t0), [64..70) the reductions' totals
     volatile int* sflag = reinterpret_cast<volatile int*>(smem + 640);      // [0] give up, [1] this is the last workgroup to leave, [2] its OR of the systems' states
     int shFlip = 0;
     char* arena = smem + 1024;
@@ -647,6 +658,18 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
         if (g >= 1 && g <= nz - 1 && gy >= 1 && gy <= ny - 1) inM |= 1u << j;
     }
     auto isIn = [&](int j) { return (inM >> j) & 1u; };
+    // bit j: thread-row j is one of the mesh's interior ROWS (1 .. nz-1) -- uniform over the wave (the half c), ONE scalar for the
+    // twelve rows, laundered per phase like the state block: as twelve comparisons `g >= 1 && g <= nz - 1` the compiler hoisted
+    // twelve 64-bit masks (and their conjunctions with the column conditions) out of the iteration loop and reloaded them from
+    // spilled scalar registers at every conditional store
+    unsigned rowM = 0;
+#pragma unroll
+    for (int j = 0; j < PS_J; ++j) {
+        const int g = gb + gs * j;
+        if (g >= 1 && g <= nz - 1) rowM |= 1u << j;
+    }
+    rowM = __builtin_amdgcn_readfirstlane(rowM);
+    auto rowIn = [&](int j) -> bool { return (rowM >> j) & 1u; };
     // ... as a factor 0 / 1: the rows are computed without branches -- non-interior nodes have harmless coefficients in the planes
     // (mass 1: no division by zero) and their results are multiplied away.  (One `if (interior)` per row and pass made the
     // compiler keep twelve 64-bit lane masks in scalar registers, spill them, and branch around every row.)
@@ -770,7 +793,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
         int st = 0;
         double est = 0.0;
         it = 0;
-#define PS_PHASE() kb = kb0; asm volatile("" : "+v"(e0), "+v"(t0i), "+v"(inM), "+v"(tidv), "+v"(lanev), "+v"(ljv), "+v"(g4v), "+v"(iyv), "+s"(kb))   /* row offsets / masks / the state block's scalars are re-derived per PHASE instead of living in registers across all of them */
+#define PS_PHASE() kb = kb0; asm volatile("" : "+v"(e0), "+v"(t0i), "+v"(inM), "+v"(tidv), "+v"(lanev), "+v"(ljv), "+v"(g4v), "+v"(iyv), "+s"(kb), "+s"(rowM))   /* row offsets / masks / the state block's scalars are re-derived per PHASE instead of living in registers across all of them */
         for (;;) {
             PS_PHASE();
             const bool stampIt = L.stamps != nullptr && it == 2;      // (uniform)
@@ -827,14 +850,14 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                     const c32 u2 = ps_scal(mk(j), ps_cadd(uc, ps_cmul(ps_scal(L.w2, ps_dinv(dk, dm, wJ)), ps_csub(rr(j), av))));
                     if ((iyv < LWh)) T1[ti] = u2;
                     const int g = gb + gs * j;
-                    if (j >= PS_HALO && own() && g >= 1 && g <= nz - 1) *ps_at(pubZ1, eo(j)) = float2{u2.re, u2.im};
+                    if (j >= PS_HALO && rowIn(j) && own()) *ps_at(pubZ1, eo(j)) = float2{u2.re, u2.im};
                 });
                 __syncthreads();
             } else {
 #pragma unroll
                 for (int j = PS_HALO; j < PS_J; ++j) {
                     const int g = gb + gs * j;
-                    if (own() && g >= 1 && g <= nz - 1) *ps_at(pubZ1, eo(j)) = float2{T0[ps_opq(t0i) + j * ts].re, T0[ps_opq(t0i) + j * ts].im};
+                    if (rowIn(j) && own()) *ps_at(pubZ1, eo(j)) = float2{T0[ps_opq(t0i) + j * ts].re, T0[ps_opq(t0i) + j * ts].im};
                 }
             }
             // t on the own rows, straight into the bf16 hi/lo planes of the forward transform (the first tile's space: with two sweeps
@@ -865,7 +888,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                     bf16_split_pk(tv[q].re, tv[q].im, hp2, lp);
                     b[0] = (unsigned short)hp2; b[PLW] = (unsigned short)(hp2 >> 16);
                     b[2 * PLW] = (unsigned short)lp; b[3 * PLW] = (unsigned short)(lp >> 16);
-                    if (SW == 2 && g >= 1 && g <= nz - 1) *ps_at(tbuf1, eo(j)) = float2{tv[q].re, tv[q].im};
+                    if (SW == 2 && rowIn(j)) *ps_at(tbuf1, eo(j)) = float2{tv[q].re, tv[q].im};
                 }
             }
             if constexpr (CS == 1) {
@@ -1152,10 +1175,10 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             }
             if (SW == 2) { ar += p1r; ai += p1i; }
             if (CS > 1 && !own()) { ar = 0; ai = 0; zzs = 0; }                 // (a halo column's rows belong to the neighbour part's sums)
-            ps_block_sum4<NWV>(ar, ai, zzs, xxPrev, sh, shFlip);              // (its barrier also completes the tile; |x|^2: the previous update's partials)
-            if (tid == 0) {                                                    // R1, first half: this workgroup's partial sums
-                const double v4[4] = {ar, ai, zzs, xxPrev};
-                ps_publish<4>(recS() + ((long)jw * 2 + 0) * 8, v4, L.tagBase + 2ull * (unsigned)it);
+            {
+                double v4[4] = {ar, ai, zzs, xxPrev};
+                ps_block_sum_t0<NWV, 4>(v4, sh, shFlip);                      // (its barrier also completes the tile; |x|^2: the previous update's partials)
+                if (tid == 0) ps_publish<4>(recS() + ((long)jw * 2 + 0) * 8, v4, L.tagBase + 2ull * (unsigned)it);      // R1, first half: this workgroup's partial sums
             }
             if constexpr (SW == 2) {
                 // second post-sweep, while the partial sums travel (rows j >= 2)
@@ -1291,15 +1314,16 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
 #pragma unroll
                 for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q, g = gb + gs * j;
-                    xv[q] = *ps_at(xs1, (own() && g >= 1 && g <= nz - 1) ? eo(j) : (unsigned)(NYP + 1));
+                    xv[q] = *ps_at(xs1, (rowIn(j) && own()) ? eo(j) : (unsigned)(NYP + 1));
                 }
             }
             if (CS > 1 && !own()) { pqr = 0; pqi = 0; }
-            { double dz = 0; ps_block_sum4<NWV>(pqr, pqi, dum2, dz, sh, shFlip); }
-            if (tid == 0) {
-                const double v2[2] = {pqr, pqi};
-                ps_publish<2>(recS() + ((long)jw * 2 + 1) * 8, v2, L.tagBase + 2ull * (unsigned)it + 1ull);
+            {
+                double v2[2] = {pqr, pqi};
+                ps_block_sum_t0<NWV, 2>(v2, sh, shFlip);
+                if (tid == 0) ps_publish<2>(recS() + ((long)jw * 2 + 1) * 8, v2, L.tagBase + 2ull * (unsigned)it + 1ull);
             }
+            (void)dum2;
             PS_STAMP(9)
             if (wave == 0) {                                                   // R2
                 double t2[2] = {0, 0};
@@ -1323,7 +1347,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
 #pragma unroll
                 for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q, g = gb + gs * j;
-                    if ((iyv < LWh) && g >= 1 && g <= nz - 1) {
+                    if (rowIn(j) && (iyv < LWh)) {
                         // (p and q vanish on boundary and pad nodes: x keeps its Dirichlet values there, r stays zero)
                         r64[q] -= al * Qs[tu0 + j * ts - PS_HALO * TW];        // (a halo column's copy: the same bits as its owner's)
                         if (CS == 1 || mine) {
