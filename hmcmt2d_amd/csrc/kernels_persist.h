@@ -787,11 +787,10 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
         auto rr = [&](int j) -> c32 { return j < PS_HALO ? rh[j < PS_HALO ? j : 0] : c32{(float)r64[j >= PS_HALO ? j - PS_HALO : 0].re, (float)r64[j >= PS_HALO ? j - PS_HALO : 0].im}; };
 
         cplx rhoPrev = cplx{0, 0}, rhoCur = cplx{0, 0};
-        double errRef = 0.0, xxPrev = 0.0;      // errRef: a tenth of the error estimate the stagnation watch counts from
+        double refN = 0.0, refD = 1.0, estN = 0.0, estD = 1.0, xxPrev = 0.0;      // refN / refD: a hundredth of the squared error estimate the stagnation watch counts from; estN / estD: this iteration's
         int errRefIt = 0;
         bool stalled = false;
         int st = 0;
-        double est = 0.0;
         it = 0;
 #define PS_PHASE() kb = kb0; asm volatile("" : "+v"(e0), "+v"(t0i), "+v"(inM), "+v"(tidv), "+v"(lanev), "+v"(ljv), "+v"(g4v), "+v"(iyv), "+s"(kb), "+s"(rowM))   /* row offsets / masks / the state block's scalars are re-derived per PHASE instead of living in registers across all of them */
         for (;;) {
@@ -1248,20 +1247,24 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             else if (zz <= L.tol2 * xx) on = false;
             else if (it - 1 >= L.maxit) { on = false; st = HMCMT_ENOCONV; }
             if (!(isfinite(rz.re) && isfinite(rz.im) && isfinite(zz) && isfinite(xx))) { on = false; st = HMCMT_EBREAKDOWN; }
-            est = first ? (zz == 0.0 ? 0.0 : 1.0) : sqrt(zz / xx);
             {
-                // (the reference of the stagnation watch as a scalar, assigned unconditionally: as a conditionally assigned vector value
-                //  it was the one register pair the loop still kept in scratch -- reloaded here behind an s_waitcnt vmcnt(0) that also
-                //  waited for the coefficient loads this phase has just requested)
-                // (errRef holds a TENTH of the reference estimate: the product formed where it is assigned, once, not at every comparison)
-                const bool better = first || est < errRef;
-                errRef = ps_unif(better ? 0.1 * est : errRef);
+                // The error estimate sqrt(zz / xx) (1 at the first iteration) is FORMED only when the system leaves the loop (the record);
+                // the stagnation watch compares squares, cross-multiplied: est < ref / 10  <=>  zz * refD < refN * xx with
+                // refN / refD = ref^2 / 100 -- an fp64 division and a square root less per iteration, in every wave.  The reference as
+                // scalars, assigned unconditionally: as a conditionally assigned vector value it was the one register pair the loop still
+                // kept in scratch -- reloaded here behind an s_waitcnt vmcnt(0) that also waited for the coefficient loads this phase
+                // has just requested.
+                estN = first ? (zz == 0.0 ? 0.0 : 1.0) : zz; estD = first ? 1.0 : xx;
+                const bool better = first || zz * refD < refN * xx;
+                refN = ps_unif(better ? 0.01 * estN : refN);
+                refD = ps_unif(better ? estD : refD);
                 if (better) errRefIt = it;
                 else if (on && it - errRefIt > kb->stallIt) { stalled = true; on = false; }
             }
             if (!on) break;
             const cplx be = first ? cplx{0, 0} : rz / rhoPrev;
             rhoPrev = rz; rhoCur = rz;
+            const c32 bef = c32{(float)be.re, (float)be.im};
             // ================= p = z + beta p (rounded to complex64) -> the other tile; q = A p; p'q =================
             constexpr int JP = SW == 2 ? 2 : 1;
             {
@@ -1272,9 +1275,10 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                     c32 pv = c32{0, 0};
                     if (j >= JP) {
                         const c32 zv = TZ[ti];
-                        const double pr = (double)pold[j].re, pi = (double)pold[j].im;
-                        const double vr = __builtin_fma(be.re, pr, __builtin_fma(-be.im, pi, (double)zv.re)), vi = __builtin_fma(be.re, pi, __builtin_fma(be.im, pr, (double)zv.im));
-                        pv = ps_scal(mk(j), c32{(float)vr, (float)vi});
+                        // (in float with explicit fma -- every workgroup the same bits --: p is rounded to complex64 whatever it is formed in, and
+                        //  x += alpha p, r -= alpha A p hold for any p; formed in fp64 and rounded it cost four conversions in and two out per row)
+                        const float vr = __builtin_fmaf(bef.re, pold[j].re, __builtin_fmaf(-bef.im, pold[j].im, zv.re)), vi = __builtin_fmaf(bef.re, pold[j].im, __builtin_fmaf(bef.im, pold[j].re, zv.im));
+                        pv = ps_scal(mk(j), c32{vr, vi});
                     }
                     if ((iyv < LWh)) TP[ti] = pv;
                 }
@@ -1393,7 +1397,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
         if (jw == 0 && tid == 0) {
             if (L.cntActive) atomicAdd(L.cntActive, (unsigned long long)max(it - 1, 0));   // (roofline accounting: iterations x systems of a sampled evaluation)
             kb->iters[s] = it - 1;
-            kb->errEst[s] = est;
+            kb->errEst[s] = sqrt(estN / estD);
             if (st) { kb->status[s] = st; *kb->failHost = st; }
             if (stalled) *kb->stallHost = 1;
             else { kb->active[s] = 0; if (atomicSub(kb->nactive, 1) == 1) *kb->nactHost = 0; }
