@@ -217,6 +217,27 @@ constexpr int PS_GRP = HMCMT_PS_GRP;      // rows the scheduler may interleave i
 // two workgroups compute (an own row of one, a halo row of the other) must come out BIT FOR BIT the same in both -- the
 // halo rows' p enters the owners' fp64 q = A p, and x += alpha p, r -= alpha q stay consistent only if every workgroup uses
 // the same p -- so the terms are ordered by MESH direction (north, south), not by the thread's direction (outer, inner).
+// LDS reads the compiler must not pair up (relaxed workgroup-scope atomic loads: plain ds_read_b64 / ds_read_b32 with immediate
+// offsets).  Paired into ds_read2_b64 / ds_read2_b32 -- 8-bit offsets -- the five points and five coefficients of a stencil row
+// cost four extra address additions per row, and ds_read2_b64 takes the LDS twice the cycles of two ds_read_b64.
+#ifndef HMCMT_PS_LDS_ATOMIC
+#define HMCMT_PS_LDS_ATOMIC 1
+#endif
+__device__ __forceinline__ c32 ps_lds_c32(const c32* p) {
+#if HMCMT_PS_LDS_ATOMIC
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return c32{__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32))};
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ float ps_lds_f32(const float* p) {
+#if HMCMT_PS_LDS_ATOMIC
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+#else
+    return *p;
+#endif
+}
 template <bool MESH, int JLO, int JHI = PS_J, class F>
 __device__ __forceinline__ void ps_rows(const PsPl& co, const c32* __restrict__ S, int t0i_, int es, int c, int tw, F&& f) {
     const int t0i = ps_opq(t0i_);
@@ -236,10 +257,10 @@ __device__ __forceinline__ void ps_rows(const PsPl& co, const c32* __restrict__ 
         float cw, ce, dm, cn, cs;
         if constexpr (MESH) {
             const c32* __restrict__ p0 = S + (ti - tw - 1);
-            un = p0[1]; uw = p0[tw]; uc = p0[tw + 1]; ue = p0[tw + 2]; us = p0[2 * tw + 1];
+            un = ps_lds_c32(p0 + 1); uw = ps_lds_c32(p0 + tw); uc = ps_lds_c32(p0 + tw + 1); ue = ps_lds_c32(p0 + tw + 2); us = ps_lds_c32(p0 + 2 * tw + 1);
             const float* __restrict__ e0 = co.E + (ti - 1);
             const float* __restrict__ v0 = co.V + (ti - tw);
-            cw = e0[0]; ce = e0[1]; dm = co.M[ti]; cn = v0[0]; cs = v0[tw];
+            cw = ps_lds_f32(e0); ce = ps_lds_f32(e0 + 1); dm = ps_lds_f32(co.M + ti); cn = ps_lds_f32(v0); cs = ps_lds_f32(v0 + tw);
         } else {
             uc = S[ti]; ue = S[ti + 1]; uw = S[ti - 1];
             const c32 ui = S[ti + es], uo = S[ti - es];
