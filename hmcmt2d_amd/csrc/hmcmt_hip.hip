@@ -1474,6 +1474,7 @@ static int persist_setup(hmcmt_ctx* ctx) {
     int cuPerXcd = 0, G = 0, cw = 0, mw = 32, cs = 1;
     size_t lds = 0;
     if (!persist_shape(ctx, k.twist, cuPerXcd, G, cw, mw, lds, &cs)) return 0;
+    if ((size_t)k.S * (size_t)k.vstride >= ((size_t)1 << 27)) return 0;      // (the kernel's 32-bit lane offsets carry the system's element offset: kernels_persist.h, so32)
     ctx->persistMW = mw;
     const void* fns[24] = {reinterpret_cast<const void*>(k_cocg_persist<256, 1, 32, 1, 208>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 32, 1, 208>),
                            reinterpret_cast<const void*>(k_cocg_persist<128, 1, 32, 1, 112>), reinterpret_cast<const void*>(k_cocg_persist<128, 2, 32, 1, 112>),
@@ -2237,7 +2238,7 @@ int hmcmt_persist_envelope(int64_t ny, int64_t nz, int32_t cus_per_xcd, int64_t 
     for (int i = 0; i < 6; ++i) out[i] = 0;
     for (int cs = 1; cs <= 2; ++cs) {
         int G = 0, cw = 0, mw = 0; size_t lds = 0;
-        if (persist_shape_dims(k, 1, cs, cus_per_xcd, G, cw, mw, lds)) {
+        if (persist_shape_dims(k, 1, cs, cus_per_xcd, G, cw, mw, lds) && (size_t)nsystems * (size_t)k.NYP * (size_t)k.NZP < ((size_t)1 << 27)) {
             out[0] = cs; out[1] = cw; out[2] = G; out[3] = mw; out[4] = (int64_t)lds;
             out[5] = std::max<int64_t>(1, std::min<int64_t>((nsystems + 7) / 8, cus_per_xcd / G));
             break;

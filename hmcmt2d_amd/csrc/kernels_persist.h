@@ -262,6 +262,7 @@ __device__ __forceinline__ void ps_rows(const PsPl& co, const c32* __restrict__ 
             const float* __restrict__ v0 = co.V + (ti - tw);
             cw = ps_lds_f32(e0); ce = ps_lds_f32(e0 + 1); dm = ps_lds_f32(co.M + ti); cn = ps_lds_f32(v0); cs = ps_lds_f32(v0 + tw);
         } else {
+            // (plain loads here: as unpaired atomic loads they cost the generic kernels 40-60 more spilled registers)
             uc = S[ti]; ue = S[ti + 1]; uw = S[ti - 1];
             const c32 ui = S[ti + es], uo = S[ti - es];
             un = c ? ui : uo; us = c ? uo : ui;
@@ -290,7 +291,7 @@ __device__ __forceinline__ c32 ps_dinv_at(const PsPl& co, int ti, int es, int c,
     if constexpr (MESH) {
         const float* __restrict__ e0 = co.E + (ti - 1);
         const float* __restrict__ v0 = co.V + (ti - tw);
-        const float cw = e0[0], ce = e0[1], dm = co.M[ti], cn = v0[0], cs = v0[tw];
+        const float cw = ps_lds_f32(e0), ce = ps_lds_f32(e0 + 1), dm = ps_lds_f32(co.M + ti), cn = ps_lds_f32(v0), cs = ps_lds_f32(v0 + tw);
         return ps_dinv(-((ce + cw) + (cn + cs)), dm, wJ);
     } else {
         const float ce = co.E[ti], cw = co.E[ti - 1], dm = co.M[ti], va = co.V[ti], vb = co.V[ti - es];
@@ -700,10 +701,15 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
     // element offset of (row j, gy) in a system's [NZP][NYP] arrays: ONE 32-bit lane offset serves every array (uniform base
     // pointer + offset: 64-bit per-row addresses of a dozen arrays were what the register allocator spilled).  eo: the node itself
     // (valid where the row is in the mesh), ei: the node if it is an interior one, else a harmless interior node (unconditional loads)
-    int e0 = gb * NYP + gy;
+    // (so32 = s * vstride, the system's element offset, is PART of the lane offset: an array of the solve is addressed as its base
+    //  from the state block + the lane offset, nothing per system and array is multiplied or held; persist_shape keeps
+    //  S * vstride below 2^27 elements.  First version: every array's `base + s * vstride` re-derived where it was used -- a scalar
+    //  load, a wait and a 64-bit multiply, twenty times per iteration)
+    const int e0b = gb * NYP + gy;
+    int e0 = e0b, so32 = 0;
     const int es = gs * NYP;
     auto eo = [&](int j) -> unsigned { return (unsigned)(e0 + j * es); };
-    auto ei = [&](int j) -> unsigned { return isIn(j) ? (unsigned)(e0 + j * es) : (unsigned)(NYP + 1); };
+    auto ei = [&](int j) -> unsigned { return isIn(j) ? (unsigned)(e0 + j * es) : (unsigned)(NYP + 1 + so32); };
     int t0i = tb * TW + iy;                                             // the same for the tiles in LDS: t0i + j * ts
     const int ts = gs * TW;
     // LDS carve (ps_lds_bytes)
@@ -746,12 +752,15 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
         // per-system bases, re-derived where they are used (kb is laundered per phase: none of this lives across the solve)
         auto so = [&]() -> long { return (long)s * kb->vstride; };
         auto mo = [&]() -> long { return (long)mode * kb->vstride; };
-        auto pubR = [&]() -> float2* { return kb->pubR + so(); };
-        auto pubZ = [&]() -> float2* { return kb->pubZ + so(); };
-        auto pubP = [&]() -> float2* { return kb->pubP + so(); };
-        auto tbuf = [&]() -> float2* { return kb->tbuf + so(); };      // t of the own rows (complex64): the rho identity of the two-sweep smoother needs it behind the FDM stage
-        auto xsys = [&]() -> cplx* { return L.x + so(); };
-        auto rsys = [&]() -> cplx* { return L.r + so(); };
+        so32 = s * (int)kb->vstride;
+        e0 = e0b + so32;
+        // (bases of ALL systems: eo() / ei() carry the system's offset)
+        auto pubR = [&]() -> float2* { return kb->pubR; };
+        auto pubZ = [&]() -> float2* { return kb->pubZ; };
+        auto pubP = [&]() -> float2* { return kb->pubP; };
+        auto tbuf = [&]() -> float2* { return kb->tbuf; };      // t of the own rows (complex64): the rho identity of the two-sweep smoother needs it behind the FDM stage
+        auto xsys = [&]() -> cplx* { return L.x; };
+        auto rsys = [&]() -> cplx* { return L.r; };
         auto recS = [&]() -> u4v* { return kb->rec + (long)s * MAXNB * 2 * 8; };
         // ---- coefficients of the tile -> the planes in LDS (the previous system's last reads lie in front of a barrier)
         {
@@ -1074,7 +1083,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                         for (int h2 = 0; h2 < 2; ++h2) {
                             const int tau = 8 * rg + 2 * g4v + h2, g = R0 + tau, col = (t ? tl1 : tl0) * 16 + ljv;
                             const bool in = g >= 1 && g <= nz - 1 && col >= 1 && col <= ny - 1;
-                            const unsigned e = in ? (unsigned)(g * NYP + col) : (unsigned)(NYP + 1);
+                            const unsigned e = (unsigned)((in ? g * NYP + col : NYP + 1) + so32);
                             zq[rg][t][h2] = ps_ld_f2(ps_at(pubZ2, e));
                         }
 #pragma unroll
@@ -1222,7 +1231,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                 for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q, g = gb + gs * j;
                     const c32 zv = TZ[ps_opq(t0i) + j * ts];
-                    if (own() && g >= 1 && g <= nz - 1) *ps_at(L.zout + so(), eo(j)) = float2{zv.re, zv.im};
+                    if (own() && g >= 1 && g <= nz - 1) *ps_at(L.zout, eo(j)) = float2{zv.re, zv.im};
                 }
                 break;
             }
@@ -1246,7 +1255,8 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             // the fp64 stencil coefficients of the own rows: requested here, they arrive under the p update
             double dm64[PS_NO], ce64[PS_NO], cw64[PS_NO], ci64[PS_NO], co64[PS_NO];
             {
-                const double *dMm = kb->dM + mo(), *cYm = kb->cY + mo(), *cZm = kb->cZ + mo();
+                const long mso = mo() - (long)so32;       // (the coefficients are per polarisation: the lane offsets carry the system's)
+                const double *dMm = kb->dM + mso, *cYm = kb->cY + mso, *cZm = kb->cZ + mso;
 #pragma unroll
                 for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q;
@@ -1318,7 +1328,9 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                 for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q;
                     const int ti = tq0 + j * ts;
-                    const c32 pc = TP[ti], pe = TP[ti + 1], pw = TP[ti - 1], pi = TP[MESH ? ti - TW : ti + ts], po = TP[MESH ? ti + TW : ti - ts];
+                    c32 pc, pe, pw, pi, po;
+                    if constexpr (MESH) { pc = ps_lds_c32(TP + ti); pe = ps_lds_c32(TP + ti + 1); pw = ps_lds_c32(TP + ti - 1); pi = ps_lds_c32(TP + ti - TW); po = ps_lds_c32(TP + ti + TW); }
+                    else { pc = TP[ti]; pe = TP[ti + 1]; pw = TP[ti - 1]; pi = TP[ti + ts]; po = TP[ti - ts]; }
                     const double dmw = w * dm64[q];
                     const double dk = -((ce64[q] + cw64[q]) + (ci64[q] + co64[q]));
                     // (explicit fma throughout: twelve instructions per row instead of twenty-two)
