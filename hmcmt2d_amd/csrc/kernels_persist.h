@@ -404,6 +404,13 @@ __device__ __forceinline__ void ps_slab_solve_reg(PsKP kb, char* smem, const flo
     const float* g1 = f1 + h * RL;                        // row scalars of this half (ps_slab_tables)
     const float* g2 = f2 + h * RL;
     c32 a[RC], ipv[RC], cc[RC];
+    // the row scalars of this lane's chunk (constant over the solve, in LDS): requested HERE, unconditionally (the tables are padded
+    // behind a half's last row), so that they arrive under the global loads below -- read where they are used, inside each row's
+    // `if (row of the half)`, they were a dependent LDS round trip per row in both serial chains
+    // (the second sweep's behind the first sweep's barrier, into the same registers: sixteen registers at once spilled)
+    float g1v[RC];
+#pragma unroll
+    for (int i = 0; i < RC; ++i) g1v[i] = g1[min(r0 + i, RL - 1)];      // (rows beyond the half are not used: clamped into the table)
     // ---- rows -> registers: a = yhat (the sum of the column parts' partial products) x inverse pivot
     {
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(kb->yhat + so), 0, (int)(vs * 8), 0x00020000);
@@ -438,7 +445,7 @@ __device__ __forceinline__ void ps_slab_solve_reg(PsKP kb, char* smem, const flo
         for (int i = 0; i < RC; ++i) {
             const int rl = r0 + i;
             if (rl <= lastH) {
-                const c32 nb = (-g1[rl]) * ipv[i];
+                const c32 nb = (-g1v[i]) * ipv[i];
                 xl = ps_cfma(a[i], nb, xl);
                 cp = nb * cp;
             }
@@ -456,6 +463,8 @@ __device__ __forceinline__ void ps_slab_solve_reg(PsKP kb, char* smem, const flo
         }
     }
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RC; ++i) g1v[i] = g2[min(r0 + i, RL - 1)];      // (the substitution sweep's row scalars: they arrive under the records' chain)
     c32 xin = c32{0, 0}, xlast = c32{0, 0};
     if (act) {
         // the inflow of this chunk, the end values of both halves (chains of P records), the join
@@ -494,7 +503,7 @@ __device__ __forceinline__ void ps_slab_solve_reg(PsKP kb, char* smem, const flo
             if (rl == lastH) { yl = xlast; dp = c32{0, 0}; }
             else if (rl < lastH) {
                 const c32 x1 = ps_cfma(a[i], cc[i], xin);
-                const c32 nb = (-g2[rl]) * ipv[i];
+                const c32 nb = (-g1v[i]) * ipv[i];
                 yl = ps_cfma(x1, nb, yl);
                 dp = nb * dp;
             }
