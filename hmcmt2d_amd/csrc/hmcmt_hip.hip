@@ -1353,12 +1353,13 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (ctx->d_pstamps) {                                // HMCMT_STAMPS=persist: phases of the third iteration of the last solve
         std::vector<long long> st(16 * 256);
         hipMemcpy(st.data(), ctx->d_pstamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost);
-        double acc[12] = {0}, sl[3] = {0}; long n = 0, nsl = 0;
+        double acc[12] = {0}, sl[3] = {0}, bt[3] = {0}; long n = 0, nsl = 0, nbt = 0;
         for (int b = 0; b < 256; ++b) {
             const long long* p = &st[16 * b];
             if (!p[0] || !p[11]) continue;
             ++n;
             for (int i = 1; i < 12; ++i) acc[i] += (double)(p[i] - p[i - 1]);
+            if (p[14] && p[15]) { ++nbt; bt[0] += (double)(p[14] - p[5]); bt[1] += (double)(p[15] - p[14]); bt[2] += (double)(p[6] - p[15]); }       // (back transform: planes -> LDS | MFMA loop | epilogue)
             if (p[12] && p[13]) { ++nsl; sl[0] += (double)(p[12] - p[3]); sl[1] += (double)(p[13] - p[12]); sl[2] += (double)(p[4] - p[13]); }   // (workgroups with a slab)
         }
 #ifdef HMCMT_PS_DBGX
@@ -1377,6 +1378,7 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
                             "post-smooth %.2f wait-R1 %.2f scalars+p+q %.2f wait-R2 %.2f update %.2f | iteration %.2f\n", n, acc[1] * us, acc[2] * us, acc[3] * us, acc[4] * us, acc[5] * us, acc[6] * us,
                     acc[7] * us, acc[8] * us, acc[9] * us, acc[10] * us, acc[11] * us, tot * us);
             if (nsl) fprintf(stderr, "   slabs, the %ld workgroups that have one: load %.2f, the two sweeps %.2f, store %.2f us\n", nsl, sl[0] * us * n / nsl, sl[1] * us * n / nsl, sl[2] * us * n / nsl);
+            if (nbt) fprintf(stderr, "   back transform: operand planes -> LDS (+ the epilogue operands' loads) %.2f, MFMA loop %.2f, epilogue %.2f us\n", bt[0] * us * n / nbt, bt[1] * us * n / nbt, bt[2] * us * n / nbt);
         }
     }
     if (ctx->sv.stamps) {                                // HMCMT_STAMPS: phase stamps of the last launch that wrote them

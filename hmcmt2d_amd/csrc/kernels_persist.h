@@ -1110,6 +1110,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (the planes' direct loads: in LDS before the barrier)
             __syncthreads();
+            PS_STAMP(14)                                                        // (the operand planes have landed)
             double ar = 0, ai = 0, zzs = 0;
             {
                 f4v acc[3][2];
@@ -1161,6 +1162,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                         }
                     }
                 }
+                PS_STAMP(15)                                              // (the MFMA loop is through)
                 if constexpr (CS > 1) __syncthreads();                    // (the operand planes span both tiles: every wave's reads before the output)
 #pragma unroll
                 for (int rg = 0; rg < 3; ++rg)
