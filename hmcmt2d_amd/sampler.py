@@ -373,7 +373,7 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
     thread each, every context confined to its share of the CUs of every XCD (HipContext(cu_share=...),
     hmcmt_next_cu_share: CU-masked streams): the persistent solve kernels of the chains are co-resident, each with its share of
     the system slots.  Measured at the headline size near the true model (bench.py `two_chains_per_gpu`,
-    scripts/gpu_cu_share_probe.py): two chains on halves 1.15x the aggregate steps/s of one chain on the whole device, four
+    scripts/gpu_cu_share_probe.py): two chains on halves 1.13-1.15x the aggregate steps/s of one chain on the whole device, four
     on quarters 1.17x.  (The shares' streams are BLOCKING HIP streams: keep other GPU work of the process off the legacy
     default stream while chains sample, or it serialises them -- DESIGN 7.)  A mesh whose systems need
     more workgroups than a share's CUs per XCD hold (the stress size: 30 of 16) runs the launch-per-phase loop in each share.  The chains
