@@ -1386,7 +1386,9 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             // ================= alpha; x += alpha p, r -= alpha q; publish r', p =================
             const cplx al = rhoCur / cplx{sh[68], sh[69]};
             const c32 alf = c32{(float)al.re, (float)al.im};
-            double xxs = 0, dum3 = 0, dum4 = 0;
+            // (|x|^2 of this thread's rows in float: it scales the stopping rule |z| <= tol |x| and nothing else -- seven digits are five
+            //  more than that needs --, and as a double carried through the seven rows it was what the two-part kernel spilled per row)
+            float xxs = 0.f; double dum3 = 0, dum4 = 0;
             {
                 const int tu0 = ps_opq(t0i);
                 const bool mine = own();
@@ -1406,7 +1408,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                             const c32 pv = TP[tu0 + j * ts];
                             const cplx xn = cplx{__builtin_fma(-al.im, (double)pv.im, __builtin_fma(al.re, (double)pv.re, xv[q].re)), __builtin_fma(al.im, (double)pv.re, __builtin_fma(al.re, (double)pv.im, xv[q].im))};
                             *ps_at(xs2, eo(j)) = xn;
-                            xxs = __builtin_fma(xn.re, xn.re, __builtin_fma(xn.im, xn.im, xxs));                // (rows 1 .. nz-1, all columns: as the launch-per-phase kernels)
+                            { const float xr = (float)xn.re, xi = (float)xn.im; xxs = __builtin_fmaf(xr, xr, __builtin_fmaf(xi, xi, xxs)); }       // (rows 1 .. nz-1, all columns: as the launch-per-phase kernels)
                             *ps_at(pubR3, eo(j)) = float2{(float)r64[q].re, (float)r64[q].im};
                             *ps_at(pubP3, eo(j)) = float2{pv.re, pv.im};
                         }
@@ -1417,7 +1419,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             for (int j = 0; j < PS_HALO; ++j)
                 if (j >= JP + 1) rh[j] = mk(j) * (rh[j] - alf * qh[j]);
             (void)dum3; (void)dum4;
-            xxPrev = xxs;                                                      // (this thread's part: reduced and published with the next reduction)
+            xxPrev = (double)xxs;                                              // (this thread's part: reduced and published with the next reduction)
             // One sweep per side: q's fp64 rows sit in the FIRST tile's space (TZ = T0), whose complex64 slots belong to other
             // threads -- and the next iteration's first act is to write z1 there.  A wave that leaves this phase early (few
             // rows in the mesh, halo columns without an x update) overwrote q of a wave still reading it: x += alpha p with
