@@ -122,7 +122,8 @@ struct hmcmt_ctx {
     int sweepsUsed[2] = {1, 1};              // ... what the last evaluation's solves used
     int sweepsCount2[2] = {0, 0}, sweepsSince[2] = {0, 0};   // ... iterations of the last two-sweep solve, solves since the last probe
     bool sweepsProbe[2] = {false, false};    // ... the solve at hand is a one-sweep probe out of the two-sweep mode
-    int sweepsUp = 30, sweepsDown = 6;       // auto: one sweep -> two above sweepsUp iterations, two -> one below sweepsDown (12: the first,
+    int sweepsUp = 12, sweepsDown = 6;       // auto: one sweep -> two above sweepsUp iterations (rounds 2-4: 30 -- a two-sweep iteration of the launch-per-phase loop cost 1.20 one-sweep
+                                             // ones; in the persistent kernel 1.15 / 1.10, and solves of 18-24 iterations near the true model gain 2-7 % from two), two -> one below sweepsDown (12: the first,
                                              // cheap steps of every clamped burn-in trajectory switched back and the next ones up again)
     long long* backStamps = nullptr;         // HMCMT_BACK_STAMPS: per-block s_memtime stamps of k_back_post (debug entry only)
     size_t maxLdsBack = 64 * 1024;
@@ -665,7 +666,8 @@ int spin_progress(hmcmt_ctx* ctx, int value) {
     if (*(volatile int*)ctx->h_prog != value) HIPCHK(hipStreamSynchronize(ctx->stream));   // reports the error, if any
     return 0;
 }
-constexpr double SWEEPS2_COST = 1.20;       // time of a two-sweep iteration / time of a one-sweep iteration (59-60 us / 50 us at the headline size)
+constexpr double SWEEPS2_COST = 1.20;       // time of a two-sweep iteration / time of a one-sweep iteration on the launch-per-phase loop (59-60 us / 50 us at the headline size)
+constexpr double SWEEPS2_COST_PERSIST = 1.15, SWEEPS2_COST_PERSIST_CS2 = 1.10;   // ... in the persistent kernel (35.1 / 30.6 us at cfg3, 42.5 / 38.9 at cfg5)
 constexpr int SWEEPS_PROBE_EVERY = 40;      // in two-sweep mode: every so many solves of a kind one solve runs one sweep, to compare
 // damped Jacobi sweeps on each side of the FDM stage for the next solve of this kind.  Two sweeps cut the iterations by
 // 20 % (smooth models) to 35 % (high-contrast ones) and cost ~20 % more time per iteration: by
@@ -1229,7 +1231,8 @@ void parse_stats(hmcmt_ctx* ctx, bool withAdjoint) {
             if (ctx->sweepsUsed[kind] == 1) {
                 if (ctx->sweepsProbe[kind]) {                 // a probe with one sweep: keep it if it is the cheaper one
                     ctx->sweepsProbe[kind] = false;
-                    next = (double)mx <= SWEEPS2_COST * ctx->sweepsCount2[kind] ? 1 : 2;
+                    const double cost2 = (ctx->persistCW && ctx->persistOn) ? (ctx->persistCS > 1 ? SWEEPS2_COST_PERSIST_CS2 : SWEEPS2_COST_PERSIST) : SWEEPS2_COST;
+                    next = (double)mx <= cost2 * ctx->sweepsCount2[kind] ? 1 : 2;
                 } else if (mx > ctx->sweepsUp) next = 2;
             } else {
                 ctx->sweepsCount2[kind] = mx;

@@ -215,7 +215,8 @@ def test_followers_queued_behind_the_solve_change_nothing(monkeypatch):
         assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
     monkeypatch.setenv("HMCMT_SPEC", "1")
     monkeypatch.setenv("HMCMT_STALL_IT", "1")
-    ctx = _ctx(monkeypatch, mesh, data, inv, True)
+    ctx = _ctx(monkeypatch, mesh, data, inv, True, 1)      # (one sweep per side: with two -- the default behind a cold solve of more than
+                                                           #  HMCMT_SWEEPS_UP iterations -- the estimate drops tenfold every other iteration and nothing stalls)
     ctx.grad(m)                                            # (cold: no followers queued early)
     p, f, g = ctx.grad(m + 0.02)                           # warm: queued early, gate closed by the stalled solves
     st = ctx.stats()
