@@ -862,13 +862,16 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             PS_STAMP(0)
             // ================= pre-smoother: z1 = D r (T0) [-> z2 = z1 + w2 D (r - A z1) (T1)] -> t = r - A z on the own rows =================
             constexpr int JZ1 = SW == 2 ? 3 : 4;
-            {
+            // (ONE condition around a pass for the lanes behind the tile's last column -- 48 of 256 at the headline width --, not one
+            //  around each of its tile writes: 160 conditional blocks per iteration were 800 scalar instructions, and a scalar
+            //  instruction costs a wave as much issue time as a vector one: scripts/probe/readlane_cost.hip)
+            if (iyv < LWh) {
                 const int tw0 = ps_opq(t0i);
 #pragma unroll
                 for (int j = 0; j < PS_J; ++j) {
                     const int ti = tw0 + j * ts;
                     const c32 v = j >= JZ1 ? ps_scal(mk(j), ps_cmul(ps_dinv_at<MESH>(co, ti, ts, c, TW, kb->wJ), rr(j))) : c32{0, 0};
-                    if ((iyv < LWh)) T0[ti] = v;
+                    T0[ti] = v;
                 }
             }
             __syncthreads();
@@ -878,18 +881,19 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             //  64-bit multiply in front of every store)
             float2* const pubZ1 = pubZ();
             if constexpr (SW == 2) {
-                {
-                    const int tw0 = ps_opq(t0i);
+                if (iyv < LWh) {
+                    {
+                        const int tw0 = ps_opq(t0i);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if ((iyv < LWh)) T1[tw0 + j * ts] = c32{0, 0};
+                        for (int j = 0; j < 4; ++j) T1[tw0 + j * ts] = c32{0, 0};
+                    }
+                    const float wJ = kb->wJ;
+                    ps_rows<MESH, 4>(co, T0, t0i, ts, c, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+                        const c32 u2 = ps_scal(mk(j), ps_cadd(uc, ps_cmul(ps_scal(L.w2, ps_dinv(dk, dm, wJ)), ps_csub(rr(j), av))));
+                        T1[ti] = u2;
+                        if (j >= PS_HALO && rowIn(j) && (CS == 1 || own())) *ps_at(pubZ1, eo(j)) = float2{u2.re, u2.im};
+                    });
                 }
-                const float wJ = kb->wJ;
-                ps_rows<MESH, 4>(co, T0, t0i, ts, c, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
-                    const c32 u2 = ps_scal(mk(j), ps_cadd(uc, ps_cmul(ps_scal(L.w2, ps_dinv(dk, dm, wJ)), ps_csub(rr(j), av))));
-                    if ((iyv < LWh)) T1[ti] = u2;
-                    const int g = gb + gs * j;
-                    if (j >= PS_HALO && rowIn(j) && own()) *ps_at(pubZ1, eo(j)) = float2{u2.re, u2.im};
-                });
                 __syncthreads();
             } else {
 #pragma unroll
@@ -901,6 +905,9 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             // t on the own rows, straight into the bf16 hi/lo planes of the forward transform (the first tile's space: with two sweeps
             // its readers are behind the barrier above; with one, t is formed from the first tile itself, so a barrier separates them)
             c32 tv[PS_NO];
+#pragma unroll
+            for (int q = 0; q < PS_NO; ++q) tv[q] = c32{0, 0};
+            if (iyv < LWh)
             ps_rows<MESH, PS_HALO>(co, SW == 2 ? T1 : T0, t0i, ts, c, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
                 const c32 rv = rr(j);
                 tv[j - PS_HALO] = ps_scal(mk(j), ps_csub(rv, av));
@@ -1189,16 +1196,16 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             PS_STAMP(6)
             PS_PHASE();
             // ================= post-smoother: zf = z3 + [w2] D (r - A z3) (T1 -> T0) [-> z = zf + D (r - A zf) (T0 -> T1)] =================
-            {
-                const int tw0 = ps_opq(t0i);
-                if ((iyv < LWh)) T0[tw0] = c32{0, 0};
-            }
-            {
+            if (iyv < LWh) {
+                {
+                    const int tw0 = ps_opq(t0i);
+                    T0[tw0] = c32{0, 0};
+                }
                 const float wJ = kb->wJ;
                 ps_rows<MESH, 1>(co, T1, t0i, ts, c, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
                     const c32 d = ps_dinv(dk, dm, wJ);
                     const c32 zf = ps_scal(mk(j), ps_cadd(uc, ps_cmul(SW == 2 ? ps_scal(L.w2, d) : d, ps_csub(rr(j), av))));
-                    if ((iyv < LWh)) T0[ti] = zf;
+                    T0[ti] = zf;
                     if (j >= PS_HALO) {
                         zzs = __builtin_fma((double)zf.re, (double)zf.re, __builtin_fma((double)zf.im, (double)zf.im, zzs));
                         if (SW == 2) {
@@ -1222,16 +1229,18 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             }
             if constexpr (SW == 2) {
                 // second post-sweep, while the partial sums travel (rows j >= 2)
-                {
-                    const int tw0 = ps_opq(t0i);
+                if (iyv < LWh) {
+                    {
+                        const int tw0 = ps_opq(t0i);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) if ((iyv < LWh)) T1[tw0 + j * ts] = c32{0, 0};
+                        for (int j = 0; j < 2; ++j) T1[tw0 + j * ts] = c32{0, 0};
+                    }
+                    const float wJ = kb->wJ;
+                    ps_rows<MESH, 2>(co, T0, t0i, ts, c, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+                        const c32 z5 = ps_scal(mk(j), ps_cadd(uc, ps_cmul(ps_dinv(dk, dm, wJ), ps_csub(rr(j), av))));
+                        T1[ti] = z5;
+                    });
                 }
-                const float wJ = kb->wJ;
-                ps_rows<MESH, 2>(co, T0, t0i, ts, c, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
-                    const c32 z5 = ps_scal(mk(j), ps_cadd(uc, ps_cmul(ps_dinv(dk, dm, wJ), ps_csub(rr(j), av))));
-                    if ((iyv < LWh)) T1[ti] = z5;
-                });
             }
             c32* const TZ = SW == 2 ? T1 : T0;           // the preconditioned residual z
             c32* const TP = SW == 2 ? T0 : T1;           // ... the new direction goes to the other tile, q behind z's
@@ -1309,7 +1318,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             const c32 bef = c32{(float)be.re, (float)be.im};
             // ================= p = z + beta p (rounded to complex64) -> the other tile; q = A p; p'q =================
             constexpr int JP = SW == 2 ? 2 : 1;
-            {
+            if (iyv < LWh) {
                 const int tw0 = ps_opq(t0i);
 #pragma unroll
                 for (int j = 0; j < PS_J; ++j) {
@@ -1322,7 +1331,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                         const float vr = __builtin_fmaf(bef.re, pold[j].re, __builtin_fmaf(-bef.im, pold[j].im, zv.re)), vi = __builtin_fmaf(bef.re, pold[j].im, __builtin_fmaf(bef.im, pold[j].re, zv.im));
                         pv = ps_scal(mk(j), c32{vr, vi});
                     }
-                    if ((iyv < LWh)) TP[ti] = pv;
+                    TP[ti] = pv;
                 }
             }
             __syncthreads();
@@ -1330,10 +1339,10 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             c32 qh[PS_HALO];                                                   // the halo rows' q: fp32
 #pragma unroll
             for (int j = 0; j < PS_HALO; ++j) qh[j] = c32{0, 0};
-            ps_rows<MESH, JP + 1, PS_HALO>(co, TP, t0i, ts, c, TW, [&](int j, int, c32, c32 av, float, float) __attribute__((always_inline)) { qh[j] = av; });
-            // own rows: fp64; q itself waits in LDS for alpha (each thread reads back what it wrote: z's tile is free now)
             double pqr = 0, pqi = 0, dum2 = 0;
-            {
+            if (iyv < LWh) {
+                ps_rows<MESH, JP + 1, PS_HALO>(co, TP, t0i, ts, c, TW, [&](int j, int, c32, c32 av, float, float) __attribute__((always_inline)) { qh[j] = av; });
+                // own rows: fp64; q itself waits in LDS for alpha (each thread reads back what it wrote: z's tile is free now)
                 const int tq0 = ps_opq(t0i);
 #pragma unroll
                 for (int q = 0; q < PS_NO; ++q) {
@@ -1353,7 +1362,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                     const cplx qv = (double)mk(j) * acc;                      // (a non-interior node: coefficients of a harmless node, p = 0)
                     pqr = __builtin_fma((double)pc.re, qv.re, __builtin_fma(-(double)pc.im, qv.im, pqr));
                     pqi = __builtin_fma((double)pc.re, qv.im, __builtin_fma((double)pc.im, qv.re, pqi));
-                    if ((iyv < LWh)) Qs[ti - PS_HALO * TW] = qv;
+                    Qs[ti - PS_HALO * TW] = qv;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1363,7 +1372,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
 #pragma unroll
                 for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q, g = gb + gs * j;
-                    xv[q] = *ps_at(xs1, (rowIn(j) && own()) ? eo(j) : (unsigned)(NYP + 1));
+                    xv[q] = *ps_at(xs1, (rowIn(j) && own()) ? eo(j) : (unsigned)(NYP + 1 + so32));
                 }
             }
             if (CS > 1 && !own()) { pqr = 0; pqi = 0; }
