@@ -201,10 +201,9 @@ __device__ __forceinline__ bool ps_collect(const u4v* recSys, int which, int G, 
 // The float stencil coefficients of the tile live in LDS for the whole solve (three planes [24][NYP] behind the region the
 // phases share: 48 registers per thread in the first version, which the compiler spilled): E = coupling to the east neighbour
 // (the west one is the neighbour's E; column 0 holds the coupling of column 1 to the boundary), M = omega * mass, V = coupling
-// of a row to the next row TOWARDS THE MIDDLE of the tile (the two halves of a tile are mirrored; the last row of a half
-// couples to the first row of the other half) -- in the width-specialised kernels (NYK) the coupling of a tile row to the next
-// tile row to the SOUTH instead (mesh orientation: no select of north / south from inner / outer in every row of every pass).
-// The diagonal is minus the sum of the four couplings.
+// of a tile row to the next tile row to the SOUTH (mesh orientation, whichever way the mirrored half of the tile walks its column:
+// the first version stored "the coupling towards the middle of the tile" and every row of every pass selected north / south from
+// inner / outer by the thread's half).  The diagonal is minus the sum of the four couplings.
 struct PsPl { const float *E, *M, *V; };
 #ifndef HMCMT_PS_GRP
 #define HMCMT_PS_GRP 3
@@ -238,38 +237,25 @@ __device__ __forceinline__ float ps_lds_f32(const float* p) {
     return *p;
 #endif
 }
-template <bool MESH, int JLO, int JHI = PS_J, class F>
-__device__ __forceinline__ void ps_rows(const PsPl& co, const c32* __restrict__ S, int t0i_, int es, int c, int tw, F&& f) {
+template <int JLO, int JHI = PS_J, class F>
+__device__ __forceinline__ void ps_rows(const PsPl& co, const c32* __restrict__ S, int t0i_, int es, int tw, F&& f) {
     const int t0i = ps_opq(t0i_);
     // (a rolling window over the column -- the row's outer neighbour and the row itself are the previous row's centre and inner
     //  neighbour, three tile reads per row instead of five -- was measured and lost: the values carried from row to row cost the
     //  two-sweep kernel 60 more spilled registers, 46 -> 51 us per iteration)
-    // MESH (the width-specialised kernels, NYK: the V plane in mesh orientation): neighbours and couplings are addressed by mesh
-    // direction -- north is one tile row up (index - tw), whichever way the thread walks its column -- from the lowest address of
-    // the row's five points: with the tile width a compile-time constant every access of a row is ONE address register + an
-    // immediate offset, and there is no select between "inner" and "outer" (the stencil passes issued ~50 vector instructions
-    // per row, half of them address arithmetic, selects and reloads of spilled bases).  Without a constant width this form costs
-    // the generic kernels 40 more spilled registers: they keep the select.
+    // Neighbours and couplings are addressed by MESH direction -- north is one tile row up (index - tw), whichever way the thread
+    // walks its column; the V plane holds the coupling to the south row -- from the lowest address of the row's five points: with
+    // the tile width a compile-time constant (the width-specialised kernels, NYK) every access of a row is ONE address register +
+    // an immediate offset, and there is no select between "inner" and "outer" (the stencil passes issued ~50 vector instructions
+    // per row, half of them address arithmetic, selects and reloads of spilled bases).
 #pragma unroll
     for (int j = JLO; j < JHI; ++j) {
         const int ti = t0i + j * es;
-        c32 un, us, uw, uc, ue;
-        float cw, ce, dm, cn, cs;
-        if constexpr (MESH) {
-            const c32* __restrict__ p0 = S + (ti - tw - 1);
-            un = ps_lds_c32(p0 + 1); uw = ps_lds_c32(p0 + tw); uc = ps_lds_c32(p0 + tw + 1); ue = ps_lds_c32(p0 + tw + 2); us = ps_lds_c32(p0 + 2 * tw + 1);
-            const float* __restrict__ e0 = co.E + (ti - 1);
-            const float* __restrict__ v0 = co.V + (ti - tw);
-            cw = ps_lds_f32(e0); ce = ps_lds_f32(e0 + 1); dm = ps_lds_f32(co.M + ti); cn = ps_lds_f32(v0); cs = ps_lds_f32(v0 + tw);
-        } else {
-            // (plain loads here: as unpaired atomic loads they cost the generic kernels 40-60 more spilled registers)
-            uc = S[ti]; ue = S[ti + 1]; uw = S[ti - 1];
-            const c32 ui = S[ti + es], uo = S[ti - es];
-            un = c ? ui : uo; us = c ? uo : ui;
-            ce = co.E[ti]; cw = co.E[ti - 1]; dm = co.M[ti];
-            const float va = co.V[ti], vb = co.V[ti - es];
-            cn = c ? va : vb; cs = c ? vb : va;
-        }
+        const c32* __restrict__ p0 = S + (ti - tw - 1);
+        const c32 un = ps_lds_c32(p0 + 1), uw = ps_lds_c32(p0 + tw), uc = ps_lds_c32(p0 + tw + 1), ue = ps_lds_c32(p0 + tw + 2), us = ps_lds_c32(p0 + 2 * tw + 1);
+        const float* __restrict__ e0 = co.E + (ti - 1);
+        const float* __restrict__ v0 = co.V + (ti - tw);
+        const float cw = ps_lds_f32(e0), ce = ps_lds_f32(e0 + 1), dm = ps_lds_f32(co.M + ti), cn = ps_lds_f32(v0), cs = ps_lds_f32(v0 + tw);
         const float dk = -((ce + cw) + (cn + cs));
         float are = __builtin_fmaf(-dm, uc.im, dk * uc.re), aim = __builtin_fmaf(dm, uc.re, dk * uc.im);
         are = __builtin_fmaf(ce, ue.re, are); aim = __builtin_fmaf(ce, ue.im, aim);
@@ -286,18 +272,11 @@ __device__ __forceinline__ c32 ps_dinv(float dk, float dm, float wJ) {
     return c32{dk * inv, -(dm * inv)};
 }
 // ... of tile index ti, from the planes (the same sum as in ps_rows)
-template <bool MESH>
-__device__ __forceinline__ c32 ps_dinv_at(const PsPl& co, int ti, int es, int c, int tw, float wJ) {
-    if constexpr (MESH) {
-        const float* __restrict__ e0 = co.E + (ti - 1);
-        const float* __restrict__ v0 = co.V + (ti - tw);
-        const float cw = ps_lds_f32(e0), ce = ps_lds_f32(e0 + 1), dm = ps_lds_f32(co.M + ti), cn = ps_lds_f32(v0), cs = ps_lds_f32(v0 + tw);
-        return ps_dinv(-((ce + cw) + (cn + cs)), dm, wJ);
-    } else {
-        const float ce = co.E[ti], cw = co.E[ti - 1], dm = co.M[ti], va = co.V[ti], vb = co.V[ti - es];
-        const float cn = c ? va : vb, cs = c ? vb : va;
-        return ps_dinv(-((ce + cw) + (cn + cs)), dm, wJ);
-    }
+__device__ __forceinline__ c32 ps_dinv_at(const PsPl& co, int ti, int tw, float wJ) {
+    const float* __restrict__ e0 = co.E + (ti - 1);
+    const float* __restrict__ v0 = co.V + (ti - tw);
+    const float cw = ps_lds_f32(e0), ce = ps_lds_f32(e0 + 1), dm = ps_lds_f32(co.M + ti), cn = ps_lds_f32(v0), cs = ps_lds_f32(v0 + tw);
+    return ps_dinv(-((ce + cw) + (cn + cs)), dm, wJ);
 }
 
 // block-wide deterministic sums of NV doubles (NWV waves); the totals arrive in THREAD 0 only -- it is the one that publishes them
@@ -600,10 +579,6 @@ __host__ __device__ inline int ps_plane_width(int NYP) {
 template <int CW, int SW, int MW = 32, int CS = 1, int NYK = 0>
 __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
     constexpr int NT = 2 * CW, NWV = NT / 64;
-#ifndef HMCMT_PS_MESH_CS2
-#define HMCMT_PS_MESH_CS2 0
-#endif
-    constexpr bool MESH = NYK > 0 && (CS == 1 || HMCMT_PS_MESH_CS2);       // the V plane in mesh orientation (ps_rows)
     static_assert(NYK == 0 || (NYK % 16 == 0 && (CS == 1 || NYK % 32 == 0)), "width specialisation: whole MFMA tiles, equal column parts");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* sh = reinterpret_cast<double*>(smem);                           // [2][32] block reductions (ps_block_sum_t0), [64..70) the reductions' totals
@@ -796,9 +771,8 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                     // V[tile row] = the coupling to the next tile row to the SOUTH.  This thread knows the edge between its row j and
                     // the next one inwards: for the upper half that is the row's own south edge, for the mirrored half the south edge
                     // of the row above it in the tile (both halves write the edge between rows 11 and 12: the same value)
-                    // (generic kernels: V[tile row] = the coupling towards the middle of the tile)
-                    pv[(MESH && c) ? ti - TW : ti] = vin[j] != 0.f ? vin[j] : vout[j + 1];
-                    if (MESH && c && j == 0) pv[ti] = 0.f;                 // (the last tile row's south edge: never used, never garbage)
+                    pv[c ? ti - TW : ti] = vin[j] != 0.f ? vin[j] : vout[j + 1];
+                    if (c && j == 0) pv[ti] = 0.f;                         // (the last tile row's south edge: never used, never garbage)
                 }
             }
         }
@@ -870,7 +844,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
 #pragma unroll
                 for (int j = 0; j < PS_J; ++j) {
                     const int ti = tw0 + j * ts;
-                    const c32 v = j >= JZ1 ? ps_scal(mk(j), ps_cmul(ps_dinv_at<MESH>(co, ti, ts, c, TW, kb->wJ), rr(j))) : c32{0, 0};
+                    const c32 v = j >= JZ1 ? ps_scal(mk(j), ps_cmul(ps_dinv_at(co, ti, TW, kb->wJ), rr(j))) : c32{0, 0};
                     T0[ti] = v;
                 }
             }
@@ -888,7 +862,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                         for (int j = 0; j < 4; ++j) T1[tw0 + j * ts] = c32{0, 0};
                     }
                     const float wJ = kb->wJ;
-                    ps_rows<MESH, 4>(co, T0, t0i, ts, c, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+                    ps_rows<4>(co, T0, t0i, ts, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
                         const c32 u2 = ps_scal(mk(j), ps_cadd(uc, ps_cmul(ps_scal(L.w2, ps_dinv(dk, dm, wJ)), ps_csub(rr(j), av))));
                         T1[ti] = u2;
                         if (j >= PS_HALO && rowIn(j) && (CS == 1 || own())) *ps_at(pubZ1, eo(j)) = float2{u2.re, u2.im};
@@ -908,7 +882,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
 #pragma unroll
             for (int q = 0; q < PS_NO; ++q) tv[q] = c32{0, 0};
             if (iyv < LWh)
-            ps_rows<MESH, PS_HALO>(co, SW == 2 ? T1 : T0, t0i, ts, c, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+            ps_rows<PS_HALO>(co, SW == 2 ? T1 : T0, t0i, ts, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
                 const c32 rv = rr(j);
                 tv[j - PS_HALO] = ps_scal(mk(j), ps_csub(rv, av));
                 if (SW == 2) {
@@ -1144,14 +1118,10 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
 #pragma unroll
                             for (int rg = 0; rg < 3; ++rg) {
                                 u4v ahn = ahc, aln = alc;
-                                if constexpr (CS == 1 || NYK > 0) {
+                                {
                                     const int kgn = rg < 2 ? kg : kg + 1, rgn = rg < 2 ? rg + 1 : 0;
                                     if (kgn < KG && kgn < (CS == 1 ? 8 : 16)) ldA(kgn, rgn, ahn, aln);
                                     __builtin_amdgcn_sched_barrier(0);
-                                } else {
-                                    // (column parts: the eight registers of the second stage cost the two-part kernel 66 spilled registers -- its
-                                    //  steps load their own rows)
-                                    if (kg + rg > 0) ldA(kg, rg, ahc, alc);
                                 }
 #pragma unroll
                                 for (int t = 0; t < 2; ++t) {
@@ -1202,7 +1172,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                     T0[tw0] = c32{0, 0};
                 }
                 const float wJ = kb->wJ;
-                ps_rows<MESH, 1>(co, T1, t0i, ts, c, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+                ps_rows<1>(co, T1, t0i, ts, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
                     const c32 d = ps_dinv(dk, dm, wJ);
                     const c32 zf = ps_scal(mk(j), ps_cadd(uc, ps_cmul(SW == 2 ? ps_scal(L.w2, d) : d, ps_csub(rr(j), av))));
                     T0[ti] = zf;
@@ -1236,7 +1206,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                         for (int j = 0; j < 2; ++j) T1[tw0 + j * ts] = c32{0, 0};
                     }
                     const float wJ = kb->wJ;
-                    ps_rows<MESH, 2>(co, T0, t0i, ts, c, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
+                    ps_rows<2>(co, T0, t0i, ts, TW, [&](int j, int ti, c32 uc, c32 av, float dk, float dm) __attribute__((always_inline)) {
                         const c32 z5 = ps_scal(mk(j), ps_cadd(uc, ps_cmul(ps_dinv(dk, dm, wJ), ps_csub(rr(j), av))));
                         T1[ti] = z5;
                     });
@@ -1284,8 +1254,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                     dm64[q] = *ps_at(dMm, e);
                     ce64[q] = *ps_at(cYm, e); cw64[q] = *ps_at(cYm, e - 1u);
                     const double cs = *ps_at(cZm, e), cn = *ps_at(cZm, e - (unsigned)NYP);
-                    // (generic kernels: inner / outer neighbour of the mirrored half; width-specialised ones: north / south, no select)
-                    ci64[q] = MESH ? cn : (c ? cn : cs); co64[q] = MESH ? cs : (c ? cs : cn);
+                    ci64[q] = cn; co64[q] = cs;          // (north / south: mesh orientation, no select by the thread's half)
                 }
             }
             // ================= scalars: rho, error estimate, convergence, beta =================
@@ -1341,16 +1310,14 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             for (int j = 0; j < PS_HALO; ++j) qh[j] = c32{0, 0};
             double pqr = 0, pqi = 0, dum2 = 0;
             if (iyv < LWh) {
-                ps_rows<MESH, JP + 1, PS_HALO>(co, TP, t0i, ts, c, TW, [&](int j, int, c32, c32 av, float, float) __attribute__((always_inline)) { qh[j] = av; });
+                ps_rows<JP + 1, PS_HALO>(co, TP, t0i, ts, TW, [&](int j, int, c32, c32 av, float, float) __attribute__((always_inline)) { qh[j] = av; });
                 // own rows: fp64; q itself waits in LDS for alpha (each thread reads back what it wrote: z's tile is free now)
                 const int tq0 = ps_opq(t0i);
 #pragma unroll
                 for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q;
                     const int ti = tq0 + j * ts;
-                    c32 pc, pe, pw, pi, po;
-                    if constexpr (MESH) { pc = ps_lds_c32(TP + ti); pe = ps_lds_c32(TP + ti + 1); pw = ps_lds_c32(TP + ti - 1); pi = ps_lds_c32(TP + ti - TW); po = ps_lds_c32(TP + ti + TW); }
-                    else { pc = TP[ti]; pe = TP[ti + 1]; pw = TP[ti - 1]; pi = TP[ti + ts]; po = TP[ti - ts]; }
+                    const c32 pc = ps_lds_c32(TP + ti), pe = ps_lds_c32(TP + ti + 1), pw = ps_lds_c32(TP + ti - 1), pi = ps_lds_c32(TP + ti - TW), po = ps_lds_c32(TP + ti + TW);
                     const double dmw = w * dm64[q];
                     const double dk = -((ce64[q] + cw64[q]) + (ci64[q] + co64[q]));
                     // (explicit fma throughout: twelve instructions per row instead of twenty-two)
