@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             // (|x|^2 of this thread's rows in float: it scales the stopping rule |z| <= tol |x| and nothing else -- seven digits are five
             //  more than that needs --, and as a double carried through the seven rows it was what the two-part kernel spilled per row)
             float xxs = 0.f; double dum3 = 0, dum4 = 0;
-            {
+            if (iyv < LWh) {                    // (one column condition around the phase; the row conditions are scalar branches)
                 const int tu0 = ps_opq(t0i);
                 const bool mine = own();
                 cplx* const xs2 = xsys();
@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
 #pragma unroll
                 for (int q = 0; q < PS_NO; ++q) {
                     const int j = PS_HALO + q, g = gb + gs * j;
-                    if (rowIn(j) && (iyv < LWh)) {
+                    if (rowIn(j)) {
                         // (p and q vanish on boundary and pad nodes: x keeps its Dirichlet values there, r stays zero)
                         {
                             const cplx qv = Qs[tu0 + j * ts - PS_HALO * TW];
