@@ -1030,7 +1030,13 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             // ================= tridiagonal solves of this workgroup's mode slabs =================
             for (int slab = jw; slab < nslab; slab += G) ps_slab_solve_reg<NT, MW, CS, NYK>(kb, arena, tabF1, tabF2, s, slab, tidv, stampNow ? L.stamps + (long)blockIdx.x * 16 : nullptr);
             PS_STAMP(4)
-            u4v bbk[8][2];                                                     // the wave's V' fragments of the back transform: in flight during the wait
+            // T2, first half: this workgroup's solved slabs are in the L2 -> arrive.  The wave's V' fragments of the back transform are
+            // requested BEHIND the arrival (requested in front of it, as first written, the s_waitcnt vmcnt(0) that drains the slabs'
+            // stores waited for these loads too: every workgroup arrived a memory round trip late)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) sys_arrive();
+            u4v bbk[8][2];                                                     // ... in flight during the wait
             {
                 const int lo = lanev;
 #pragma unroll
@@ -1040,7 +1046,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                     bbk[q][1] = *ps_at(kb->Vtb, (unsigned)((kg * NTc + tl1) * 64 + lo));
                 }
             }
-            if (!sys_sync()) { alive = false; break; }                         // T2: every solved slab is in the L2
+            if (!sys_wait()) { alive = false; break; }                         // T2, second half: every solved slab is in the L2
             PS_STAMP(5)
             PS_PHASE();
             ++it;
