@@ -1169,10 +1169,10 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
         const SpecFn specA = [&](const int* gate, int gen) {
             View vg = v; vg.gate = gate; vg.gateGen = gen;
             if (ctx->sensWaitPending) { ctx->sensWaitPending = false; hipStreamWaitEvent(st, ctx->evSens, 0); }
-            hipLaunchKernelGGL(k_wb, dim3((v.nz + v.ny + 127) / 128, S), dim3(128), 0, st, vg, solve_rec(ctx, 1));
+            { const int nwbx = (v.nz + v.ny + 127) / 128, ngcx = (v.nCell + 127) / 128;       // (k_wb + k_gradcell: one launch)
+              hipLaunchKernelGGL(k_wb_gradcell, dim3(nwbx * S + ngcx * 2 * GRAD_NG), dim3(128), 0, st, vg, solve_rec(ctx, 1), nwbx, ngcx); }
             hipEventRecord(ctx->evRec, st);
             hipLaunchKernelGGL(k_bcsens_contract, dim3((v.nz + 127) / 128, 2, S), dim3(128), 0, st, vg);
-            hipLaunchKernelGGL(k_gradcell, dim3((v.nCell + 127) / 128, 2, GRAD_NG), dim3(128), 0, st, vg);
             hipLaunchKernelGGL(k_gradfinal, grid1(4 * v.nAC, 128), dim3(128), 0, st, vg);
         };
         rc = solve(ctx, v.Lam, 1, true, specPlain ? &specA : nullptr);
@@ -1191,10 +1191,10 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
         if (!specAdj) {
             ProfScope ps(ctx, 6);
             if (ctx->sensWaitPending) { ctx->sensWaitPending = false; HIPCHK(hipStreamWaitEvent(st, ctx->evSens, 0)); }     // (a solve of fewer than 8 iterations)
-            hipLaunchKernelGGL(k_wb, dim3((v.nz + v.ny + 127) / 128, S), dim3(128), 0, st, v, solve_rec(ctx, 1));      // (+ the adjoint solve's records)
+            { const int nwbx = (v.nz + v.ny + 127) / 128, ngcx = (v.nCell + 127) / 128;       // (k_wb (+ the adjoint solve's records) + k_gradcell: one launch)
+              hipLaunchKernelGGL(k_wb_gradcell, dim3(nwbx * S + ngcx * 2 * GRAD_NG), dim3(128), 0, st, v, solve_rec(ctx, 1), nwbx, ngcx); }
             HIPCHK(hipEventRecord(ctx->evRec, st));                        // behind the records of the last solve
             hipLaunchKernelGGL(k_bcsens_contract, dim3((v.nz + 127) / 128, 2, S), dim3(128), 0, st, v);
-            hipLaunchKernelGGL(k_gradcell, dim3((v.nCell + 127) / 128, 2, GRAD_NG), dim3(128), 0, st, v);
             hipLaunchKernelGGL(k_gradfinal, grid1(4 * v.nAC, 128), dim3(128), 0, st, v);
         }
         if (ctx->wantTicks) ctx->hostUs[2] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hostT2).count();

@@ -395,6 +395,29 @@ __global__ void k_wb(View v, SolveRec rec) {
     else if (e < v.nz + v.ny) item_colw(v, s, e - v.nz);
     tick_end(v.ticks, TK_WB);
 }
+// k_wb and k_gradcell in ONE launch (end of round 5): the per-cell P-terms read the two solves' fields only, the boundary weights
+// feed k_bcsens_contract -- nothing of one is read by the other, and as two launches of a few microseconds each they were two
+// boundaries of the serial tail behind the adjoint solve.  Blocks [0, nwb) are k_wb's (nwbx per system), the rest k_gradcell's
+// (ngcx per mode and frequency group).
+__global__ __launch_bounds__(128) void k_wb_gradcell(View v, SolveRec rec, int nwbx, int ngcx) {
+    if (gate_closed(v)) return;
+    const int nwb = nwbx * v.S;
+    if ((int)blockIdx.x < nwb) {
+        const int bx = blockIdx.x % nwbx, s = blockIdx.x / nwbx;
+        const int e = bx * blockDim.x + threadIdx.x;
+        tick_begin(v.ticks, TK_WB);
+        if (rec.recI && e == 0) write_solve_rec(rec, s);
+        if (e < v.nz) item_wside(v, s, e + 1);
+        else if (e < v.nz + v.ny) item_colw(v, s, e - v.nz);
+        tick_end(v.ticks, TK_WB);
+    } else {
+        const int idx = blockIdx.x - nwb;
+        const int cb = idx % ngcx, mode = (idx / ngcx) & 1, grp = idx / (2 * ngcx);
+        const int c = cb * blockDim.x + threadIdx.x;
+        if (c < v.nCell) item_gradcell_group(v, mode, grp, c);
+        if (threadIdx.x == 0 && idx == 0) { /* (ticks: the slot of k_gradcell stays empty in fused runs) */ }
+    }
+}
 __global__ __launch_bounds__(64) void k_bcsens_pre(View v) {
     int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
     if (c < v.nz) item_bcsens_pre(v, s, prof, c);
