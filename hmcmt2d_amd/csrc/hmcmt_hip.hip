@@ -632,6 +632,15 @@ int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout, in
                          else hipLaunchKernelGGL((k_cocg_persist<CW, SWP, 32, 1>), grid, dim3(2 * CW), lds, ctx->stream, a); } while (0)
     // width-specialised instantiations (PS_WIDTHS: the row width is a compile-time constant) where the mesh has one of those widths
     const int wk = ctx->persistWidthK;
+    // HMCMT_STAMPS=persist: the instantiations with the phase stamps compiled in (the 512-thread shapes the phase tables are made on)
+    if (ctx->d_pstamps && ctx->persistCW == 256 && (ctx->persistCS == 2 || ctx->persistMW == 32)) {
+#define PSS(SWP) do { if (wk == 208 && ctx->persistCS == 1) hipLaunchKernelGGL((k_cocg_persist<256, SWP, 32, 1, 208, true>), grid, dim3(512), lds, ctx->stream, a); \
+                      else if (wk == 416 && ctx->persistCS == 2) hipLaunchKernelGGL((k_cocg_persist<256, SWP, 16, 2, 416, true>), grid, dim3(512), lds, ctx->stream, a); \
+                      else if (ctx->persistCS == 2) hipLaunchKernelGGL((k_cocg_persist<256, SWP, 16, 2, 0, true>), grid, dim3(512), lds, ctx->stream, a); \
+                      else hipLaunchKernelGGL((k_cocg_persist<256, SWP, 32, 1, 0, true>), grid, dim3(512), lds, ctx->stream, a); } while (0)
+        if (sweeps == 2) PSS(2); else PSS(1);
+#undef PSS
+    } else
     if (wk == 208 && ctx->persistCW == 256 && ctx->persistCS == 1 && ctx->persistMW == 32) {
         if (sweeps == 2) hipLaunchKernelGGL((k_cocg_persist<256, 2, 32, 1, 208>), grid, dim3(512), lds, ctx->stream, a);
         else hipLaunchKernelGGL((k_cocg_persist<256, 1, 32, 1, 208>), grid, dim3(512), lds, ctx->stream, a);
@@ -1481,7 +1490,11 @@ static int persist_setup(hmcmt_ctx* ctx) {
     if (!persist_shape(ctx, k.twist, cuPerXcd, G, cw, mw, lds, &cs)) return 0;
     if ((size_t)k.S * (size_t)k.vstride >= ((size_t)1 << 27)) return 0;      // (the kernel's 32-bit lane offsets carry the system's element offset: kernels_persist.h, so32)
     ctx->persistMW = mw;
-    const void* fns[24] = {reinterpret_cast<const void*>(k_cocg_persist<256, 1, 32, 1, 208>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 32, 1, 208>),
+    const void* fns[32] = {reinterpret_cast<const void*>(k_cocg_persist<256, 1, 32, 1, 208, true>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 32, 1, 208, true>),
+                           reinterpret_cast<const void*>(k_cocg_persist<256, 1, 16, 2, 416, true>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 16, 2, 416, true>),
+                           reinterpret_cast<const void*>(k_cocg_persist<256, 1, 32, 1, 0, true>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 32, 1, 0, true>),
+                           reinterpret_cast<const void*>(k_cocg_persist<256, 1, 16, 2, 0, true>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 16, 2, 0, true>),
+                           reinterpret_cast<const void*>(k_cocg_persist<256, 1, 32, 1, 208>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 32, 1, 208>),
                            reinterpret_cast<const void*>(k_cocg_persist<128, 1, 32, 1, 112>), reinterpret_cast<const void*>(k_cocg_persist<128, 2, 32, 1, 112>),
                            reinterpret_cast<const void*>(k_cocg_persist<256, 1, 16, 2, 416>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 16, 2, 416>),
                            reinterpret_cast<const void*>(k_cocg_persist<256, 1, 32, 1>), reinterpret_cast<const void*>(k_cocg_persist<256, 2, 32, 1>),

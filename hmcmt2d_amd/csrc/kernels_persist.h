@@ -571,12 +571,14 @@ __host__ __device__ inline int ps_plane_width(int NYP) {
 
 // (a UNIFORM branch around the stamp -- stamps requested and third iteration --, thread 0 inside it: as one per-lane condition the
 //  compiler kept its lane mask and the stamps' address in spilled scalar registers and reloaded both at each of the twelve stamps)
-#define PS_STAMP(i) if (stampIt) { if (tid == 0) L.stamps[(long)blockIdx.x * 16 + (i)] = wall_clock64(); }
+// ST: the stamps are compiled in (the instantiations HMCMT_STAMPS=persist launches); without it a stamp is nothing -- as a run-time
+//  check of a launch argument each of the fourteen cost a reload of two spilled scalars, a mask and a branch per iteration
+#define PS_STAMP(i) if constexpr (ST) { if (stampIt) { if (tid == 0) L.stamps[(long)blockIdx.x * 16 + (i)] = wall_clock64(); } }
 
 // NYK > 0: the kernel is specialised for meshes of NYK padded nodes per row (tile width, plane strides and the LDS carve's row
 // strides are compile-time constants: the stencil passes address a row's points and coefficients as one register + immediates);
 // NYK = 0 takes the width from the state block.  Column parts: NYK must be a multiple of 32 (two parts of equal width).
-template <int CW, int SW, int MW = 32, int CS = 1, int NYK = 0>
+template <int CW, int SW, int MW = 32, int CS = 1, int NYK = 0, bool ST = false>
 __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
     constexpr int NT = 2 * CW, NWV = NT / 64;
     static_assert(NYK == 0 || (NYK % 16 == 0 && (CS == 1 || NYK % 32 == 0)), "width specialisation: whole MFMA tiles, equal column parts");
@@ -808,7 +810,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
 #define PS_PHASE() kb = kb0; asm volatile("" : "+v"(e0), "+v"(t0i), "+v"(inM), "+v"(tidv), "+v"(lanev), "+v"(ljv), "+v"(g4v), "+v"(iyv), "+s"(kb), "+s"(rowM))   /* row offsets / masks / the state block's scalars are re-derived per PHASE instead of living in registers across all of them */
         for (;;) {
             PS_PHASE();
-            const bool stampIt = L.stamps != nullptr && it == 2;      // (uniform)
+            const bool stampIt = ST && L.stamps != nullptr && it == 2;      // (uniform)
             const bool stampNow = stampIt && tid == 0;
             // the wave's V fragments of the forward transform (constant; KGF <= 8 k-groups x 2 column tiles): requested here, they
             // arrive under the pre-smoother (every phase of this loop is a memory round trip + a little arithmetic: what can be
