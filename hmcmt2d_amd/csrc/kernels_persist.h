@@ -42,6 +42,15 @@
 // through a CONSTANT-address-space pointer that is laundered at every phase: a phase loads the scalars it needs with s_load from a
 // hot line and drops them, instead of 968 bytes of by-value kernarg being held in (and spilled from: 417 SGPR spills, 821
 // v_readlane in the iteration loop) scalar registers for the whole solve.  What changes per launch is PsLaunch (88 B).
+// (3) THE INSTRUCTION STREAM (second half of round 5) -- the vector phases are bound by instruction ISSUE (a scalar
+// instruction costs a wave as much issue time as a vector one), so what the compiler made of the source was read in the ISA and
+// put right: instantiations with the row width a compile-time constant (NYK: 112 / 208 / 416 nodes); the stencil rows addressed in
+// MESH orientation from one register + immediates, their LDS reads unpaired (relaxed atomic loads); ONE column condition around a
+// pass instead of one around each tile write (which also took every register spill with it); the loops' exits decided on scalars
+// (readfirstlane: uniform loops, loop-carried scalars in scalar registers); array bases once per phase and the system's element
+// offset inside the 32-bit lane offsets; fp64 product-sums as explicit fma; block sums whose totals only thread 0 forms; the
+// transforms' MFMA loops as explicit two-stage pipelines; T2's arrival in front of the next phase's prefetches; the phase stamps
+// compiled in only where asked for (ST).  39.5 -> 32.6 us per iteration at cfg3, 46.9 -> 39.8 at cfg5.
 // Reference: the solves at MTFwdSolver/mt2DTE.jl:47-55, mt2DTM.jl:46-54, MTSensitivity/compJacTMatVec.jl:220-229, 291-300.
 #pragma once
 
