@@ -157,6 +157,9 @@ struct hmcmt_ctx {
     long long *d_wmRow = nullptr, *d_wmCol = nullptr;
     double *d_lfPart = nullptr, *d_lfScal = nullptr;
     int* d_lfFlag = nullptr;
+    int* d_lfDone = nullptr;                 // [nAC] LfMom::done
+    int lfGen = 0;                           // LfMom::gen of the last evaluation that carried a momentum update
+    LfMom lfMom{};                           // a momentum update of hmcmt_leapfrog* that the evaluation's last kernel performs (k_gradfinal)
     int* h_lfFlag = nullptr;                 // pinned copy of d_lfFlag (read after a synchronisation)
     double* d_gStart = nullptr;              // data gradient at the start model of the last trajectory (a rejection restarts there)
     bool havePrior = false, lfHaveGrad = false, lfFlagPending = false;
@@ -1181,8 +1184,8 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
             { const int nwbx = (v.nz + v.ny + 127) / 128, ngcx = (v.nCell + 127) / 128;       // (k_wb + k_gradcell: one launch)
               hipLaunchKernelGGL(k_wb_gradcell, dim3(nwbx * S + ngcx * 2 * GRAD_NG), dim3(128), 0, st, vg, solve_rec(ctx, 1), nwbx, ngcx); }
             hipEventRecord(ctx->evRec, st);
-            hipLaunchKernelGGL(k_bcsens_contract, dim3((v.nz + 127) / 128, 2, S), dim3(128), 0, st, vg);
-            hipLaunchKernelGGL(k_gradfinal, grid1(4 * v.nAC, 128), dim3(128), 0, st, vg);
+            hipLaunchKernelGGL(k_bcsens_contract, dim3((v.nz + 127) / 128, 2, S), dim3(128), 0, st, vg, ctx->lfMom.on ? ctx->lfMom.L.part : (double*)nullptr);
+            hipLaunchKernelGGL(k_gradfinal, grid1(4 * v.nAC, 128), dim3(128), 0, st, vg, ctx->lfMom);
         };
         rc = solve(ctx, v.Lam, 1, true, specPlain ? &specA : nullptr);
         const bool specAdj = ctx->specValid;
@@ -1203,8 +1206,8 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
             { const int nwbx = (v.nz + v.ny + 127) / 128, ngcx = (v.nCell + 127) / 128;       // (k_wb (+ the adjoint solve's records) + k_gradcell: one launch)
               hipLaunchKernelGGL(k_wb_gradcell, dim3(nwbx * S + ngcx * 2 * GRAD_NG), dim3(128), 0, st, v, solve_rec(ctx, 1), nwbx, ngcx); }
             HIPCHK(hipEventRecord(ctx->evRec, st));                        // behind the records of the last solve
-            hipLaunchKernelGGL(k_bcsens_contract, dim3((v.nz + 127) / 128, 2, S), dim3(128), 0, st, v);
-            hipLaunchKernelGGL(k_gradfinal, grid1(4 * v.nAC, 128), dim3(128), 0, st, v);
+            hipLaunchKernelGGL(k_bcsens_contract, dim3((v.nz + 127) / 128, 2, S), dim3(128), 0, st, v, ctx->lfMom.on ? ctx->lfMom.L.part : (double*)nullptr);
+            hipLaunchKernelGGL(k_gradfinal, grid1(4 * v.nAC, 128), dim3(128), 0, st, v, ctx->lfMom);
         }
         if (ctx->wantTicks) ctx->hostUs[2] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hostT2).count();
     }
@@ -2483,6 +2486,7 @@ int hmcmt_set_prior(hmcmt_ctx* ctx, const double* mref, const int64_t* rowptr, c
         if ((rc = dalloc(ctx, &ctx->d_lfPart, (size_t)LFNB))) return rc;
         if ((rc = dalloc(ctx, &ctx->d_lfScal, (size_t)4))) return rc;
         if ((rc = dalloc(ctx, &ctx->d_lfFlag, (size_t)1))) return rc;
+        if ((rc = dalloc(ctx, &ctx->d_lfDone, (size_t)n))) return rc;
         if ((rc = dalloc(ctx, &ctx->d_gStart, (size_t)n))) return rc;
         HIPCHK(hipHostMalloc((void**)&ctx->h_lfFlag, sizeof(int), hipHostMallocDefault));
         *ctx->h_lfFlag = 0;
@@ -2521,14 +2525,16 @@ static int leapfrog_core(hmcmt_ctx* ctx, double* d_m, double* d_p, double dt, in
     hipLaunchKernelGGL(k_lf_momentum_max, dim3(LFNB), dim3(256), 0, st, lf, regParam, 0.5 * dt, dt);
     for (int k = 1; k <= L; ++k) {
         ctx->lfStep = LfStep{1, lf, dt, lnSigMin, lnSigMax};            // (the position update: performed by the evaluation's first kernel)
+        // (... and the momentum update behind the gradient, with the step bound of the next position update, by its last one)
+        ctx->lfMom = LfMom{1, lf, regParam, (k < L ? 1.0 : 0.5) * dt, dt, ++ctx->lfGen, ctx->d_lfDone};
         rc = evaluate(ctx, d_m, true, d_pred, d_misfit, ctx->d_g);      // (reports a failure of the step before)
         ctx->lfStep.on = 0;
+        ctx->lfMom.on = 0;
         if (rc) return rc;
         // asynchronous, as hmcmt_grad_device_async: the next step's launches overlap this step's gradient tail
         ctx->statsPending = true;
         ctx->pendingAdj = true;
         ++evals;
-        hipLaunchKernelGGL(k_lf_momentum_max, dim3(LFNB), dim3(256), 0, st, lf, regParam, (k < L ? 1.0 : 0.5) * dt, dt);
     }
     if ((rc = collect_pending(ctx))) return rc;
     hipLaunchKernelGGL(k_lf_mnorm, dim3(LFNB), dim3(256), 0, st, lf, regParam);

@@ -59,6 +59,9 @@ __device__ __forceinline__ double lf_step_bound(const LfView& L) {
 }
 // a position update that k_sigma_rows performs on its way (the device-resident leapfrog: one launch less per step)
 struct LfStep { int on; LfView L; double dt, lo, hi; };
+// a momentum update that k_gradfinal performs on its way (one launch less per step): gen / done make it happen once per
+// parameter and evaluation however often the gradient's last kernel runs (a repeated evaluation, speculative followers)
+struct LfMom { int on; LfView L; double lambda, cdt, dt; int gen; int* done; };
 // k_sigma + k_rowmean: one wave per cell row computes the row's conductivities and, from the values it has just formed,
 // the lateral means (same summation order as k_rowmean) -- the FDM background (k_pivot) then needs nothing but this launch
 __global__ __launch_bounds__(64) void k_sigma_rows(View v, LfStep step) {
@@ -422,9 +425,11 @@ __global__ __launch_bounds__(64) void k_bcsens_pre(View v) {
     int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
     if (c < v.nz) item_bcsens_pre(v, s, prof, c);
 }
-__global__ void k_bcsens_contract(View v) {
+__global__ void k_bcsens_contract(View v, double* lfPart) {
     if (gate_closed(v)) return;
     int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
+    // (the step-bound maxima k_gradfinal collects behind this launch start from zero)
+    if (lfPart && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x < LFNB) lfPart[threadIdx.x] = 0.0;
     tick_begin(v.ticks, TK_BCSENS);
     if (c < v.nz) item_bcsens_contract(v, s, prof, c);
     tick_end(v.ticks, TK_BCSENS);
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(64) void k_qterm(View v) {
 }
 // final assembly with four lanes per active cell (a latency-bound loop over the systems: 4x the threads), each
 // taking every fourth system / partial sum; the four partial sums are added in lane order
-__global__ void k_gradfinal(View v) {
+__global__ void k_gradfinal(View v, LfMom mom) {
     if (gate_closed(v)) return;
     const int t = TID1, a = t >> 2, l = t & 3;
     tick_begin(v.ticks, TK_GRADFINAL);
@@ -458,7 +463,34 @@ __global__ void k_gradfinal(View v) {
     }
     // lanes 4a .. 4a+3 are neighbours in a wave (the grid is a multiple of 64 threads)
     const double g1 = __shfl_down(g, 1, 4), g2 = __shfl_down(g, 2, 4), g3 = __shfl_down(g, 3, 4);
-    if (a < v.nAC && l == 0) v.grad[a] = exp(v.m[a]) * (((g + g1) + g2) + g3);
+    const bool own = a < v.nAC && l == 0;
+    double gd = 0.0;
+    if (own) { gd = exp(v.m[a]) * (((g + g1) + g2) + g3); v.grad[a] = gd; }
+    if (mom.on) {
+        // the momentum update of the leapfrog step this gradient belongs to (k_lf_momentum_max's arithmetic, HMCSampler.jl:255-263)
+        // and the maxima of |dt*invM*p| for the position update that follows (:237-240; zeroed by k_bcsens_contract)
+        const LfView& L = mom.L;
+        double mx = 0.0;
+        if (own) {
+            double p = L.p[a];
+            if (mom.done[a] != mom.gen) {
+                double acc = 0.0;
+                for (long long q = L.wmRow[a]; q < L.wmRow[a + 1]; ++q) {
+                    const long long j = L.wmCol[q];
+                    acc += L.wmVal[q] * (L.m[j] - L.mref[j]);
+                }
+                const double gt = gd + mom.lambda * acc;
+                p = p - mom.cdt * gt;
+                L.p[a] = p;
+                mom.done[a] = mom.gen;
+            }
+            mx = fmax(0.0, fabs(mom.dt * L.invM[a] * p));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+        if ((threadIdx.x & 63) == 0 && mx > 0.0)
+            atomicMax(reinterpret_cast<unsigned long long*>(L.part + (blockIdx.x & (LFNB - 1))), (unsigned long long)__double_as_longlong(mx));
+    }
     tick_end(v.ticks, TK_GRADFINAL);
 }
 
