@@ -178,6 +178,14 @@ struct hmcmt_ctx {
     unsigned shareMask = 0xF;             // ... as quarters
     int persistWidthK = 0;                // 112 / 208 / 416: the mesh's padded row width has a width-specialised persistent kernel (launch_persist)
     int persistCS = 1, persistGZ = 0;     // column parts of a row block (2: wide meshes, kernels_persist.h), row blocks per system
+    // the order in which the queues of the persistent kernel take the systems (PsLaunch::order; persist_balance): per solve kind
+    int* d_psOrder = nullptr;             // [2][S]
+    int* h_psOrder = nullptr;             // pinned staging of the same
+    std::vector<int> psOrder[2];          // what the device copy holds (empty: the kernel's own order, no table passed)
+    bool psBalance = true;                // HMCMT_PERSIST_BALANCE=0: never
+    std::vector<float> psCost[2];         // the costs the tables are made from (smoothed iteration counts)
+    float psSmooth = 0.75f;               // weight of the older costs (HMCMT_PERSIST_BALANCE_SMOOTH; cfg5, 96-step chains: 0 -> 84.3, 0.5 -> 84.8, 0.75 -> 85.0 steps/s, index order 83.4)
+    long psRebalanced = 0;
     PsConst psShadow{};                   // what d_psConst holds (launch_persist refreshes the device copy when a field differs)
     PsConst* d_psConst = nullptr;         // the kernel's launch-invariant state, read through a constant-address-space pointer
     bool psConstValid = false;
@@ -627,6 +635,7 @@ int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout, in
     if (ctx->gateGen >= 0x3fffffff) ctx->gateGen = 0;           // (wrap BEFORE the increment: the followers are handed ctx->gateGen, the value this launch writes)
     a.gateGen = ++ctx->gateGen;
     a.dbgPlace = ctx->dbgPlace; ctx->dbgPlace = 0;
+    a.order = ctx->psOrder[kind == 1].empty() ? nullptr : ctx->d_psOrder + (kind == 1 ? k.S : 0);
     if (ctx->d_pstamps) HIPCHK(hipMemsetAsync(ctx->d_pstamps, 0, sizeof(long long) * 16 * 256, ctx->stream));
     const dim3 grid(groups * ctx->persistG);
     const size_t lds = ctx->persistLds;
@@ -1216,6 +1225,52 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
     return 0;
 }
 
+// Meshes whose systems do not all fit the chip at once (cfg5: 64 systems, one per XCD at a time) run them through 8 x slots
+// queues, and a queue's time is the SUM of its systems' iterations: taken in index order (XCD x: systems x, x + 8, ..) the longest
+// queue of the cfg5 chain holds 3.5 % more iterations than the mean (forward; 2.9 % adjoint) and the other XCDs idle at the end of
+// every solve.  The iteration counts of consecutive solves of a chain differ by one or two, so the last solve's counts are the
+// next one's costs: longest-first into the least loaded queue that has room (every queue keeps its number of systems: the
+// kernel's loop bounds do not change).  A new table is taken when the present one is more than 1 % behind it.
+void persist_balance(hmcmt_ctx* ctx, int kind) {
+    const int S = ctx->sv.S, NQ = 8 * ctx->persistSlots;
+    if (!ctx->psBalance || !ctx->d_psOrder || NQ <= 0 || S <= NQ) return;
+    // (costs: the mean of the last solve's counts and the costs before it -- the counts of one system wander by one or two from
+    //  step to step, and a table made from one solve's noise is a worse guess for the next than one made from two)
+    std::vector<float>& cost = ctx->psCost[kind];
+    const int* last = ctx->itersLast.data() + (size_t)kind * S;
+    if (cost.empty()) cost.assign(last, last + S);
+    else for (int i = 0; i < S; ++i) cost[i] = ctx->psSmooth * cost[i] + (1.f - ctx->psSmooth) * (float)last[i];
+    auto makespan = [&](const int* tab) {
+        double worst = 0;
+        for (int j = 0; j < NQ; ++j) { double t = 0; for (int q = j; q < S; q += NQ) t += cost[tab ? tab[q] : q]; worst = std::max(worst, t); }
+        return worst;
+    };
+    std::vector<int> idx(S), tab(S), fill(NQ, 0);
+    std::vector<double> load(NQ, 0.0);
+    for (int i = 0; i < S; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    for (int i = 0; i < S; ++i) {
+        int best = -1;
+        for (int j = 0; j < NQ; ++j) {
+            if (j + NQ * fill[j] >= S) continue;                       // (the queue is full)
+            if (best < 0 || load[j] < load[best]) best = j;
+        }
+        tab[best + NQ * fill[best]] = idx[i];
+        ++fill[best]; load[best] += cost[idx[i]];
+    }
+    std::vector<int>& cur = ctx->psOrder[kind];
+    const double now = makespan(cur.empty() ? nullptr : cur.data()), lpt = makespan(tab.data());
+    if (now <= 1.01 * lpt) return;
+    std::memcpy(ctx->h_psOrder + (size_t)kind * S, tab.data(), sizeof(int) * S);
+    // (stream order: behind every launch that reads the old table, in front of the next solve)
+    if (hipMemcpyAsync(ctx->d_psOrder + (size_t)kind * S, ctx->h_psOrder + (size_t)kind * S, sizeof(int) * S, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    cur = tab;
+    ++ctx->psRebalanced;
+}
+
 // the per-solve records (written by k_solve_end into mapped pinned memory) -> statistics; the caller has waited for them
 void parse_stats(hmcmt_ctx* ctx, bool withAdjoint) {
     const int S = ctx->v.S, nk = withAdjoint ? 2 : 1;
@@ -1237,6 +1292,7 @@ void parse_stats(hmcmt_ctx* ctx, bool withAdjoint) {
         // first convergence poll of the next evaluation: where this one actually finished (the loop itself only
         // knows how many iterations it launched, which includes the empty ones behind the last poll)
         if (ctx->solveDone[kind] && mx > 0) (kind == 0 ? ctx->lastItFwd : ctx->lastItAdj) = mx;
+        if (ctx->solveDone[kind] && mx > 0 && ctx->stats.status == 0 && ctx->persistCW && ctx->persistOn) persist_balance(ctx, kind);
         // ... and the smoother of the next solve of this kind (pick_sweeps): two sweeps per side when this one was long
         if (ctx->sweepsMode == 0 && ctx->solveDone[kind] && mx > 0) {
             int& next = ctx->sweepsKind[kind];
@@ -1423,6 +1479,7 @@ int hmcmt_destroy(hmcmt_ctx* ctx) {
     if (ctx->h_rec) hipHostFree(ctx->h_rec);
     if (ctx->h_stage) hipHostFree(ctx->h_stage);
     if (ctx->h_lfFlag) hipHostFree(ctx->h_lfFlag);
+    if (ctx->h_psOrder) hipHostFree(ctx->h_psOrder);
     if (ctx->evModel) hipEventDestroy(ctx->evModel);
     if (ctx->evSens) hipEventDestroy(ctx->evSens);
     if (ctx->evExtF) hipEventDestroy(ctx->evExtF);
@@ -1547,6 +1604,15 @@ static int persist_setup(hmcmt_ctx* ctx) {
         ctx->allocs.push_back(pc);
         ctx->d_psConst = reinterpret_cast<PsConst*>(pc);
         ctx->psConstValid = false;
+    }
+    if (k.S > 8 * ctx->persistSlots) {          // (more than one round of systems: persist_balance)
+        void* po = nullptr;
+        HIPCHK(hipMalloc(&po, 2 * sizeof(int) * (size_t)k.S));
+        ctx->allocs.push_back(po);
+        ctx->d_psOrder = reinterpret_cast<int*>(po);
+        HIPCHK(hipHostMalloc((void**)&ctx->h_psOrder, 2 * sizeof(int) * (size_t)k.S, hipHostMallocDefault));
+        if (const char* e = getenv("HMCMT_PERSIST_BALANCE")) ctx->psBalance = e[0] != '0';
+        if (const char* e = getenv("HMCMT_PERSIST_BALANCE_SMOOTH")) ctx->psSmooth = (float)std::min(0.95, std::max(0.0, atof(e)));
     }
     if (cs > 1) {
         void* y2 = nullptr;
@@ -2246,6 +2312,17 @@ int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out) {
 int hmcmt_persist_width(const hmcmt_ctx* ctx, int32_t* width) {
     if (!ctx || !width) return HMCMT_EINVAL;
     *width = ctx->persistCW ? ctx->persistWidthK : 0;
+    return 0;
+}
+
+// The order in which the persistent kernel's queues take the systems of a solve of `kind` (0 forward, 1 adjoint): order[q] = the
+// system at position q = queue + queues * round (queues = 8 x slots per XCD; persist_balance), the identity while no table is in
+// use; *rebalanced = how often this context took a new table.
+int hmcmt_persist_order(const hmcmt_ctx* ctx, int32_t kind, int32_t* order, int64_t* rebalanced) {
+    if (!ctx || kind < 0 || kind > 1) return HMCMT_EINVAL;
+    const std::vector<int>& t = ctx->psOrder[kind];
+    if (order) for (int q = 0; q < ctx->sv.S; ++q) order[q] = t.empty() ? q : t[q];
+    if (rebalanced) *rebalanced = ctx->psRebalanced;
     return 0;
 }
 

@@ -96,7 +96,7 @@ typedef const __attribute__((address_space(4))) PsConst* PsKP;
 template <class T>
 __device__ __forceinline__ const __attribute__((address_space(4))) T* ps_c4(const T* p) { return (const __attribute__((address_space(4))) T*)p; }   // arrays no kernel of the launch writes: scalar loads
 
-// What changes from launch to launch: the kernel's only argument (88 bytes).
+// What changes from launch to launch: the kernel's only argument (96 bytes).
 struct PsLaunch {
     const PsConst* kc;
     cplx *x, *r;               // the solve's iterate and residual [S][vstride]
@@ -111,6 +111,7 @@ struct PsLaunch {
     int gateGen;               //   converged and without a failure, -gateGen otherwise -- written by the last workgroup to leave
     int tickId;                // HMCMT_TICKS: TK_PERSIST_F / TK_PERSIST_A
     int dbgPlace;              // test hook: 1 + index of a group that is to FAIL its placement check (hmcmt_debug_flags)
+    const int* order;          // [S] (or null): position xcd + 8 (slot + slots round) of the queues -> system (a permutation; launch_persist)
 };
 
 __device__ __forceinline__ unsigned ps_xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 0xf; }
@@ -738,8 +739,11 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
         //  would hold the fp64 stencil coefficients of one polarisation instead of two -- leave the iteration at 42 us and cost the
         //  headline chain 3 %: the slow systems of a solve are neighbours in frequency and then share an L2 to the end, while
         //  here they are spread over the XCDs, each running alone at 39 us per iteration once its neighbours are done.)
-        const int s = xcd + 8 * (slot + slots * round);
-        if (s >= kb->S) break;
+        // (L.order: the queues balanced by the host from the last solve's iteration counts -- with more than one round a queue's time
+        //  is the SUM of its systems' iterations; the same systems solved in another order, nothing else changes)
+        const int q = xcd + 8 * (slot + slots * round);
+        if (q >= kb->S) break;
+        const int s = L.order ? ps_c4(L.order)[q] : q;
         if (!kb->active[s]) continue;
         const int mode = s >= kb->nFreq;
         const double w = ps_c4(kb->omega)[s];

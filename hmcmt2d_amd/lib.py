@@ -121,6 +121,7 @@ def load_library():
     lib.hmcmt_debug_hog.argtypes = [vp, C.c_int32, C.c_int32]
     lib.hmcmt_next_cu_share.argtypes = [C.c_int32, C.c_int32]
     lib.hmcmt_persist_width.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.hmcmt_persist_order.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), c_int64_p]
     lib.hmcmt_persist_envelope.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int64, c_int64_p]
     lib.hmcmt_guard.argtypes = [vp, c_double_p]
     lib.hmcmt_debug_fdm_fwd.argtypes = [vp, c_double_p, c_double_p]
@@ -129,7 +130,7 @@ def load_library():
                  "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async",
                  "hmcmt_wait", "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead",
                  "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond",
-                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_persist_envelope", "hmcmt_persist_width"):
+                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_persist_envelope", "hmcmt_persist_width", "hmcmt_persist_order"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -140,7 +141,7 @@ EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "h
                     "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async", "hmcmt_wait",
                     "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead", "hmcmt_dims",
                     "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
-                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_persist_envelope", "hmcmt_persist_width", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
+                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_persist_envelope", "hmcmt_persist_width", "hmcmt_persist_order", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
                     "hmcmt_comm_last_error"]
 
 
@@ -447,6 +448,14 @@ class HipContext:
         w = C.c_int32(0)
         self._check(self.lib.hmcmt_persist_width(self.h, C.byref(w)))
         return int(w.value)
+
+    def persist_order(self, kind=0):
+        """(order, rebalanced): the order in which the persistent kernel's queues take the systems of a forward (0) / adjoint (1)
+        solve -- position queue + queues * round -> system -- and how often the context has re-balanced it (hmcmt_persist_order)."""
+        order = (C.c_int32 * self.S)()
+        n = C.c_int64(0)
+        self._check(self.lib.hmcmt_persist_order(self.h, int(kind), order, C.byref(n)))
+        return np.array(list(order)), int(n.value)
 
     def debug_hog(self, nblocks, ms):
         """Test hook: nblocks workgroups holding a CU's LDS each for ms milliseconds on a stream of their own (returns once they are resident)."""

@@ -254,6 +254,11 @@ int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out12);  /* {threads/2 (0:
                                                                    column parts per row block (1; 2 on meshes wider than one tile: the stress size),
                                                                    timed-out waits (each one: the evaluation redone with the launch-per-phase loop),
                                                                    CU share index, CU share count (hmcmt_next_cu_share)} */
+int hmcmt_persist_order(const hmcmt_ctx* ctx, int32_t kind, int32_t* order, int64_t* rebalanced);   /* meshes whose systems take turns on the chip (more systems than 8 x
+                                                             slots per XCD: cfg5): the order in which the persistent kernel's queues take the systems of a solve of
+                                                             `kind` (0 forward, 1 adjoint) -- order[nsystems], position queue + queues * round -> system --, balanced from
+                                                             the previous solve's iteration counts (HMCMT_PERSIST_BALANCE=0: never; the same systems, the same results);
+                                                             *rebalanced = tables taken so far.  Either pointer may be NULL */
 int hmcmt_persist_width(const hmcmt_ctx* ctx, int32_t* width);   /* the compile-time row width (padded nodes: 112 / 208 / 416) of the width-specialised persistent
                                                                      kernel this context launches; 0: the generic kernel (HMCMT_PERSIST_WIDTHK=0 forces it) */
 int hmcmt_debug_hog(hmcmt_ctx* ctx, int32_t nblocks, int32_t ms);   /* test hook: nblocks workgroups that each hold a CU's LDS for ms milliseconds on a stream of their own (a foreign tenant on the device); returns once they are resident, without waiting for them to end */

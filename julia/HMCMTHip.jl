@@ -27,7 +27,7 @@ using Distributed              # myid
 using HMCMT.HMCFileIO, HMCMT.HMCStruct, HMCMT.HMCUtility
 
 export HipContext, hipContext, compDataGradient, hipForward, setPrior!, proposeLeapfrog, proposeLeapfrogDevice!,
-       hipWait, hipStats, hipGuard, hipPersistInfo, hipPersistEnvelope, hipNextCuShare, destroy!, commId, SampleComm, allgatherSamples
+       hipWait, hipStats, hipGuard, hipPersistInfo, hipPersistEnvelope, hipPersistOrder, hipNextCuShare, destroy!, commId, SampleComm, allgatherSamples
 
 const libhmcmt = get(ENV, "HMCMT_HIP_LIB", joinpath(@__DIR__, "..", "hmcmt2d_amd", "libhmcmt_hip.so"))
 
@@ -348,6 +348,23 @@ function hipPersistWidth(ctx::HipContext)
     rc = ccall((:hmcmt_persist_width, libhmcmt), Cint, (Ptr{Cvoid}, Ptr{Int32}), ctx.ptr, w)
     rc == 0 || error("hmcmt_persist_width failed")
     return Int(w[])
+end
+
+"""
+    hipPersistOrder(ctx, kind = 0) -> (order, rebalanced)
+
+The order (0-based system indices; position queue + queues * round) in which the persistent kernel's queues take the systems of a
+forward (`kind = 0`) or adjoint (`1`) solve, and how often the context has re-balanced it from the iteration counts of the
+previous solve (`hmcmt_persist_order`; meshes whose systems take turns on the chip).
+"""
+function hipPersistOrder(ctx::HipContext, kind::Integer = 0)
+    dims = zeros(Int32, 7)
+    ccall((:hmcmt_dims, libhmcmt), Cint, (Ptr{Cvoid}, Ptr{Int32}), ctx.ptr, dims) == 0 || error("hmcmt_dims failed")
+    order = zeros(Int32, dims[3])          # (systems = 2 x frequencies)
+    n = Ref{Int64}(0)
+    rc = ccall((:hmcmt_persist_order, libhmcmt), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int64}), ctx.ptr, Int32(kind), order, n)
+    rc == 0 || error("hmcmt_persist_order failed")
+    return order, Int(n[])
 end
 
 """

@@ -468,3 +468,42 @@ def test_width_specialised_kernels_equal_the_generic_ones_and_the_oracle(monkeyp
     assert np.abs(it1 - it0).max() <= 1, (it1, it0)
     po, mo, go = oracle_eval(mesh, data, inv, m)
     assert relmax(p1, po) < 1e-9 and abs(f1 - mo) / mo < 1e-9 and relmax(g1, go) < 1e-7
+
+
+def test_balanced_queues_solve_the_same_systems_to_the_same_bits(monkeypatch):
+    """Meshes whose systems take turns on the chip (more systems than 8 x slots per XCD; cfg5: 64 systems, one per XCD at a time):
+    a queue's time is the SUM of its systems' iterations, and the host re-orders the queues longest-first from the previous
+    solve's iteration counts (persist_balance; hmcmt_persist_order).  A 230-wide ragged mesh with 20 frequencies: 40 systems on
+    32 queues (two column parts, 4 row blocks: four systems per XCD at a time), eight queues hold two systems.  The same systems
+    are solved, only later or earlier: every result has the same bits as with HMCMT_PERSIST_BALANCE=0, the oracle's values at the
+    parity levels, and the table is a permutation that pairs the long systems with short ones."""
+    mesh, data, inv, m = ragged_problem(230, 50, 20, 6, 4, 3)
+    rng = np.random.default_rng(5)
+    m2 = m + 0.02 * rng.standard_normal(len(m))
+    res = {}
+    for bal in (1, 0):
+        monkeypatch.setenv("HMCMT_PERSIST_BALANCE", str(bal))
+        ctx = _ctx(monkeypatch, mesh, data, inv, True, 1)
+        info = ctx.persist_info()
+        assert info["column_parts"] == 2 and ctx.S == 40 and 8 * info["slots_per_xcd"] == 32, info
+        order0, n0 = ctx.persist_order(0)
+        assert n0 == 0 and np.array_equal(order0, np.arange(40))
+        ctx.grad(m)                                   # (index order: no counts yet)
+        it1 = ctx.iters()
+        out = ctx.grad(m2)                            # (the queues ordered from the first evaluation's counts)
+        res[bal] = out + (ctx.stats(), ctx.iters(), [ctx.persist_order(k) for k in (0, 1)], it1)
+        assert ctx.persist_info()["solves"] == 4
+        ctx.close()
+    (p1, f1, g1, s1, i1, ord1, itA), (p0, f0, g0, s0, i0, ord0, _) = res[1], res[0]
+    assert s1["status"] == 0 and s0["status"] == 0
+    assert np.array_equal(p1, p0) and f1 == f0 and np.array_equal(g1, g0) and np.array_equal(i1, i0)
+    for kind in (0, 1):
+        (tab, n), (tab0, nn0) = ord1[kind], ord0[kind]
+        assert nn0 == 0 and np.array_equal(tab0, np.arange(40))
+        assert n >= 1 and sorted(tab.tolist()) == list(range(40))
+        # the longest queue of the table under the counts it was made from: not longer than that of the index order
+        cost = itA[kind]
+        span = lambda t: max(cost[t[q::32]].sum() for q in range(32))
+        assert span(tab) <= span(np.arange(40)), (span(tab), span(np.arange(40)))
+    po, mo, go = oracle_eval(mesh, data, inv, m2)
+    assert relmax(p1, po) < 1e-8 and abs(f1 - mo) / mo < 1e-8 and relmax(g1, go) < 2e-6
