@@ -44,10 +44,11 @@ for name, cs, sw, n_eval in cases:
             print(f"   {name} evaluation {k}: {e}", flush=True)
     dt = time.time() - t0
     info, gd = ctx.persist_info(), ctx.guard()
+    tables = ctx.persist_order(0)[1]         # (meshes whose systems take turns: how often the queues were re-balanced)
     ctx.set_options(verify=True)
     ctx.grad(mm + 1e-3)
     st = ctx.stats()
     ctx.close()
-    print(f"{name}{' (column parts forced)' if cs else ''}{' sweeps ' + sw if sw else ''} [parts {info['column_parts']}, {info['workgroups_per_system']} workgroups/system, {info['slots_per_xcd']} slots/XCD]: {n} evaluations in {dt:.1f} s ({n / dt:.0f}/s), failed {bad}, persistent solves {info['solves']} of {2 * n + 2}, placement fallbacks {info['placement_fallbacks']} timeouts {info['timeouts']}, "
+    print(f"{name}{' (column parts forced)' if cs else ''}{' sweeps ' + sw if sw else ''} [parts {info['column_parts']}, {info['workgroups_per_system']} workgroups/system, {info['slots_per_xcd']} slots/XCD]: {n} evaluations in {dt:.1f} s ({n / dt:.0f}/s), failed {bad}, persistent solves {info['solves']} of {2 * n + 2}, placement fallbacks {info['placement_fallbacks']} timeouts {info['timeouts']}, queue tables taken {tables}, "
           f"guard checks {gd['checks']} trips {gd['trips']} worst {gd['worst_true_res']:.1e}; final verify: status {st['status']} true_res {st['true_res_max']:.1e} "
           f"iters {st['iters_fwd_max']}/{st['iters_adj_max']} fp64 restarts in the last evaluation {st['fallback_solves']}", flush=True)
