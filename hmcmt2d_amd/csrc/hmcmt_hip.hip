@@ -1231,21 +1231,14 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
 // every solve.  The iteration counts of consecutive solves of a chain differ by one or two, so the last solve's counts are the
 // next one's costs: longest-first into the least loaded queue that has room (every queue keeps its number of systems: the
 // kernel's loop bounds do not change).  A new table is taken when the present one is more than 1 % behind it.
-void persist_balance(hmcmt_ctx* ctx, int kind) {
-    const int S = ctx->sv.S, NQ = 8 * ctx->persistSlots;
-    if (!ctx->psBalance || !ctx->d_psOrder || NQ <= 0 || S <= NQ) return;
-    // (costs: the mean of the last solve's counts and the costs before it -- the counts of one system wander by one or two from
-    //  step to step, and a table made from one solve's noise is a worse guess for the next than one made from two)
-    std::vector<float>& cost = ctx->psCost[kind];
-    const int* last = ctx->itersLast.data() + (size_t)kind * S;
-    if (cost.empty()) cost.assign(last, last + S);
-    else for (int i = 0; i < S; ++i) cost[i] = ctx->psSmooth * cost[i] + (1.f - ctx->psSmooth) * (float)last[i];
-    auto makespan = [&](const int* tab) {
-        double worst = 0;
-        for (int j = 0; j < NQ; ++j) { double t = 0; for (int q = j; q < S; q += NQ) t += cost[tab ? tab[q] : q]; worst = std::max(worst, t); }
-        return worst;
-    };
-    std::vector<int> idx(S), tab(S), fill(NQ, 0);
+// (the packing alone -- pure arithmetic, also behind hmcmt_persist_pack: position q = queue + NQ * round of the table -> system)
+static double queues_makespan(const float* cost, int S, int NQ, const int* tab) {
+    double worst = 0;
+    for (int j = 0; j < NQ; ++j) { double t = 0; for (int q = j; q < S; q += NQ) t += cost[tab ? tab[q] : q]; worst = std::max(worst, t); }
+    return worst;
+}
+static void pack_queues(const float* cost, int S, int NQ, int* tab) {
+    std::vector<int> idx(S), fill(NQ, 0);
     std::vector<double> load(NQ, 0.0);
     for (int i = 0; i < S; ++i) idx[i] = i;
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost[a] > cost[b]; });
@@ -1258,8 +1251,22 @@ void persist_balance(hmcmt_ctx* ctx, int kind) {
         tab[best + NQ * fill[best]] = idx[i];
         ++fill[best]; load[best] += cost[idx[i]];
     }
+    // (with queues of unequal length the greedy table can lose to the index order on a handful of systems: then that one)
+    if (queues_makespan(cost, S, NQ, tab) > queues_makespan(cost, S, NQ, nullptr)) for (int i = 0; i < S; ++i) tab[i] = i;
+}
+void persist_balance(hmcmt_ctx* ctx, int kind) {
+    const int S = ctx->sv.S, NQ = 8 * ctx->persistSlots;
+    if (!ctx->psBalance || !ctx->d_psOrder || NQ <= 0 || S <= NQ) return;
+    // (costs: the mean of the last solve's counts and the costs before it -- the counts of one system wander by one or two from
+    //  step to step, and a table made from one solve's noise is a worse guess for the next than one made from several)
+    std::vector<float>& cost = ctx->psCost[kind];
+    const int* last = ctx->itersLast.data() + (size_t)kind * S;
+    if (cost.empty()) cost.assign(last, last + S);
+    else for (int i = 0; i < S; ++i) cost[i] = ctx->psSmooth * cost[i] + (1.f - ctx->psSmooth) * (float)last[i];
+    std::vector<int> tab(S);
+    pack_queues(cost.data(), S, NQ, tab.data());
     std::vector<int>& cur = ctx->psOrder[kind];
-    const double now = makespan(cur.empty() ? nullptr : cur.data()), lpt = makespan(tab.data());
+    const double now = queues_makespan(cost.data(), S, NQ, cur.empty() ? nullptr : cur.data()), lpt = queues_makespan(cost.data(), S, NQ, tab.data());
     if (now <= 1.01 * lpt) return;
     std::memcpy(ctx->h_psOrder + (size_t)kind * S, tab.data(), sizeof(int) * S);
     // (stream order: behind every launch that reads the old table, in front of the next solve)
@@ -2323,6 +2330,23 @@ int hmcmt_persist_order(const hmcmt_ctx* ctx, int32_t kind, int32_t* order, int6
     const std::vector<int>& t = ctx->psOrder[kind];
     if (order) for (int q = 0; q < ctx->sv.S; ++q) order[q] = t.empty() ? q : t[q];
     if (rebalanced) *rebalanced = ctx->psRebalanced;
+    return 0;
+}
+
+// The packing hmcmt_persist_order's tables are made with, on the caller's costs (no device, no context): nsystems systems of
+// cost[s] >= 0 onto `queues` queues that take turns -- position q = queue + queues * round, every queue keeps the number of
+// positions the index order gives it --, longest first into the least loaded queue that has room; order[q] = system.
+// *makespan (may be NULL) = the largest queue sum of the table; with order == NULL only that of the index order is computed.
+int hmcmt_persist_pack(const double* cost, int32_t nsystems, int32_t queues, int32_t* order, double* makespan) {
+    if (!cost || nsystems < 1 || queues < 1) return HMCMT_EINVAL;
+    std::vector<float> c(nsystems);
+    for (int i = 0; i < nsystems; ++i) { if (!(cost[i] >= 0)) return HMCMT_EINVAL; c[i] = (float)cost[i]; }
+    if (order) {
+        std::vector<int> tab(nsystems);
+        pack_queues(c.data(), nsystems, queues, tab.data());
+        for (int i = 0; i < nsystems; ++i) order[i] = tab[i];
+        if (makespan) *makespan = queues_makespan(c.data(), nsystems, queues, tab.data());
+    } else if (makespan) *makespan = queues_makespan(c.data(), nsystems, queues, nullptr);
     return 0;
 }
 

@@ -122,6 +122,7 @@ def load_library():
     lib.hmcmt_next_cu_share.argtypes = [C.c_int32, C.c_int32]
     lib.hmcmt_persist_width.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.hmcmt_persist_order.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), c_int64_p]
+    lib.hmcmt_persist_pack.argtypes = [c_double_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), c_double_p]
     lib.hmcmt_persist_envelope.argtypes = [C.c_int64, C.c_int64, C.c_int32, C.c_int64, c_int64_p]
     lib.hmcmt_guard.argtypes = [vp, c_double_p]
     lib.hmcmt_debug_fdm_fwd.argtypes = [vp, c_double_p, c_double_p]
@@ -130,7 +131,7 @@ def load_library():
                  "hmcmt_grad", "hmcmt_forward", "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async",
                  "hmcmt_wait", "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead",
                  "hmcmt_dims", "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond",
-                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_persist_envelope", "hmcmt_persist_width", "hmcmt_persist_order"):
+                 "hmcmt_debug_fdm_fwd", "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_persist_envelope", "hmcmt_persist_width", "hmcmt_persist_order", "hmcmt_persist_pack"):
         getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -141,7 +142,7 @@ EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "h
                     "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async", "hmcmt_wait",
                     "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead", "hmcmt_dims",
                     "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
-                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_persist_envelope", "hmcmt_persist_width", "hmcmt_persist_order", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
+                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_persist_envelope", "hmcmt_persist_width", "hmcmt_persist_order", "hmcmt_persist_pack", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
                     "hmcmt_comm_last_error"]
 
 
@@ -201,6 +202,22 @@ def persist_envelope(ny, nz, cus_per_xcd=32, nsystems=32):
     if rc != 0:
         raise HmcmtError(rc, "hmcmt_persist_envelope: ny >= 2, nz >= 3, cus_per_xcd >= 1, nsystems >= 1")
     return dict(zip(("column_parts", "threads_half", "workgroups_per_system", "slab_modes", "lds_bytes", "slots_per_xcd"), (int(x) for x in out)))
+
+
+def persist_pack(cost, queues):
+    """(order, makespan, makespan of the index order): the packing behind HipContext.persist_order on the caller's costs
+    (hmcmt_persist_pack: pure arithmetic, no GPU needed) -- systems onto `queues` queues that take turns, position
+    queue + queues * round -> system."""
+    lib = load_library()
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
+    order = (C.c_int32 * len(cost))()
+    m1, m0 = C.c_double(0.0), C.c_double(0.0)
+    rc = lib.hmcmt_persist_pack(_dp(cost), len(cost), int(queues), order, C.byref(m1))
+    if rc == 0:
+        rc = lib.hmcmt_persist_pack(_dp(cost), len(cost), int(queues), None, C.byref(m0))
+    if rc != 0:
+        raise HmcmtError(rc, "hmcmt_persist_pack: costs >= 0, at least one system and one queue")
+    return np.array(list(order)), float(m1.value), float(m0.value)
 
 
 class HipContext:

@@ -259,6 +259,10 @@ int hmcmt_persist_order(const hmcmt_ctx* ctx, int32_t kind, int32_t* order, int6
                                                              `kind` (0 forward, 1 adjoint) -- order[nsystems], position queue + queues * round -> system --, balanced from
                                                              the previous solve's iteration counts (HMCMT_PERSIST_BALANCE=0: never; the same systems, the same results);
                                                              *rebalanced = tables taken so far.  Either pointer may be NULL */
+int hmcmt_persist_pack(const double* cost, int32_t nsystems, int32_t queues, int32_t* order, double* makespan);   /* no device needed: the packing behind
+                                                             hmcmt_persist_order on the caller's costs -- nsystems systems onto `queues` queues that take turns (position
+                                                             queue + queues * round), longest first into the least loaded queue that has room; order[nsystems] = system at
+                                                             each position, *makespan = the largest queue sum (order NULL: that of the index order) */
 int hmcmt_persist_width(const hmcmt_ctx* ctx, int32_t* width);   /* the compile-time row width (padded nodes: 112 / 208 / 416) of the width-specialised persistent
                                                                      kernel this context launches; 0: the generic kernel (HMCMT_PERSIST_WIDTHK=0 forces it) */
 int hmcmt_debug_hog(hmcmt_ctx* ctx, int32_t nblocks, int32_t ms);   /* test hook: nblocks workgroups that each hold a CU's LDS for ms milliseconds on a stream of their own (a foreign tenant on the device); returns once they are resident, without waiting for them to end */

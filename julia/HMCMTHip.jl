@@ -27,7 +27,7 @@ using Distributed              # myid
 using HMCMT.HMCFileIO, HMCMT.HMCStruct, HMCMT.HMCUtility
 
 export HipContext, hipContext, compDataGradient, hipForward, setPrior!, proposeLeapfrog, proposeLeapfrogDevice!,
-       hipWait, hipStats, hipGuard, hipPersistInfo, hipPersistEnvelope, hipPersistOrder, hipNextCuShare, destroy!, commId, SampleComm, allgatherSamples
+       hipWait, hipStats, hipGuard, hipPersistInfo, hipPersistEnvelope, hipPersistOrder, hipPersistPack, hipNextCuShare, destroy!, commId, SampleComm, allgatherSamples
 
 const libhmcmt = get(ENV, "HMCMT_HIP_LIB", joinpath(@__DIR__, "..", "hmcmt2d_amd", "libhmcmt_hip.so"))
 
@@ -365,6 +365,22 @@ function hipPersistOrder(ctx::HipContext, kind::Integer = 0)
     rc = ccall((:hmcmt_persist_order, libhmcmt), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int64}), ctx.ptr, Int32(kind), order, n)
     rc == 0 || error("hmcmt_persist_order failed")
     return order, Int(n[])
+end
+
+"""
+    hipPersistPack(cost, queues) -> (order, makespan)
+
+The packing behind `hipPersistOrder` on the caller's costs (`hmcmt_persist_pack`; no device needed): systems onto `queues`
+queues that take turns, longest first into the least loaded queue that has room; `order` holds 0-based system indices by
+position queue + queues * round, `makespan` the largest queue sum.
+"""
+function hipPersistPack(cost::AbstractVector{<:Real}, queues::Integer)
+    c = Vector{Float64}(cost)
+    order = zeros(Int32, length(c))
+    m = Ref{Float64}(0.0)
+    rc = ccall((:hmcmt_persist_pack, libhmcmt), Cint, (Ptr{Float64}, Int32, Int32, Ptr{Int32}, Ptr{Float64}), c, Int32(length(c)), Int32(queues), order, m)
+    rc == 0 || error("hmcmt_persist_pack failed")
+    return order, m[]
 end
 
 """
