@@ -235,25 +235,37 @@ def two_chains_leg(torch, HipContext, mesh, data, inv, local, dev, m_true, mref,
     ctxb = HipContext(mesh, data, inv, device_id=local, cu_share=(1, 2))
     ca = Chain(ctxa, torch, dev, m_true, mref, inv.Wm, seed=7)
     cb_ = Chain(ctxb, torch, dev, m_true, mref, inv.Wm, seed=8)
-    for c in (ca, cb_):
-        c.run(2 * LTRAJ)
+    # Each thread creates its stream, runs two warm trajectories, meets the other at a barrier and THEN times a FIXED number of
+    # steps (Ke = 48 whatever --steps is; VERDICT r5: timed from thread start with the stream creation and the first trajectory's
+    # transients inside, 20 steps per chain, the leg read 0.62x of one chain where a 48-step run reads 1.15x).  The timed region of
+    # a chain is its own: per-chain ms/step; the aggregate is both chains' steps over the span from the common start to the last end.
+    gate = threading.Barrier(2)
+    span = {}
 
-    def run_on_own_stream(c):
+    def run_on_own_stream(c, key):
         # CU-masked streams are BLOCKING streams (hipExtStreamCreateWithCUMask takes no flags): torch work on the legacy default
         # stream would wait for the other chain's trajectory in flight, and make it wait -- each chain's torch ops (momentum draw,
         # kinetic energies) go to a stream of its own, as a multi-chain host would arrange it
-        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            c.run(2 * LTRAJ)
+            st.synchronize()
+            gate.wait()
+            t0 = time.perf_counter()
             c.run(Ke)
-    th = [threading.Thread(target=run_on_own_stream, args=(c,)) for c in (ca, cb_)]
+            st.synchronize()
+            span[key] = (t0, time.perf_counter())
+    th = [threading.Thread(target=run_on_own_stream, args=(c, i)) for i, c in enumerate((ca, cb_))]
     torch.cuda.synchronize()
-    t5 = time.perf_counter()
     for t in th:
         t.start()
     for t in th:
         t.join()
     torch.cuda.synchronize()
-    t5 = time.perf_counter() - t5
+    t5 = max(e for _, e in span.values()) - min(b for b, _ in span.values())
     res = {"steps_per_s_aggregate": 2 * Ke / t5, "steps_per_chain": Ke,
+           "ms_per_step_by_chain": [1e3 * (e - b) / Ke for b, e in (span[0], span[1])],
+           "timed": "inside each chain's thread, behind its stream's creation, two warm trajectories and a barrier with the other chain",
            "persistent_solves": [ctxa.persist_info()["solves"], ctxb.persist_info()["solves"]],
            "slots_per_xcd": [ctxa.persist_info()["slots_per_xcd"], ctxb.persist_info()["slots_per_xcd"]],
            "state": "two independent chains near the true model on ONE GPU: two contexts, two host threads, "
@@ -349,7 +361,10 @@ def main():
 
     # ---- headline: real trajectories from the rough state -------------------------------------------------------
     chain = Chain(ctx, torch, dev, S.rough_state(nAC, seed=1 + rank), mref, inv.Wm, seed=20250114 + rank)
-    chain.run(W)
+    # warm-up: the W steps asked for, but never less than two WHOLE trajectories (the first one starts from a context without history --
+    # cold solves, the sweep count not yet chosen --, and a 5-step warm-up leaves the timed region starting in mid-trajectory)
+    Wrun = max(W, 2 * LTRAJ)
+    chain.run(Wrun)
     chain.iters.clear(); acc0, rej0 = chain.accepted, chain.rejected
     prof_every, prof_overhead_us = 0, 0.0
     if not os.environ.get("HMCMT_BENCH_NOPROF"):
@@ -642,7 +657,20 @@ def main():
         roofs, iteration, step_bytes = build_roofline(
             prof, cnt, f"every launch of this kernel in every {prof_every}. evaluation of the timed region (HIP events on the "
                        "library's stream), launches that found all systems converged included", prof_every)
+        # Everything under `roofline` is measured in THIS run (HIP events, the device's iteration counters).  What comes from the
+        # committed rocprofv3 passes of this command (profiles/pmc_traffic.json: PMC bytes per launch, --stats average) describes
+        # another run's launch population: it goes under `roofline_committed_profile`, labelled; `roofline.traffic` is null here.
+        committed = {"source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes and --kernel-trace --stats of this command, "
+                               "collected by scripts/gpu_profile_all.sh in the round that file was committed; another run's launch population)",
+                     "kernels": []}
+        for r in roofs:
+            committed["kernels"].append({"kernel": r["kernel"][:60], "traffic_bytes_per_launch": r.pop("traffic", None),
+                                         "frac_traffic_against_this_runs_launch_time": r.pop("frac_traffic", None),
+                                         "rocprofv3_avg_launch_us": r.pop("rocprofv3_avg_launch_us", None)})
+            r["traffic"] = None
+            r["traffic_source"] = "not collected in this run (PMC counters need rocprofv3): see roofline_committed_profile"
         ms_step = 1e3 * elapsed / K
+        traj_ms = head.get("ms_per_step_by_trajectory") or []
         step = {"bytes_per_step": step_bytes, "ms_per_step": ms_step, "achieved": step_bytes / (ms_step * 1e-3) / 1e9,
                 "unit": "GB/s", "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "algorithmic bytes of the iteration kernels per leapfrog step (sampled evaluations) / wall time per step / 8 TB/s"}
@@ -662,7 +690,10 @@ def main():
                        "smoother_sweeps_last_evaluation": st["smoother_sweeps"],
                        "parallelism": f"chains x{world}" if world > 1 else "1 chain"},
             "chain": head,
+            "median_ms_per_step_by_trajectory": float(np.median(traj_ms)) if traj_ms else None,
+            "warmup_steps_run": Wrun,
             "roofline": roofs[0], "roofline_other": roofs[1:], "roofline_iteration": iteration, "roofline_step": step,
+            "roofline_committed_profile": committed,
             "check": check,
         }
         if world == 1 and not args.no_extras:
@@ -676,7 +707,7 @@ def main():
             out["cpu_baseline"] = cpu
         if world == 1 and not args.no_extras:
             ctx.close()                          # (a context on the whole device overlaps the two chains' shares)
-            out["two_chains_per_gpu"] = two_chains_leg(torch, HipContext, mesh, data, inv, local, dev, m_true, mref, min(K, 48))
+            out["two_chains_per_gpu"] = two_chains_leg(torch, HipContext, mesh, data, inv, local, dev, m_true, mref, 48)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if dist is not None:

@@ -55,6 +55,7 @@ constexpr int VBLOCK = HMCMT_VBLOCK;        // threads of the vector kernels (bu
 #include "kernels_fdm.h"
 #include "kernels_fused.h"
 #include "kernels_persist.h"
+#include "kernels_persist4.h"
 #include "kernels_path.h"
 
 }  // namespace
@@ -178,6 +179,9 @@ struct hmcmt_ctx {
     unsigned shareMask = 0xF;             // ... as quarters
     int persistWidthK = 0;                // 112 / 208 / 416: the mesh's padded row width has a width-specialised persistent kernel (launch_persist)
     int persistCS = 1, persistGZ = 0;     // column parts of a row block (2: wide meshes, kernels_persist.h), row blocks per system
+    int persistStrips = 2;                // 4: the four-strip kernel (kernels_persist4.h: 4 x persistCW threads, four waves per SIMD); HMCMT_PERSIST_STRIPS=2 keeps k_cocg_persist
+    int persistRC = 8;                    // ... rows per chunk of its slab sweeps
+    size_t persistLds4 = 0;               // ... its LDS bytes
     // the order in which the queues of the persistent kernel take the systems (PsLaunch::order; persist_balance): per solve kind
     int* d_psOrder = nullptr;             // [2][S]
     int* h_psOrder = nullptr;             // pinned staging of the same
@@ -191,6 +195,7 @@ struct hmcmt_ctx {
     bool psConstValid = false;
     float2* d_yhat2 = nullptr;            // column parts: the second part's partial product of the forward transform
     unsigned persistSpin = PS_SPIN_LIMIT; // HMCMT_PS_SPIN: polls before a wait of the kernel gives up (tests shorten it)
+    int persistWhyOff = 0;                // why persistOn is false: 1 = a placement fallback (for good), 2 = a timed-out wait (backoff)
     long persistBackoff = 0;              // after a timed-out wait: solves on the launch-per-phase loop before the kernel is tried again (doubles per timeout)
     bool persistTimedOut = false;         // a wait of the last persistent launch timed out: evaluate() redoes the evaluation with the launch-per-phase loop
     int dbgPlace = 0;                     // test hook (hmcmt_debug_flags bit 2): the next persistent launch's first group fails its placement check
@@ -638,6 +643,21 @@ int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout, in
     a.order = ctx->psOrder[kind == 1].empty() ? nullptr : ctx->d_psOrder + (kind == 1 ? k.S : 0);
     if (ctx->d_pstamps) HIPCHK(hipMemsetAsync(ctx->d_pstamps, 0, sizeof(long long) * 16 * 256, ctx->stream));
     const dim3 grid(groups * ctx->persistG);
+    if (ctx->persistStrips == 4) {
+        // the four-strip kernel (kernels_persist4.h): 4 x CW threads, one column part, 32-mode slabs
+        const size_t lds4 = ctx->persistLds4;
+        const int cw = ctx->persistCW, wk4 = ctx->persistWidthK;
+        const bool st = ctx->d_pstamps != nullptr;
+#define PS4L(CW, NYK, RCC, STT) do { if (sweeps == 2) hipLaunchKernelGGL((k_cocg_persist4<CW, 2, 32, NYK, RCC, STT>), grid, dim3(4 * CW), lds4, ctx->stream, a); \
+                                     else hipLaunchKernelGGL((k_cocg_persist4<CW, 1, 32, NYK, RCC, STT>), grid, dim3(4 * CW), lds4, ctx->stream, a); } while (0)
+        if (cw == 256 && wk4 == 208 && ctx->persistRC == 4) { if (st) PS4L(256, 208, 4, true); else PS4L(256, 208, 4, false); }
+        else if (cw == 256) PS4L(256, 0, 4, false);
+        else if (cw == 128) PS4L(128, 0, 4, false);
+        else PS4L(64, 0, 4, false);
+#undef PS4L
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     const size_t lds = ctx->persistLds;
 #define PSL(CW, SWP) do { if (ctx->persistCS > 1) hipLaunchKernelGGL((k_cocg_persist<CW, SWP, 16, 2>), grid, dim3(2 * CW), lds, ctx->stream, a); \
                          else if (ctx->persistMW == 16) hipLaunchKernelGGL((k_cocg_persist<CW, SWP, 16, 1>), grid, dim3(2 * CW), lds, ctx->stream, a); \
@@ -747,13 +767,16 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
     cplx* const r_entry = k.r;
     bool viaPersist = false, stalledP = false, specIssued = false;
     ctx->specValid = false;
-    if (!ctx->persistOn && ctx->persistBackoff > 0 && --ctx->persistBackoff == 0) ctx->persistOn = true;      // (after a timed-out wait: another try)
+    // (after a timed-out wait: another try when the backoff has run out -- a context that left the kernel because of its PLACEMENT
+    //  stays off for good: persistWhyOff)
+    if (!ctx->persistOn && ctx->persistWhyOff == 2 && ctx->persistBackoff > 0 && --ctx->persistBackoff == 0) { ctx->persistOn = true; ctx->persistWhyOff = 0; }
     if (fused && persist_ok(ctx)) {
         // ONE launch solves every system (kernels_persist.h).  The kernel tells the host through mapped words: the progress
         // word when its last workgroup leaves, the active-system counter, the stagnation / failure / placement flags.
         ctx->preDone = false;                          // (it does its own first pre-smoothing pass)
         *(volatile int*)ctx->h_stall = 0;
         *(volatile int*)(ctx->h_stall + 2) = 0;
+        *(volatile int*)(ctx->h_stall + 3) = 0;
         *(volatile int*)ctx->h_prog = 0;
         { ProfScope ps(ctx, 2); int prc = launch_persist(ctx, k.sweeps, 0, nullptr, kind); if (prc) return prc; }
         ++ctx->persistSolves;
@@ -761,19 +784,24 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
         if (kind == 0) launch_adjoint_side(ctx);        // (the host is free while the device solves)
         if (spec && ctx->specOn) { (*spec)(ctx->d_gate + kind, ctx->gateGen); specIssued = true; }
         { int prc = spin_progress(ctx, PS_DONE); if (prc) return prc; }
-        if (*(volatile int*)(ctx->h_stall + 1) == HMCMT_EHIP) {
-            // a wait inside the kernel timed out (its grid was not co-resident: a foreign kernel holds CUs, a lock directory that
+        if (*(volatile int*)(ctx->h_stall + 3)) {
+            // a wait inside the kernel timed out (a word of its own: a healthy group's system that ends with a status afterwards
+            // overwrites the shared status word, and the redo below would be skipped) (its grid was not co-resident: a foreign kernel holds CUs, a lock directory that
             // does not coordinate): the systems are in no defined state.  This context leaves the persistent kernel -- for 256 solves
             // after the first timeout, twice as long after every further one --, and evaluate() runs the evaluation again, cold,
             // with the launch-per-phase loop, which works under any sharing
             ctx->persistTimedOut = true;
-            ctx->persistOn = false; ++ctx->persistTimeouts;
+            ctx->persistOn = false; ctx->persistWhyOff = 2; ++ctx->persistTimeouts;
             ctx->persistBackoff = 256l << std::min<long long>(ctx->persistTimeouts - 1, 6);     // (the tenant may leave: 256, 512, .. 16 384 solves, then another try)
         }
         if (*(volatile int*)(ctx->h_stall + 2)) {
             // the group's workgroups were not on one XCD (or the kernel could not be placed): nothing was touched by those
             // groups -- this context goes back to the launch-per-phase loop for good
-            ctx->persistOn = false; ++ctx->persistFallbacks;
+            ctx->persistOn = false; ctx->persistWhyOff = 1; ctx->persistBackoff = 0; ++ctx->persistFallbacks;
+            if (ctx->persistFallbacks == 1)
+                fprintf(stderr, "libhmcmt_hip: the workgroups of a system of the persistent solve kernel were not dispatched to one XCD (a partitioned device, "
+                                "another dispatch order?); this context runs the launch-per-phase loop from here on -- same results, several times slower "
+                                "(hmcmt_persist_info: placement_fallbacks, why_off)\n");
         } else {
             viaPersist = true;
             if (*(volatile int*)ctx->h_nactive == 0) done = true;
@@ -1629,6 +1657,25 @@ static int persist_setup(hmcmt_ctx* ctx) {
         ctx->allocs.push_back(y2);
         ctx->d_yhat2 = reinterpret_cast<float2*>(y2);
     }
+    // the four-strip kernel where it applies: one column part, 32-mode slabs, a column tile of the transforms per wave, the slab
+    // sweeps' chunks of four rows covering half the rows; HMCMT_PERSIST_STRIPS=2 keeps the two-half kernel (A/B)
+    ctx->persistStrips = 2;
+    {
+        const char* e = getenv("HMCMT_PERSIST_STRIPS");
+        const int want = e ? atoi(e) : 2;      // (round 6: the four-strip kernel is opt-in -- it measured 530 against 600 steps/s at the headline size)
+        const size_t lds4 = ps4_lds_bytes(k.NYP, k.NZP, k.nz, 32, 4 * cw);
+        if (want == 4 && cs == 1 && mw == 32 && 4 * cw <= 1024 && k.NYP / 16 <= 4 * cw / 64 && ps4_slab_rc(k.nz, 32, 4 * cw) == 4 && lds4 <= (size_t)160 * 1024) {
+            const void* f4[] = {reinterpret_cast<const void*>(k_cocg_persist4<256, 1, 32, 208, 4, false>), reinterpret_cast<const void*>(k_cocg_persist4<256, 2, 32, 208, 4, false>),
+                                reinterpret_cast<const void*>(k_cocg_persist4<256, 1, 32, 208, 4, true>), reinterpret_cast<const void*>(k_cocg_persist4<256, 2, 32, 208, 4, true>),
+                                reinterpret_cast<const void*>(k_cocg_persist4<256, 1, 32, 0, 4, false>), reinterpret_cast<const void*>(k_cocg_persist4<256, 2, 32, 0, 4, false>),
+                                reinterpret_cast<const void*>(k_cocg_persist4<128, 1, 32, 0, 4, false>), reinterpret_cast<const void*>(k_cocg_persist4<128, 2, 32, 0, 4, false>),
+                                reinterpret_cast<const void*>(k_cocg_persist4<64, 1, 32, 0, 4, false>), reinterpret_cast<const void*>(k_cocg_persist4<64, 2, 32, 0, 4, false>)};
+            bool ok4 = true;
+            for (const void* f : f4)
+                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); ok4 = false; }
+            if (ok4) { ctx->persistStrips = 4; ctx->persistRC = 4; ctx->persistLds4 = lds4; }
+        }
+    }
     if (const char* es = getenv("HMCMT_STAMPS")) if (!strcmp(es, "persist")) {
         HIPCHK(hipMalloc((void**)&ctx->d_pstamps, sizeof(long long) * 16 * 256));
         HIPCHK(hipMemset(ctx->d_pstamps, 0, sizeof(long long) * 16 * 256));
@@ -2242,7 +2289,8 @@ int hmcmt_debug_transform(hmcmt_ctx* ctx, int32_t which, const double* A, double
 
 int hmcmt_debug_flags(hmcmt_ctx* ctx, int32_t flags) {
     if (!ctx || (flags & ~7)) return HMCMT_EINVAL;
-    if (flags & 4) ctx->dbgPlace = 1;                     // (one-shot: the next persistent launch's first system group fails its placement check)
+    if (flags & 8) ctx->dbgPlace = -1;                    // (one-shot: EVERY group of the next persistent launch fails its placement check -- the all-fallback regime of a partitioned device)
+    else if (flags & 4) ctx->dbgPlace = 1;                     // (one-shot: the next persistent launch's first system group fails its placement check)
     flags &= 3;
     ctx->dbgFlags = flags;
     ctx->memo[0].valid = ctx->memo[1].valid = false;      // (stored results belong to the flags they were computed under)
@@ -2302,15 +2350,20 @@ int hmcmt_guard(const hmcmt_ctx* ctx, double* out) {
 // the persistent solve kernel and this context: out = {threads per workgroup / 2 (0: the problem does not fit the kernel),
 // workgroups per system, system slots per XCD, enabled (HMCMT_PERSIST, no placement failure so far), solves it has run,
 // solves handed back to the launch-per-phase loop because the workgroups of a system were not on one XCD}
-int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out) {
-    if (!ctx || !out) return HMCMT_EINVAL;
-    out[0] = ctx->persistCW; out[1] = ctx->persistG; out[2] = ctx->persistSlots; out[3] = ctx->persistOn ? 1 : 0;
-    out[4] = ctx->persistSolves; out[5] = ctx->persistFallbacks;
-    out[6] = persist_ok(ctx) ? 1 : 0;              // would the next default-path solve use it (alone on the device, device lock held)
-    out[7] = ctx->persistCW ? ctx->persistMW : 0;  // modes per slab
-    out[8] = ctx->persistCW ? ctx->persistCS : 0;  // column parts per row block (2: wide meshes)
-    out[9] = ctx->persistTimeouts;                 // timed-out waits (the evaluation was redone with the launch-per-phase loop)
-    out[10] = ctx->shareIdx; out[11] = ctx->shareCnt;   // this context's share of every XCD's CUs (hmcmt_next_cu_share)
+int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out, int32_t nout) {
+    if (!ctx || !out || nout < 0) return HMCMT_EINVAL;
+    // (the caller says how many slots it has: fields are only ever appended, a caller built against an older header gets the ones it knows)
+    const int64_t v[HMCMT_PERSIST_INFO_FIELDS] = {
+        ctx->persistCW, ctx->persistG, ctx->persistSlots, ctx->persistOn ? 1 : 0,
+        ctx->persistSolves, ctx->persistFallbacks,
+        persist_ok(ctx) ? 1 : 0,              // would the next default-path solve use it (alone on the device, device lock held)
+        ctx->persistCW ? ctx->persistMW : 0,  // modes per slab
+        ctx->persistCW ? ctx->persistCS : 0,  // column parts per row block (2: wide meshes)
+        ctx->persistTimeouts,                 // timed-out waits (the evaluation was redone with the launch-per-phase loop)
+        ctx->shareIdx, ctx->shareCnt,         // this context's share of every XCD's CUs (hmcmt_next_cu_share)
+        ctx->persistCW ? ctx->persistStrips : 0,   // strips of tile rows per column: 2 (k_cocg_persist) or 4 (k_cocg_persist4: threads = strips x threads_half)
+        ctx->persistWhyOff};                  // why the kernel is off: 0 it is not / HMCMT_PERSIST=0, 1 placement (for good), 2 a timed-out wait (tried again after the backoff)
+    for (int i = 0; i < nout && i < HMCMT_PERSIST_INFO_FIELDS; ++i) out[i] = v[i];
     return 0;
 }
 
@@ -2426,7 +2479,7 @@ int hmcmt_debug_persist_precond(hmcmt_ctx* ctx, int32_t sweeps, const double* r,
     if ((rc = launch_persist(ctx, sweeps, 1, ctx->sv.z32))) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (*(volatile int*)(ctx->h_stall + 2)) { ctx->err = "persistent kernel: the workgroups of a system were not placed on one XCD"; return HMCMT_EHIP; }
-    if (*(volatile int*)(ctx->h_stall + 1)) { ctx->err = "persistent kernel: a wait timed out"; return HMCMT_EHIP; }
+    if (*(volatile int*)(ctx->h_stall + 1) || *(volatile int*)(ctx->h_stall + 3)) { ctx->err = "persistent kernel: a wait timed out"; return HMCMT_EHIP; }
     std::vector<float2> h(n);
     HIPCHK(hipMemcpy(h.data(), ctx->sv.z32, n * sizeof(float2), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n; ++i) { z[2 * i] = h[i].x; z[2 * i + 1] = h[i].y; }

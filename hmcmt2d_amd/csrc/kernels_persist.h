@@ -328,7 +328,7 @@ __host__ __device__ inline size_t ps_slab_bytes(int nz, int mw, int nt) {
     const int n = nz - 1, mid = (n + 1) / 2;
     return (size_t)32 * nt + (size_t)2 * mw * 8 + (size_t)2 * (mid + 1 + PSL_PAD) * mw * 8;
 }
-__host__ __device__ inline bool ps_slab_fits(int nz, int mw, int nt) { return nt / (2 * mw) >= 1 && (nz - 1 + 1) / 2 <= PS_RCMAX * (nt / (2 * mw)); }
+__host__ __device__ inline bool ps_slab_fits(int nz, int mw, int nt, int rc = PS_RCMAX) { return nt / (2 * mw) >= 1 && (nz - 1 + 1) / 2 <= rc * (nt / (2 * mw)); }
 
 // per-row scalars of a system's slab sweeps (o of the row's coefficient in the elimination / in the substitution sweep): constant
 // over the solve, so they are formed once per system and live behind the coefficient planes -- in the slab arena they were formed
@@ -373,9 +373,9 @@ template <int NT, int MW> struct PsChunks { static constexpr int P = NT / (2 * M
 __device__ __forceinline__ c32 ps_cfma(c32 a, c32 b, c32 x) {      // a + b x
     return c32{__builtin_fmaf(-b.im, x.im, __builtin_fmaf(b.re, x.re, a.re)), __builtin_fmaf(b.im, x.re, __builtin_fmaf(b.re, x.im, a.im))};
 }
-template <int NT, int MW, int CS, int NYK = 0>
+template <int NT, int MW, int CS, int NYK = 0, int RC = PS_RCMAX>
 __device__ __forceinline__ void ps_slab_solve_reg(PsKP kb, char* smem, const float* f1, const float* f2, int s, int slab, int tidx, long long* stp = nullptr) {
-    constexpr int P = PsChunks<NT, MW>::P, NL = 2 * MW * P, RC = PS_RCMAX;      // (chunks of RC rows exactly: rows behind a half's last one are identity rows)
+    constexpr int P = PsChunks<NT, MW>::P, NL = 2 * MW * P;      // (chunks of RC rows exactly: rows behind a half's last one are identity rows)
     const int NYP = NYK ? NYK : kb->NYP, NZP = kb->NZP, n = kb->nz - 1, nyi = kb->ny - 1;
     const int mid = twist_mid(n, 1), RL = mid + 1 + PSL_PAD;
     c32* recF = reinterpret_cast<c32*>(smem);             // [2][P][MW] x {last local value, last product} of the elimination sweep
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
     __syncthreads();
     // ---- placement check: the G workgroups of the group must share an XCD (their hand-offs go through ITS L2)
     if (tid == 0) {
-        const unsigned forced = L.dbgPlace == 1 + xcd * slots + slot ? 1u << 31 : 0u;      // (test hook: this group fails)
+        const unsigned forced = (L.dbgPlace == 1 + xcd * slots + slot || L.dbgPlace < 0) ? 1u << 31 : 0u;      // (test hooks: this group / every group fails)
         __hip_atomic_fetch_or(sy + 2, (1u << ps_xcc_id()) | forced, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(sy + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1451,7 +1451,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
     __syncthreads();
     tick_end(kb->ticks, L.tickId);
     if (tid == 0) {
-        if (sflag[0] == 2) *kb->failHost = HMCMT_EHIP;       // a wait timed out: the solve is void (the host redoes it with the launch-per-phase loop)
+        if (sflag[0] == 2) { *kb->failHost = HMCMT_EHIP; kb->placeHost[1] = 1; }       // a wait timed out: the solve is void (the host redoes it with the launch-per-phase loop; a word of its own, stallHost[3]: the status word may be overwritten by a healthy group's system)
         __threadfence_system();
         const unsigned nLeft = __hip_atomic_fetch_add(kb->exitCnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sflag[1] = nLeft == gridDim.x - 1 ? 1 : 0;

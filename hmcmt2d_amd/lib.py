@@ -17,7 +17,7 @@ SO_PATH = os.environ.get("HMCMT_LIB_PATH") or os.path.join(HERE, "libhmcmt_hip.s
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = [os.path.join(CSRC, "hmcmt_hip.hip"), os.path.join(CSRC, "mumps_shim.hip"), os.path.join(CSRC, "comm.hip")]
 HEADERS = [os.path.join(CSRC, h) for h in ("hmcmt_math.h", "hmcmt_items.h", "hmcmt_host.h", "kernels_cocg.h", "kernels_fdm.h",
-                                            "kernels_fused.h", "kernels_persist.h", "kernels_path.h")] + \
+                                            "kernels_fused.h", "kernels_persist.h", "kernels_persist4.h", "kernels_path.h")] + \
           [os.path.join(HERE, "..", "include", "hmcmt.h"), os.path.join(HERE, "..", "include", "hmcmt_mumps.h")]
 
 HMCMT_NCAT = 8
@@ -117,7 +117,7 @@ def load_library():
     lib.hmcmt_debug_spmv.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_precond.argtypes = [vp, c_double_p, c_double_p]
     lib.hmcmt_debug_persist_precond.argtypes = [vp, C.c_int32, c_double_p, c_double_p]
-    lib.hmcmt_persist_info.argtypes = [vp, c_int64_p]
+    lib.hmcmt_persist_info.argtypes = [vp, c_int64_p, C.c_int32]
     lib.hmcmt_debug_hog.argtypes = [vp, C.c_int32, C.c_int32]
     lib.hmcmt_next_cu_share.argtypes = [C.c_int32, C.c_int32]
     lib.hmcmt_persist_width.argtypes = [vp, C.POINTER(C.c_int32)]
@@ -455,10 +455,10 @@ class HipContext:
 
     def persist_info(self):
         """The persistent solve kernel and this context (kernels_persist.h): shape, whether it is enabled, how many solves it ran."""
-        out = (C.c_int64 * 12)()
-        self._check(self.lib.hmcmt_persist_info(self.h, out))
+        out = (C.c_int64 * 14)()
+        self._check(self.lib.hmcmt_persist_info(self.h, out, 14))
         return dict(zip(("threads_half", "workgroups_per_system", "slots_per_xcd", "enabled", "solves", "placement_fallbacks", "usable_now", "slab_modes",
-                         "column_parts", "timeouts", "cu_share_index", "cu_share_count"), (int(x) for x in out)))
+                         "column_parts", "timeouts", "cu_share_index", "cu_share_count", "strips", "why_off"), (int(x) for x in out)))
 
     def persist_width(self):
         """Row width (padded nodes) of the width-specialised persistent kernel this context launches; 0: the generic kernel."""

@@ -248,12 +248,17 @@ int hmcmt_next_cu_share(int32_t index, int32_t count);   /* the calling thread's
                                                              each with its share of the system slots (cfg3: two chains 1.15x one chain's steps/s).  Such a context's
                                                              streams are blocking HIP streams: they synchronise with the legacy default stream.
                                                              Consumed by that create; default: the whole device */
-int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out12);  /* {threads/2 (0: not applicable), workgroups per system, slots per XCD, enabled, solves, placement fallbacks,
+#define HMCMT_PERSIST_INFO_FIELDS 14
+int hmcmt_persist_info(const hmcmt_ctx* ctx, int64_t* out, int32_t nout);  /* writes min(nout, HMCMT_PERSIST_INFO_FIELDS) values -- fields are only ever APPENDED, so a caller built against an
+                                                                   older header passes its own count and gets the fields it knows --:
+                                                                   {threads per strip (0: not applicable), workgroups per system, slots per XCD, enabled, solves, placement fallbacks,
                                                                    usable now (this context alone on its device in the process AND the process holds the device's advisory lock),
                                                                    modes per slab of its tridiagonal solves (32; 16 on tall meshes and with column parts),
                                                                    column parts per row block (1; 2 on meshes wider than one tile: the stress size),
                                                                    timed-out waits (each one: the evaluation redone with the launch-per-phase loop),
-                                                                   CU share index, CU share count (hmcmt_next_cu_share)} */
+                                                                   CU share index, CU share count (hmcmt_next_cu_share),
+                                                                   strips of tile rows per column (2: k_cocg_persist, 4: k_cocg_persist4; threads per workgroup = strips x threads per strip),
+                                                                   why the kernel is off (0: it is not, or HMCMT_PERSIST=0; 1: a placement fallback, for good; 2: a timed-out wait, tried again later)} */
 int hmcmt_persist_order(const hmcmt_ctx* ctx, int32_t kind, int32_t* order, int64_t* rebalanced);   /* meshes whose systems take turns on the chip (more systems than 8 x
                                                              slots per XCD: cfg5): the order in which the persistent kernel's queues take the systems of a solve of
                                                              `kind` (0 forward, 1 adjoint) -- order[nsystems], position queue + queues * round -> system --, balanced from

@@ -27,7 +27,7 @@ using Distributed              # myid
 using HMCMT.HMCFileIO, HMCMT.HMCStruct, HMCMT.HMCUtility
 
 export HipContext, hipContext, compDataGradient, hipForward, setPrior!, proposeLeapfrog, proposeLeapfrogDevice!,
-       hipWait, hipStats, hipGuard, hipPersistInfo, hipPersistEnvelope, hipPersistOrder, hipPersistPack, hipNextCuShare, destroy!, commId, SampleComm, allgatherSamples
+       hipWait, hipStats, hipGuard, hipPersistInfo, hipPersistWidth, hipPersistEnvelope, hipPersistOrder, hipPersistPack, hipNextCuShare, destroy!, commId, SampleComm, allgatherSamples
 
 const libhmcmt = get(ENV, "HMCMT_HIP_LIB", joinpath(@__DIR__, "..", "hmcmt2d_amd", "libhmcmt_hip.so"))
 
@@ -329,12 +329,12 @@ the launch-per-phase loop: same results, slower); `timeouts` / `placement_fallba
 this library cannot see.
 """
 function hipPersistInfo(ctx::HipContext)
-    out = zeros(Int64, 12)
-    rc = ccall((:hmcmt_persist_info, libhmcmt), Cint, (Ptr{Cvoid}, Ptr{Int64}), ctx.ptr, out)
+    out = zeros(Int64, 14)
+    rc = ccall((:hmcmt_persist_info, libhmcmt), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int32), ctx.ptr, out, Int32(length(out)))
     checkerr(ctx.ptr, rc)
     return (threads_half = out[1], workgroups_per_system = out[2], slots_per_xcd = out[3], enabled = out[4], solves = out[5],
             placement_fallbacks = out[6], usable_now = out[7], slab_modes = out[8], column_parts = out[9], timeouts = out[10],
-            cu_share_index = out[11], cu_share_count = out[12])
+            cu_share_index = out[11], cu_share_count = out[12], strips = out[13], why_off = out[14])
 end
 
 """
