@@ -283,6 +283,8 @@ def spawn_ranks(n):
     stdout -- the one JSON line -- is this process's stdout; the exit code is the first non-zero one of the ranks."""
     import socket
     import subprocess
+    # (a free port by bind-and-close: another process can take it before rank 0 binds it -- MASTER_PORT in the environment overrides
+    #  it, and a rendezvous that fails on "address in use" shows up as rank 0's exit within the poll loop below, not as a hang)
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -292,15 +294,23 @@ def spawn_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # all ranks polled in one loop: a rank r > 0 that dies while rank 0 sits in init_process_group or a barrier is seen at once
+    # (waiting for the ranks in order, rank 0's wait blocked until the store / NCCL timeout -- minutes -- before the failure showed)
     rc = 0
-    for r, p in enumerate(procs):
-        c = p.wait()
-        if c != 0 and rc == 0:
-            rc = c if c > 0 else 1
-            print(f"bench.py: rank {r} exited with {c}", file=sys.stderr)
-            for q in procs:                      # (the others would wait at the barrier for ever)
-                if q.poll() is None:
+    left = dict(enumerate(procs))
+    while left:
+        for r, p in list(left.items()):
+            c = p.poll()
+            if c is None:
+                continue
+            del left[r]
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                print(f"bench.py: rank {r} exited with {c}", file=sys.stderr)
+                for q in left.values():              # (the others would wait at the barrier for ever)
                     q.terminate()
+        if left:
+            time.sleep(0.05)
     return rc
 
 

@@ -31,6 +31,7 @@
 #include <unistd.h>
 #include <sys/file.h>
 #include "../../include/hmcmt.h"
+#include "../../include/hmcmt_debug.h"
 #include "hmcmt_host.h"
 #include "hmcmt_items.h"
 
@@ -195,6 +196,9 @@ struct hmcmt_ctx {
     bool psConstValid = false;
     float2* d_yhat2 = nullptr;            // column parts: the second part's partial product of the forward transform
     unsigned persistSpin = PS_SPIN_LIMIT; // HMCMT_PS_SPIN: polls before a wait of the kernel gives up (tests shorten it)
+    struct PsStart { int resid = 0, begin = 0; };      // the solve's start inside the persistent kernel (PsLaunch::resid / begin): set by evaluate_once for the NEXT solve
+    PsStart psStart{};
+    bool psInKernelStart = true;          // HMCMT_PS_START=0: k_resid0 / k_solve_begin in launches of their own, as until round 5 (A/B)
     int persistWhyOff = 0;                // why persistOn is false: 1 = a placement fallback (for good), 2 = a timed-out wait (backoff)
     long persistBackoff = 0;              // after a timed-out wait: solves on the launch-per-phase loop before the kernel is tried again (doubles per timeout)
     bool persistTimedOut = false;         // a wait of the last persistent launch timed out: evaluate() redoes the evaluation with the launch-per-phase loop
@@ -598,7 +602,7 @@ bool persist_ok(const hmcmt_ctx* ctx) {
     return ctx->persistOn && ctx->persistCW > 0 && ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0 && persist_alone(ctx);
 }
 // one launch = the whole solve (or, precondOnly, one application of the preconditioner to k.r -> zout)
-int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout, int kind = 0) {
+int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout, int kind = 0, hmcmt_ctx::PsStart start = hmcmt_ctx::PsStart{}) {
     Solver& k = ctx->sv;
     const int groups = 8 * ctx->persistSlots;
     // the launch-invariant state: rebuilt from the solver's structures on every launch (a few hundred bytes of host work) and
@@ -641,6 +645,9 @@ int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout, in
     a.gateGen = ++ctx->gateGen;
     a.dbgPlace = ctx->dbgPlace; ctx->dbgPlace = 0;
     a.order = ctx->psOrder[kind == 1].empty() ? nullptr : ctx->d_psOrder + (kind == 1 ? k.S : 0);
+    a.resid = start.resid; a.begin = start.begin; a.nOn = ctx->nSysOn; a.sysOn = ctx->v.sysOn;
+    a.doneCnt = ctx->d_psync + 32 * groups + 4;       // (in the block the kernel's last workgroup clears: exitCnt at +0, fail at +8)
+    if (start.begin) *(volatile int*)ctx->h_nactive = ctx->nSysOn;      // (mapped: "not all done yet" until the kernel's last converged system says otherwise)
     if (ctx->d_pstamps) HIPCHK(hipMemsetAsync(ctx->d_pstamps, 0, sizeof(long long) * 16 * 256, ctx->stream));
     const dim3 grid(groups * ctx->persistG);
     if (ctx->persistStrips == 4) {
@@ -749,7 +756,9 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
     // problem's right-hand side lives in x's boundary nodes (k_trueres forms it), the adjoint one was copied to d_b by evaluate()
     const bool guard = !ctx->opt.verify && ctx->guardNow;
     // all systems of the requested modes start active (device copy: no host round trip)
-    if (!ctx->solveBegun)           // (otherwise done by the residual kernel in front of this solve)
+    const hmcmt_ctx::PsStart start = ctx->psStart;          // (evaluate_once: residual and bookkeeping inside the persistent kernel)
+    ctx->psStart = hmcmt_ctx::PsStart{};
+    if (!ctx->solveBegun)           // (otherwise done by the residual kernel in front of this solve -- or about to be done by the persistent kernel)
         hipLaunchKernelGGL(k_solve_begin, dim3((S * MAXNB + 255) / 256), dim3(256), 0, ctx->stream, k, ctx->v.sysOn);
     ctx->solveBegun = false;
     if (k.cntActive) { ++ctx->profSolves; ctx->profStartSys += ctx->nSysOn; if (k.sweeps == 2) ++ctx->profSolves2; }
@@ -765,7 +774,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
     const dim3 tg((k.ny - 1 + 63) / 64, S);
     const bool fused = ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0;
     cplx* const r_entry = k.r;
-    bool viaPersist = false, stalledP = false, specIssued = false;
+    bool viaPersist = false, stalledP = false, specIssued = false, placeFallback = false;
     ctx->specValid = false;
     // (after a timed-out wait: another try when the backoff has run out -- a context that left the kernel because of its PLACEMENT
     //  stays off for good: persistWhyOff)
@@ -778,7 +787,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
         *(volatile int*)(ctx->h_stall + 2) = 0;
         *(volatile int*)(ctx->h_stall + 3) = 0;
         *(volatile int*)ctx->h_prog = 0;
-        { ProfScope ps(ctx, 2); int prc = launch_persist(ctx, k.sweeps, 0, nullptr, kind); if (prc) return prc; }
+        { ProfScope ps(ctx, 2); int prc = launch_persist(ctx, k.sweeps, 0, nullptr, kind, start); if (prc) return prc; }
         ++ctx->persistSolves;
         if (k.cntActive) ++ctx->profPersistSolves;
         if (kind == 0) launch_adjoint_side(ctx);        // (the host is free while the device solves)
@@ -798,6 +807,13 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
             // the group's workgroups were not on one XCD (or the kernel could not be placed): nothing was touched by those
             // groups -- this context goes back to the launch-per-phase loop for good
             ctx->persistOn = false; ctx->persistWhyOff = 1; ctx->persistBackoff = 0; ++ctx->persistFallbacks;
+            placeFallback = true;
+            if (start.begin) {
+                // (the kernel was to form the residual itself: the systems it did not touch -- still active -- have none yet; the
+                //  launch-per-phase loop's partial sums start from zero)
+                HIPCHK(hipMemsetAsync(k.partB, 0, (size_t)S * MAXNB * sizeof(double), ctx->stream));
+                if (start.resid) hipLaunchKernelGGL(k_resid0, dim3(k.NB, S), dim3(VBLOCK), 0, ctx->stream, k, x, start.resid, (const int*)nullptr, 1);
+            }
             if (ctx->persistFallbacks == 1)
                 fprintf(stderr, "libhmcmt_hip: the workgroups of a system of the persistent solve kernel were not dispatched to one XCD (a partitioned device, "
                                 "another dispatch order?); this context runs the launch-per-phase loop from here on -- same results, several times slower "
@@ -808,6 +824,13 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
             else if (*(volatile int*)ctx->h_stall) stalledP = true;
         }
     }
+    if (start.begin && !viaPersist && !placeFallback) {
+        // (the persistent kernel was to start this solve but did not run after all -- a second context has appeared on the device since
+        //  evaluate_once looked --: the start as launches of their own)
+        if (start.resid) hipLaunchKernelGGL(k_resid0, dim3(k.NB, S), dim3(VBLOCK), 0, ctx->stream, k, x, start.resid, ctx->v.sysOn, 0);
+        else hipLaunchKernelGGL(k_solve_begin, dim3((S * MAXNB + 255) / 256), dim3(256), 0, ctx->stream, k, ctx->v.sysOn);
+    }
+    if (start.begin && viaPersist && stalledP) HIPCHK(hipMemsetAsync(k.partB, 0, (size_t)S * MAXNB * sizeof(double), ctx->stream));   // (the fp64 restart's loop: its partial sums start from zero)
     if (fused && !viaPersist) {
         { int prc = apply_precond(ctx); if (prc) return prc; }          // z = P^-1 r and the partial sums of r'z, |z|^2
         float2* pb[2] = {k.p32a, k.p32b};
@@ -890,6 +913,12 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
     (void)stalledP;
     if (!done && !(viaPersist && *(volatile int*)(ctx->h_stall + 1))) {
         if (viaPersist) it = 0;
+        // (a mesh wider than 447 cells has no fp64 eigen-transform to restart with: a NUMERICAL event -- a stagnating solve -- ends the
+        //  evaluation as "not converged", not as an invalid argument from launch_transform)
+        if (fused && ctx->hp.NYP / 16 > 28) {
+            ctx->err = "a mixed-precision solve stagnated on a mesh wider than 447 cells, where the fp64 restart does not exist (include/hmcmt.h, hmcmt_create): not converged";
+            return HMCMT_ENOCONV;
+        }
         const bool restart = fused;      // coming from the fused loop: restart COCG with the fp64 preconditioner
         if (restart) { ctx->lpFallback = true; ++ctx->stats.fallback_solves; }
         // z = P^-1 r ; rho = r'z ; p = z
@@ -1050,6 +1079,9 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
                               startLds <= (size_t)150 * 1024 && !ctx->noFusedStart;
     const int sweepsF = pick_sweeps(ctx, 0), sweepsA = pick_sweeps(ctx, 1);
     bool fusedStart = fusedStartOk && sweepsF == 1;      // (k_resid_pre does ONE pre-sweep; two go through k_resid0 + the solve's own start)
+    // the solves' start -- initial residual, bookkeeping -- inside the persistent kernel (kernels_persist.h, PsLaunch::resid / begin)
+    const bool inKernelStart = ctx->psInKernelStart && ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0 && !ctx->opt.verify &&
+                               !ctx->guardNow && persist_ok(ctx);
     ctx->sv.sweeps = sweepsF;
     ctx->stats.smoother_sweeps = 10 * sweepsF + (wantGrad ? sweepsA : 0);
     ctx->sweepsUsed[0] = sweepsF; if (wantGrad) ctx->sweepsUsed[1] = sweepsA;
@@ -1131,13 +1163,19 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
             }
         }
         if (extrap) HIPCHK(hipStreamWaitEvent(st, ctx->evExtF, 0));
-        // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X
+        // r = -Aio*bc - Aii*x0 with x0 = previous solution (or 0): one stencil pass over X -- inside the persistent kernel's per-system
+        // set-up where that kernel runs the solve (round 6: k_resid0 + its launch boundary were 25 us in front of the forward solve)
+        if (inKernelStart) {
+            ctx->psStart.resid = 1; ctx->psStart.begin = 1;
+            ctx->solveBegun = true;
+            fusedStart = false;
+        } else
         if (fusedStart) {
             launch_resid_pre(ctx, startLds, v.X, 1);
             std::swap(ctx->sv.r, ctx->sv.r2);             // (the residual went to the second buffer; swapped back after the solve)
             ctx->solveBegun = ctx->preDone = true;
         } else {
-            hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, 1, ctx->opt.verify ? nullptr : ctx->v.sysOn);
+            hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.X, 1, ctx->opt.verify ? nullptr : ctx->v.sysOn, 0);
             ctx->solveBegun = !ctx->opt.verify;
         }
         if (ctx->wantTicks) { ctx->hostUs[0] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hostT0).count(); ++ctx->hostN; }
@@ -1163,7 +1201,7 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
     int rc = solve(ctx, v.X, 0, true, specPlain ? &specF : nullptr);
     const bool specFwd = ctx->specValid;
     if (fusedStart) std::swap(ctx->sv.r, ctx->sv.r2);
-    fusedStart = fusedStartOk && sweepsA == 1;
+    fusedStart = fusedStartOk && sweepsA == 1 && !inKernelStart;
     ctx->sv.sweeps = sweepsA;
     if (rc == 0 && ctx->solveFail) {
         launch_solve_end(ctx, 0);
@@ -1204,12 +1242,17 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
             }
             if (ctx->guardNow) HIPCHK(hipMemcpyAsync(ctx->d_b, v.R, vecBytes, hipMemcpyDeviceToDevice, st));
             if (ctx->extAWaitPending) { ctx->extAWaitPending = false; HIPCHK(hipStreamWaitEvent(st, ctx->evExtA, 0)); }   // (a forward solve too short to have issued it)
+            if (inKernelStart && persist_ok(ctx)) {
+                // (warm start: r = b - A lambda0 with b on the receiver layer's two node rows; cold: the buffer k_src has filled IS the residual)
+                ctx->psStart.resid = warmA ? 2 + v.zid : 0; ctx->psStart.begin = 1;
+                ctx->solveBegun = true;
+            } else
             if (warmA && fusedStart) {
                 launch_resid_pre(ctx, startLds, v.Lam, sparseSrc ? 2 + v.zid : 0);
                 std::swap(ctx->sv.r, ctx->sv.r2);
                 ctx->solveBegun = ctx->preDone = true;
             } else if (warmA) {
-                hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, sparseSrc ? 2 + v.zid : 0, ctx->v.sysOn);
+                hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, sparseSrc ? 2 + v.zid : 0, ctx->v.sysOn, 0);
                 ctx->solveBegun = true;
             }
         }
@@ -1578,6 +1621,7 @@ static bool persist_shape(const hmcmt_ctx* ctx, int twist, int& cuPerXcd, int& G
 static int persist_setup(hmcmt_ctx* ctx) {
     const Solver& k = ctx->sv;
     if (const char* e = getenv("HMCMT_PERSIST")) ctx->persistOn = e[0] != '0';
+    if (const char* e = getenv("HMCMT_PS_START")) ctx->psInKernelStart = e[0] != '0';
     if (const char* e = getenv("HMCMT_PS_SPIN")) ctx->persistSpin = (unsigned)std::max(1024l, atol(e));
     ctx->persistCW = 0;
     int cuPerXcd = 0, G = 0, cw = 0, mw = 32, cs = 1;
@@ -1694,7 +1738,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
     // the fp64 eigen-transform kernel (fdm_precision = 1, and the restart of a stagnating mixed-precision solve) holds at most
     // 28 column tiles of 16 nodes.  A wider mesh runs the default mixed-precision path (the reference takes any mesh,
     // readEMModel2D.jl:11-154); it is refused here only where fp64 is ASKED for, and a restart that needs the kernel fails that
-    // evaluation with HMCMT_EINVAL (launch_transform) -- the safety net is what such a mesh goes without, not the solver.
+    // evaluation with HMCMT_ENOCONV (solve()) -- the safety net is what such a mesh goes without, not the solver.
     if (ctx->hp.NYP / 16 > 28 && ctx->opt.fdm_precision == 1) { ctx->err = "fdm_precision = 1 on a mesh wider than 447 cells: the fp64 eigen-transform holds ny + 1 <= 448 nodes (include/hmcmt.h, hmcmt_create)"; return HMCMT_EINVAL; }
     HIPCHK(hipSetDevice(device_id));
     ctx->shareMask = quarter_mask(ctx->shareIdx, ctx->shareCnt);      // (hmcmt_next_cu_share, taken over by hmcmt_create)
@@ -2288,7 +2332,7 @@ int hmcmt_debug_transform(hmcmt_ctx* ctx, int32_t which, const double* A, double
 }
 
 int hmcmt_debug_flags(hmcmt_ctx* ctx, int32_t flags) {
-    if (!ctx || (flags & ~7)) return HMCMT_EINVAL;
+    if (!ctx || (flags & ~15)) return HMCMT_EINVAL;
     if (flags & 8) ctx->dbgPlace = -1;                    // (one-shot: EVERY group of the next persistent launch fails its placement check -- the all-fallback regime of a partitioned device)
     else if (flags & 4) ctx->dbgPlace = 1;                     // (one-shot: the next persistent launch's first system group fails its placement check)
     flags &= 3;

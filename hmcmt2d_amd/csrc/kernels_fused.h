@@ -542,8 +542,11 @@ __global__ __launch_bounds__(NT) void k_update_fused(Solver k, const float2* pcu
 // values in x); 2 + row: it is read on node rows row, row + 1 only and zero elsewhere -- the adjoint sources live on the two
 // node rows of the receiver layer (item_src), so the buffer need not be cleared in front of k_src (a 11 MB fill and an API
 // call between the solves) nor read here outside those rows
-__global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r, const int* __restrict__ sysOn) {
+// onlyActive: systems whose active flag is off are left alone (behind a persistent launch that was to form the residual itself and
+// left some systems untouched: kernels_persist.h, PsLaunch::resid)
+__global__ __launch_bounds__(VBLOCK) void k_resid0(Solver k, cplx* x, int zero_r, const int* __restrict__ sysOn, int onlyActive) {
     const int s = blockIdx.y;
+    if (onlyActive && !k.active[s]) return;
     if (sysOn && blockIdx.x == 0 && blockIdx.y == 0) {
         for (int t = threadIdx.x; t < k.S * MAXNB; t += VBLOCK) k.partB[t] = 0.0;
         for (int t = threadIdx.x; t < k.S; t += VBLOCK) { k.active[t] = sysOn[t]; k.iters[t] = 0; k.status[t] = 0; }

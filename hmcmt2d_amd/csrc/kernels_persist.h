@@ -96,7 +96,7 @@ typedef const __attribute__((address_space(4))) PsConst* PsKP;
 template <class T>
 __device__ __forceinline__ const __attribute__((address_space(4))) T* ps_c4(const T* p) { return (const __attribute__((address_space(4))) T*)p; }   // arrays no kernel of the launch writes: scalar loads
 
-// What changes from launch to launch: the kernel's only argument (96 bytes).
+// What changes from launch to launch: the kernel's only argument (128 bytes).
 struct PsLaunch {
     const PsConst* kc;
     cplx *x, *r;               // the solve's iterate and residual [S][vstride]
@@ -112,6 +112,14 @@ struct PsLaunch {
     int tickId;                // HMCMT_TICKS: TK_PERSIST_F / TK_PERSIST_A
     int dbgPlace;              // test hook: 1 + index of a group that is to FAIL its placement check (hmcmt_debug_flags)
     const int* order;          // [S] (or null): position xcd + 8 (slot + slots round) of the queues -> system (a permutation; launch_persist)
+    // round 6: the solve's START inside the kernel -- what k_resid0 / k_solve_begin did in a launch of their own
+    // (10-14 us + a launch boundary in front of either solve)
+    int resid;                 // 0: r as given; 1: r = -A x (the forward problem: its sources are the Dirichlet values in x); 2 + row: r = b - A x, b read from r on
+                               // the node rows row, row + 1 and zero elsewhere (the adjoint sources: the receiver layer's two node rows) -- k_resid0's zero_r
+    int begin;                 // 1: the solve's bookkeeping here (active <- sysOn, iterations / status cleared, "all systems done" on the kernel's own counter)
+    int nOn;                   // systems that are on (sum of sysOn)
+    const int* sysOn;          // [S]
+    unsigned* doneCnt;         // device word (zero at launch, in the sync block the last workgroup clears): systems that have ended converged
 };
 
 __device__ __forceinline__ unsigned ps_xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 0xf; }
@@ -632,6 +640,16 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
     // (what decides a loop's exit is read as a SCALAR -- readfirstlane of the LDS word every lane reads alike --: the compiler then knows
     //  the solve's loops for uniform ones, and what they carry from iteration to iteration may live in scalar registers)
     bool alive = __builtin_amdgcn_readfirstlane(sflag[0]) == 0;
+    if (!alive && L.begin && jw == 0 && tid == 0 && sflag[0] == 1) {
+        // (a misplaced group leaves its systems untouched -- with the solve's bookkeeping done in this kernel, that includes marking them
+        //  as still to be solved: the host's launch-per-phase loop forms their residual and takes them)
+        for (int round = 0;; ++round) {
+            const int q = xcd + 8 * (slot + slots * round);
+            if (q >= kb->S) break;
+            const int s = L.order ? L.order[q] : q;
+            kb->active[s] = L.sysOn[s]; kb->iters[s] = 0; kb->status[s] = 0;
+        }
+    }
 
     auto sys_arrive = [&]() {           // ONE thread, behind ITS OWN payload stores (or behind a drained workgroup barrier)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -744,7 +762,9 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
         const int q = xcd + 8 * (slot + slots * round);
         if (q >= kb->S) break;
         const int s = L.order ? ps_c4(L.order)[q] : q;
-        if (!kb->active[s]) continue;
+        if (L.begin) {
+            if (!ps_c4(L.sysOn)[s]) { if (jw == 0 && tid == 0) { kb->active[s] = 0; kb->iters[s] = 0; kb->status[s] = 0; } continue; }
+        } else if (!kb->active[s]) continue;
         const int mode = s >= kb->nFreq;
         const double w = ps_c4(kb->omega)[s];
         const float wf = (float)w;
@@ -796,10 +816,55 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
         // is a copy, refreshed from the owners like the halo rows'), r of the halo rows (complex64, refreshed every iteration)
         cplx r64[PS_NO];
         c32 rh[PS_HALO];
+        if (L.resid) {
+            // the initial residual r = b - A x0 of the own rows, formed HERE (fp64, the arithmetic of q = A p below with x in p's place): the
+            // forward problem's sources are the Dirichlet values on x's boundary nodes (b = 0), the adjoint sources live on the receiver
+            // layer's two node rows of r (k_resid0's zero_r; kernels_fused.h).  Rows in two batches: all seven rows' fifteen operands at
+            // once are 210 registers.
+            const long mso = mo() - (long)so32;
+            const double *dMm = kb->dM + mso, *cYm = kb->cY + mso, *cZm = kb->cZ + mso;
+            const cplx* const xs0 = L.x;
+            const cplx* const rs0 = L.r;
+            const int brow = L.resid - 2;
+#pragma unroll
+            for (int q0 = 0; q0 < PS_NO; q0 += 4) {
+                cplx xc[4], xe[4], xw[4], xn[4], xso[4], bv[4];
+                double dm[4], ce[4], cw[4], cn[4], cs[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (q0 + a < PS_NO) {
+                        const int j = PS_HALO + q0 + a, g = gb + gs * j;
+                        const unsigned e = ei(j);
+                        xc[a] = *ps_at(xs0, e); xe[a] = *ps_at(xs0, e + 1u); xw[a] = *ps_at(xs0, e - 1u);
+                        xn[a] = *ps_at(xs0, e - (unsigned)NYP); xso[a] = *ps_at(xs0, e + (unsigned)NYP);
+                        dm[a] = *ps_at(dMm, e); ce[a] = *ps_at(cYm, e); cw[a] = *ps_at(cYm, e - 1u);
+                        cs[a] = *ps_at(cZm, e); cn[a] = *ps_at(cZm, e - (unsigned)NYP);
+                        const bool hasB = L.resid >= 2 && (unsigned)(g - brow) < 2u;
+                        bv[a] = *ps_at(rs0, hasB ? e : (unsigned)(NYP + 1 + so32));
+                        if (!hasB) bv[a] = cplx{0, 0};
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (q0 + a < PS_NO) {
+                        const int j = PS_HALO + q0 + a;
+                        const double dmw = w * dm[a];
+                        const double dk = -((ce[a] + cw[a]) + (cn[a] + cs[a]));
+                        cplx acc = cplx{__builtin_fma(-dmw, xc[a].im, dk * xc[a].re), __builtin_fma(dmw, xc[a].re, dk * xc[a].im)};
+                        acc = cplx{__builtin_fma(ce[a], xe[a].re, acc.re), __builtin_fma(ce[a], xe[a].im, acc.im)};
+                        acc = cplx{__builtin_fma(cw[a], xw[a].re, acc.re), __builtin_fma(cw[a], xw[a].im, acc.im)};
+                        acc = cplx{__builtin_fma(cn[a], xn[a].re, acc.re), __builtin_fma(cn[a], xn[a].im, acc.im)};
+                        acc = cplx{__builtin_fma(cs[a], xso[a].re, acc.re), __builtin_fma(cs[a], xso[a].im, acc.im)};
+                        r64[q0 + a] = cplx{bv[a].re - acc.re, bv[a].im - acc.im};
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < PS_NO; ++q) {
             const int j = PS_HALO + q, g = gb + gs * j;
-            r64[q] = *ps_at(rsys(), ei(j));
+            if (!L.resid) r64[q] = *ps_at(rsys(), ei(j));
             r64[q] = (double)mk(j) * r64[q];
             if (own() && g >= 1 && g <= nz - 1) {
                 *ps_at(pubR(), eo(j)) = float2{(float)r64[q].re, (float)r64[q].im};
@@ -1441,9 +1506,14 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             if (L.cntActive) atomicAdd(L.cntActive, (unsigned long long)max(it - 1, 0));   // (roofline accounting: iterations x systems of a sampled evaluation)
             kb->iters[s] = it - 1;
             kb->errEst[s] = sqrt(estN / estD);
+            if (L.begin) kb->status[s] = st;
             if (st) { kb->status[s] = st; *kb->failHost = st; }
-            if (stalled) *kb->stallHost = 1;
-            else { kb->active[s] = 0; if (atomicSub(kb->nactive, 1) == 1) *kb->nactHost = 0; }
+            if (stalled) { *kb->stallHost = 1; if (L.begin) kb->active[s] = 1; }
+            else {
+                kb->active[s] = 0;
+                if (L.begin) { if (__hip_atomic_fetch_add(L.doneCnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)L.nOn) *kb->nactHost = 0; }
+                else if (atomicSub(kb->nactive, 1) == 1) *kb->nactHost = 0;
+            }
         }
     }
     // ---- exit: the last workgroup to leave tells the host
@@ -1468,11 +1538,15 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                         __hip_atomic_load(kb->active + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
             // (an OR over the workgroup through the scratch kilobyte: __syncthreads_or brings a static __shared__ word of its own,
             //  and static + dynamic LDS beyond 160 KB makes hipFuncSetAttribute refuse the kernel)
-            if (tid == 0) sflag[2] = 0;
+            int nact = 0;
+            if (L.begin) for (int s = tid; s < S; s += NT) nact += __hip_atomic_load(kb->active + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1 : 0;
+            if (tid == 0) { sflag[2] = 0; sflag[3] = 0; }
             __syncthreads();
             if (bad) sflag[2] = 1;
+            if (nact) atomicAdd(const_cast<int*>(sflag + 3), nact);
             __syncthreads();
             if (tid == 0 && L.gateOut) *L.gateOut = sflag[2] ? -L.gateGen : L.gateGen;
+            if (tid == 0 && L.begin) *kb->nactive = sflag[3];      // (systems still active -- stalled, displaced --: what the host's launch-per-phase loop counts down)
         }
         // The barrier counters, the exit counter and the failure word go back to zero for the
         // next launch (a memset in front of every launch was a 5 us fill kernel on the stream: 12 us between the residual kernel

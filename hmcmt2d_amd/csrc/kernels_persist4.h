@@ -108,6 +108,14 @@ __global__ __launch_bounds__(4 * CW) void k_cocg_persist4(PsLaunch L) {
     }
     __syncthreads();
     bool alive = __builtin_amdgcn_readfirstlane(sflag[0]) == 0;
+    if (!alive && L.begin && jw == 0 && tid == 0 && sflag[0] == 1) {      // (a misplaced group: its systems stay to be solved, kernels_persist.h)
+        for (int round = 0;; ++round) {
+            const int q = xcd + 8 * (slot + slots * round);
+            if (q >= kb->S) break;
+            const int s = L.order ? L.order[q] : q;
+            kb->active[s] = L.sysOn[s]; kb->iters[s] = 0; kb->status[s] = 0;
+        }
+    }
 
     auto sys_arrive = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -175,7 +183,9 @@ __global__ __launch_bounds__(4 * CW) void k_cocg_persist4(PsLaunch L) {
         const int q = xcd + 8 * (slot + slots * round);
         if (q >= kb->S) break;
         const int s = L.order ? ps_c4(L.order)[q] : q;
-        if (!kb->active[s]) continue;
+        if (L.begin) {
+            if (!ps_c4(L.sysOn)[s]) { if (jw == 0 && tid == 0) { kb->active[s] = 0; kb->iters[s] = 0; kb->status[s] = 0; } continue; }
+        } else if (!kb->active[s]) continue;
         const int mode = s >= kb->nFreq;
         const double w = ps_c4(kb->omega)[s];
         const float wf = (float)w;
@@ -212,20 +222,66 @@ __global__ __launch_bounds__(4 * CW) void k_cocg_persist4(PsLaunch L) {
         // registers of 128 were what the register allocator kept in scratch and reloaded in front of every stencil pass
         c32 rf[J];
         {
-            const cplx* const rs0 = L.r;
+            cplx* const rs0 = L.r;
             float2* const pR = kb->pubR;
             float2* const pP = kb->pubP;
+            // (L.resid: the initial residual r = b - A x0 of the own rows formed here and stored -- k_resid0's launch, kernels_persist.h;
+            //  two rows at a time: thirty operands of the 128 registers)
+            const long mso = mo() - (long)so32;
+            const double *dMm = kb->dM + mso, *cYm = kb->cY + mso, *cZm = kb->cZ + mso;
+            const cplx* const xs0 = L.x;
+            const int brow = L.resid - 2;
 #pragma unroll
-            for (int j = 0; j < J; ++j) {
-                rf[j] = c32{0, 0};
-                if (outer && j < PS_HALO) continue;
-                cplx v = *ps_at(rs0, ei(j));
-                v = (double)mk(j) * v;
-                rf[j] = c32{(float)v.re, (float)v.im};
-                if (iyv < TW && rowIn(j)) {
-                    *ps_at(pR, eo(j)) = float2{rf[j].re, rf[j].im};
-                    *ps_at(pP, eo(j)) = float2{0.f, 0.f};
+            for (int j0 = 0; j0 < J; j0 += 2) {
+                cplx v2[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) v2[a] = cplx{0, 0};
+                if (!(outer && j0 + 1 < PS_HALO)) {
+                    if (L.resid) {
+                        cplx xc[2], xe[2], xw[2], xn[2], xso[2], bv[2];
+                        double dm[2], ce[2], cw[2], cn[2], cs[2];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            const int j = j0 + a, g = gb + gs * j;
+                            const unsigned e = ei(j);
+                            xc[a] = *ps_at(xs0, e); xe[a] = *ps_at(xs0, e + 1u); xw[a] = *ps_at(xs0, e - 1u);
+                            xn[a] = *ps_at(xs0, e - (unsigned)NYP); xso[a] = *ps_at(xs0, e + (unsigned)NYP);
+                            dm[a] = *ps_at(dMm, e); ce[a] = *ps_at(cYm, e); cw[a] = *ps_at(cYm, e - 1u);
+                            cs[a] = *ps_at(cZm, e); cn[a] = *ps_at(cZm, e - (unsigned)NYP);
+                            const bool hasB = L.resid >= 2 && (unsigned)(g - brow) < 2u;
+                            bv[a] = *ps_at(rs0, hasB ? e : (unsigned)(NYP + 1 + so32));
+                            if (!hasB) bv[a] = cplx{0, 0};
+                        }
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            const double dmw = w * dm[a];
+                            const double dk = -((ce[a] + cw[a]) + (cn[a] + cs[a]));
+                            cplx acc = cplx{__builtin_fma(-dmw, xc[a].im, dk * xc[a].re), __builtin_fma(dmw, xc[a].re, dk * xc[a].im)};
+                            acc = cplx{__builtin_fma(ce[a], xe[a].re, acc.re), __builtin_fma(ce[a], xe[a].im, acc.im)};
+                            acc = cplx{__builtin_fma(cw[a], xw[a].re, acc.re), __builtin_fma(cw[a], xw[a].im, acc.im)};
+                            acc = cplx{__builtin_fma(cn[a], xn[a].re, acc.re), __builtin_fma(cn[a], xn[a].im, acc.im)};
+                            acc = cplx{__builtin_fma(cs[a], xso[a].re, acc.re), __builtin_fma(cs[a], xso[a].im, acc.im)};
+                            v2[a] = cplx{bv[a].re - acc.re, bv[a].im - acc.im};
+                        }
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) v2[a] = *ps_at(rs0, ei(j0 + a));
+                    }
                 }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int j = j0 + a;
+                    rf[j] = c32{0, 0};
+                    if (outer && j < PS_HALO) continue;
+                    const cplx v = (double)mk(j) * v2[a];
+                    rf[j] = c32{(float)v.re, (float)v.im};
+                    if (iyv < TW && rowIn(j)) {
+                        if (L.resid) *ps_at(rs0, eo(j)) = v;
+                        *ps_at(pR, eo(j)) = float2{rf[j].re, rf[j].im};
+                        *ps_at(pP, eo(j)) = float2{0.f, 0.f};
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (!sys_sync()) { alive = false; break; }
@@ -729,9 +785,14 @@ __global__ __launch_bounds__(4 * CW) void k_cocg_persist4(PsLaunch L) {
             if (L.cntActive) atomicAdd(L.cntActive, (unsigned long long)max(it - 1, 0));
             kb->iters[s] = it - 1;
             kb->errEst[s] = sqrt(estN / estD);
+            if (L.begin) kb->status[s] = st;
             if (st) { kb->status[s] = st; *kb->failHost = st; }
-            if (stalled) *kb->stallHost = 1;
-            else { kb->active[s] = 0; if (atomicSub(kb->nactive, 1) == 1) *kb->nactHost = 0; }
+            if (stalled) { *kb->stallHost = 1; if (L.begin) kb->active[s] = 1; }
+            else {
+                kb->active[s] = 0;
+                if (L.begin) { if (__hip_atomic_fetch_add(L.doneCnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)L.nOn) *kb->nactHost = 0; }
+                else if (atomicSub(kb->nactive, 1) == 1) *kb->nactHost = 0;
+            }
         }
     }
     // ---- exit: the last workgroup to leave tells the host (kernels_persist.h)
@@ -752,11 +813,15 @@ __global__ __launch_bounds__(4 * CW) void k_cocg_persist4(PsLaunch L) {
             for (int s = tid; s < S; s += NT)
                 bad |= (__hip_atomic_load(kb->status + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
                         __hip_atomic_load(kb->active + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
-            if (tid == 0) sflag[2] = 0;
+            int nact = 0;
+            if (L.begin) for (int s = tid; s < S; s += NT) nact += __hip_atomic_load(kb->active + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1 : 0;
+            if (tid == 0) { sflag[2] = 0; sflag[3] = 0; }
             __syncthreads();
             if (bad) sflag[2] = 1;
+            if (nact) atomicAdd(const_cast<int*>(sflag + 3), nact);
             __syncthreads();
             if (tid == 0 && L.gateOut) *L.gateOut = sflag[2] ? -L.gateGen : L.gateGen;
+            if (tid == 0 && L.begin) *kb->nactive = sflag[3];
         }
         unsigned* const syn = kb->sync;
         for (int i = tid; i < kb->syncWords; i += NT) syn[i] = 0u;

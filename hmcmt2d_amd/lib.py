@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 SOURCES = [os.path.join(CSRC, "hmcmt_hip.hip"), os.path.join(CSRC, "mumps_shim.hip"), os.path.join(CSRC, "comm.hip")]
 HEADERS = [os.path.join(CSRC, h) for h in ("hmcmt_math.h", "hmcmt_items.h", "hmcmt_host.h", "kernels_cocg.h", "kernels_fdm.h",
                                             "kernels_fused.h", "kernels_persist.h", "kernels_persist4.h", "kernels_path.h")] + \
-          [os.path.join(HERE, "..", "include", "hmcmt.h"), os.path.join(HERE, "..", "include", "hmcmt_mumps.h")]
+          [os.path.join(HERE, "..", "include", h) for h in ("hmcmt.h", "hmcmt_debug.h", "hmcmt_mumps.h")]
 
 HMCMT_NCAT = 8
 CATEGORIES = ["fdm_transform", "tridiagonal", "spmv", "vector_ops", "assembly_bc", "receivers", "gradient",
@@ -137,13 +137,18 @@ def load_library():
     return lib
 
 
-EXPORTED_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "hmcmt_last_error",
-                    "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters", "hmcmt_grad", "hmcmt_forward",
-                    "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async", "hmcmt_wait",
-                    "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead", "hmcmt_dims",
-                    "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
-                    "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_guard", "hmcmt_debug_hog", "hmcmt_next_cu_share", "hmcmt_persist_envelope", "hmcmt_persist_width", "hmcmt_persist_order", "hmcmt_persist_pack", "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy",
-                    "hmcmt_comm_last_error"]
+# include/hmcmt.h: the drop-in boundary
+PRODUCT_SYMBOLS = ["hmcmt_default_options", "hmcmt_create", "hmcmt_destroy", "hmcmt_last_error",
+                   "hmcmt_set_options", "hmcmt_get_stats", "hmcmt_get_iters", "hmcmt_grad", "hmcmt_forward",
+                   "hmcmt_grad_device", "hmcmt_forward_device", "hmcmt_grad_device_async", "hmcmt_wait",
+                   "hmcmt_set_prior", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_get_fields", "hmcmt_guard", "hmcmt_next_cu_share",
+                   "hmcmt_comm_id", "hmcmt_comm_create", "hmcmt_allgather_samples", "hmcmt_comm_destroy", "hmcmt_comm_last_error"]
+# include/hmcmt_debug.h: instrumentation, introspection of the persistent kernel, test hooks
+DEBUG_SYMBOLS = ["hmcmt_profile", "hmcmt_profile_every", "hmcmt_profile_read", "hmcmt_profile_counters", "hmcmt_profile_overhead", "hmcmt_dims",
+                 "hmcmt_debug_transform", "hmcmt_debug_flags", "hmcmt_debug_spmv", "hmcmt_debug_precond", "hmcmt_debug_fdm_fwd",
+                 "hmcmt_debug_back_post", "hmcmt_debug_persist_precond", "hmcmt_persist_info", "hmcmt_debug_hog", "hmcmt_persist_envelope",
+                 "hmcmt_persist_width", "hmcmt_persist_order", "hmcmt_persist_pack"]
+EXPORTED_SYMBOLS = PRODUCT_SYMBOLS + DEBUG_SYMBOLS
 
 
 def _dp(a):
@@ -430,10 +435,11 @@ class HipContext:
         return Cc
 
     def debug_flags(self, freeze_boundary=False, no_boundary_terms=False, fail_placement=False):
-        """Test hook (include/hmcmt.h): hold the Dirichlet values at the previous evaluation's / leave dBC^T w out of the gradient /
-        (one-shot) let the first system group of the next persistent launch fail its placement check."""
+        """Test hook (include/hmcmt_debug.h): hold the Dirichlet values at the previous evaluation's / leave dBC^T w out of the gradient /
+        (one-shot) let the first system group -- fail_placement="all": EVERY group -- of the next persistent launch fail its placement check."""
         self._cache = None
-        self._check(self.lib.hmcmt_debug_flags(self.h, (1 if freeze_boundary else 0) | (2 if no_boundary_terms else 0) | (4 if fail_placement else 0)))
+        place = 8 if fail_placement == "all" else (4 if fail_placement else 0)
+        self._check(self.lib.hmcmt_debug_flags(self.h, (1 if freeze_boundary else 0) | (2 if no_boundary_terms else 0) | place))
 
     def debug_spmv(self, p):
         p = self._vec(p)

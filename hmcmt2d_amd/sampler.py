@@ -66,6 +66,12 @@ def get_context(mtMesh, mtData, invParam, device_id=None, **opts) -> HipContext:
     return ctx
 
 
+def cu_shares_for(chains_per_gpu, nlocal):
+    """CU shares (hmcmt_next_cu_share) for `nlocal` chains of this rank under chains_per_gpu: the largest of 4, 2, 1 that exceeds
+    neither -- every share in use, none idle (parallelHMC.jl:23-45 runs np chains over fewer workers the same way)."""
+    return max(sh for sh in (4, 2, 1) if sh <= max(1, min(int(chains_per_gpu), int(nlocal))))
+
+
 def release_context(invParam, device_id=None):
     for key in [k for k in _contexts if k[0] == id(invParam) and (device_id is None or k[1] == int(device_id))]:
         _drop_context(key)
@@ -404,7 +410,10 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
     mine = list(range(rank, nchains, world))
     results = {}
 
-    shares = int(chains_per_gpu) if int(chains_per_gpu) in (2, 4) and len(mine) > 1 else 1
+    # shares of every XCD's CUs = chains that actually run at a time: the largest of (4, 2, 1) that neither exceeds chains_per_gpu nor
+    # the chains this rank has (chains_per_gpu = 4 with two local chains: halves, not quarters -- a quarter to a half of the GPU would
+    # idle for the whole run), and that many worker threads (three chains on two shares: two at a time, then the third)
+    shares = cu_shares_for(chains_per_gpu, len(mine))
     if int(chains_per_gpu) > 1 and int(chains_per_gpu) not in (2, 4):
         import warnings
         warnings.warn("chains_per_gpu must be 1, 2 or 4 (shares of every XCD's CUs): other values run concurrent contexts on the "
@@ -421,13 +430,15 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
             inv_c, prior_c, mesh_c = copy.deepcopy(invParam), copy.deepcopy(hmcprior), copy.deepcopy(mtMesh)
             with share_lock:
                 my_share = free_shares.pop(0) if shares > 1 else None
-            ctx_kw = {} if my_share is None else {"cu_share": (my_share, shares)}
-            ctx_c = context_factory(mesh_c, mtData, inv_c, dev_id) if context_factory is not None else \
-                get_context(mesh_c, mtData, inv_c, device_id=dev_id, **ctx_kw)
-            kw = dict(sampler_kw)
-            if kw.get("checkpoint"):                        # one checkpoint file per chain
-                kw["checkpoint"] = f"{kw['checkpoint']}.chain{c + 1}"
             try:
+                # (the context is created INSIDE the try: a create that raises hands its share back, and the next chain fails with
+                #  the real error instead of an IndexError on an empty list)
+                ctx_kw = {} if my_share is None else {"cu_share": (my_share, shares)}
+                ctx_c = context_factory(mesh_c, mtData, inv_c, dev_id) if context_factory is not None else \
+                    get_context(mesh_c, mtData, inv_c, device_id=dev_id, **ctx_kw)
+                kw = dict(sampler_kw)
+                if kw.get("checkpoint"):                        # one checkpoint file per chain
+                    kw["checkpoint"] = f"{kw['checkpoint']}.chain{c + 1}"
                 model, stats, data = runHMCSampler(mesh_c, mtData, inv_c, prior_c, rng, ctx=ctx_c, **kw)
             finally:
                 release_context(inv_c)
@@ -438,7 +449,8 @@ def parallelHMCSampler(mtMesh, mtData, invParam, hmcprior, pids=None, seed=0, ou
 
     if chains_per_gpu > 1 and len(mine) > 1:
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=int(chains_per_gpu)) as pool:      # (the library calls release the GIL)
+        workers = shares if int(chains_per_gpu) in (2, 4) else int(chains_per_gpu)
+        with ThreadPoolExecutor(max_workers=workers) as pool:      # (the library calls release the GIL)
             list(pool.map(one_chain, mine))
     else:
         for c in mine:

@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include "hmcmt.h"
+#include "hmcmt_debug.h"
 #include "hmcmt_mumps.h"
 
 #define FIELD(type, f) printf("offsetof %s.%s %zu\n", #type, #f, offsetof(type, f))

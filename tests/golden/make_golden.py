@@ -1,5 +1,5 @@
 """Generates the golden vectors tests/golden/*.npz with the oracle (run in the build
-container: `python tests/golden/make_golden.py [names...]`; names: tiny cfg2 cfg1 cfg3s cfg3 cfg5s dprism3d coprod2 rhophase).  Inputs: BASELINE.json-style synthetic configs
+container: `python tests/golden/make_golden.py [names...]`; names: tiny cfg2 cfg1 cfg3s cfg3 cfg5s cfg5 dprism3d coprod2 rhophase).  Inputs: BASELINE.json-style synthetic configs
 (hmcmt2d_amd/synthetic.py), observed data = oracle forward of the true model + 3 % seeded noise,
 evaluation state m = ln(0.01) + 0.3 N(0,1) (seed 1).  Outputs: predData, misfit, gradient, the
 receiver-row fields and (tiny only) every intermediate term of J^T v.
@@ -156,6 +156,36 @@ def make_cfg5_subset():
     print("cfg5s misfit", misfit, misfit2, "file kB", os.path.getsize(os.path.join(HERE, "cfg5s.npz")) // 1024)
 
 
+def make_cfg5_full():
+    """BASELINE configs[4] in full: the stress mesh (400x200 cells + 7 air rows, 82 194 unknowns per system), ALL 32 frequencies,
+    TE+TM, 5 184 data (cfg5s.npz holds 3 of the 32).  Oracle pred / misfit / gradient at the rough state and
+    at the true model on observations = oracle forward of the true model + seeded noise; receiver-row fields of every frequency.
+    dense_dbc=False (the boundary-derivative products without the 1.6 GB dense matrix per system; the same numbers: tests/test_golden.py).
+    About seven core-minutes; the file holds receiver rows only (< 3 MB)."""
+    mesh, data, sig_true = S.make_config("cfg5")
+    O.setupTensorMesh2D(mesh)
+    mesh.sigma = sig_true.copy()
+    pred_t, _ = O.MT2DFwdSolver(mesh, data)
+    obs, err = S.noisy_observations(pred_t)
+    ny, nz = mesh.gridSize
+    nair = len(mesh.airLayer)
+    mesh.sigma = np.concatenate([np.full(ny * nair, S.SIG_AIR), np.full(ny * (nz - nair), 0.01)])
+    inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, obs, err)
+    m = S.rough_state(len(inv.strModel))
+    inv.strModel = m.copy()
+    keep = {}
+    pred, misfit, grad = O.compDataGradient(mesh, data, inv, HMCPrior(), False, keep)
+    rows = slice(nair * (ny + 1), (nair + 2) * (ny + 1))
+    out = dict(obs=obs, err=err, m=m, pred=pred, misfit=misfit, grad=grad,
+               exTE_rx=keep["exTE"][rows, :], hxTM_rx=keep["hxTM"][rows, :])
+    m_true = np.log(sig_true[inv.activeIdx])
+    inv.strModel = m_true.copy()
+    pred2, misfit2, grad2 = O.compDataGradient(mesh, data, inv, HMCPrior(), False)
+    out.update(pred_true=pred2, misfit_true=misfit2, grad_true=grad2)
+    np.savez_compressed(os.path.join(HERE, "cfg5.npz"), **out)
+    print("cfg5 misfit", misfit, misfit2, "file kB", os.path.getsize(os.path.join(HERE, "cfg5.npz")) // 1024)
+
+
 def make_rho_phase():
     """tiny config with DataType Rho_Pha (apparent resistivity + phase of both polarisations, a tenth of the data
     masked out): observations = oracle response of the true model + 5 % / 1.5 degree noise."""
@@ -230,6 +260,8 @@ if __name__ == "__main__":
             make_cfg3_full()
         elif nm == "cfg5s":
             make_cfg5_subset()
+        elif nm == "cfg5":
+            make_cfg5_full()
         elif nm == "rhophase":
             make_rho_phase()
         else:

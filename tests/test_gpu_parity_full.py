@@ -144,6 +144,51 @@ def test_cfg3_all_sixteen_frequencies_parity():
     ctx.close()
 
 
+def test_cfg3_parity_of_the_four_strip_kernel(monkeypatch):
+    """The headline configuration through k_cocg_persist4 (HMCMT_PERSIST_STRIPS=4: 1 024 threads per workgroup, four waves per SIMD,
+    kernels_persist4.h) against the same golden: rough state and true model, verify on, then the warm-started default path."""
+    monkeypatch.setenv("HMCMT_PERSIST_STRIPS", "4")
+    g = np.load(os.path.join(GOLDEN, "cfg3.npz"))
+    mesh, data, inv, m = make_problem("cfg3")
+    ctx = HipContext(mesh, data, inv, verify=True)
+    info = ctx.persist_info()
+    assert info["strips"] == 4 and info["threads_half"] == 256 and info["workgroups_per_system"] == 8 and info["slots_per_xcd"] == 4
+    _check(ctx, m, g["pred"], float(g["misfit"]), g["grad"], inv, mesh)
+    _, sig_true = S.make_config("cfg3")[1:]
+    m_true = np.log(sig_true[inv.activeIdx])
+    _check(ctx, m_true, g["pred_true"], float(g["misfit_true"]), g["grad_true"], inv, mesh, grad_tol=3e-7, misfit_tol=2e-8)
+    ctx.set_options(verify=0)
+    for _ in range(2):
+        pred, misfit, grad = ctx.grad(m + 0.0)
+    assert relmax(pred, g["pred"]) < PRED_TOL and gerr_split(grad, g["grad"], inv, mesh)[0] < GRAD_TOL
+    info = ctx.persist_info()
+    assert info["solves"] >= 6 and info["placement_fallbacks"] == 0 and info["timeouts"] == 0 and info["enabled"] == 1
+    ctx.close()
+
+
+def test_cfg5_all_thirtytwo_frequencies_parity():
+    """BASELINE configs[4] IN FULL: 400x200 cells + 7 air rows, ALL 32 frequencies, TE+TM, 5 184 data, 64 systems
+    of 82 194 unknowns on the persistent kernel with two column parts -- predData / misfit / gradient / receiver-row fields against
+    the oracle's golden at the rough state and at the true model (tests/golden/make_golden.py::make_cfg5_full, dense_dbc=False)."""
+    g = np.load(os.path.join(GOLDEN, "cfg5.npz"))
+    mesh, data, inv, m = make_problem("cfg5")
+    assert np.array_equal(m, g["m"]) and len(data.freqs) == 32 and len(g["pred"]) == 2 * 32 * 81 and np.array_equal(inv.obsData, g["obs"])
+    ctx = HipContext(mesh, data, inv, verify=True)
+    _check(ctx, m, g["pred"], float(g["misfit"]), g["grad"], inv, mesh, res_tol=2e-8)
+    ex, hx = ctx.fields()
+    ny = mesh.gridSize[0]; zid = len(mesh.airLayer)
+    rows = slice(zid * (ny + 1), (zid + 2) * (ny + 1))
+    assert relmax(ex[rows], g["exTE_rx"]) < 1e-9 and relmax(hx[rows], g["hxTM_rx"]) < 1e-9
+    _, sig_true = S.make_config("cfg5")[1:]
+    m_true = np.log(sig_true[inv.activeIdx])
+    _, _, g_true = _check(ctx, m_true, g["pred_true"], float(g["misfit_true"]), g["grad_true"], inv, mesh, grad_tol=3e-7, misfit_tol=2e-8, res_tol=2e-8)
+    assert np.abs(g_true - g["grad_true"]).max() < 1e-9 * np.abs(g["grad"]).max()
+    info = ctx.persist_info()
+    assert info["workgroups_per_system"] == 30 and info["slots_per_xcd"] == 1 and info["slab_modes"] == 16 and info["column_parts"] == 2
+    _ran_the_persistent_kernel(ctx, 2, width=416)
+    ctx.close()
+
+
 def test_cfg5_mesh_frequency_subset_parity_and_full_run_agreement():
     """BASELINE configs[4]'s mesh (400x200 cells + 7 air rows, 82 194 unknowns per system: since round 5 the persistent kernel
     with two column parts per row block; rounds 1-4: the wide-mesh launch-per-phase kernels) with 3 of its 32 frequencies (100, 0.59, 0.01 Hz): predData / misfit / gradient

@@ -336,6 +336,60 @@ def test_a_misplaced_group_leaves_the_other_groups_results_intact(monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("strips", [2, 4])
+def test_every_group_misplaced_is_the_all_fallback_regime_end_to_end(monkeypatch, capfd, strips):
+    """hmcmt_debug_flags bit 3: EVERY system group of the next launch fails its placement check -- what a device in another
+    partition mode, or a driver that dispatches workgroups to the XCDs in another order than b -> XCD b mod 8
+    (kernels_persist.h:26-28), would do to every launch.  No system is touched by the kernel; the whole
+    evaluation runs the launch-per-phase loop; the context says so ONCE on stderr, stays off for good (why_off = 1: no backoff
+    re-enables it) and keeps giving the oracle's numbers."""
+    monkeypatch.setenv("HMCMT_PERSIST_STRIPS", str(strips))
+    mesh, data, inv, m = make_problem("cfg2")
+    ctx = _ctx(monkeypatch, mesh, data, inv, True, 2, verify=True)
+    assert ctx.persist_info()["strips"] == strips
+    ctx.debug_flags(fail_placement="all")
+    capfd.readouterr()
+    p, f, g = ctx.grad(m)
+    err = capfd.readouterr().err
+    st, info = ctx.stats(), ctx.persist_info()
+    assert "not dispatched to one XCD" in err and err.count("libhmcmt_hip") == 1
+    assert info["placement_fallbacks"] == 1 and info["enabled"] == 0 and info["why_off"] == 1 and info["solves"] == 1
+    assert st["status"] == 0 and st["true_res_max"] < 1e-9
+    po, mo, go = oracle_eval(mesh, data, inv, m)
+    assert relmax(p, po) < 1e-9 and abs(f - mo) / mo < 1e-9 and relmax(g, go) < 1e-7
+    for k in range(3):                                     # ... it stays on the loop, silently, with the same answers
+        p2, f2, g2 = ctx.grad(m + 0.01 * (k + 1))
+    assert capfd.readouterr().err == "" and ctx.persist_info()["solves"] == 1 and ctx.persist_info()["enabled"] == 0 and ctx.stats()["status"] == 0
+    po, mo, go = oracle_eval(mesh, data, inv, m + 0.03)
+    assert relmax(p2, po) < 1e-9 and relmax(g2, go) < 1e-7
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,sweeps", [("cfg2", 1), ("cfg2", 2), ("tiny", 2), ("cfg1", 2)])
+def test_four_strip_kernel_equals_the_two_half_kernel_and_the_oracle(monkeypatch, name, sweeps):
+    """k_cocg_persist4 (kernels_persist4.h: four strips of six tile rows per column, 4 x threads_half threads, 128 VGPRs, four
+    waves per SIMD; opt-in, HMCMT_PERSIST_STRIPS=4) against k_cocg_persist on the same problems: the same iteration counts
+    (+-1), results to the solver tolerance, the oracle's values, bitwise repeatable.  (The headline mesh: tests/test_gpu_parity_full.py.)"""
+    mesh, data, inv, m = make_problem(name)
+    res = {}
+    for strips in (2, 4):
+        monkeypatch.setenv("HMCMT_PERSIST_STRIPS", str(strips))
+        ctx = _ctx(monkeypatch, mesh, data, inv, True, sweeps, verify=True)
+        res[strips] = ctx.grad(m) + (ctx.stats(), ctx.persist_info())
+        if strips == 4:
+            again = ctx.grad(m + 0.0)
+            assert np.array_equal(again[0], res[4][0]) and np.array_equal(again[2], res[4][2])      # bitwise repeatable
+        ctx.close()
+    (p0, f0, g0, s0, i0), (p1, f1, g1, s1, i1) = res[2], res[4]
+    assert i0["strips"] == 2 and i1["strips"] == 4 and i1["solves"] >= 2 and i1["placement_fallbacks"] == 0 and i1["timeouts"] == 0
+    assert i1["threads_half"] == i0["threads_half"] and i1["workgroups_per_system"] == i0["workgroups_per_system"]
+    assert s1["status"] == 0 and s1["fallback_solves"] == 0 and s1["true_res_max"] < 1e-9
+    assert abs(s1["iters_fwd_max"] - s0["iters_fwd_max"]) <= 1 and abs(s1["iters_adj_max"] - s0["iters_adj_max"]) <= 1
+    assert relmax(p1, p0) < 1e-9 and abs(f1 - f0) / abs(f0) < 1e-9 and relmax(g1, g0) < 1e-8
+    po, mo, go = oracle_eval(mesh, data, inv, m)
+    assert relmax(p1, po) < 1e-9 and abs(f1 - mo) / mo < 1e-9 and relmax(g1, go) < 1e-7
+
+
 def test_a_timed_out_wait_falls_back_to_the_launch_per_phase_loop(monkeypatch):
     """A foreign kernel whose backlog of workgroups keeps every CU busy (hmcmt_debug_hog: 1500 workgroups with a CU's whole LDS
     each, 100 ms apiece: six rounds over the chip) competes with the persistent kernel's workgroups for the CUs that come free:

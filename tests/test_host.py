@@ -202,3 +202,12 @@ def test_bench_gpus_n_spawns_one_rank_process_per_gpu():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], capture_output=True, text=True,
                        timeout=300, env=env, cwd=root)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_cu_shares_follow_the_chains_that_actually_run():
+    """parallelHMCSampler(chains_per_gpu=c) with n local chains: shares = the largest of 4, 2, 1 that exceeds neither (ADVICE r5:
+    chains_per_gpu = 4 with two local chains confined each chain to a quarter of every XCD and left half the GPU idle)."""
+    from hmcmt2d_amd.sampler import cu_shares_for
+    assert [cu_shares_for(4, n) for n in (1, 2, 3, 4, 7)] == [1, 2, 2, 4, 4]
+    assert [cu_shares_for(2, n) for n in (1, 2, 3)] == [1, 2, 2]
+    assert cu_shares_for(1, 8) == 1 and cu_shares_for(3, 8) == 2
