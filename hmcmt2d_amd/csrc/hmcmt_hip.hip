@@ -657,7 +657,7 @@ int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout, in
         const bool st = ctx->d_pstamps != nullptr;
 #define PS4L(CW, NYK, RCC, STT) do { if (sweeps == 2) hipLaunchKernelGGL((k_cocg_persist4<CW, 2, 32, NYK, RCC, STT>), grid, dim3(4 * CW), lds4, ctx->stream, a); \
                                      else hipLaunchKernelGGL((k_cocg_persist4<CW, 1, 32, NYK, RCC, STT>), grid, dim3(4 * CW), lds4, ctx->stream, a); } while (0)
-        if (cw == 256 && wk4 == 208 && ctx->persistRC == 4) { if (st) PS4L(256, 208, 4, true); else PS4L(256, 208, 4, false); }
+        if (cw == 256 && wk4 == 208) { if (st) PS4L(256, 208, 4, true); else PS4L(256, 208, 4, false); }
         else if (cw == 256) PS4L(256, 0, 4, false);
         else if (cw == 128) PS4L(128, 0, 4, false);
         else PS4L(64, 0, 4, false);
@@ -812,7 +812,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
                 // (the kernel was to form the residual itself: the systems it did not touch -- still active -- have none yet; the
                 //  launch-per-phase loop's partial sums start from zero)
                 HIPCHK(hipMemsetAsync(k.partB, 0, (size_t)S * MAXNB * sizeof(double), ctx->stream));
-                if (start.resid) hipLaunchKernelGGL(k_resid0, dim3(k.NB, S), dim3(VBLOCK), 0, ctx->stream, k, x, start.resid, (const int*)nullptr, 1);
+                if (start.resid) hipLaunchKernelGGL(k_resid0, dim3(k.NB, S), dim3(VBLOCK), 0, ctx->stream, k, x, start.resid == PS_RESID_FULL ? 0 : start.resid, (const int*)nullptr, 1);
             }
             if (ctx->persistFallbacks == 1)
                 fprintf(stderr, "libhmcmt_hip: the workgroups of a system of the persistent solve kernel were not dispatched to one XCD (a partitioned device, "
@@ -827,7 +827,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
     if (start.begin && !viaPersist && !placeFallback) {
         // (the persistent kernel was to start this solve but did not run after all -- a second context has appeared on the device since
         //  evaluate_once looked --: the start as launches of their own)
-        if (start.resid) hipLaunchKernelGGL(k_resid0, dim3(k.NB, S), dim3(VBLOCK), 0, ctx->stream, k, x, start.resid, ctx->v.sysOn, 0);
+        if (start.resid) hipLaunchKernelGGL(k_resid0, dim3(k.NB, S), dim3(VBLOCK), 0, ctx->stream, k, x, start.resid == PS_RESID_FULL ? 0 : start.resid, ctx->v.sysOn, 0);
         else hipLaunchKernelGGL(k_solve_begin, dim3((S * MAXNB + 255) / 256), dim3(256), 0, ctx->stream, k, ctx->v.sysOn);
     }
     if (start.begin && viaPersist && stalledP) HIPCHK(hipMemsetAsync(k.partB, 0, (size_t)S * MAXNB * sizeof(double), ctx->stream));   // (the fp64 restart's loop: its partial sums start from zero)
@@ -1080,8 +1080,7 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
     const int sweepsF = pick_sweeps(ctx, 0), sweepsA = pick_sweeps(ctx, 1);
     bool fusedStart = fusedStartOk && sweepsF == 1;      // (k_resid_pre does ONE pre-sweep; two go through k_resid0 + the solve's own start)
     // the solves' start -- initial residual, bookkeeping -- inside the persistent kernel (kernels_persist.h, PsLaunch::resid / begin)
-    const bool inKernelStart = ctx->psInKernelStart && ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0 && !ctx->opt.verify &&
-                               !ctx->guardNow && persist_ok(ctx);
+    const bool inKernelStart = ctx->psInKernelStart && ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && ctx->opt.fdm_precision == 0 && !ctx->opt.verify && persist_ok(ctx);
     ctx->sv.sweeps = sweepsF;
     ctx->stats.smoother_sweeps = 10 * sweepsF + (wantGrad ? sweepsA : 0);
     ctx->sweepsUsed[0] = sweepsF; if (wantGrad) ctx->sweepsUsed[1] = sweepsA;
@@ -1244,7 +1243,7 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
             if (ctx->extAWaitPending) { ctx->extAWaitPending = false; HIPCHK(hipStreamWaitEvent(st, ctx->evExtA, 0)); }   // (a forward solve too short to have issued it)
             if (inKernelStart && persist_ok(ctx)) {
                 // (warm start: r = b - A lambda0 with b on the receiver layer's two node rows; cold: the buffer k_src has filled IS the residual)
-                ctx->psStart.resid = warmA ? 2 + v.zid : 0; ctx->psStart.begin = 1;
+                ctx->psStart.resid = warmA ? (sparseSrc ? 2 + v.zid : PS_RESID_FULL) : 0; ctx->psStart.begin = 1;
                 ctx->solveBegun = true;
             } else
             if (warmA && fusedStart) {

