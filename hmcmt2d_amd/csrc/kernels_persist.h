@@ -1154,6 +1154,7 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                                                              (gc * rowU + (i - row * rowU)) * 16, 0, 0, 16);      // (aux 16 = sc1: other CUs wrote these)
                 }
                 if (tidv < 16) reinterpret_cast<unsigned*>(PL)[PS_ROWS * 4 * NYP / 2 + tid] = 0u;          // the last K-group's over-read pad (n16 is a multiple of 64: no lane writes there)
+                __builtin_amdgcn_sched_barrier(0);      // (the planes' loads are the OLDEST in flight: the wait below counts on it)
 #pragma unroll
                 for (int rg = 0; rg < 3; ++rg)
 #pragma unroll
@@ -1178,7 +1179,10 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
                     }
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (the planes' direct loads: in LDS before the barrier)
+            // the planes' direct loads must be in LDS before the barrier; the seventeen loads requested behind them (the epilogue's twelve
+            // operands, the halo rows' r') are not needed before the MFMA loop is through: they stay in flight (loads return in order)
+            if constexpr (CS == 1) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             PS_STAMP(14)                                                        // (the operand planes have landed)
             double ar = 0, ai = 0, zzs = 0;
