@@ -257,16 +257,25 @@ def two_chains_leg(torch, HipContext, mesh, data, inv, local, dev, m_true, mref,
             span[key] = (t0, time.perf_counter())
     th = [threading.Thread(target=run_on_own_stream, args=(c, i)) for i, c in enumerate((ca, cb_))]
     torch.cuda.synchronize()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
+    import gc
+    gc.collect()
+    gc.disable()                      # (no collector pauses inside the timed region, as in timed(): a collection holds the GIL -- BOTH chains' host
+    try:                              #  threads -- for 35-70 ms: one run in seven read 530-650 instead of 840-880 steps/s, one trajectory of both chains at 6-11 ms per step)
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    finally:
+        gc.enable()
     torch.cuda.synchronize()
     t5 = max(e for _, e in span.values()) - min(b for b, _ in span.values())
     res = {"steps_per_s_aggregate": 2 * Ke / t5, "steps_per_chain": Ke,
            "ms_per_step_by_chain": [1e3 * (e - b) / Ke for b, e in (span[0], span[1])],
            "timed": "inside each chain's thread, behind its stream's creation, two warm trajectories and a barrier with the other chain",
            "persistent_solves": [ctxa.persist_info()["solves"], ctxb.persist_info()["solves"]],
+           "timeouts_and_placement_fallbacks": [[c.persist_info()["timeouts"], c.persist_info()["placement_fallbacks"]] for c in (ctxa, ctxb)],
+           "ms_per_step_by_trajectory": [[round(x, 2) for x in c.ms_per_step[-(Ke // LTRAJ):]] for c in (ca, cb_)],
+           "iters_last_step_by_trajectory": [[list(t[:2]) for t in c.iters[-(Ke // LTRAJ):]] for c in (ca, cb_)],
            "slots_per_xcd": [ctxa.persist_info()["slots_per_xcd"], ctxb.persist_info()["slots_per_xcd"]],
            "state": "two independent chains near the true model on ONE GPU: two contexts, two host threads, "
                     "each context on half the CUs of every XCD (CU-masked streams), their persistent solve "

@@ -247,3 +247,72 @@ def test_queue_packing_of_the_persistent_kernel_without_a_device():
     with pytest.raises(HmcmtError):
         persist_pack([1.0, -2.0], 2)
 
+
+
+def _c_prototypes():
+    """name -> (return type, [(type, name)]) of every function the two headers declare."""
+    protos = {}
+    for header in ("hmcmt.h", "hmcmt_debug.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for m in re.finditer(r"^\s*(int|void|const char\*)\s+(hmcmt_[a-z_]+)\s*\(([^;]*?)\)\s*;", text, flags=re.M | re.S):
+            params = []
+            for p in [q.strip() for q in m.group(3).replace("\n", " ").split(",") if q.strip() and q.strip() != "void"]:
+                mm = re.match(r"(.*?)([A-Za-z_][A-Za-z_0-9]*)\s*(\[[^\]]*\])?$", p)
+                ty = (mm.group(1) + ("*" if mm.group(3) else "")).replace(" ", "")
+                params.append((ty, mm.group(2)))
+            protos[m.group(2)] = (m.group(1), params)
+    return protos
+
+
+# which Julia ccall types may carry a C parameter type (julia/HMCMTHip.jl: ComplexF64 arrays are interleaved doubles, Ref{T} is T*)
+_JL_OK = {
+    "hmcmt_ctx**": {"Ref{Ptr{Cvoid}}"}, "hmcmt_comm**": {"Ref{Ptr{Cvoid}}"},
+    "hmcmt_ctx*": {"Ptr{Cvoid}"}, "consthmcmt_ctx*": {"Ptr{Cvoid}"}, "hmcmt_comm*": {"Ptr{Cvoid}"}, "consthmcmt_comm*": {"Ptr{Cvoid}"},
+    "int32_t": {"Int32", "Cint"}, "int64_t": {"Int64"}, "double": {"Float64", "Cdouble"},
+    "constdouble*": {"Ptr{Float64}", "Ptr{ComplexF64}", "Ptr{Cvoid}"}, "double*": {"Ptr{Float64}", "Ptr{ComplexF64}", "Ref{Float64}", "Ptr{Cvoid}"},
+    "constint64_t*": {"Ptr{Int64}"}, "int64_t*": {"Ptr{Int64}", "Ref{Int64}"}, "int32_t*": {"Ptr{Int32}", "Ref{Int32}"},
+    "constuint8_t*": {"Ptr{UInt8}"}, "void*": {"Ptr{UInt8}", "Ptr{Cvoid}"}, "constvoid*": {"Ptr{UInt8}", "Ptr{Cvoid}"},
+    "consthmcmt_options*": {"Ptr{HmcmtOptions}", "Ref{HmcmtOptions}"}, "hmcmt_options*": {"Ref{HmcmtOptions}"}, "hmcmt_stats*": {"Ref{HmcmtStats}"},
+}
+
+
+def test_julia_ccalls_match_the_c_prototypes_argument_by_argument():
+    """julia/HMCMTHip.jl has never been executed (no Julia in the image): every `ccall` in it is held to the C
+    prototype of include/hmcmt.h / hmcmt_debug.h -- return type, NUMBER, ORDER and TYPE of the arguments -- and the values handed to
+    the 25-argument hmcmt_create are checked name by name against the header's parameter names."""
+    src = open(os.path.join(ROOT, "julia", "HMCMTHip.jl")).read()
+    protos = _c_prototypes()
+    seen = set()
+    for m in re.finditer(r"ccall\(\(:(\w+), libhmcmt\),\s*(\w+),\s*\(", src):
+        name, ret = m.group(1), m.group(2)
+        i = j = m.end(); depth = 1
+        while depth:
+            depth += src[j] == "("; depth -= src[j] == ")"; j += 1
+        types = [t.strip() for t in re.split(r",(?![^{]*\})", src[i:j - 1]) if t.strip()]
+        assert name in protos, f"{name}: ccall of a symbol no header declares"
+        cret, params = protos[name]
+        assert (ret, cret) in (("Cint", "int"), ("Cstring", "const char*"), ("Cvoid", "void")), (name, ret, cret)
+        assert len(types) == len(params), f"{name}: {len(types)} ccall argument types, {len(params)} C parameters"
+        for k, (jt, (ct, pname)) in enumerate(zip(types, params)):
+            assert jt in _JL_OK[ct], f"{name}: argument {k + 1} ({pname}) is {ct} in C, {jt} in the ccall"
+        seen.add(name)
+        if name == "hmcmt_create":
+            # the values: one per type, in the header's order (lengths for the counts)
+            k = j
+            while src[k] != ",":
+                k += 1
+            depth = 0; k += 1; start = k
+            while not (src[k] == ")" and depth == 0):
+                depth += src[k] in "(["; depth -= src[k] in ")]"; k += 1
+            vals = [v.strip() for v in re.split(r",(?![^(]*\))", src[start:k]) if v.strip()]
+            assert len(vals) == len(params) == 25
+            expect = {"ny": "ny", "nz": "nz", "yLen": "yLen", "zLen": "zLen", "origin": "origin", "nFreq": "length(mtData.freqs)", "freqs": "freqs",
+                      "nRx": "length(rxY)", "rxY": "rxY", "rxZ": "rxZ", "nComp": "length(compMode)", "compMode": "compMode",
+                      "nData": "length(obs)", "freqID": "freqID", "rxID": "rxID", "dtID": "dtID", "dataID": "dataID", "obs": "obs",
+                      "dataW": "dataW", "nAC": "length(activeIdx)", "activeIdx": "activeIdx", "bgModel": "bgModel", "device_id": "device"}
+            for (ct, pname), v in zip(params, vals):
+                if pname in expect:
+                    assert expect[pname] in v, f"hmcmt_create: parameter {pname} receives `{v}`"
+    for sym in ("hmcmt_create", "hmcmt_grad", "hmcmt_forward", "hmcmt_leapfrog", "hmcmt_leapfrog_device", "hmcmt_set_prior", "hmcmt_get_stats"):
+        assert sym in seen
