@@ -1188,7 +1188,9 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
     // the gradient's tail behind the adjoint one) are handed to solve() to be queued behind the persistent launch at once (SpecFn).
     // Only where that is the plain case: a gradient evaluation with a warm adjoint start (no clearing of the right-hand side), no
     // true-residual check, no guard copy, no HIP-event sampling.
-    const bool sparseSrcPlan = warmA && !ctx->opt.verify && !ctx->guardNow;
+    // (round 6: with the solve's start inside the persistent kernel a COLD adjoint start is the sparse case too -- r = b - A 0 with b read on the
+    //  receiver layer's two node rows: no 11 MB fill of the right-hand side in front of k_src, and the followers are queued speculatively as well)
+    const bool sparseSrcPlan = (warmA || inKernelStart) && !ctx->opt.verify && !ctx->guardNow;
     const bool specPlain = wantGrad && sparseSrcPlan && !ctx->evalSampled;
     const int nsrcBlocks = (2 * (v.ny + 1) + 127) / 128;
     double* const misfitPtr = d_misfit ? d_misfit : ctx->d_misfit;
@@ -1243,14 +1245,14 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
             if (ctx->extAWaitPending) { ctx->extAWaitPending = false; HIPCHK(hipStreamWaitEvent(st, ctx->evExtA, 0)); }   // (a forward solve too short to have issued it)
             if (inKernelStart && persist_ok(ctx)) {
                 // (warm start: r = b - A lambda0 with b on the receiver layer's two node rows; cold: the buffer k_src has filled IS the residual)
-                ctx->psStart.resid = warmA ? (sparseSrc ? 2 + v.zid : PS_RESID_FULL) : 0; ctx->psStart.begin = 1;
+                ctx->psStart.resid = (warmA || sparseSrc) ? (sparseSrc ? 2 + v.zid : PS_RESID_FULL) : 0; ctx->psStart.begin = 1;
                 ctx->solveBegun = true;
             } else
             if (warmA && fusedStart) {
                 launch_resid_pre(ctx, startLds, v.Lam, sparseSrc ? 2 + v.zid : 0);
                 std::swap(ctx->sv.r, ctx->sv.r2);
                 ctx->solveBegun = ctx->preDone = true;
-            } else if (warmA) {
+            } else if (warmA || sparseSrc) {      // (cold and sparse: the persistent kernel was to start this solve and is off since the forward one -- lambda0 = 0, r = b)
                 hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, sparseSrc ? 2 + v.zid : 0, ctx->v.sysOn, 0);
                 ctx->solveBegun = true;
             }
