@@ -715,7 +715,7 @@ int spin_progress(hmcmt_ctx* ctx, int value) {
     return 0;
 }
 constexpr double SWEEPS2_COST = 1.20;       // time of a two-sweep iteration / time of a one-sweep iteration on the launch-per-phase loop (59-60 us / 50 us at the headline size)
-constexpr double SWEEPS2_COST_PERSIST = 1.15, SWEEPS2_COST_PERSIST_CS2 = 1.10;   // ... in the persistent kernel (35.1 / 30.6 us at cfg3, 42.5 / 38.9 at cfg5)
+constexpr double SWEEPS2_COST_PERSIST = 1.12, SWEEPS2_COST_PERSIST_CS2 = 1.08;   // ... in the persistent kernel (round 6 stamps: 33.1 / 29.6 us at cfg3, 40.0 / 37.1 at cfg5; round 5: 1.15 / 1.10)
 constexpr int SWEEPS_PROBE_EVERY = 40;      // in two-sweep mode: every so many solves of a kind one solve runs one sweep, to compare
 // damped Jacobi sweeps on each side of the FDM stage for the next solve of this kind.  Two sweeps cut the iterations by
 // 20 % (smooth models) to 35 % (high-contrast ones) and cost ~20 % more time per iteration: by

@@ -9,7 +9,8 @@ from hmcmt2d_amd import synthetic as S, invsetup as I
 from hmcmt2d_amd.lib import HipContext
 state = sys.argv[1] if len(sys.argv) > 1 else "true"
 ntraj = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-mesh, data, inv0, sig_true = B.build_problem("cfg3")
+cfgname = sys.argv[3] if len(sys.argv) > 3 else "cfg3"
+mesh, data, inv0, sig_true = B.build_problem(cfgname)
 ctx0 = HipContext(mesh, data, inv0)
 m_true = np.log(sig_true[inv0.activeIdx])
 pred_true, _ = ctx0.forward(m_true); ctx0.close()
