@@ -365,6 +365,36 @@ def test_every_group_misplaced_is_the_all_fallback_regime_end_to_end(monkeypatch
     ctx.close()
 
 
+@pytest.mark.parametrize("which", [True, "all"])
+@pytest.mark.parametrize("start", ["1", "0"])
+def test_misplaced_groups_when_the_kernel_was_to_start_the_solve(monkeypatch, which, start):
+    """Round 6: the initial residual and the solve's bookkeeping are formed INSIDE the persistent kernel (PsLaunch::resid / begin;
+    not under options.verify, which the other placement tests use).  A group that fails its placement check -- one, or every one --
+    then leaves systems that have no residual yet: it marks them "to be solved", the host forms their residual (k_resid0 on the active
+    systems only: the other groups' results stay) and its launch-per-phase loop takes them.  Cold and warm-started evaluations, the
+    forward and the adjoint solve (right-hand side on the receiver layer's rows), against HMCMT_PS_START=0 and the oracle."""
+    monkeypatch.setenv("HMCMT_PS_START", start)
+    mesh, data, inv, m = make_problem("cfg2")
+    ctx = _ctx(monkeypatch, mesh, data, inv, True, 2)
+    ctx.grad(m)                                            # a history for the warm start
+    ctx.debug_flags(fail_placement=which)
+    p, f, g = ctx.grad(m + 0.01)
+    info = ctx.persist_info()
+    assert info["placement_fallbacks"] == 1 and info["enabled"] == 0 and info["why_off"] == 1 and ctx.stats()["status"] == 0
+    po, mo, go = oracle_eval(mesh, data, inv, m + 0.01)
+    assert relmax(p, po) < 1e-9 and abs(f - mo) / mo < 1e-9 and relmax(g, go) < 1e-7
+    p2, f2, g2 = ctx.grad(m + 0.02)                        # ... and on with the launch-per-phase loop
+    po, mo, go = oracle_eval(mesh, data, inv, m + 0.02)
+    assert relmax(p2, po) < 1e-9 and relmax(g2, go) < 1e-7 and ctx.persist_info()["solves"] == 3
+    ctx.close()
+    ctx = _ctx(monkeypatch, mesh, data, inv, True, 2)      # the FIRST (cold) evaluation of a context: cold adjoint start, sparse right-hand side
+    ctx.debug_flags(fail_placement=which)
+    p, f, g = ctx.grad(m)
+    po, mo, go = oracle_eval(mesh, data, inv, m)
+    assert relmax(p, po) < 1e-9 and relmax(g, go) < 1e-7 and ctx.persist_info()["placement_fallbacks"] == 1
+    ctx.close()
+
+
 @pytest.mark.parametrize("name,sweeps", [("cfg2", 1), ("cfg2", 2), ("tiny", 2), ("cfg1", 2)])
 def test_four_strip_kernel_equals_the_two_half_kernel_and_the_oracle(monkeypatch, name, sweeps):
     """k_cocg_persist4 (kernels_persist4.h: four strips of six tile rows per column, 4 x threads_half threads, 128 VGPRs, four
