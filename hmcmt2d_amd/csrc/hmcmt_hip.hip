@@ -1265,8 +1265,8 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
             { const int nwbx = (v.nz + v.ny + 127) / 128, ngcx = (v.nCell + 127) / 128;       // (k_wb + k_gradcell: one launch)
               hipLaunchKernelGGL(k_wb_gradcell, dim3(nwbx * S + ngcx * 2 * GRAD_NG), dim3(128), 0, st, vg, solve_rec(ctx, 1), nwbx, ngcx); }
             hipEventRecord(ctx->evRec, st);
-            hipLaunchKernelGGL(k_bcsens_contract, dim3((v.nz + 127) / 128, 2, S), dim3(128), 0, st, vg, ctx->lfMom.on ? ctx->lfMom.L.part : (double*)nullptr);
-            hipLaunchKernelGGL(k_gradfinal, grid1(4 * v.nAC, 128), dim3(128), 0, st, vg, ctx->lfMom);
+            hipLaunchKernelGGL(k_bcsens_contract, dim3((BCC_L * v.nz + 127) / 128, 2, S), dim3(128), 0, st, vg, ctx->lfMom.on ? ctx->lfMom.L.part : (double*)nullptr);
+            hipLaunchKernelGGL(k_gradfinal, grid1(GF_L * v.nAC, 128), dim3(128), 0, st, vg, ctx->lfMom);
         };
         rc = solve(ctx, v.Lam, 1, true, specPlain ? &specA : nullptr);
         const bool specAdj = ctx->specValid;
@@ -1287,8 +1287,8 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
             { const int nwbx = (v.nz + v.ny + 127) / 128, ngcx = (v.nCell + 127) / 128;       // (k_wb (+ the adjoint solve's records) + k_gradcell: one launch)
               hipLaunchKernelGGL(k_wb_gradcell, dim3(nwbx * S + ngcx * 2 * GRAD_NG), dim3(128), 0, st, v, solve_rec(ctx, 1), nwbx, ngcx); }
             HIPCHK(hipEventRecord(ctx->evRec, st));                        // behind the records of the last solve
-            hipLaunchKernelGGL(k_bcsens_contract, dim3((v.nz + 127) / 128, 2, S), dim3(128), 0, st, v, ctx->lfMom.on ? ctx->lfMom.L.part : (double*)nullptr);
-            hipLaunchKernelGGL(k_gradfinal, grid1(4 * v.nAC, 128), dim3(128), 0, st, v, ctx->lfMom);
+            hipLaunchKernelGGL(k_bcsens_contract, dim3((BCC_L * v.nz + 127) / 128, 2, S), dim3(128), 0, st, v, ctx->lfMom.on ? ctx->lfMom.L.part : (double*)nullptr);
+            hipLaunchKernelGGL(k_gradfinal, grid1(GF_L * v.nAC, 128), dim3(128), 0, st, v, ctx->lfMom);
         }
         if (ctx->wantTicks) ctx->hostUs[2] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hostT2).count();
     }

@@ -425,13 +425,40 @@ __global__ __launch_bounds__(64) void k_bcsens_pre(View v) {
     int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
     if (c < v.nz) item_bcsens_pre(v, s, prof, c);
 }
+// Round 6: FOUR lanes per (system, profile, column) -- item_bcsens_contract's nz products in four contiguous quarters of the rows, the
+// quarters added in lane order --: with one lane per column the launch is 107 waves walking 13 batches of loads one after the other
+// (13 us at the headline size, all latency); the gradient's tail behind the adjoint solve is a chain of such kernels.
+constexpr int BCC_L = 4;
 __global__ void k_bcsens_contract(View v, double* lfPart) {
     if (gate_closed(v)) return;
-    int c = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, c = t / BCC_L, l = t % BCC_L, prof = blockIdx.y, s = blockIdx.z;
     // (the step-bound maxima k_gradfinal collects behind this launch start from zero)
     if (lfPart && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x < LFNB) lfPart[threadIdx.x] = 0.0;
     tick_begin(v.ticks, TK_BCSENS);
-    if (c < v.nz) item_bcsens_contract(v, s, prof, c);
+    cplx acc = cplx{0.0, 0.0};
+    const bool on = c < v.nz && v.sysOn[s];
+    if (on) {
+        const cplx* D = v.dBC + ((long)s * 2 + prof) * v.nz * v.nz + c;
+        const cplx* w = (prof == 0 ? v.wL : v.wR) + (long)s * v.nz;
+        const int per = (v.nz + BCC_L - 1) / BCC_L, j0 = l * per, j1 = min(j0 + per, v.nz);
+        int j = j0;
+        for (; j + 8 <= j1; j += 8) {
+            cplx d[8], ww[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { d[q] = D[(long)(j + q) * v.nz]; ww[q] = w[j + q]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += d[q] * ww[q];
+        }
+        for (; j < j1; ++j) acc += D[(long)j * v.nz] * w[j];
+    }
+    // lanes 4c .. 4c+3 are neighbours in a wave (128 threads per workgroup: a multiple of four)
+    const double r1 = __shfl_down(acc.re, 1, BCC_L), r2 = __shfl_down(acc.re, 2, BCC_L), r3 = __shfl_down(acc.re, 3, BCC_L);
+    const double i1 = __shfl_down(acc.im, 1, BCC_L), i2 = __shfl_down(acc.im, 2, BCC_L), i3 = __shfl_down(acc.im, 3, BCC_L);
+    if (c < v.nz && l == 0) {
+        const cplx tot = cplx{((acc.re + r1) + r2) + r3, ((acc.im + i1) + i2) + i3};
+        const long o = (long)s * v.nz + c;
+        if (prof == 0) v.gL[o] = tot; else v.gR[o] = tot;
+    }
     tick_end(v.ticks, TK_BCSENS);
 }
 __global__ void k_gradcell(View v) {
@@ -445,27 +472,31 @@ __global__ __launch_bounds__(64) void k_qterm(View v) {
     int ky = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
     if (ky < v.ny) item_qterm(v, s, ky);
 }
-// final assembly with four lanes per active cell (a latency-bound loop over the systems: 4x the threads), each
-// taking every fourth system / partial sum; the four partial sums are added in lane order
+// final assembly with EIGHT lanes per active cell (round 6; four until then: a latency-bound loop over the systems -- the last kernel of a
+// leapfrog step, and the next step's first waits for it), each taking every eighth system / partial sum; the eight partial sums are
+// added in lane order
+constexpr int GF_L = 8;
 __global__ void k_gradfinal(View v, LfMom mom) {
     if (gate_closed(v)) return;
-    const int t = TID1, a = t >> 2, l = t & 3;
+    const int t = TID1, a = t / GF_L, l = t % GF_L;
     tick_begin(v.ticks, TK_GRADFINAL);
     double g = 0.0;
     if (a < v.nAC) {
         const int cell = v.act[a];
         const int ky = cell % v.ny, kz = cell / v.ny;
-        for (int q = l; q < 2 * GRAD_NG; q += 4) g += v.gPartG[(long)q * v.nCell + cell];
+        for (int q = l; q < 2 * GRAD_NG; q += GF_L) g += v.gPartG[(long)q * v.nCell + cell];
 #pragma unroll 4
-        for (int s = l; s < v.S; s += 4) g += gradfinal_sys(v, s, ky, kz);
+        for (int s = l; s < v.S; s += GF_L) g += gradfinal_sys(v, s, ky, kz);
         if (kz == v.zid)
-            for (int s = l; s < v.S; s += 4) g += v.qPart[(long)s * v.ny + ky];
+            for (int s = l; s < v.S; s += GF_L) g += v.qPart[(long)s * v.ny + ky];
     }
-    // lanes 4a .. 4a+3 are neighbours in a wave (the grid is a multiple of 64 threads)
-    const double g1 = __shfl_down(g, 1, 4), g2 = __shfl_down(g, 2, 4), g3 = __shfl_down(g, 3, 4);
+    // lanes 8a .. 8a+7 are neighbours in a wave (the grid is a multiple of 64 threads)
+    double gs = g;
+#pragma unroll
+    for (int o = 1; o < GF_L; ++o) gs += __shfl_down(g, o, GF_L);
     const bool own = a < v.nAC && l == 0;
     double gd = 0.0;
-    if (own) { gd = exp(v.m[a]) * (((g + g1) + g2) + g3); v.grad[a] = gd; }
+    if (own) { gd = exp(v.m[a]) * gs; v.grad[a] = gd; }
     if (mom.on) {
         // the momentum update of the leapfrog step this gradient belongs to (k_lf_momentum_max's arithmetic, HMCSampler.jl:255-263)
         // and the maxima of |dt*invM*p| for the position update that follows (:237-240; zeroed by k_bcsens_contract)
