@@ -1757,7 +1757,16 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         HIPCHK(hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)mask.size(), mask.data()));
         HIPCHK(hipExtStreamCreateWithCUMask(&ctx->side, (uint32_t)mask.size(), mask.data()));
     } else {
-        HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        // The main stream at the HIGHEST priority: streams of one priority are multiplexed onto GPU_MAX_HW_QUEUES (4) hardware queues in the
+        // order of their creation, and a host that has created streams before this context -- an initialised RCCL process group, torch --
+        // left the main and the side stream on ONE queue: the side stream's 0.33 ms of sensitivity tables per step then ran IN FRONT OF the
+        // solves instead of beside them (round 6: bench.py under a process group 519-531 steps/s against 606-625 without; with
+        // GPU_MAX_HW_QUEUES=8 626).  Another priority is another set of queues.  HMCMT_STREAM_PRIORITY=0: both streams at the default one.
+        int prLeast = 0, prGreatest = 0;
+        const char* ep = getenv("HMCMT_STREAM_PRIORITY");
+        const bool hiPr = !(ep && ep[0] == '0') && hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest) == hipSuccess && prGreatest != prLeast;
+        if (hiPr) HIPCHK(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prGreatest));
+        else { (void)hipGetLastError(); HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); }
         HIPCHK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     }
     // events between the library's own streams: no system-scope fence at the record (HMCMT_EVENT_FLAGS: 0 the default

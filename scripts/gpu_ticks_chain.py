@@ -18,6 +18,10 @@ obs, err = S.noisy_observations(pred_true)
 inv = I.setupInverseDataModel(mesh, [S.SIG_AIR], 0.0, 0.0, obs, err)
 ctx = HipContext(mesh, data, inv, warm_start="extrapolate")
 dev = torch.device("cuda", 0)
+if os.environ.get("HMCMT_BENCH_FORCE_PG"):        # (round 6: what an initialised RCCL process group does to the chain)
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29543")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev); dist.barrier()
 n = ctx.nAC
 start = {"true": m_true, "rough": S.rough_state(n)}[state]
 c = B.Chain(ctx, torch, dev, start, np.full(n, np.log(0.01)), inv.Wm, seed=7)
