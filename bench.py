@@ -438,7 +438,12 @@ def main():
         Ke = min(K, 48)
         # (ii) the same sampler started at the true model
         c2 = Chain(ctx, torch, dev, m_true, mref, inv.Wm, seed=7)
-        c2.run(max(W, 2 * LTRAJ)); c2.iters.clear(); a0, r0 = c2.accepted, c2.rejected     # (two trajectories: the first one starts from
+        c2.run(max(W, 2 * LTRAJ))
+        for _ in range(4):                # (... and until the chain has taken BOTH branches of the accept test once, six trajectories at most: the first
+            if c2.accepted and c2.rejected:   #  accepted proposal is the first use of the device leapfrog's "start from the end gradient" path -- on a fresh
+                break                     #  box its first launch cost 26 ms inside a 29 ms timed region: near_true_state read 360 for 690)
+            c2.run(LTRAJ)
+        c2.iters.clear(); a0, r0 = c2.accepted, c2.rejected     # (two trajectories: the first one starts from
         #  the headline chain's fields and iteration counts, a transient of the context's history, not of this state)
         t2 = timed(torch, None, lambda: c2.run(Ke))
         s2 = c2.summary(); s2["accepted"] -= a0; s2["rejected"] -= r0
