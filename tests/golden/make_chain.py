@@ -35,7 +35,20 @@ def start_model(mesh, inv):
 
 # the second chain (round 4): BASELINE configs[0]'s mesh -- 96 x 49 earth cells, 4 frequencies, the 2-layer model without the
 # block (synthetic.CONFIGS["cfg1"], observations of cfg1.npz) --, 100 samples, the same sampler settings
-CHAINS = {"cfg2": dict(nsamples=NSAMPLES, burn=50), "cfg1": dict(nsamples=100, burn=25)}
+# the third chain (round 6; VERDICT r5 weak 9: "posterior parity runs at half the example's step"): the reference's OWN example directory
+# HMCMT/examples/dprism3d as shipped (tests/golden/examples/dprism3d: startupfile, model and data file unchanged) at the example's own
+# settings -- dt = 0.03, L in [6, 10], lambda = 1, rho in [1, 1e4] ohm-m (startupfile:3-8) -- from the file's own start model, the
+# reference model pinned to the file's 100 ohm-m (`rhoref`: the reference draws it at random, HMCSampler.jl:100-109);
+# 60 samples (about half an hour of oracle time)
+CHAINS = {"cfg2": dict(nsamples=NSAMPLES, burn=50), "cfg1": dict(nsamples=100, burn=25), "dprism3d": dict(nsamples=60, burn=15)}
+
+
+def example_problem(name):
+    """(mesh, data, inv, prior) of a reference example directory, read through readstartupFile, with the chain length of CHAINS"""
+    from hmcmt2d_amd.fileio import readstartupFile
+    mesh, data, inv, prior = readstartupFile(os.path.join(HERE, "examples", name, "startupfile"))
+    prior.totalsamples = CHAINS[name]["nsamples"]; prior.burninsamples = CHAINS[name]["burn"]
+    return mesh, data, inv, prior
 
 
 def chain_prior_of(name):
@@ -54,12 +67,16 @@ if __name__ == "__main__":
     from tests.helpers import make_problem
     name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
     nmax = int(sys.argv[2]) if len(sys.argv) > 2 else None         # (a shorter trial run: nothing is written)
-    mesh, data, inv, _ = make_problem(name)
-    O.setupTensorMesh2D(mesh)
-    prior = chain_prior_of(name)
+    if name == "dprism3d":
+        mesh, data, inv, prior = example_problem(name)
+        O.setupTensorMesh2D(mesh)
+    else:
+        mesh, data, inv, _ = make_problem(name)
+        O.setupTensorMesh2D(mesh)
+        prior = chain_prior_of(name)
+        inv.strModel = start_model_of(name, mesh, inv)
     if nmax:
         prior.totalsamples = nmax; prior.burninsamples = min(prior.burninsamples, nmax // 2)
-    inv.strModel = start_model_of(name, mesh, inv)
     t0 = time.time()
     hm, st, hd = O.runHMCSampler(mesh, data, copy.deepcopy(inv), prior, np.random.default_rng(SEED), rhoref=RHOREF, dense_dbc=False)
     print("chain done in %.0f s: accepted %d of %d, nfevals %d, misfit %.1f -> %.1f" % (
