@@ -95,6 +95,9 @@ struct hmcmt_ctx {
     bool wantTicks = false;               // HMCMT_TICKS: in-kernel wall-clock stamps (View::ticks), printed at destroy
     int bcCW = 0, bcSlots = 1;            // k_bc_fused: boundary columns per workgroup (0: k_bc_layers + k_bc_forward), edge slots
     size_t bcLds = 0;
+    int bcbCW = 0, bcbSlots = 1;          // k_bc_blocked (meshes k_bc_fused's slabs do not fit): columns per workgroup (0: the two-kernel form)
+    int bcbNT = 512, bcbLBu = 14, bcbLBd = 8;   // its threads, layers per block of the two recurrences
+    size_t bcbLds = 0;
     cplx* d_fieldsOut = nullptr;
     // pinned host staging
     int* h_nactive = nullptr;
@@ -1128,6 +1131,8 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
         if (!freezeBC) {
             if (ctx->bcCW > 0) {
                 hipLaunchKernelGGL(k_bc_fused, dim3((v.ny + ctx->bcCW) / ctx->bcCW, v.nFreq), dim3(256), ctx->bcLds, st, v, ctx->bcCW, ctx->bcSlots);
+            } else if (ctx->bcbCW > 0) {
+                hipLaunchKernelGGL(k_bc_blocked, dim3((v.ny + ctx->bcbCW) / ctx->bcbCW, v.nFreq), dim3(ctx->bcbNT), ctx->bcbLds, st, v, ctx->bcbCW, ctx->bcbSlots, ctx->bcbLBu, ctx->bcbLBd);
             } else {
                 hipLaunchKernelGGL(k_bc_layers, dim3((v.ny + 1 + 63) / 64, v.nz, v.nFreq), dim3(64), 0, st, v);
                 hipLaunchKernelGGL(k_bc_forward, dim3((v.ny + 1 + 63) / 64, v.nFreq), dim3(64), 4 * (size_t)v.nz * sizeof(cplx), st, v);
@@ -1808,6 +1813,25 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
             if (cw > 0 && cw <= 256 && lds <= (size_t)80 * 1024 &&
                 hipFuncSetAttribute(reinterpret_cast<const void*>(k_bc_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess) {
                 ctx->bcCW = cw; ctx->bcSlots = slots; ctx->bcLds = lds;
+            }
+            // otherwise the layer-blocked form (HMCMT_BC_BLOCKED = 0: the two-kernel form; "columns[,threads[,up layers[,down layers]]]"
+            // per workgroup and block)
+            // default: 1 024 threads (15 producer waves beside the chain wave: the transcendental work needs the occupancy), columns
+            // such that the workgroups of a frequency divide its columns evenly and fill the chip at the stress size (401 columns, 32
+            // frequencies: 8 x 51 -> 256 workgroups, one per CU), as many layers per bottom -> top block as the producers have threads
+            int nt = 1024, cb = 64, lbu = 0, lbd = 8;
+            { const int g = (cols + 63) / 64; int per = 256 / std::max(1, ctx->hp.nFreq); per = std::max(g, std::min(per, (cols + 15) / 16)); cb = (cols + per - 1) / per; }
+            if (const char* eb = getenv("HMCMT_BC_BLOCKED")) sscanf(eb, "%d,%d,%d,%d", &cb, &nt, &lbu, &lbd);
+            const bool blockedOff = cb <= 0;
+            cb = std::max(1, std::min(cb, 64)); nt = std::max(128, std::min(1024, nt / 64 * 64));
+            if (lbu <= 0) lbu = (nt - 64) / cb;
+            lbu = std::max(1, std::min(std::min(lbu, nz), (nt - 64) / cb));
+            lbd = std::max(1, std::min(std::min(lbd, nz), (nt - 64) / cb));
+            const int bslots = cols <= cb ? 2 : 1;
+            const size_t blds = ((size_t)2 * std::max(3 * lbu, 5 * lbd) * cb + (size_t)bslots * 2 * nz) * sizeof(cplx);
+            if (ctx->bcCW == 0 && !blockedOff && blds <= (size_t)150 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_bc_blocked), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess) {
+                ctx->bcbCW = cb; ctx->bcbSlots = bslots; ctx->bcbLds = blds; ctx->bcbNT = nt; ctx->bcbLBu = lbu; ctx->bcbLBd = lbd;
             }
         }
         ctx->wantTicks = getenv("HMCMT_TICKS") != nullptr;

@@ -261,6 +261,214 @@ __global__ __launch_bounds__(256) void k_bc_fused(View v, int CW, int nslot) {
     }
     tick_end(v.ticks, TK_BC);
 }
+// The same in one launch for meshes whose slabs do NOT fit k_bc_fused's LDS (the stress size: 207 layers x 401 columns x 32
+// frequencies; until round 6 k_bc_layers wrote and k_bc_forward read a 340 MB table there, 75 + 194 us, the second one 224 waves
+// walking 52 blocks of loads one after the other).  LAYER BLOCKS through a two-buffer ring in LDS: wave 0 runs the serial recurrences
+// of the workgroup's CW columns (one lane each) on block b while the other waves build the per-layer terms of block b+1, one barrier
+// per block.  Bottom -> top (blocks of LBu layers) the producers do the transcendental work (layer_up_terms: k, e+, zp, th,
+// zp*(zp*th)) -- the three terms of the impedance recurrence go to the ring, k and e+ to a stash in global memory (32 B per layer and
+// column: 85 MB at the stress size, it stays in the Infinity Cache) --; top -> bottom (blocks of LBd layers) they read k, k of the
+// layer below and e+ back, BCB_D blocks ahead of their use, and form the amplitude propagation's four terms (layer_down_terms: no
+// transcendentals).  Same item functions and the same order of operations per column as k_bc_fused / bc1d_up / bc1d_down (the
+// projective pair is rescaled by an exact power of two every four layers: no effect on the quotient).
+// LDS: max(ring[2][3][LBu][CW], ring[2][5][LBd][CW]) complex, then the edge column(s)' amplitudes, amp[nslot][nz][2].
+// The host makes LBu * CW and LBd * CW <= the number of producer threads (one item per producer and block).
+constexpr int BCB_D = 3;
+// workgroup barrier that orders LDS only: __syncthreads() also drains the vector-memory queue (s_waitcnt vmcnt(0)), which would make
+// every block of the amplitude pass wait for the stash entries it has just requested for three blocks later
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__global__ __launch_bounds__(1024) void k_bc_blocked(View v, int CW, int nslot, int LBu, int LBd) {
+    extern __shared__ __attribute__((aligned(16))) char smem_bcb[];
+    tick_begin(v.ticks, TK_BC);
+    const int nz = v.nz, bsu = LBu * CW, bsd = LBd * CW, nbu = (nz + LBu - 1) / LBu, nbd = (nz + LBd - 1) / LBd;
+    cplx* ring = reinterpret_cast<cplx*>(smem_bcb);
+    cplx* amp = ring + 2 * max(3 * bsu, 5 * bsd);
+    __shared__ FwdTop top[2];
+    __shared__ int deadAt[2];
+    const int col0 = blockIdx.x * CW, f = blockIdx.y;
+    const bool onE = v.sysOn[f] != 0, onH = v.sysOn[v.nFreq + f] != 0;
+    if (!onE && !onH) return;
+    const double omega = v.omega[f];
+    cplx* XE = v.X + (long)f * v.vstride;
+    cplx* XH = v.X + (long)(v.nFreq + f) * v.vstride;
+    const long ls = v.ny + 1, qs = (long)nz * ls;
+    cplx* stK = v.fwdTab + (long)f * FWD_NQ * qs;         // the stash: k, e+ of every layer and column of this frequency
+    cplx* stE = stK + qs;
+    const bool has0 = col0 == 0, hasN = col0 <= v.ny && v.ny < col0 + CW;
+    const bool chain = threadIdx.x < 64;
+    const int ptid = (int)threadIdx.x - 64;
+    const int col = col0 + threadIdx.x;
+    const bool serial = (int)threadIdx.x < CW && col <= v.ny;
+    const bool isEdge = serial && (col == 0 || col == v.ny);
+    const int slot = (col == 0 || nslot == 1) ? 0 : 1;    // (one slot: the two edge columns are in different workgroups)
+    if (serial) {
+        if (onE) XE[nidx(v, col, 0)] = cplx{1.0, 0.0};    // top row incl. corners
+        if (onH) XH[nidx(v, col, 0)] = cplx{1.0, 0.0};
+    }
+    // block b of the impedance recurrence: layers nz-1 - LBu b - t (slabs 0 zp, 1 th, 2 zp*(zp*th)) into buffer b & 1; one item per
+    // thread and block, its conductivity and thickness requested one block ahead (up_fetch) of the transcendental work (up_item)
+    auto up_fetch = [&](int b, int item, double& sig, double& h) {
+        sig = 1.0; h = 1.0;
+        const int t = item / CW, c = item - t * CW, j = nz - 1 - b * LBu - t;
+        if (b < nbu && item < bsu && j >= 0) { sig = bc_column_sigma(v, j, min(col0 + c, v.ny)); h = v.zLen[j]; }
+    };
+    auto up_item = [&](int b, int item, double sig, double h) {
+        const int t = item / CW, c = item - t * CW, j = nz - 1 - b * LBu - t;
+        if (item >= bsu || j < 0) return;
+        cplx* B = ring + (b & 1) * 3 * bsu;
+        cplx kk, ep, zp, th, zt;
+        layer_up_terms(sig, omega, h, kk, ep, zp, th, zt);
+        B[item] = zp; B[bsu + item] = th; B[2 * bsu + item] = zt;
+        if (col0 + c <= v.ny) { stK[(long)j * ls + col0 + c] = kk; stE[(long)j * ls + col0 + c] = ep; }
+    };
+    // block b of the amplitude propagation: layers LBd b + t (slabs 0 k of the layer below, 1..4 m11 m12 m21 m22) into buffer b & 1;
+    // producer p has item p of every block, its three stash entries are requested BCB_D blocks ahead (dn_load) of their use (dn_store)
+    struct DnIn { cplx k, kn, ep; };
+    static_assert(BCB_D == 3, "three register slots");
+    const int dt_ = ptid >= 0 ? ptid / CW : 0, dc_ = ptid >= 0 ? ptid - dt_ * CW : 0;
+    auto dn_load = [&](int b, DnIn& p) {
+        const int i = b * LBd + dt_;
+        if (b < nbd && ptid < bsd && i < nz) {
+            const long o = (long)i * ls + min(col0 + dc_, v.ny);
+            p.k = stK[o]; p.ep = stE[o];
+            p.kn = stK[i + 1 < nz ? o + ls : o];          // (an index, not a select of the two values: that one became a select of ADDRESSES, the slot's in scratch memory)
+        }
+    };
+    auto dn_store = [&](int b, const DnIn& p) {
+        cplx* B = ring + (b & 1) * 5 * bsd;
+        const int i = b * LBd + dt_;
+        if (b < nbd && ptid < bsd && i < nz) {
+            cplx m11, m12, m21, m22;
+            layer_down_terms(p.k, p.kn, i + 1 >= nz, p.ep, m11, m12, m21, m22);
+            B[ptid] = p.kn; B[bsd + ptid] = m11; B[2 * bsd + ptid] = m12; B[3 * bsd + ptid] = m21; B[4 * bsd + ptid] = m22;
+        }
+    };
+    const cplx one = cplx{1.0, 0.0};
+    double sgN, hzN;
+    up_fetch(0, threadIdx.x, sgN, hzN);
+    up_item(0, threadIdx.x, sgN, hzN);
+    if (!chain) up_fetch(1, ptid, sgN, hzN);
+    __syncthreads();
+    // --- impedance bottom -> top (bc1d_up): Z = N/D carried projectively
+    cplx zn = one, zd = one;
+    for (int b = 0; b < nbu; ++b) {
+        if (!chain) {
+            const double s1 = sgN, h1 = hzN;
+            up_fetch(b + 2, ptid, sgN, hzN);
+            if (b + 1 < nbu) up_item(b + 1, ptid, s1, h1);
+        } else if (serial) {
+            const cplx* B = ring + (b & 1) * 3 * bsu + threadIdx.x;
+            const int cnt = min(LBu, nz - b * LBu);
+            if (b == 0) zn = B[0];                        // half-space below the last layer with the last layer's conductivity
+            for (int h = 0; h < cnt; h += 4) {
+                cplx c1[4], c2[4], c3[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int tt = h + t < cnt ? h + t : cnt - 1;
+                    c1[t] = B[tt * CW]; c3[t] = B[bsu + tt * CW]; c2[t] = B[2 * bsu + tt * CW];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (h + t < cnt) {
+                        const cplx nn = c1[t] * zn + c2[t] * zd;
+                        zd = c1[t] * zd + zn * c3[t];
+                        zn = nn;
+                    }
+                const int e = -ilogb(fmax(fmax(fabs(zd.re), fabs(zd.im)), fmax(fabs(zn.re), fabs(zn.im))));
+                if (e > -1000 && e < 1000) {              // (zero / inf / nan: leave alone, the division below reports it)
+                    zn = cplx{ldexp(zn.re, e), ldexp(zn.im, e)};
+                    zd = cplx{ldexp(zd.re, e), ldexp(zd.im, e)};
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // (the stash entries were written by threads of this workgroup: the barrier above orders them)
+    // --- amplitudes top -> bottom (bc1d_down)
+    const double omu0 = omega * MU0, iomu0 = 1.0 / omu0;
+    cplx eu = one, ed = one, kj = one;
+    FwdTop tp;
+    bool dead = false;
+    int dAt = nz;                                         // first layer behind the overflow cut-off
+    cplx* ea = amp + (long)slot * 2 * nz;
+    // The chain wave and the producers walk the blocks in loops of their OWN (the same number of barriers in each: the hardware counts
+    // arrivals, not program counters): in one loop the producers' three register slots would stay allocated through the chain's steps,
+    // and at 128 registers per lane (1 024 threads) the chain spilled.
+    if (chain) {
+        if (serial) {
+            const cplx ztmp = zn / zd;
+            kj = stK[col];
+            const cplx a = omu0 / (ztmp * kj);
+            eu = 0.5 * (one - a); ed = 0.5 * (one + a);
+            tp.if0E = crecip(eu + ed); tp.if0H = crecip(((ed - eu) * kj) * iomu0); tp.iomu0 = iomu0;
+        }
+        lds_barrier();
+        for (int b = 0; b < nbd; ++b) {
+            if (serial) {
+                const cplx* B = ring + (b & 1) * 5 * bsd + threadIdx.x;
+                const int cnt = min(LBd, nz - b * LBd);
+                for (int h = 0; h < cnt; h += 4) {
+                    cplx kn_[4], m11[4], m12[4], m21[4], m22[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int tt = h + t < cnt ? h + t : cnt - 1;
+                        kn_[t] = B[tt * CW]; m11[t] = B[bsd + tt * CW]; m12[t] = B[2 * bsd + tt * CW]; m21[t] = B[3 * bsd + tt * CW]; m22[t] = B[4 * bsd + tt * CW];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (h + t < cnt) {
+                            const int i = b * LBd + h + t;
+                            const cplx nu = m11[t] * eu + m12[t] * ed;
+                            const cplx nd = m21[t] * eu + m22[t] * ed;
+                            const double e2 = cabs2(nu + nd), e1 = cabs2(eu + ed);   // |.|^2: same ordering as |.|
+                            dead = dead || e2 - e1 > 0.0 || isnan(e2);               // overflow cut-off: zero from here down
+                            eu = nu; ed = nd; kj = kn_[t];
+                            if (isEdge) { ea[2 * i] = eu; ea[2 * i + 1] = ed; if (dead && dAt > i) dAt = i; }
+                        }
+                }
+            }
+            lds_barrier();
+        }
+    } else {
+        DnIn p0, p1, p2;                                  // (named, not an array: the slot of a block, b % 3, is a compile-time choice)
+        dn_load(0, p0); dn_load(1, p1); dn_load(2, p2);
+        dn_store(0, p0);
+        dn_load(3, p0);
+        lds_barrier();
+        // while the chain walks block b: form block b+1 from its slot and request block b+4 into it
+        for (int b0 = 0; b0 < nbd; b0 += BCB_D) {
+            dn_store(b0 + 1, p1); dn_load(b0 + 1 + BCB_D, p1);
+            lds_barrier();
+            if (b0 + 1 < nbd) { dn_store(b0 + 2, p2); dn_load(b0 + 2 + BCB_D, p2); lds_barrier(); }
+            if (b0 + 2 < nbd) { dn_store(b0 + 3, p0); dn_load(b0 + 3 + BCB_D, p0); lds_barrier(); }
+        }
+    }
+    if (serial) {
+        if (isEdge) { top[slot] = tp; deadAt[slot] = dAt; }
+        else {
+            cplx lastE, lastH;
+            fwd_outputs(tp, eu, ed, kj, dead, lastE, lastH);
+            if (onE) XE[nidx(v, col, nz)] = lastE;
+            if (onH) XH[nidx(v, col, nz)] = lastH;
+        }
+    }
+    if (has0 || hasN) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nz; i += blockDim.x) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (e == 0 ? !has0 : !hasN) continue;
+                const int ecol = e == 0 ? 0 : v.ny, sl = (e == 0 || nslot == 1) ? 0 : 1;
+                const cplx kjn = stK[(long)(i + 1 < nz ? i + 1 : nz - 1) * ls + ecol];      // k of the layer below (the last layer: its own)
+                cplx oE, oH;
+                fwd_outputs(top[sl], amp[((long)sl * nz + i) * 2], amp[((long)sl * nz + i) * 2 + 1], kjn, i >= deadAt[sl], oE, oH);
+                if (onE) XE[nidx(v, ecol, 1 + i)] = oE;
+                if (onH) XH[nidx(v, ecol, 1 + i)] = oH;
+            }
+        }
+    }
+    tick_end(v.ticks, TK_BC);
+}
 __global__ __launch_bounds__(64) void k_sens_layers(View v) {
     int j = blockIdx.x * blockDim.x + threadIdx.x, prof = blockIdx.y, s = blockIdx.z;
     if (j <= v.nz) item_sens_layers(v, s, prof, j);

@@ -323,12 +323,16 @@ def test_full_fields_adjoint_fields_and_per_system_terms():
             assert shallow < GRAD_TOL and deep < GRAD_DEEP_TOL, (md, f, shallow, deep)
 
 
-@pytest.mark.parametrize("columns", ["0", "2", "16"])
-def test_boundary_fields_by_every_kernel_form(columns, monkeypatch):
-    """The Dirichlet values of tiny.npz through the two-kernel form (HMCMT_BC_FUSED=0: k_bc_layers + k_bc_forward) and
-    through k_bc_fused with 2 and with 16 boundary columns per workgroup -- 16 puts both edge columns of the 13-column
-    mesh into one workgroup (its two-slot case), which the column count chosen for real meshes never does."""
+@pytest.mark.parametrize("columns,blocked", [("0", "0"), ("2", "0"), ("16", "0"), ("0", "4,256,8,8"), ("0", "16,128,4,3")])
+def test_boundary_fields_by_every_kernel_form(columns, blocked, monkeypatch):
+    """The Dirichlet values of tiny.npz through the two-kernel form (HMCMT_BC_FUSED=0, HMCMT_BC_BLOCKED=0: k_bc_layers +
+    k_bc_forward), through k_bc_fused with 2 and with 16 boundary columns per workgroup -- 16 puts both edge columns of the
+    13-column mesh into one workgroup (its two-slot case), which the column count chosen for real meshes never does -- and
+    through the layer-blocked k_bc_blocked (the stress size's form) with 4 columns per workgroup of 256 threads (11 layers:
+    one whole block of 8 and one of 3) and with 16 per workgroup of 128 (blocks of 4 bottom -> top, of 3 top -> bottom: more
+    blocks than the prefetch is deep)."""
     monkeypatch.setenv("HMCMT_BC_FUSED", columns)
+    monkeypatch.setenv("HMCMT_BC_BLOCKED", blocked)
     g = np.load(os.path.join(GOLDEN, "tiny.npz"))
     mesh, data, inv, m = make_problem("tiny")
     ny, nz = mesh.gridSize
@@ -342,6 +346,39 @@ def test_boundary_fields_by_every_kernel_form(columns, monkeypatch):
             sc = np.abs(ref[:, f]).max()
             assert np.abs(got[io, f] - g[f"{md}{f}_bc"]).max() < 1e-10 * sc
     ctx.close()
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg1"])
+def test_layer_blocked_boundary_fields_equal_the_fused_ones(name, monkeypatch):
+    """k_bc_blocked (layer blocks through an LDS ring, the form of meshes too deep and wide for k_bc_fused's slabs) against
+    k_bc_fused on meshes with several whole layer blocks: the same Dirichlet values on the boundary nodes of every system and
+    the same predicted data.  Same item functions and order of operations per column; the two kernels' unrolled steps differ
+    in the last bits (1e-15 of the value down to the last rows).  In the thick padding layers at the bottom the amplitude
+    recurrence (mt1DField.jl:62-83: two amplitudes that grow like e^{+a} per layer while their sum decays like e^{-a})
+    amplifies such a difference up to a thousandfold per layer, in any implementation (k_bc_fused against the ORACLE shows the
+    same there): 1e-12 of the field's scale in the upper three quarters of the rows, 1e-8 below (where the values are 1e-4 of
+    the surface field and less)."""
+    mesh, data, inv, m = make_problem(name)
+    ny, nz = mesh.gridSize
+    from oracle import hmcmt_oracle as O
+    ii, io = O.getBoundaryIndex(ny, nz)
+    io = np.asarray(io)
+    upper = io[io // (ny + 1) <= (3 * nz) // 4]
+    out = {}
+    for form, env in (("fused", {}), ("blocked", {"HMCMT_BC_FUSED": "0", "HMCMT_BC_BLOCKED": "24,512,14,8"})):
+        for k in ("HMCMT_BC_FUSED", "HMCMT_BC_BLOCKED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        ctx = HipContext(mesh, data, inv)
+        pred, _, _ = ctx.grad(m)
+        ex, hx = ctx.fields()
+        out[form] = (pred, ex, hx)
+        ctx.close()
+    for a, b in zip(out["fused"][1:], out["blocked"][1:]):
+        assert np.abs(a[upper] - b[upper]).max() <= 1e-12 * np.abs(a).max()
+        assert np.abs(a[io] - b[io]).max() <= 1e-8 * np.abs(a).max()
+    assert np.abs(out["fused"][0] - out["blocked"][0]).max() <= 1e-10 * np.abs(out["fused"][0]).max()
 
 
 def test_rho_phase_data_type():
