@@ -201,6 +201,8 @@ struct hmcmt_ctx {
     unsigned persistSpin = PS_SPIN_LIMIT; // HMCMT_PS_SPIN: polls before a wait of the kernel gives up (tests shorten it)
     struct PsStart { int resid = 0, begin = 0; };      // the solve's start inside the persistent kernel (PsLaunch::resid / begin): set by evaluate_once for the NEXT solve
     PsStart psStart{};
+    bool lazyDinv = true;                 // HMCMT_LAZY_DINV=0: k_coef_all writes every system's Jacobi diagonal in every evaluation, as until round 6 (A/B)
+    bool dinvValid = true;                // Solver::dinv / dinv32 belong to the current model (ensure_dinv)
     bool psInKernelStart = true;          // HMCMT_PS_START=0: k_resid0 / k_solve_begin in launches of their own, as until round 5 (A/B)
     int persistWhyOff = 0;                // why persistOn is false: 1 = a placement fallback (for good), 2 = a timed-out wait (backoff)
     long persistBackoff = 0;              // after a timed-out wait: solves on the launch-per-phase loop before the kernel is tried again (doubles per timeout)
@@ -746,6 +748,13 @@ SolveRec solve_rec(hmcmt_ctx* ctx, int kind) {
 // (18 us behind the forward solve, 11 behind the adjoint one) run under kernels that are already in the queue.  ctx->specValid
 // says whether they ran; if not (a stalled, failed or displaced solve: they returned at once) the caller queues them again.
 using SpecFn = std::function<void(const int* gate, int gen)>;
+// The Jacobi diagonals of every system for the kernels of the launch-per-phase loop, where k_coef_all left them out (an evaluation that
+// was to run in the persistent kernel: a placement fallback, a stagnated system's fp64 restart, a second context on the device).
+void ensure_dinv(hmcmt_ctx* ctx) {
+    if (ctx->dinvValid) return;
+    hipLaunchKernelGGL(k_dinv, dim3(ctx->sv.NB, ctx->sv.S), dim3(VBLOCK), 0, ctx->stream, ctx->sv, ctx->jacobiW);
+    ctx->dinvValid = true;
+}
 int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn* spec = nullptr) {
     Solver& k = ctx->sv;
     const View& v = ctx->v;
@@ -811,6 +820,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
             // groups -- this context goes back to the launch-per-phase loop for good
             ctx->persistOn = false; ctx->persistWhyOff = 1; ctx->persistBackoff = 0; ++ctx->persistFallbacks;
             placeFallback = true;
+            ensure_dinv(ctx);
             if (start.begin) {
                 // (the kernel was to form the residual itself: the systems it did not touch -- still active -- have none yet; the
                 //  launch-per-phase loop's partial sums start from zero)
@@ -827,6 +837,7 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
             else if (*(volatile int*)ctx->h_stall) stalledP = true;
         }
     }
+    if (!(viaPersist && done)) ensure_dinv(ctx);          // (everything below that touches the systems again reads the diagonals)
     if (start.begin && !viaPersist && !placeFallback) {
         // (the persistent kernel was to start this solve but did not run after all -- a second context has appeared on the device since
         //  evaluate_once looked --: the start as launches of their own)
@@ -1158,7 +1169,11 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
         }
         HIPCHK(issue_pivot(sA));
         if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI && !ctx->noCoefAll) {
-            hipLaunchKernelGGL(k_coef_all, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, sB, v, ctx->sv, ctx->jacobiW, const_cast<float4*>(ctx->sv.cf32));
+            // (the per-system Jacobi diagonals only where something will read them: not the persistent kernel -- ensure_dinv)
+            const bool lazy = ctx->lazyDinv && inKernelStart;
+            hipLaunchKernelGGL(k_coef_all, dim3(lazy ? std::max(ctx->sv.NB, (int)std::min<long>(512, (v.vstride + VBLOCK - 1) / VBLOCK)) : ctx->sv.NB, lazy ? 2 : S), dim3(VBLOCK), 0, sB, v, ctx->sv, ctx->jacobiW, const_cast<float4*>(ctx->sv.cf32),
+                               lazy ? v.nFreq : 1);
+            ctx->dinvValid = !lazy;
         } else {
             hipLaunchKernelGGL(k_coef, grid1(nodes, 256), dim3(256), 0, sB, v, 0, 1, 1, 0);
             if (ctx->opt.precond == HMCMT_PRECOND_FDM_JACOBI) {
@@ -1254,10 +1269,12 @@ int evaluate_once(hmcmt_ctx* ctx, const double* d_m, bool wantGrad, double* d_pr
                 ctx->solveBegun = true;
             } else
             if (warmA && fusedStart) {
+                ensure_dinv(ctx);
                 launch_resid_pre(ctx, startLds, v.Lam, sparseSrc ? 2 + v.zid : 0);
                 std::swap(ctx->sv.r, ctx->sv.r2);
                 ctx->solveBegun = ctx->preDone = true;
             } else if (warmA || sparseSrc) {      // (cold and sparse: the persistent kernel was to start this solve and is off since the forward one -- lambda0 = 0, r = b)
+                ensure_dinv(ctx);
                 hipLaunchKernelGGL(k_resid0, dim3(ctx->sv.NB, S), dim3(VBLOCK), 0, st, ctx->sv, v.Lam, sparseSrc ? 2 + v.zid : 0, ctx->v.sysOn, 0);
                 ctx->solveBegun = true;
             }
@@ -1838,6 +1855,7 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
         ctx->noFusedStart = getenv("HMCMT_NO_FUSED_START") != nullptr;
         ctx->noSigmaRows = getenv("HMCMT_NO_SIGMA_ROWS") != nullptr;
         ctx->noCoefAll = getenv("HMCMT_NO_COEF_ALL") != nullptr;
+        if (const char* el = getenv("HMCMT_LAZY_DINV")) ctx->lazyDinv = el[0] != '0';
         if (const char* ed = getenv("HMCMT_DEBUG_FLAGS")) ctx->dbgFlags = atoi(ed);                  // (measurement only: hmcmt_debug_flags)
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<FW_NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_fdm_fwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess)
@@ -2401,6 +2419,7 @@ int hmcmt_debug_precond(hmcmt_ctx* ctx, const double* r, double* z) {
     if (rc) return rc;
     const int merged = ctx->sv.merged2;
     ctx->sv.merged2 = 0;                 // (two sweeps: the last one as a launch of its own, so that z exists in memory)
+    ensure_dinv(ctx);
     apply_precond(ctx);
     ctx->sv.merged2 = merged;
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2635,6 +2654,7 @@ int hmcmt_debug_back_post(hmcmt_ctx* ctx, const double* y, const double* r, doub
     int rc = set_all_active(ctx);
     if (rc) return rc;
     const bool keep = ctx->fusedBack;
+    ensure_dinv(ctx);
     std::vector<cplx> pa((size_t)k.S * MAXNB);
     std::vector<double> pz((size_t)k.S * MAXNB);
     for (int pass = 0; pass < 2; ++pass) {

@@ -293,13 +293,17 @@ __global__ __launch_bounds__(VBLOCK) void k_dinv(Solver k, double wJ) {
 // couplings and the stiffness diagonal from 1/sigma, TE: the mass from sigma; the other half is constant and read -- and from
 // it the system's Jacobi diagonal; the threads of the first system of each mode also store the coefficient arrays and
 // their packed float copy (Solver::cf32).  grid (NB, S)
-__global__ __launch_bounds__(VBLOCK) void k_coef_all(View v, Solver k, double wJ, float4* __restrict__ cf) {
-    const int s = blockIdx.y, mode = s >= k.nFreq;
+// sysStride = nFreq with a grid of (NB, 2): the two writers only -- an evaluation whose solves run in the persistent kernel, which forms
+// the Jacobi diagonal from the coefficients and never reads Solver::dinv (the other systems' diagonals are 64 x 24 B per node of
+// stores at the stress size, 110 us in front of the forward solve); k_dinv makes up for them if a solve leaves that kernel after all.
+__global__ __launch_bounds__(VBLOCK) void k_coef_all(View v, Solver k, double wJ, float4* __restrict__ cf, int sysStride) {
+    const int s = blockIdx.y * sysStride, mode = s >= k.nFreq;
     tick_begin(v.ticks, TK_COEF);
     const bool writer = s == mode * k.nFreq;
     const long mo = (long)mode * k.vstride, so = (long)s * k.vstride;
     const double w = k.omega[s];
-    const long e0 = (long)blockIdx.x * k.chunk, e1 = min(e0 + k.chunk, k.vstride);
+    const long per = (k.vstride + gridDim.x - 1) / gridDim.x;          // (gridDim.x = NB: Solver::chunk; the writers-only launch spreads the nodes wider)
+    const long e0 = (long)blockIdx.x * per, e1 = min(e0 + per, k.vstride);
     for (long e = e0 + threadIdx.x; e < e1; e += VBLOCK) {
         const int iz = (int)(e / k.NYP), iy = (int)(e - (long)iz * k.NYP);
         const bool rowI = iz >= 1 && iz <= k.nz - 1, colI = iy >= 1 && iy <= k.ny - 1, interior = rowI && colI;
