@@ -395,6 +395,36 @@ def test_misplaced_groups_when_the_kernel_was_to_start_the_solve(monkeypatch, wh
     ctx.close()
 
 
+@pytest.mark.parametrize("which", [True, "all"])
+def test_jacobi_diagonals_left_out_for_the_persistent_kernel_are_made_up_on_the_way_out(monkeypatch, which):
+    """Round 6: an evaluation whose solves are to run in the persistent kernel has k_coef_all write the two polarisations'
+    coefficient arrays only -- that kernel forms the Jacobi diagonal itself; the 2 x nFreq per-system diagonals (Solver::dinv) are
+    stores nobody reads.  When a solve leaves the kernel after all (here: misplaced groups), k_dinv makes up for them before the
+    launch-per-phase loop's kernels read them (ensure_dinv): iteration counts and results BITWISE equal to HMCMT_LAZY_DINV=0,
+    where every evaluation writes them (stale diagonals -- the previous model's, or none -- would only cost iterations, which
+    is why the counts are compared)."""
+    mesh, data, inv, m = make_problem("cfg2")
+    out = {}
+    for lazy in ("1", "0"):
+        monkeypatch.setenv("HMCMT_LAZY_DINV", lazy)
+        ctx = _ctx(monkeypatch, mesh, data, inv, True, 2)
+        ctx.grad(m)
+        ctx.debug_flags(fail_placement=which)
+        a = ctx.grad(m + 0.5)                              # (far from the first model: its diagonals would be poor ones)
+        ia = ctx.iters().copy()
+        b = ctx.grad(m + 0.3)                              # ... and on with the launch-per-phase loop
+        out[lazy] = (a, ia, b, ctx.iters().copy(), ctx.persist_info())
+        assert ctx.stats()["status"] == 0
+        ctx.close()
+    for k in (0, 2):
+        for x, y in zip(out["1"][k], out["0"][k]):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+    assert np.array_equal(out["1"][1], out["0"][1]) and np.array_equal(out["1"][3], out["0"][3])
+    assert out["1"][4]["placement_fallbacks"] == 1 and out["1"][4]["enabled"] == 0
+    po, mo, go = oracle_eval(mesh, data, inv, m + 0.3)
+    assert relmax(out["1"][2][0], po) < 1e-9 and relmax(out["1"][2][2], go) < 1e-6      # (a rough model without options.verify's tightened solves)
+
+
 @pytest.mark.parametrize("name,sweeps", [("cfg2", 1), ("cfg2", 2), ("tiny", 2), ("cfg1", 2)])
 def test_four_strip_kernel_equals_the_two_half_kernel_and_the_oracle(monkeypatch, name, sweeps):
     """k_cocg_persist4 (kernels_persist4.h: four strips of six tile rows per column, 4 x threads_half threads, 128 VGPRs, four
