@@ -95,6 +95,8 @@ struct hmcmt_ctx {
     bool wantTicks = false;               // HMCMT_TICKS: in-kernel wall-clock stamps (View::ticks), printed at destroy
     int bcCW = 0, bcSlots = 1;            // k_bc_fused: boundary columns per workgroup (0: k_bc_layers + k_bc_forward), edge slots
     size_t bcLds = 0;
+    bool sensFusedAlways = false;         // HMCMT_SENS_FUSED=1: also where the persistent kernel leaves CUs free (launch_adjoint_side)
+    size_t sensFusedLds = 0;              // k_sens_fused: its LDS bytes (0: k_sens_layers + k_sens_profile + k_bcsens_pre; HMCMT_SENS_FUSED=0)
     int bcbCW = 0, bcbSlots = 1;          // k_bc_blocked (meshes k_bc_fused's slabs do not fit): columns per workgroup (0: the two-kernel form)
     int bcbNT = 512, bcbLBu = 14, bcbLBd = 8;   // its threads, layers per block of the two recurrences
     size_t bcbLds = 0;
@@ -171,6 +173,7 @@ struct hmcmt_ctx {
     int solveFail = 0;                    // status a system of the last solve gave up with (mapped failure word), 0 = none
     // persistent solve kernel (kernels_persist.h)
     bool persistOn = true;                // HMCMT_PERSIST=0: the launch-per-phase loop only
+    bool persistFillsShare = false;
     int persistG = 0, persistSlots = 0, persistCW = 0;   // workgroups per system, system slots per XCD, threads / 2 (0: the problem does not fit the kernel)
     size_t persistLds = 0;
     unsigned* d_psync = nullptr;          // [8 * slots][32] barrier words | exit counter | fail word
@@ -652,6 +655,7 @@ int launch_persist(hmcmt_ctx* ctx, int sweeps, int precondOnly, float2* zout, in
     a.order = ctx->psOrder[kind == 1].empty() ? nullptr : ctx->d_psOrder + (kind == 1 ? k.S : 0);
     a.resid = start.resid; a.begin = start.begin; a.nOn = ctx->nSysOn; a.sysOn = ctx->v.sysOn;
     a.doneCnt = ctx->d_psync + 32 * groups + 4;       // (in the block the kernel's last workgroup clears: exitCnt at +0, fail at +8)
+    a.placedCnt = precondOnly ? nullptr : ctx->d_psync + 32 * groups + 5; a.nGroups = groups;
     if (start.begin) *(volatile int*)ctx->h_nactive = ctx->nSysOn;      // (mapped: "not all done yet" until the kernel's last converged system says otherwise)
     if (ctx->d_pstamps) HIPCHK(hipMemsetAsync(ctx->d_pstamps, 0, sizeof(long long) * 16 * 256, ctx->stream));
     const dim3 grid(groups * ctx->persistG);
@@ -802,7 +806,18 @@ int solve(hmcmt_ctx* ctx, cplx* x, int kind, bool deferEnd = false, const SpecFn
         { ProfScope ps(ctx, 2); int prc = launch_persist(ctx, k.sweeps, 0, nullptr, kind, start); if (prc) return prc; }
         ++ctx->persistSolves;
         if (k.cntActive) ++ctx->profPersistSolves;
-        if (kind == 0) launch_adjoint_side(ctx);        // (the host is free while the device solves)
+        if (kind == 0 && ctx->sidePending) {
+            // (the host is free while the device solves.)  Not before the persistent kernel's whole grid is resident (progress word 1, behind
+            // the last group's placement check): the side streams do not wait for the kernels in front of the solve, and k_sens_fused's
+            // workgroups (LDS, 256 threads), dispatched first, sit on CUs this kernel's workgroups need -- at the stress size the solve
+            // started 0.1 ms late.  (A misplaced group never reports: the kernel then ends early, PS_DONE ends this wait as well.)
+            long spins = 0;
+            while (*(volatile int*)ctx->h_prog == 0 && ++spins < (1l << 26)) {
+                __builtin_ia32_pause();
+                if ((spins & 0xffff) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;
+            }
+            launch_adjoint_side(ctx);
+        }
         if (spec && ctx->specOn) { (*spec)(ctx->d_gate + kind, ctx->gateGen); specIssued = true; }
         { int prc = spin_progress(ctx, PS_DONE); if (prc) return prc; }
         if (*(volatile int*)(ctx->h_stall + 3)) {
@@ -1030,10 +1045,20 @@ void launch_adjoint_side(hmcmt_ctx* ctx) {
     }
     if (ctx->sideSens) {
         hipStreamWaitEvent(ctx->side, ctx->evPiv, 0);          // (the lateral means come from the second side stream)
-        hipLaunchKernelGGL(k_sens_layers, dim3((v.nz + 1 + 63) / 64, 3, S), dim3(64), 0, ctx->side, v);
-        hipLaunchKernelGGL(k_sens_profile, dim3((3 * S + 63) / 64), dim3(64), 0, ctx->side, v);
-        // the serial half of dBC^T w (78 us on a handful of CUs) depends on sigma only: here, not after the adjoint solve
-        hipLaunchKernelGGL(k_bcsens_pre, dim3((v.nz + 63) / 64, 3, S), dim3(64), 0, ctx->side, v);
+        // One launch (k_sens_fused) where the persistent kernel fills the chip: the side stream's kernels then run as the first systems
+        // converge, 0.2 ms instead of 0.37 at the headline size.  Where a solve leaves CUs free (the stress size: 240 of 256) the three
+        // small kernels trickle along on them for milliseconds, harmlessly -- the side stream gets next to nothing of the machine
+        // beside a solve there: the adjoint guess in front takes the whole forward solve, ANY kernel behind it starts at the adjoint
+        // solve's own start, and the fused one's workgroups (LDS, 256 threads) then sit on CUs that solve's workgroups need (measured:
+        // 84.2 against 85.0 steps/s; the tables in front of the guess: 83.5, the guess then delays the adjoint solve).
+        if (ctx->sensFusedLds > 0 && (ctx->sensFusedAlways || !persist_ok(ctx) || ctx->persistFillsShare)) {
+            hipLaunchKernelGGL(k_sens_fused, dim3(3, S), dim3(std::min(256, (v.nz + 1 + 63) / 64 * 64)), ctx->sensFusedLds, ctx->side, v);
+        } else {
+            hipLaunchKernelGGL(k_sens_layers, dim3((v.nz + 1 + 63) / 64, 3, S), dim3(64), 0, ctx->side, v);
+            hipLaunchKernelGGL(k_sens_profile, dim3((3 * S + 63) / 64), dim3(64), 0, ctx->side, v);
+            // the serial half of dBC^T w (78 us on a handful of CUs) depends on sigma only: here, not after the adjoint solve
+            hipLaunchKernelGGL(k_bcsens_pre, dim3((v.nz + 63) / 64, 3, S), dim3(64), 0, ctx->side, v);
+        }
         hipEventRecord(ctx->evSens, ctx->side);
     }
 }
@@ -1678,6 +1703,7 @@ static int persist_setup(hmcmt_ctx* ctx) {
     ctx->persistWidthK = (((k.NYP == 208 || k.NYP == 112) && cs == 1) || (k.NYP == 416 && cs == 2)) ? k.NYP : 0;
     if (const char* e = getenv("HMCMT_PERSIST_WIDTHK")) if (e[0] == '0') ctx->persistWidthK = 0;
     ctx->persistSlots = std::max(1, std::min((k.S + 7) / 8, cuPerXcd / G));
+    ctx->persistFillsShare = ctx->persistSlots * G >= cuPerXcd;       // (no CU of this context's share left over beside a solve: launch_adjoint_side)
     ctx->persistLds = lds;
     ctx->psyncBytes = ((size_t)(32 * 8 * ctx->persistSlots + 16) * sizeof(unsigned) + 15) & ~(size_t)15;
     void* q = nullptr;
@@ -1850,6 +1876,14 @@ static int create_impl(hmcmt_ctx* ctx, int32_t device_id) {
                 hipFuncSetAttribute(reinterpret_cast<const void*>(k_bc_blocked), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess) {
                 ctx->bcbCW = cb; ctx->bcbSlots = bslots; ctx->bcbLds = blds; ctx->bcbNT = nt; ctx->bcbLBu = lbu; ctx->bcbLBd = lbd;
             }
+        }
+        {
+            const size_t sl = (size_t)12 * (ctx->hp.nz + 1) * sizeof(cplx) + (size_t)ctx->hp.nz * sizeof(double);
+            const char* es = getenv("HMCMT_SENS_FUSED");
+            ctx->sensFusedAlways = es && es[0] == '1';
+            if (!(es && es[0] == '0') && sl <= (size_t)150 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_sens_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess)
+                ctx->sensFusedLds = sl;
         }
         ctx->wantTicks = getenv("HMCMT_TICKS") != nullptr;
         ctx->noFusedStart = getenv("HMCMT_NO_FUSED_START") != nullptr;

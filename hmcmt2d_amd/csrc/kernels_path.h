@@ -479,6 +479,64 @@ __global__ __launch_bounds__(64) void k_sens_profile(View v) {
     if (e < 3 * v.S) item_sens_profile(v, e / 3, e % 3);
     tick_end(v.ticks, TK_SENS);
 }
+// k_sens_layers + k_sens_profile + k_bcsens_pre in ONE launch (end of round 6), one workgroup per (system, profile), every table in LDS:
+// as three launches the stages handed their tables on through global memory and walked them row by row -- uniform loads in front of
+// every row's arithmetic, on the two CUs per XCD a solve leaves free, behind the persistent kernel's traffic in the L2's queues: 0.4 ms for
+// the 192 serial profiles and 4.8 ms for the derivative columns at the stress size, all latency.  Here the layers' terms are formed by the
+// whole workgroup (stage 1), lane 0 walks the profile (stage 2) and every lane its derivative column (stage 3) with nothing but LDS reads in
+// the loops; what leaves the workgroup is what the gradient's tail reads (dBC, gMn) and the TM boundary values (bcsL / bcsR / bcsB).
+// Same item functions in the same order: bitwise the three-kernel results.  LDS: 12 (nz+1) complex + nz doubles.
+__global__ __launch_bounds__(256) void k_sens_fused(View v) {
+    extern __shared__ __attribute__((aligned(16))) char smem_sf[];
+    const int prof = blockIdx.x, s = blockIdx.y, nz = v.nz;
+    const long n1 = nz + 1;
+    if (!v.sysOn[s]) {
+        if (prof == 2) for (int c = threadIdx.x; c < nz; c += blockDim.x) v.gMn[(long)s * nz + c] = cplx{0, 0};
+        return;
+    }
+    tick_begin(v.ticks, TK_SENS);
+    cplx* T = reinterpret_cast<cplx*>(smem_sf);           // [5][n1]: ka, 1/ka, exp(i ka h), its inverse, exp(-2 i ka h)
+    cplx* sEu = T + 5 * n1;                               // [n1]
+    cplx* sEd = sEu + n1;                                 // [n1]
+    cplx* sMix = sEd + n1;                                // [4][nz]
+    cplx* sDz1 = sMix + 4 * (long)nz;                     // [nz]
+    double* sZ = reinterpret_cast<double*>(sDz1 + nz);    // [nz] the layers' thicknesses (a global load in a serial loop waits for the solve's traffic)
+    __shared__ cplx z1sh;
+    __shared__ int deadsh;
+    const bool tm = s >= v.nFreq;
+    const double omega = v.omega[s];
+    for (int j = threadIdx.x; j <= nz; j += blockDim.x) { // stage 1 (item_sens_layers)
+        const int jj = j < nz ? j : nz - 1;
+        if (j < nz) sZ[j] = v.zLen[j];
+        const double sig = prof == 0 ? v.sigma[(long)jj * v.ny] : (prof == 1 ? v.sigma[(long)jj * v.ny + v.ny - 1] : v.sigMeanA[jj]);
+        cplx t[5];
+        layer_sens(sig, omega, v.zLen[jj], t);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) T[q * n1 + j] = t[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                               // stage 2 (item_sens_profile)
+        cplx* fout = nullptr;
+        long fstride = 1;
+        if (tm) {                                         // `bc` of getBCderivTM (compJacTMatVec.jl:309,315)
+            if (prof == 0) fout = v.bcsL + (long)s * nz;
+            else if (prof == 1) fout = v.bcsR + (long)s * nz;
+            else { fout = v.bcsB + s; fstride = 0; }      // only the bottom value of the mean profile
+        }
+        cplx z1;
+        deadsh = sens_profile(omega, nz, sZ, tm, T, T + n1, T + 2 * n1, T + 3 * n1, T + 4 * n1, sEu, sEd, sMix, sDz1, &z1, fout, fstride);
+        z1sh = z1;
+    }
+    __syncthreads();
+    const cplx z1 = z1sh;
+    const int dead = deadsh;
+    for (int c = threadIdx.x; c < nz; c += blockDim.x) {  // stage 3 (item_bcsens_pre)
+        cplx* out = prof < 2 ? v.dBC + ((long)s * 2 + prof) * nz * nz + c : nullptr;
+        const cplx g = bc1d_sens_column(omega, nz, sZ, tm, c, T, T + n1, T + 2 * n1, T + 3 * n1, sEu, sEd, sMix, sDz1, z1, dead, nullptr, 1, out, nz);
+        if (prof == 2) v.gMn[(long)s * nz + c] = g;
+    }
+    tick_end(v.ticks, TK_SENS);
+}
 __global__ void k_rhs(View v) {
     int e = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
     if (e >= v.NZP * (v.ny + 1)) return;

@@ -121,6 +121,8 @@ struct PsLaunch {
     int nOn;                   // systems that are on (sum of sysOn)
     const int* sysOn;          // [S]
     unsigned* doneCnt;         // device word (zero at launch, in the sync block the last workgroup clears): systems that have ended converged
+    unsigned* placedCnt;       // ... groups that have passed their placement check: the last one stores 1 to the host's progress word (nullable)
+    int nGroups;               // groups of this launch
 };
 
 __device__ __forceinline__ unsigned ps_xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 0xf; }
@@ -637,6 +639,10 @@ __global__ __launch_bounds__(2 * CW) void k_cocg_persist(PsLaunch L) {
             sflag[0] = 1;
             __hip_atomic_store(kb->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *kb->placeHost = 1;
+        } else if (jw == 0 && L.placedCnt) {
+            // every workgroup of this group is resident; behind the last group the whole grid is -- the host holds back the side streams'
+            // work of the adjoint half until then (launch_adjoint_side: dispatched first, its workgroups would sit on CUs this kernel needs)
+            if (__hip_atomic_fetch_add(L.placedCnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)L.nGroups) *(volatile int*)kb->progHost = 1;
         }
     }
     __syncthreads();

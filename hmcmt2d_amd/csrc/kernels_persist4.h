@@ -104,6 +104,8 @@ __global__ __launch_bounds__(4 * CW) void k_cocg_persist4(PsLaunch L) {
             sflag[0] = 1;
             __hip_atomic_store(kb->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *kb->placeHost = 1;
+        } else if (jw == 0 && L.placedCnt) {               // (the whole grid is resident behind the last group: kernels_persist.h)
+            if (__hip_atomic_fetch_add(L.placedCnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)L.nGroups) *(volatile int*)kb->progHost = 1;
         }
     }
     __syncthreads();

@@ -570,6 +570,30 @@ def test_fused_solve_start_matches_separate_kernels(monkeypatch):
     assert sa["status"] == 0 and sb["status"] == 0
 
 
+@pytest.mark.parametrize("name", ["tiny", "cfg2", "tiny_rhophase"])
+def test_fused_sensitivity_tables_equal_the_three_kernel_ones_bitwise(name, monkeypatch):
+    """k_sens_fused (per-layer terms, the serial profile and the derivative columns of getBCDerivMatrix, MT1DSensitivity.jl:25-333,
+    in one launch with every table in LDS; round 6) against k_sens_layers + k_sens_profile + k_bcsens_pre: the same item functions
+    on the same numbers in the same order -- predicted data, misfit and gradient (whose boundary terms are all that reads those
+    tables) bitwise equal, on a cold and on a warm-started evaluation."""
+    if name == "tiny_rhophase":
+        from tests.helpers import rhophase_problem
+        mesh, data, inv, m, _ = rhophase_problem()
+    else:
+        mesh, data, inv, m = make_problem(name)
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("HMCMT_SENS_FUSED", fused)
+        ctx = HipContext(mesh, data, inv)
+        out[fused] = [ctx.grad(m), ctx.grad(m + 0.02)]
+        assert ctx.stats()["status"] == 0
+        ctx.close()
+    for (pa, fa, ga), (pb, fb, gb) in zip(out["1"], out["0"]):
+        assert np.array_equal(pa, pb) and fa == fb and np.array_equal(ga, gb)
+    po, mo, go = oracle_eval(mesh, data, inv, m + 0.02)
+    assert relmax(out["1"][1][0], po) < 1e-8 and relmax(out["1"][1][2], go) < 1e-6      # (production tolerances: no options.verify)
+
+
 def test_sampler_context_lands_on_the_ranks_device(monkeypatch):
     """parallelHMCSampler / runHMCSampler / get_context take the GPU from LOCAL_RANK (one process per GPU,
     parallelHMC.jl:23-40): the context is created there, the process's current HIP device is that device afterwards,
