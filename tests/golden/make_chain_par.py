@@ -1,4 +1,4 @@
-"""Generates tests/golden/cfg3_chain.npz: a 40-sample HMC chain of the ORACLE at the headline size (BASELINE configs[2]: 200 x 100
+"""Generates tests/golden/cfg3_chain.npz (and cfg5_chain.npz): a 40-sample HMC chain of the ORACLE at the headline size (BASELINE configs[2]: 200 x 100
 cells + 7 air rows, 16 frequencies, TE+TM, 41 receivers; observations of cfg3.npz) with bench.py's sampler settings -- dt = 0.03,
 L in [6, 10], lambda = 1, bounds rho in [1, 1e4] ohm-m (examples/dprism3d/startupfile:3-8) --, homogeneous 100 ohm-m reference
 model, the chain state started at the synthetic's true model (bench.py's `near_true_state` chain), numpy Generator seed 2025:
@@ -12,7 +12,8 @@ MT2DFwdSolver on ITS frequencies' data (the data are sorted by frequency: contig
 predicted data and adds the misfits and the gradients in frequency order.  Nothing of the arithmetic changes but the order
 of that last sum (the serial oracle adds the frequencies' J^T v inside compJacTMatVec).
 
-    python tests/golden/make_chain_cfg3.py [samples for a trial run: nothing is written]      (about 15 minutes on 8 cores)
+    python tests/golden/make_chain_par.py [cfg3|cfg5] [samples for a trial run: nothing is written]
+(cfg3: 11 minutes on 8 cores; cfg5 -- the stress size, 64 systems of 82 194 unknowns, make_chain.py's CHAINS["cfg5"] -- about an hour)
 """
 import copy
 import os
@@ -24,7 +25,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 HERE = os.path.dirname(os.path.abspath(__file__))
-NAME, PER = "cfg3", 2                      # frequencies per worker task
+NAME = (sys.argv[1] if len(sys.argv) > 1 else "cfg3") if __name__ == "__main__" else os.environ.get("HMCMT_CHAIN_NAME", "cfg3")     # (the spawned workers read the parent's choice from the environment)
+PER = 2                                    # frequencies per worker task
 
 _cache = {}
 
@@ -68,7 +70,7 @@ if __name__ == "__main__":
     from oracle import hmcmt_oracle as O
     from tests.helpers import make_problem
     from tests.golden.make_chain import chain_prior_of, start_model_of, SEED, RHOREF
-    nmax = int(sys.argv[1]) if len(sys.argv) > 1 else None
+    nmax = int(sys.argv[2]) if len(sys.argv) > 2 else None
     mesh, data, inv, _ = make_problem(NAME)
     O.setupTensorMesh2D(mesh)
     prior = chain_prior_of(NAME)
@@ -76,6 +78,7 @@ if __name__ == "__main__":
     if nmax:
         prior.totalsamples = nmax; prior.burninsamples = min(prior.burninsamples, nmax // 2)
     nW = (len(data.freqs) + PER - 1) // PER
+    os.environ["HMCMT_CHAIN_NAME"] = NAME
     pool = mp.get_context("spawn").Pool(min(nW, len(os.sched_getaffinity(0))))
     nev = [0, 0]
 
