@@ -12,7 +12,7 @@ MT2DFwdSolver on ITS frequencies' data (the data are sorted by frequency: contig
 predicted data and adds the misfits and the gradients in frequency order.  Nothing of the arithmetic changes but the order
 of that last sum (the serial oracle adds the frequencies' J^T v inside compJacTMatVec).
 
-    python tests/golden/make_chain_par.py [cfg3|cfg5] [samples for a trial run: nothing is written]
+    python tests/golden/make_chain_par.py [cfg3|cfg5] [samples for a trial run: nothing is written | traj: one trajectory from the rough state]
 (cfg3: 11 minutes on 8 cores; cfg5 -- the stress size, 64 systems of 82 194 unknowns, make_chain.py's CHAINS["cfg5"] -- about an hour)
 """
 import copy
@@ -70,7 +70,7 @@ if __name__ == "__main__":
     from oracle import hmcmt_oracle as O
     from tests.helpers import make_problem
     from tests.golden.make_chain import chain_prior_of, start_model_of, SEED, RHOREF
-    nmax = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    nmax = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "traj" else None
     mesh, data, inv, _ = make_problem(NAME)
     O.setupTensorMesh2D(mesh)
     prior = chain_prior_of(NAME)
@@ -100,6 +100,28 @@ if __name__ == "__main__":
 
     O.compDataGradient, O.MT2DFwdSolver = par_grad, par_fwd
     t0 = time.time()
+    if len(sys.argv) > 2 and sys.argv[2] == "traj":
+        # ONE trajectory of bench.py's headline chain -- the chain started at SURVEY 8(d)'s rough state, the regime `value` is timed in: clamped
+        # steps, bound reflections, models that get rougher with every step --: proposeLeapfrog (HMCSampler.jl:206-269) from the rough state
+        # with the first momentum of the generator, L = 8, and the Hamiltonian terms at the proposal -> tests/golden/<name>_rough_traj.npz
+        from hmcmt2d_amd import synthetic as S
+        n = len(inv.strModel)
+        m0 = S.rough_state(n)
+        inv.refModel = np.full(n, np.log(1.0 / RHOREF))
+        invM = np.ones(n)
+        p0 = O.getMomentumVector(n, np.ones(n), np.random.default_rng(SEED))
+        L = 8
+        inv2 = copy.deepcopy(inv)
+        m1, p1 = O.proposeLeapfrog(m0.copy(), p0.copy(), invM, mesh, data, inv2, prior, L, False)
+        D, K, H, M, pred = O.getHamiltonian(data, mesh, inv2, prior, p1, invM)
+        pool.close()
+        print("trajectory done in %.0f s (%d gradient + %d forward evaluations): misfit at the proposal %.1f, kinetic %.1f, model norm %.1f; max |m1 - m0| %.2f" % (
+            time.time() - t0, nev[0], nev[1], D, K, M, np.abs(m1 - m0).max()), flush=True)
+        # (m0 and p0 are S.rough_state(n) and the generator's first momentum: kept in the small file only, the test re-draws them)
+        start = dict(m0=m0, p0=p0) if n <= 20000 else {}
+        np.savez_compressed(os.path.join(HERE, f"{NAME}_rough_traj.npz"), m1=m1, p1=p1, D=D, K=K, H=H, M=M, pred=pred, dt=prior.dt, L=L,
+                            bounds=np.array(prior.sigBounds), mref=inv.refModel[:1], seed=SEED, **start)
+        sys.exit(0)
     hm, st, hd = O.runHMCSampler(mesh, data, copy.deepcopy(inv), prior, np.random.default_rng(SEED), rhoref=RHOREF, dense_dbc=False)
     pool.close()
     print("chain done in %.0f s (%d gradient + %d forward evaluations): accepted %d of %d, nfevals %d, misfit %.1f -> %.1f" % (

@@ -381,6 +381,46 @@ def test_layer_blocked_boundary_fields_equal_the_fused_ones(name, monkeypatch):
     assert np.abs(out["fused"][0] - out["blocked"][0]).max() <= 1e-10 * np.abs(out["fused"][0]).max()
 
 
+@pytest.mark.parametrize("name", ["cfg3", "cfg5"])
+def test_headline_chain_trajectory_from_the_rough_state_against_the_oracle(name):
+    """ONE trajectory of the chain bench.py times (`value`: started at SURVEY 8(d)'s rough state) at the headline size and at the
+    stress size, against the oracle's proposeLeapfrog (HMCSampler.jl:206-269; tests/golden/make_chain_par.py <name> traj ->
+    <name>_rough_traj.npz): nine evaluations of the hot path along models that move by up to 5.2 in ln sigma (clamped steps: the
+    gradient is 1e5), the device-resident leapfrog, the persistent kernel with the smoother the library picks there (cfg5: two
+    column parts, the layer-blocked boundary fields).  The proposal (model: exact steps of a clamped momentum; momentum: eight
+    gradients of size 1e5 added up), the Hamiltonian terms and the predicted data at it."""
+    import copy
+    from hmcmt2d_amd import sampler, synthetic as S
+    from hmcmt2d_amd.structs import initHMCParameter, HMCPrior
+    from oracle import hmcmt_oracle as O
+    g = np.load(os.path.join(GOLDEN, f"{name}_rough_traj.npz"))
+    mesh, data, inv, _ = make_problem(name)
+    n = len(inv.strModel)
+    inv.refModel = np.full(n, float(g["mref"][0]))
+    m0, p0 = S.rough_state(n), O.getMomentumVector(n, np.ones(n), np.random.default_rng(int(g["seed"])))
+    if "m0" in g.files:
+        assert np.array_equal(m0, g["m0"]) and np.array_equal(p0, g["p0"])
+    L = int(g["L"])
+    prior = HMCPrior(dt=float(g["dt"]), timestep=[L, L], sigBounds=list(g["bounds"]), regParam=1.0)
+    ctx = HipContext(mesh, data, inv)
+    hp = initHMCParameter(n); hp.invM[:] = 1.0; hp.sqrtM[:] = 1.0
+    hp.rhomodel, hp.momentum = m0.copy(), p0.copy()
+    ctx.set_prior(inv.refModel, inv.Wm, hp.invM)
+    inv_b = copy.deepcopy(inv)
+    m1, p1 = sampler.proposeLeapfrogDevice(hp, mesh, data, inv_b, prior, None, L, ctx)
+    assert prior.nfevals == L + 1 and ctx.stats()["status"] == 0
+    _ran_the_persistent_kernel(ctx, 1 if name == "cfg3" else 2)
+    hp2 = initHMCParameter(n); hp2.invM[:] = 1.0; hp2.momentum = p1
+    d, k, h, mn, pred = sampler.getHamiltonian(data, mesh, inv_b, prior, hp2, ctx)
+    em, ep = relmax(m1, g["m1"]), relmax(p1, g["p1"])
+    print(f"\n[headline trajectory, {name}] model {em:.1e} momentum {ep:.1e} misfit {abs(d - float(g['D'])) / float(g['D']):.1e} kinetic {abs(k - float(g['K'])) / float(g['K']):.1e} "
+          f"model norm {abs(mn - float(g['M'])) / float(g['M']):.1e} predicted data {relmax(pred, g['pred']):.1e}")
+    assert em < 2e-8 and ep < 1e-6
+    assert abs(d - float(g["D"])) < 1e-7 * float(g["D"]) and abs(k - float(g["K"])) < 1e-7 * float(g["K"]) and abs(mn - float(g["M"])) < 1e-7 * float(g["M"])
+    assert relmax(pred, g["pred"]) < 1e-8
+    ctx.close()
+
+
 def test_rho_phase_data_type():
     """DataType Rho_Pha (apparent resistivity + phase in degrees, both polarisations, a tenth of the data masked out;
     SURVEY 8(f)4): predicted data, misfit and gradient against the oracle and its golden; then the TE-only subset
