@@ -1,5 +1,5 @@
 """Generates the golden vectors tests/golden/*.npz with the oracle (run in the build
-container: `python tests/golden/make_golden.py [names...]`; names: tiny cfg2 cfg1 cfg3s cfg3 cfg5s cfg5 dprism3d coprod2 rhophase).  Inputs: BASELINE.json-style synthetic configs
+container: `python tests/golden/make_golden.py [names...]`; names: tiny cfg2 cfg1 cfg3s cfg3 cfg5s cfg5 dprism3d coprod2 rhophase rhophase_cfg1).  Inputs: BASELINE.json-style synthetic configs
 (hmcmt2d_amd/synthetic.py), observed data = oracle forward of the true model + 3 % seeded noise,
 evaluation state m = ln(0.01) + 0.3 N(0,1) (seed 1).  Outputs: predData, misfit, gradient, the
 receiver-row fields and (tiny only) every intermediate term of J^T v.
@@ -186,10 +186,11 @@ def make_cfg5_full():
     print("cfg5 misfit", misfit, misfit2, "file kB", os.path.getsize(os.path.join(HERE, "cfg5.npz")) // 1024)
 
 
-def make_rho_phase():
-    """tiny config with DataType Rho_Pha (apparent resistivity + phase of both polarisations, a tenth of the data
-    masked out): observations = oracle response of the true model + 5 % / 1.5 degree noise."""
-    mesh, dz, sig_true = S.make_config("tiny")
+def make_rho_phase(name="tiny"):
+    """tiny config (and, end of round 6, cfg1: BASELINE configs[0]'s mesh, 96 x 49 cells + 7 air rows, 4 frequencies) with DataType
+    Rho_Pha (apparent resistivity + phase of both polarisations, a tenth of the data masked out): observations = oracle response of
+    the true model + 5 % / 1.5 degree noise."""
+    mesh, dz, sig_true = S.make_config(name)
     data = S.make_rhophase_layout(dz.freqs, dz.rxLoc[:, 0])
     O.setupTensorMesh2D(mesh)
     mesh.sigma = sig_true.copy()
@@ -208,8 +209,8 @@ def make_rho_phase():
     m = S.rough_state(len(inv.strModel))
     inv.strModel = m.copy()
     pred, misfit, grad = O.compDataGradient(mesh, data, inv, HMCPrior(), True)
-    np.savez_compressed(os.path.join(HERE, "tiny_rhophase.npz"), keep=keep, obs=obs, err=err, m=m, pred=pred, misfit=misfit, grad=grad)
-    print("tiny_rhophase nData", len(obs), "misfit", misfit, "|grad|max", np.abs(grad).max())
+    np.savez_compressed(os.path.join(HERE, f"{name}_rhophase.npz"), keep=keep, obs=obs, err=err, m=m, pred=pred, misfit=misfit, grad=grad)
+    print(f"{name}_rhophase nData", len(obs), "misfit", misfit, "|grad|max", np.abs(grad).max())
 
 
 def make_example(name):
@@ -264,5 +265,7 @@ if __name__ == "__main__":
             make_cfg5_full()
         elif nm == "rhophase":
             make_rho_phase()
+        elif nm == "rhophase_cfg1":
+            make_rho_phase("cfg1")
         else:
             make_example(nm)

@@ -114,11 +114,11 @@ class OracleContext:
         return p, self.O.compDataMisfit(p, self.inv)
 
 
-def rhophase_problem():
-    """tiny config with DataType Rho_Pha and the masked data set of tests/golden/tiny_rhophase.npz.
+def rhophase_problem(name="tiny"):
+    """tiny (or cfg1) config with DataType Rho_Pha and the masked data set of tests/golden/<name>_rhophase.npz.
     Returns (mesh, data, inv, m, golden)."""
-    g = np.load(os.path.join(GOLDEN, "tiny_rhophase.npz"))
-    mesh, dz, _ = S.make_config("tiny")
+    g = np.load(os.path.join(GOLDEN, f"{name}_rhophase.npz"))
+    mesh, dz, _ = S.make_config(name)
     data = S.make_rhophase_layout(dz.freqs, dz.rxLoc[:, 0])
     keep = g["keep"]
     data.dataID = keep.copy()

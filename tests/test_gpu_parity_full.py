@@ -421,12 +421,14 @@ def test_headline_chain_trajectory_from_the_rough_state_against_the_oracle(name)
     ctx.close()
 
 
-def test_rho_phase_data_type():
+@pytest.mark.parametrize("name", ["tiny", "cfg1"])
+def test_rho_phase_data_type(name):
     """DataType Rho_Pha (apparent resistivity + phase in degrees, both polarisations, a tenth of the data masked out;
     SURVEY 8(f)4): predicted data, misfit and gradient against the oracle and its golden; then the TE-only subset
-    (RhoXY + PhsXY), for which the TM systems must not iterate."""
+    (RhoXY + PhsXY), for which the TM systems must not iterate.  On the tiny mesh and (end of round 6) on BASELINE
+    configs[0]'s: 96 x 49 cells + 7 air rows, 4 frequencies, 41 receivers -- the width-specialised persistent kernel."""
     from tests.helpers import rhophase_problem
-    mesh, data, inv, m, g = rhophase_problem()
+    mesh, data, inv, m, g = rhophase_problem(name)
     ctx = HipContext(mesh, data, inv, verify=True)
     # (rho_a = |Z|^2/(w mu0) doubles the impedance's relative error: 3e-9, measured 1e-9)
     rp = dict(deep_rows=3, pred_tol=3e-9, misfit_tol=3e-9)
