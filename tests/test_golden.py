@@ -172,3 +172,32 @@ def test_reference_output_of_the_julia_crosscheck_when_present():
     inv.strModel = g["m1"].copy()
     pred, misfit, grad = O.compDataGradient(mesh, data, inv, HMCPrior(), True)      # (dense dBC: the reference's own form)
     assert relmax(pred, ref["m1"]["pred"]) < 1e-9 and np.abs(grad - ref["m1"]["grad"])[: -5 * ny].max() < 1e-6 * np.abs(ref["m1"]["grad"]).max()
+
+
+def test_the_parallel_chain_generator_evaluates_what_the_serial_oracle_evaluates(monkeypatch):
+    """tests/golden/make_chain_par.py (the generator of cfg3_chain.npz, cfg5_chain.npz and the *_rough_traj.npz files) hands the
+    oracle's frequency loop to worker processes: every worker runs the oracle's own compDataGradient / MT2DFwdSolver on a pair of
+    frequencies' data, the parent concatenates the predicted data and adds misfits and gradients.  Here, in one process on
+    BASELINE configs[1]: the split evaluation against the serial oracle at the same model -- predicted data and misfit equal
+    (bitwise with single-threaded BLAS on both sides; 1e-13 allows for a threaded one), the gradient to the order of one sum --,
+    and the forward-only task against the same predicted data."""
+    import importlib.util
+    from threadpoolctl import threadpool_limits
+    from oracle import hmcmt_oracle as O
+    from hmcmt2d_amd.structs import HMCPrior
+    monkeypatch.setenv("HMCMT_CHAIN_NAME", "cfg2")
+    spec = importlib.util.spec_from_file_location("make_chain_par", os.path.join(GOLDEN, "make_chain_par.py"))
+    mcp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mcp)
+    assert mcp.NAME == "cfg2"
+    mesh, data, inv, m = make_problem("cfg2")
+    O.setupTensorMesh2D(mesh)
+    inv.strModel = m.copy()
+    with threadpool_limits(limits=1):
+        p0, f0, g0 = O.compDataGradient(mesh, data, inv, HMCPrior(), False)
+    nW = (len(data.freqs) + mcp.PER - 1) // mcp.PER
+    res = [mcp._task((w, m, True)) for w in range(nW)]
+    p1, f1, g1 = np.concatenate([r[0] for r in res]), sum(r[1] for r in res), sum(r[2] for r in res)
+    assert relmax(p1, p0) < 1e-13 and abs(f1 - f0) < 1e-13 * f0 and relmax(g1, g0) < 1e-12
+    fw = [mcp._task((w, mesh.sigma, False)) for w in range(nW)]
+    assert relmax(np.concatenate([r[0] for r in fw]), p0) < 1e-13
